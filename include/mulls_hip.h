@@ -1,0 +1,206 @@
+/*
+ * mulls_hip.h — C ABI of libmulls_hip.so, the MI355X (gfx950) implementation of the MULLS-ICP hot path.
+ *
+ * What this boundary replaces (all citations relative to the MULLS reference tree):
+ *   CRegistration<PointT>::mm_lls_icp()            include/common/cregistration.hpp:1114-1440
+ *   CRegistration<PointT>::determine_corres()      include/common/cregistration.hpp:1701-1835
+ *   multi_metrics_lls_tran_estimation() + pt2pl/pt2li/pt2pt summations
+ *                                                  include/common/cregistration.hpp:1869-2275
+ *   get_multi_metrics_lls_residual()               include/common/cregistration.hpp:2518-2677
+ *   intersection_filter()                          include/common/cregistration.hpp:2894-2922
+ *
+ * The reference has no FFI: mm_lls_icp is a member of a header-only class template.  The drop-in is therefore
+ * (i) this C ABI (plain pointers + sizes, no C++/torch types) and (ii) include/cregistration_hip.hpp, which
+ * re-creates the member function with its verbatim signature and marshals pcl clouds into the structs below
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - Feature-class index == character index of the reference's `used_feature_type` string
+ *     (cregistration.hpp:1196-1201, :1213-1232): 0 ground, 1 pillar, 2 facade, 3 beam, 4 roof, 5 vertex.
+ *   - Points are pcl::PointXYZINormal records (48 B): x@0 y@4 z@8 | normal_x@16 normal_y@20 normal_z@24 |
+ *     intensity@32 curvature@36.  `stride` is the byte distance between records (48 for PCL clouds).
+ *   - Matrices are column-major doubles (Eigen's default), 4x4 -> [16], 6x6 -> [36].
+ *   - Every entry point returns 0 on success or a negative MULLS_E_* infrastructure error.  The reference's
+ *     registration status (1, -1, -2, -3, 0; cregistration.hpp:1131-1136) is returned in mulls_result.code.
+ *     Nothing is thrown across the ABI.
+ *   - Caller memory is only borrowed for the duration of a call.
+ */
+#ifndef MULLS_HIP_H
+#define MULLS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MULLS_NCLASS 6
+#define MULLS_POINT_BYTES 48
+
+enum mulls_class
+{
+	MULLS_GROUND = 0, /* point-to-plane */
+	MULLS_PILLAR = 1, /* point-to-line  */
+	MULLS_FACADE = 2, /* point-to-plane */
+	MULLS_BEAM = 3,	  /* point-to-line  */
+	MULLS_ROOF = 4,	  /* point-to-plane */
+	MULLS_VERTEX = 5  /* point-to-point */
+};
+
+enum mulls_error
+{
+	MULLS_OK = 0,
+	MULLS_E_INVALID = -100,	   /* bad argument */
+	MULLS_E_HIP = -101,		   /* a HIP runtime call failed (see mulls_last_error) */
+	MULLS_E_NO_DEVICE = -102,  /* no gfx950 device / kernels could not be loaded */
+	MULLS_E_UNSUPPORTED = -103 /* option not implemented by this build */
+};
+
+/* One feature-class cloud, borrowed from the caller (AoS of 48-byte PointXYZINormal records). */
+typedef struct mulls_cloud
+{
+	const void *pts;
+	uint32_t n;
+	uint32_t stride;
+} mulls_cloud;
+
+/* One registration problem = the reference's constraint_t inputs (utility.hpp:561-590).
+ *   tgt[c]      block1->pc_{ground,pillar,facade,beam,roof,vertex}                 (cregistration.hpp:1180)
+ *   src[c]      block2->pc_*_down, or block2->pc_* when use_more_points; src[5] is always block2->pc_vertex (:1181)
+ *   src_down[c] block2->pc_*_down, only read when params.undistort (cregistration.hpp:1251-1253); may be all-zero
+ *   tgt_bound   block1->local_bound as {min_x,min_y,min_z,max_x,max_y,max_z}       (cregistration.hpp:2916)
+ *   init_guess  the by-value Eigen::Matrix4d initial_guess, column-major           (cregistration.hpp:1120) */
+typedef struct mulls_pair
+{
+	mulls_cloud tgt[MULLS_NCLASS];
+	mulls_cloud src[MULLS_NCLASS];
+	mulls_cloud src_down[MULLS_NCLASS];
+	double tgt_bound[6];
+	double init_guess[16];
+} mulls_pair;
+
+/* The positional arguments of mm_lls_icp (cregistration.hpp:1114-1123), in order, plus ABI-only knobs at the end. */
+typedef struct mulls_params
+{
+	int32_t max_iter_num;			 /* 20 */
+	float dis_thre_unit;			 /* 1.5 */
+	float converge_translation;		 /* 0.002 */
+	float converge_rotation_d;		 /* 0.01 */
+	float dis_thre_min;				 /* 0.4 */
+	float dis_thre_update_rate;		 /* 1.1 */
+	char used_feature_type[8];		 /* "111110" */
+	char weight_strategy[8];		 /* "1101" */
+	float z_xy_balanced_ratio;		 /* 1.0 */
+	float pt2pt_residual_window;	 /* 0.1 */
+	float pt2pl_residual_window;	 /* 0.1 */
+	float pt2li_residual_window;	 /* 0.1 */
+	uint8_t apply_intersection_filter; /* true */
+	uint8_t apply_motion_undistortion; /* false */
+	uint8_t normal_shooting_on;		   /* false */
+	uint8_t use_more_points;		   /* false (only decides which clouds the adapter passes as src[]) */
+	float normal_bearing;			 /* 45.0 */
+	uint8_t keep_less_source_points; /* false */
+	uint8_t faithful;				 /* ABI-only. 1 = reproduce reference quirks (pt2li off-diagonals dropped,
+										vertex residual weighted by d^2); 0 = mathematically intended version */
+	uint8_t reserved_[2];
+	float sigma_thre;				 /* 0.5 */
+	float min_neccessary_corr_ratio; /* 0.03 */
+	float max_bearable_rotation_d;	 /* 45.0 */
+	uint64_t rng_seed;				 /* ABI-only. seed for keep_less_source_points (reference seeds with time(NULL)) */
+} mulls_params;
+
+/* Optional per-iteration record (debug / parity triage).  Filled when mulls_result.trace != NULL. */
+typedef struct mulls_iter_trace
+{
+	int32_t iter;
+	uint32_t ncorr[MULLS_NCLASS]; /* correspondences that entered the estimation (after all rejectors) */
+	uint32_t nsrc[MULLS_NCLASS];  /* live source points of the class after this iteration's search */
+	float thr[MULLS_NCLASS];	  /* dis_thre used by this iteration's search */
+	double atpa[36];			  /* normal matrix after the mirror step (cregistration.hpp:1924-1938) */
+	double atpb[6];
+	double x[6];				  /* tx ty tz roll pitch yaw of this step */
+} mulls_iter_trace;
+
+typedef struct mulls_result
+{
+	int32_t code;		/* 1 ok, -1 step too large, -2 too few correspondences, -3 sigma too large, 0 loop never ran */
+	int32_t iters;		/* iterations whose correspondence search ran */
+	double T[16];		/* constraint_t::Trans1_2, column-major (cregistration.hpp:1405) */
+	double info[36];	/* constraint_t::information_matrix, column-major (:1418) */
+	float sigma;		/* constraint_t::sigma (:1419) */
+	float confidence;	/* constraint_t::confidence (:1420) */
+	uint32_t ncorr[MULLS_NCLASS]; /* correspondences per class at the last search */
+	uint32_t nsrc0[MULLS_NCLASS]; /* source points per class after the intersection filter */
+	uint32_t ntgt0[MULLS_NCLASS]; /* target points per class after the intersection filter */
+	int32_t singular;			  /* ABI-only: 1 if a non-finite solve was observed (reference does not check, B-11) */
+	float ms_total;				  /* wall time of this registration inside the library (batch: batch time / n) */
+	mulls_iter_trace *trace;	  /* in: caller array or NULL */
+	int32_t trace_cap;			  /* in: capacity of trace[] */
+	int32_t trace_len;			  /* out */
+} mulls_result;
+
+/* Per-kernel device time of the last mulls_batch_run, measured with hipEvents on the library's stream
+ * when mulls_set_profiling(ctx, 1) is on (adds one event pair per launch; keep off for throughput runs). */
+typedef struct mulls_profile
+{
+	double ms_setup;	  /* clone + initial guess + intersection filter kernels */
+	double ms_nn;		  /* correspondence-search kernel, summed over launches */
+	double ms_filter;	  /* duplicate / distance / direction rejection kernel */
+	double ms_accum;	  /* normal-equation accumulation kernel (+ partial finish) */
+	double ms_residual;	  /* posterior residual kernel */
+	int32_t launches_nn;  /* number of correspondence-search launches in the run */
+	int32_t iterations;	  /* lock-step iterations executed by the run */
+	uint64_t nn_pair_evals; /* source-target distance evaluations issued by those launches */
+	uint64_t nn_src_pts;	/* live source points searched, summed over launches */
+	uint64_t nn_tgt_pts;	/* target points streamed (per job tile), summed over launches */
+} mulls_profile;
+
+typedef struct mulls_ctx mulls_ctx;		/* one per host thread / HIP stream */
+typedef struct mulls_batch mulls_batch; /* device-resident set of pairs */
+
+void mulls_default_params(mulls_params *p);
+
+int mulls_create(int device, mulls_ctx **out);
+void mulls_destroy(mulls_ctx *ctx);
+const char *mulls_last_error(const mulls_ctx *ctx);
+int mulls_set_profiling(mulls_ctx *ctx, int on);
+int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
+/* raw hipStream_t the library launches on (so callers can bracket it with their own events) */
+void *mulls_stream(mulls_ctx *ctx);
+
+/* replaces one mm_lls_icp call: upload, register, release */
+int mulls_icp(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result);
+
+/* n independent pairs advanced in lock-step (one launch set + one host sync per ICP iteration for the batch) */
+int mulls_icp_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
+
+/* device-resident form: stage once, run many times (each run re-clones the staged clouds like
+ * cloudblock_t::clone_feature does, utility.hpp:524-550) */
+int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_batch **out);
+int mulls_batch_run(mulls_ctx *ctx, mulls_batch *batch, const mulls_params *params, mulls_result *results);
+void mulls_batch_destroy(mulls_ctx *ctx, mulls_batch *batch);
+
+/* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
+
+/* batch_transform_feature_points (cregistration.hpp:1685-1696): in place on a host cloud via the device kernel */
+int mulls_stage_transform(mulls_ctx *ctx, void *pts, uint32_t n, uint32_t stride, const double T[16]);
+
+/* determine_corres (cregistration.hpp:1701-1835) on already-transformed clouds.
+ * Outputs, each sized n_src: match[s] = target index or -1, d2[s] = squared NN distance (float),
+ * flags[s] bit0 = survives compaction (always 1 when n_src < 500), bit1 = final correspondence. */
+int mulls_stage_correspond(mulls_ctx *ctx, const mulls_cloud *src, const mulls_cloud *tgt, float dis_thre,
+						   int normal_check, float angle_thre_degree, int32_t *match, float *d2, uint8_t *flags);
+
+/* one class' contribution to ATPA (21 packed upper/lower terms, row-major-upper enumeration) and ATPb (6):
+ * metric 0 = pt2pl (:2066-2156), 1 = pt2li (:2160-2275), 2 = pt2pt (:1976-2063).  out27 = 21 + 6 doubles;
+ * weight_out[k] (may be NULL) = value the reference leaves in pcl::Correspondence::weight. */
+int mulls_stage_accumulate(mulls_ctx *ctx, int metric, const mulls_cloud *src, const mulls_cloud *tgt,
+						   const int32_t *corr_src, const int32_t *corr_tgt, const float *corr_d2, uint32_t ncorr,
+						   int iter_num, float class_weight, int dist_w, int resid_w, int inten_w, float window,
+						   double *out27, float *weight_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULLS_HIP_H */

@@ -1,0 +1,269 @@
+"""ctypes mirror of include/mulls_hip.h (the C ABI of libmulls_hip.so).
+
+Pure declarations: structs, constants and helpers that turn numpy arrays into ``mulls_cloud`` / ``mulls_pair``
+records.  No compute happens here.  The struct layout must stay in lock-step with include/mulls_hip.h
+(tests/test_abi.py checks sizes against the compiled library).
+"""
+import ctypes as C
+
+import numpy as np
+
+NCLASS = 6
+POINT_BYTES = 48
+GROUND, PILLAR, FACADE, BEAM, ROOF, VERTEX = range(6)
+CLASS_NAMES = ("ground", "pillar", "facade", "beam", "roof", "vertex")
+
+MULLS_OK = 0
+MULLS_E_INVALID = -100
+MULLS_E_HIP = -101
+MULLS_E_NO_DEVICE = -102
+MULLS_E_UNSUPPORTED = -103
+
+# numpy view of pcl::PointXYZINormal (48 B)
+POINT_DTYPE = np.dtype(
+    {
+        "names": ["x", "y", "z", "nx", "ny", "nz", "intensity", "curvature"],
+        "formats": [np.float32] * 8,
+        "offsets": [0, 4, 8, 16, 20, 24, 32, 36],
+        "itemsize": POINT_BYTES,
+    }
+)
+
+
+class Cloud(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("n", C.c_uint32), ("stride", C.c_uint32)]
+
+
+class Pair(C.Structure):
+    _fields_ = [
+        ("tgt", Cloud * NCLASS),
+        ("src", Cloud * NCLASS),
+        ("src_down", Cloud * NCLASS),
+        ("tgt_bound", C.c_double * 6),
+        ("init_guess", C.c_double * 16),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("max_iter_num", C.c_int32),
+        ("dis_thre_unit", C.c_float),
+        ("converge_translation", C.c_float),
+        ("converge_rotation_d", C.c_float),
+        ("dis_thre_min", C.c_float),
+        ("dis_thre_update_rate", C.c_float),
+        ("used_feature_type", C.c_char * 8),
+        ("weight_strategy", C.c_char * 8),
+        ("z_xy_balanced_ratio", C.c_float),
+        ("pt2pt_residual_window", C.c_float),
+        ("pt2pl_residual_window", C.c_float),
+        ("pt2li_residual_window", C.c_float),
+        ("apply_intersection_filter", C.c_uint8),
+        ("apply_motion_undistortion", C.c_uint8),
+        ("normal_shooting_on", C.c_uint8),
+        ("use_more_points", C.c_uint8),
+        ("normal_bearing", C.c_float),
+        ("keep_less_source_points", C.c_uint8),
+        ("faithful", C.c_uint8),
+        ("reserved_", C.c_uint8 * 2),
+        ("sigma_thre", C.c_float),
+        ("min_neccessary_corr_ratio", C.c_float),
+        ("max_bearable_rotation_d", C.c_float),
+        ("rng_seed", C.c_uint64),
+    ]
+
+
+class IterTrace(C.Structure):
+    _fields_ = [
+        ("iter", C.c_int32),
+        ("ncorr", C.c_uint32 * NCLASS),
+        ("nsrc", C.c_uint32 * NCLASS),
+        ("thr", C.c_float * NCLASS),
+        ("atpa", C.c_double * 36),
+        ("atpb", C.c_double * 6),
+        ("x", C.c_double * 6),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("code", C.c_int32),
+        ("iters", C.c_int32),
+        ("T", C.c_double * 16),
+        ("info", C.c_double * 36),
+        ("sigma", C.c_float),
+        ("confidence", C.c_float),
+        ("ncorr", C.c_uint32 * NCLASS),
+        ("nsrc0", C.c_uint32 * NCLASS),
+        ("ntgt0", C.c_uint32 * NCLASS),
+        ("singular", C.c_int32),
+        ("ms_total", C.c_float),
+        ("trace", C.POINTER(IterTrace)),
+        ("trace_cap", C.c_int32),
+        ("trace_len", C.c_int32),
+    ]
+
+    # convenience views (row-major numpy matrices)
+    def T_matrix(self):
+        return np.array(self.T[:], dtype=np.float64).reshape(4, 4).T.copy()
+
+    def info_matrix(self):
+        return np.array(self.info[:], dtype=np.float64).reshape(6, 6).T.copy()
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("ms_setup", C.c_double),
+        ("ms_nn", C.c_double),
+        ("ms_filter", C.c_double),
+        ("ms_accum", C.c_double),
+        ("ms_residual", C.c_double),
+        ("launches_nn", C.c_int32),
+        ("iterations", C.c_int32),
+        ("nn_pair_evals", C.c_uint64),
+        ("nn_src_pts", C.c_uint64),
+        ("nn_tgt_pts", C.c_uint64),
+    ]
+
+
+def default_params(**overrides):
+    """mm_lls_icp's default arguments (cregistration.hpp:1114-1123)."""
+    p = Params()
+    p.max_iter_num = 20
+    p.dis_thre_unit = 1.5
+    p.converge_translation = 0.002
+    p.converge_rotation_d = 0.01
+    p.dis_thre_min = 0.4
+    p.dis_thre_update_rate = 1.1
+    p.used_feature_type = b"111110"
+    p.weight_strategy = b"1101"
+    p.z_xy_balanced_ratio = 1.0
+    p.pt2pt_residual_window = 0.1
+    p.pt2pl_residual_window = 0.1
+    p.pt2li_residual_window = 0.1
+    p.apply_intersection_filter = 1
+    p.apply_motion_undistortion = 0
+    p.normal_shooting_on = 0
+    p.use_more_points = 0
+    p.normal_bearing = 45.0
+    p.keep_less_source_points = 0
+    p.faithful = 1
+    p.sigma_thre = 0.5
+    p.min_neccessary_corr_ratio = 0.03
+    p.max_bearable_rotation_d = 45.0
+    p.rng_seed = 0
+    for k, v in overrides.items():
+        if isinstance(v, str):
+            v = v.encode()
+        setattr(p, k, v)
+    return p
+
+
+def kitti_params(**overrides):
+    """The positional values test/mulls_slam.cpp:642-648 passes with script/config/lo_gflag_list_kitti_urban.txt
+    (column s2s/s2m)."""
+    kw = dict(
+        max_iter_num=20,
+        dis_thre_unit=1.4,
+        converge_translation=0.0005,
+        converge_rotation_d=0.001,
+        dis_thre_min=0.5,
+        dis_thre_update_rate=1.1,
+        used_feature_type="111000",
+        weight_strategy="1111",
+        z_xy_balanced_ratio=1.0,
+        pt2pt_residual_window=0.05,
+        pt2pl_residual_window=0.05,
+        pt2li_residual_window=0.05,
+        apply_intersection_filter=1,
+        normal_bearing=20.0,
+        sigma_thre=0.35,
+        min_neccessary_corr_ratio=0.03,
+        max_bearable_rotation_d=45.0,
+    )
+    kw.update(overrides)
+    return default_params(**kw)
+
+
+def make_points(xyz, normals=None, intensity=None, curvature=None):
+    """Build a (n,) POINT_DTYPE array from column arrays."""
+    xyz = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+    n = xyz.shape[0]
+    pts = np.zeros(n, dtype=POINT_DTYPE)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if normals is not None:
+        normals = np.asarray(normals, dtype=np.float32).reshape(-1, 3)
+        pts["nx"], pts["ny"], pts["nz"] = normals[:, 0], normals[:, 1], normals[:, 2]
+    if intensity is not None:
+        pts["intensity"] = np.asarray(intensity, dtype=np.float32)
+    if curvature is not None:
+        pts["curvature"] = np.asarray(curvature, dtype=np.float32)
+    return pts
+
+
+def as_cloud(pts):
+    """mulls_cloud borrowing a POINT_DTYPE numpy array (caller keeps the array alive)."""
+    c = Cloud()
+    if pts is None or len(pts) == 0:
+        c.pts, c.n, c.stride = None, 0, POINT_BYTES
+        return c
+    assert pts.dtype == POINT_DTYPE and pts.flags["C_CONTIGUOUS"]
+    c.pts = pts.ctypes.data
+    c.n = len(pts)
+    c.stride = POINT_BYTES
+    return c
+
+
+class PairData:
+    """Owns the numpy arrays of one registration problem and exposes the ctypes ``Pair`` borrowing them."""
+
+    def __init__(self, tgt, src, init_guess=None, tgt_bound=None, src_down=None):
+        empty = np.zeros(0, dtype=POINT_DTYPE)
+        self.tgt = [np.ascontiguousarray(t) if t is not None else empty for t in tgt]
+        self.src = [np.ascontiguousarray(s) if s is not None else empty for s in src]
+        self.src_down = None if src_down is None else [np.ascontiguousarray(s) if s is not None else empty for s in src_down]
+        self.init_guess = np.eye(4) if init_guess is None else np.asarray(init_guess, dtype=np.float64)
+        if tgt_bound is None:
+            allp = [t for t in self.tgt if len(t)]
+            if allp:
+                mn = [min(float(t[k].min()) for t in allp) for k in ("x", "y", "z")]
+                mx = [max(float(t[k].max()) for t in allp) for k in ("x", "y", "z")]
+            else:
+                mn, mx = [0.0] * 3, [0.0] * 3
+            tgt_bound = mn + mx
+        self.tgt_bound = [float(v) for v in tgt_bound]
+
+    def fill(self, pair):
+        for c in range(NCLASS):
+            pair.tgt[c] = as_cloud(self.tgt[c])
+            pair.src[c] = as_cloud(self.src[c])
+            pair.src_down[c] = as_cloud(self.src_down[c]) if self.src_down is not None else as_cloud(None)
+        for k in range(6):
+            pair.tgt_bound[k] = self.tgt_bound[k]
+        g = np.asarray(self.init_guess, dtype=np.float64).T.reshape(-1)  # column-major
+        for k in range(16):
+            pair.init_guess[k] = float(g[k])
+        return pair
+
+    def as_pair(self):
+        return self.fill(Pair())
+
+
+def make_pair_array(pairs):
+    arr = (Pair * len(pairs))()
+    for i, p in enumerate(pairs):
+        p.fill(arr[i])
+    return arr
+
+
+def make_result_array(n, trace_cap=0):
+    res = (Result * n)()
+    traces = []
+    if trace_cap:
+        for i in range(n):
+            t = (IterTrace * trace_cap)()
+            traces.append(t)
+            res[i].trace = C.cast(t, C.POINTER(IterTrace))
+            res[i].trace_cap = trace_cap
+    res._traces = traces  # keep alive
+    return res

@@ -1,0 +1,92 @@
+// device_types.h — plain structs shared by the HIP kernels (kernels.hip) and the host driver (driver.cpp).
+// Layouts live in HBM exactly as declared here; see DESIGN.md §"Data layout in HBM".
+#pragma once
+#include <stdint.h>
+
+#define MULLS_NC 6		  // feature classes, index == used_feature_type character index
+#define MULLS_NTERM 27	  // 21 packed normal-matrix terms + 6 right-hand-side terms
+#define MULLS_BLOCK 256	  // threads per workgroup = 4 wave64
+#define MULLS_SRC_PER_THREAD 2 // source points per lane in the filter / accumulate kernels
+#define MULLS_SRC_PER_BLOCK (MULLS_BLOCK * MULLS_SRC_PER_THREAD) // = 512 source points per job
+#define MULLS_NN_BLOCK 128	  // correspondence search: 2 wave64 per workgroup ...
+#define MULLS_NN_PTS 4		  // ... x 4 register-blocked source points per lane = the same 512 points per job
+#define MULLS_TILE 2048		  // target points staged per LDS tile (3 planar float arrays -> 24 KiB)
+
+// bits of the per-source-point flag byte
+#define MULLS_F_ALIVE 1u // still part of the source cloud (reference: survived every compaction, cregistration.hpp:1755-1792)
+#define MULLS_F_VALID 2u // member of Corr_f, i.e. enters the estimation (:1794-1830)
+
+// One feature-class cloud pair of one registration.  Points are SoA float4: pos = (x,y,z,intensity),
+// nrm = (nx,ny,nz,curvature).  Offsets index the batch-wide arenas.
+struct CloudDesc
+{
+	uint32_t src_stage; // first record of this cloud in the staged AoS upload (48-B records)
+	uint32_t tgt_stage;
+	uint32_t src_n0; // staged point count
+	uint32_t tgt_n0;
+	uint32_t src_off; // first element in the working SoA arenas
+	uint32_t tgt_off;
+	uint32_t src_n; // count after the intersection filter (fixed for the rest of the registration)
+	uint32_t tgt_n;
+	uint32_t alive_cur;	 // live source points at the start of the current iteration (gates :1727 and :1755)
+	uint32_t alive_next; // accumulator filled by k_filter
+	uint32_t n_matched;	 // |Corr| of the current iteration (before duplicate removal), filled by k_nn
+	uint32_t valid_next; // accumulator filled by k_filter
+	uint32_t n_valid;	 // |Corr_f| currently in force (may be stale, SURVEY B-4)
+	uint32_t job_begin;	 // this cloud's range in the job table
+	uint32_t job_end;
+	uint32_t pad_;
+};
+
+// Per-pair state rewritten by the host before every lock-step iteration (one H2D copy for the whole batch).
+struct PairState
+{
+	double T[12];	 // rows of [R|t] applied to the source this iteration (TempTran; identity at i = 0)
+	double x[6];	 // last solved step, used by the residual pass
+	float thr[MULLS_NC]; // dis_thre per class for this iteration's search
+	int32_t iter;	 // iteration number i (feeds the adaptive range weight and the residual-weight gate)
+	int32_t active;	 // 1: run search + estimation this iteration
+	int32_t want_residual; // 1: run the posterior residual pass instead (pair already converged)
+	int32_t pad_;
+};
+
+struct PairSetup // written once per run
+{
+	double guess[12];	 // rows of the initial guess [R|t]
+	double tgt_bound[6]; // block1->local_bound
+};
+
+// Per-pair output of one lock-step iteration (D2H once per iteration for the whole batch).
+struct PairOut
+{
+	double sums[MULLS_NC][MULLS_NTERM]; // per class: 21 packed terms (row-major upper enumeration) + 6 rhs; residual pass: [0]=VTPV [1]=n
+	uint32_t n_valid[MULLS_NC];
+	uint32_t n_alive[MULLS_NC];
+	uint32_t src_n[MULLS_NC];
+	uint32_t tgt_n[MULLS_NC];
+};
+
+// One workgroup's worth of the correspondence search / filter / accumulation.
+struct Job
+{
+	uint32_t pair;
+	uint32_t cls;
+	uint32_t start; // first source point (relative to the cloud) handled by this workgroup
+	uint32_t pad_;
+};
+
+// Run-wide constants (kernel argument, by value).
+struct RunParams
+{
+	uint8_t used[MULLS_NC];
+	uint8_t w_balance, w_resid, w_dist, w_inten; // weight_strategy[0..3]
+	uint8_t crop;								 // apply_intersection_filter
+	uint8_t faithful;
+	float z_xy_ratio;
+	float win_pt, win_pl, win_li;
+	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule
+	uint8_t pad_[3];
+	float class_w_value;
+	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
+	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
+};

@@ -1,0 +1,956 @@
+// driver.cpp — host side of libmulls_hip.so: the C ABI of include/mulls_hip.h, device-resident batches and the
+// lock-step ICP iteration loop (reference: CRegistration::mm_lls_icp, include/common/cregistration.hpp:1114-1440).
+//
+// Division of labour (BASELINE.json north_star): correspondences, rejection and the normal-equation reduction run in
+// the HIP kernels of kernels.hip; per iteration and per pair the host receives 6 x 27 doubles + a few counters, mirrors
+// and solves the 6x6 system, builds the rigid step, applies the convergence / health tests and writes the next
+// PairState.  One H2D copy, three to four launches, one D2H copy and one stream sync advance the whole batch by one
+// ICP iteration.  There is no CPU fallback anywhere in this file: without a usable HIP device every entry point
+// fails with MULLS_E_NO_DEVICE / MULLS_E_HIP.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mulls_hip.h"
+#include "device_types.h"
+#include "hostmath.h"
+#include "launch.h"
+
+using mulls::Mat4;
+using mulls::Mat6;
+
+struct mulls_ctx
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	bool profiling = false;
+	mulls_profile prof{};
+	hipEvent_t ev[10] = {};
+	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
+};
+
+struct mulls_batch
+{
+	int n = 0;
+	size_t n_src = 0, n_tgt = 0; // staged points over all pairs and classes
+	std::vector<CloudDesc> descs_h;
+	std::vector<PairSetup> setup_h;
+	std::vector<Job> setup_jobs_h;
+	std::vector<Job> jobs_h;
+	std::string jobs_key;
+	uint32_t njobs = 0;
+	// device
+	float4 *stage = nullptr;
+	float4 *tmp_pos = nullptr, *tmp_nrm = nullptr;
+	float4 *spos = nullptr, *snrm = nullptr, *tpos = nullptr, *tnrm = nullptr;
+	uint8_t *flag = nullptr;
+	int32_t *match = nullptr, *nn_idx = nullptr;
+	float *wd = nullptr, *nn_d2 = nullptr;
+	unsigned long long *winner = nullptr;
+	CloudDesc *descs = nullptr;
+	PairSetup *setup = nullptr;
+	PairState *states = nullptr;
+	PairOut *outs = nullptr;
+	uint32_t *bbox = nullptr;
+	Job *setup_jobs = nullptr;
+	Job *jobs = nullptr;
+	double *partial = nullptr;
+	uint32_t jobs_cap = 0;
+	// pinned host mirrors
+	PairState *states_h = nullptr;
+	PairOut *outs_h = nullptr;
+	uint32_t *bbox_h = nullptr;
+};
+
+namespace
+{
+
+#define HIPCHK(ctx, call)                                                                                                   \
+	do                                                                                                                      \
+	{                                                                                                                       \
+		hipError_t e_ = (call);                                                                                             \
+		if (e_ != hipSuccess)                                                                                               \
+		{                                                                                                                   \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                                 \
+			return MULLS_E_HIP;                                                                                             \
+		}                                                                                                                   \
+	} while (0)
+
+template <typename T>
+int dmalloc(mulls_ctx *ctx, T **p, size_t count)
+{
+	*p = nullptr;
+	HIPCHK(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+	return MULLS_OK;
+}
+
+inline int metric_of(int c) { return (c == MULLS_PILLAR || c == MULLS_BEAM) ? 1 : (c == MULLS_VERTEX ? 2 : 0); }
+
+void rows12(const double colmajor[16], double out[12])
+{
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 4; c++)
+			out[r * 4 + c] = colmajor[r + 4 * c];
+}
+
+// host-side life of one pair during a run
+struct PairHost
+{
+	Mat4 guess, temp;
+	float thr[MULLS_NC];
+	int code = 0;
+	int iters = 0;
+	bool active = true, want_residual = false, done = false;
+	bool first = true;
+	double x[6] = {0, 0, 0, 0, 0, 0};
+	Mat6 cofactor, info;
+	double sigma2 = 1.0;
+	float ratio = 1.0f;
+	int src_feature_count = 0;
+	int singular = 0;
+	uint32_t alive_prev[MULLS_NC];
+};
+
+// packed index of (r,c), r <= c, in the row-major-upper enumeration used by k_accum
+inline int packed(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+
+// The 6x6 the reference inverts: pt2pl / pt2pt wrote the lower triangle, pt2li the upper one, then the mirror copies
+// lower -> upper (cregistration.hpp:1924-1938).  Class order of the += chain on shared slots: ground, facade, roof
+// (pl), pillar, beam (li), vertex (pt) (:1914-1921).
+void assemble_normal(const PairOut &o, bool faithful, Mat6 &N, double b[6])
+{
+	static const int order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM, MULLS_VERTEX};
+	for (int r = 0; r < 6; r++)
+		for (int c = r; c < 6; c++)
+		{
+			const int k = packed(r, c);
+			double lower = 0.0, upper = 0.0;
+			for (int i = 0; i < 6; i++)
+			{
+				const int cls = order[i];
+				const double v = o.sums[cls][k];
+				if (metric_of(cls) == 1 && r != c)
+					upper += v;
+				else
+					lower += v;
+			}
+			const double val = (r == c) ? lower : (faithful ? lower : lower + upper);
+			N.at(c, r) = val;
+			N.at(r, c) = val;
+		}
+	for (int j = 0; j < 6; j++)
+	{
+		double acc = 0.0;
+		for (int i = 0; i < 6; i++)
+			acc += o.sums[order[i]][21 + j];
+		b[j] = acc;
+	}
+}
+
+int check_params(mulls_ctx *ctx, const mulls_params *P)
+{
+	if (!P)
+		return MULLS_E_INVALID;
+	if (std::strlen(P->used_feature_type) < 6 || std::strlen(P->weight_strategy) < 4)
+	{
+		ctx->err = "used_feature_type needs 6 characters and weight_strategy 4";
+		return MULLS_E_INVALID;
+	}
+	if (P->normal_shooting_on || P->apply_motion_undistortion || P->keep_less_source_points)
+	{
+		ctx->err = "normal_shooting_on / apply_motion_undistortion / keep_less_source_points are not implemented by this build";
+		return MULLS_E_UNSUPPORTED;
+	}
+	return MULLS_OK;
+}
+
+void build_jobs(mulls_batch *B, const mulls_params *P)
+{
+	std::string key(P->used_feature_type, 6);
+	if (key == B->jobs_key)
+		return;
+	B->jobs_h.clear();
+	for (int p = 0; p < B->n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			d.job_begin = (uint32_t)B->jobs_h.size();
+			if (P->used_feature_type[c] == '1')
+				for (uint32_t s = 0; s < d.src_n0; s += MULLS_SRC_PER_BLOCK)
+				{
+					Job j = {(uint32_t)p, (uint32_t)c, s, 0};
+					B->jobs_h.push_back(j);
+				}
+			d.job_end = (uint32_t)B->jobs_h.size();
+		}
+	B->njobs = (uint32_t)B->jobs_h.size();
+	B->jobs_key = key;
+}
+
+struct EvTimer
+{
+	mulls_ctx *ctx;
+	int used = 0;
+	double *slot[5];
+	void begin(double *acc)
+	{
+		if (!ctx->profiling)
+			return;
+		slot[used / 2] = acc;
+		(void)hipEventRecord(ctx->ev[used], ctx->stream);
+	}
+	void end()
+	{
+		if (!ctx->profiling)
+			return;
+		(void)hipEventRecord(ctx->ev[used + 1], ctx->stream);
+		used += 2;
+	}
+	void collect() // after a stream sync
+	{
+		for (int i = 0; i < used; i += 2)
+		{
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
+			*slot[i / 2] += ms;
+		}
+		used = 0;
+	}
+};
+
+} // namespace
+
+extern "C"
+{
+
+	void mulls_default_params(mulls_params *p)
+	{
+		std::memset(p, 0, sizeof(*p));
+		p->max_iter_num = 20;
+		p->dis_thre_unit = 1.5f;
+		p->converge_translation = 0.002f;
+		p->converge_rotation_d = 0.01f;
+		p->dis_thre_min = 0.4f;
+		p->dis_thre_update_rate = 1.1f;
+		std::strcpy(p->used_feature_type, "111110");
+		std::strcpy(p->weight_strategy, "1101");
+		p->z_xy_balanced_ratio = 1.0f;
+		p->pt2pt_residual_window = 0.1f;
+		p->pt2pl_residual_window = 0.1f;
+		p->pt2li_residual_window = 0.1f;
+		p->apply_intersection_filter = 1;
+		p->normal_bearing = 45.0f;
+		p->faithful = 1;
+		p->sigma_thre = 0.5f;
+		p->min_neccessary_corr_ratio = 0.03f;
+		p->max_bearable_rotation_d = 45.0f;
+	}
+
+	int mulls_create(int device, mulls_ctx **out)
+	{
+		if (!out)
+			return MULLS_E_INVALID;
+		*out = nullptr;
+		int count = 0;
+		if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+			return MULLS_E_NO_DEVICE;
+		mulls_ctx *ctx = new mulls_ctx();
+		ctx->device = device;
+		if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+		{
+			delete ctx;
+			return MULLS_E_NO_DEVICE;
+		}
+		for (auto &e : ctx->ev)
+			(void)hipEventCreate(&e);
+		*out = ctx;
+		return MULLS_OK;
+	}
+
+	void mulls_destroy(mulls_ctx *ctx)
+	{
+		if (!ctx)
+			return;
+		(void)hipSetDevice(ctx->device);
+		for (auto &e : ctx->ev)
+			if (e)
+				(void)hipEventDestroy(e);
+		if (ctx->stream)
+			(void)hipStreamDestroy(ctx->stream);
+		delete ctx;
+	}
+
+	const char *mulls_last_error(const mulls_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+	int mulls_set_profiling(mulls_ctx *ctx, int on)
+	{
+		if (!ctx)
+			return MULLS_E_INVALID;
+		ctx->profiling = on != 0;
+		return MULLS_OK;
+	}
+
+	int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out)
+	{
+		if (!ctx || !out)
+			return MULLS_E_INVALID;
+		*out = ctx->prof;
+		return MULLS_OK;
+	}
+
+	void *mulls_stream(mulls_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+	void mulls_batch_destroy(mulls_ctx *ctx, mulls_batch *B)
+	{
+		if (!B)
+			return;
+		if (ctx)
+			(void)hipSetDevice(ctx->device);
+		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
+					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->bbox, B->setup_jobs, B->jobs, B->partial};
+		for (void *p : dev)
+			if (p)
+				(void)hipFree(p);
+		if (B->states_h)
+			(void)hipHostFree(B->states_h);
+		if (B->outs_h)
+			(void)hipHostFree(B->outs_h);
+		if (B->bbox_h)
+			(void)hipHostFree(B->bbox_h);
+		delete B;
+	}
+
+	int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_batch **out)
+	{
+		if (!ctx || !pairs || n <= 0 || !out)
+			return MULLS_E_INVALID;
+		*out = nullptr;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		mulls_batch *B = new mulls_batch();
+		B->n = n;
+		B->descs_h.resize((size_t)n * MULLS_NC);
+		B->setup_h.resize(n);
+		size_t stage_rec = 0, so = 0, to = 0;
+		for (int p = 0; p < n; p++)
+		{
+			for (int c = 0; c < MULLS_NC; c++)
+			{
+				CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+				std::memset(&d, 0, sizeof(d));
+				const mulls_cloud &s = pairs[p].src[c], &t = pairs[p].tgt[c];
+				if ((s.n && (!s.pts || s.stride < MULLS_POINT_BYTES)) || (t.n && (!t.pts || t.stride < MULLS_POINT_BYTES)))
+				{
+					ctx->err = "cloud with points but null pointer or stride < 48";
+					delete B;
+					return MULLS_E_INVALID;
+				}
+				d.src_stage = (uint32_t)stage_rec;
+				d.src_n0 = s.n;
+				stage_rec += s.n;
+				d.tgt_stage = (uint32_t)stage_rec;
+				d.tgt_n0 = t.n;
+				stage_rec += t.n;
+				d.src_off = (uint32_t)so;
+				d.tgt_off = (uint32_t)to;
+				so += s.n;
+				to += t.n;
+				for (uint32_t k = 0; k < s.n; k += MULLS_BLOCK)
+				{
+					Job j = {(uint32_t)p, (uint32_t)c, k, 0};
+					B->setup_jobs_h.push_back(j);
+				}
+			}
+			rows12(pairs[p].init_guess, B->setup_h[p].guess);
+			std::memcpy(B->setup_h[p].tgt_bound, pairs[p].tgt_bound, sizeof(double) * 6);
+		}
+		if (stage_rec >= (1ull << 31))
+		{
+			ctx->err = "batch too large (>= 2^31 points)";
+			delete B;
+			return MULLS_E_INVALID;
+		}
+		B->n_src = so;
+		B->n_tgt = to;
+
+		int rc = MULLS_OK;
+		auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
+		A(dmalloc(ctx, &B->stage, stage_rec * 3));
+		A(dmalloc(ctx, &B->tmp_pos, so));
+		A(dmalloc(ctx, &B->tmp_nrm, so));
+		A(dmalloc(ctx, &B->spos, so));
+		A(dmalloc(ctx, &B->snrm, so));
+		A(dmalloc(ctx, &B->tpos, to));
+		A(dmalloc(ctx, &B->tnrm, to));
+		A(dmalloc(ctx, &B->flag, so));
+		A(dmalloc(ctx, &B->match, so));
+		A(dmalloc(ctx, &B->nn_idx, so));
+		A(dmalloc(ctx, &B->wd, so));
+		A(dmalloc(ctx, &B->nn_d2, so));
+		A(dmalloc(ctx, &B->winner, to));
+		A(dmalloc(ctx, &B->descs, (size_t)n * MULLS_NC));
+		A(dmalloc(ctx, &B->setup, (size_t)n));
+		A(dmalloc(ctx, &B->states, (size_t)n));
+		A(dmalloc(ctx, &B->outs, (size_t)n));
+		A(dmalloc(ctx, &B->bbox, (size_t)n * 6));
+		A(dmalloc(ctx, &B->setup_jobs, B->setup_jobs_h.size()));
+		if (rc != MULLS_OK)
+		{
+			mulls_batch_destroy(ctx, B);
+			return rc;
+		}
+		if (hipHostMalloc((void **)&B->states_h, sizeof(PairState) * n, hipHostMallocDefault) != hipSuccess ||
+			hipHostMalloc((void **)&B->outs_h, sizeof(PairOut) * n, hipHostMallocDefault) != hipSuccess ||
+			hipHostMalloc((void **)&B->bbox_h, sizeof(uint32_t) * 6 * n, hipHostMallocDefault) != hipSuccess)
+		{
+			ctx->err = "hipHostMalloc failed";
+			mulls_batch_destroy(ctx, B);
+			return MULLS_E_HIP;
+		}
+		for (int p = 0; p < n; p++)
+			for (int k = 0; k < 6; k++)
+				B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
+
+		// stage the caller's AoS records (48-B PointXYZINormal) contiguously, then one H2D copy
+		{
+			std::vector<uint8_t> host(std::max<size_t>(stage_rec, 1) * MULLS_POINT_BYTES);
+			for (int p = 0; p < n; p++)
+				for (int c = 0; c < MULLS_NC; c++)
+				{
+					const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+					const mulls_cloud *cl[2] = {&pairs[p].src[c], &pairs[p].tgt[c]};
+					const uint32_t off[2] = {d.src_stage, d.tgt_stage};
+					for (int k = 0; k < 2; k++)
+					{
+						uint8_t *dst = host.data() + (size_t)off[k] * MULLS_POINT_BYTES;
+						const uint8_t *src = (const uint8_t *)cl[k]->pts;
+						if (cl[k]->stride == MULLS_POINT_BYTES)
+							std::memcpy(dst, src, (size_t)cl[k]->n * MULLS_POINT_BYTES);
+						else
+							for (uint32_t i = 0; i < cl[k]->n; i++)
+								std::memcpy(dst + (size_t)i * MULLS_POINT_BYTES, src + (size_t)i * cl[k]->stride, MULLS_POINT_BYTES);
+					}
+				}
+			hipError_t e = hipMemcpy(B->stage, host.data(), stage_rec * MULLS_POINT_BYTES, hipMemcpyHostToDevice);
+			if (e == hipSuccess)
+				e = hipMemcpy(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice);
+			if (e == hipSuccess)
+				e = hipMemcpy(B->setup, B->setup_h.data(), sizeof(PairSetup) * n, hipMemcpyHostToDevice);
+			if (e == hipSuccess)
+				e = hipMemset(B->winner, 0xff, std::max<size_t>(to, 1) * sizeof(unsigned long long));
+			if (e != hipSuccess)
+			{
+				ctx->err = std::string("staging upload: ") + hipGetErrorString(e);
+				mulls_batch_destroy(ctx, B);
+				return MULLS_E_HIP;
+			}
+		}
+		*out = B;
+		return MULLS_OK;
+	}
+
+	int mulls_batch_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P, mulls_result *results)
+	{
+		if (!ctx || !B || !results)
+			return MULLS_E_INVALID;
+		int rc = check_params(ctx, P);
+		if (rc != MULLS_OK)
+			return rc;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		const auto wall0 = std::chrono::steady_clock::now();
+		const int n = B->n;
+		hipStream_t st = ctx->stream;
+		ctx->prof = mulls_profile{};
+		EvTimer evt{ctx};
+
+		RunParams rp;
+		std::memset(&rp, 0, sizeof(rp));
+		for (int c = 0; c < MULLS_NC; c++)
+			rp.used[c] = P->used_feature_type[c] == '1';
+		rp.w_balance = P->weight_strategy[0] == '1';
+		rp.w_resid = P->weight_strategy[1] == '1';
+		rp.w_dist = P->weight_strategy[2] == '1';
+		rp.w_inten = P->weight_strategy[3] == '1';
+		rp.crop = P->apply_intersection_filter != 0;
+		rp.faithful = P->faithful != 0;
+		rp.z_xy_ratio = P->z_xy_balanced_ratio;
+		rp.win_pt = P->pt2pt_residual_window;
+		rp.win_pl = P->pt2pl_residual_window;
+		rp.win_li = P->pt2li_residual_window;
+		rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
+		rp.tick_base = ctx->tick;
+		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
+
+		// job table (static for a given used_feature_type) + fresh descriptors
+		build_jobs(B, P);
+		if (B->njobs > B->jobs_cap)
+		{
+			if (B->jobs)
+				(void)hipFree(B->jobs);
+			if (B->partial)
+				(void)hipFree(B->partial);
+			B->jobs = nullptr;
+			B->partial = nullptr;
+			if (dmalloc(ctx, &B->jobs, B->njobs) != MULLS_OK || dmalloc(ctx, &B->partial, (size_t)B->njobs * MULLS_NTERM) != MULLS_OK)
+				return MULLS_E_HIP;
+			B->jobs_cap = B->njobs;
+		}
+		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
+
+		// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188)
+		evt.begin(&ctx->prof.ms_setup);
+		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
+		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
+					B->match, B->wd, rp.crop);
+		evt.end();
+
+		std::vector<PairHost> H(n);
+		const float max_bearable_translation = (float)(2.0 * P->dis_thre_unit);
+		const float converge_rotation = (float)(P->converge_rotation_d / 180.0 * M_PI);
+		const float max_bearable_rotation = (float)(P->max_bearable_rotation_d / 180.0 * M_PI);
+		for (int p = 0; p < n; p++)
+		{
+			PairHost &h = H[p];
+			for (int r = 0; r < 3; r++)
+				for (int c = 0; c < 4; c++)
+					h.guess.at(r, c) = B->setup_h[p].guess[r * 4 + c];
+			h.guess.at(3, 0) = h.guess.at(3, 1) = h.guess.at(3, 2) = 0.0;
+			h.guess.at(3, 3) = 1.0;
+			h.temp = Mat4::identity();
+			for (int c = 0; c < MULLS_NC; c++)
+				h.thr[c] = P->dis_thre_unit;
+			h.cofactor = Mat6::identity();
+			h.info = Mat6::identity();
+			h.active = P->max_iter_num > 0;
+			h.done = !h.active;
+			results[p].trace_len = 0;
+			std::memset(results[p].ncorr, 0, sizeof(results[p].ncorr));
+			std::memset(results[p].nsrc0, 0, sizeof(results[p].nsrc0));
+			std::memset(results[p].ntgt0, 0, sizeof(results[p].ntgt0));
+		}
+
+		int lock_iter = 0;
+		for (;; lock_iter++)
+		{
+			bool any_active = false, any_resid = false;
+			for (int p = 0; p < n; p++)
+			{
+				any_active |= H[p].active;
+				any_resid |= H[p].want_residual;
+			}
+			if (!any_active && !any_resid)
+				break;
+			for (int p = 0; p < n; p++)
+			{
+				PairState &s = B->states_h[p];
+				const PairHost &h = H[p];
+				for (int r = 0; r < 3; r++)
+					for (int c = 0; c < 4; c++)
+						s.T[r * 4 + c] = h.temp.at(r, c);
+				std::memcpy(s.x, h.x, sizeof(s.x));
+				std::memcpy(s.thr, h.thr, sizeof(s.thr));
+				s.iter = h.want_residual ? h.iters - 1 : lock_iter;
+				s.active = h.active ? 1 : 0;
+				s.want_residual = h.want_residual ? 1 : 0;
+				s.pad_ = 0;
+			}
+			HIPCHK(ctx, hipMemcpyAsync(B->states, B->states_h, sizeof(PairState) * n, hipMemcpyHostToDevice, st));
+			if (any_active)
+			{
+				evt.begin(&ctx->prof.ms_nn);
+				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				evt.end();
+				evt.begin(&ctx->prof.ms_filter);
+				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
+							  B->winner);
+				evt.end();
+				ctx->prof.launches_nn++;
+				ctx->prof.iterations++;
+			}
+			evt.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
+			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
+			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs);
+			evt.end();
+			HIPCHK(ctx, hipMemcpyAsync(B->outs_h, B->outs, sizeof(PairOut) * n, hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			evt.collect();
+
+			for (int p = 0; p < n; p++)
+			{
+				PairHost &h = H[p];
+				const PairOut &o = B->outs_h[p];
+				mulls_result &R = results[p];
+				if (h.want_residual)
+				{
+					// get_multi_metrics_lls_residual (cregistration.hpp:2518-2544) + information matrix (:1386)
+					static const int order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM, MULLS_VERTEX};
+					double VTPV = 0.0;
+					long obs = 0;
+					for (int i = 0; i < 6; i++)
+					{
+						VTPV += o.sums[order[i]][0];
+						obs += (long)o.sums[order[i]][1];
+					}
+					h.sigma2 = VTPV / (double)((int)obs - 6);
+					h.code = (std::sqrt(h.sigma2) < (double)P->sigma_thre) ? 1 : -3;
+					Mat6 cinv;
+					mulls::invert6(h.cofactor, cinv);
+					for (int k = 0; k < 36; k++)
+						h.info.v[k] = (1.0 / h.sigma2) * cinv.v[k];
+					h.want_residual = false;
+					h.done = true;
+					continue;
+				}
+				if (!h.active)
+					continue;
+				const int i = lock_iter;
+				h.iters = i + 1;
+				if (h.first)
+				{
+					for (int c = 0; c < MULLS_NC; c++)
+					{
+						R.nsrc0[c] = o.src_n[c];
+						R.ntgt0[c] = o.tgt_n[c];
+						h.alive_prev[c] = o.src_n[c];
+					}
+					h.src_feature_count = 0; // cregistration.hpp:1195-1201
+					if (rp.used[1])
+						h.src_feature_count += (int)o.src_n[MULLS_PILLAR];
+					if (rp.used[2])
+						h.src_feature_count += (int)o.src_n[MULLS_FACADE];
+					if (rp.used[3])
+						h.src_feature_count += (int)o.src_n[MULLS_BEAM];
+					h.first = false;
+				}
+				for (int c = 0; c < MULLS_NC; c++)
+				{
+					if (rp.used[c] && h.alive_prev[c] >= 3 && o.tgt_n[c] >= 3)
+					{
+						ctx->prof.nn_pair_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
+						ctx->prof.nn_src_pts += h.alive_prev[c];
+						ctx->prof.nn_tgt_pts += (uint64_t)o.tgt_n[c] * (B->descs_h[p * MULLS_NC + c].job_end - B->descs_h[p * MULLS_NC + c].job_begin);
+					}
+					h.alive_prev[c] = o.n_alive[c];
+					R.ncorr[c] = o.n_valid[c];
+				}
+				int total = 0;
+				for (int c = 0; c < MULLS_NC; c++)
+					total += (int)o.n_valid[c];
+				const int necessary = (int)(o.n_valid[MULLS_PILLAR] + o.n_valid[MULLS_BEAM] + o.n_valid[MULLS_FACADE]);
+				h.ratio = (float)(1.0 * necessary / h.src_feature_count);
+
+				mulls_iter_trace *tr = nullptr;
+				if (R.trace && R.trace_len < R.trace_cap)
+				{
+					tr = &R.trace[R.trace_len++];
+					std::memset(tr, 0, sizeof(*tr));
+					tr->iter = i;
+					for (int c = 0; c < MULLS_NC; c++)
+					{
+						tr->ncorr[c] = o.n_valid[c];
+						tr->nsrc[c] = o.n_alive[c];
+						tr->thr[c] = h.thr[c];
+					}
+				}
+
+				if (total < 40 || necessary < 20 || h.ratio < P->min_neccessary_corr_ratio) // :1305-1311
+				{
+					h.code = -2;
+					h.temp = Mat4::identity();
+					h.active = false;
+					h.done = true;
+					continue;
+				}
+				for (int c = 0; c < MULLS_NC; c++) // update_corr_dist_thre :1855-1866
+				{
+					const double v = 1.0 * h.thr[c] / P->dis_thre_update_rate;
+					h.thr[c] = (float)((v > P->dis_thre_min) ? v : (double)P->dis_thre_min);
+				}
+				Mat6 N;
+				double b[6];
+				assemble_normal(o, rp.faithful != 0, N, b);
+				if (!mulls::solve_step(N, b, h.x, h.cofactor))
+					h.singular = 1;
+				if (tr)
+				{
+					std::memcpy(tr->atpa, N.v, sizeof(tr->atpa));
+					std::memcpy(tr->atpb, b, sizeof(tr->atpb));
+					std::memcpy(tr->x, h.x, sizeof(tr->x));
+				}
+				h.temp = mulls::euler_step_to_matrix(h.x);
+				const double tsn = std::sqrt(h.x[0] * h.x[0] + h.x[1] * h.x[1] + h.x[2] * h.x[2]);
+				const double rsa = mulls::rotation_angle(h.temp);
+				if (tsn > max_bearable_translation || std::fabs(rsa) > max_bearable_rotation) // :1348-1354
+				{
+					h.code = -1;
+					h.temp = Mat4::identity();
+					h.active = false;
+					h.done = true;
+					continue;
+				}
+				if (i == P->max_iter_num - 1 || (i > 2 && tsn < P->converge_translation && std::fabs(rsa) < converge_rotation)) // :1357
+				{
+					h.active = false;
+					h.want_residual = true; // the residual pass runs on the device before anything else touches this pair
+					continue;
+				}
+				h.guess = h.temp * h.guess; // :1400
+			}
+		}
+
+		const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
+		for (int p = 0; p < n; p++)
+		{
+			PairHost &h = H[p];
+			mulls_result &R = results[p];
+			h.guess = h.temp * h.guess; // :1403
+			R.code = h.code;
+			R.iters = h.iters;
+			std::memcpy(R.T, h.guess.v, sizeof(R.T));
+			std::memcpy(R.info, h.info.v, sizeof(R.info));
+			R.sigma = (float)std::sqrt(h.sigma2);
+			R.confidence = h.ratio;
+			R.singular = h.singular;
+			R.ms_total = (float)(wall_ms / n);
+		}
+		return MULLS_OK;
+	}
+
+	int mulls_icp_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results)
+	{
+		if (!ctx)
+			return MULLS_E_INVALID;
+		int rc = check_params(ctx, params);
+		if (rc != MULLS_OK)
+			return rc;
+		mulls_batch *B = nullptr;
+		rc = mulls_batch_create(ctx, pairs, n, &B);
+		if (rc != MULLS_OK)
+			return rc;
+		rc = mulls_batch_run(ctx, B, params, results);
+		mulls_batch_destroy(ctx, B);
+		return rc;
+	}
+
+	int mulls_icp(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result)
+	{
+		return mulls_icp_batch(ctx, pair, 1, params, result);
+	}
+
+	// ------------------------------------------------------------------------------------------------------------
+	// stage-level entry points
+	int mulls_stage_transform(mulls_ctx *ctx, void *pts, uint32_t n, uint32_t stride, const double T[16])
+	{
+		if (!ctx || (n && !pts) || stride != MULLS_POINT_BYTES || !T)
+			return MULLS_E_INVALID;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		float4 *d = nullptr;
+		double *dT = nullptr;
+		double t12[12];
+		rows12(T, t12);
+		if (dmalloc(ctx, &d, (size_t)n * 3) != MULLS_OK || dmalloc(ctx, &dT, 12) != MULLS_OK)
+			return MULLS_E_HIP;
+		hipError_t e = hipMemcpyAsync(d, pts, (size_t)n * MULLS_POINT_BYTES, hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(dT, t12, sizeof(t12), hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess)
+		{
+			launch_transform_aos(ctx->stream, d, n, dT);
+			e = hipMemcpyAsync(pts, d, (size_t)n * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, ctx->stream);
+		}
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(ctx->stream);
+		(void)hipFree(d);
+		(void)hipFree(dT);
+		if (e != hipSuccess)
+		{
+			ctx->err = hipGetErrorString(e);
+			return MULLS_E_HIP;
+		}
+		return MULLS_OK;
+	}
+
+	namespace
+	{
+	// one-pair, one-class batch with identity guess and no intersection filter; leaves the batch set up (clone + crop run)
+	int stage_batch(mulls_ctx *ctx, int cls, const mulls_cloud *src, const mulls_cloud *tgt, mulls_batch **out, RunParams *rp,
+					const char *used6)
+	{
+		mulls_pair pr;
+		std::memset(&pr, 0, sizeof(pr));
+		pr.src[cls] = *src;
+		pr.tgt[cls] = *tgt;
+		for (int k = 0; k < 4; k++)
+			pr.init_guess[5 * k] = 1.0;
+		int rc = mulls_batch_create(ctx, &pr, 1, out);
+		if (rc != MULLS_OK)
+			return rc;
+		mulls_batch *B = *out;
+		mulls_params P;
+		mulls_default_params(&P);
+		std::strcpy(P.used_feature_type, used6);
+		build_jobs(B, &P);
+		if (dmalloc(ctx, &B->jobs, B->njobs) != MULLS_OK || dmalloc(ctx, &B->partial, (size_t)B->njobs * MULLS_NTERM) != MULLS_OK)
+			return MULLS_E_HIP;
+		B->jobs_cap = B->njobs;
+		hipStream_t st = ctx->stream;
+		std::memset(rp, 0, sizeof(*rp));
+		rp->used[cls] = 1;
+		rp->faithful = 1;
+		rp->tick_base = ctx->tick;
+		ctx->tick += 4;
+		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6, hipMemcpyHostToDevice, st));
+		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
+		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
+					B->wd, 0);
+		return MULLS_OK;
+	}
+	void identity_state(PairState *s, int iter)
+	{
+		std::memset(s, 0, sizeof(*s));
+		s->T[0] = s->T[5] = s->T[10] = 1.0;
+		s->iter = iter;
+		s->active = 1;
+	}
+	} // namespace
+
+	int mulls_stage_correspond(mulls_ctx *ctx, const mulls_cloud *src, const mulls_cloud *tgt, float dis_thre, int normal_check,
+							   float angle_thre_degree, int32_t *match, float *d2, uint8_t *flags)
+	{
+		if (!ctx || !src || !tgt || !match || !d2 || !flags)
+			return MULLS_E_INVALID;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		if (src->n == 0)
+			return MULLS_OK;
+		const int cls = normal_check ? MULLS_GROUND : MULLS_VERTEX;
+		mulls_batch *B = nullptr;
+		RunParams rp;
+		int rc = stage_batch(ctx, cls, src, tgt, &B, &rp, normal_check ? "100000" : "000001");
+		if (rc == MULLS_OK)
+		{
+			rp.cos_bearing = std::cos(angle_thre_degree / 180.0 * M_PI);
+			identity_state(&B->states_h[0], 0);
+			for (int c = 0; c < MULLS_NC; c++)
+				B->states_h[0].thr[c] = dis_thre;
+			hipStream_t st = ctx->stream;
+			hipError_t e = hipMemcpyAsync(B->states, B->states_h, sizeof(PairState), hipMemcpyHostToDevice, st);
+			launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
+						  B->winner);
+			const uint32_t off = B->descs_h[cls].src_off;
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(match, B->nn_idx + off, sizeof(int32_t) * src->n, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(d2, B->nn_d2 + off, sizeof(float) * src->n, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(flags, B->flag + off, src->n, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(st);
+			if (e != hipSuccess)
+			{
+				ctx->err = hipGetErrorString(e);
+				rc = MULLS_E_HIP;
+			}
+			if (rc == MULLS_OK && (src->n < 3 || tgt->n < 3))
+				for (uint32_t i = 0; i < src->n; i++) // search skipped (K_min): nothing was written by the kernels
+				{
+					match[i] = -1;
+					d2[i] = 0.0f;
+				}
+		}
+		mulls_batch_destroy(ctx, B);
+		return rc;
+	}
+
+	int mulls_stage_accumulate(mulls_ctx *ctx, int metric, const mulls_cloud *src, const mulls_cloud *tgt, const int32_t *corr_src,
+							   const int32_t *corr_tgt, const float *corr_d2, uint32_t ncorr, int iter_num, float class_weight, int dist_w,
+							   int resid_w, int inten_w, float window, double *out27, float *weight_out)
+	{
+		if (!ctx || !src || !tgt || !out27 || metric < 0 || metric > 2 || (ncorr && (!corr_src || !corr_tgt)))
+			return MULLS_E_INVALID;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		for (int k = 0; k < 27; k++)
+			out27[k] = 0.0;
+		if (src->n == 0 || ncorr == 0)
+			return MULLS_OK;
+		for (uint32_t i = 0; i < ncorr; i++)
+			if (corr_src[i] < 0 || (uint32_t)corr_src[i] >= src->n || corr_tgt[i] < 0 || (uint32_t)corr_tgt[i] >= tgt->n)
+				return MULLS_E_INVALID;
+		const int cls = metric == 0 ? MULLS_FACADE : (metric == 1 ? MULLS_PILLAR : MULLS_VERTEX);
+		const char *used = metric == 0 ? "001000" : (metric == 1 ? "010000" : "000001");
+		mulls_batch *B = nullptr;
+		RunParams rp;
+		int rc = stage_batch(ctx, cls, src, tgt, &B, &rp, used);
+		int32_t *dcs = nullptr, *dct = nullptr;
+		float *dcd = nullptr;
+		if (rc == MULLS_OK)
+		{
+			rp.w_dist = dist_w != 0;
+			rp.w_resid = resid_w != 0; // k_accum additionally requires iter_num > 2, like the reference
+			rp.w_inten = inten_w != 0;
+			rp.win_pl = rp.win_li = rp.win_pt = window;
+			rp.force_class_w = 1;
+			rp.class_w_value = class_weight;
+			hipStream_t st = ctx->stream;
+			hipError_t e = hipSuccess;
+			if (dmalloc(ctx, &dcs, ncorr) != MULLS_OK || dmalloc(ctx, &dct, ncorr) != MULLS_OK || dmalloc(ctx, &dcd, ncorr) != MULLS_OK)
+				e = hipErrorOutOfMemory;
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(dcs, corr_src, sizeof(int32_t) * ncorr, hipMemcpyHostToDevice, st);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(dct, corr_tgt, sizeof(int32_t) * ncorr, hipMemcpyHostToDevice, st);
+			if (e == hipSuccess && corr_d2)
+				e = hipMemcpyAsync(dcd, corr_d2, sizeof(float) * ncorr, hipMemcpyHostToDevice, st);
+			identity_state(&B->states_h[0], iter_num);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(B->states, B->states_h, sizeof(PairState), hipMemcpyHostToDevice, st);
+			const uint32_t off = B->descs_h[cls].src_off;
+			if (e == hipSuccess)
+			{
+				// clear every flag to "alive, not a correspondence", then switch the requested ones on
+				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
+				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
+				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
+				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs);
+			}
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(B->outs_h, B->outs, sizeof(PairOut), hipMemcpyDeviceToHost, st);
+			std::vector<float> wall(src->n);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(wall.data(), B->wd + off, sizeof(float) * src->n, hipMemcpyDeviceToHost, st);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(st);
+			if (e != hipSuccess)
+			{
+				ctx->err = hipGetErrorString(e);
+				rc = MULLS_E_HIP;
+			}
+			else
+			{
+				std::memcpy(out27, B->outs_h[0].sums[cls], sizeof(double) * 27);
+				if (weight_out)
+					for (uint32_t i = 0; i < ncorr; i++)
+						weight_out[i] = wall[corr_src[i]];
+			}
+		}
+		if (dcs)
+			(void)hipFree(dcs);
+		if (dct)
+			(void)hipFree(dct);
+		if (dcd)
+			(void)hipFree(dcd);
+		mulls_batch_destroy(ctx, B);
+		return rc;
+	}
+}

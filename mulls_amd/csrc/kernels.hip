@@ -1,0 +1,894 @@
+// kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the MULLS-ICP hot path.
+//
+// Reference semantics implemented here (citations relative to the MULLS tree, include/common/):
+//   k_clone_src   cloudblock_t::clone_feature + batch_transform_feature_points(initial_guess)   utility.hpp:524-550, cregistration.hpp:1183
+//   k_crop        intersection_filter / bbx_filter (stable compaction of all 12 clouds)          cregistration.hpp:2894-2922, cfilter.hpp:950-981
+//   k_nn          batch_transform_feature_points(TempTran) fused with the exact 1-NN search      cregistration.hpp:1260, :1740-1747
+//   k_filter      duplicate rule, permanent source compaction, distance + direction rejectors    cregistration.hpp:1755-1830
+//   k_accum       pt2pl / pt2li / pt2pt normal-equation terms, and the posterior residual pass   cregistration.hpp:1976-2275, :2546-2677
+//   k_finish      fixed-order reduction of per-workgroup partials, per-iteration bookkeeping
+//
+// Numerics policy: every float/double operation order follows the reference's C++ expressions; the translation unit
+// is compiled with -ffp-contract=off (the reference build has no FMA: CMakeLists.txt:43, no -march), float sqrt and
+// division are IEEE-correct (hipcc default), accumulators are double.  No MFMA: this is a search plus a reduction.
+//
+// Launch geometry: 256-thread workgroups (4 wave64).  The search / filter / accumulate kernels share one static job
+// table (one job = 512 consecutive source points of one feature class of one pair); dead source points keep their
+// slot and are masked by a flag byte instead of being physically compacted, which makes the job table iteration-
+// invariant and the whole batch advance with three launches per ICP iteration.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+#pragma clang fp contract(off)
+
+namespace
+{
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+	uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t k)
+{
+	uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+	return __uint_as_float(u);
+}
+
+__device__ __forceinline__ bool class_called(const RunParams &rp, const CloudDesc &d, int cls)
+{
+	// `if (used[c] && src.size() > 0) determine_corres(...)` (cregistration.hpp:1272-1292) combined with the
+	// K_min = 3 early return inside it (:1727-1728, :1832-1833)
+	return rp.used[cls] && d.alive_cur >= 3u && d.tgt_n >= 3u;
+}
+
+// wave64 + 4-wave workgroup sum of an unsigned count; result valid in every thread
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4)
+{
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_down(v, off);
+	int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__syncthreads();
+	if (lane == 0)
+		lds4[wave] = v;
+	__syncthreads();
+	return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Setup 1: clone the staged source clouds into SoA and apply the initial guess (double math, float store); reduce
+// the bounding box of the transformed ground / pillar / facade source clouds (cregistration.hpp:2912-2915).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+															const PairSetup *__restrict__ setup, const float4 *__restrict__ stage,
+															float4 *__restrict__ tmp_pos, float4 *__restrict__ tmp_nrm,
+															uint32_t *__restrict__ bbox /* [pair][6] ordered keys */)
+{
+	const Job job = jobs[blockIdx.x];
+	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t s = job.start + threadIdx.x;
+	const bool in = s < d.src_n0;
+	const double *G = setup[job.pair].guess;
+	float x = 0, y = 0, z = 0;
+	if (in)
+	{
+		const float4 *rec = stage + (size_t)(d.src_stage + s) * 3;
+		float4 a = rec[0], b = rec[1], c = rec[2]; // (x y z _) (nx ny nz _) (intensity curvature _ _)
+		double px = a.x, py = a.y, pz = a.z, nx = b.x, ny = b.y, nz = b.z;
+		x = (float)(G[0] * px + G[1] * py + G[2] * pz + G[3]);
+		y = (float)(G[4] * px + G[5] * py + G[6] * pz + G[7]);
+		z = (float)(G[8] * px + G[9] * py + G[10] * pz + G[11]);
+		float onx = (float)(G[0] * nx + G[1] * ny + G[2] * nz);
+		float ony = (float)(G[4] * nx + G[5] * ny + G[6] * nz);
+		float onz = (float)(G[8] * nx + G[9] * ny + G[10] * nz);
+		tmp_pos[d.src_off + s] = make_float4(x, y, z, c.x);
+		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, c.y);
+	}
+	if (job.cls == 0 || job.cls == 1 || job.cls == 2)
+	{
+		uint32_t k[6];
+		k[0] = in ? f2ord(x) : 0xffffffffu;
+		k[1] = in ? f2ord(y) : 0xffffffffu;
+		k[2] = in ? f2ord(z) : 0xffffffffu;
+		k[3] = in ? f2ord(x) : 0u;
+		k[4] = in ? f2ord(y) : 0u;
+		k[5] = in ? f2ord(z) : 0u;
+		for (int off = 32; off > 0; off >>= 1)
+			for (int j = 0; j < 3; j++)
+			{
+				k[j] = min(k[j], (uint32_t)__shfl_down(k[j], off));
+				k[3 + j] = max(k[3 + j], (uint32_t)__shfl_down(k[3 + j], off));
+			}
+		if ((threadIdx.x & 63) == 0)
+			for (int j = 0; j < 3; j++)
+			{
+				atomicMin(&bbox[job.pair * 6 + j], k[j]);
+				atomicMax(&bbox[job.pair * 6 + 3 + j], k[3 + j]);
+			}
+	}
+}
+
+// Setup 2: order-preserving compaction of one cloud by the intersection box.  One workgroup per (pair, class, side);
+// side 0 = source (reads the SoA written by k_clone_src), side 1 = target (reads the staged AoS records).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ descs, const PairSetup *__restrict__ setup,
+													   const uint32_t *__restrict__ bbox, const float4 *__restrict__ stage,
+													   const float4 *__restrict__ tmp_pos, const float4 *__restrict__ tmp_nrm,
+													   float4 *__restrict__ spos, float4 *__restrict__ snrm, float4 *__restrict__ tpos,
+													   float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, int32_t *__restrict__ match,
+													   float *__restrict__ wd, int crop)
+{
+	__shared__ uint32_t wave_cnt[4];
+	const uint32_t pair = blockIdx.x / (MULLS_NC * 2);
+	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
+	const uint32_t side = blockIdx.x & 1;
+	CloudDesc &d = descs[pair * MULLS_NC + cls];
+	const uint32_t n0 = side ? d.tgt_n0 : d.src_n0;
+	const uint32_t off = side ? d.tgt_off : d.src_off;
+	double lo[3], hi[3];
+	if (crop)
+	{
+		for (int k = 0; k < 3; k++)
+		{
+			uint32_t kmin = bbox[pair * 6 + k], kmax = bbox[pair * 6 + 3 + k];
+			// an empty union keeps (+DBL_MAX, -DBL_MAX) like CloudUtility::merge_bbx (utility.hpp:867-884)
+			double mmin = (kmin == 0xffffffffu && kmax == 0u) ? 1.7976931348623157e308 : (double)ord2f(kmin);
+			double mmax = (kmin == 0xffffffffu && kmax == 0u) ? -1.7976931348623157e308 : (double)ord2f(kmax);
+			double b1min = setup[pair].tgt_bound[k], b1max = setup[pair].tgt_bound[3 + k];
+			const float pad = 1.0f;
+			lo[k] = ((b1min > mmin) ? b1min : mmin) - pad; // get_intersection_bbx, utility.hpp:857-865
+			hi[k] = ((b1max < mmax) ? b1max : mmax) + pad;
+		}
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < n0; base += MULLS_BLOCK)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const bool in = i < n0;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		if (in)
+		{
+			if (side)
+			{
+				const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
+				float4 a = rec[0], b = rec[1], c = rec[2];
+				p = make_float4(a.x, a.y, a.z, c.x);
+				q = make_float4(b.x, b.y, b.z, c.y);
+			}
+			else
+			{
+				p = tmp_pos[off + i];
+				q = tmp_nrm[off + i];
+			}
+		}
+		bool keep = in;
+		if (crop && in) // strict inequalities, float coordinate promoted to double (cfilter.hpp:959-961)
+			keep = (double)p.x > lo[0] && (double)p.x < hi[0] && (double)p.y > lo[1] && (double)p.y < hi[1] && (double)p.z > lo[2] &&
+				   (double)p.z < hi[2];
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads();
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			const uint32_t dst = off + running + wbase + before;
+			if (side)
+			{
+				tpos[dst] = p;
+				tnrm[dst] = q;
+			}
+			else
+			{
+				spos[dst] = p;
+				snrm[dst] = q;
+				flag[dst] = MULLS_F_ALIVE;
+				match[dst] = -1;
+				wd[dst] = 0.0f;
+			}
+		}
+		running += total;
+	}
+	if (threadIdx.x == 0)
+	{
+		if (side)
+			d.tgt_n = running;
+		else
+		{
+			d.src_n = running;
+			d.alive_cur = running;
+			d.alive_next = 0;
+			d.n_matched = 0;
+			d.valid_next = 0;
+			d.n_valid = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Correspondence search.  A workgroup is 2 wave64 (MULLS_NN_BLOCK = 128 lanes); each lane owns MULLS_NN_PTS = 4
+// source points of the job's 512-point slice: it applies this iteration's rigid step (double math, float store, in
+// place — the reference accumulates float rounding the same way), then scans the whole target class cloud.  Targets
+// are streamed from HBM with coalesced 16-B loads and staged in LDS as three planar arrays X[], Y[], Z[], so that one
+// ds_read_b128 (wave-uniform address -> broadcast) delivers one coordinate of FOUR targets: 6 LDS reads per 8
+// targets against ~290 VALU instructions, which keeps the LDS pipe ~10 % busy and the kernel VALU-bound.
+// Distances are FLANN's L2_Simple<float>: ((dx*dx)+(dy*dy))+(dz*dz), no FMA.  Per source point the scan keeps the
+// running minimum and the first index of the 8-target group that produced it (one v_min3 chain + one compare per
+// group instead of a compare/select pair per target); the exact target index — lowest index among bit-equal
+// distances — is recovered afterwards by re-evaluating that one group from L2.
+template <int NPTS>
+__device__ __forceinline__ void nn_scan_group(const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, uint32_t j,
+											   const float (&px)[NPTS], const float (&py)[NPTS], const float (&pz)[NPTS], float (&best)[NPTS],
+											   uint32_t (&grp)[NPTS], uint32_t gidx)
+{
+	const float4 x0 = *reinterpret_cast<const float4 *>(X + j), x1 = *reinterpret_cast<const float4 *>(X + j + 4);
+	const float4 y0 = *reinterpret_cast<const float4 *>(Y + j), y1 = *reinterpret_cast<const float4 *>(Y + j + 4);
+	const float4 z0 = *reinterpret_cast<const float4 *>(Z + j), z1 = *reinterpret_cast<const float4 *>(Z + j + 4);
+	const float tx[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+	const float ty[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+	const float tz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+	for (int u = 0; u < NPTS; u++)
+	{
+		float dd[8];
+#pragma unroll
+		for (int v = 0; v < 8; v++)
+		{
+			const float dx = px[u] - tx[v], dy = py[u] - ty[v], dz = pz[u] - tz[v];
+			dd[v] = (dx * dx + dy * dy) + dz * dz;
+		}
+		const float m = fminf(fminf(fminf(dd[0], dd[1]), fminf(dd[2], dd[3])), fminf(fminf(dd[4], dd[5]), fminf(dd[6], dd[7])));
+		const bool upd = m < best[u]; // strict: an equal later distance never replaces an earlier one
+		best[u] = upd ? m : best[u];
+		grp[u] = upd ? gidx : grp[u];
+	}
+}
+
+__global__ __launch_bounds__(MULLS_NN_BLOCK) void k_nn(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+														const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
+														float4 *__restrict__ snrm, const float4 *__restrict__ tpos,
+														const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+														unsigned long long *__restrict__ winner)
+{
+	__shared__ __attribute__((aligned(16))) float tileX[MULLS_TILE];
+	__shared__ __attribute__((aligned(16))) float tileY[MULLS_TILE];
+	__shared__ __attribute__((aligned(16))) float tileZ[MULLS_TILE];
+	const Job job = jobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n, alive_cur = d.alive_cur;
+	const bool called = class_called(rp, d, job.cls);
+	const float *__restrict__ tp = reinterpret_cast<const float *>(tpos + d.tgt_off);
+
+	uint32_t s[MULLS_NN_PTS];
+	bool alive[MULLS_NN_PTS];
+	float px[MULLS_NN_PTS], py[MULLS_NN_PTS], pz[MULLS_NN_PTS];
+#pragma unroll
+	for (int u = 0; u < MULLS_NN_PTS; u++)
+	{
+		s[u] = job.start + threadIdx.x + u * MULLS_NN_BLOCK;
+		alive[u] = s[u] < src_n && (flag[d.src_off + s[u]] & MULLS_F_ALIVE);
+		px[u] = py[u] = pz[u] = 0.0f;
+		if (alive[u])
+		{
+			// pcl::transformPointCloudWithNormals<PointT,double> (cregistration.hpp:1690-1695)
+			float4 p = spos[d.src_off + s[u]], n = snrm[d.src_off + s[u]];
+			const double *T = ps.T;
+			double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+			px[u] = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+			py[u] = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+			pz[u] = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+			float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+			float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+			float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+			spos[d.src_off + s[u]] = make_float4(px[u], py[u], pz[u], p.w);
+			snrm[d.src_off + s[u]] = make_float4(onx, ony, onz, n.w);
+		}
+	}
+	if (!called)
+		return; // correspondences of the previous iteration stay in force
+
+	const float INF = __builtin_inff();
+	float best[MULLS_NN_PTS];
+	uint32_t grp[MULLS_NN_PTS]; // first target index of the winning 8-group
+#pragma unroll
+	for (int u = 0; u < MULLS_NN_PTS; u++)
+	{
+		best[u] = INF;
+		grp[u] = 0;
+	}
+
+	for (uint32_t base = 0; base < tgt_n; base += MULLS_TILE)
+	{
+		const uint32_t nt = min((uint32_t)MULLS_TILE, tgt_n - base);
+		const uint32_t nt8 = (nt + 7u) & ~7u;
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < nt8; k += MULLS_NN_BLOCK)
+		{
+			// +inf padding keeps the unrolled scan free of tail code: (p - inf)^2 = inf never beats a finite minimum
+			const float4 t = (k < nt) ? tpos[d.tgt_off + base + k] : make_float4(INF, INF, INF, 0.0f);
+			tileX[k] = t.x;
+			tileY[k] = t.y;
+			tileZ[k] = t.z;
+		}
+		__syncthreads();
+		for (uint32_t j = 0; j < nt8; j += 8)
+			nn_scan_group<MULLS_NN_PTS>(tileX, tileY, tileZ, j, px, py, pz, best, grp, base + j);
+	}
+
+	// recover the exact index inside the winning group (bit-identical re-evaluation)
+	const float r = 2.5f * ps.thr[job.cls];	 // filter_dis_times * dis_thre (float), cregistration.hpp:1745
+	const double maxd = (double)r;			 // widened to the `double max_distance` parameter
+	const double max_dist_sqr = maxd * maxd; // CorrespondenceEstimation::determineCorrespondences
+	const bool gate = alive_cur >= 500u;	 // K_filter_distant_point, cregistration.hpp:1755
+	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	uint32_t matched_cnt = 0;
+#pragma unroll
+	for (int u = 0; u < MULLS_NN_PTS; u++)
+	{
+		if (!alive[u])
+			continue;
+		int idx = -1;
+		for (int v = 7; v >= 0; v--)
+		{
+			const uint32_t t = grp[u] + v;
+			if (t < tgt_n)
+			{
+				float ddx = px[u] - tp[4 * t], ddy = py[u] - tp[4 * t + 1], ddz = pz[u] - tp[4 * t + 2];
+				float dist = (ddx * ddx + ddy * ddy) + ddz * ddz;
+				if (dist == best[u])
+					idx = (int)t;
+			}
+		}
+		const bool matched = idx >= 0 && !((double)best[u] > max_dist_sqr);
+		nn_idx[d.src_off + s[u]] = matched ? idx : -1;
+		nn_d2[d.src_off + s[u]] = best[u];
+		if (matched)
+		{
+			matched_cnt++;
+			if (gate) // duplicate rule: the lowest source index claims the target (first-come in the reference's serial walk)
+				atomicMin(&winner[d.tgt_off + idx], key_hi | (unsigned long long)s[u]);
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0 && matched_cnt)
+		atomicAdd(&d.n_matched, matched_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Rejection chain of determine_corres after the search (cregistration.hpp:1755-1830).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+														 const PairState *__restrict__ states, RunParams rp,
+														 const float4 *__restrict__ snrm, const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag,
+														 const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
+														 int32_t *__restrict__ match, float *__restrict__ wd,
+														 const unsigned long long *__restrict__ winner)
+{
+	__shared__ uint32_t red4[4];
+	const Job job = jobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	if (!class_called(rp, d, job.cls))
+		return;
+	const bool gate = d.alive_cur >= 500u;
+	const bool any_match = d.n_matched > 0u;
+	const bool normal_check = job.cls != 5; // vertex correspondences skip the direction check (cregistration.hpp:1292)
+	const float thr = ps.thr[job.cls];
+	const float max_sqr = thr * thr;							   // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	const double cos_thre = rp.cos_bearing;						   // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
+	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	uint32_t n_alive = 0, n_valid = 0;
+#pragma unroll
+	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	{
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		if (s >= d.src_n)
+			continue;
+		const uint32_t g = d.src_off + s;
+		uint32_t f = flag[g];
+		if (!(f & MULLS_F_ALIVE))
+			continue;
+		bool alive = true, valid;
+		int m;
+		if (any_match)
+		{
+			m = nn_idx[g];
+			valid = m >= 0;
+			if (gate && (m < 0 || winner[d.tgt_off + m] != (key_hi | (unsigned long long)s)))
+			{
+				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+				valid = false;
+			}
+			if (valid)
+			{
+				const float dist = nn_d2[g];
+				valid = !(dist > max_sqr);
+				if (valid)
+				{
+					match[g] = m;
+					wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+				}
+			}
+		}
+		else if (gate)
+		{
+			alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+			valid = false;
+			m = -1;
+		}
+		else
+		{
+			// CorrespondenceRejectorDistance::getCorrespondences returned early on the empty input: the previous
+			// Corr_f is still in place (SURVEY B-4) and goes through the direction check again.
+			valid = (f & MULLS_F_VALID) != 0;
+			m = match[g];
+		}
+		if (valid && normal_check)
+		{
+			const float4 n1 = snrm[g], n2 = tnrm[d.tgt_off + m];
+			const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+			const float c = (float)fabs(dot);
+			if ((double)c < cos_thre)
+				valid = false;
+		}
+		flag[g] = (uint8_t)((alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u));
+		n_alive += alive ? 1u : 0u;
+		n_valid += valid ? 1u : 0u;
+	}
+	const uint32_t ta = block_sum_u32(n_alive, red4);
+	const uint32_t tv = block_sum_u32(n_valid, red4);
+	if (threadIdx.x == 0)
+	{
+		if (ta)
+			atomicAdd(&d.alive_next, ta);
+		if (tv)
+			atomicAdd(&d.valid_next, tv);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight functions (cregistration.hpp:2686-2722) — float/double mix exactly as written there
+namespace
+{
+__device__ __forceinline__ float w_dist_adaptive(float dist, int iter_num)
+{
+	const float unit_dist = 30.0f, b_min = 0.7f, b_max = 1.3f, b_step = 0.05f;
+	float t = b_min + b_step * iter_num;
+	float b_current = (t < b_max) ? t : b_max;
+	float temp = (float)(b_current + (1.0 - b_current) * dist / unit_dist);
+	temp = (float)((temp > 0.01) ? (double)temp : 0.01);
+	return temp;
+}
+__device__ __forceinline__ float w_intensity(float i1, float i2)
+{
+	float ratio = fabsf(i1 - i2) / 255.0f;
+	return (float)exp(-1.0 * ratio);
+}
+__device__ __forceinline__ float w_residual(float res, float thre)
+{
+	return (res > thre) ? ((2 * res * thre + (1 * 1 - 2 * 1) * (thre * thre)) / res / res) : 1.0f;
+}
+__device__ __forceinline__ int metric_of(int cls) { return (cls == 1 || cls == 3) ? 1 : (cls == 5 ? 2 : 0); }
+} // namespace
+
+// Normal-equation accumulation (active pairs) or posterior residual (pairs flagged want_residual).  27 double
+// accumulators per lane -> wave64 shuffle tree -> 4-wave LDS combine -> one 27-double partial per workgroup, summed
+// in fixed order by k_finish (run-to-run deterministic, unlike atomicAdd(double)).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+														const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
+														const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm,
+														const uint8_t *__restrict__ flag, const int32_t *__restrict__ match, float *__restrict__ wd,
+														double *__restrict__ partial)
+{
+	__shared__ double red[4][MULLS_NTERM];
+	const Job job = jobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active && !ps.want_residual)
+		return;
+	const CloudDesc *pd = descs + job.pair * MULLS_NC;
+	const CloudDesc &d = pd[job.cls];
+	const int metric = metric_of(job.cls);
+	const bool residual_pass = ps.want_residual != 0;
+
+	float class_w = 1.0f;
+	if (rp.force_class_w)
+		class_w = rp.class_w_value; // stage-level entry point only (mulls_stage_accumulate)
+	else if (!residual_pass && rp.w_balance && (job.cls == 0 || job.cls == 4))
+	{
+		// w_ground = max_(0.01, z_xy * (m2 + 2*m3 - m4) / (0.0001 + 2.0*m1))   (cregistration.hpp:1886-1894)
+		int cnt[MULLS_NC];
+		for (int c = 0; c < MULLS_NC; c++)
+			cnt[c] = (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
+		int m1 = cnt[0] + cnt[4], m2 = cnt[2], m3 = cnt[1], m4 = cnt[3];
+		double v = rp.z_xy_ratio * (m2 + 2 * m3 - m4) / (0.0001 + 2.0 * m1);
+		class_w = (float)((0.01 > v) ? 0.01 : v);
+	}
+	const int iter_num = ps.iter;
+	const bool resid_w = rp.w_resid && iter_num > 2;
+	const bool dist_w = rp.w_dist, inten_w = rp.w_inten;
+	const float window = metric == 0 ? rp.win_pl : (metric == 1 ? rp.win_li : rp.win_pt);
+
+	double acc[MULLS_NTERM];
+#pragma unroll
+	for (int k = 0; k < MULLS_NTERM; k++)
+		acc[k] = 0.0;
+
+#pragma unroll
+	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	{
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		if (s >= d.src_n)
+			continue;
+		const uint32_t g = d.src_off + s;
+		if ((flag[g] & (MULLS_F_ALIVE | MULLS_F_VALID)) != (MULLS_F_ALIVE | MULLS_F_VALID))
+			continue;
+		const int m = match[g];
+		const float4 P = spos[g], Q = tpos[d.tgt_off + m], N = tnrm[d.tgt_off + m];
+		const float px = P.x, py = P.y, pz = P.z, pi = P.w;
+		const float qx = Q.x, qy = Q.y, qz = Q.z, qi = Q.w;
+
+		if (residual_pass)
+		{
+			const double *x = ps.x;
+			const float cw = wd[g]; // pcl::Correspondence::weight — for vertex points this is still d^2
+			if (metric == 0)
+			{
+				float ntx = N.x, nty = N.y, ntz = N.z;
+				float a = ntz * py - nty * pz;
+				float b = ntx * pz - ntz * px;
+				float c = nty * px - ntx * py;
+				float dd = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+				float res = (float)(ntx * x[0] + nty * x[1] + ntz * x[2] + a * x[3] + b * x[4] + c * x[5] - dd);
+				acc[0] += cw * res * res;
+				acc[1] += 1.0;
+			}
+			else
+			{
+				float dx = px - qx, dy = py - qy, dz = pz - qz;
+				double A[3][6], bb[3];
+				if (metric == 1)
+				{
+					float vx = N.x, vy = N.y, vz = N.z;
+					A[0][0] = 0;
+					A[0][1] = vz;
+					A[0][2] = -vy;
+					A[0][3] = -vz * pz - vy * py;
+					A[0][4] = vy * px;
+					A[0][5] = vz * px;
+					A[1][0] = -vz;
+					A[1][1] = 0;
+					A[1][2] = vx;
+					A[1][3] = vx * py;
+					A[1][4] = -vx * px - vz * pz;
+					A[1][5] = vz * py;
+					A[2][0] = vy;
+					A[2][1] = -vx;
+					A[2][2] = 0;
+					A[2][3] = vx * pz;
+					A[2][4] = vy * pz;
+					A[2][5] = -vy * py - vx * px;
+					bb[0] = -vz * dy + vy * dz;
+					bb[1] = -vx * dz + vz * dx;
+					bb[2] = -vy * dx + vx * dy;
+				}
+				else
+				{
+					A[0][0] = 1, A[0][1] = 0, A[0][2] = 0, A[0][3] = 0, A[0][4] = pz, A[0][5] = -py;
+					A[1][0] = 0, A[1][1] = 1, A[1][2] = 0, A[1][3] = -pz, A[1][4] = 0, A[1][5] = px;
+					A[2][0] = 0, A[2][1] = 0, A[2][2] = 1, A[2][3] = py, A[2][4] = -px, A[2][5] = 0;
+					bb[0] = -dx, bb[1] = -dy, bb[2] = -dz;
+				}
+				double r[3];
+				for (int k = 0; k < 3; k++)
+				{
+					double t = 0;
+					for (int j = 0; j < 6; j++)
+						t += A[k][j] * x[j];
+					r[k] = t - bb[k];
+				}
+				acc[0] += cw * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+				acc[1] += 3.0;
+			}
+			continue;
+		}
+
+		const float dist = sqrtf(qx * qx + qy * qy + qz * qz);
+		if (metric == 0) // pt2pl_lls_summation, cregistration.hpp:2066-2156
+		{
+			float ntx = N.x, nty = N.y, ntz = N.z;
+			float w = class_w;
+			float a = ntz * py - nty * pz;
+			float b = ntx * pz - ntz * px;
+			float c = nty * px - ntx * py;
+			float dd = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+			if (dist_w)
+				w = w * w_dist_adaptive(dist, iter_num);
+			if (resid_w)
+				w = w * w_residual(fabsf(dd), window);
+			if (inten_w)
+				w = w * w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			wd[g] = w;
+			acc[0] += w * ntx * ntx;
+			acc[1] += w * ntx * nty;
+			acc[2] += w * ntx * ntz;
+			acc[3] += w * a * ntx;
+			acc[4] += w * b * ntx;
+			acc[5] += w * c * ntx;
+			acc[6] += w * nty * nty;
+			acc[7] += w * nty * ntz;
+			acc[8] += w * a * nty;
+			acc[9] += w * b * nty;
+			acc[10] += w * c * nty;
+			acc[11] += w * ntz * ntz;
+			acc[12] += w * a * ntz;
+			acc[13] += w * b * ntz;
+			acc[14] += w * c * ntz;
+			acc[15] += w * a * a;
+			acc[16] += w * a * b;
+			acc[17] += w * a * c;
+			acc[18] += w * b * b;
+			acc[19] += w * b * c;
+			acc[20] += w * c * c;
+			acc[21] += w * dd * ntx;
+			acc[22] += w * dd * nty;
+			acc[23] += w * dd * ntz;
+			acc[24] += w * dd * a;
+			acc[25] += w * dd * b;
+			acc[26] += w * dd * c;
+		}
+		else if (metric == 1) // pt2li_lls_pri_direction_summation, cregistration.hpp:2160-2275
+		{
+			float vx = N.x, vy = N.y, vz = N.z;
+			float dx = px - qx, dy = py - qy, dz = pz - qz;
+			double A[3][6], bv[3];
+			A[0][0] = 0;
+			A[0][1] = -vz;
+			A[0][2] = vy;
+			A[0][3] = vy * py + vz * pz;
+			A[0][4] = -vy * px;
+			A[0][5] = -vz * px;
+			A[1][0] = vz;
+			A[1][1] = 0;
+			A[1][2] = -vx;
+			A[1][3] = -vx * py;
+			A[1][4] = vz * pz + vx * px;
+			A[1][5] = -vz * py;
+			A[2][0] = -vy;
+			A[2][1] = vx;
+			A[2][2] = 0;
+			A[2][3] = -vx * pz;
+			A[2][4] = -vy * pz;
+			A[2][5] = vx * px + vy * py;
+			bv[0] = -vy * dz + vz * dy;
+			bv[1] = -vz * dx + vx * dz;
+			bv[2] = -vx * dy + vy * dx;
+			float ex = (float)fabs(bv[0]), ey = (float)fabs(bv[1]), ez = (float)fabs(bv[2]);
+			float ed = sqrtf(ex * ex + ey * ey + ez * ez);
+			float wx = class_w;
+			if (dist_w)
+				wx *= w_dist_adaptive(dist, iter_num);
+			if (inten_w)
+				wx *= w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			if (resid_w)
+				wx = wx * w_residual(ed, window);
+			wd[g] = wx;
+			const double sw = (double)sqrtf(wx);
+			for (int r = 0; r < 3; r++)
+			{
+				for (int c = 0; c < 6; c++)
+					A[r][c] = sw * A[r][c];
+				bv[r] = sw * bv[r];
+			}
+			int k = 0;
+#pragma unroll
+			for (int j = 0; j < 6; j++)
+#pragma unroll
+				for (int c = j; c < 6; c++)
+					acc[k++] += (A[0][j] * A[0][c] + A[1][j] * A[1][c]) + A[2][j] * A[2][c];
+#pragma unroll
+			for (int j = 0; j < 6; j++)
+				acc[21 + j] += (A[0][j] * bv[0] + A[1][j] * bv[1]) + A[2][j] * bv[2];
+		}
+		else // pt2pt_lls_summation, cregistration.hpp:1976-2063 (never writes the correspondence weight)
+		{
+			float dx = px - qx, dy = py - qy, dz = pz - qz;
+			float wx = class_w, wy, wz;
+			if (dist_w)
+				wx = wx * w_dist_adaptive(dist, iter_num);
+			if (resid_w)
+				wx = wx * w_residual(sqrtf(dx * dx + dy * dy + dz * dz), window);
+			if (inten_w)
+				wx = wx * w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			wy = wx;
+			wz = wx;
+			if (!rp.faithful)
+				wd[g] = wx; // intended behaviour: weight the vertex residual by its weight, not by d^2
+			acc[0] += wx;
+			acc[4] += wx * pz;
+			acc[5] += (-wx * py);
+			acc[6] += wy;
+			acc[8] += (-wy * pz);
+			acc[10] += wy * px;
+			acc[11] += wz;
+			acc[12] += wz * py;
+			acc[13] += (-wz * px);
+			acc[15] += wy * pz * pz + wz * py * py;
+			acc[16] += (-wz * px * py);
+			acc[17] += (-wy * px * pz);
+			acc[18] += wx * pz * pz + wz * px * px;
+			acc[19] += (-wx * py * pz);
+			acc[20] += wx * py * py + wy * px * px;
+			acc[21] += (-wx * dx);
+			acc[22] += (-wy * dy);
+			acc[23] += (-wz * dz);
+			acc[24] += wy * pz * dy - wz * py * dz;
+			acc[25] += wz * px * dz - wx * pz * dx;
+			acc[26] += wx * py * dx - wy * px * dy;
+		}
+	}
+
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int k = 0; k < MULLS_NTERM; k++)
+	{
+		double v = acc[k];
+		for (int off = 32; off > 0; off >>= 1)
+			v += __shfl_down(v, off);
+		if (lane == 0)
+			red[wave][k] = v;
+	}
+	__syncthreads();
+	if (threadIdx.x < MULLS_NTERM)
+		partial[(size_t)blockIdx.x * MULLS_NTERM + threadIdx.x] =
+			((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup per pair: sum the per-job partials of every class in job order, then roll the per-class counters
+// over to the next iteration.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
+														 const double *__restrict__ partial, PairOut *__restrict__ out)
+{
+	const uint32_t pair = blockIdx.x;
+	const PairState &ps = states[pair];
+	if (!ps.active && !ps.want_residual)
+		return;
+	CloudDesc *pd = descs + pair * MULLS_NC;
+	if (threadIdx.x < MULLS_NC * MULLS_NTERM)
+	{
+		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
+		double sum = 0.0;
+		if (rp.used[c])
+			for (uint32_t j = pd[c].job_begin; j < pd[c].job_end; j++)
+				sum += partial[(size_t)j * MULLS_NTERM + t];
+		out[pair].sums[c][t] = sum;
+	}
+	__syncthreads();
+	if (threadIdx.x < MULLS_NC)
+	{
+		const int c = threadIdx.x;
+		CloudDesc &d = pd[c];
+		if (ps.active)
+		{
+			if (class_called(rp, d, c))
+			{
+				d.n_valid = d.valid_next;
+				d.alive_cur = d.alive_next;
+			}
+			d.alive_next = 0;
+			d.valid_next = 0;
+			d.n_matched = 0;
+		}
+		out[pair].n_valid[c] = d.n_valid;
+		out[pair].n_alive[c] = d.alive_cur;
+		out[pair].src_n[c] = d.src_n;
+		out[pair].tgt_n[c] = d.tgt_n;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stage-level helpers for the parity tests (mulls_stage_* in include/mulls_hip.h)
+__global__ void k_transform_aos(float4 *__restrict__ recs, uint32_t n, const double *__restrict__ T /* 12 row-major */)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	float4 a = recs[(size_t)i * 3], b = recs[(size_t)i * 3 + 1];
+	double x = a.x, y = a.y, z = a.z, nx = b.x, ny = b.y, nz = b.z;
+	a.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+	a.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+	a.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+	b.x = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+	b.y = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+	b.z = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+	recs[(size_t)i * 3] = a;
+	recs[(size_t)i * 3 + 1] = b;
+}
+
+// force a given correspondence list into the flag/match/wd arrays (mulls_stage_accumulate)
+__global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, const int32_t *__restrict__ ct, const float *__restrict__ cd,
+						   uint32_t n, uint8_t *__restrict__ flag, int32_t *__restrict__ match, float *__restrict__ wd)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t g = src_off + (uint32_t)cs[i];
+	flag[g] = MULLS_F_ALIVE | MULLS_F_VALID;
+	match[g] = ct[i];
+	wd[g] = cd ? cd[i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
+#include "launch.h"
+
+void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
+					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_clone_src, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, setup, stage, tmp_pos, tmp_nrm, bbox);
+}
+void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
+				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
+				 int32_t *match, float *wd, int crop)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm,
+						   tpos, tnrm, flag, match, wd, crop);
+}
+void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
+			   float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_nn, dim3(njobs), dim3(MULLS_NN_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, tpos, flag, nn_idx, nn_d2, winner);
+}
+void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
+				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,
+				   const unsigned long long *winner)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_filter, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, snrm, tnrm, flag, nn_idx, nn_d2, match, wd,
+						   winner);
+}
+void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
+				  const float4 *spos, const float4 *tpos, const float4 *tnrm, const uint8_t *flag, const int32_t *match, float *wd,
+				  double *partial)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial);
+}
+void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
+				   PairOut *out)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out);
+}
+void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12)
+{
+	if (n)
+		hipLaunchKernelGGL(k_transform_aos, dim3((n + 255) / 256), dim3(256), 0, st, recs, n, T12);
+}
+void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
+					 int32_t *match, float *wd)
+{
+	if (n)
+		hipLaunchKernelGGL(k_set_corr, dim3((n + 255) / 256), dim3(256), 0, st, src_off, cs, ct, cd, n, flag, match, wd);
+}

@@ -1,0 +1,171 @@
+"""Python host-side binding of libmulls_hip.so (the C ABI in include/mulls_hip.h).
+
+This is plumbing for the tests, bench.py and smoke(): it loads the in-tree shared library with ctypes and forwards
+calls.  There is deliberately NO fallback: if the HIP library is missing or no gfx950 device is usable, every call
+raises.  The product for C++ callers is the library itself plus include/cregistration_hip.hpp.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmulls_hip.so")
+_LIB = None
+
+
+class MullsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmulls_hip.so (raises if it has not been built: run `python -m mulls_amd.build`)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MullsError("libmulls_hip.so is not built (python -m mulls_amd.build); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mulls_default_params.argtypes = [C.POINTER(abi.Params)]
+    lib.mulls_default_params.restype = None
+    lib.mulls_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.mulls_destroy.argtypes = [vp]
+    lib.mulls_destroy.restype = None
+    lib.mulls_last_error.argtypes = [vp]
+    lib.mulls_last_error.restype = C.c_char_p
+    lib.mulls_set_profiling.argtypes = [vp, C.c_int]
+    lib.mulls_get_profile.argtypes = [vp, C.POINTER(abi.Profile)]
+    lib.mulls_stream.argtypes = [vp]
+    lib.mulls_stream.restype = vp
+    lib.mulls_icp.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_icp_batch.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_batch_create.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(vp)]
+    lib.mulls_batch_run.argtypes = [vp, vp, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_batch_destroy.argtypes = [vp, vp]
+    lib.mulls_batch_destroy.restype = None
+    lib.mulls_stage_transform.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
+    lib.mulls_stage_correspond.argtypes = [vp, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), C.c_float, C.c_int, C.c_float, vp, vp, vp]
+    lib.mulls_stage_accumulate.argtypes = [vp, C.c_int, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), vp, vp, vp, C.c_uint32, C.c_int,
+                                           C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    _LIB = lib
+    return lib
+
+
+EXPORTS = [
+    "mulls_default_params", "mulls_create", "mulls_destroy", "mulls_last_error", "mulls_set_profiling", "mulls_get_profile",
+    "mulls_stream", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
+    "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate",
+]
+
+
+class Context:
+    """mulls_ctx: one HIP stream on one device."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.mulls_create(device, C.byref(self.h))
+        if rc != 0:
+            raise MullsError("mulls_create(device=%d) failed with %d (no usable gfx950 device?)" % (device, rc))
+
+    def close(self):
+        if self.h:
+            self.lib.mulls_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MullsError("%s failed with %d: %s" % (what, rc, self.lib.mulls_last_error(self.h).decode()))
+
+    def set_profiling(self, on):
+        self._check(self.lib.mulls_set_profiling(self.h, int(on)), "mulls_set_profiling")
+
+    def profile(self):
+        p = abi.Profile()
+        self._check(self.lib.mulls_get_profile(self.h, C.byref(p)), "mulls_get_profile")
+        return p
+
+    def stream(self):
+        return self.lib.mulls_stream(self.h)
+
+    # --- mm_lls_icp replacements -------------------------------------------------------------------------------
+    def icp(self, pair, params, trace_cap=0):
+        res = abi.make_result_array(1, trace_cap)
+        p = pair.as_pair()
+        self._check(self.lib.mulls_icp(self.h, C.byref(p), C.byref(params), res), "mulls_icp")
+        return res
+
+    def icp_batch(self, pairs, params, trace_cap=0):
+        arr = abi.make_pair_array(pairs)
+        res = abi.make_result_array(len(pairs), trace_cap)
+        self._check(self.lib.mulls_icp_batch(self.h, arr, len(pairs), C.byref(params), res), "mulls_icp_batch")
+        return res
+
+    def batch(self, pairs):
+        return Batch(self, pairs)
+
+    # --- stage-level entry points --------------------------------------------------------------------------------
+    def transform(self, pts, T):
+        pts = np.ascontiguousarray(pts).copy()
+        Tc = (C.c_double * 16)(*np.asarray(T, dtype=np.float64).T.reshape(-1))
+        self._check(self.lib.mulls_stage_transform(self.h, pts.ctypes.data, len(pts), abi.POINT_BYTES, Tc), "mulls_stage_transform")
+        return pts
+
+    def correspond(self, src, tgt, dis_thre, normal_check=True, angle_deg=45.0):
+        n = len(src)
+        match = np.zeros(n, np.int32)
+        d2 = np.zeros(n, np.float32)
+        flags = np.zeros(n, np.uint8)
+        cs, ct = abi.as_cloud(src), abi.as_cloud(tgt)
+        self._check(self.lib.mulls_stage_correspond(self.h, C.byref(cs), C.byref(ct), dis_thre, int(normal_check), angle_deg,
+                                                    match.ctypes.data, d2.ctypes.data, flags.ctypes.data), "mulls_stage_correspond")
+        return match, d2, flags
+
+    def accumulate(self, metric, src, tgt, corr_src, corr_tgt, corr_d2, iter_num, class_weight, dist_w, resid_w, inten_w, window):
+        corr_src = np.ascontiguousarray(corr_src, np.int32)
+        corr_tgt = np.ascontiguousarray(corr_tgt, np.int32)
+        corr_d2 = np.ascontiguousarray(corr_d2, np.float32)
+        out = np.zeros(27, np.float64)
+        w = np.zeros(len(corr_src), np.float32)
+        cs, ct = abi.as_cloud(src), abi.as_cloud(tgt)
+        self._check(self.lib.mulls_stage_accumulate(self.h, int(metric), C.byref(cs), C.byref(ct), corr_src.ctypes.data, corr_tgt.ctypes.data,
+                                                    corr_d2.ctypes.data, len(corr_src), int(iter_num), class_weight, int(dist_w), int(resid_w),
+                                                    int(inten_w), window, out.ctypes.data, w.ctypes.data), "mulls_stage_accumulate")
+        return out, w
+
+
+class Batch:
+    """mulls_batch: pairs staged in HBM once, registered any number of times."""
+
+    def __init__(self, ctx, pairs):
+        self.ctx = ctx
+        self.n = len(pairs)
+        self._pairs = pairs  # keep numpy storage alive during create
+        arr = abi.make_pair_array(pairs)
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.mulls_batch_create(ctx.h, arr, self.n, C.byref(self.h)), "mulls_batch_create")
+
+    def run(self, params, trace_cap=0, results=None):
+        res = results if results is not None else abi.make_result_array(self.n, trace_cap)
+        self.ctx._check(self.ctx.lib.mulls_batch_run(self.ctx.h, self.h, C.byref(params), res), "mulls_batch_run")
+        return res
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.mulls_batch_destroy(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,1494 @@
+// mulls_oracle.cpp — CPU ORACLE for the MULLS-ICP hot path.  TEST INFRASTRUCTURE ONLY.
+//
+//   * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and bench.py's
+//     cpu_baseline leg may load liboracle.  Nothing under mulls_amd/ links, imports or calls it.
+//   * It is a dependency-free restatement (no PCL / Eigen / FLANN / glog — none exist in this image) of
+//       /root/reference/include/common/cregistration.hpp:1114-1440  (mm_lls_icp driver)
+//       :1685-1696 (batch_transform_feature_points)   :1701-1835 (determine_corres)
+//       :1855-1866 (update_corr_dist_thre)            :1869-1967 (multi_metrics_lls_tran_estimation)
+//       :1976-2275 (pt2pt / pt2pl / pt2li summations) :2518-2722 (residual pass, weight functions)
+//       :2740-2764 (construct_trans_a)                :2795-2836 (get_quat_euler_jacobi)
+//       :2894-2922 (intersection_filter)  + utility.hpp:817-886, cfilter.hpp:950-981, :2613-2655
+//     and of the third-party behaviour the path relies on (not under /root/reference; unvendored, no lockfile):
+//       PCL 1.7-1.10 (apt libpcl-dev, Dockerfile:1-8): CorrespondenceEstimation::determineCorrespondences,
+//       CorrespondenceRejectorDistance, transformPointCloudWithNormals<PointT,double>, pcl::Correspondence's
+//       distance/weight union; FLANN 1.8/1.9 KDTreeSingleIndex + L2_Simple<float>; Eigen 3.3.7 PartialPivLU
+//       inverse, AngleAxisd(Matrix3d).
+//   * PARITY UNPINNED by the restatement alone: the reference ships no tests, golden vectors or recorded
+//     outputs for this path.  The restatement is pinned instead against oracle/_ref — the
+//     reference's own function bodies compiled against a minimal PCL/Eigen stand-in (oracle/ref_shim/, see
+//     oracle/Makefile) — wherever that library is built; see DESIGN.md §Oracle for exactly what that does and
+//     does not pin.
+//
+// Build: see oracle/Makefile (g++ -O3 -ffp-contract=off -fopenmp).  FMA contraction must stay off: the reference
+// is built -O3 without -march (CMakeLists.txt:43), i.e. plain SSE2 mul/add.
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/mulls_hip.h"
+
+namespace
+{
+
+struct Pt // pcl::PointXYZINormal, 48 B
+{
+	float x, y, z, d3;
+	float nx, ny, nz, n3;
+	float intensity, curvature, p2, p3;
+};
+static_assert(sizeof(Pt) == 48, "PointXYZINormal layout");
+typedef std::vector<Pt> Cloud;
+
+struct Corr // pcl::Correspondence: {int index_query; int index_match; union{float distance; float weight;};}
+{
+	int q, m;
+	float dw;
+};
+typedef std::vector<Corr> Corrs;
+
+// ---------------------------------------------------------------------------------------------------------
+// small fixed-size linear algebra (column-major like Eigen)
+struct M4
+{
+	double a[16];
+	double &operator()(int r, int c) { return a[r + 4 * c]; }
+	double operator()(int r, int c) const { return a[r + 4 * c]; }
+};
+struct M6
+{
+	double a[36];
+	double &operator()(int r, int c) { return a[r + 6 * c]; }
+	double operator()(int r, int c) const { return a[r + 6 * c]; }
+};
+
+M4 m4_identity()
+{
+	M4 m;
+	for (int i = 0; i < 16; i++)
+		m.a[i] = (i % 5 == 0) ? 1.0 : 0.0;
+	return m;
+}
+M4 m4_mul(const M4 &A, const M4 &B)
+{
+	M4 C;
+	for (int r = 0; r < 4; r++)
+		for (int c = 0; c < 4; c++)
+		{
+			double s = 0;
+			for (int k = 0; k < 4; k++)
+				s += A(r, k) * B(k, c);
+			C(r, c) = s;
+		}
+	return C;
+}
+// general inverse of a 4x4 (only needed for the undistortion branch; Eigen uses a cofactor formula there,
+// an LU-based inverse agrees to rounding)
+bool lu_inverse(const double *A, double *Ainv, int n);
+M4 m4_inverse(const M4 &A)
+{
+	M4 R;
+	lu_inverse(A.a, R.a, 4);
+	return R;
+}
+
+// Eigen 3.3 PartialPivLU-style inverse: P A = L U, then solve against the identity.
+bool lu_inverse(const double *A, double *Ainv, int n)
+{
+	double lu[36];
+	int perm[6];
+	for (int i = 0; i < n * n; i++)
+		lu[i] = A[i];
+	for (int i = 0; i < n; i++)
+		perm[i] = i;
+	bool ok = true;
+	for (int k = 0; k < n; k++)
+	{
+		int piv = k;
+		double best = std::fabs(lu[k + n * k]);
+		for (int r = k + 1; r < n; r++)
+		{
+			double v = std::fabs(lu[r + n * k]);
+			if (v > best)
+			{
+				best = v;
+				piv = r;
+			}
+		}
+		if (best == 0.0)
+			ok = false; // Eigen does not stop either; inf/NaN propagate (SURVEY B-11)
+		if (piv != k)
+		{
+			for (int c = 0; c < n; c++)
+				std::swap(lu[k + n * c], lu[piv + n * c]);
+			std::swap(perm[k], perm[piv]);
+		}
+		double d = lu[k + n * k];
+		for (int r = k + 1; r < n; r++)
+			lu[r + n * k] /= d;
+		for (int c = k + 1; c < n; c++)
+		{
+			double u = lu[k + n * c];
+			for (int r = k + 1; r < n; r++)
+				lu[r + n * c] -= lu[r + n * k] * u;
+		}
+	}
+	for (int c = 0; c < n; c++)
+	{
+		double y[6];
+		for (int r = 0; r < n; r++)
+			y[r] = (perm[r] == c) ? 1.0 : 0.0;
+		for (int r = 0; r < n; r++) // L y' = y (unit lower)
+			for (int k = 0; k < r; k++)
+				y[r] -= lu[r + n * k] * y[k];
+		for (int r = n - 1; r >= 0; r--) // U x = y'
+		{
+			for (int k = r + 1; k < n; k++)
+				y[r] -= lu[r + n * k] * y[k];
+			y[r] /= lu[r + n * r];
+		}
+		for (int r = 0; r < n; r++)
+			Ainv[r + n * c] = y[r];
+	}
+	return ok;
+}
+
+// Eigen::AngleAxisd(Matrix3d).angle(): rotation matrix -> quaternion (Shepperd branches) -> 2*atan2(|v|,|w|)
+double angle_of_rotation(const M4 &T)
+{
+	double m[3][3];
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			m[r][c] = T(r, c);
+	double q[4]; // x y z w
+	double t = m[0][0] + m[1][1] + m[2][2];
+	if (t > 0.0)
+	{
+		t = std::sqrt(t + 1.0);
+		q[3] = 0.5 * t;
+		t = 0.5 / t;
+		q[0] = (m[2][1] - m[1][2]) * t;
+		q[1] = (m[0][2] - m[2][0]) * t;
+		q[2] = (m[1][0] - m[0][1]) * t;
+	}
+	else
+	{
+		int i = 0;
+		if (m[1][1] > m[0][0])
+			i = 1;
+		if (m[2][2] > m[i][i])
+			i = 2;
+		int j = (i + 1) % 3, k = (j + 1) % 3;
+		t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+		q[i] = 0.5 * t;
+		t = 0.5 / t;
+		q[3] = (m[k][j] - m[j][k]) * t;
+		q[j] = (m[j][i] + m[i][j]) * t;
+		q[k] = (m[k][i] + m[i][k]) * t;
+	}
+	double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+	if (n != 0.0)
+		return 2.0 * std::atan2(n, std::fabs(q[3]));
+	return 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pcl::transformPointCloudWithNormals<PointT,double>(cloud, cloud, T)  (cregistration.hpp:1690-1695)
+void transform_cloud(Cloud &c, const M4 &T)
+{
+	for (size_t i = 0; i < c.size(); i++)
+	{
+		Pt &p = c[i];
+		double x = p.x, y = p.y, z = p.z;
+		p.x = static_cast<float>(T(0, 0) * x + T(0, 1) * y + T(0, 2) * z + T(0, 3));
+		p.y = static_cast<float>(T(1, 0) * x + T(1, 1) * y + T(1, 2) * z + T(1, 3));
+		p.z = static_cast<float>(T(2, 0) * x + T(2, 1) * y + T(2, 2) * z + T(2, 3));
+		double nx = p.nx, ny = p.ny, nz = p.nz;
+		p.nx = static_cast<float>(T(0, 0) * nx + T(0, 1) * ny + T(0, 2) * nz);
+		p.ny = static_cast<float>(T(1, 0) * nx + T(1, 1) * ny + T(1, 2) * nz);
+		p.nz = static_cast<float>(T(2, 0) * nx + T(2, 1) * ny + T(2, 2) * nz);
+	}
+}
+
+// FLANN L2_Simple<float>: result += diff*diff over x,y,z in that order, float accumulation
+inline float l2_simple(const Pt &a, const Pt &b)
+{
+	float result = 0.0f, diff;
+	diff = a.x - b.x;
+	result += diff * diff;
+	diff = a.y - b.y;
+	result += diff * diff;
+	diff = a.z - b.z;
+	result += diff * diff;
+	return result;
+}
+
+// Exact 1-NN index standing in for pcl::search::KdTree -> FLANN KDTreeSingleIndex (max leaf 15).  Ties on the
+// float distance resolve to the lowest target index (FLANN's tie order is implementation-defined, SURVEY B-16).
+class KdTree
+{
+  public:
+	void build(const Cloud &c)
+	{
+		cloud_ = &c;
+		idx_.resize(c.size());
+		for (size_t i = 0; i < c.size(); i++)
+			idx_[i] = (int)i;
+		nodes_.clear();
+		nodes_.reserve(c.size() / 4 + 8);
+		if (!c.empty())
+			build_rec(0, (int)c.size());
+	}
+	bool empty() const { return nodes_.empty(); }
+	// returns index or -1; d2 = squared distance (float)
+	int nearest(const Pt &q, float &d2) const
+	{
+		int best = -1;
+		float bd = FLT_MAX;
+		if (!nodes_.empty())
+			search(0, q, best, bd);
+		d2 = bd;
+		return best;
+	}
+	// k nearest (ascending), for the normal-shooting variant
+	void knearest(const Pt &q, int k, std::vector<std::pair<float, int>> &out) const
+	{
+		out.clear();
+		if (nodes_.empty())
+			return;
+		ksearch(0, q, k, out);
+	}
+
+  private:
+	struct Node
+	{
+		int lo, hi;		  // leaf: range in idx_
+		int left, right;  // children or -1
+		int dim;
+		float split_lo, split_hi; // max of left side / min of right side along dim
+	};
+	static float coord(const Pt &p, int d) { return d == 0 ? p.x : (d == 1 ? p.y : p.z); }
+
+	int build_rec(int lo, int hi)
+	{
+		Node n;
+		n.lo = lo;
+		n.hi = hi;
+		n.left = n.right = -1;
+		n.dim = 0;
+		n.split_lo = n.split_hi = 0;
+		int id = (int)nodes_.size();
+		nodes_.push_back(n);
+		if (hi - lo <= 15)
+			return id;
+		float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+		for (int i = lo; i < hi; i++)
+			for (int d = 0; d < 3; d++)
+			{
+				float v = coord((*cloud_)[idx_[i]], d);
+				mn[d] = std::min(mn[d], v);
+				mx[d] = std::max(mx[d], v);
+			}
+		int dim = 0;
+		if (mx[1] - mn[1] > mx[dim] - mn[dim])
+			dim = 1;
+		if (mx[2] - mn[2] > mx[dim] - mn[dim])
+			dim = 2;
+		int mid = (lo + hi) / 2;
+		std::nth_element(idx_.begin() + lo, idx_.begin() + mid, idx_.begin() + hi, [&](int a, int b) {
+			float va = coord((*cloud_)[a], dim), vb = coord((*cloud_)[b], dim);
+			return va < vb || (va == vb && a < b);
+		});
+		float slo = -FLT_MAX, shi = FLT_MAX;
+		for (int i = lo; i < mid; i++)
+			slo = std::max(slo, coord((*cloud_)[idx_[i]], dim));
+		for (int i = mid; i < hi; i++)
+			shi = std::min(shi, coord((*cloud_)[idx_[i]], dim));
+		int l = build_rec(lo, mid);
+		int r = build_rec(mid, hi);
+		nodes_[id].left = l;
+		nodes_[id].right = r;
+		nodes_[id].dim = dim;
+		nodes_[id].split_lo = slo;
+		nodes_[id].split_hi = shi;
+		return id;
+	}
+	void search(int id, const Pt &q, int &best, float &bd) const
+	{
+		const Node &n = nodes_[id];
+		if (n.left < 0)
+		{
+			for (int i = n.lo; i < n.hi; i++)
+			{
+				int t = idx_[i];
+				float d = l2_simple(q, (*cloud_)[t]);
+				if (d < bd || (d == bd && t < best))
+				{
+					bd = d;
+					best = t;
+				}
+			}
+			return;
+		}
+		float v = coord(q, n.dim);
+		// conservative lower bounds of the distance to either side (float; a bound <= the true distance)
+		float dl = v > n.split_lo ? v - n.split_lo : 0.0f;
+		float dr = v < n.split_hi ? n.split_hi - v : 0.0f;
+		// shrink by one ulp-ish factor so rounding in d*d can never prune a true (or tied) neighbour
+		float bl = dl * dl * 0.999999f, br = dr * dr * 0.999999f;
+		if (dl <= dr)
+		{
+			if (bl <= bd)
+				search(n.left, q, best, bd);
+			if (br <= bd)
+				search(n.right, q, best, bd);
+		}
+		else
+		{
+			if (br <= bd)
+				search(n.right, q, best, bd);
+			if (bl <= bd)
+				search(n.left, q, best, bd);
+		}
+	}
+	void ksearch(int id, const Pt &q, int k, std::vector<std::pair<float, int>> &out) const
+	{
+		const Node &n = nodes_[id];
+		if (n.left < 0)
+		{
+			for (int i = n.lo; i < n.hi; i++)
+			{
+				int t = idx_[i];
+				std::pair<float, int> e(l2_simple(q, (*cloud_)[t]), t);
+				if ((int)out.size() < k || e < out.back())
+				{
+					out.insert(std::upper_bound(out.begin(), out.end(), e), e);
+					if ((int)out.size() > k)
+						out.pop_back();
+				}
+			}
+			return;
+		}
+		float v = coord(q, n.dim);
+		float dl = v > n.split_lo ? v - n.split_lo : 0.0f;
+		float dr = v < n.split_hi ? n.split_hi - v : 0.0f;
+		float bl = dl * dl * 0.999999f, br = dr * dr * 0.999999f;
+		int first = dl <= dr ? n.left : n.right, second = dl <= dr ? n.right : n.left;
+		float bf = dl <= dr ? bl : br, bs = dl <= dr ? br : bl;
+		if ((int)out.size() < k || bf <= out.back().first)
+			ksearch(first, q, k, out);
+		if ((int)out.size() < k || bs <= out.back().first)
+			ksearch(second, q, k, out);
+	}
+	const Cloud *cloud_ = nullptr;
+	std::vector<int> idx_;
+	std::vector<Node> nodes_;
+};
+
+int brute_nearest(const Cloud &tgt, const Pt &q, float &d2)
+{
+	int best = -1;
+	float bd = FLT_MAX;
+	for (size_t t = 0; t < tgt.size(); t++)
+	{
+		float d = l2_simple(q, tgt[t]);
+		if (d < bd)
+		{
+			bd = d;
+			best = (int)t;
+		}
+	}
+	d2 = bd;
+	return best;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// determine_corres (cregistration.hpp:1701-1835).  `src` is mutated exactly like the reference
+// (permanent compaction when |src| >= 500); `orig` carries the original index of every surviving source point
+// so tests can compare against an implementation that keeps flags instead of compacting.
+bool determine_corres(Cloud &src, std::vector<int> &orig, const Cloud &tgt, const KdTree *tree, float dis_thre, Corrs &corr_f,
+					  bool normal_shooting_on, bool normal_check, float angle_thre_degree, bool brute,
+					  bool duplicate_check = true, int K_filter_distant_point = 500)
+{
+	const int K_min = 3;
+	const float filter_dis_times = 2.5f;
+	const int normal_shooting_candidate_count = 10;
+
+	if (!((int)src.size() >= K_min && (int)tgt.size() >= K_min))
+		return 0; // corr_f untouched: the previous iteration's content survives
+
+	Corrs corr;
+	const double max_distance = filter_dis_times * dis_thre; // float product widened to the double parameter
+	if (normal_shooting_on)
+	{
+		// pcl::registration::CorrespondenceEstimationNormalShooting::determineCorrespondences (PCL 1.8-1.10):
+		// among the k nearest, minimise |n_s x (p_t - p_s)|^2 (double); reject if that minimum > max_distance
+		// (compared to r, not r^2 — PCL quirk); stored distance = that candidate's squared Euclidean distance.
+		std::vector<std::pair<float, int>> knn;
+		for (size_t s = 0; s < src.size(); s++)
+		{
+			tree->knearest(src[s], normal_shooting_candidate_count, knn);
+			double min_dist = std::numeric_limits<double>::max();
+			int min_index = 0;
+			for (size_t j = 0; j < knn.size(); j++)
+			{
+				const Pt &t = tgt[knn[j].second];
+				// PCL computes pt = src - tgt in float fields, then the cross product in double
+				float ptx = src[s].x - t.x, pty = src[s].y - t.y, ptz = src[s].z - t.z;
+				double Vx = ptx, Vy = pty, Vz = ptz;
+				double Nx = src[s].nx, Ny = src[s].ny, Nz = src[s].nz;
+				double cx = Ny * Vz - Nz * Vy, cy = Nz * Vx - Nx * Vz, cz = Nx * Vy - Ny * Vx;
+				double dist = cx * cx + cy * cy + cz * cz;
+				if (dist < min_dist)
+				{
+					min_dist = dist;
+					min_index = (int)j;
+				}
+			}
+			if (knn.empty() || min_dist > max_distance)
+				continue;
+			Corr c = {(int)s, knn[min_index].second, knn[min_index].first};
+			corr.push_back(c);
+		}
+	}
+	else
+	{
+		// pcl::registration::CorrespondenceEstimation::determineCorrespondences(corrs, double max_distance)
+		const double max_dist_sqr = max_distance * max_distance;
+		for (size_t s = 0; s < src.size(); s++)
+		{
+			float d2;
+			int t = brute ? brute_nearest(tgt, src[s], d2) : tree->nearest(src[s], d2);
+			if (t < 0 || (double)d2 > max_dist_sqr)
+				continue;
+			Corr c = {(int)s, t, d2};
+			corr.push_back(c);
+		}
+	}
+
+	bool compacted = false;
+	if ((int)src.size() >= K_filter_distant_point) // :1755
+	{
+		int count = 0;
+		std::vector<unsigned int> table(tgt.size(), 0);
+		Cloud src_f;
+		std::vector<int> orig_f;
+		Corrs kept;
+		for (size_t i = 0; i < corr.size(); i++)
+		{
+			int s_index = corr[i].q, t_index = corr[i].m;
+			if (duplicate_check && table[t_index] > 0)
+				continue; // erased
+			table[t_index]++;
+			src_f.push_back(src[s_index]);
+			orig_f.push_back(orig[s_index]);
+			Corr c = corr[i];
+			c.q = count++;
+			kept.push_back(c);
+		}
+		corr.swap(kept);
+		src.swap(src_f);
+		orig.swap(orig_f);
+		compacted = true;
+	}
+
+	// CorrespondenceRejectorDistance: setMaximumDistance(float d) stores d*d as float; getCorrespondences()
+	// returns WITHOUT touching the output when the input is empty.
+	if (!corr.empty())
+	{
+		const float max_sqr = dis_thre * dis_thre;
+		corr_f.clear();
+		for (size_t i = 0; i < corr.size(); i++)
+			if (!(corr[i].dw > max_sqr))
+				corr_f.push_back(corr[i]);
+	}
+	else if (compacted)
+	{
+		// Reference behaviour here is undefined: the source cloud was just replaced by an empty one while the
+		// stale corr_f still indexes the old one (out-of-bounds reads at :1813).  Defined here (and in the HIP
+		// path) as "no correspondences".
+		corr_f.clear();
+	}
+
+	if (normal_check) // :1798-1830
+	{
+		const double cos_thre = std::cos(angle_thre_degree / 180.0 * M_PI);
+		Corrs kept;
+		for (size_t i = 0; i < corr_f.size(); i++)
+		{
+			const Pt &ps = src[corr_f[i].q];
+			const Pt &pt = tgt[corr_f[i].m];
+			double d = (double)ps.nx * (double)pt.nx + (double)ps.ny * (double)pt.ny + (double)ps.nz * (double)pt.nz;
+			float cos_intersection_angle = (float)std::fabs(d);
+			if ((double)cos_intersection_angle < cos_thre)
+				continue;
+			kept.push_back(corr_f[i]);
+		}
+		corr_f.swap(kept);
+	}
+	return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight functions (cregistration.hpp:2686-2722)
+inline float get_weight_by_dist_adaptive(float dist, int iter_num, float unit_dist = 30.0f, float b_min = 0.7f, float b_max = 1.3f,
+										 float b_step = 0.05f)
+{
+	float t = b_min + b_step * iter_num;
+	float b_current = (t < b_max) ? t : b_max;
+	float temp_weight = (float)(b_current + (1.0 - b_current) * dist / unit_dist);
+	temp_weight = (float)((temp_weight > 0.01) ? (double)temp_weight : 0.01);
+	return temp_weight;
+}
+inline float get_weight_by_intensity(float intensity_1, float intensity_2, float intensity_scale = 255.0f)
+{
+	float intensity_diff_ratio = std::fabs(intensity_1 - intensity_2) / intensity_scale;
+	float intensity_weight = (float)std::exp(-1.0 * intensity_diff_ratio);
+	return intensity_weight;
+}
+inline float get_weight_by_residual(float res, float huber_thre, int delta = 1)
+{
+	return (float)((res > huber_thre) ? (double)((2 * res * huber_thre + (delta * delta - 2 * delta) * (huber_thre * huber_thre)) / res / res)
+									  : (1.0));
+}
+
+struct Normal
+{
+	double lower[36]; // slots written with coeffRef(k) by pt2pl / pt2pt (k = row + 6*col, rows >= cols) AND the diagonal
+					  // slots of pt2li (ATPA(j,j) is the same memory), so the += order on the diagonal equals the reference's
+	double upper[36]; // strictly-upper slots written with ATPA(j,k), k>j by pt2li
+	double b[6];
+	void zero()
+	{
+		std::memset(lower, 0, sizeof(lower));
+		std::memset(upper, 0, sizeof(upper));
+		std::memset(b, 0, sizeof(b));
+	}
+};
+
+// pt2pl_lls_summation (cregistration.hpp:2066-2156)
+void pt2pl_sum(const Cloud &S, const Cloud &T, Corrs &corr, Normal &N, int iter_num, float weight, bool dist_w, bool resid_w, bool inten_w,
+			   float window)
+{
+	double *A = N.lower;
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float ntx = t.nx, nty = t.ny, ntz = t.nz;
+		float pi = s.intensity, qi = t.intensity;
+		float w = weight;
+		float a = ntz * py - nty * pz;
+		float b = ntx * pz - ntz * px;
+		float c = nty * px - ntx * py;
+		float d = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+		float dist = std::sqrt(qx * qx + qy * qy + qz * qz);
+		if (dist_w)
+			w = w * get_weight_by_dist_adaptive(dist, iter_num);
+		if (resid_w)
+			w = w * get_weight_by_residual(std::fabs(d), window);
+		if (inten_w)
+			w = w * get_weight_by_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+		corr[i].dw = w;
+		A[0] += w * ntx * ntx;
+		A[1] += w * ntx * nty;
+		A[2] += w * ntx * ntz;
+		A[3] += w * a * ntx;
+		A[4] += w * b * ntx;
+		A[5] += w * c * ntx;
+		A[7] += w * nty * nty;
+		A[8] += w * nty * ntz;
+		A[9] += w * a * nty;
+		A[10] += w * b * nty;
+		A[11] += w * c * nty;
+		A[14] += w * ntz * ntz;
+		A[15] += w * a * ntz;
+		A[16] += w * b * ntz;
+		A[17] += w * c * ntz;
+		A[21] += w * a * a;
+		A[22] += w * a * b;
+		A[23] += w * a * c;
+		A[28] += w * b * b;
+		A[29] += w * b * c;
+		A[35] += w * c * c;
+		N.b[0] += w * d * ntx;
+		N.b[1] += w * d * nty;
+		N.b[2] += w * d * ntz;
+		N.b[3] += w * d * a;
+		N.b[4] += w * d * b;
+		N.b[5] += w * d * c;
+	}
+}
+
+// pt2li_lls_pri_direction_summation (cregistration.hpp:2160-2275)
+void pt2li_sum(const Cloud &S, const Cloud &T, Corrs &corr, Normal &N, int iter_num, float weight, bool dist_w, bool resid_w, bool inten_w,
+			   float window)
+{
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float vx = t.nx, vy = t.ny, vz = t.nz;
+		float pi = s.intensity, qi = t.intensity;
+		float dx = px - qx, dy = py - qy, dz = pz - qz;
+		double Am[3][6], bv[3];
+		Am[0][0] = 0;
+		Am[0][1] = -vz;
+		Am[0][2] = vy;
+		Am[0][3] = vy * py + vz * pz;
+		Am[0][4] = -vy * px;
+		Am[0][5] = -vz * px;
+		Am[1][0] = vz;
+		Am[1][1] = 0;
+		Am[1][2] = -vx;
+		Am[1][3] = -vx * py;
+		Am[1][4] = vz * pz + vx * px;
+		Am[1][5] = -vz * py;
+		Am[2][0] = -vy;
+		Am[2][1] = vx;
+		Am[2][2] = 0;
+		Am[2][3] = -vx * pz;
+		Am[2][4] = -vy * pz;
+		Am[2][5] = vx * px + vy * py;
+		bv[0] = -vy * dz + vz * dy;
+		bv[1] = -vz * dx + vx * dz;
+		bv[2] = -vx * dy + vy * dx;
+		float ex = (float)std::fabs(bv[0]), ey = (float)std::fabs(bv[1]), ez = (float)std::fabs(bv[2]);
+		float ed = std::sqrt(ex * ex + ey * ey + ez * ez);
+		float wx = weight;
+		float dist = std::sqrt(qx * qx + qy * qy + qz * qz);
+		if (dist_w)
+			wx *= get_weight_by_dist_adaptive(dist, iter_num);
+		if (inten_w)
+			wx *= get_weight_by_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+		if (resid_w)
+			wx = wx * get_weight_by_residual(ed, window);
+		corr[i].dw = wx;
+		double sw = (double)std::sqrt(wx); // std::sqrt(float) -> float, stored in a double Wmat
+		for (int r = 0; r < 3; r++)
+		{
+			for (int c = 0; c < 6; c++)
+				Am[r][c] = sw * Am[r][c];
+			bv[r] = sw * bv[r];
+		}
+		for (int j = 0; j < 6; j++)
+			for (int k = j; k < 6; k++)
+				(j == k ? N.lower : N.upper)[j + 6 * k] += (Am[0][j] * Am[0][k] + Am[1][j] * Am[1][k]) + Am[2][j] * Am[2][k];
+		for (int j = 0; j < 6; j++)
+			N.b[j] += (Am[0][j] * bv[0] + Am[1][j] * bv[1]) + Am[2][j] * bv[2];
+	}
+}
+
+// pt2pt_lls_summation (cregistration.hpp:1976-2063).  Does NOT write corr.weight.
+void pt2pt_sum(const Cloud &S, const Cloud &T, Corrs &corr, Normal &N, int iter_num, float weight, bool dist_w, bool resid_w, bool inten_w,
+			   float window)
+{
+	double *A = N.lower;
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float pi = s.intensity, qi = t.intensity;
+		float dx = px - qx, dy = py - qy, dz = pz - qz;
+		float wx = weight, wy, wz;
+		float dist = std::sqrt(qx * qx + qy * qy + qz * qz);
+		if (dist_w)
+			wx = wx * get_weight_by_dist_adaptive(dist, iter_num);
+		if (resid_w)
+			wx = wx * get_weight_by_residual(std::sqrt(dx * dx + dy * dy + dz * dz), window);
+		if (inten_w)
+			wx = wx * get_weight_by_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+		wy = wx;
+		wz = wx;
+		A[0] += wx;
+		A[4] += wx * pz;
+		A[5] += (-wx * py);
+		A[7] += wy;
+		A[9] += (-wy * pz);
+		A[11] += wy * px;
+		A[14] += wz;
+		A[15] += wz * py;
+		A[16] += (-wz * px);
+		A[21] += wy * pz * pz + wz * py * py;
+		A[22] += (-wz * px * py);
+		A[23] += (-wy * px * pz);
+		A[28] += wx * pz * pz + wz * px * px;
+		A[29] += (-wx * py * pz);
+		A[35] += wx * py * py + wy * px * px;
+		N.b[0] += (-wx * dx);
+		N.b[1] += (-wy * dy);
+		N.b[2] += (-wz * dz);
+		N.b[3] += wy * pz * dy - wz * py * dz;
+		N.b[4] += wz * px * dz - wx * pz * dx;
+		N.b[5] += wx * py * dx - wy * px * dy;
+	}
+}
+
+// assemble the 6x6 the reference actually inverts.  faithful: the mirror (cregistration.hpp:1924-1938) copies the
+// LOWER triangle over the upper one, so pt2li's off-diagonal terms (written to the upper triangle) are discarded.
+void assemble_atpa(const Normal &N, bool faithful, M6 &ATPA)
+{
+	for (int c = 0; c < 6; c++)
+		for (int r = 0; r < 6; r++)
+		{
+			int k = r + 6 * c;
+			if (r == c)
+				ATPA.a[k] = N.lower[k];
+			else if (r > c)
+				ATPA.a[k] = N.lower[k] + (faithful ? 0.0 : N.upper[c + 6 * r]);
+			else
+				ATPA.a[k] = 0; // filled by the mirror below
+		}
+	for (int c = 0; c < 6; c++)
+		for (int r = 0; r < c; r++)
+			ATPA.a[r + 6 * c] = ATPA.a[c + 6 * r];
+}
+
+void construct_trans_a(const double x[6], M4 &T) // cregistration.hpp:2740-2764
+{
+	double tx = x[0], ty = x[1], tz = x[2], alpha = x[3], beta = x[4], gamma = x[5];
+	for (int i = 0; i < 16; i++)
+		T.a[i] = 0;
+	T(0, 0) = std::cos(gamma) * std::cos(beta);
+	T(0, 1) = -std::sin(gamma) * std::cos(alpha) + std::cos(gamma) * std::sin(beta) * std::sin(alpha);
+	T(0, 2) = std::sin(gamma) * std::sin(alpha) + std::cos(gamma) * std::sin(beta) * std::cos(alpha);
+	T(1, 0) = std::sin(gamma) * std::cos(beta);
+	T(1, 1) = std::cos(gamma) * std::cos(alpha) + std::sin(gamma) * std::sin(beta) * std::sin(alpha);
+	T(1, 2) = -std::cos(gamma) * std::sin(alpha) + std::sin(gamma) * std::sin(beta) * std::cos(alpha);
+	T(2, 0) = -std::sin(beta);
+	T(2, 1) = std::cos(beta) * std::sin(alpha);
+	T(2, 2) = std::cos(beta) * std::cos(alpha);
+	T(0, 3) = tx;
+	T(1, 3) = ty;
+	T(2, 3) = tz;
+	T(3, 3) = 1.0;
+}
+
+void get_quat_euler_jacobi(const double e[3], double J[3][3]) // cregistration.hpp:2795-2819 (xyz branch); float locals
+{
+	float sr = (float)std::sin(0.5 * e[0]), sp = (float)std::sin(0.5 * e[1]), sy = (float)std::sin(0.5 * e[2]);
+	float cr = (float)std::cos(0.5 * e[0]), cp = (float)std::cos(0.5 * e[1]), cy = (float)std::cos(0.5 * e[2]);
+	J[0][0] = 0.5 * (cr * cp * cy + sr * sp * sy);
+	J[0][1] = 0.5 * (-sr * sp * cy - cr * cp * sy);
+	J[0][2] = 0.5 * (-sr * cp * sy - cr * sp * cy);
+	J[1][0] = 0.5 * (-sr * sp * cy + cr * cp * sy);
+	J[1][1] = 0.5 * (cr * cp * cy - sr * sp * sy);
+	J[1][2] = 0.5 * (-cr * sp * sy + sr * cp * cy);
+	J[2][0] = 0.5 * (-sr * cp * sy - cr * sp * cy);
+	J[2][1] = 0.5 * (-cr * sp * sy - sr * cp * cy);
+	J[2][2] = 0.5 * (cr * cp * cy + sr * sp * sy);
+}
+
+// the part of multi_metrics_lls_tran_estimation after the summations (cregistration.hpp:1951-1964)
+bool solve_normal(const M6 &ATPA, const double ATPb[6], double x[6], M6 &cof)
+{
+	M6 inv;
+	bool ok = lu_inverse(ATPA.a, inv.a, 6);
+	for (int r = 0; r < 6; r++)
+	{
+		double s = 0;
+		for (int c = 0; c < 6; c++)
+			s += inv(r, c) * ATPb[c];
+		x[r] = s;
+	}
+	double J[3][3];
+	get_quat_euler_jacobi(x + 3, J);
+	cof = inv;
+	double Q33[3][3], Q03[3][3], Q30[3][3], tmp[3][3];
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+		{
+			Q33[r][c] = cof(3 + r, 3 + c);
+			Q03[r][c] = cof(r, 3 + c);
+			Q30[r][c] = cof(3 + r, c);
+		}
+	// Q33 = J * Q33 * J^T
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			tmp[r][c] = J[r][0] * Q33[0][c] + J[r][1] * Q33[1][c] + J[r][2] * Q33[2][c];
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			cof(3 + r, 3 + c) = tmp[r][0] * J[c][0] + tmp[r][1] * J[c][1] + tmp[r][2] * J[c][2];
+	// Q03 = Q03 * J^T
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			cof(r, 3 + c) = Q03[r][0] * J[c][0] + Q03[r][1] * J[c][1] + Q03[r][2] * J[c][2];
+	// Q30 = J * Q30
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			cof(3 + r, c) = J[r][0] * Q30[0][c] + J[r][1] * Q30[1][c] + J[r][2] * Q30[2][c];
+	bool finite = true;
+	for (int i = 0; i < 6; i++)
+		finite = finite && std::isfinite(x[i]);
+	return ok && finite;
+}
+
+// residual pass (cregistration.hpp:2546-2677)
+void pt2pl_residual(const Cloud &S, const Cloud &T, const Corrs &corr, const double x[6], double &VTPV, int &n)
+{
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float ntx = t.nx, nty = t.ny, ntz = t.nz;
+		float a = ntz * py - nty * pz;
+		float b = ntx * pz - ntz * px;
+		float c = nty * px - ntx * py;
+		float d = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+		float residual = (float)(ntx * x[0] + nty * x[1] + ntz * x[2] + a * x[3] + b * x[4] + c * x[5] - d);
+		VTPV += corr[i].dw * residual * residual;
+		n++;
+	}
+}
+void pt2li_residual(const Cloud &S, const Cloud &T, const Corrs &corr, const double x[6], double &VTPV, int &n)
+{
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float vx = t.nx, vy = t.ny, vz = t.nz;
+		float dx = px - qx, dy = py - qy, dz = pz - qz;
+		double A[3][6] = {{0, vz, -vy, -vz * pz - vy * py, vy * px, vz * px},
+						  {-vz, 0, vx, vx * py, -vx * px - vz * pz, vz * py},
+						  {vy, -vx, 0, vx * pz, vy * pz, -vy * py - vx * px}};
+		double b[3] = {-vz * dy + vy * dz, -vx * dz + vz * dx, -vy * dx + vx * dy};
+		double r[3];
+		for (int k = 0; k < 3; k++)
+		{
+			double acc = 0;
+			for (int j = 0; j < 6; j++)
+				acc += A[k][j] * x[j];
+			r[k] = acc - b[k];
+		}
+		VTPV += corr[i].dw * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+		n += 3;
+	}
+}
+void pt2pt_residual(const Cloud &S, const Cloud &T, const Corrs &corr, const double x[6], double &VTPV, int &n, bool faithful)
+{
+	for (size_t i = 0; i < corr.size(); i++)
+	{
+		const Pt &s = S[corr[i].q];
+		const Pt &t = T[corr[i].m];
+		float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z;
+		float dx = px - qx, dy = py - qy, dz = pz - qz;
+		double A[3][6] = {{1, 0, 0, 0, pz, -py}, {0, 1, 0, -pz, 0, px}, {0, 0, 1, py, -px, 0}};
+		double b[3] = {-dx, -dy, -dz};
+		double r[3];
+		for (int k = 0; k < 3; k++)
+		{
+			double acc = 0;
+			for (int j = 0; j < 6; j++)
+				acc += A[k][j] * x[j];
+			r[k] = acc - b[k];
+		}
+		// faithful: weight was never written for vertex correspondences, the union still holds d^2
+		float w = corr[i].dw;
+		(void)faithful; // non-faithful callers store the real weight in dw before the residual pass
+		VTPV += w * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+		n += 3;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------
+void load_cloud(const mulls_cloud &c, Cloud &out)
+{
+	out.resize(c.n);
+	const uint8_t *p = (const uint8_t *)c.pts;
+	for (uint32_t i = 0; i < c.n; i++)
+		std::memcpy(&out[i], p + (size_t)i * c.stride, sizeof(Pt));
+}
+
+// CFilter::bbx_filter (cfilter.hpp:950-981): strict inequalities, float coordinate vs double bound
+void bbx_filter(Cloud &c, const double b[6])
+{
+	Cloud out;
+	for (size_t i = 0; i < c.size(); i++)
+		if (c[i].x > b[0] && c[i].x < b[3] && c[i].y > b[1] && c[i].y < b[4] && c[i].z > b[2] && c[i].z < b[5])
+			out.push_back(c[i]);
+	c.swap(out);
+}
+void cloud_bbx(const Cloud &c, double b[6]) // utility.hpp:817-848
+{
+	b[0] = b[1] = b[2] = DBL_MAX;
+	b[3] = b[4] = b[5] = -DBL_MAX;
+	for (size_t i = 0; i < c.size(); i++)
+	{
+		if (b[0] > c[i].x)
+			b[0] = c[i].x;
+		if (b[1] > c[i].y)
+			b[1] = c[i].y;
+		if (b[2] > c[i].z)
+			b[2] = c[i].z;
+		if (b[3] < c[i].x)
+			b[3] = c[i].x;
+		if (b[4] < c[i].y)
+			b[4] = c[i].y;
+		if (b[5] < c[i].z)
+			b[5] = c[i].z;
+	}
+}
+
+struct Quat
+{
+	double w, x, y, z;
+};
+Quat quat_from_matrix(const M4 &T)
+{
+	double m[3][3];
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			m[r][c] = T(r, c);
+	double q[4];
+	double t = m[0][0] + m[1][1] + m[2][2];
+	if (t > 0.0)
+	{
+		t = std::sqrt(t + 1.0);
+		q[3] = 0.5 * t;
+		t = 0.5 / t;
+		q[0] = (m[2][1] - m[1][2]) * t;
+		q[1] = (m[0][2] - m[2][0]) * t;
+		q[2] = (m[1][0] - m[0][1]) * t;
+	}
+	else
+	{
+		int i = 0;
+		if (m[1][1] > m[0][0])
+			i = 1;
+		if (m[2][2] > m[i][i])
+			i = 2;
+		int j = (i + 1) % 3, k = (j + 1) % 3;
+		t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+		q[i] = 0.5 * t;
+		t = 0.5 / t;
+		q[3] = (m[k][j] - m[j][k]) * t;
+		q[j] = (m[j][i] + m[i][j]) * t;
+		q[k] = (m[k][i] + m[i][k]) * t;
+	}
+	Quat r = {q[3], q[0], q[1], q[2]};
+	return r;
+}
+// Eigen 3.3 QuaternionBase::slerp(t, other) from the identity quaternion
+Quat slerp_from_identity(double t, const Quat &o)
+{
+	const double one = 1.0 - DBL_EPSILON;
+	double d = o.w; // dot(identity, other)
+	double absD = std::fabs(d);
+	double scale0, scale1;
+	if (absD >= one)
+	{
+		scale0 = 1.0 - t;
+		scale1 = t;
+	}
+	else
+	{
+		double theta = std::acos(absD);
+		double sinTheta = std::sin(theta);
+		scale0 = std::sin((1.0 - t) * theta) / sinTheta;
+		scale1 = std::sin((t * theta)) / sinTheta;
+	}
+	if (d < 0)
+		scale1 = -scale1;
+	Quat r = {scale0 + scale1 * o.w, scale1 * o.x, scale1 * o.y, scale1 * o.z};
+	return r;
+}
+// Eigen quaternion * vector: v + 2w (u x v) + 2 u x (u x v)  (QuaternionBase::_transformVector)
+void quat_rotate(const Quat &q, const double v[3], double out[3])
+{
+	double ux = q.x, uy = q.y, uz = q.z;
+	double uvx = 2.0 * (uy * v[2] - uz * v[1]), uvy = 2.0 * (uz * v[0] - ux * v[2]), uvz = 2.0 * (ux * v[1] - uy * v[0]);
+	out[0] = v[0] + q.w * uvx + (uy * uvz - uz * uvy);
+	out[1] = v[1] + q.w * uvy + (uz * uvx - ux * uvz);
+	out[2] = v[2] + q.w * uvz + (ux * uvy - uy * uvx);
+}
+// CFilter::apply_motion_compensation(in, out, Tran) (cfilter.hpp:493-516); serial restatement
+void apply_motion_compensation(const Cloud &in, Cloud &out, const M4 &Tran)
+{
+	out = in;
+	Quat q21 = quat_from_matrix(Tran);
+	for (size_t i = 0; i < in.size(); i++)
+	{
+		float s = in[i].curvature;
+		if (s < 0.0f || s > 1.0 - 0.0f)
+			continue;
+		Quat dq = slerp_from_identity((double)s, q21);
+		double v[3] = {in[i].x, in[i].y, in[i].z}, r[3];
+		quat_rotate(dq, v, r);
+		out[i].x = (float)(r[0] + (double)s * Tran(0, 3));
+		out[i].y = (float)(r[1] + (double)s * Tran(1, 3));
+		out[i].z = (float)(r[2] + (double)s * Tran(2, 3));
+	}
+}
+
+inline bool used(const mulls_params *p, int c) { return p->used_feature_type[c] == '1'; }
+inline int metric_of(int c) { return (c == MULLS_PILLAR || c == MULLS_BEAM) ? 1 : (c == MULLS_VERTEX ? 2 : 0); }
+
+int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int brute, int use_omp)
+{
+	auto tic = std::chrono::steady_clock::now();
+	int process_code = 0;
+	const int min_total_corr_num = 40, min_neccessary_corr_num = 20;
+	float neccessary_corr_ratio = 1.0f;
+	M6 cofactor, information;
+	for (int i = 0; i < 36; i++)
+		cofactor.a[i] = information.a[i] = (i % 7 == 0) ? 1.0 : 0.0;
+	double sigma_square_post = 1.0;
+	M4 TempTran = m4_identity();
+	double x[6] = {0, 0, 0, 0, 0, 0};
+	int singular = 0;
+
+	float thr[6];
+	for (int c = 0; c < 6; c++)
+		thr[c] = P->dis_thre_unit;
+	float max_bearable_translation = (float)(2.0 * P->dis_thre_unit);
+	float converge_rotation = (float)(P->converge_rotation_d / 180.0 * M_PI);
+	float max_bearable_rotation = (float)(P->max_bearable_rotation_d / 180.0 * M_PI);
+
+	Cloud tc[6], sc[6];
+	std::vector<int> orig[6];
+	for (int c = 0; c < 6; c++)
+	{
+		load_cloud(pair->tgt[c], tc[c]);
+		load_cloud(pair->src[c], sc[c]);
+	}
+	M4 guess;
+	std::memcpy(guess.a, pair->init_guess, sizeof(guess.a));
+	for (int c = 0; c < 6; c++)
+		transform_cloud(sc[c], guess); // :1183 (all six, used or not)
+
+	const bool undistort = P->apply_motion_undistortion != 0;
+	if (P->apply_intersection_filter && !undistort) // :1186-1188, :2894-2922
+	{
+		double b[3][6], merged[6] = {DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
+		cloud_bbx(sc[MULLS_GROUND], b[0]);
+		cloud_bbx(sc[MULLS_PILLAR], b[1]);
+		cloud_bbx(sc[MULLS_FACADE], b[2]);
+		for (int i = 0; i < 3; i++)
+			for (int k = 0; k < 3; k++)
+			{
+				merged[k] = std::min(merged[k], b[i][k]);
+				merged[3 + k] = std::max(merged[3 + k], b[i][3 + k]);
+			}
+		const float pad = 1.0f;
+		double ib[6];
+		for (int k = 0; k < 3; k++)
+		{
+			ib[k] = std::max(pair->tgt_bound[k], merged[k]) - pad;
+			ib[3 + k] = std::min(pair->tgt_bound[3 + k], merged[3 + k]) + pad;
+		}
+		for (int c = 0; c < 6; c++)
+		{
+			bbx_filter(tc[c], ib);
+			bbx_filter(sc[c], ib);
+		}
+	}
+	if (P->keep_less_source_points && !undistort)
+		return MULLS_E_UNSUPPORTED; // pcl::RandomSample seeded with time(NULL): callers must pre-thin (SURVEY B-13)
+
+	for (int c = 0; c < 6; c++)
+	{
+		orig[c].resize(sc[c].size());
+		for (size_t i = 0; i < sc[c].size(); i++)
+			orig[c][i] = (int)i;
+		R->nsrc0[c] = (uint32_t)sc[c].size();
+		R->ntgt0[c] = (uint32_t)tc[c].size();
+	}
+
+	int source_feature_points_count = 0;
+	if (used(P, 1))
+		source_feature_points_count += (int)sc[MULLS_PILLAR].size();
+	if (used(P, 2))
+		source_feature_points_count += (int)sc[MULLS_FACADE].size();
+	if (used(P, 3))
+		source_feature_points_count += (int)sc[MULLS_BEAM].size();
+
+	KdTree tree[6];
+	if (!brute)
+	{
+		// :1209-1232 — three OpenMP sections {ground, roof} {pillar, beam} {facade}, vertex afterwards
+#pragma omp parallel sections if (use_omp)
+		{
+#pragma omp section
+			{
+				if (used(P, 0) && !tc[0].empty())
+					tree[0].build(tc[0]);
+				if (used(P, 4) && !tc[4].empty())
+					tree[4].build(tc[4]);
+			}
+#pragma omp section
+			{
+				if (used(P, 1) && !tc[1].empty())
+					tree[1].build(tc[1]);
+				if (used(P, 3) && !tc[3].empty())
+					tree[3].build(tc[3]);
+			}
+#pragma omp section
+			{
+				if (used(P, 2) && !tc[2].empty())
+					tree[2].build(tc[2]);
+			}
+		}
+		if (used(P, 5) && !tc[5].empty())
+			tree[5].build(tc[5]);
+	}
+
+	Corrs corr[6];
+	const bool ns = P->normal_shooting_on != 0;
+	const float bearing = P->normal_bearing;
+	int iters = 0;
+	R->trace_len = 0;
+
+	for (int i = 0; i < P->max_iter_num; i++)
+	{
+		if (undistort && i == 0) // :1248-1258
+		{
+			M4 inv_guess = m4_inverse(guess);
+			for (int c = 0; c < 5; c++) // vertex is not regenerated (cfilter.hpp:540,547)
+			{
+				Cloud down;
+				load_cloud(pair->src_down[c].pts ? pair->src_down[c] : pair->src[c], down);
+				apply_motion_compensation(down, sc[c], inv_guess);
+				orig[c].resize(sc[c].size());
+				for (size_t k = 0; k < sc[c].size(); k++)
+					orig[c][k] = (int)k;
+			}
+			for (int c = 0; c < 6; c++)
+				transform_cloud(sc[c], guess);
+		}
+		else
+			for (int c = 0; c < 6; c++)
+				transform_cloud(sc[c], TempTran);
+
+		float thr_used[6];
+		for (int c = 0; c < 6; c++)
+			thr_used[c] = thr[c];
+
+			// :1268-1292 — sections {ground} {pillar} {facade, beam}, then roof, vertex serially
+#pragma omp parallel sections if (use_omp)
+		{
+#pragma omp section
+			{
+				if (used(P, 0) && sc[0].size() > 0)
+					determine_corres(sc[0], orig[0], tc[0], &tree[0], thr[0], corr[0], ns, true, bearing, brute);
+			}
+#pragma omp section
+			{
+				if (used(P, 1) && sc[1].size() > 0)
+					determine_corres(sc[1], orig[1], tc[1], &tree[1], thr[1], corr[1], false, true, bearing, brute);
+			}
+#pragma omp section
+			{
+				if (used(P, 2) && sc[2].size() > 0)
+					determine_corres(sc[2], orig[2], tc[2], &tree[2], thr[2], corr[2], ns, true, bearing, brute);
+				if (used(P, 3) && sc[3].size() > 0)
+					determine_corres(sc[3], orig[3], tc[3], &tree[3], thr[3], corr[3], false, true, bearing, brute);
+			}
+		}
+		if (used(P, 4) && sc[4].size() > 0)
+			determine_corres(sc[4], orig[4], tc[4], &tree[4], thr[4], corr[4], ns, true, bearing, brute);
+		if (used(P, 5) && sc[5].size() > 0)
+			determine_corres(sc[5], orig[5], tc[5], &tree[5], thr[5], corr[5], false, false, 40.0f, brute);
+		iters = i + 1;
+
+		int total_corr_num = 0;
+		for (int c = 0; c < 6; c++)
+			total_corr_num += (int)corr[c].size();
+		int neccessary_corr_num = (int)(corr[MULLS_PILLAR].size() + corr[MULLS_BEAM].size() + corr[MULLS_FACADE].size());
+		neccessary_corr_ratio = (float)(1.0 * neccessary_corr_num / source_feature_points_count);
+
+		mulls_iter_trace *tr = nullptr;
+		if (R->trace && R->trace_len < R->trace_cap)
+		{
+			tr = &R->trace[R->trace_len++];
+			std::memset(tr, 0, sizeof(*tr));
+			tr->iter = i;
+			for (int c = 0; c < 6; c++)
+			{
+				tr->ncorr[c] = (uint32_t)corr[c].size();
+				tr->nsrc[c] = (uint32_t)sc[c].size();
+				tr->thr[c] = thr_used[c];
+			}
+		}
+		for (int c = 0; c < 6; c++)
+			R->ncorr[c] = (uint32_t)corr[c].size();
+
+		if (total_corr_num < min_total_corr_num || neccessary_corr_num < min_neccessary_corr_num ||
+			neccessary_corr_ratio < P->min_neccessary_corr_ratio)
+		{
+			process_code = -2;
+			TempTran = m4_identity();
+			break;
+		}
+
+		for (int c = 0; c < 6; c++) // update_corr_dist_thre :1855-1866
+		{
+			double v = 1.0 * thr[c] / P->dis_thre_update_rate;
+			thr[c] = (float)((v > P->dis_thre_min) ? v : (double)P->dis_thre_min);
+		}
+
+		// multi_metrics_lls_tran_estimation :1869-1967
+		{
+			float w_ground = 1.0f, w_roof = 1.0f;
+			int m1 = (int)(corr[MULLS_GROUND].size() + corr[MULLS_ROOF].size());
+			int m2 = (int)corr[MULLS_FACADE].size();
+			int m3 = (int)corr[MULLS_PILLAR].size();
+			int m4 = (int)corr[MULLS_BEAM].size();
+			if (P->weight_strategy[0] == '1')
+			{
+				double v = P->z_xy_balanced_ratio * (m2 + 2 * m3 - m4) / (0.0001 + 2.0 * m1);
+				w_ground = (float)((0.01 > v) ? 0.01 : v);
+				w_roof = w_ground;
+			}
+			bool resid_w = (P->weight_strategy[1] == '1' && i > 2);
+			bool dist_w = P->weight_strategy[2] == '1';
+			bool inten_w = P->weight_strategy[3] == '1';
+			Normal N;
+			N.zero();
+			pt2pl_sum(sc[0], tc[0], corr[0], N, i, w_ground, dist_w, resid_w, inten_w, P->pt2pl_residual_window);
+			pt2pl_sum(sc[2], tc[2], corr[2], N, i, 1.0f, dist_w, resid_w, inten_w, P->pt2pl_residual_window);
+			pt2pl_sum(sc[4], tc[4], corr[4], N, i, w_roof, dist_w, resid_w, inten_w, P->pt2pl_residual_window);
+			pt2li_sum(sc[1], tc[1], corr[1], N, i, 1.0f, dist_w, resid_w, inten_w, P->pt2li_residual_window);
+			pt2li_sum(sc[3], tc[3], corr[3], N, i, 1.0f, dist_w, resid_w, inten_w, P->pt2li_residual_window);
+			if (!P->faithful)
+			{
+				// intended version: keep the real weight for the vertex residual pass
+				Corrs tmp = corr[5];
+				pt2pt_sum(sc[5], tc[5], corr[5], N, i, 1.0f, dist_w, resid_w, inten_w, P->pt2pt_residual_window);
+				for (size_t k = 0; k < corr[5].size(); k++)
+				{
+					const Pt &s = sc[5][corr[5][k].q];
+					const Pt &t = tc[5][corr[5][k].m];
+					float dx = s.x - t.x, dy = s.y - t.y, dz = s.z - t.z;
+					float w = 1.0f;
+					float dist = std::sqrt(t.x * t.x + t.y * t.y + t.z * t.z);
+					if (dist_w)
+						w = w * get_weight_by_dist_adaptive(dist, i);
+					if (resid_w)
+						w = w * get_weight_by_residual(std::sqrt(dx * dx + dy * dy + dz * dz), P->pt2pt_residual_window);
+					if (inten_w)
+						w = w * get_weight_by_intensity((float)(s.intensity + 0.0001), (float)(t.intensity + 0.0001));
+					corr[5][k].dw = w;
+				}
+			}
+			else
+				pt2pt_sum(sc[5], tc[5], corr[5], N, i, 1.0f, dist_w, resid_w, inten_w, P->pt2pt_residual_window);
+
+			M6 ATPA;
+			assemble_atpa(N, P->faithful != 0, ATPA);
+			if (!solve_normal(ATPA, N.b, x, cofactor))
+				singular = 1;
+			if (tr)
+			{
+				std::memcpy(tr->atpa, ATPA.a, sizeof(tr->atpa));
+				std::memcpy(tr->atpb, N.b, sizeof(tr->atpb));
+				std::memcpy(tr->x, x, sizeof(tr->x));
+			}
+		}
+		construct_trans_a(x, TempTran);
+
+		double ts_norm = std::sqrt(TempTran(0, 3) * TempTran(0, 3) + TempTran(1, 3) * TempTran(1, 3) + TempTran(2, 3) * TempTran(2, 3));
+		double rs_angle = angle_of_rotation(TempTran);
+		if (ts_norm > max_bearable_translation || std::fabs(rs_angle) > max_bearable_rotation)
+		{
+			process_code = -1;
+			TempTran = m4_identity();
+			break;
+		}
+		if (i == P->max_iter_num - 1 || (i > 2 && ts_norm < P->converge_translation && std::fabs(rs_angle) < converge_rotation))
+		{
+			double VTPV = 0;
+			int n = 0;
+			pt2pl_residual(sc[0], tc[0], corr[0], x, VTPV, n);
+			pt2pl_residual(sc[2], tc[2], corr[2], x, VTPV, n);
+			pt2pl_residual(sc[4], tc[4], corr[4], x, VTPV, n);
+			pt2li_residual(sc[1], tc[1], corr[1], x, VTPV, n);
+			pt2li_residual(sc[3], tc[3], corr[3], x, VTPV, n);
+			pt2pt_residual(sc[5], tc[5], corr[5], x, VTPV, n, P->faithful != 0);
+			sigma_square_post = VTPV / (n - 6);
+			process_code = (std::sqrt(sigma_square_post) < (double)P->sigma_thre) ? 1 : -3;
+			M6 cinv;
+			lu_inverse(cofactor.a, cinv.a, 6);
+			for (int k = 0; k < 36; k++)
+				information.a[k] = (1.0 / sigma_square_post) * cinv.a[k];
+			break;
+		}
+		guess = m4_mul(TempTran, guess);
+	}
+	guess = m4_mul(TempTran, guess); // :1403
+
+	R->code = process_code;
+	R->iters = iters;
+	std::memcpy(R->T, guess.a, sizeof(R->T));
+	std::memcpy(R->info, information.a, sizeof(R->info));
+	R->sigma = (float)std::sqrt(sigma_square_post);
+	R->confidence = neccessary_corr_ratio;
+	R->singular = singular;
+	R->ms_total = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - tic).count() * 1000.0);
+	return MULLS_OK;
+}
+
+} // namespace
+
+extern "C"
+{
+
+	void mulls_oracle_default_params(mulls_params *p)
+	{
+		std::memset(p, 0, sizeof(*p));
+		p->max_iter_num = 20;
+		p->dis_thre_unit = 1.5f;
+		p->converge_translation = 0.002f;
+		p->converge_rotation_d = 0.01f;
+		p->dis_thre_min = 0.4f;
+		p->dis_thre_update_rate = 1.1f;
+		std::strcpy(p->used_feature_type, "111110");
+		std::strcpy(p->weight_strategy, "1101");
+		p->z_xy_balanced_ratio = 1.0f;
+		p->pt2pt_residual_window = 0.1f;
+		p->pt2pl_residual_window = 0.1f;
+		p->pt2li_residual_window = 0.1f;
+		p->apply_intersection_filter = 1;
+		p->normal_bearing = 45.0f;
+		p->faithful = 1;
+		p->sigma_thre = 0.5f;
+		p->min_neccessary_corr_ratio = 0.03f;
+		p->max_bearable_rotation_d = 45.0f;
+	}
+
+	// nn_mode: 0 = kd-tree (the PCL/FLANN cost model), 1 = brute force (cross-check).  use_omp: 1 = the reference's
+	// 3-wide OpenMP sections, 0 = serial.
+	int mulls_oracle_icp(const mulls_pair *pair, const mulls_params *params, mulls_result *result, int nn_mode, int use_omp)
+	{
+		if (!pair || !params || !result)
+			return MULLS_E_INVALID;
+		return icp_impl(pair, params, result, nn_mode, use_omp);
+	}
+
+	int mulls_oracle_transform(void *pts, uint32_t n, uint32_t stride, const double T[16])
+	{
+		Cloud c;
+		mulls_cloud mc = {pts, n, stride};
+		load_cloud(mc, c);
+		M4 m;
+		std::memcpy(m.a, T, sizeof(m.a));
+		transform_cloud(c, m);
+		for (uint32_t i = 0; i < n; i++)
+			std::memcpy((uint8_t *)pts + (size_t)i * stride, &c[i], sizeof(Pt));
+		return 0;
+	}
+
+	// same contract as mulls_stage_correspond (include/mulls_hip.h); outputs indexed by ORIGINAL source index
+	int mulls_oracle_correspond(const mulls_cloud *src, const mulls_cloud *tgt, float dis_thre, int normal_check, float angle_thre_degree,
+								int32_t *match, float *d2, uint8_t *flags, int nn_mode)
+	{
+		Cloud S, T;
+		load_cloud(*src, S);
+		load_cloud(*tgt, T);
+		std::vector<int> orig(S.size());
+		for (size_t i = 0; i < S.size(); i++)
+			orig[i] = (int)i;
+		KdTree tree;
+		if (!nn_mode)
+			tree.build(T);
+		// raw NN for every source point (match/d2 outputs)
+		const double maxd = (double)(2.5f * dis_thre);
+		for (size_t s = 0; s < S.size(); s++)
+		{
+			float dd;
+			int t = (T.size() < 3 || S.size() < 3) ? -1 : (nn_mode ? brute_nearest(T, S[s], dd) : tree.nearest(S[s], dd));
+			if (t >= 0 && (double)dd > maxd * maxd)
+				t = -1;
+			match[s] = t;
+			d2[s] = t >= 0 ? dd : 0.0f;
+			flags[s] = 0;
+		}
+		Corrs cf;
+		size_t n0 = S.size();
+		determine_corres(S, orig, T, &tree, dis_thre, cf, false, normal_check != 0, angle_thre_degree, nn_mode != 0);
+		(void)n0;
+		for (size_t k = 0; k < orig.size(); k++) // identity when no compaction happened
+			flags[orig[k]] |= 1;
+		for (size_t k = 0; k < cf.size(); k++)
+			flags[orig[cf[k].q]] |= 2;
+		return 0;
+	}
+
+	int mulls_oracle_accumulate(int metric, const mulls_cloud *src, const mulls_cloud *tgt, const int32_t *corr_src, const int32_t *corr_tgt,
+								const float *corr_d2, uint32_t ncorr, int iter_num, float class_weight, int dist_w, int resid_w, int inten_w,
+								float window, double *out27, float *weight_out)
+	{
+		Cloud S, T;
+		load_cloud(*src, S);
+		load_cloud(*tgt, T);
+		Corrs c(ncorr);
+		for (uint32_t i = 0; i < ncorr; i++)
+		{
+			c[i].q = corr_src[i];
+			c[i].m = corr_tgt[i];
+			c[i].dw = corr_d2 ? corr_d2[i] : 0.0f;
+		}
+		Normal N;
+		N.zero();
+		if (metric == 0)
+			pt2pl_sum(S, T, c, N, iter_num, class_weight, dist_w, resid_w, inten_w, window);
+		else if (metric == 1)
+			pt2li_sum(S, T, c, N, iter_num, class_weight, dist_w, resid_w, inten_w, window);
+		else
+			pt2pt_sum(S, T, c, N, iter_num, class_weight, dist_w, resid_w, inten_w, window);
+		int k = 0;
+		for (int r = 0; r < 6; r++) // row-major-upper enumeration (r <= cc)
+			for (int cc = r; cc < 6; cc++)
+				out27[k++] = (metric == 1 && r != cc) ? N.upper[r + 6 * cc] : N.lower[cc + 6 * r];
+		for (int j = 0; j < 6; j++)
+			out27[21 + j] = N.b[j];
+		if (weight_out)
+			for (uint32_t i = 0; i < ncorr; i++)
+				weight_out[i] = c[i].dw;
+		return 0;
+	}
+
+	// kd-tree vs brute-force self check helper: nearest neighbour of every src point, no radius
+	int mulls_oracle_nn(const mulls_cloud *src, const mulls_cloud *tgt, int32_t *match, float *d2, int nn_mode)
+	{
+		Cloud S, T;
+		load_cloud(*src, S);
+		load_cloud(*tgt, T);
+		KdTree tree;
+		if (!nn_mode)
+			tree.build(T);
+		for (size_t s = 0; s < S.size(); s++)
+			match[s] = nn_mode ? brute_nearest(T, S[s], d2[s]) : tree.nearest(S[s], d2[s]);
+		return 0;
+	}
+
+	// host pieces exposed for unit tests
+	void mulls_oracle_construct_trans(const double x[6], double T[16])
+	{
+		M4 m;
+		construct_trans_a(x, m);
+		std::memcpy(T, m.a, sizeof(m.a));
+	}
+	int mulls_oracle_solve(const double atpa[36], const double atpb[6], double x[6], double cof[36])
+	{
+		M6 A, C;
+		std::memcpy(A.a, atpa, sizeof(A.a));
+		bool ok = solve_normal(A, atpb, x, C);
+		std::memcpy(cof, C.a, sizeof(C.a));
+		return ok ? 0 : 1;
+	}
+	double mulls_oracle_rotation_angle(const double T[16])
+	{
+		M4 m;
+		std::memcpy(m.a, T, sizeof(m.a));
+		return angle_of_rotation(m);
+	}
+}

@@ -1,0 +1,105 @@
+"""ctypes binding of oracle/liboracle.so — the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+mulls_amd/ does.  See the header of oracle/mulls_oracle.cpp for what the oracle restates and how it is pinned.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mulls_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "mulls_oracle.cpp")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.mulls_oracle_icp.argtypes = [C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result), C.c_int, C.c_int]
+        _LIB.mulls_oracle_icp.restype = C.c_int
+        _LIB.mulls_oracle_rotation_angle.restype = C.c_double
+    return _LIB
+
+
+def icp(pair, params, trace_cap=0, nn_mode=0, use_omp=1):
+    """Run the oracle on one abi.PairData.  Returns abi.Result (index 0 of a 1-element array)."""
+    res = abi.make_result_array(1, trace_cap)
+    p = pair.as_pair()
+    rc = lib().mulls_oracle_icp(C.byref(p), C.byref(params), C.byref(res[0]), nn_mode, use_omp)
+    if rc != 0:
+        raise RuntimeError("oracle returned %d" % rc)
+    return res
+
+
+def transform(pts, T):
+    pts = np.ascontiguousarray(pts).copy()
+    Tc = (C.c_double * 16)(*np.asarray(T, dtype=np.float64).T.reshape(-1))
+    lib().mulls_oracle_transform(C.c_void_p(pts.ctypes.data), C.c_uint32(len(pts)), C.c_uint32(abi.POINT_BYTES), Tc)
+    return pts
+
+
+def correspond(src, tgt, dis_thre, normal_check=True, angle_deg=45.0, nn_mode=0):
+    n = len(src)
+    match = np.zeros(n, np.int32)
+    d2 = np.zeros(n, np.float32)
+    flags = np.zeros(n, np.uint8)
+    cs, ct = abi.as_cloud(src), abi.as_cloud(tgt)
+    lib().mulls_oracle_correspond(C.byref(cs), C.byref(ct), C.c_float(dis_thre), int(normal_check), C.c_float(angle_deg),
+                                  match.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), flags.ctypes.data_as(C.c_void_p), nn_mode)
+    return match, d2, flags
+
+
+def accumulate(metric, src, tgt, corr_src, corr_tgt, corr_d2, iter_num, class_weight, dist_w, resid_w, inten_w, window):
+    corr_src = np.ascontiguousarray(corr_src, np.int32)
+    corr_tgt = np.ascontiguousarray(corr_tgt, np.int32)
+    corr_d2 = np.ascontiguousarray(corr_d2, np.float32)
+    out = np.zeros(27, np.float64)
+    w = np.zeros(len(corr_src), np.float32)
+    cs, ct = abi.as_cloud(src), abi.as_cloud(tgt)
+    lib().mulls_oracle_accumulate(int(metric), C.byref(cs), C.byref(ct), corr_src.ctypes.data_as(C.c_void_p),
+                                  corr_tgt.ctypes.data_as(C.c_void_p), corr_d2.ctypes.data_as(C.c_void_p), C.c_uint32(len(corr_src)),
+                                  int(iter_num), C.c_float(class_weight), int(dist_w), int(resid_w), int(inten_w), C.c_float(window),
+                                  out.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p))
+    return out, w
+
+
+def nn(src, tgt, nn_mode=0):
+    n = len(src)
+    match = np.zeros(n, np.int32)
+    d2 = np.zeros(n, np.float32)
+    cs, ct = abi.as_cloud(src), abi.as_cloud(tgt)
+    lib().mulls_oracle_nn(C.byref(cs), C.byref(ct), match.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), nn_mode)
+    return match, d2
+
+
+def construct_trans(x):
+    xs = (C.c_double * 6)(*x)
+    T = (C.c_double * 16)()
+    lib().mulls_oracle_construct_trans(xs, T)
+    return np.array(T[:]).reshape(4, 4).T.copy()
+
+
+def solve(atpa, atpb):
+    A = (C.c_double * 36)(*np.asarray(atpa, np.float64).T.reshape(-1))
+    b = (C.c_double * 6)(*atpb)
+    x = (C.c_double * 6)()
+    cof = (C.c_double * 36)()
+    rc = lib().mulls_oracle_solve(A, b, x, cof)
+    return rc, np.array(x[:]), np.array(cof[:]).reshape(6, 6).T.copy()
+
+
+def rotation_angle(T):
+    Tc = (C.c_double * 16)(*np.asarray(T, dtype=np.float64).T.reshape(-1))
+    return float(lib().mulls_oracle_rotation_angle(Tc))
