@@ -153,7 +153,8 @@ typedef struct mulls_profile
 	int32_t iterations;	  /* lock-step iterations executed by the run */
 	uint64_t nn_pair_evals; /* source-target distance evaluations issued by those launches */
 	uint64_t nn_src_pts;	/* live source points searched, summed over launches */
-	uint64_t nn_tgt_pts;	/* target points streamed (per job tile), summed over launches */
+	uint64_t nn_tgt_pts;	/* target points streamed into LDS (once per 512-source job), summed over launches */
+	uint64_t nn_tgt_unique; /* target points of the searched class clouds (once per cloud), summed over launches */
 } mulls_profile;
 
 typedef struct mulls_ctx mulls_ctx;		/* one per host thread / HIP stream */

@@ -123,6 +123,7 @@ class Profile(C.Structure):
         ("nn_pair_evals", C.c_uint64),
         ("nn_src_pts", C.c_uint64),
         ("nn_tgt_pts", C.c_uint64),
+        ("nn_tgt_unique", C.c_uint64),
     ]
 
 
@@ -201,6 +202,19 @@ def make_points(xyz, normals=None, intensity=None, curvature=None):
     return pts
 
 
+def as_points(a):
+    """Coerce any structured array carrying the eight point fields to a contiguous POINT_DTYPE array."""
+    if a is None:
+        return np.zeros(0, dtype=POINT_DTYPE)
+    a = np.asarray(a)
+    if a.dtype == POINT_DTYPE and a.flags["C_CONTIGUOUS"]:
+        return a
+    out = np.zeros(len(a), dtype=POINT_DTYPE)
+    for k in POINT_DTYPE.names:
+        out[k] = a[k]
+    return out
+
+
 def as_cloud(pts):
     """mulls_cloud borrowing a POINT_DTYPE numpy array (caller keeps the array alive)."""
     c = Cloud()
@@ -218,10 +232,9 @@ class PairData:
     """Owns the numpy arrays of one registration problem and exposes the ctypes ``Pair`` borrowing them."""
 
     def __init__(self, tgt, src, init_guess=None, tgt_bound=None, src_down=None):
-        empty = np.zeros(0, dtype=POINT_DTYPE)
-        self.tgt = [np.ascontiguousarray(t) if t is not None else empty for t in tgt]
-        self.src = [np.ascontiguousarray(s) if s is not None else empty for s in src]
-        self.src_down = None if src_down is None else [np.ascontiguousarray(s) if s is not None else empty for s in src_down]
+        self.tgt = [as_points(t) for t in tgt]
+        self.src = [as_points(s) for s in src]
+        self.src_down = None if src_down is None else [as_points(s) for s in src_down]
         self.init_guess = np.eye(4) if init_guess is None else np.asarray(init_guess, dtype=np.float64)
         if tgt_bound is None:
             allp = [t for t in self.tgt if len(t)]

@@ -637,6 +637,7 @@ extern "C"
 					{
 						ctx->prof.nn_pair_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
 						ctx->prof.nn_src_pts += h.alive_prev[c];
+						ctx->prof.nn_tgt_unique += o.tgt_n[c];
 						ctx->prof.nn_tgt_pts += (uint64_t)o.tgt_n[c] * (B->descs_h[p * MULLS_NC + c].job_end - B->descs_h[p * MULLS_NC + c].job_begin);
 					}
 					h.alive_prev[c] = o.n_alive[c];

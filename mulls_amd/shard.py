@@ -1,0 +1,53 @@
+"""Sharding of independent scan pairs over the GPUs of one node (one process per GPU, torch.distributed).
+
+Scan pairs are independent: the data path has no collective.  Every rank registers its own block of
+pairs; the only exchange is one gather of the small per-pair result records onto rank 0 at the end of a step
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+RECORD = 16 + 36 + 4  # T (16) + information matrix (36) + code, iters, sigma, confidence
+
+
+def block_partition(n_items, world_size, rank):
+    """Static block partition: pair p -> rank floor(p * world_size / n_items) (contiguous, sizes differ by at most 1)."""
+    lo = (n_items * rank) // world_size
+    hi = (n_items * (rank + 1)) // world_size
+    return lo, hi
+
+
+def pack_results(results, n):
+    """ctypes Result array -> (n, RECORD) float64 table."""
+    out = np.zeros((n, RECORD), np.float64)
+    for i in range(n):
+        r = results[i]
+        out[i, :16] = r.T[:]
+        out[i, 16:52] = r.info[:]
+        out[i, 52:] = (r.code, r.iters, r.sigma, r.confidence)
+    return out
+
+
+def gather_results(table, device=None, dst=0):
+    """Gather every rank's (n_r, RECORD) table on rank `dst`.  Returns the concatenated table there, None elsewhere.
+    Without an initialised process group (single-GPU run) the table is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return table
+    world, rank = dist.get_world_size(), dist.get_rank()
+    t = torch.from_numpy(np.ascontiguousarray(table))
+    if device is not None:
+        t = t.to(device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = torch.zeros((pad, RECORD), dtype=torch.float64, device=t.device)
+    buf[: t.shape[0]] = t
+    if rank == dst:
+        parts = [torch.zeros_like(buf) for _ in range(world)]
+        dist.gather(buf, parts, dst=dst)
+        return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)])
+    dist.gather(buf, None, dst=dst)
+    return None

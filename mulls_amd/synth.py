@@ -71,6 +71,11 @@ class Scene:
 
 
 def raycast(scene, pose, n_beams=64, n_az=1900, elev_deg=(-24.8, 2.0), max_range=120.0, range_noise=0.02, seed=0):
+    with np.errstate(all="ignore"):
+        return _raycast(scene, pose, n_beams, n_az, elev_deg, max_range, range_noise, seed)
+
+
+def _raycast(scene, pose, n_beams, n_az, elev_deg, max_range, range_noise, seed):
     """Cast one revolution from the sensor at world pose `pose` (4x4, sensor->world).
 
     Returns a dict of per-return arrays in the SENSOR frame: xyz (n,3), nrm (n,3), cls (n,), intensity (n,), t (n,) in [0,1].

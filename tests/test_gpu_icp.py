@@ -1,0 +1,156 @@
+"""GPU parity of the whole path (mm_lls_icp) against the oracle through mulls_icp / mulls_icp_batch / mulls_batch_run.
+
+Tolerances (BASELINE.json north_star): transform within 1e-4 m / 1e-4 rad.  Observed agreement is ~1e-12; the tests
+pin 1e-7 so a real regression cannot hide inside the contractual tolerance.  Integer outputs (process code, iteration
+count, per-iteration correspondence and live-source counts) must be identical."""
+import numpy as np
+import pytest
+
+from conftest import planes_scene, transformed_copy
+from mulls_amd import abi, synth
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_T, TOL_R = 1e-7, 1e-7
+
+
+def compare(ro, rg, check_trace=True):
+    assert ro.code == rg.code and ro.iters == rg.iters
+    assert list(ro.ncorr) == list(rg.ncorr)
+    assert list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
+    dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
+    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    assert abs(ro.sigma - rg.sigma) <= 1e-6 * max(1.0, abs(ro.sigma))
+    assert ro.confidence == rg.confidence
+    io, ig = ro.info_matrix(), rg.info_matrix()
+    assert np.abs(io - ig).max() <= 1e-6 * np.abs(io).max()
+    if check_trace:
+        assert ro.trace_len == rg.trace_len
+        for k in range(ro.trace_len):
+            a, b = ro.trace[k], rg.trace[k]
+            assert list(a.ncorr) == list(b.ncorr) and list(a.nsrc) == list(b.nsrc), k
+            assert list(a.thr) == list(b.thr)
+            if any(a.atpa[:]):
+                sa = np.abs(np.array(a.atpa[:])).max()
+                assert np.abs(np.array(a.atpa[:]) - np.array(b.atpa[:])).max() <= 1e-10 * sa
+                assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() <= 1e-9
+
+
+PARAM_SETS = {
+    "kitti_s2s": dict(base="kitti", dis_thre_unit=2.4),
+    "kitti_fixed20": dict(base="kitti", converge_translation=0.0, converge_rotation_d=0.0),
+    "defaults_5classes": dict(base="default"),
+    "all6_nofilter": dict(base="default", used_feature_type="111111", apply_intersection_filter=0, weight_strategy="1111"),
+    "unfaithful": dict(base="default", used_feature_type="111111", faithful=0),
+    "equal_weights": dict(base="default", weight_strategy="0000", used_feature_type="111100"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PARAM_SETS))
+def test_icp_matches_oracle(ctx, pairs_small, name):
+    kw = dict(PARAM_SETS[name])
+    base = kw.pop("base")
+    P = abi.kitti_params(**kw) if base == "kitti" else abi.default_params(**kw)
+    for pair, _ in pairs_small:
+        ro = pyoracle.icp(pair, P, trace_cap=48)[0]
+        rg = ctx.icp(pair, P, trace_cap=48)[0]
+        compare(ro, rg)
+
+
+def test_full_size_kitti_pair(ctx):
+    """BASELINE config #2 at full size: 64-beam ~120k-point scans, source 800/400/1200, 20 iterations."""
+    pair, T_gt = synth.make_pair(101)
+    assert pair.n_raw[0] > 100000
+    P = abi.kitti_params(converge_translation=0.0, converge_rotation_d=0.0)
+    ro = pyoracle.icp(pair, P, trace_cap=24)[0]
+    rg = ctx.icp(pair, P, trace_cap=24)[0]
+    assert rg.iters == 20
+    compare(ro, rg)
+    dt, dr = synth.pose_error(rg.T_matrix(), T_gt)
+    assert dt < 0.05 and dr < 2e-3
+
+
+def test_batch_equals_single(ctx, pairs_small):
+    P = abi.kitti_params(dis_thre_unit=2.4)
+    pairs = [p for p, _ in pairs_small] * 3
+    rb = ctx.icp_batch(pairs, P)
+    for i, pr in enumerate(pairs):
+        r1 = ctx.icp(pr, P)[0]
+        assert r1.code == rb[i].code and r1.iters == rb[i].iters
+        assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma  # bit-identical
+
+
+def test_resident_batch_is_repeatable(ctx, pairs_small):
+    """mulls_batch_run re-clones the staged clouds every run: identical results run after run, run-to-run deterministic."""
+    P = abi.kitti_params(dis_thre_unit=2.4)
+    b = ctx.batch([p for p, _ in pairs_small])
+    r1 = b.run(P)
+    first = [(r.code, r.iters, tuple(r.T), tuple(r.info), r.sigma) for r in r1]
+    for _ in range(3):
+        r2 = b.run(P)
+        assert [(r.code, r.iters, tuple(r.T), tuple(r.info), r.sigma) for r in r2] == first
+    P2 = abi.default_params()  # different class set on the same staged batch
+    r3 = b.run(P2)
+    ro = pyoracle.icp(pairs_small[0][0], P2)[0]
+    compare(ro, r3[0], check_trace=False)
+    b.close()
+
+
+def test_mixed_outcomes_in_one_batch(ctx):
+    """Pairs that fail early (-2), step too far (-1), exceed sigma (-3) or never iterate sit next to healthy ones."""
+    rng = np.random.default_rng(7)
+    tgt = planes_scene(rng)
+    good = abi.PairData(tgt, transformed_copy(tgt, np.linalg.inv(synth.se3(0.1, 0.05, 0.0, 0, 0, 0.01))))
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    empty = abi.PairData(tgt, [None] * 6)
+    P = abi.default_params(used_feature_type="111000", apply_intersection_filter=0)
+    pairs = [good, far, good, empty, far]
+    rb = ctx.icp_batch(pairs, P, trace_cap=24)
+    for i, pr in enumerate(pairs):
+        ro = pyoracle.icp(pr, P, trace_cap=24)[0]
+        compare(ro, rb[i])
+    assert [r.code for r in rb] == [1, -2, 1, -2, -2]
+    for kw, code in ((dict(max_bearable_rotation_d=0.1), -1), (dict(sigma_thre=1e-9), -3), (dict(max_iter_num=0), 0)):
+        P2 = abi.default_params(used_feature_type="111000", **kw)
+        pr = abi.PairData(tgt, transformed_copy(tgt, np.linalg.inv(synth.se3(0.05, 0, 0, 0, 0, 0.03))))
+        ro, rg = pyoracle.icp(pr, P2)[0], ctx.icp(pr, P2)[0]
+        assert ro.code == code
+        compare(ro, rg, check_trace=False)
+
+
+def test_analytic_recovery_on_gpu(ctx):
+    rng = np.random.default_rng(4)
+    tgt = planes_scene(rng)
+    T_true = synth.se3(0.20, -0.15, 0.10, 0.01, -0.008, 0.02)
+    pair = abi.PairData(tgt, transformed_copy(tgt, np.linalg.inv(T_true)))
+    P = abi.default_params(used_feature_type="111000", weight_strategy="1000", converge_translation=1e-7, converge_rotation_d=1e-6,
+                           max_iter_num=30)
+    r = ctx.icp(pair, P)[0]
+    dt, dr = synth.pose_error(r.T_matrix(), T_true)
+    assert r.code == 1 and dt < 2e-5 and dr < 2e-6
+
+
+def test_stale_correspondences_and_tiny_clouds(ctx):
+    """SURVEY B-4: classes with < 3 points are skipped (their correspondence list stays empty), classes that lose all
+    matches keep the stale list; both implementations must agree on counts every iteration."""
+    rng = np.random.default_rng(9)
+    tgt = planes_scene(rng, n_per=300)
+    src = transformed_copy(tgt, np.linalg.inv(synth.se3(0.3, 0.1, 0.0, 0, 0, 0.01)))
+    src[abi.PILLAR] = src[abi.PILLAR][:2]  # below K_min
+    tgt2 = list(tgt)
+    tgt2[abi.GROUND] = tgt2[abi.GROUND][:2]
+    P = abi.default_params(used_feature_type="111000", dis_thre_unit=1.0, dis_thre_min=0.05, dis_thre_update_rate=2.0, max_iter_num=8,
+                           min_neccessary_corr_ratio=0.0, apply_intersection_filter=0)
+    for pr in (abi.PairData(tgt, src), abi.PairData(tgt2, src)):
+        ro = pyoracle.icp(pr, P, trace_cap=16)[0]
+        rg = ctx.icp(pr, P, trace_cap=16)[0]
+        compare(ro, rg)
+
+
+def test_unsupported_options_are_refused(ctx, pairs_small):
+    from mulls_amd import lib
+
+    for kw in (dict(normal_shooting_on=1), dict(apply_motion_undistortion=1), dict(keep_less_source_points=1)):
+        with pytest.raises(lib.MullsError):
+            ctx.icp(pairs_small[0][0], abi.default_params(**kw))
