@@ -1115,7 +1115,7 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 	if (!brute)
 	{
 		// :1209-1232 — three OpenMP sections {ground, roof} {pillar, beam} {facade}, vertex afterwards
-#pragma omp parallel sections if (use_omp)
+#pragma omp parallel sections num_threads(3) if (use_omp)
 		{
 #pragma omp section
 			{
@@ -1173,7 +1173,7 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 			thr_used[c] = thr[c];
 
 			// :1268-1292 — sections {ground} {pillar} {facade, beam}, then roof, vertex serially
-#pragma omp parallel sections if (use_omp)
+#pragma omp parallel sections num_threads(3) if (use_omp)
 		{
 #pragma omp section
 			{

@@ -22,7 +22,7 @@ def compare(ro, rg, check_trace=True):
     dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
     assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
     assert abs(ro.sigma - rg.sigma) <= 1e-6 * max(1.0, abs(ro.sigma))
-    assert ro.confidence == rg.confidence
+    assert ro.confidence == rg.confidence or (np.isnan(ro.confidence) and np.isnan(rg.confidence))
     io, ig = ro.info_matrix(), rg.info_matrix()
     assert np.abs(io - ig).max() <= 1e-6 * np.abs(io).max()
     if check_trace:
