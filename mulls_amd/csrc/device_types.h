@@ -12,6 +12,9 @@
 #define MULLS_NN_PTS 4		  // ... x 4 register-blocked source points per lane = the same 512 points per job
 #define MULLS_TILE 2048		  // target points staged per LDS tile (3 planar float arrays -> 24 KiB)
 
+#define MULLS_MAXCELLS 65536u // cells of one target-class grid (cell table = 256 KiB per cloud)
+#define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
+
 // bits of the per-source-point flag byte
 #define MULLS_F_ALIVE 1u // still part of the source cloud (reference: survived every compaction, cregistration.hpp:1755-1792)
 #define MULLS_F_VALID 2u // member of Corr_f, i.e. enters the estimation (:1794-1830)
@@ -36,6 +39,18 @@ struct CloudDesc
 	uint32_t job_begin;	 // this cloud's range in the job table
 	uint32_t job_end;
 	uint32_t pad_;
+};
+
+// Uniform grid over one cropped target-class cloud (exact fixed-radius search tier).  cell id = (cz*ny + cy)*nx + cx,
+// x fastest, so the cells cx0..cx1 of one (cy,cz) row are one contiguous range of the cell-sorted target array.
+struct GridDesc
+{
+	float ox, oy, oz; // origin = minimum corner of the cloud
+	float inv_h, h;
+	uint32_t nx, ny, nz;
+	uint32_t ncell;
+	uint32_t cell_off; // first entry of this cloud in the batch-wide cell tables (ncell + 1 entries are used)
+	uint32_t pad_[2];
 };
 
 // Per-pair state rewritten by the host before every lock-step iteration (one H2D copy for the whole batch).

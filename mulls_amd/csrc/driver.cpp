@@ -35,6 +35,7 @@ struct mulls_ctx
 	mulls_profile prof{};
 	hipEvent_t ev[10] = {};
 	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
+	int nn_mode = 0;   // 0 auto (grid tier), 1 LDS-tiled brute force, 2 grid
 };
 
 struct mulls_batch
@@ -45,6 +46,7 @@ struct mulls_batch
 	std::vector<PairSetup> setup_h;
 	std::vector<Job> setup_jobs_h;
 	std::vector<Job> jobs_h;
+	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
 	std::string jobs_key;
 	uint32_t njobs = 0;
 	// device
@@ -64,6 +66,12 @@ struct mulls_batch
 	Job *jobs = nullptr;
 	double *partial = nullptr;
 	uint32_t jobs_cap = 0;
+	Job *tjobs = nullptr;
+	uint32_t tjobs_cap = 0;
+	GridDesc *grids = nullptr;
+	float4 *tsorted = nullptr;
+	uint32_t *cell_cnt = nullptr, *cell_start = nullptr;
+	size_t cells_cap = 0; // entries allocated in each of the two cell tables
 	// pinned host mirrors
 	PairState *states_h = nullptr;
 	PairOut *outs_h = nullptr;
@@ -191,6 +199,15 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 				}
 			d.job_end = (uint32_t)B->jobs_h.size();
 		}
+	B->tjobs_h.clear();
+	for (int p = 0; p < B->n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+			if (P->used_feature_type[c] == '1')
+				for (uint32_t s = 0; s < B->descs_h[p * MULLS_NC + c].tgt_n0; s += MULLS_BLOCK)
+				{
+					Job j = {(uint32_t)p, (uint32_t)c, s, 0};
+					B->tjobs_h.push_back(j);
+				}
 	B->njobs = (uint32_t)B->jobs_h.size();
 	B->jobs_key = key;
 }
@@ -308,6 +325,14 @@ extern "C"
 
 	void *mulls_stream(mulls_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+	int mulls_set_nn_mode(mulls_ctx *ctx, int mode)
+	{
+		if (!ctx || mode < 0 || mode > 2)
+			return MULLS_E_INVALID;
+		ctx->nn_mode = mode;
+		return MULLS_OK;
+	}
+
 	void mulls_batch_destroy(mulls_ctx *ctx, mulls_batch *B)
 	{
 		if (!B)
@@ -315,7 +340,8 @@ extern "C"
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
-					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->bbox, B->setup_jobs, B->jobs, B->partial};
+					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->bbox, B->setup_jobs, B->jobs, B->partial,
+					   B->tjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start};
 		for (void *p : dev)
 			if (p)
 				(void)hipFree(p);
@@ -401,6 +427,8 @@ extern "C"
 		A(dmalloc(ctx, &B->outs, (size_t)n));
 		A(dmalloc(ctx, &B->bbox, (size_t)n * 6));
 		A(dmalloc(ctx, &B->setup_jobs, B->setup_jobs_h.size()));
+		A(dmalloc(ctx, &B->grids, (size_t)n * MULLS_NC));
+		A(dmalloc(ctx, &B->tsorted, to));
 		if (rc != MULLS_OK)
 		{
 			mulls_batch_destroy(ctx, B);
@@ -505,12 +533,46 @@ extern "C"
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
+		const bool use_grid = ctx->nn_mode != 1;
+		if (use_grid)
+		{
+			int n_used = 0;
+			for (int c = 0; c < MULLS_NC; c++)
+				n_used += rp.used[c];
+			const size_t cells = (size_t)n * n_used * (MULLS_MAXCELLS + 1u);
+			if (cells > B->cells_cap)
+			{
+				if (B->cell_cnt)
+					(void)hipFree(B->cell_cnt);
+				if (B->cell_start)
+					(void)hipFree(B->cell_start);
+				B->cell_cnt = B->cell_start = nullptr;
+				B->cells_cap = 0;
+				if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK)
+					return MULLS_E_HIP;
+				B->cells_cap = cells;
+			}
+			if (B->tjobs_h.size() > B->tjobs_cap)
+			{
+				if (B->tjobs)
+					(void)hipFree(B->tjobs);
+				B->tjobs = nullptr;
+				if (dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
+					return MULLS_E_HIP;
+				B->tjobs_cap = (uint32_t)B->tjobs_h.size();
+			}
+			HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
+		}
 
-		// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188)
+		// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188), then the target grids
 		evt.begin(&ctx->prof.ms_setup);
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
 		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
-					B->match, B->wd, rp.crop);
+					B->match, B->wd, rp, B->grids);
+		if (use_grid)
+			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
+							  B->tsorted);
 		evt.end();
 
 		std::vector<PairHost> H(n);
@@ -567,7 +629,11 @@ extern "C"
 			if (any_active)
 			{
 				evt.begin(&ctx->prof.ms_nn);
-				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				if (use_grid)
+					launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+								   B->nn_idx, B->nn_d2, B->winner);
+				else
+					launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 				evt.end();
 				evt.begin(&ctx->prof.ms_filter);
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
@@ -635,7 +701,8 @@ extern "C"
 				{
 					if (rp.used[c] && h.alive_prev[c] >= 3 && o.tgt_n[c] >= 3)
 					{
-						ctx->prof.nn_pair_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
+						if (!use_grid)
+							ctx->prof.nn_pair_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
 						ctx->prof.nn_src_pts += h.alive_prev[c];
 						ctx->prof.nn_tgt_unique += o.tgt_n[c];
 						ctx->prof.nn_tgt_pts += (uint64_t)o.tgt_n[c] * (B->descs_h[p * MULLS_NC + c].job_end - B->descs_h[p * MULLS_NC + c].job_begin);
@@ -814,7 +881,19 @@ extern "C"
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6, hipMemcpyHostToDevice, st));
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
-					B->wd, 0);
+					B->wd, *rp, B->grids);
+		if (ctx->nn_mode != 1)
+		{
+			const size_t cells = MULLS_MAXCELLS + 1u;
+			if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK ||
+				dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
+				return MULLS_E_HIP;
+			B->cells_cap = cells;
+			B->tjobs_cap = (uint32_t)B->tjobs_h.size();
+			HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, cells * sizeof(uint32_t), st));
+			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->cell_cnt, B->cell_start, B->tsorted);
+		}
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)
@@ -846,7 +925,11 @@ extern "C"
 				B->states_h[0].thr[c] = dis_thre;
 			hipStream_t st = ctx->stream;
 			hipError_t e = hipMemcpyAsync(B->states, B->states_h, sizeof(PairState), hipMemcpyHostToDevice, st);
-			launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+			if (ctx->nn_mode != 1)
+				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+							   B->nn_idx, B->nn_d2, B->winner);
+			else
+				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
 						  B->winner);
 			const uint32_t off = B->descs_h[cls].src_off;

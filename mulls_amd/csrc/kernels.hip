@@ -120,9 +120,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 													   const float4 *__restrict__ tmp_pos, const float4 *__restrict__ tmp_nrm,
 													   float4 *__restrict__ spos, float4 *__restrict__ snrm, float4 *__restrict__ tpos,
 													   float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, int32_t *__restrict__ match,
-													   float *__restrict__ wd, int crop)
+													   float *__restrict__ wd, RunParams rp, GridDesc *__restrict__ grids)
 {
+	const int crop = rp.crop;
 	__shared__ uint32_t wave_cnt[4];
+	__shared__ float box_red[4][6];
 	const uint32_t pair = blockIdx.x / (MULLS_NC * 2);
 	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
 	const uint32_t side = blockIdx.x & 1;
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 	}
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t running = 0;
+	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 	for (uint32_t base = 0; base < n0; base += MULLS_BLOCK)
 	{
 		const uint32_t i = base + threadIdx.x;
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			{
 				tpos[dst] = p;
 				tnrm[dst] = q;
+				bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+				bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
 			}
 			else
 			{
@@ -201,6 +206,64 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			}
 		}
 		running += total;
+	}
+	if (side && grids)
+	{
+		// bounding box of the surviving target points -> uniform grid descriptor for the grid search tier
+		for (int k = 0; k < 3; k++)
+			for (int off = 32; off > 0; off >>= 1)
+			{
+				bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
+				bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
+			}
+		__syncthreads();
+		if (lane == 0)
+			for (int k = 0; k < 3; k++)
+			{
+				box_red[wave][k] = bmin[k];
+				box_red[wave][3 + k] = bmax[k];
+			}
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			float lo3[3], hi3[3];
+			for (int k = 0; k < 3; k++)
+			{
+				lo3[k] = fminf(fminf(box_red[0][k], box_red[1][k]), fminf(box_red[2][k], box_red[3][k]));
+				hi3[k] = fmaxf(fmaxf(box_red[0][3 + k], box_red[1][3 + k]), fmaxf(box_red[2][3 + k], box_red[3][3 + k]));
+			}
+			GridDesc g;
+			g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
+			g.h = MULLS_GRID_H0;
+			g.nx = g.ny = g.nz = 1;
+			g.ncell = 0;
+			if (running > 0)
+				for (;;)
+				{
+					g.inv_h = 1.0f / g.h;
+					// same float expression as grid_cell() so that the largest coordinate lands in the last cell
+					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
+					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
+					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)MULLS_MAXCELLS)
+						break;
+					g.h *= 1.25f;
+				}
+			else
+				g.inv_h = 1.0f;
+			// cell tables are laid out over the USED classes only: slot = pair * n_used + rank of this class among them
+			uint32_t n_used = 0, rank = 0;
+			for (uint32_t c = 0; c < MULLS_NC; c++)
+			{
+				if (c < cls && rp.used[c])
+					rank++;
+				n_used += rp.used[c] ? 1u : 0u;
+			}
+			g.ncell = (running > 0 && rp.used[cls]) ? g.nx * g.ny * g.nz : 0u;
+			g.cell_off = (pair * n_used + rank) * (MULLS_MAXCELLS + 1u);
+			g.pad_[0] = g.pad_[1] = 0;
+			grids[pair * MULLS_NC + cls] = g;
+		}
 	}
 	if (threadIdx.x == 0)
 	{
@@ -363,6 +426,212 @@ __global__ __launch_bounds__(MULLS_NN_BLOCK) void k_nn(const Job *__restrict__ j
 			matched_cnt++;
 			if (gate) // duplicate rule: the lowest source index claims the target (first-come in the reference's serial walk)
 				atomicMin(&winner[d.tgt_off + idx], key_hi | (unsigned long long)s[u]);
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0 && matched_cnt)
+		atomicAdd(&d.n_matched, matched_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Exact fixed-radius search tier on a uniform grid.  The reference discards every match farther than 2.5*dis_thre
+// (cregistration.hpp:1745), so visiting only the cells that intersect the search ball returns the same nearest
+// neighbour as the kd-tree — provided no candidate inside the ball can be skipped.  That holds by construction:
+// the cell coordinate is a monotone function of the float coordinate (subtract origin, scale, floor, clamp), so every
+// target with |t.x - p.x| <= R lies in a cell between cell(p.x - R) and cell(p.x + R); R carries a relative 1e-4 and
+// an absolute 1e-4 m margin over the float rounding of the distance arithmetic.  Ties on the float distance resolve to
+// the lowest original target index explicitly (the cell-sorted order is not index order).
+namespace
+{
+__device__ __forceinline__ int grid_cell(float v, float o, float inv_h, uint32_t n)
+{
+	const float c = floorf((v - o) * inv_h);
+	return (int)fminf(fmaxf(c, 0.0f), (float)(n - 1u));
+}
+__device__ __forceinline__ uint32_t grid_cell_id(const GridDesc &g, float x, float y, float z)
+{
+	return ((uint32_t)grid_cell(z, g.oz, g.inv_h, g.nz) * g.ny + (uint32_t)grid_cell(y, g.oy, g.inv_h, g.ny)) * g.nx +
+		   (uint32_t)grid_cell(x, g.ox, g.inv_h, g.nx);
+}
+// evaluate every target in the cells intersecting the cube [p - R, p + R]
+__device__ __forceinline__ void grid_scan_box(const GridDesc &g, const uint32_t *__restrict__ cstart, const float4 *__restrict__ ts,
+											   float px, float py, float pz, float R, float &best, int &bi)
+{
+	const float Rm = R * 1.0001f + 1e-4f;
+	const int x0 = grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = grid_cell(px + Rm, g.ox, g.inv_h, g.nx);
+	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
+	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
+	for (int cz = z0; cz <= z1; cz++)
+		for (int cy = y0; cy <= y1; cy++)
+		{
+			const uint32_t row = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx;
+			const uint32_t lo = cstart[row + (uint32_t)x0], hi = cstart[row + (uint32_t)x1 + 1u];
+			for (uint32_t t = lo; t < hi; t++)
+			{
+				const float4 q = ts[t];
+				const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+				const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+				const int idx = __float_as_int(q.w);
+				if (dist < best || (dist == best && idx < bi))
+				{
+					best = dist;
+					bi = idx;
+				}
+			}
+		}
+}
+} // namespace
+
+// histogram of target points per grid cell (one 256-point chunk of one target cloud per workgroup)
+__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_count(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+															 const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
+															 uint32_t *__restrict__ cell_cnt)
+{
+	const Job job = tjobs[blockIdx.x];
+	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t t = job.start + threadIdx.x;
+	if (t >= d.tgt_n)
+		return;
+	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+	const float4 p = tpos[d.tgt_off + t];
+	atomicAdd(&cell_cnt[g.cell_off + grid_cell_id(g, p.x, p.y, p.z)], 1u);
+}
+
+// exclusive scan of one cloud's cell histogram (one workgroup per (pair, class)); leaves the counters zeroed so that
+// k_grid_scatter can reuse them as insertion cursors
+__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scan(const GridDesc *__restrict__ grids, RunParams rp,
+															uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ cell_start)
+{
+	__shared__ uint32_t wave_tot[4];
+	const uint32_t cls = blockIdx.x % MULLS_NC;
+	if (!rp.used[cls])
+		return;
+	const GridDesc g = grids[blockIdx.x];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < g.ncell; base += MULLS_BLOCK * 4)
+	{
+		// four consecutive cells per lane
+		const uint32_t c0 = base + threadIdx.x * 4;
+		uint32_t v[4], sum = 0;
+		for (int k = 0; k < 4; k++)
+		{
+			v[k] = (c0 + k < g.ncell) ? cell_cnt[g.cell_off + c0 + k] : 0u;
+			sum += v[k];
+		}
+		uint32_t incl = sum;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if (lane >= off)
+				incl += o;
+		}
+		__syncthreads();
+		if (lane == 63)
+			wave_tot[wave] = incl;
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_tot[w];
+			total += wave_tot[w];
+		}
+		uint32_t ex = running + wbase + incl - sum;
+		for (int k = 0; k < 4; k++)
+			if (c0 + k < g.ncell)
+			{
+				cell_start[g.cell_off + c0 + k] = ex;
+				cell_cnt[g.cell_off + c0 + k] = 0u;
+				ex += v[k];
+			}
+		running += total;
+	}
+	if (threadIdx.x == 0)
+		cell_start[g.cell_off + g.ncell] = running;
+}
+
+// counting-sort scatter: target positions ordered by cell, original index carried in .w
+__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scatter(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+															   const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
+															   uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ cell_start,
+															   float4 *__restrict__ tsorted)
+{
+	const Job job = tjobs[blockIdx.x];
+	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t t = job.start + threadIdx.x;
+	if (t >= d.tgt_n)
+		return;
+	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+	const float4 p = tpos[d.tgt_off + t];
+	const uint32_t cell = g.cell_off + grid_cell_id(g, p.x, p.y, p.z);
+	const uint32_t slot = cell_start[cell] + atomicAdd(&cell_cnt[cell], 1u);
+	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
+}
+
+// Correspondence search, grid tier: one lane per source point (MULLS_SRC_PER_THREAD points per lane, one after the
+// other), same fused rigid step and same outputs as k_nn.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+														  const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
+														  float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
+														  const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
+														  const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+														  unsigned long long *__restrict__ winner)
+{
+	const Job job = jobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
+	const bool called = class_called(rp, d, job.cls);
+	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+	const uint32_t *__restrict__ cstart = cell_start + g.cell_off;
+	const float4 *__restrict__ ts = tsorted + d.tgt_off;
+	const float r = 2.5f * ps.thr[job.cls];	 // filter_dis_times * dis_thre (float), cregistration.hpp:1745
+	const double maxd = (double)r;
+	const double max_dist_sqr = maxd * maxd;
+	const bool gate = alive_cur >= 500u;
+	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	const float m = fminf(r, g.h); // first probe: the 3x3x3 neighbourhood at most
+	uint32_t matched_cnt = 0;
+#pragma unroll
+	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	{
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		if (s >= src_n || !(flag[d.src_off + s] & MULLS_F_ALIVE))
+			continue;
+		float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+		const double *T = ps.T;
+		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+		const float px = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+		const float py = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+		const float pz = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+		const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+		const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+		const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+		spos[d.src_off + s] = make_float4(px, py, pz, p.w);
+		snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+		if (!called)
+			continue;
+		float best = __builtin_inff();
+		int bi = -1;
+		grid_scan_box(g, cstart, ts, px, py, pz, m, best, bi);
+		if (!(bi >= 0 && best <= m * m))
+		{
+			// nothing inside the first probe: widen to the current best distance, or to the rejection radius
+			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
+			grid_scan_box(g, cstart, ts, px, py, pz, R, best, bi);
+		}
+		const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
+		nn_idx[d.src_off + s] = matched ? bi : -1;
+		nn_d2[d.src_off + s] = best;
+		if (matched)
+		{
+			matched_cnt++;
+			if (gate)
+				atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
 		}
 	}
 	for (int off = 32; off > 0; off >>= 1)
@@ -848,11 +1117,28 @@ void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const Clo
 }
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
-				 int32_t *match, float *wd, int crop)
+				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids)
 {
 	if (npairs)
 		hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm,
-						   tpos, tnrm, flag, match, wd, crop);
+						   tpos, tnrm, flag, match, wd, rp, grids);
+}
+void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
+					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted)
+{
+	if (!ntjobs || !npairs)
+		return;
+	hipLaunchKernelGGL(k_grid_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt);
+	hipLaunchKernelGGL(k_grid_scan, dim3(npairs * MULLS_NC), dim3(MULLS_BLOCK), 0, st, grids, rp, cell_cnt, cell_start);
+	hipLaunchKernelGGL(k_grid_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt, cell_start, tsorted);
+}
+void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
+					float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag,
+					int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_nn_grid, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted, flag,
+						   nn_idx, nn_d2, winner);
 }
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 			   float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)

@@ -38,6 +38,7 @@ def load():
     lib.mulls_last_error.restype = C.c_char_p
     lib.mulls_set_profiling.argtypes = [vp, C.c_int]
     lib.mulls_get_profile.argtypes = [vp, C.POINTER(abi.Profile)]
+    lib.mulls_set_nn_mode.argtypes = [vp, C.c_int]
     lib.mulls_stream.argtypes = [vp]
     lib.mulls_stream.restype = vp
     lib.mulls_icp.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
@@ -56,7 +57,7 @@ def load():
 
 EXPORTS = [
     "mulls_default_params", "mulls_create", "mulls_destroy", "mulls_last_error", "mulls_set_profiling", "mulls_get_profile",
-    "mulls_stream", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
+    "mulls_stream", "mulls_set_nn_mode", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
     "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate",
 ]
 
@@ -88,6 +89,10 @@ class Context:
 
     def set_profiling(self, on):
         self._check(self.lib.mulls_set_profiling(self.h, int(on)), "mulls_set_profiling")
+
+    def set_nn_mode(self, mode):
+        """0 auto (grid), 1 LDS-tiled brute force, 2 uniform grid."""
+        self._check(self.lib.mulls_set_nn_mode(self.h, int(mode)), "mulls_set_nn_mode")
 
     def profile(self):
         p = abi.Profile()

@@ -16,12 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
-def ctx():
-    """HIP context on device 0.  No fallback: if the library or the device is missing the gpu tests fail."""
+@pytest.fixture(scope="session", params=[2, 1], ids=["grid", "brute"])
+def ctx(request):
+    """HIP context on device 0, once per correspondence-search tier (uniform grid / LDS-tiled brute force).
+    No fallback: if the library or the device is missing the gpu tests fail."""
     from mulls_amd import lib
 
     c = lib.Context(0)
+    c.set_nn_mode(request.param)
     yield c
     c.close()
 

@@ -29,7 +29,12 @@ print("PARITY", "OK" if ok else "MISMATCH")
 
 # timing: batch of replicated pairs, fixed 20 iterations
 Pb = abi.kitti_params(converge_translation=0.0, converge_rotation_d=0.0)
-for nb in (1, 16, 64, 256):
+import sys as _s
+modes = [(2, "grid"), (1, "brute")]
+for mode, name in modes:
+  ctx.set_nn_mode(mode); print("== nn tier:", name)
+  for nb in (1, 16, 64, 256, 1024):
+    if mode == 1 and nb > 256: continue
     batch = ctx.batch([pairs[i % 4][0] for i in range(nb)])
     res = batch.run(Pb)
     t = time.time(); reps = 3
@@ -37,9 +42,8 @@ for nb in (1, 16, 64, 256):
         res = batch.run(Pb)
     dt = (time.time() - t) / reps
     print("batch %4d: %.2f ms/run  %.1f reg/s  iters %d code %d" % (nb, dt * 1e3, nb / dt, res[0].iters, res[0].code))
-    if nb == 256:
+    if nb >= 256:
         ctx.set_profiling(True); batch.run(Pb); pf = ctx.profile(); ctx.set_profiling(False)
-        print("profile ms: setup %.3f nn %.3f filter %.3f accum %.3f resid %.3f launches %d evals %.3e" % (
-            pf.ms_setup, pf.ms_nn, pf.ms_filter, pf.ms_accum, pf.ms_residual, pf.launches_nn, pf.nn_pair_evals))
-        print("nn: %.3f Geval/s, %.2f Tlaneop/s (9.3 ops/eval)" % (pf.nn_pair_evals / pf.ms_nn / 1e6, pf.nn_pair_evals * 9.3 / pf.ms_nn / 1e9))
+        print("   profile ms: setup %.3f nn %.3f filter %.3f accum %.3f resid %.3f launches %d" % (
+            pf.ms_setup, pf.ms_nn, pf.ms_filter, pf.ms_accum, pf.ms_residual, pf.launches_nn))
     batch.close()
