@@ -168,7 +168,7 @@ const char *mulls_last_error(const mulls_ctx *ctx);
 int mulls_set_profiling(mulls_ctx *ctx, int on);
 int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
 /* correspondence-search tier: 0 = auto (exact uniform-grid fixed-radius search), 1 = LDS-tiled brute force,
- * 2 = grid.  Both tiers return identical correspondences (tests/test_gpu_stages.py). */
+ * 2 = uniform grid.  Both tiers are exact and return identical correspondences (tests/test_gpu_stages.py). */
 int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
 /* raw hipStream_t the library launches on (so callers can bracket it with their own events) */
 void *mulls_stream(mulls_ctx *ctx);

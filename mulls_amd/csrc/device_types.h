@@ -13,6 +13,8 @@
 #define MULLS_TILE 2048		  // target points staged per LDS tile (3 planar float arrays -> 24 KiB)
 
 #define MULLS_MAXCELLS 65536u // cells of one target-class grid (cell table = 256 KiB per cloud)
+#define MULLS_MAXROWS 4096u   // (cy,cz) rows of one grid
+#define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
 #define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
 
 // bits of the per-source-point flag byte

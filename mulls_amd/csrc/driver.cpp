@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -35,7 +36,7 @@ struct mulls_ctx
 	mulls_profile prof{};
 	hipEvent_t ev[10] = {};
 	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
-	int nn_mode = 0;   // 0 auto (grid tier), 1 LDS-tiled brute force, 2 grid
+	int nn_mode = 0;   // 0 auto (uniform grid), 1 LDS-tiled brute force, 2 uniform grid
 };
 
 struct mulls_batch
@@ -72,9 +73,13 @@ struct mulls_batch
 	float4 *tsorted = nullptr;
 	uint32_t *cell_cnt = nullptr, *cell_start = nullptr;
 	size_t cells_cap = 0; // entries allocated in each of the two cell tables
-	// pinned host mirrors
+	// pinned, device-mapped host memory (zero-copy): per-iteration pair states in, per-pair sums out, completion epoch
 	PairState *states_h = nullptr;
 	PairOut *outs_h = nullptr;
+	volatile uint32_t *epoch_h = nullptr;
+	uint32_t *epoch_dev = nullptr;
+	uint32_t epoch = 0;
+	uint32_t *ticket = nullptr; // device: arrival counter of k_finish
 	uint32_t *bbox_h = nullptr;
 };
 
@@ -212,6 +217,35 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 	B->jobs_key = key;
 }
 
+// Wait until k_finish has published the current epoch.  The host spins on the pinned word (a few microseconds of latency
+// instead of an interrupt-driven stream synchronisation); a stalled device is caught by falling back to
+// hipStreamSynchronize, which also surfaces asynchronous HIP errors.
+int wait_epoch(mulls_ctx *ctx, mulls_batch *B)
+{
+	const uint32_t want = B->epoch;
+	if (!ctx->profiling)
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint64_t spins = 0;; spins++)
+		{
+			if (*B->epoch_h == want)
+			{
+				std::atomic_thread_fence(std::memory_order_acquire);
+				return MULLS_OK;
+			}
+			if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+				break;
+		}
+	}
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	if (*B->epoch_h != want)
+	{
+		ctx->err = "device did not publish the iteration epoch";
+		return MULLS_E_HIP;
+	}
+	return MULLS_OK;
+}
+
 struct EvTimer
 {
 	mulls_ctx *ctx;
@@ -340,7 +374,7 @@ extern "C"
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
-					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->bbox, B->setup_jobs, B->jobs, B->partial,
+					   B->nn_d2, B->winner, B->descs, B->setup, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
 					   B->tjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start};
 		for (void *p : dev)
 			if (p)
@@ -351,6 +385,8 @@ extern "C"
 			(void)hipHostFree(B->outs_h);
 		if (B->bbox_h)
 			(void)hipHostFree(B->bbox_h);
+		if (B->epoch_h)
+			(void)hipHostFree((void *)B->epoch_h);
 		delete B;
 	}
 
@@ -423,8 +459,7 @@ extern "C"
 		A(dmalloc(ctx, &B->winner, to));
 		A(dmalloc(ctx, &B->descs, (size_t)n * MULLS_NC));
 		A(dmalloc(ctx, &B->setup, (size_t)n));
-		A(dmalloc(ctx, &B->states, (size_t)n));
-		A(dmalloc(ctx, &B->outs, (size_t)n));
+		A(dmalloc(ctx, &B->ticket, 1));
 		A(dmalloc(ctx, &B->bbox, (size_t)n * 6));
 		A(dmalloc(ctx, &B->setup_jobs, B->setup_jobs_h.size()));
 		A(dmalloc(ctx, &B->grids, (size_t)n * MULLS_NC));
@@ -434,14 +469,21 @@ extern "C"
 			mulls_batch_destroy(ctx, B);
 			return rc;
 		}
-		if (hipHostMalloc((void **)&B->states_h, sizeof(PairState) * n, hipHostMallocDefault) != hipSuccess ||
-			hipHostMalloc((void **)&B->outs_h, sizeof(PairOut) * n, hipHostMallocDefault) != hipSuccess ||
-			hipHostMalloc((void **)&B->bbox_h, sizeof(uint32_t) * 6 * n, hipHostMallocDefault) != hipSuccess)
+		if (hipHostMalloc((void **)&B->states_h, sizeof(PairState) * n, hipHostMallocMapped) != hipSuccess ||
+			hipHostMalloc((void **)&B->outs_h, sizeof(PairOut) * n, hipHostMallocMapped) != hipSuccess ||
+			hipHostMalloc((void **)&B->epoch_h, 64, hipHostMallocMapped) != hipSuccess ||
+			hipHostMalloc((void **)&B->bbox_h, sizeof(uint32_t) * 6 * n, hipHostMallocDefault) != hipSuccess ||
+			hipHostGetDevicePointer((void **)&B->states, B->states_h, 0) != hipSuccess ||
+			hipHostGetDevicePointer((void **)&B->outs, B->outs_h, 0) != hipSuccess ||
+			hipHostGetDevicePointer((void **)&B->epoch_dev, (void *)B->epoch_h, 0) != hipSuccess ||
+			hipMemset(B->ticket, 0, sizeof(uint32_t)) != hipSuccess)
 		{
-			ctx->err = "hipHostMalloc failed";
+			ctx->err = "pinned host memory setup failed";
 			mulls_batch_destroy(ctx, B);
 			return MULLS_E_HIP;
 		}
+		*B->epoch_h = 0;
+		std::memset(B->states_h, 0, sizeof(PairState) * n);
 		for (int p = 0; p < n; p++)
 			for (int k = 0; k < 6; k++)
 				B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
@@ -600,6 +642,21 @@ extern "C"
 			std::memset(results[p].ntgt0, 0, sizeof(results[p].ntgt0));
 		}
 
+		if (P->max_iter_num <= 0)
+		{
+			// the iteration loop never runs (process code 0): still report the post-filter cloud sizes
+			std::vector<CloudDesc> back(B->descs_h.size());
+			HIPCHK(ctx, hipMemcpyAsync(back.data(), B->descs, sizeof(CloudDesc) * back.size(), hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			evt.collect();
+			for (int p = 0; p < n; p++)
+				for (int c = 0; c < MULLS_NC; c++)
+				{
+					results[p].nsrc0[c] = back[p * MULLS_NC + c].src_n;
+					results[p].ntgt0[c] = back[p * MULLS_NC + c].tgt_n;
+				}
+		}
+
 		int lock_iter = 0;
 		for (;; lock_iter++)
 		{
@@ -625,7 +682,6 @@ extern "C"
 				s.want_residual = h.want_residual ? 1 : 0;
 				s.pad_ = 0;
 			}
-			HIPCHK(ctx, hipMemcpyAsync(B->states, B->states_h, sizeof(PairState) * n, hipMemcpyHostToDevice, st));
 			if (any_active)
 			{
 				evt.begin(&ctx->prof.ms_nn);
@@ -644,10 +700,10 @@ extern "C"
 			}
 			evt.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs);
+			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->ticket, B->epoch_dev, ++B->epoch);
 			evt.end();
-			HIPCHK(ctx, hipMemcpyAsync(B->outs_h, B->outs, sizeof(PairOut) * n, hipMemcpyDeviceToHost, st));
-			HIPCHK(ctx, hipStreamSynchronize(st));
+			if (wait_epoch(ctx, B) != MULLS_OK)
+				return MULLS_E_HIP;
 			evt.collect();
 
 			for (int p = 0; p < n; p++)
@@ -775,6 +831,7 @@ extern "C"
 			}
 		}
 
+		HIPCHK(ctx, hipStreamSynchronize(st));
 		const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
 		for (int p = 0; p < n; p++)
 		{
@@ -924,7 +981,7 @@ extern "C"
 			for (int c = 0; c < MULLS_NC; c++)
 				B->states_h[0].thr[c] = dis_thre;
 			hipStream_t st = ctx->stream;
-			hipError_t e = hipMemcpyAsync(B->states, B->states_h, sizeof(PairState), hipMemcpyHostToDevice, st);
+			hipError_t e = hipSuccess;
 			if (ctx->nn_mode != 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
@@ -997,8 +1054,6 @@ extern "C"
 			if (e == hipSuccess && corr_d2)
 				e = hipMemcpyAsync(dcd, corr_d2, sizeof(float) * ncorr, hipMemcpyHostToDevice, st);
 			identity_state(&B->states_h[0], iter_num);
-			if (e == hipSuccess)
-				e = hipMemcpyAsync(B->states, B->states_h, sizeof(PairState), hipMemcpyHostToDevice, st);
 			const uint32_t off = B->descs_h[cls].src_off;
 			if (e == hipSuccess)
 			{
@@ -1006,10 +1061,8 @@ extern "C"
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
 				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs);
+				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->ticket, B->epoch_dev, ++B->epoch);
 			}
-			if (e == hipSuccess)
-				e = hipMemcpyAsync(B->outs_h, B->outs, sizeof(PairOut), hipMemcpyDeviceToHost, st);
 			std::vector<float> wall(src->n);
 			if (e == hipSuccess)
 				e = hipMemcpyAsync(wall.data(), B->wd + off, sizeof(float) * src->n, hipMemcpyDeviceToHost, st);

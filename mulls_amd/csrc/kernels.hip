@@ -245,7 +245,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
 					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
 					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
-					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)MULLS_MAXCELLS)
+					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)MULLS_MAXCELLS &&
+						(unsigned long long)g.ny * g.nz <= (unsigned long long)MULLS_MAXROWS)
 						break;
 					g.h *= 1.25f;
 				}
@@ -454,32 +455,107 @@ __device__ __forceinline__ uint32_t grid_cell_id(const GridDesc &g, float x, flo
 	return ((uint32_t)grid_cell(z, g.oz, g.inv_h, g.nz) * g.ny + (uint32_t)grid_cell(y, g.oy, g.inv_h, g.ny)) * g.nx +
 		   (uint32_t)grid_cell(x, g.ox, g.inv_h, g.nx);
 }
-// evaluate every target in the cells intersecting the cube [p - R, p + R]
+// Evaluate every target in the cells intersecting the cube [p - R, p + R].  The MULLS_GRID_GROUP (= 16) lanes of a
+// sub-group share one query.  Rows (fixed cy,cz; cells x0..x1 are one contiguous range of the cell-sorted array) are
+// taken 16 at a time: lane j fetches the bounds of row j (16 rows per memory latency), then every lane issues its
+// first candidate load of 8 rows back to back (coalesced 256-B segments), and only rows holding more than 16
+// candidates loop further.  Chunks whose 16 rows are all empty cost one latency and no candidate work.
 __device__ __forceinline__ void grid_scan_box(const GridDesc &g, const uint32_t *__restrict__ cstart, const float4 *__restrict__ ts,
-											   float px, float py, float pz, float R, float &best, int &bi)
+											   float px, float py, float pz, float R, uint32_t sub, float &best, int &bi)
 {
 	const float Rm = R * 1.0001f + 1e-4f;
 	const int x0 = grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = grid_cell(px + Rm, g.ox, g.inv_h, g.nx);
 	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
 	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
-	for (int cz = z0; cz <= z1; cz++)
-		for (int cy = y0; cy <= y1; cy++)
+	const int nyc = y1 - y0 + 1, nrows = nyc * (z1 - z0 + 1);
+	const uint32_t gshift = (threadIdx.x & 63u) & ~(MULLS_GRID_GROUP - 1u); // first lane of this sub-group inside its wave
+	for (int base = 0; base < nrows; base += (int)MULLS_GRID_GROUP)
+	{
+		const int j = base + (int)sub;
+		uint32_t lo = 0, hi = 0;
+		if (j < nrows)
 		{
-			const uint32_t row = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx;
-			const uint32_t lo = cstart[row + (uint32_t)x0], hi = cstart[row + (uint32_t)x1 + 1u];
-			for (uint32_t t = lo; t < hi; t++)
+			const uint32_t row = ((uint32_t)(z0 + j / nyc) * g.ny + (uint32_t)(y0 + j % nyc)) * g.nx;
+			lo = cstart[row + (uint32_t)x0];
+			hi = cstart[row + (uint32_t)x1 + 1u];
+		}
+		const uint32_t nonempty = (uint32_t)(__ballot(hi > lo) >> gshift) & 0xffffu; // per sub-group: which of its 16 rows hold points
+		if (!nonempty)
+			continue;
+#pragma unroll
+		for (int half = 0; half < 2; half++) // 8 rows at a time keeps the register footprint at 8 float4 of loads in flight
+		{
+			if (!((nonempty >> (8 * half)) & 0xffu))
+				continue;
+			float4 q[8];
+			bool ok[8];
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
 			{
-				const float4 q = ts[t];
-				const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-				const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
-				const int idx = __float_as_int(q.w);
-				if (dist < best || (dist == best && idx < bi))
+				const uint32_t t = __shfl(lo, 8 * half + jj, MULLS_GRID_GROUP) + sub;
+				ok[jj] = t < __shfl(hi, 8 * half + jj, MULLS_GRID_GROUP);
+				if (ok[jj])
+					q[jj] = ts[t];
+			}
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				if (ok[jj])
 				{
-					best = dist;
-					bi = idx;
+					const float dx = px - q[jj].x, dy = py - q[jj].y, dz = pz - q[jj].z;
+					const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+					const int idx = __float_as_int(q[jj].w);
+					if (dist < best || (dist == best && idx < bi))
+					{
+						best = dist;
+						bi = idx;
+					}
 				}
+		}
+		// rows holding more than 16 candidates: four loads in flight per lane and trip
+		for (uint32_t rem = nonempty; rem; rem &= rem - 1u)
+		{
+			const int jj = __ffs((int)rem) - 1;
+			const uint32_t lo_j = __shfl(lo, jj, MULLS_GRID_GROUP), hi_j = __shfl(hi, jj, MULLS_GRID_GROUP);
+			for (uint32_t t = lo_j + sub + MULLS_GRID_GROUP; t < hi_j; t += 4 * MULLS_GRID_GROUP)
+			{
+				float4 c[4];
+				bool v[4];
+#pragma unroll
+				for (int w = 0; w < 4; w++)
+				{
+					v[w] = t + w * MULLS_GRID_GROUP < hi_j;
+					if (v[w])
+						c[w] = ts[t + w * MULLS_GRID_GROUP];
+				}
+#pragma unroll
+				for (int w = 0; w < 4; w++)
+					if (v[w])
+					{
+						const float dx = px - c[w].x, dy = py - c[w].y, dz = pz - c[w].z;
+						const float dist = (dx * dx + dy * dy) + dz * dz;
+						const int idx = __float_as_int(c[w].w);
+						if (dist < best || (dist == best && idx < bi))
+						{
+							best = dist;
+							bi = idx;
+						}
+					}
 			}
 		}
+	}
+}
+// lexicographic (distance, original index) minimum over the lanes of one sub-group; result in every lane
+__device__ __forceinline__ void group_min(float &best, int &bi)
+{
+#pragma unroll
+	for (int mask = MULLS_GRID_GROUP / 2; mask > 0; mask >>= 1)
+	{
+		const float ob = __shfl_xor(best, mask, MULLS_GRID_GROUP);
+		const int oi = __shfl_xor(bi, mask, MULLS_GRID_GROUP);
+		const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+		best = take ? ob : best;
+		bi = take ? oi : bi;
+	}
 }
 } // namespace
 
@@ -570,8 +646,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scatter(const Job *__restr
 	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
-// Correspondence search, grid tier: one lane per source point (MULLS_SRC_PER_THREAD points per lane, one after the
-// other), same fused rigid step and same outputs as k_nn.
+// Correspondence search, grid tier.  A 16-lane sub-group (4 per wave64, 16 per workgroup) owns one source point at a
+// time: every lane applies the same fused rigid step (wave-uniform loads), the sub-group sweeps the candidate rows of
+// the 3x3x3 cell neighbourhood with coalesced loads, reduces (distance, index) with 4 xor-shuffles, and — only when
+// nothing lies within one cell edge — widens the sweep to the current best distance or the rejection radius.
+// Outputs are identical to k_nn.
 __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
 														  const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 														  float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
@@ -589,49 +668,60 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	const uint32_t *__restrict__ cstart = cell_start + g.cell_off;
 	const float4 *__restrict__ ts = tsorted + d.tgt_off;
-	const float r = 2.5f * ps.thr[job.cls];	 // filter_dis_times * dis_thre (float), cregistration.hpp:1745
+	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
 	const double maxd = (double)r;
 	const double max_dist_sqr = maxd * maxd;
 	const bool gate = alive_cur >= 500u;
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
-	const float m = fminf(r, g.h); // first probe: the 3x3x3 neighbourhood at most
+	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
+	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
+	const double T0 = ps.T[0], T1 = ps.T[1], T2 = ps.T[2], T3 = ps.T[3], T4 = ps.T[4], T5 = ps.T[5], T6 = ps.T[6], T7 = ps.T[7],
+				 T8 = ps.T[8], T9 = ps.T[9], T10 = ps.T[10], T11 = ps.T[11];
 	uint32_t matched_cnt = 0;
-#pragma unroll
-	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_BLOCK / MULLS_GRID_GROUP)
 	{
-		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
-		if (s >= src_n || !(flag[d.src_off + s] & MULLS_F_ALIVE))
+		const uint32_t s = job.start + k;
+		if (s >= src_n)
+			break;
+		if (!(flag[d.src_off + s] & MULLS_F_ALIVE))
 			continue;
-		float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
-		const double *T = ps.T;
+		const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
 		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
-		const float px = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
-		const float py = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
-		const float pz = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-		const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
-		const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
-		const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
-		spos[d.src_off + s] = make_float4(px, py, pz, p.w);
-		snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+		const float px = (float)(T0 * x + T1 * y + T2 * z + T3);
+		const float py = (float)(T4 * x + T5 * y + T6 * z + T7);
+		const float pz = (float)(T8 * x + T9 * y + T10 * z + T11);
+		if (sub == 0)
+		{
+			const float onx = (float)(T0 * nx + T1 * ny + T2 * nz);
+			const float ony = (float)(T4 * nx + T5 * ny + T6 * nz);
+			const float onz = (float)(T8 * nx + T9 * ny + T10 * nz);
+			spos[d.src_off + s] = make_float4(px, py, pz, p.w);
+			snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+		}
 		if (!called)
 			continue;
 		float best = __builtin_inff();
 		int bi = -1;
-		grid_scan_box(g, cstart, ts, px, py, pz, m, best, bi);
+		grid_scan_box(g, cstart, ts, px, py, pz, m, sub, best, bi); // first probe: at most 3x3 rows of 3 cells
+		group_min(best, bi);
 		if (!(bi >= 0 && best <= m * m))
 		{
 			// nothing inside the first probe: widen to the current best distance, or to the rejection radius
 			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
-			grid_scan_box(g, cstart, ts, px, py, pz, R, best, bi);
+			grid_scan_box(g, cstart, ts, px, py, pz, R, sub, best, bi);
+			group_min(best, bi);
 		}
-		const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
-		nn_idx[d.src_off + s] = matched ? bi : -1;
-		nn_d2[d.src_off + s] = best;
-		if (matched)
+		if (sub == 0)
 		{
-			matched_cnt++;
-			if (gate)
-				atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
+			const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
+			nn_idx[d.src_off + s] = matched ? bi : -1;
+			nn_d2[d.src_off + s] = best;
+			if (matched)
+			{
+				matched_cnt++;
+				if (gate)
+					atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
+			}
 		}
 	}
 	for (int off = 32; off > 0; off >>= 1)
@@ -1033,14 +1123,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 // ---------------------------------------------------------------------------------------------------------------
 // One workgroup per pair: sum the per-job partials of every class in job order, then roll the per-class counters
 // over to the next iteration.
-__global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
-														 const double *__restrict__ partial, PairOut *__restrict__ out)
+//
+// `states` and `out` live in pinned host memory (zero-copy): the per-pair records cross PCIe directly, with no
+// copy-engine command and no stream synchronisation per iteration.  Completion is published through a host-visible
+// epoch word: every workgroup makes its stores system-visible, takes a ticket, and the last one to arrive writes the
+// epoch the host is spinning on.
+namespace
 {
-	const uint32_t pair = blockIdx.x;
-	const PairState &ps = states[pair];
-	if (!ps.active && !ps.want_residual)
-		return;
-	CloudDesc *pd = descs + pair * MULLS_NC;
+__device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, const RunParams &rp, const double *__restrict__ partial,
+											 PairOut &o)
+{
 	if (threadIdx.x < MULLS_NC * MULLS_NTERM)
 	{
 		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
@@ -1048,7 +1140,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ 
 		if (rp.used[c])
 			for (uint32_t j = pd[c].job_begin; j < pd[c].job_end; j++)
 				sum += partial[(size_t)j * MULLS_NTERM + t];
-		out[pair].sums[c][t] = sum;
+		o.sums[c][t] = sum;
 	}
 	__syncthreads();
 	if (threadIdx.x < MULLS_NC)
@@ -1066,10 +1158,33 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ 
 			d.valid_next = 0;
 			d.n_matched = 0;
 		}
-		out[pair].n_valid[c] = d.n_valid;
-		out[pair].n_alive[c] = d.alive_cur;
-		out[pair].src_n[c] = d.src_n;
-		out[pair].tgt_n[c] = d.tgt_n;
+		o.n_valid[c] = d.n_valid;
+		o.n_alive[c] = d.alive_cur;
+		o.src_n[c] = d.src_n;
+		o.tgt_n[c] = d.tgt_n;
+	}
+}
+} // namespace
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
+														 const double *__restrict__ partial, PairOut *__restrict__ out, uint32_t *__restrict__ ticket,
+														 volatile uint32_t *host_epoch, uint32_t epoch)
+{
+	const uint32_t pair = blockIdx.x;
+	const int active = states[pair].active, want_residual = states[pair].want_residual;
+	if (active || want_residual) // uniform per workgroup
+		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair]);
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		const uint32_t t = atomicAdd(ticket, 1u);
+		if (t == gridDim.x - 1u)
+		{
+			*ticket = 0u; // re-armed for the next launch (stream order: nobody else touches it before)
+			__threadfence_system();
+			*host_epoch = epoch;
+		}
 	}
 }
 
@@ -1162,10 +1277,10 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial);
 }
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
-				   PairOut *out)
+				   PairOut *out, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch)
 {
 	if (npairs)
-		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out);
+		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, ticket, host_epoch, epoch);
 }
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12)
 {
