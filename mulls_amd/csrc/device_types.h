@@ -14,7 +14,10 @@
 
 #define MULLS_MAXCELLS 65536u // cells of one target-class grid (cell table = 256 KiB per cloud)
 #define MULLS_MAXROWS 4096u   // (cy,cz) rows of one grid
+#define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
+#define MULLS_LDS_MAXPTS 10240u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB)
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
+#define MULLS_CELL_STRIDE (MULLS_MAXCELLS + 16u) // entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned)
 #define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
 
 // bits of the per-source-point flag byte
@@ -64,7 +67,7 @@ struct PairState
 	int32_t iter;	 // iteration number i (feeds the adaptive range weight and the residual-weight gate)
 	int32_t active;	 // 1: run search + estimation this iteration
 	int32_t want_residual; // 1: run the posterior residual pass instead (pair already converged)
-	int32_t pad_;
+	int32_t pad_[3];	   // sizeof(PairState) = 192, a multiple of 16 (k_push_states moves uint4 words)
 };
 
 struct PairSetup // written once per run
@@ -105,5 +108,7 @@ struct RunParams
 	uint8_t pad_[3];
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
+	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging
+	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

@@ -36,7 +36,7 @@ struct mulls_ctx
 	mulls_profile prof{};
 	hipEvent_t ev[10] = {};
 	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
-	int nn_mode = 0;   // 0 auto (uniform grid), 1 LDS-tiled brute force, 2 uniform grid
+	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 
 struct mulls_batch
@@ -60,7 +60,8 @@ struct mulls_batch
 	unsigned long long *winner = nullptr;
 	CloudDesc *descs = nullptr;
 	PairSetup *setup = nullptr;
-	PairState *states = nullptr;
+	PairState *states = nullptr;	 // HBM copy of the pair states (filled by k_push_states every iteration)
+	PairState *states_pin = nullptr; // device address of the pinned host array states_h
 	PairOut *outs = nullptr;
 	uint32_t *bbox = nullptr;
 	Job *setup_jobs = nullptr;
@@ -246,6 +247,38 @@ int wait_epoch(mulls_ctx *ctx, mulls_batch *B)
 	return MULLS_OK;
 }
 
+// cell budget of the LDS tier: whatever the 160 KiB leave free next to the staged points (14 B each) and the query block
+uint32_t lds_cells_for(uint32_t cap)
+{
+	const long free_bytes = 160L * 1024L - (long)MULLS_SRC_PER_BLOCK * 16L - (long)cap * 14L - 64L;
+	long cells = free_bytes / 2 - 8;
+	cells = std::min<long>(cells, (long)MULLS_MAXCELLS);
+	return (uint32_t)std::max<long>(cells, 4096);
+}
+
+// search tier of a run: 0 = LDS-tiled brute force, 1 = uniform grid in global memory, 2 = uniform grid staged in LDS
+int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[MULLS_NC], uint32_t *lds_cap)
+{
+	uint32_t max_t = 0;
+	for (int p = 0; p < B->n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+			if (used[c])
+				max_t = std::max(max_t, B->descs_h[p * MULLS_NC + c].tgt_n0);
+	*lds_cap = std::max(8u, (max_t + 7u) & ~7u);
+	const bool fits = max_t <= MULLS_LDS_MAXPTS;
+	switch (ctx->nn_mode)
+	{
+	case 1:
+		return 0;
+	case 2:
+		return 1;
+	case 3:
+		return fits ? 2 : -1;
+	default:
+		return fits ? 2 : 1;
+	}
+}
+
 struct EvTimer
 {
 	mulls_ctx *ctx;
@@ -361,7 +394,7 @@ extern "C"
 
 	int mulls_set_nn_mode(mulls_ctx *ctx, int mode)
 	{
-		if (!ctx || mode < 0 || mode > 2)
+		if (!ctx || mode < 0 || mode > 3)
 			return MULLS_E_INVALID;
 		ctx->nn_mode = mode;
 		return MULLS_OK;
@@ -374,7 +407,7 @@ extern "C"
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
-					   B->nn_d2, B->winner, B->descs, B->setup, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
+					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
 					   B->tjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start};
 		for (void *p : dev)
 			if (p)
@@ -460,6 +493,7 @@ extern "C"
 		A(dmalloc(ctx, &B->descs, (size_t)n * MULLS_NC));
 		A(dmalloc(ctx, &B->setup, (size_t)n));
 		A(dmalloc(ctx, &B->ticket, 1));
+		A(dmalloc(ctx, &B->states, (size_t)n));
 		A(dmalloc(ctx, &B->bbox, (size_t)n * 6));
 		A(dmalloc(ctx, &B->setup_jobs, B->setup_jobs_h.size()));
 		A(dmalloc(ctx, &B->grids, (size_t)n * MULLS_NC));
@@ -473,7 +507,7 @@ extern "C"
 			hipHostMalloc((void **)&B->outs_h, sizeof(PairOut) * n, hipHostMallocMapped) != hipSuccess ||
 			hipHostMalloc((void **)&B->epoch_h, 64, hipHostMallocMapped) != hipSuccess ||
 			hipHostMalloc((void **)&B->bbox_h, sizeof(uint32_t) * 6 * n, hipHostMallocDefault) != hipSuccess ||
-			hipHostGetDevicePointer((void **)&B->states, B->states_h, 0) != hipSuccess ||
+			hipHostGetDevicePointer((void **)&B->states_pin, B->states_h, 0) != hipSuccess ||
 			hipHostGetDevicePointer((void **)&B->outs, B->outs_h, 0) != hipSuccess ||
 			hipHostGetDevicePointer((void **)&B->epoch_dev, (void *)B->epoch_h, 0) != hipSuccess ||
 			hipMemset(B->ticket, 0, sizeof(uint32_t)) != hipSuccess)
@@ -557,6 +591,8 @@ extern "C"
 		rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
 		rp.tick_base = ctx->tick;
 		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
+		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
+			rp.debug_stop = (uint32_t)std::atoi(dbg);
 
 		// job table (static for a given used_feature_type) + fresh descriptors
 		build_jobs(B, P);
@@ -575,13 +611,21 @@ extern "C"
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
-		const bool use_grid = ctx->nn_mode != 1;
+		uint32_t lds_cap = 0;
+		const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
+		if (tier < 0)
+		{
+			ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
+			return MULLS_E_INVALID;
+		}
+		rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : MULLS_MAXCELLS;
+		const bool use_grid = tier != 0;
 		if (use_grid)
 		{
 			int n_used = 0;
 			for (int c = 0; c < MULLS_NC; c++)
 				n_used += rp.used[c];
-			const size_t cells = (size_t)n * n_used * (MULLS_MAXCELLS + 1u);
+			const size_t cells = (size_t)n * n_used * MULLS_CELL_STRIDE;
 			if (cells > B->cells_cap)
 			{
 				if (B->cell_cnt)
@@ -680,12 +724,22 @@ extern "C"
 				s.iter = h.want_residual ? h.iters - 1 : lock_iter;
 				s.active = h.active ? 1 : 0;
 				s.want_residual = h.want_residual ? 1 : 0;
-				s.pad_ = 0;
+				s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
 			}
+			launch_push_states(st, B->states_pin, B->states, (uint32_t)n);
 			if (any_active)
 			{
 				evt.begin(&ctx->prof.ms_nn);
-				if (use_grid)
+				if (tier == 2)
+				{
+					if (launch_nn_lds(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+									  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
+					{
+						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
+						return MULLS_E_HIP;
+					}
+				}
+				else if (tier == 1)
 					launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 								   B->nn_idx, B->nn_d2, B->winner);
 				else
@@ -931,6 +985,10 @@ extern "C"
 		std::memset(rp, 0, sizeof(*rp));
 		rp->used[cls] = 1;
 		rp->faithful = 1;
+		{
+			uint32_t cap_unused = 0;
+			rp->grid_maxcells = choose_tier(ctx, B, rp->used, &cap_unused) == 2 ? lds_cells_for(cap_unused) : MULLS_MAXCELLS;
+		}
 		rp->tick_base = ctx->tick;
 		ctx->tick += 4;
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
@@ -941,7 +999,7 @@ extern "C"
 					B->wd, *rp, B->grids);
 		if (ctx->nn_mode != 1)
 		{
-			const size_t cells = MULLS_MAXCELLS + 1u;
+			const size_t cells = MULLS_CELL_STRIDE;
 			if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK ||
 				dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
 				return MULLS_E_HIP;
@@ -982,9 +1040,17 @@ extern "C"
 				B->states_h[0].thr[c] = dis_thre;
 			hipStream_t st = ctx->stream;
 			hipError_t e = hipSuccess;
-			if (ctx->nn_mode != 1)
+			launch_push_states(st, B->states_pin, B->states, 1);
+			uint32_t lds_cap = 0;
+			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
+			if (tier == 2)
+				launch_nn_lds(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+							  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells);
+			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
+			else if (tier < 0)
+				rc = MULLS_E_INVALID;
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
@@ -1054,6 +1120,7 @@ extern "C"
 			if (e == hipSuccess && corr_d2)
 				e = hipMemcpyAsync(dcd, corr_d2, sizeof(float) * ncorr, hipMemcpyHostToDevice, st);
 			identity_state(&B->states_h[0], iter_num);
+			launch_push_states(ctx->stream, B->states_pin, B->states, 1);
 			const uint32_t off = B->descs_h[cls].src_off;
 			if (e == hipSuccess)
 			{

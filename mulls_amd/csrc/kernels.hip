@@ -245,7 +245,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
 					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
 					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
-					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)MULLS_MAXCELLS &&
+					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells &&
 						(unsigned long long)g.ny * g.nz <= (unsigned long long)MULLS_MAXROWS)
 						break;
 					g.h *= 1.25f;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 				n_used += rp.used[c] ? 1u : 0u;
 			}
 			g.ncell = (running > 0 && rp.used[cls]) ? g.nx * g.ny * g.nz : 0u;
-			g.cell_off = (pair * n_used + rank) * (MULLS_MAXCELLS + 1u);
+			g.cell_off = (pair * n_used + rank) * MULLS_CELL_STRIDE;
 			g.pad_[0] = g.pad_[1] = 0;
 			grids[pair * MULLS_NC + cls] = g;
 		}
@@ -646,10 +646,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scatter(const Job *__restr
 	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
-// Correspondence search, grid tier.  A 16-lane sub-group (4 per wave64, 16 per workgroup) owns one source point at a
-// time: every lane applies the same fused rigid step (wave-uniform loads), the sub-group sweeps the candidate rows of
-// the 3x3x3 cell neighbourhood with coalesced loads, reduces (distance, index) with 4 xor-shuffles, and — only when
-// nothing lies within one cell edge — widens the sweep to the current best distance or the rejection radius.
+// Correspondence search, grid tier.  Phase 1: every lane applies this iteration's rigid step to two source points
+// (coalesced 16-B traffic, double math once per point) and parks the transformed position in LDS.  Phase 2: a 16-lane
+// sub-group (4 per wave64, 16 per workgroup) owns one query at a time: it sweeps the candidate rows of the 3x3x3 cell
+// neighbourhood with coalesced loads, reduces (distance, index) with 4 xor-shuffles, and — only when nothing lies
+// within one cell edge — widens the sweep to the current best distance or the rejection radius.
 // Outputs are identical to k_nn.
 __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
 														  const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 														  const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 														  unsigned long long *__restrict__ winner)
 {
+	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = 1 for live points, 0 for dead / out of range
 	const Job job = jobs[blockIdx.x];
 	const PairState &ps = states[job.pair];
 	if (!ps.active)
@@ -665,6 +667,35 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
 	const bool called = class_called(rp, d, job.cls);
+	{
+		const double *T = ps.T;
+#pragma unroll
+		for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+		{
+			const uint32_t k = threadIdx.x + u * MULLS_BLOCK, s = job.start + k;
+			float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
+			{
+				// pcl::transformPointCloudWithNormals<PointT,double> (cregistration.hpp:1690-1695)
+				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+				out.w = 1.0f;
+				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+				spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
+				snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+			}
+			qpos[k] = out;
+		}
+	}
+	if (!called)
+		return; // correspondences of the previous iteration stay in force
+	__syncthreads();
+
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	const uint32_t *__restrict__ cstart = cell_start + g.cell_off;
 	const float4 *__restrict__ ts = tsorted + d.tgt_off;
@@ -675,41 +706,337 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
-	const double T0 = ps.T[0], T1 = ps.T[1], T2 = ps.T[2], T3 = ps.T[3], T4 = ps.T[4], T5 = ps.T[5], T6 = ps.T[6], T7 = ps.T[7],
-				 T8 = ps.T[8], T9 = ps.T[9], T10 = ps.T[10], T11 = ps.T[11];
 	uint32_t matched_cnt = 0;
 	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_BLOCK / MULLS_GRID_GROUP)
 	{
 		const uint32_t s = job.start + k;
 		if (s >= src_n)
 			break;
-		if (!(flag[d.src_off + s] & MULLS_F_ALIVE))
-			continue;
-		const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
-		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
-		const float px = (float)(T0 * x + T1 * y + T2 * z + T3);
-		const float py = (float)(T4 * x + T5 * y + T6 * z + T7);
-		const float pz = (float)(T8 * x + T9 * y + T10 * z + T11);
-		if (sub == 0)
-		{
-			const float onx = (float)(T0 * nx + T1 * ny + T2 * nz);
-			const float ony = (float)(T4 * nx + T5 * ny + T6 * nz);
-			const float onz = (float)(T8 * nx + T9 * ny + T10 * nz);
-			spos[d.src_off + s] = make_float4(px, py, pz, p.w);
-			snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
-		}
-		if (!called)
+		const float4 q = qpos[k];
+		if (q.w == 0.0f)
 			continue;
 		float best = __builtin_inff();
 		int bi = -1;
-		grid_scan_box(g, cstart, ts, px, py, pz, m, sub, best, bi); // first probe: at most 3x3 rows of 3 cells
+		grid_scan_box(g, cstart, ts, q.x, q.y, q.z, m, sub, best, bi); // first probe: at most 3x3 rows of 3 cells
 		group_min(best, bi);
 		if (!(bi >= 0 && best <= m * m))
 		{
 			// nothing inside the first probe: widen to the current best distance, or to the rejection radius
 			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
-			grid_scan_box(g, cstart, ts, px, py, pz, R, sub, best, bi);
+			grid_scan_box(g, cstart, ts, q.x, q.y, q.z, R, sub, best, bi);
 			group_min(best, bi);
+		}
+		if (sub == 0)
+		{
+			const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
+			nn_idx[d.src_off + s] = matched ? bi : -1;
+			nn_d2[d.src_off + s] = best;
+			if (matched)
+			{
+				matched_cnt++;
+				if (gate)
+					atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
+			}
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0 && matched_cnt)
+		atomicAdd(&d.n_matched, matched_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Correspondence search, LDS grid tier — the default whenever every searched target class cloud holds at most
+// MULLS_LDS_MAXPTS points (the reference-default KITTI sizes).  Rationale (profiles/r01_c_pmc_grid.txt): the global-memory
+// grid tier is neither HBM- nor VALU-bound, it waits (69 % s_waitcnt) on chains of 64-B sector gathers with ~2 us
+// latency.  Here one workgroup (512 lanes, one 512-point job) first brings the whole cell-sorted target class cloud
+// on chip with coalesced 16-B loads — planar X[] Y[] Z[] floats, a uint16 original index per point, a uint16 cell
+// table (as many cells as the rest of the 160 KiB allows) — and then runs exactly the cooperative sweep of k_nn_grid against
+// LDS: lane j of a 16-lane sub-group reads the bounds of row j, the sub-group strides over each row's contiguous
+// candidates (consecutive LDS addresses: conflict-free), 4 xor-shuffles reduce (distance, index).  Same exactness
+// argument, same outputs as k_nn / k_nn_grid.
+namespace
+{
+struct LdsGrid
+{
+	const float *X, *Y, *Z;
+	const uint16_t *IDX, *CS;
+};
+
+// (distance, index) lexicographic minimum over the 16 lanes of a DPP row, VALU only (no LDS-crossbar shuffles):
+// quad xor-1, quad xor-2, half-row mirror, row mirror.  Result in every lane.
+template <int CTRL>
+__device__ __forceinline__ void dpp_min_step(float &best, int &bi)
+{
+	const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false));
+	const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
+	const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
+	best = take ? ob : best;
+	bi = take ? oi : bi;
+}
+__device__ __forceinline__ void row16_min(float &best, int &bi)
+{
+	dpp_min_step<0xB1>(best, bi);  // quad_perm [1,0,3,2]
+	dpp_min_step<0x4E>(best, bi);  // quad_perm [2,3,0,1]
+	dpp_min_step<0x141>(best, bi); // row_half_mirror
+	dpp_min_step<0x140>(best, bi); // row_mirror
+}
+
+__device__ __forceinline__ void lds_eval(const LdsGrid &L, uint32_t t, float px, float py, float pz, float &best, int &bi)
+{
+	const float dx = px - L.X[t], dy = py - L.Y[t], dz = pz - L.Z[t];
+	const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+	const int idx = (int)L.IDX[t];
+	if (dist < best || (dist == best && idx < bi))
+	{
+		best = dist;
+		bi = idx;
+	}
+}
+
+// Evaluate every staged target in the cells intersecting the cube [p - R, p + R] (same exactness argument as
+// grid_scan_box), optionally skipping one cell that has been swept already.  Candidate ranges (rows; the row of the
+// skipped cell splits in two) are taken three at a time; all lanes read the range bounds themselves (same address
+// within the sub-group: LDS broadcast), then the first candidate of each range is fetched before any is consumed.
+// When the box is just the skipped cell nothing is touched at all (the common case after the own-cell probe).
+#define MULLS_LDS_CHUNK 3
+__device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
+											  int skip_x, int skip_y, int skip_z, float &best, int &bi)
+{
+	const float Rm = R * 1.0001f + 1e-4f;
+	const int x0 = grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = grid_cell(px + Rm, g.ox, g.inv_h, g.nx);
+	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
+	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
+	if (x0 == x1 && y0 == y1 && z0 == z1 && x0 == skip_x && y0 == skip_y && z0 == skip_z)
+		return;
+	int cy = y0, cz = z0;
+	bool second_half = false; // the skipped cell's row is visited twice: cells left of it, then cells right of it
+	while (cz <= z1)
+	{
+		uint32_t lo[MULLS_LDS_CHUNK], hi[MULLS_LDS_CHUNK];
+#pragma unroll
+		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		{
+			const bool valid = cz <= z1;
+			const uint32_t row = ((uint32_t)(valid ? cz : z0) * g.ny + (uint32_t)cy) * g.nx;
+			const bool split = valid && cy == skip_y && cz == skip_z && skip_x >= x0 && skip_x <= x1;
+			const uint32_t a = (split && second_half) ? (uint32_t)skip_x + 1u : (uint32_t)x0;
+			const uint32_t e = (split && !second_half) ? (uint32_t)skip_x : (uint32_t)x1 + 1u;
+			lo[jj] = L.CS[row + a];
+			hi[jj] = valid ? (uint32_t)L.CS[row + e] : lo[jj];
+			if (split && !second_half)
+				second_half = true;
+			else
+			{
+				second_half = false;
+				if (++cy > y1)
+				{
+					cy = y0;
+					cz++;
+				}
+			}
+		}
+		float tx[MULLS_LDS_CHUNK], ty[MULLS_LDS_CHUNK], tz[MULLS_LDS_CHUNK];
+		uint32_t ti[MULLS_LDS_CHUNK];
+#pragma unroll
+		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		{
+			const uint32_t t = lo[jj] + sub;
+			const bool ok = t < hi[jj];
+			const uint32_t tt = ok ? t : 0u;
+			tx[jj] = L.X[tt];
+			ty[jj] = L.Y[tt];
+			tz[jj] = L.Z[tt];
+			ti[jj] = ok ? (uint32_t)L.IDX[tt] : 0xffffffffu;
+		}
+#pragma unroll
+		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		{
+			const float dx = px - tx[jj], dy = py - ty[jj], dz = pz - tz[jj];
+			const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+			const int idx = (int)ti[jj];
+			if (idx >= 0 && (dist < best || (dist == best && idx < bi)))
+			{
+				best = dist;
+				bi = idx;
+			}
+		}
+#pragma unroll
+		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++) // ranges holding more than 16 candidates
+			for (uint32_t t = lo[jj] + sub + MULLS_GRID_GROUP; t < hi[jj]; t += MULLS_GRID_GROUP)
+				lds_eval(L, t, px, py, pz, best, bi);
+	}
+}
+} // namespace
+
+__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+															 const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
+															 float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
+															 const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
+															 const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+															 unsigned long long *__restrict__ winner, uint32_t cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
+	float *X = reinterpret_cast<float *>(qpos + MULLS_SRC_PER_BLOCK), *Y = X + cap, *Z = Y + cap; // [cap] each
+	uint16_t *IDX = reinterpret_cast<uint16_t *>(Z + cap);				  // [cap]
+	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
+
+	const Job job = jobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n, alive_cur = d.alive_cur;
+	const bool called = class_called(rp, d, job.cls);
+	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+
+	// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
+	if (threadIdx.x < MULLS_SRC_PER_BLOCK)
+	{
+		const uint32_t s = job.start + threadIdx.x;
+		float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
+		{
+			const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+			const double *T = ps.T;
+			const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+			out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+			out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+			out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+			out.w = 1.0f;
+			const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+			const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+			const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+			spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
+			snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+		}
+		qpos[threadIdx.x] = out;
+	}
+	if (!called || rp.debug_stop == 1u)
+		return; // correspondences of the previous iteration stay in force
+
+	// stage the cell-sorted target cloud and its cell table (coalesced reads, each byte of the cloud once per workgroup).
+	// Loads are issued in batches of 8 / 4 per lane before the first LDS write: one memory latency per batch instead of
+	// one per element (the serial version spent ~90 us per workgroup in s_waitcnt, profiles/r01_c_pmc_grid.txt).
+	{
+		const float4 *__restrict__ ts = tsorted + d.tgt_off;
+		for (uint32_t k0 = threadIdx.x; k0 < tgt_n; k0 += 8 * MULLS_LDS_BLOCK)
+		{
+			float4 t[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t k = k0 + u * MULLS_LDS_BLOCK;
+				if (k < tgt_n)
+					t[u] = ts[k];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t k = k0 + u * MULLS_LDS_BLOCK;
+				if (k < tgt_n)
+				{
+					X[k] = t[u].x;
+					Y[k] = t[u].y;
+					Z[k] = t[u].z;
+					IDX[k] = (uint16_t)__float_as_int(t[u].w);
+				}
+			}
+		}
+		// cell table: (ncell + 1) uint32 -> uint16, moved as uint4 words (cell_off is a multiple of 4 entries)
+		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(cell_start + g.cell_off);
+		const uint32_t nw = (g.ncell + 1u + 3u) >> 2;
+		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 4 * MULLS_LDS_BLOCK)
+		{
+			uint4 v[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const uint32_t w = w0 + u * MULLS_LDS_BLOCK;
+				if (w < nw)
+					v[u] = cs4[w];
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+			{
+				const uint32_t w = w0 + u * MULLS_LDS_BLOCK;
+				if (w < nw)
+				{
+					// two packed uint16 pairs per word (entries past ncell are padding and never read)
+					reinterpret_cast<uint32_t *>(CS)[2 * w] = (v[u].x & 0xffffu) | (v[u].y << 16);
+					reinterpret_cast<uint32_t *>(CS)[2 * w + 1] = (v[u].z & 0xffffu) | (v[u].w << 16);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (rp.debug_stop == 2u)
+		return;
+
+	const LdsGrid L = {X, Y, Z, IDX, CS};
+	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
+	const double maxd = (double)r;
+	const double max_dist_sqr = maxd * maxd;
+	const bool gate = alive_cur >= 500u;
+	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
+	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
+	uint32_t matched_cnt = 0;
+	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_GRID_GROUP)
+	{
+		const uint32_t s = job.start + k;
+		if (s >= src_n)
+			break;
+		const float4 q = qpos[k];
+		if (q.w == 0.0f)
+			continue;
+		float best = __builtin_inff();
+		int bi = -1;
+		if (rp.debug_stop == 5u)
+			continue;
+		// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
+		const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+		{
+			const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
+			const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
+			for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_GRID_GROUP) // two candidates in flight per lane and trip
+			{
+				const uint32_t t2 = t + MULLS_GRID_GROUP;
+				const bool ok2 = t2 < hi;
+				const uint32_t tt2 = ok2 ? t2 : t;
+				const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
+				const int ia = (int)L.IDX[t], ib = (int)L.IDX[tt2];
+				float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
+				const float da = (dx * dx + dy * dy) + dz * dz;
+				dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
+				const float db = (dx * dx + dy * dy) + dz * dz;
+				if (da < best || (da == best && ia < bi))
+				{
+					best = da;
+					bi = ia;
+				}
+				if (ok2 && (db < best || (db == best && ib < bi)))
+				{
+					best = db;
+					bi = ib;
+				}
+			}
+		}
+		row16_min(best, bi);
+		// probe 1: every other cell within min(first-probe radius, current best distance) of the query
+		if (rp.debug_stop != 3u)
+		{
+			const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
+			lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, cx, cy, cz, best, bi);
+			row16_min(best, bi);
+		}
+		if (rp.debug_stop < 3u && !(bi >= 0 && best <= m * m))
+		{
+			// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
+			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
+			lds_scan_box(g, L, q.x, q.y, q.z, R, sub, -1, -1, -1, best, bi);
+			row16_min(best, bi);
 		}
 		if (sub == 0)
 		{
@@ -1189,6 +1516,17 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-iteration input: the host writes the PairState records into pinned memory; this kernel pulls them into HBM with
+// coalesced 16-B reads over PCIe (one read of the block instead of one per workgroup of every later kernel).
+static_assert(sizeof(PairState) % 16 == 0, "PairState must be a whole number of uint4 words");
+__global__ void k_push_states(const uint4 *__restrict__ host_words, uint4 *__restrict__ dev_words, uint32_t nwords)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nwords)
+		dev_words[i] = host_words[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Stage-level helpers for the parity tests (mulls_stage_* in include/mulls_hip.h)
 __global__ void k_transform_aos(float4 *__restrict__ recs, uint32_t n, const double *__restrict__ T /* 12 row-major */)
 {
@@ -1247,6 +1585,26 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 	hipLaunchKernelGGL(k_grid_scan, dim3(npairs * MULLS_NC), dim3(MULLS_BLOCK), 0, st, grids, rp, cell_cnt, cell_start);
 	hipLaunchKernelGGL(k_grid_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt, cell_start, tsorted);
 }
+size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells)
+{
+	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)cap * 14u + ((size_t)maxcells + 8u) * 2u;
+}
+int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
+				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx,
+				  float *nn_d2, unsigned long long *winner, uint32_t cap, uint32_t maxcells)
+{
+	static bool attr_set = false;
+	if (!attr_set)
+	{
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+			return -1;
+		attr_set = true;
+	}
+	if (njobs)
+		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells), st, jobs, descs, states, rp, spos, snrm, grids,
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, cap);
+	return 0;
+}
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 					float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag,
 					int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
@@ -1281,6 +1639,13 @@ void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const Pair
 {
 	if (npairs)
 		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, ticket, host_epoch, epoch);
+}
+void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)
+{
+	const uint32_t nwords = npairs * (uint32_t)(sizeof(PairState) / 16);
+	if (nwords)
+		hipLaunchKernelGGL(k_push_states, dim3((nwords + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4 *>(host_states),
+						   reinterpret_cast<uint4 *>(dev_states), nwords);
 }
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12)
 {

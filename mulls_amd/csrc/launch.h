@@ -13,6 +13,10 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids);
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
 					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted);
+size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells);
+int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
+				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx,
+				  float *nn_d2, unsigned long long *winner, uint32_t cap, uint32_t maxcells);
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 					float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag,
 					int32_t *nn_idx, float *nn_d2, unsigned long long *winner);
@@ -26,6 +30,7 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 				  double *partial);
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
 				   PairOut *out, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch);
+void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs);
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
 					 int32_t *match, float *wd);

@@ -16,7 +16,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session", params=[2, 1], ids=["grid", "brute"])
+@pytest.fixture(scope="session", params=[3, 2, 1], ids=["grid_lds", "grid_global", "brute"])
 def ctx(request):
     """HIP context on device 0, once per correspondence-search tier (uniform grid / LDS-tiled brute force).
     No fallback: if the library or the device is missing the gpu tests fail."""

@@ -19,8 +19,13 @@ def compare(ro, rg, check_trace=True):
     assert ro.code == rg.code and ro.iters == rg.iters
     assert list(ro.ncorr) == list(rg.ncorr)
     assert list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
-    dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
-    assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
+    assert ro.singular == rg.singular
+    if np.isnan(ro.T_matrix()).any():
+        # singular normal matrix: the reference lets inf/NaN propagate (SURVEY B-11); both must agree on where
+        assert np.array_equal(np.isnan(ro.T_matrix()), np.isnan(rg.T_matrix()))
+    else:
+        dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
+        assert dt <= TOL_T and dr <= TOL_R, (dt, dr)
     assert abs(ro.sigma - rg.sigma) <= 1e-6 * max(1.0, abs(ro.sigma))
     assert ro.confidence == rg.confidence or (np.isnan(ro.confidence) and np.isnan(rg.confidence))
     io, ig = ro.info_matrix(), rg.info_matrix()
@@ -34,7 +39,10 @@ def compare(ro, rg, check_trace=True):
             if any(a.atpa[:]):
                 sa = np.abs(np.array(a.atpa[:])).max()
                 assert np.abs(np.array(a.atpa[:]) - np.array(b.atpa[:])).max() <= 1e-10 * sa
-                assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() <= 1e-9
+                if np.isfinite(np.array(a.x[:])).all():
+                    assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() <= 1e-9
+                else:
+                    assert not np.isfinite(np.array(b.x[:])).all()
 
 
 PARAM_SETS = {

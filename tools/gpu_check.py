@@ -30,11 +30,11 @@ print("PARITY", "OK" if ok else "MISMATCH")
 # timing: batch of replicated pairs, fixed 20 iterations
 Pb = abi.kitti_params(converge_translation=0.0, converge_rotation_d=0.0)
 import sys as _s
-modes = [(2, "grid"), (1, "brute")]
+modes = [(3, "grid_lds"), (2, "grid_global"), (1, "brute")]
 for mode, name in modes:
   ctx.set_nn_mode(mode); print("== nn tier:", name)
   for nb in (1, 16, 64, 256, 1024):
-    if mode == 1 and nb > 256: continue
+    if mode != 3 and nb > 256: continue
     batch = ctx.batch([pairs[i % 4][0] for i in range(nb)])
     res = batch.run(Pb)
     t = time.time(); reps = 3
