@@ -1,0 +1,202 @@
+// cregistration_hip.hpp — drop-in bridge from MULLS' CRegistration<PointT>::mm_lls_icp() to libmulls_hip.so.
+//
+// The reference has no plugin/FFI layer: mm_lls_icp is a public member of the header-only class template
+// lo::CRegistration<PointT> (include/common/cregistration.hpp:1114-1440), called positionally from
+// test/mulls_reg.cpp:194 and test/mulls_slam.cpp:477,560,642,679.  This header keeps that exact signature (argument
+// order, types, defaults) as a free function template, lo::hip::mm_lls_icp<PointT>(), so that the one-line binding a
+// maintainer adds at cregistration.hpp:1125
+//
+//     #ifdef MULLS_USE_HIP
+//         return lo::hip::mm_lls_icp<PointT>(registration_cons, max_iter_num, dis_thre_unit, converge_translation,
+//                 converge_rotation_d, dis_thre_min, dis_thre_update_rate, used_feature_type, weight_strategy,
+//                 z_xy_balanced_ratio, pt2pt_residual_window, pt2pl_residual_window, pt2li_residual_window,
+//                 initial_guess, apply_intersection_filter, apply_motion_undistortion_while_registration,
+//                 normal_shooting_on, normal_bearing, use_more_points, keep_less_source_points, sigma_thre,
+//                 min_neccessary_corr_ratio, max_bearable_rotation_d);
+//     #endif
+//
+// leaves every call site, cloudblock_t and constraint_t (include/common/utility.hpp:233-590) untouched.
+// See INTEGRATION.md for the build flags and for what is and is not reproduced (kd-tree side effect, logging).
+//
+// Requirements on the including translation unit: MULLS' utility.hpp (lo::constraint_t, lo::cloudblock_t, Matrix6d),
+// PCL point types and Eigen must already be visible — exactly what cregistration.hpp includes before line 1114.
+#ifndef MULLS_CREGISTRATION_HIP_HPP
+#define MULLS_CREGISTRATION_HIP_HPP
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "mulls_hip.h"
+
+namespace lo
+{
+namespace hip
+{
+
+// One library context per host thread (the reference path is single-threaded and stateless, SURVEY §8b "Threading").
+inline mulls_ctx *thread_context(int device = 0)
+{
+	struct Holder
+	{
+		mulls_ctx *ctx = nullptr;
+		~Holder()
+		{
+			if (ctx)
+				mulls_destroy(ctx);
+		}
+	};
+	static thread_local Holder holder;
+	if (!holder.ctx)
+	{
+		const int rc = mulls_create(device, &holder.ctx);
+		if (rc != MULLS_OK)
+			throw std::runtime_error("mulls_create failed (" + std::to_string(rc) + "): no usable gfx950 device; there is no CPU fallback");
+	}
+	return holder.ctx;
+}
+
+template <typename CloudPtr>
+inline mulls_cloud borrow(const CloudPtr &cloud)
+{
+	typedef typename std::remove_reference<decltype(cloud->points[0])>::type PointT;
+	static_assert(sizeof(PointT) >= MULLS_POINT_BYTES, "expects pcl::PointXYZINormal-compatible records (48 bytes)");
+	mulls_cloud c;
+	c.pts = cloud->points.empty() ? nullptr : static_cast<const void *>(cloud->points.data());
+	c.n = static_cast<uint32_t>(cloud->points.size());
+	c.stride = static_cast<uint32_t>(sizeof(PointT));
+	return c;
+}
+
+// When set (default), block1->tree_{ground,pillar,beam,facade,roof,vertex} are rebuilt on the cropped target clouds
+// like cregistration.hpp:1209-1232 does, because MapManager::map_based_dynamic_close_removal (src/map_manager.cpp:187-243)
+// queries them on the next frame.  The registration itself never uses a CPU kd-tree.  Benchmarks switch it off.
+inline bool &build_cpu_trees()
+{
+	static bool on = true;
+	return on;
+}
+
+template <typename PointT>
+int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud), cblock_2 (source point cloud)
+			   int max_iter_num = 20, float dis_thre_unit = 1.5, float converge_translation = 0.002, float converge_rotation_d = 0.01,
+			   float dis_thre_min = 0.4, float dis_thre_update_rate = 1.1, std::string used_feature_type = "111110",
+			   std::string weight_strategy = "1101", float z_xy_balanced_ratio = 1.0, float pt2pt_residual_window = 0.1,
+			   float pt2pl_residual_window = 0.1, float pt2li_residual_window = 0.1,
+			   Eigen::Matrix4d initial_guess = Eigen::Matrix4d::Identity(), bool apply_intersection_filter = true,
+			   bool apply_motion_undistortion_while_registration = false, bool normal_shooting_on = false, float normal_bearing = 45.0,
+			   bool use_more_points = false, bool keep_less_source_points = false, float sigma_thre = 0.5,
+			   float min_neccessary_corr_ratio = 0.03, float max_bearable_rotation_d = 45.0)
+{
+	mulls_ctx *ctx = thread_context();
+	cloudblock_t &b1 = *registration_cons.block1; // target
+	cloudblock_t &b2 = *registration_cons.block2; // source
+
+	mulls_pair pair;
+	std::memset(&pair, 0, sizeof(pair));
+	// class index == used_feature_type character index (cregistration.hpp:1196-1201)
+	pair.tgt[MULLS_GROUND] = borrow(b1.pc_ground);
+	pair.tgt[MULLS_PILLAR] = borrow(b1.pc_pillar);
+	pair.tgt[MULLS_FACADE] = borrow(b1.pc_facade);
+	pair.tgt[MULLS_BEAM] = borrow(b1.pc_beam);
+	pair.tgt[MULLS_ROOF] = borrow(b1.pc_roof);
+	pair.tgt[MULLS_VERTEX] = borrow(b1.pc_vertex);
+	// clone_feature(..., !use_more_points): down-sampled features unless use_more_points; vertex always pc_vertex (utility.hpp:524-550)
+	pair.src[MULLS_GROUND] = borrow(use_more_points ? b2.pc_ground : b2.pc_ground_down);
+	pair.src[MULLS_PILLAR] = borrow(use_more_points ? b2.pc_pillar : b2.pc_pillar_down);
+	pair.src[MULLS_FACADE] = borrow(use_more_points ? b2.pc_facade : b2.pc_facade_down);
+	pair.src[MULLS_BEAM] = borrow(use_more_points ? b2.pc_beam : b2.pc_beam_down);
+	pair.src[MULLS_ROOF] = borrow(use_more_points ? b2.pc_roof : b2.pc_roof_down);
+	pair.src[MULLS_VERTEX] = borrow(b2.pc_vertex);
+	// batch_apply_motion_compensation always starts from the _down clouds (cregistration.hpp:1251-1253)
+	pair.src_down[MULLS_GROUND] = borrow(b2.pc_ground_down);
+	pair.src_down[MULLS_PILLAR] = borrow(b2.pc_pillar_down);
+	pair.src_down[MULLS_FACADE] = borrow(b2.pc_facade_down);
+	pair.src_down[MULLS_BEAM] = borrow(b2.pc_beam_down);
+	pair.src_down[MULLS_ROOF] = borrow(b2.pc_roof_down);
+	pair.src_down[MULLS_VERTEX] = borrow(b2.pc_vertex);
+	pair.tgt_bound[0] = b1.local_bound.min_x;
+	pair.tgt_bound[1] = b1.local_bound.min_y;
+	pair.tgt_bound[2] = b1.local_bound.min_z;
+	pair.tgt_bound[3] = b1.local_bound.max_x;
+	pair.tgt_bound[4] = b1.local_bound.max_y;
+	pair.tgt_bound[5] = b1.local_bound.max_z;
+	std::memcpy(pair.init_guess, initial_guess.data(), sizeof(pair.init_guess)); // Eigen::Matrix4d is column-major
+
+	mulls_params P;
+	mulls_default_params(&P);
+	P.max_iter_num = max_iter_num;
+	P.dis_thre_unit = dis_thre_unit;
+	P.converge_translation = converge_translation;
+	P.converge_rotation_d = converge_rotation_d;
+	P.dis_thre_min = dis_thre_min;
+	P.dis_thre_update_rate = dis_thre_update_rate;
+	std::memset(P.used_feature_type, 0, sizeof(P.used_feature_type));
+	std::memset(P.weight_strategy, 0, sizeof(P.weight_strategy));
+	std::strncpy(P.used_feature_type, used_feature_type.c_str(), sizeof(P.used_feature_type) - 1);
+	std::strncpy(P.weight_strategy, weight_strategy.c_str(), sizeof(P.weight_strategy) - 1);
+	P.z_xy_balanced_ratio = z_xy_balanced_ratio;
+	P.pt2pt_residual_window = pt2pt_residual_window;
+	P.pt2pl_residual_window = pt2pl_residual_window;
+	P.pt2li_residual_window = pt2li_residual_window;
+	P.apply_intersection_filter = apply_intersection_filter;
+	P.apply_motion_undistortion = apply_motion_undistortion_while_registration;
+	P.normal_shooting_on = normal_shooting_on;
+	P.use_more_points = use_more_points;
+	P.normal_bearing = normal_bearing;
+	P.keep_less_source_points = keep_less_source_points;
+	P.faithful = 1;
+	P.sigma_thre = sigma_thre;
+	P.min_neccessary_corr_ratio = min_neccessary_corr_ratio;
+	P.max_bearable_rotation_d = max_bearable_rotation_d;
+
+	mulls_result R;
+	std::memset(&R, 0, sizeof(R));
+	const int rc = mulls_icp(ctx, &pair, &P, &R);
+	if (rc != MULLS_OK) // infrastructure failure (HIP error, unsupported option): the reference has no channel for it
+		throw std::runtime_error(std::string("mulls_icp failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+
+	// constraint_t outputs (cregistration.hpp:1405-1420)
+	std::memcpy(registration_cons.Trans1_2.data(), R.T, sizeof(R.T));
+	std::memcpy(registration_cons.information_matrix.data(), R.info, sizeof(R.info));
+	registration_cons.sigma = R.sigma;
+	registration_cons.confidence = R.confidence;
+
+	if (build_cpu_trees())
+	{
+		// kd-tree side effect of cregistration.hpp:1209-1232: trees over the intersection-filtered target clouds
+		typedef typename pcl::PointCloud<PointT> Cloud;
+		struct Item
+		{
+			int cls;
+			typename Cloud::Ptr src;
+			pcTreePtr tree;
+		};
+		const Item items[6] = {{MULLS_GROUND, b1.pc_ground, b1.tree_ground}, {MULLS_PILLAR, b1.pc_pillar, b1.tree_pillar},
+							   {MULLS_FACADE, b1.pc_facade, b1.tree_facade}, {MULLS_BEAM, b1.pc_beam, b1.tree_beam},
+							   {MULLS_ROOF, b1.pc_roof, b1.tree_roof},		 {MULLS_VERTEX, b1.pc_vertex, b1.tree_vertex}};
+		for (const Item &it : items)
+		{
+			if (used_feature_type[it.cls] != '1')
+				continue;
+			typename Cloud::Ptr cropped(new Cloud);
+			if (R.cropped)
+			{
+				for (const PointT &p : it.src->points) // CFilter::bbx_filter, strict inequalities (cfilter.hpp:959-961)
+					if (p.x > R.crop_box[0] && p.x < R.crop_box[3] && p.y > R.crop_box[1] && p.y < R.crop_box[4] && p.z > R.crop_box[2] &&
+						p.z < R.crop_box[5])
+						cropped->points.push_back(p);
+			}
+			else
+				*cropped = *it.src;
+			if (cropped->points.size() > 0)
+				it.tree->setInputCloud(cropped);
+		}
+	}
+	return R.code;
+}
+
+} // namespace hip
+} // namespace lo
+
+#endif // MULLS_CREGISTRATION_HIP_HPP

@@ -134,6 +134,9 @@ typedef struct mulls_result
 	uint32_t nsrc0[MULLS_NCLASS]; /* source points per class after the intersection filter */
 	uint32_t ntgt0[MULLS_NCLASS]; /* target points per class after the intersection filter */
 	int32_t singular;			  /* ABI-only: 1 if a non-finite solve was observed (reference does not check, B-11) */
+	int32_t cropped;			  /* 1 if the intersection filter ran (cregistration.hpp:1186-1188) */
+	double crop_box[6];			  /* its box {min_x,min_y,min_z,max_x,max_y,max_z} (utility.hpp:857-865); the adapter re-creates
+									 the reference's kd-tree side effect on block1 from it */
 	float ms_total;				  /* wall time of this registration inside the library (batch: batch time / n) */
 	mulls_iter_trace *trace;	  /* in: caller array or NULL */
 	int32_t trace_cap;			  /* in: capacity of trace[] */

@@ -97,6 +97,8 @@ class Result(C.Structure):
         ("nsrc0", C.c_uint32 * NCLASS),
         ("ntgt0", C.c_uint32 * NCLASS),
         ("singular", C.c_int32),
+        ("cropped", C.c_int32),
+        ("crop_box", C.c_double * 6),
         ("ms_total", C.c_float),
         ("trace", C.POINTER(IterTrace)),
         ("trace_cap", C.c_int32),

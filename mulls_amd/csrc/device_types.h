@@ -84,6 +84,8 @@ struct PairOut
 	uint32_t n_alive[MULLS_NC];
 	uint32_t src_n[MULLS_NC];
 	uint32_t tgt_n[MULLS_NC];
+	uint32_t bbox[6]; // ordered-key bounding box of the transformed ground/pillar/facade source clouds (k_clone_src)
+	uint32_t pad_[2];
 };
 
 // One workgroup's worth of the correspondence search / filter / accumulation.

@@ -106,6 +106,14 @@ int dmalloc(mulls_ctx *ctx, T **p, size_t count)
 	return MULLS_OK;
 }
 
+inline float ord_to_float(uint32_t k)
+{
+	const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+	float f;
+	std::memcpy(&f, &u, sizeof(f));
+	return f;
+}
+
 inline int metric_of(int c) { return (c == MULLS_PILLAR || c == MULLS_BEAM) ? 1 : (c == MULLS_VERTEX ? 2 : 0); }
 
 void rows12(const double colmajor[16], double out[12])
@@ -684,6 +692,8 @@ extern "C"
 			std::memset(results[p].ncorr, 0, sizeof(results[p].ncorr));
 			std::memset(results[p].nsrc0, 0, sizeof(results[p].nsrc0));
 			std::memset(results[p].ntgt0, 0, sizeof(results[p].ntgt0));
+			results[p].cropped = 0;
+			std::memset(results[p].crop_box, 0, sizeof(results[p].crop_box));
 		}
 
 		if (P->max_iter_num <= 0)
@@ -754,7 +764,7 @@ extern "C"
 			}
 			evt.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->ticket, B->epoch_dev, ++B->epoch);
+			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
 			evt.end();
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
@@ -797,6 +807,19 @@ extern "C"
 						R.nsrc0[c] = o.src_n[c];
 						R.ntgt0[c] = o.tgt_n[c];
 						h.alive_prev[c] = o.src_n[c];
+					}
+					// the intersection box the device used (cregistration.hpp:2912-2916), re-derived for the caller
+					R.cropped = rp.crop ? 1 : 0;
+					for (int k = 0; k < 3; k++)
+					{
+						const uint32_t kmin = o.bbox[k], kmax = o.bbox[3 + k];
+						const bool none = kmin == 0xffffffffu && kmax == 0u;
+						const double mmin = none ? 1.7976931348623157e308 : (double)ord_to_float(kmin);
+						const double mmax = none ? -1.7976931348623157e308 : (double)ord_to_float(kmax);
+						const double b1min = B->setup_h[p].tgt_bound[k], b1max = B->setup_h[p].tgt_bound[3 + k];
+						const float pad = 1.0f;
+						R.crop_box[k] = ((b1min > mmin) ? b1min : mmin) - pad;
+						R.crop_box[3 + k] = ((b1max < mmax) ? b1max : mmax) + pad;
 					}
 					h.src_feature_count = 0; // cregistration.hpp:1195-1201
 					if (rp.used[1])
@@ -1128,7 +1151,7 @@ extern "C"
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
 				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->ticket, B->epoch_dev, ++B->epoch);
+				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
 			}
 			std::vector<float> wall(src->n);
 			if (e == hipSuccess)

@@ -1458,8 +1458,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 namespace
 {
 __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, const RunParams &rp, const double *__restrict__ partial,
-											 PairOut &o)
+											 PairOut &o, const uint32_t *__restrict__ pair_bbox)
 {
+	if (threadIdx.x >= 192 && threadIdx.x < 198)
+		o.bbox[threadIdx.x - 192] = pair_bbox[threadIdx.x - 192];
 	if (threadIdx.x < MULLS_NC * MULLS_NTERM)
 	{
 		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
@@ -1494,13 +1496,13 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 } // namespace
 
 __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
-														 const double *__restrict__ partial, PairOut *__restrict__ out, uint32_t *__restrict__ ticket,
-														 volatile uint32_t *host_epoch, uint32_t epoch)
+														 const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
+														 uint32_t *__restrict__ ticket, volatile uint32_t *host_epoch, uint32_t epoch)
 {
 	const uint32_t pair = blockIdx.x;
 	const int active = states[pair].active, want_residual = states[pair].want_residual;
 	if (active || want_residual) // uniform per workgroup
-		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair]);
+		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
 	__threadfence_system();
 	__syncthreads();
 	if (threadIdx.x == 0)
@@ -1635,10 +1637,10 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial);
 }
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
-				   PairOut *out, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch)
+				   PairOut *out, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch)
 {
 	if (npairs)
-		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, ticket, host_epoch, epoch);
+		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, ticket, host_epoch, epoch);
 }
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)
 {

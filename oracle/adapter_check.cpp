@@ -1,0 +1,154 @@
+// adapter_check.cpp — end-to-end drop-in check of include/cregistration_hip.hpp (TEST INFRASTRUCTURE, built by
+// oracle/build_ref.sh next to libmulls_ref.so).
+//
+// One process, one lo::constraint_t: the reference's own lo::CRegistration<Point_T>::mm_lls_icp (its source lines,
+// compiled against oracle/ref_shim) and the adapter lo::hip::mm_lls_icp<Point_T> (-> libmulls_hip.so -> MI355X) are
+// called with the positional arguments of test/mulls_slam.cpp:642-648 / test/mulls_reg.cpp:194-195, and their
+// constraint_t outputs are printed side by side as JSON for tests/test_gpu_adapter.py to compare.
+//
+// usage: adapter_check <dump file written by the test> <kitti|reg>
+#include <chrono>
+#include <cstdio>
+
+#include "ref_shim/shim.hpp"
+
+#include "mulls_hip.h"
+
+#define max_(a, b) (((a) > (b)) ? (a) : (b))
+#define min_(a, b) (((a) < (b)) ? (a) : (b))
+
+using namespace std;
+
+typedef pcl::PointXYZINormal Point_T;
+typedef pcl::PointCloud<Point_T>::Ptr pcTPtr;
+typedef pcl::PointCloud<Point_T> pcT;
+typedef pcl::search::KdTree<Point_T>::Ptr pcTreePtr;
+typedef pcl::search::KdTree<Point_T> pcTree;
+
+#include "util_typedefs.inc"
+
+namespace lo
+{
+#include "util_types.inc"
+#include "util_cloudutility.inc"
+};
+template <typename PointT>
+class CFilter : public CloudUtility<PointT>
+{
+  public:
+#include "cfilter_body.inc"
+};
+template <typename PointT>
+class CRegistration : public CloudUtility<PointT>
+{
+  public:
+#include "creg_body.inc"
+};
+} // namespace lo
+
+#include "cregistration_hip.hpp" // the adapter under test: sees exactly the types a MULLS translation unit has at this point
+
+static bool read_cloud(FILE *f, pcTPtr &c)
+{
+	uint32_t n = 0;
+	if (fread(&n, 4, 1, f) != 1)
+		return false;
+	c->points.resize(n);
+	return n == 0 || fread(c->points.data(), sizeof(Point_T), n, f) == n;
+}
+
+static void print_result(const char *who, int code, const lo::constraint_t &con, size_t tree_pts)
+{
+	printf("{\"who\": \"%s\", \"code\": %d, \"sigma\": %.9g, \"confidence\": %.9g, \"tree_points\": %zu, \"T\": [", who, code, con.sigma,
+		   con.confidence, tree_pts);
+	for (int i = 0; i < 16; i++)
+		printf("%s%.17g", i ? ", " : "", con.Trans1_2.data()[i]);
+	printf("], \"info\": [");
+	for (int i = 0; i < 36; i++)
+		printf("%s%.17g", i ? ", " : "", con.information_matrix.data()[i]);
+	printf("]}\n");
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3)
+		return 2;
+	FILE *f = fopen(argv[1], "rb");
+	if (!f)
+		return 2;
+	lo::constraint_t con_ref, con_hip;
+	lo::constraint_t *cons[2] = {&con_ref, &con_hip};
+	double guess_raw[16], bound[6];
+	{
+		lo::cloudblock_t &b1 = *con_ref.block1, &b2 = *con_ref.block2;
+		pcTPtr *tg[6] = {&b1.pc_ground, &b1.pc_pillar, &b1.pc_facade, &b1.pc_beam, &b1.pc_roof, &b1.pc_vertex};
+		pcTPtr *sd[6] = {&b2.pc_ground_down, &b2.pc_pillar_down, &b2.pc_facade_down, &b2.pc_beam_down, &b2.pc_roof_down, &b2.pc_vertex};
+		for (int c = 0; c < 6; c++)
+			if (!read_cloud(f, *tg[c]))
+				return 3;
+		for (int c = 0; c < 6; c++)
+			if (!read_cloud(f, *sd[c]))
+				return 3;
+		if (fread(guess_raw, 8, 16, f) != 16 || fread(bound, 8, 6, f) != 6)
+			return 3;
+		fclose(f);
+		b1.local_bound.min_x = bound[0], b1.local_bound.min_y = bound[1], b1.local_bound.min_z = bound[2];
+		b1.local_bound.max_x = bound[3], b1.local_bound.max_y = bound[4], b1.local_bound.max_z = bound[5];
+	}
+	// identical second constraint (deep copies of the clouds)
+	{
+		lo::cloudblock_t &a1 = *con_ref.block1, &a2 = *con_ref.block2, &b1 = *con_hip.block1, &b2 = *con_hip.block2;
+		*b1.pc_ground = *a1.pc_ground, *b1.pc_pillar = *a1.pc_pillar, *b1.pc_facade = *a1.pc_facade, *b1.pc_beam = *a1.pc_beam;
+		*b1.pc_roof = *a1.pc_roof, *b1.pc_vertex = *a1.pc_vertex;
+		*b2.pc_ground_down = *a2.pc_ground_down, *b2.pc_pillar_down = *a2.pc_pillar_down, *b2.pc_facade_down = *a2.pc_facade_down;
+		*b2.pc_beam_down = *a2.pc_beam_down, *b2.pc_roof_down = *a2.pc_roof_down, *b2.pc_vertex = *a2.pc_vertex;
+		b1.local_bound = a1.local_bound;
+	}
+	Eigen::Matrix4d initial_guess_tran;
+	std::memcpy(initial_guess_tran.data(), guess_raw, sizeof(guess_raw));
+
+	const bool kitti = std::string(argv[2]) == "kitti";
+	lo::CRegistration<Point_T> cReg;
+	int code[2];
+	for (int w = 0; w < 2; w++)
+	{
+		lo::constraint_t &reg_con = *cons[w];
+		if (kitti)
+		{
+			// test/mulls_slam.cpp:642-648 with script/config/lo_gflag_list_kitti_urban.txt
+			const int max_iter = 20;
+			const float thre = 1.4f + 1.0f, conv_t = 0.0005f, conv_r = 0.001f, thre_min = 0.5f, win = 0.05f, bearing = 20.0f, sigma_thre = 0.35f;
+			if (w == 0)
+				code[w] = cReg.mm_lls_icp(reg_con, max_iter, thre, conv_t, conv_r, thre_min, 1.1, "111000", "1111", 1.0, win, win, win,
+										  initial_guess_tran, true, false, false, bearing, false, false, sigma_thre, 0.03, 45.0);
+			else
+				code[w] = lo::hip::mm_lls_icp<Point_T>(reg_con, max_iter, thre, conv_t, conv_r, thre_min, 1.1, "111000", "1111", 1.0, win, win,
+													  win, initial_guess_tran, true, false, false, bearing, false, false, sigma_thre, 0.03, 45.0);
+		}
+		else
+		{
+			// test/mulls_reg.cpp:194-195 with script/run_mulls_reg.sh values; the remaining nine parameters are defaulted
+			const int max_iter = 10;
+			const float thre = 3.0f, conv_t = 0.001f, conv_r = 0.01f;
+			if (w == 0)
+				code[w] = cReg.mm_lls_icp(reg_con, max_iter, thre, conv_t, conv_r, 0.25 * thre, 1.1, "111110", "1101", 1.0, 0.1, 0.1, 0.1,
+										  initial_guess_tran);
+			else
+				code[w] = lo::hip::mm_lls_icp<Point_T>(reg_con, max_iter, thre, conv_t, conv_r, 0.25 * thre, 1.1, "111110", "1101", 1.0, 0.1, 0.1,
+													  0.1, initial_guess_tran);
+		}
+	}
+	// kd-tree side effect on block1 (cregistration.hpp:1209-1232): count the points each implementation indexed
+	size_t tp[2] = {0, 0};
+	for (int w = 0; w < 2; w++)
+	{
+		lo::cloudblock_t &b = *cons[w]->block1;
+		pcTreePtr trees[6] = {b.tree_ground, b.tree_pillar, b.tree_facade, b.tree_beam, b.tree_roof, b.tree_vertex};
+		for (auto &t : trees)
+			if (t->cloud)
+				tp[w] += t->cloud->points.size();
+	}
+	print_result("reference", code[0], con_ref, tp[0]);
+	print_result("hip", code[1], con_hip, tp[1]);
+	return 0;
+}

@@ -14,11 +14,14 @@
 //       CorrespondenceRejectorDistance, transformPointCloudWithNormals<PointT,double>, pcl::Correspondence's
 //       distance/weight union; FLANN 1.8/1.9 KDTreeSingleIndex + L2_Simple<float>; Eigen 3.3.7 PartialPivLU
 //       inverse, AngleAxisd(Matrix3d).
-//   * PARITY UNPINNED by the restatement alone: the reference ships no tests, golden vectors or recorded
-//     outputs for this path.  The restatement is pinned instead against oracle/_ref — the
-//     reference's own function bodies compiled against a minimal PCL/Eigen stand-in (oracle/ref_shim/, see
-//     oracle/Makefile) — wherever that library is built; see DESIGN.md §Oracle for exactly what that does and
-//     does not pin.
+//   * Pinning.  The reference ships no tests, golden vectors or recorded outputs for this path, and
+//     PCL / Eigen / FLANN are not installable here, so the upstream binary cannot be run.  The restatement is pinned
+//     instead against oracle/_ref/libmulls_ref.so: the reference's OWN function bodies for the path (cut out of
+//     /root/reference at build time by oracle/build_ref.sh) compiled against oracle/ref_shim/shim.hpp, a stand-in for
+//     the few Eigen/PCL/boost/glog calls they make.  tests/test_ref_pin.py requires bit-for-bit agreement of every
+//     output the reference interface exposes.  That pins all MULLS-authored arithmetic and control flow (quirks
+//     included); the third-party behaviour itself (PCL correspondence estimation / rejector / transform, FLANN distance,
+//     Eigen LU and AngleAxis) stays a restatement from documentation — "parity partially pinned".  See DESIGN.md §Oracle.
 //
 // Build: see oracle/Makefile (g++ -O3 -ffp-contract=off -fopenmp).  FMA contraction must stay off: the reference
 // is built -O3 without -march (CMakeLists.txt:43), i.e. plain SSE2 mul/add.
@@ -1066,6 +1069,8 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 		transform_cloud(sc[c], guess); // :1183 (all six, used or not)
 
 	const bool undistort = P->apply_motion_undistortion != 0;
+	R->cropped = 0;
+	std::memset(R->crop_box, 0, sizeof(R->crop_box));
 	if (P->apply_intersection_filter && !undistort) // :1186-1188, :2894-2922
 	{
 		double b[3][6], merged[6] = {DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX};
@@ -1090,6 +1095,8 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 			bbx_filter(tc[c], ib);
 			bbx_filter(sc[c], ib);
 		}
+		R->cropped = 1;
+		std::memcpy(R->crop_box, ib, sizeof(ib));
 	}
 	if (P->keep_less_source_points && !undistort)
 		return MULLS_E_UNSUPPORTED; // pcl::RandomSample seeded with time(NULL): callers must pre-thin (SURVEY B-13)

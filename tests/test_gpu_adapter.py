@@ -1,0 +1,51 @@
+"""End-to-end drop-in check on the GPU box: oracle/_ref/adapter_check calls, on one lo::constraint_t, the reference's own
+CRegistration<Point_T>::mm_lls_icp (its source lines, CPU) and the adapter lo::hip::mm_lls_icp<Point_T> from
+include/cregistration_hip.hpp (-> C ABI -> MI355X), with the positional arguments of test/mulls_slam.cpp:642-648 and
+test/mulls_reg.cpp:194-195.  Both write Trans1_2 / information_matrix / sigma / confidence into their constraint_t and
+return the process code; the kd-tree side effect on block1 must cover the same number of points."""
+import json
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from mulls_amd import abi, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "adapter_check")
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/adapter_check not built")]
+
+
+def dump(pair, path):
+    with open(path, "wb") as f:
+        for clouds in (pair.tgt, pair.src):
+            for c in clouds:
+                f.write(struct.pack("<I", len(c)))
+                f.write(np.ascontiguousarray(c).tobytes())
+        f.write(np.asarray(pair.init_guess, np.float64).T.tobytes())  # column-major
+        f.write(np.asarray(pair.tgt_bound, np.float64).tobytes())
+
+
+@pytest.mark.parametrize("mode", ["kitti", "reg"])
+def test_adapter_matches_reference_class(pairs_small, mode):
+    for pair, T_gt in pairs_small:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "pair.bin")
+            dump(pair, path)
+            out = subprocess.check_output([BIN, path, mode], timeout=120).decode().strip().split("\n")
+        ref, hip = json.loads(out[0]), json.loads(out[1])
+        assert ref["who"] == "reference" and hip["who"] == "hip"
+        assert ref["code"] == hip["code"] == 1
+        Tr, Th = np.array(ref["T"]).reshape(4, 4).T, np.array(hip["T"]).reshape(4, 4).T
+        dt, dr = synth.pose_error(Th, Tr)
+        assert dt <= 1e-7 and dr <= 1e-7, (dt, dr)  # contract: 1e-4 m / 1e-4 rad
+        Ir, Ih = np.array(ref["info"]), np.array(hip["info"])
+        assert np.abs(Ir - Ih).max() <= 1e-6 * np.abs(Ir).max()
+        assert abs(ref["sigma"] - hip["sigma"]) <= 1e-6 and ref["confidence"] == hip["confidence"]
+        assert ref["tree_points"] == hip["tree_points"] > 0
+        gt_t, gt_r = synth.pose_error(Th, T_gt)
+        assert gt_t < 0.05 and gt_r < 2e-3

@@ -20,6 +20,7 @@ def compare(ro, rg, check_trace=True):
     assert list(ro.ncorr) == list(rg.ncorr)
     assert list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
     assert ro.singular == rg.singular
+    assert ro.cropped == rg.cropped and list(ro.crop_box) == list(rg.crop_box)
     if np.isnan(ro.T_matrix()).any():
         # singular normal matrix: the reference lets inf/NaN propagate (SURVEY B-11); both must agree on where
         assert np.array_equal(np.isnan(ro.T_matrix()), np.isnan(rg.T_matrix()))
