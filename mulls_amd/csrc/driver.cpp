@@ -177,6 +177,23 @@ void assemble_normal(const PairOut &o, bool faithful, Mat6 &N, double b[6])
 	}
 }
 
+// the intersection box the device used (cregistration.hpp:2912-2916, utility.hpp:857-865), re-derived for the caller
+void fill_crop_box(const RunParams &rp, const double tgt_bound[6], const uint32_t keys[6], mulls_result &R)
+{
+	R.cropped = rp.crop ? 1 : 0;
+	for (int k = 0; k < 3 && rp.crop; k++)
+	{
+		const uint32_t kmin = keys[k], kmax = keys[3 + k];
+		const bool none = kmin == 0xffffffffu && kmax == 0u;
+		const double mmin = none ? 1.7976931348623157e308 : (double)ord_to_float(kmin);
+		const double mmax = none ? -1.7976931348623157e308 : (double)ord_to_float(kmax);
+		const double b1min = tgt_bound[k], b1max = tgt_bound[3 + k];
+		const float pad = 1.0f;
+		R.crop_box[k] = ((b1min > mmin) ? b1min : mmin) - pad;
+		R.crop_box[3 + k] = ((b1max < mmax) ? b1max : mmax) + pad;
+	}
+}
+
 int check_params(mulls_ctx *ctx, const mulls_params *P)
 {
 	if (!P)
@@ -700,15 +717,20 @@ extern "C"
 		{
 			// the iteration loop never runs (process code 0): still report the post-filter cloud sizes
 			std::vector<CloudDesc> back(B->descs_h.size());
+			std::vector<uint32_t> keys((size_t)n * 6);
 			HIPCHK(ctx, hipMemcpyAsync(back.data(), B->descs, sizeof(CloudDesc) * back.size(), hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipMemcpyAsync(keys.data(), B->bbox, sizeof(uint32_t) * keys.size(), hipMemcpyDeviceToHost, st));
 			HIPCHK(ctx, hipStreamSynchronize(st));
 			evt.collect();
 			for (int p = 0; p < n; p++)
+			{
 				for (int c = 0; c < MULLS_NC; c++)
 				{
 					results[p].nsrc0[c] = back[p * MULLS_NC + c].src_n;
 					results[p].ntgt0[c] = back[p * MULLS_NC + c].tgt_n;
 				}
+				fill_crop_box(rp, B->setup_h[p].tgt_bound, &keys[(size_t)p * 6], results[p]);
+			}
 		}
 
 		int lock_iter = 0;
@@ -808,19 +830,7 @@ extern "C"
 						R.ntgt0[c] = o.tgt_n[c];
 						h.alive_prev[c] = o.src_n[c];
 					}
-					// the intersection box the device used (cregistration.hpp:2912-2916), re-derived for the caller
-					R.cropped = rp.crop ? 1 : 0;
-					for (int k = 0; k < 3; k++)
-					{
-						const uint32_t kmin = o.bbox[k], kmax = o.bbox[3 + k];
-						const bool none = kmin == 0xffffffffu && kmax == 0u;
-						const double mmin = none ? 1.7976931348623157e308 : (double)ord_to_float(kmin);
-						const double mmax = none ? -1.7976931348623157e308 : (double)ord_to_float(kmax);
-						const double b1min = B->setup_h[p].tgt_bound[k], b1max = B->setup_h[p].tgt_bound[3 + k];
-						const float pad = 1.0f;
-						R.crop_box[k] = ((b1min > mmin) ? b1min : mmin) - pad;
-						R.crop_box[3 + k] = ((b1max < mmax) ? b1max : mmax) + pad;
-					}
+					fill_crop_box(rp, B->setup_h[p].tgt_bound, o.bbox, R);
 					h.src_feature_count = 0; // cregistration.hpp:1195-1201
 					if (rp.used[1])
 						h.src_feature_count += (int)o.src_n[MULLS_PILLAR];
