@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmulls_hip.so")
 SOURCES = ["kernels.hip", "driver.cpp"]
 DEPS = ["device_types.h", "launch.h", "hostmath.h", os.path.join("..", "..", "include", "mulls_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc():
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -147,7 +147,7 @@ inline int packed(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
 // The 6x6 the reference inverts: pt2pl / pt2pt wrote the lower triangle, pt2li the upper one, then the mirror copies
 // lower -> upper (cregistration.hpp:1924-1938).  Class order of the += chain on shared slots: ground, facade, roof
 // (pl), pillar, beam (li), vertex (pt) (:1914-1921).
-void assemble_normal(const PairOut &o, bool faithful, Mat6 &N, double b[6])
+void assemble_normal(const PairOut &o, const uint8_t used[MULLS_NC], bool faithful, Mat6 &N, double b[6])
 {
 	static const int order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM, MULLS_VERTEX};
 	for (int r = 0; r < 6; r++)
@@ -158,6 +158,8 @@ void assemble_normal(const PairOut &o, bool faithful, Mat6 &N, double b[6])
 			for (int i = 0; i < 6; i++)
 			{
 				const int cls = order[i];
+				if (!used[cls])
+					continue;
 				const double v = o.sums[cls][k];
 				if (metric_of(cls) == 1 && r != c)
 					upper += v;
@@ -792,6 +794,9 @@ extern "C"
 				return MULLS_E_HIP;
 			evt.collect();
 
+			uint64_t acc_evals = 0, acc_src = 0, acc_tgt = 0, acc_tgtu = 0;
+			const int host_threads = std::max(1, std::min(16, n / 32));
+#pragma omp parallel for num_threads(host_threads) schedule(static) reduction(+ : acc_evals, acc_src, acc_tgt, acc_tgtu) if (host_threads > 1)
 			for (int p = 0; p < n; p++)
 			{
 				PairHost &h = H[p];
@@ -804,10 +809,11 @@ extern "C"
 					double VTPV = 0.0;
 					long obs = 0;
 					for (int i = 0; i < 6; i++)
-					{
-						VTPV += o.sums[order[i]][0];
-						obs += (long)o.sums[order[i]][1];
-					}
+						if (rp.used[order[i]])
+						{
+							VTPV += o.sums[order[i]][0];
+							obs += (long)o.sums[order[i]][1];
+						}
 					h.sigma2 = VTPV / (double)((int)obs - 6);
 					h.code = (std::sqrt(h.sigma2) < (double)P->sigma_thre) ? 1 : -3;
 					Mat6 cinv;
@@ -845,10 +851,10 @@ extern "C"
 					if (rp.used[c] && h.alive_prev[c] >= 3 && o.tgt_n[c] >= 3)
 					{
 						if (!use_grid)
-							ctx->prof.nn_pair_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
-						ctx->prof.nn_src_pts += h.alive_prev[c];
-						ctx->prof.nn_tgt_unique += o.tgt_n[c];
-						ctx->prof.nn_tgt_pts += (uint64_t)o.tgt_n[c] * (B->descs_h[p * MULLS_NC + c].job_end - B->descs_h[p * MULLS_NC + c].job_begin);
+							acc_evals += (uint64_t)h.alive_prev[c] * o.tgt_n[c];
+						acc_src += h.alive_prev[c];
+						acc_tgtu += o.tgt_n[c];
+						acc_tgt += (uint64_t)o.tgt_n[c] * (B->descs_h[p * MULLS_NC + c].job_end - B->descs_h[p * MULLS_NC + c].job_begin);
 					}
 					h.alive_prev[c] = o.n_alive[c];
 					R.ncorr[c] = o.n_valid[c];
@@ -888,7 +894,7 @@ extern "C"
 				}
 				Mat6 N;
 				double b[6];
-				assemble_normal(o, rp.faithful != 0, N, b);
+				assemble_normal(o, rp.used, rp.faithful != 0, N, b);
 				if (!mulls::solve_step(N, b, h.x, h.cofactor))
 					h.singular = 1;
 				if (tr)
@@ -916,6 +922,10 @@ extern "C"
 				}
 				h.guess = h.temp * h.guess; // :1400
 			}
+			ctx->prof.nn_pair_evals += acc_evals;
+			ctx->prof.nn_src_pts += acc_src;
+			ctx->prof.nn_tgt_pts += acc_tgt;
+			ctx->prof.nn_tgt_unique += acc_tgtu;
 		}
 
 		HIPCHK(ctx, hipStreamSynchronize(st));

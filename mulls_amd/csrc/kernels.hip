@@ -1465,11 +1465,13 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 	if (threadIdx.x < MULLS_NC * MULLS_NTERM)
 	{
 		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
-		double sum = 0.0;
-		if (rp.used[c])
+		if (rp.used[c]) // unused classes contribute nothing: their slots are not even sent over PCIe
+		{
+			double sum = 0.0;
 			for (uint32_t j = pd[c].job_begin; j < pd[c].job_end; j++)
 				sum += partial[(size_t)j * MULLS_NTERM + t];
-		o.sums[c][t] = sum;
+			o.sums[c][t] = sum;
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x < MULLS_NC)
