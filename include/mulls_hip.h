@@ -107,7 +107,9 @@ typedef struct mulls_params
 	float sigma_thre;				 /* 0.5 */
 	float min_neccessary_corr_ratio; /* 0.03 */
 	float max_bearable_rotation_d;	 /* 45.0 */
-	uint64_t rng_seed;				 /* ABI-only. seed for keep_less_source_points (reference seeds with time(NULL)) */
+	uint64_t rng_seed;				 /* ABI-only. keep_less_source_points thins with an order-preserving selection sampling (Knuth's
+										Algorithm S driven by splitmix64(rng_seed ^ cloud id)); the reference uses pcl::RandomSample
+										seeded with time(NULL) (cfilter.hpp:620), i.e. a different subset on every run */
 } mulls_params;
 
 /* Optional per-iteration record (debug / parity triage).  Filled when mulls_result.trace != NULL. */

@@ -43,7 +43,10 @@ struct CloudDesc
 	uint32_t n_valid;	 // |Corr_f| currently in force (may be stale, SURVEY B-4)
 	uint32_t job_begin;	 // this cloud's range in the job table
 	uint32_t job_end;
-	uint32_t pad_;
+	uint32_t sd_stage; // staged block2->pc_*_down records (motion undistortion regenerates the source from them); may alias src_stage
+	uint32_t sd_n0;
+	uint32_t src_cap; // slots reserved for this source cloud in the working arenas = max(src_n0, sd_n0)
+	uint32_t pad_[2];
 };
 
 // Uniform grid over one cropped target-class cloud (exact fixed-radius search tier).  cell id = (cz*ny + cy)*nx + cx,
@@ -74,6 +77,8 @@ struct PairSetup // written once per run
 {
 	double guess[12];	 // rows of the initial guess [R|t]
 	double tgt_bound[6]; // block1->local_bound
+	double inv_q[4];	 // quaternion (w,x,y,z) of inverse(initial_guess)'s rotation, for motion undistortion (cfilter.hpp:493-516)
+	double inv_t[4];	 // its translation (x,y,z,-)
 };
 
 // Per-pair output of one lock-step iteration (D2H once per iteration for the whole batch).
@@ -102,12 +107,13 @@ struct RunParams
 {
 	uint8_t used[MULLS_NC];
 	uint8_t w_balance, w_resid, w_dist, w_inten; // weight_strategy[0..3]
-	uint8_t crop;								 // apply_intersection_filter
+	uint8_t crop;								 // apply_intersection_filter (forced off while undistorting, cregistration.hpp:1186)
+	uint8_t undistort;							 // apply_motion_undistortion_while_registration
 	uint8_t faithful;
 	float z_xy_ratio;
 	float win_pt, win_pl, win_li;
 	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule
-	uint8_t pad_[3];
+	uint8_t pad_[2];
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging

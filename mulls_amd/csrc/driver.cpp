@@ -205,9 +205,9 @@ int check_params(mulls_ctx *ctx, const mulls_params *P)
 		ctx->err = "used_feature_type needs 6 characters and weight_strategy 4";
 		return MULLS_E_INVALID;
 	}
-	if (P->normal_shooting_on || P->apply_motion_undistortion || P->keep_less_source_points)
+	if (P->normal_shooting_on)
 	{
-		ctx->err = "normal_shooting_on / apply_motion_undistortion / keep_less_source_points are not implemented by this build";
+		ctx->err = "normal_shooting_on is not implemented by this build";
 		return MULLS_E_UNSUPPORTED;
 	}
 	return MULLS_OK;
@@ -225,7 +225,7 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 			CloudDesc &d = B->descs_h[p * MULLS_NC + c];
 			d.job_begin = (uint32_t)B->jobs_h.size();
 			if (P->used_feature_type[c] == '1')
-				for (uint32_t s = 0; s < d.src_n0; s += MULLS_SRC_PER_BLOCK)
+				for (uint32_t s = 0; s < d.src_cap; s += MULLS_SRC_PER_BLOCK)
 				{
 					Job j = {(uint32_t)p, (uint32_t)c, s, 0};
 					B->jobs_h.push_back(j);
@@ -304,6 +304,40 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	default:
 		return fits ? 2 : 1;
 	}
+}
+
+// seeded order-preserving selection sampling shared with the oracle's definition (include/mulls_hip.h: rng_seed)
+inline uint64_t splitmix64(uint64_t &x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	uint64_t z = x;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+// CFilter::random_downsample_pcl semantics (cfilter.hpp:606-628) expressed as a keep mask; returns the new size
+uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, int cloud_id)
+{
+	if ((long)n <= (long)keep_number)
+	{
+		std::memset(mask, 1, n);
+		return n;
+	}
+	std::memset(mask, 0, n);
+	if (keep_number == 0)
+		return 0;
+	uint64_t state = seed ^ (0x100000001B3ull * (uint64_t)(cloud_id + 1));
+	uint32_t need = (uint32_t)keep_number;
+	for (uint32_t i = 0; i < n && need > 0; i++)
+	{
+		const double u = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
+		if (u * (double)(n - i) < (double)need)
+		{
+			mask[i] = 1;
+			need--;
+		}
+	}
+	return (uint32_t)keep_number;
 }
 
 struct EvTimer
@@ -480,11 +514,25 @@ extern "C"
 				d.tgt_stage = (uint32_t)stage_rec;
 				d.tgt_n0 = t.n;
 				stage_rec += t.n;
+				// block2->pc_*_down for the undistortion branch: staged separately only when it is a different cloud
+				const mulls_cloud &sd = pairs[p].src_down[c];
+				const bool own_down = c != MULLS_VERTEX && sd.pts && sd.n && !(sd.pts == s.pts && sd.n == s.n && sd.stride == s.stride);
+				if (own_down && sd.stride < MULLS_POINT_BYTES)
+				{
+					ctx->err = "src_down cloud with stride < 48";
+					delete B;
+					return MULLS_E_INVALID;
+				}
+				d.sd_stage = own_down ? (uint32_t)stage_rec : d.src_stage;
+				d.sd_n0 = own_down ? sd.n : s.n;
+				if (own_down)
+					stage_rec += sd.n;
+				d.src_cap = std::max(d.src_n0, d.sd_n0);
 				d.src_off = (uint32_t)so;
 				d.tgt_off = (uint32_t)to;
-				so += s.n;
+				so += d.src_cap;
 				to += t.n;
-				for (uint32_t k = 0; k < s.n; k += MULLS_BLOCK)
+				for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
 				{
 					Job j = {(uint32_t)p, (uint32_t)c, k, 0};
 					B->setup_jobs_h.push_back(j);
@@ -492,6 +540,17 @@ extern "C"
 			}
 			rows12(pairs[p].init_guess, B->setup_h[p].guess);
 			std::memcpy(B->setup_h[p].tgt_bound, pairs[p].tgt_bound, sizeof(double) * 6);
+			{
+				// inverse(initial_guess) as quaternion + translation (cregistration.hpp:1248, cfilter.hpp:497-500)
+				Mat4 g;
+				std::memcpy(g.v, pairs[p].init_guess, sizeof(g.v));
+				const Mat4 gi = mulls::invert4(g);
+				mulls::rotation_quaternion(gi, B->setup_h[p].inv_q);
+				B->setup_h[p].inv_t[0] = gi.at(0, 3);
+				B->setup_h[p].inv_t[1] = gi.at(1, 3);
+				B->setup_h[p].inv_t[2] = gi.at(2, 3);
+				B->setup_h[p].inv_t[3] = 0.0;
+			}
 		}
 		if (stage_rec >= (1ull << 31))
 		{
@@ -556,9 +615,9 @@ extern "C"
 				for (int c = 0; c < MULLS_NC; c++)
 				{
 					const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
-					const mulls_cloud *cl[2] = {&pairs[p].src[c], &pairs[p].tgt[c]};
-					const uint32_t off[2] = {d.src_stage, d.tgt_stage};
-					for (int k = 0; k < 2; k++)
+					const mulls_cloud *cl[3] = {&pairs[p].src[c], &pairs[p].tgt[c], &pairs[p].src_down[c]};
+					const uint32_t off[3] = {d.src_stage, d.tgt_stage, d.sd_stage};
+					for (int k = 0; k < (d.sd_stage != d.src_stage ? 3 : 2); k++)
 					{
 						uint8_t *dst = host.data() + (size_t)off[k] * MULLS_POINT_BYTES;
 						const uint8_t *src = (const uint8_t *)cl[k]->pts;
@@ -609,7 +668,8 @@ extern "C"
 		rp.w_resid = P->weight_strategy[1] == '1';
 		rp.w_dist = P->weight_strategy[2] == '1';
 		rp.w_inten = P->weight_strategy[3] == '1';
-		rp.crop = P->apply_intersection_filter != 0;
+		rp.undistort = P->apply_motion_undistortion != 0;
+		rp.crop = P->apply_intersection_filter != 0 && !rp.undistort; // cregistration.hpp:1186
 		rp.faithful = P->faithful != 0;
 		rp.z_xy_ratio = P->z_xy_balanced_ratio;
 		rp.win_pt = P->pt2pt_residual_window;
@@ -680,9 +740,50 @@ extern "C"
 
 		// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188), then the target grids
 		evt.begin(&ctx->prof.ms_setup);
-		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
+		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, rp);
 		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
 					B->match, B->wd, rp, B->grids);
+		if (P->keep_less_source_points && !rp.undistort)
+		{
+			// keep_less_source_pts (cregistration.hpp:2866-2892): needs the post-filter sizes, so this (map-to-map only) option
+			// costs one extra device round trip per run
+			std::vector<CloudDesc> back(B->descs_h.size());
+			HIPCHK(ctx, hipMemcpyAsync(back.data(), B->descs, sizeof(CloudDesc) * back.size(), hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			std::vector<uint8_t> skeep(std::max<size_t>(B->n_src, 1), 1), tkeep(std::max<size_t>(B->n_tgt, 1), 1);
+			for (int p = 0; p < n; p++)
+			{
+				const CloudDesc *pd = &back[(size_t)p * MULLS_NC];
+				auto T = [&](int c, int keep) { return thin_mask(tkeep.data() + pd[c].tgt_off, pd[c].tgt_n, keep, P->rng_seed, 0 * 6 + c); };
+				auto S = [&](int c, int keep) { return thin_mask(skeep.data() + pd[c].src_off, pd[c].src_n, keep, P->rng_seed, 1 * 6 + c); };
+				const uint32_t tg = T(MULLS_GROUND, (int)(pd[MULLS_GROUND].tgt_n / 2));
+				const uint32_t tf = T(MULLS_FACADE, (int)(pd[MULLS_FACADE].tgt_n / 2));
+				S(MULLS_GROUND, (int)(tg / 4));
+				S(MULLS_FACADE, (int)(tf / 2));
+				S(MULLS_PILLAR, (int)pd[MULLS_PILLAR].tgt_n);
+				S(MULLS_BEAM, (int)pd[MULLS_BEAM].tgt_n);
+				S(MULLS_ROOF, (int)pd[MULLS_ROOF].tgt_n);
+				S(MULLS_VERTEX, (int)pd[MULLS_VERTEX].tgt_n);
+			}
+			uint8_t *d_sk = nullptr, *d_tk = nullptr;
+			if (dmalloc(ctx, &d_sk, skeep.size()) != MULLS_OK || dmalloc(ctx, &d_tk, tkeep.size()) != MULLS_OK)
+				return MULLS_E_HIP;
+			hipError_t e = hipMemcpyAsync(d_sk, skeep.data(), skeep.size(), hipMemcpyHostToDevice, st);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(d_tk, tkeep.data(), tkeep.size(), hipMemcpyHostToDevice, st);
+			if (e == hipSuccess)
+			{
+				launch_thin(st, (uint32_t)n, B->descs, d_sk, d_tk, B->spos, B->snrm, B->tpos, B->tnrm);
+				e = hipStreamSynchronize(st); // the masks are freed right below
+			}
+			(void)hipFree(d_sk);
+			(void)hipFree(d_tk);
+			if (e != hipSuccess)
+			{
+				ctx->err = std::string("keep_less_source_points: ") + hipGetErrorString(e);
+				return MULLS_E_HIP;
+			}
+		}
 		if (use_grid)
 			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
 							  B->tsorted);
@@ -832,18 +933,20 @@ extern "C"
 				{
 					for (int c = 0; c < MULLS_NC; c++)
 					{
-						R.nsrc0[c] = o.src_n[c];
+						// while undistorting, the sizes the reference counts at :1195-1201 are those of the cloned clouds,
+						// before the five non-vertex clouds are regenerated from block2->pc_*_down inside the loop
+						R.nsrc0[c] = rp.undistort ? B->descs_h[p * MULLS_NC + c].src_n0 : o.src_n[c];
 						R.ntgt0[c] = o.tgt_n[c];
 						h.alive_prev[c] = o.src_n[c];
 					}
 					fill_crop_box(rp, B->setup_h[p].tgt_bound, o.bbox, R);
 					h.src_feature_count = 0; // cregistration.hpp:1195-1201
 					if (rp.used[1])
-						h.src_feature_count += (int)o.src_n[MULLS_PILLAR];
+						h.src_feature_count += (int)R.nsrc0[MULLS_PILLAR];
 					if (rp.used[2])
-						h.src_feature_count += (int)o.src_n[MULLS_FACADE];
+						h.src_feature_count += (int)R.nsrc0[MULLS_FACADE];
 					if (rp.used[3])
-						h.src_feature_count += (int)o.src_n[MULLS_BEAM];
+						h.src_feature_count += (int)R.nsrc0[MULLS_BEAM];
 					h.first = false;
 				}
 				for (int c = 0; c < MULLS_NC; c++)
@@ -1037,7 +1140,7 @@ extern "C"
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6, hipMemcpyHostToDevice, st));
-		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox);
+		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, *rp);
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
 					B->wd, *rp, B->grids);
 		if (ctx->nn_mode != 1)

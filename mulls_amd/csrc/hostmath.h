@@ -119,6 +119,103 @@ inline bool invert6(const Mat6 &in, Mat6 &out)
 	return regular;
 }
 
+// general 4x4 inverse by the same row-pivoted LU (used for inverse(initial_guess) in the undistortion branch)
+inline Mat4 invert4(const Mat4 &in)
+{
+	const int n = 4;
+	double a[16];
+	int row_of[4];
+	std::memcpy(a, in.v, sizeof(a));
+	for (int i = 0; i < n; i++)
+		row_of[i] = i;
+	for (int col = 0; col < n; col++)
+	{
+		int p = col;
+		double big = std::fabs(a[col + n * col]);
+		for (int r = col + 1; r < n; r++)
+			if (std::fabs(a[r + n * col]) > big)
+			{
+				big = std::fabs(a[r + n * col]);
+				p = r;
+			}
+		if (p != col)
+		{
+			for (int c = 0; c < n; c++)
+			{
+				double t = a[col + n * c];
+				a[col + n * c] = a[p + n * c];
+				a[p + n * c] = t;
+			}
+			int t = row_of[col];
+			row_of[col] = row_of[p];
+			row_of[p] = t;
+		}
+		const double piv = a[col + n * col];
+		for (int r = col + 1; r < n; r++)
+			a[r + n * col] /= piv;
+		for (int c = col + 1; c < n; c++)
+		{
+			const double top = a[col + n * c];
+			for (int r = col + 1; r < n; r++)
+				a[r + n * c] -= a[r + n * col] * top;
+		}
+	}
+	Mat4 out;
+	for (int c = 0; c < n; c++)
+	{
+		double y[4];
+		for (int r = 0; r < n; r++)
+			y[r] = (row_of[r] == c) ? 1.0 : 0.0;
+		for (int r = 1; r < n; r++)
+			for (int k = 0; k < r; k++)
+				y[r] -= a[r + n * k] * y[k];
+		for (int r = n - 1; r >= 0; r--)
+		{
+			for (int k = r + 1; k < n; k++)
+				y[r] -= a[r + n * k] * y[k];
+			y[r] /= a[r + n * r];
+		}
+		for (int r = 0; r < n; r++)
+			out.v[r + n * c] = y[r];
+	}
+	return out;
+}
+
+// unit quaternion (w,x,y,z) of the upper-left 3x3 (Shepperd branches, as Eigen::Quaterniond(Matrix3d))
+inline void rotation_quaternion(const Mat4 &T, double q[4])
+{
+	const double r00 = T.at(0, 0), r11 = T.at(1, 1), r22 = T.at(2, 2);
+	const double tr = r00 + r11 + r22;
+	if (tr > 0.0)
+	{
+		double s = std::sqrt(tr + 1.0);
+		q[0] = 0.5 * s;
+		s = 0.5 / s;
+		q[1] = (T.at(2, 1) - T.at(1, 2)) * s;
+		q[2] = (T.at(0, 2) - T.at(2, 0)) * s;
+		q[3] = (T.at(1, 0) - T.at(0, 1)) * s;
+	}
+	else
+	{
+		int i = 0;
+		if (r11 > r00)
+			i = 1;
+		if (r22 > T.at(i, i))
+			i = 2;
+		const int j = (i + 1) % 3, k = (j + 1) % 3;
+		double s = std::sqrt(T.at(i, i) - T.at(j, j) - T.at(k, k) + 1.0);
+		double v[3];
+		v[i] = 0.5 * s;
+		s = 0.5 / s;
+		q[0] = (T.at(k, j) - T.at(j, k)) * s;
+		v[j] = (T.at(j, i) + T.at(i, j)) * s;
+		v[k] = (T.at(k, i) + T.at(i, k)) * s;
+		q[1] = v[0];
+		q[2] = v[1];
+		q[3] = v[2];
+	}
+}
+
 // tx ty tz roll pitch yaw -> [Rz(yaw) Ry(pitch) Rx(roll) | t]
 inline Mat4 euler_step_to_matrix(const double x[6])
 {

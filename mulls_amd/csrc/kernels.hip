@@ -67,25 +67,70 @@ __device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t *lds4)
 __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
 															const PairSetup *__restrict__ setup, const float4 *__restrict__ stage,
 															float4 *__restrict__ tmp_pos, float4 *__restrict__ tmp_nrm,
-															uint32_t *__restrict__ bbox /* [pair][6] ordered keys */)
+															uint32_t *__restrict__ bbox /* [pair][6] ordered keys */, RunParams rp)
 {
 	const Job job = jobs[blockIdx.x];
 	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t s = job.start + threadIdx.x;
-	const bool in = s < d.src_n0;
-	const double *G = setup[job.pair].guess;
+	// motion undistortion regenerates the five non-vertex clouds from block2->pc_*_down (cregistration.hpp:1251-1253)
+	const bool regen = rp.undistort && job.cls != 5;
+	const uint32_t n_in = regen ? d.sd_n0 : d.src_n0;
+	const bool in = s < n_in;
+	const PairSetup &su = setup[job.pair];
+	const double *G = su.guess;
 	float x = 0, y = 0, z = 0;
 	if (in)
 	{
-		const float4 *rec = stage + (size_t)(d.src_stage + s) * 3;
+		const float4 *rec = stage + (size_t)((regen ? d.sd_stage : d.src_stage) + s) * 3;
 		float4 a = rec[0], b = rec[1], c = rec[2]; // (x y z _) (nx ny nz _) (intensity curvature _ _)
-		double px = a.x, py = a.y, pz = a.z, nx = b.x, ny = b.y, nz = b.z;
-		x = (float)(G[0] * px + G[1] * py + G[2] * pz + G[3]);
-		y = (float)(G[4] * px + G[5] * py + G[6] * pz + G[7]);
-		z = (float)(G[8] * px + G[9] * py + G[10] * pz + G[11]);
-		float onx = (float)(G[0] * nx + G[1] * ny + G[2] * nz);
-		float ony = (float)(G[4] * nx + G[5] * ny + G[6] * nz);
-		float onz = (float)(G[8] * nx + G[9] * ny + G[10] * nz);
+		if (regen)
+		{
+			// CFilter::apply_motion_compensation(in, out, inverse(initial_guess)) (cfilter.hpp:493-516): the point is moved
+			// by the fraction `curvature` (its time stamp in [0,1]) of the inverse guess — slerp from the identity
+			// quaternion, linear translation — in double, stored as float; normals are copied unrotated.
+			const float sc = c.y;
+			if (!(sc < 0.0f || (double)sc > 1.0 - 0.0f))
+			{
+				const double t = (double)sc, one = 1.0 - 2.220446049250313e-16;
+				const double dq = su.inv_q[0], absD = fabs(dq);
+				double s0, s1;
+				if (absD >= one)
+				{
+					s0 = 1.0 - t;
+					s1 = t;
+				}
+				else
+				{
+					const double theta = acos(absD), sinTheta = sin(theta);
+					s0 = sin((1.0 - t) * theta) / sinTheta;
+					s1 = sin((t * theta)) / sinTheta;
+				}
+				if (dq < 0)
+					s1 = -s1;
+				const double qw = s0 + s1 * su.inv_q[0], qx = s1 * su.inv_q[1], qy = s1 * su.inv_q[2], qz = s1 * su.inv_q[3];
+				const double vx = a.x, vy = a.y, vz = a.z;
+				const double uvx = 2.0 * (qy * vz - qz * vy), uvy = 2.0 * (qz * vx - qx * vz), uvz = 2.0 * (qx * vy - qy * vx);
+				const double rx = vx + qw * uvx + (qy * uvz - qz * uvy);
+				const double ry = vy + qw * uvy + (qz * uvx - qx * uvz);
+				const double rz = vz + qw * uvz + (qx * uvy - qy * uvx);
+				a.x = (float)(rx + t * su.inv_t[0]);
+				a.y = (float)(ry + t * su.inv_t[1]);
+				a.z = (float)(rz + t * su.inv_t[2]);
+			}
+		}
+		const int reps = (rp.undistort && job.cls == 5) ? 2 : 1; // the vertex cloud is not regenerated: it receives the guess twice
+		float onx = b.x, ony = b.y, onz = b.z;					  // (cregistration.hpp:1183 and :1257)
+		x = a.x, y = a.y, z = a.z;
+		for (int rep = 0; rep < reps; rep++)
+		{
+			const double px = x, py = y, pz = z, nx = onx, ny = ony, nz = onz;
+			x = (float)(G[0] * px + G[1] * py + G[2] * pz + G[3]);
+			y = (float)(G[4] * px + G[5] * py + G[6] * pz + G[7]);
+			z = (float)(G[8] * px + G[9] * py + G[10] * pz + G[11]);
+			onx = (float)(G[0] * nx + G[1] * ny + G[2] * nz);
+			ony = (float)(G[4] * nx + G[5] * ny + G[6] * nz);
+			onz = (float)(G[8] * nx + G[9] * ny + G[10] * nz);
+		}
 		tmp_pos[d.src_off + s] = make_float4(x, y, z, c.x);
 		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, c.y);
 	}
@@ -129,7 +174,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
 	const uint32_t side = blockIdx.x & 1;
 	CloudDesc &d = descs[pair * MULLS_NC + cls];
-	const uint32_t n0 = side ? d.tgt_n0 : d.src_n0;
+	const uint32_t n0 = side ? d.tgt_n0 : ((rp.undistort && cls != 5) ? d.sd_n0 : d.src_n0);
 	const uint32_t off = side ? d.tgt_off : d.src_off;
 	double lo[3], hi[3];
 	if (crop)
@@ -278,6 +323,68 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			d.n_matched = 0;
 			d.valid_next = 0;
 			d.n_valid = 0;
+		}
+	}
+}
+
+// Setup 2b (keep_less_source_points only): order-preserving in-place compaction of one cloud by a host-made keep mask
+// (cregistration.hpp:2866-2892).  One workgroup per (pair, class, side); destinations never overtake unread sources.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_thin(CloudDesc *__restrict__ descs, const uint8_t *__restrict__ src_keep,
+													   const uint8_t *__restrict__ tgt_keep, float4 *__restrict__ spos, float4 *__restrict__ snrm,
+													   float4 *__restrict__ tpos, float4 *__restrict__ tnrm)
+{
+	__shared__ uint32_t wave_cnt[4];
+	const uint32_t pair = blockIdx.x / (MULLS_NC * 2);
+	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
+	const uint32_t side = blockIdx.x & 1;
+	CloudDesc &d = descs[pair * MULLS_NC + cls];
+	const uint32_t n0 = side ? d.tgt_n : d.src_n;
+	const uint32_t off = side ? d.tgt_off : d.src_off;
+	const uint8_t *keepm = (side ? tgt_keep : src_keep) + off;
+	float4 *pos = side ? tpos : spos, *nrm = side ? tnrm : snrm;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < n0; base += MULLS_BLOCK)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const bool in = i < n0;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		bool keep = false;
+		if (in)
+		{
+			p = pos[off + i];
+			q = nrm[off + i];
+			keep = keepm[i] != 0;
+		}
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads(); // every load of this chunk has completed before any store of it
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			const uint32_t dst = off + running + wbase + before;
+			pos[dst] = p;
+			nrm[dst] = q;
+		}
+		running += total;
+	}
+	if (threadIdx.x == 0)
+	{
+		if (side)
+			d.tgt_n = running;
+		else
+		{
+			d.src_n = running;
+			d.alive_cur = running;
 		}
 	}
 }
@@ -1567,10 +1674,10 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 #include "launch.h"
 
 void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
-					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox)
+					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp)
 {
 	if (njobs)
-		hipLaunchKernelGGL(k_clone_src, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, setup, stage, tmp_pos, tmp_nrm, bbox);
+		hipLaunchKernelGGL(k_clone_src, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, setup, stage, tmp_pos, tmp_nrm, bbox, rp);
 }
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
@@ -1579,6 +1686,12 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 	if (npairs)
 		hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm,
 						   tpos, tnrm, flag, match, wd, rp, grids);
+}
+void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
+				 float4 *tpos, float4 *tnrm)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_thin, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, src_keep, tgt_keep, spos, snrm, tpos, tnrm);
 }
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
 					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted)

@@ -7,10 +7,12 @@
 
 #include <hip/hip_vector_types.h>
 void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
-					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox);
+					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp);
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
 				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids);
+void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
+				 float4 *tpos, float4 *tnrm);
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
 					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted);
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells);

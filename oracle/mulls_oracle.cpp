@@ -941,6 +941,41 @@ void cloud_bbx(const Cloud &c, double b[6]) // utility.hpp:817-848
 	}
 }
 
+// CFilter::random_downsample_pcl (cfilter.hpp:606-628) with the ABI's seeded selection sampling (Knuth's Algorithm S
+// driven by splitmix64): unchanged if size <= keep, emptied if keep == 0, otherwise exactly `keep` points, order kept.
+inline uint64_t splitmix64(uint64_t &x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	uint64_t z = x;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+void random_downsample(Cloud &c, int keep_number, uint64_t seed, int cloud_id)
+{
+	if ((long)c.size() <= (long)keep_number)
+		return;
+	if (keep_number == 0)
+	{
+		c.clear();
+		return;
+	}
+	uint64_t state = seed ^ (0x100000001B3ull * (uint64_t)(cloud_id + 1));
+	Cloud out;
+	size_t need = (size_t)keep_number;
+	const size_t N = c.size();
+	for (size_t i = 0; i < N && need > 0; i++)
+	{
+		const double u = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
+		if (u * (double)(N - i) < (double)need)
+		{
+			out.push_back(c[i]);
+			need--;
+		}
+	}
+	c.swap(out);
+}
+
 struct Quat
 {
 	double w, x, y, z;
@@ -1098,8 +1133,19 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 		R->cropped = 1;
 		std::memcpy(R->crop_box, ib, sizeof(ib));
 	}
-	if (P->keep_less_source_points && !undistort)
-		return MULLS_E_UNSUPPORTED; // pcl::RandomSample seeded with time(NULL): callers must pre-thin (SURVEY B-13)
+	if (P->keep_less_source_points && !undistort) // keep_less_source_pts, cregistration.hpp:2866-2892
+	{
+		// upstream thins with pcl::RandomSample seeded by time(NULL) (cfilter.hpp:620), i.e. differently on every run;
+		// the ABI defines a seeded, order-preserving selection sampling instead (include/mulls_hip.h, rng_seed)
+		random_downsample(tc[MULLS_GROUND], (int)(tc[MULLS_GROUND].size() / 2), P->rng_seed, 0 * 6 + MULLS_GROUND);
+		random_downsample(tc[MULLS_FACADE], (int)(tc[MULLS_FACADE].size() / 2), P->rng_seed, 0 * 6 + MULLS_FACADE);
+		random_downsample(sc[MULLS_GROUND], (int)(tc[MULLS_GROUND].size() / 4), P->rng_seed, 1 * 6 + MULLS_GROUND);
+		random_downsample(sc[MULLS_FACADE], (int)(tc[MULLS_FACADE].size() / 2), P->rng_seed, 1 * 6 + MULLS_FACADE);
+		random_downsample(sc[MULLS_PILLAR], (int)(tc[MULLS_PILLAR].size()), P->rng_seed, 1 * 6 + MULLS_PILLAR);
+		random_downsample(sc[MULLS_BEAM], (int)(tc[MULLS_BEAM].size()), P->rng_seed, 1 * 6 + MULLS_BEAM);
+		random_downsample(sc[MULLS_ROOF], (int)(tc[MULLS_ROOF].size()), P->rng_seed, 1 * 6 + MULLS_ROOF);
+		random_downsample(sc[MULLS_VERTEX], (int)(tc[MULLS_VERTEX].size()), P->rng_seed, 1 * 6 + MULLS_VERTEX);
+	}
 
 	for (int c = 0; c < 6; c++)
 	{

@@ -157,9 +157,48 @@ def test_stale_correspondences_and_tiny_clouds(ctx):
         compare(ro, rg)
 
 
+@pytest.mark.parametrize("used", ["111110", "111111", "111000"])
+def test_motion_undistortion(ctx, pairs_small, used):
+    """apply_motion_undistortion_while_registration (cregistration.hpp:1248-1258, cfilter.hpp:493-549): the five
+    non-vertex source clouds are regenerated from block2->pc_*_down with per-point slerp, the intersection filter is
+    skipped, and the vertex cloud receives the initial guess twice (reference quirk)."""
+    P = abi.default_params(apply_motion_undistortion=1, used_feature_type=used)
+    for pair, _ in pairs_small:
+        assert pair.src[0]["curvature"].max() > 0.5  # time stamps present
+        ro = pyoracle.icp(pair, P, trace_cap=32)[0]
+        rg = ctx.icp(pair, P, trace_cap=32)[0]
+        compare(ro, rg)
+    # use_more_points: src = un-down-sampled clouds, src_down = the down-sampled ones the regeneration starts from
+    pair, _ = pairs_small[0]
+    rng = np.random.default_rng(0)
+    down = [c[np.sort(rng.choice(len(c), size=max(len(c) // 2, min(len(c), 3)), replace=False))] if len(c) else c for c in pair.src]
+    pr = abi.PairData(pair.tgt, pair.src, init_guess=pair.init_guess, tgt_bound=pair.tgt_bound, src_down=down)
+    P = abi.default_params(apply_motion_undistortion=1, use_more_points=1)
+    ro = pyoracle.icp(pr, P, trace_cap=32)[0]
+    rg = ctx.icp(pr, P, trace_cap=32)[0]
+    compare(ro, rg)
+    assert list(rg.nsrc0) == [len(c) for c in pair.src]
+
+
+@pytest.mark.parametrize("seed", [0, 7, 123456789])
+def test_keep_less_source_points(ctx, pairs_small, seed):
+    """keep_less_source_pts (cregistration.hpp:2866-2892) as used by the map-to-map registrations (test/mulls_slam.cpp:477-482):
+    halves target ground/facade, caps every source class relative to its target.  Seeded selection sampling, same
+    definition in oracle and device."""
+    P = abi.default_params(keep_less_source_points=1, use_more_points=1, rng_seed=seed, max_iter_num=6)
+    for pair, _ in pairs_small[:2]:
+        # map-to-map shape: source as dense as the target
+        pr = abi.PairData(pair.tgt, [pyoracle.transform(t, np.linalg.inv(pair.init_guess)) for t in pair.tgt], init_guess=pair.init_guess,
+                          tgt_bound=pair.tgt_bound)
+        ro = pyoracle.icp(pr, P, trace_cap=16)[0]
+        rg = ctx.icp(pr, P, trace_cap=16)[0]
+        compare(ro, rg)
+        assert rg.ntgt0[abi.GROUND] <= (len(pair.tgt[abi.GROUND]) + 1) // 2 and rg.nsrc0[abi.GROUND] <= rg.ntgt0[abi.GROUND] // 4 + 1
+
+
 def test_unsupported_options_are_refused(ctx, pairs_small):
     from mulls_amd import lib
 
-    for kw in (dict(normal_shooting_on=1), dict(apply_motion_undistortion=1), dict(keep_less_source_points=1)):
+    for kw in (dict(normal_shooting_on=1),):
         with pytest.raises(lib.MullsError):
             ctx.icp(pairs_small[0][0], abi.default_params(**kw))

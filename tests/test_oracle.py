@@ -249,3 +249,15 @@ def test_synthetic_pairs_converge_near_ground_truth(pairs_small):
         assert r.code == 1
         dt, dr = synth.pose_error(r.T_matrix(), T_gt)
         assert dt < 0.05 and dr < 2e-3
+
+
+def test_keep_less_source_points_is_seeded_and_order_preserving(pairs_small):
+    pair, _ = pairs_small[0]
+    P = abi.default_params(keep_less_source_points=1, rng_seed=5, max_iter_num=2)
+    a = pyoracle.icp(pair, P)[0]
+    b = pyoracle.icp(pair, P)[0]
+    assert a.T[:] == b.T[:] and list(a.nsrc0) == list(b.nsrc0)
+    assert a.ntgt0[abi.GROUND] == a.cropped * 0 + (pyoracle.icp(pair, abi.default_params(max_iter_num=2))[0].ntgt0[abi.GROUND] // 2)
+    P.rng_seed = 6
+    c = pyoracle.icp(pair, P)[0]
+    assert list(c.ntgt0) == list(a.ntgt0) and c.T[:] != a.T[:]
