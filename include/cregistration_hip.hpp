@@ -153,7 +153,7 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 	mulls_result R;
 	std::memset(&R, 0, sizeof(R));
 	const int rc = mulls_icp(ctx, &pair, &P, &R);
-	if (rc != MULLS_OK) // infrastructure failure (HIP error, unsupported option): the reference has no channel for it
+	if (rc != MULLS_OK) // infrastructure failure (no device, HIP error): the reference has no channel for it
 		throw std::runtime_error(std::string("mulls_icp failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
 
 	// constraint_t outputs (cregistration.hpp:1405-1420)

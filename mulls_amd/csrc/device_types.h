@@ -109,11 +109,12 @@ struct RunParams
 	uint8_t w_balance, w_resid, w_dist, w_inten; // weight_strategy[0..3]
 	uint8_t crop;								 // apply_intersection_filter (forced off while undistorting, cregistration.hpp:1186)
 	uint8_t undistort;							 // apply_motion_undistortion_while_registration
+	uint8_t normal_shooting;					 // normal_shooting_on: ground / facade / roof use the 10-NN normal-shooting search
 	uint8_t faithful;
 	float z_xy_ratio;
 	float win_pt, win_pl, win_li;
 	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule
-	uint8_t pad_[2];
+	uint8_t pad_[1];
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging

@@ -205,11 +205,6 @@ int check_params(mulls_ctx *ctx, const mulls_params *P)
 		ctx->err = "used_feature_type needs 6 characters and weight_strategy 4";
 		return MULLS_E_INVALID;
 	}
-	if (P->normal_shooting_on)
-	{
-		ctx->err = "normal_shooting_on is not implemented by this build";
-		return MULLS_E_UNSUPPORTED;
-	}
 	return MULLS_OK;
 }
 
@@ -668,6 +663,7 @@ extern "C"
 		rp.w_resid = P->weight_strategy[1] == '1';
 		rp.w_dist = P->weight_strategy[2] == '1';
 		rp.w_inten = P->weight_strategy[3] == '1';
+		rp.normal_shooting = P->normal_shooting_on != 0;
 		rp.undistort = P->apply_motion_undistortion != 0;
 		rp.crop = P->apply_intersection_filter != 0 && !rp.undistort; // cregistration.hpp:1186
 		rp.faithful = P->faithful != 0;
@@ -879,6 +875,9 @@ extern "C"
 								   B->nn_idx, B->nn_d2, B->winner);
 				else
 					launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				if (rp.normal_shooting)
+					launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2,
+									B->winner);
 				evt.end();
 				evt.begin(&ctx->prof.ms_filter);
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,

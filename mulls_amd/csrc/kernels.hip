@@ -439,8 +439,8 @@ __global__ __launch_bounds__(MULLS_NN_BLOCK) void k_nn(const Job *__restrict__ j
 	__shared__ __attribute__((aligned(16))) float tileZ[MULLS_TILE];
 	const Job job = jobs[blockIdx.x];
 	const PairState &ps = states[job.pair];
-	if (!ps.active)
-		return;
+	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
+		return; // planar classes are served by k_nn_shoot while normal shooting is on
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n, alive_cur = d.alive_cur;
 	const bool called = class_called(rp, d, job.cls);
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = 1 for live points, 0 for dead / out of range
 	const Job job = jobs[blockIdx.x];
 	const PairState &ps = states[job.pair];
-	if (!ps.active)
+	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 
 	const Job job = jobs[blockIdx.x];
 	const PairState &ps = states[job.pair];
-	if (!ps.active)
+	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n, alive_cur = d.alive_cur;
@@ -1156,6 +1156,137 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				if (gate)
 					atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
 			}
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0 && matched_cnt)
+		atomicAdd(&d.n_matched, matched_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Normal-shooting correspondence search (normal_shooting_on; planar classes only: cregistration.hpp:1730-1739, PCL's
+// CorrespondenceEstimationNormalShooting with k = 10).  Among the 10 nearest targets (ascending (d^2, index)) the one
+// minimising |n_s x (p_t - p_s)|^2 (double) wins; it is rejected if that minimum exceeds max_distance (compared with
+// r = 2.5*thr, not r^2 — PCL quirk); the stored distance is that candidate's squared Euclidean distance.  No shipped
+// configuration enables the option, so this kernel is written for exactness, not speed: one query per lane, targets
+// broadcast from an LDS tile, a sorted 10-entry list per lane.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_nn_shoot(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+														   const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
+														   float4 *__restrict__ snrm, const float4 *__restrict__ tpos,
+														   const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+														   unsigned long long *__restrict__ winner)
+{
+	__shared__ float4 tile[1024];
+	const Job job = jobs[blockIdx.x];
+	if (!(job.cls == 0 || job.cls == 2 || job.cls == 4))
+		return; // pillar / beam / vertex always use the plain nearest neighbour
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n, alive_cur = d.alive_cur;
+	const bool called = class_called(rp, d, job.cls);
+	const float r = 2.5f * ps.thr[job.cls];
+	const double max_distance = (double)r;
+	const bool gate = alive_cur >= 500u;
+	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	uint32_t matched_cnt = 0;
+	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++) // uniform trip count: the tile loop below contains barriers
+	{
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		const bool alive = s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE);
+		float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
+		if (alive)
+		{
+			const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+			const double *T = ps.T;
+			const double x = p.x, y = p.y, z = p.z, ax = n.x, ay = n.y, az = n.z;
+			px = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+			py = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+			pz = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+			nx = (float)(T[0] * ax + T[1] * ay + T[2] * az);
+			ny = (float)(T[4] * ax + T[5] * ay + T[6] * az);
+			nz = (float)(T[8] * ax + T[9] * ay + T[10] * az);
+			spos[d.src_off + s] = make_float4(px, py, pz, p.w);
+			snrm[d.src_off + s] = make_float4(nx, ny, nz, n.w);
+		}
+		if (!called)
+			continue;
+		float kd[10];
+		int ki[10];
+#pragma unroll
+		for (int j = 0; j < 10; j++)
+		{
+			kd[j] = __builtin_inff();
+			ki[j] = 0x7fffffff;
+		}
+		for (uint32_t base = 0; base < tgt_n; base += 1024)
+		{
+			const uint32_t nt = min(1024u, tgt_n - base);
+			__syncthreads();
+			for (uint32_t k = threadIdx.x; k < nt; k += MULLS_BLOCK)
+				tile[k] = tpos[d.tgt_off + base + k];
+			__syncthreads();
+			for (uint32_t j = 0; j < nt; j++)
+			{
+				const float4 t = tile[j];
+				const float dx = px - t.x, dy = py - t.y, dz = pz - t.z;
+				float dist = (dx * dx + dy * dy) + dz * dz;
+				int idx = (int)(base + j);
+				if (dist < kd[9]) // indices arrive in ascending order: an equal distance never displaces an earlier index
+				{
+#pragma unroll
+					for (int q = 0; q < 10; q++) // sorted insertion by one pass of compare-exchange
+					{
+						const bool lt = dist < kd[q];
+						const float td = kd[q];
+						const int ti = ki[q];
+						kd[q] = lt ? dist : td;
+						ki[q] = lt ? idx : ti;
+						dist = lt ? td : dist;
+						idx = lt ? ti : idx;
+					}
+				}
+			}
+		}
+		if (!alive)
+			continue;
+		double min_dist = 1.7976931348623157e308;
+		int min_index = 0;
+		const int found = (int)min(10u, tgt_n);
+#pragma unroll
+		for (int j = 0; j < 10; j++)
+			if (j < found)
+			{
+				const float4 t = tpos[d.tgt_off + (uint32_t)ki[j]];
+				const float ptx = px - t.x, pty = py - t.y, ptz = pz - t.z; // PCL forms the difference in float
+				const double Vx = ptx, Vy = pty, Vz = ptz, Nx = nx, Ny = ny, Nz = nz;
+				const double cx = Ny * Vz - Nz * Vy, cy = Nz * Vx - Nx * Vz, cz = Nx * Vy - Ny * Vx;
+				const double dist = cx * cx + cy * cy + cz * cz;
+				if (dist < min_dist)
+				{
+					min_dist = dist;
+					min_index = j;
+				}
+			}
+		float sel_d = 0.0f;
+		int sel_i = -1;
+#pragma unroll
+		for (int j = 0; j < 10; j++)
+			if (j == min_index)
+			{
+				sel_d = kd[j];
+				sel_i = ki[j];
+			}
+		const bool matched = found > 0 && !(min_dist > max_distance);
+		nn_idx[d.src_off + s] = matched ? sel_i : -1;
+		nn_d2[d.src_off + s] = sel_d;
+		if (matched)
+		{
+			matched_cnt++;
+			if (gate)
+				atomicMin(&winner[d.tgt_off + sel_i], key_hi | (unsigned long long)s);
 		}
 	}
 	for (int off = 32; off > 0; off >>= 1)
@@ -1735,6 +1866,13 @@ void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs
 {
 	if (njobs)
 		hipLaunchKernelGGL(k_nn, dim3(njobs), dim3(MULLS_NN_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, tpos, flag, nn_idx, nn_d2, winner);
+}
+void launch_nn_shoot(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
+					 float4 *spos, float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_nn_shoot, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, tpos, flag, nn_idx, nn_d2,
+						   winner);
 }
 void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,

@@ -196,9 +196,11 @@ def test_keep_less_source_points(ctx, pairs_small, seed):
         assert rg.ntgt0[abi.GROUND] <= (len(pair.tgt[abi.GROUND]) + 1) // 2 and rg.nsrc0[abi.GROUND] <= rg.ntgt0[abi.GROUND] // 4 + 1
 
 
-def test_unsupported_options_are_refused(ctx, pairs_small):
-    from mulls_amd import lib
-
-    for kw in (dict(normal_shooting_on=1),):
-        with pytest.raises(lib.MullsError):
-            ctx.icp(pairs_small[0][0], abi.default_params(**kw))
+@pytest.mark.parametrize("used", ["111110", "101010"])
+def test_normal_shooting(ctx, pairs_small, used):
+    """normal_shooting_on: planar classes use PCL's CorrespondenceEstimationNormalShooting (k = 10)."""
+    P = abi.default_params(normal_shooting_on=1, used_feature_type=used, min_neccessary_corr_ratio=0.0 if used == "101010" else 0.03)
+    for pair, _ in pairs_small:
+        ro = pyoracle.icp(pair, P, trace_cap=32)[0]
+        rg = ctx.icp(pair, P, trace_cap=32)[0]
+        compare(ro, rg)
