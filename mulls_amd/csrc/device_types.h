@@ -12,12 +12,12 @@
 #define MULLS_NN_PTS 4		  // ... x 4 register-blocked source points per lane = the same 512 points per job
 #define MULLS_TILE 2048		  // target points staged per LDS tile (3 planar float arrays -> 24 KiB)
 
-#define MULLS_MAXCELLS 65536u // cells of one target-class grid (cell table = 256 KiB per cloud)
+#define MULLS_MAXCELLS 65536u // default cell budget of one target-class grid (256 KiB per cloud); grows with the cloud, see driver.cpp
+#define MULLS_MAXCELLS_CAP (1u << 22)
 #define MULLS_MAXROWS 4096u   // (cy,cz) rows of one grid
 #define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
 #define MULLS_LDS_MAXPTS 10240u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB)
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
-#define MULLS_CELL_STRIDE (MULLS_MAXCELLS + 16u) // entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned)
 #define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
 
 // bits of the per-source-point flag byte
@@ -118,6 +118,7 @@ struct RunParams
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging
+	uint32_t cell_stride;	// entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned), >= grid_maxcells + 1
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

@@ -701,14 +701,16 @@ extern "C"
 			ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
 			return MULLS_E_INVALID;
 		}
-		rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : MULLS_MAXCELLS;
+		// global-memory tier: about four cells per target point of the largest searched cloud, so dense clouds get finer cells
+		rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * lds_cap));
+		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
 		const bool use_grid = tier != 0;
 		if (use_grid)
 		{
 			int n_used = 0;
 			for (int c = 0; c < MULLS_NC; c++)
 				n_used += rp.used[c];
-			const size_t cells = (size_t)n * n_used * MULLS_CELL_STRIDE;
+			const size_t cells = (size_t)n * n_used * rp.cell_stride;
 			if (cells > B->cells_cap)
 			{
 				if (B->cell_cnt)
@@ -1132,7 +1134,10 @@ extern "C"
 		rp->faithful = 1;
 		{
 			uint32_t cap_unused = 0;
-			rp->grid_maxcells = choose_tier(ctx, B, rp->used, &cap_unused) == 2 ? lds_cells_for(cap_unused) : MULLS_MAXCELLS;
+			rp->grid_maxcells = choose_tier(ctx, B, rp->used, &cap_unused) == 2
+									? lds_cells_for(cap_unused)
+									: std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * cap_unused));
+			rp->cell_stride = ((rp->grid_maxcells + 1u + 15u) & ~15u);
 		}
 		rp->tick_base = ctx->tick;
 		ctx->tick += 4;
@@ -1144,7 +1149,7 @@ extern "C"
 					B->wd, *rp, B->grids);
 		if (ctx->nn_mode != 1)
 		{
-			const size_t cells = MULLS_CELL_STRIDE;
+			const size_t cells = rp->cell_stride;
 			if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK ||
 				dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
 				return MULLS_E_HIP;

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 				n_used += rp.used[c] ? 1u : 0u;
 			}
 			g.ncell = (running > 0 && rp.used[cls]) ? g.nx * g.ny * g.nz : 0u;
-			g.cell_off = (pair * n_used + rank) * MULLS_CELL_STRIDE;
+			g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
 			g.pad_[0] = g.pad_[1] = 0;
 			grids[pair * MULLS_NC + cls] = g;
 		}
@@ -824,8 +824,51 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 			continue;
 		float best = __builtin_inff();
 		int bi = -1;
-		grid_scan_box(g, cstart, ts, q.x, q.y, q.z, m, sub, best, bi); // first probe: at most 3x3 rows of 3 cells
+		// probe 0: the query's own cell (dense clouds hold tens to hundreds of targets per cell: this alone gives a tight bound)
+		const int ocx = grid_cell(q.x, g.ox, g.inv_h, g.nx), ocy = grid_cell(q.y, g.oy, g.inv_h, g.ny), ocz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+		{
+			const uint32_t cell = ((uint32_t)ocz * g.ny + (uint32_t)ocy) * g.nx + (uint32_t)ocx;
+			const uint32_t lo = cstart[cell], hi = cstart[cell + 1u];
+			for (uint32_t t = lo + sub; t < hi; t += 4 * MULLS_GRID_GROUP)
+			{
+				float4 c[4];
+				bool v[4];
+#pragma unroll
+				for (int w = 0; w < 4; w++)
+				{
+					v[w] = t + w * MULLS_GRID_GROUP < hi;
+					if (v[w])
+						c[w] = ts[t + w * MULLS_GRID_GROUP];
+				}
+#pragma unroll
+				for (int w = 0; w < 4; w++)
+					if (v[w])
+					{
+						const float dx = q.x - c[w].x, dy = q.y - c[w].y, dz = q.z - c[w].z;
+						const float dist = (dx * dx + dy * dy) + dz * dz;
+						const int idx = __float_as_int(c[w].w);
+						if (dist < best || (dist == best && idx < bi))
+						{
+							best = dist;
+							bi = idx;
+						}
+					}
+			}
+		}
 		group_min(best, bi);
+		// probe 1: the cells within min(first-probe radius, current best distance); skipped when that box is the own cell
+		{
+			const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
+			const float Rm = R1 * 1.0001f + 1e-4f;
+			const bool own_only = grid_cell(q.x - Rm, g.ox, g.inv_h, g.nx) == ocx && grid_cell(q.x + Rm, g.ox, g.inv_h, g.nx) == ocx &&
+								  grid_cell(q.y - Rm, g.oy, g.inv_h, g.ny) == ocy && grid_cell(q.y + Rm, g.oy, g.inv_h, g.ny) == ocy &&
+								  grid_cell(q.z - Rm, g.oz, g.inv_h, g.nz) == ocz && grid_cell(q.z + Rm, g.oz, g.inv_h, g.nz) == ocz;
+			if (!own_only)
+			{
+				grid_scan_box(g, cstart, ts, q.x, q.y, q.z, R1, sub, best, bi);
+				group_min(best, bi);
+			}
+		}
 		if (!(bi >= 0 && best <= m * m))
 		{
 			// nothing inside the first probe: widen to the current best distance, or to the rejection radius

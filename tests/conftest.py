@@ -29,6 +29,16 @@ def ctx(request):
 
 
 @pytest.fixture(scope="session")
+def ctx_auto():
+    """HIP context with the default tier selection (LDS grid for small targets, global-memory grid for large ones)."""
+    from mulls_amd import lib
+
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
 def pairs_small():
     """A few reduced-size synthetic scan pairs (fast enough for the CPU suite)."""
     from mulls_amd import abi, synth
