@@ -36,6 +36,7 @@ struct mulls_ctx
 	mulls_profile prof{};
 	hipEvent_t ev[10] = {};
 	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
+	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 
@@ -82,6 +83,9 @@ struct mulls_batch
 	uint32_t epoch = 0;
 	uint32_t *ticket = nullptr; // device: arrival counter of k_finish
 	uint32_t *bbox_h = nullptr;
+	uint8_t *upload_h = nullptr; // pinned staging buffer of the caller's point records
+	// capacities (elements) of the grow-only arrays
+	size_t cap_stage = 0, cap_src[9] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
 
 namespace
@@ -335,6 +339,202 @@ uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, in
 	return (uint32_t)keep_number;
 }
 
+// grow-only device / pinned arrays: a batch object can be refilled with new pairs without touching the allocator when
+// the previous capacity suffices (mulls_icp / mulls_icp_batch reuse one cached batch per context)
+template <typename T>
+int grow(mulls_ctx *ctx, T **p, size_t *cap, size_t need, bool *grew = nullptr)
+{
+	if (grew)
+		*grew = false;
+	if (*p && *cap >= need)
+		return MULLS_OK;
+	if (*p)
+		(void)hipFree(*p);
+	*p = nullptr;
+	const size_t want = std::max<size_t>(need + need / 4, 64);
+	HIPCHK(ctx, hipMalloc((void **)p, want * sizeof(T)));
+	*cap = want;
+	if (grew)
+		*grew = true;
+	return MULLS_OK;
+}
+template <typename T>
+int grow_pinned(mulls_ctx *ctx, T **p, size_t *cap, size_t need, unsigned flags)
+{
+	if (*p && *cap >= need)
+		return MULLS_OK;
+	if (*p)
+		(void)hipHostFree((void *)*p);
+	*p = nullptr;
+	const size_t want = std::max<size_t>(need + need / 4, 64);
+	HIPCHK(ctx, hipHostMalloc((void **)p, want * sizeof(T), flags));
+	*cap = want;
+	return MULLS_OK;
+}
+
+// lay the pairs out in the batch arenas, (re)allocate what is too small and stage the caller's clouds in HBM
+int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
+{
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	B->n = n;
+	B->descs_h.assign((size_t)n * MULLS_NC, CloudDesc());
+	B->setup_h.assign(n, PairSetup());
+	B->setup_jobs_h.clear();
+	B->jobs_key.clear(); // the job table depends on the layout
+	size_t stage_rec = 0, so = 0, to = 0;
+	for (int p = 0; p < n; p++)
+	{
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			std::memset(&d, 0, sizeof(d));
+			const mulls_cloud &s = pairs[p].src[c], &t = pairs[p].tgt[c];
+			if ((s.n && (!s.pts || s.stride < MULLS_POINT_BYTES)) || (t.n && (!t.pts || t.stride < MULLS_POINT_BYTES)))
+			{
+				ctx->err = "cloud with points but null pointer or stride < 48";
+				return MULLS_E_INVALID;
+			}
+			d.src_stage = (uint32_t)stage_rec;
+			d.src_n0 = s.n;
+			stage_rec += s.n;
+			d.tgt_stage = (uint32_t)stage_rec;
+			d.tgt_n0 = t.n;
+			stage_rec += t.n;
+			// block2->pc_*_down for the undistortion branch: staged separately only when it is a different cloud
+			const mulls_cloud &sd = pairs[p].src_down[c];
+			const bool own_down = c != MULLS_VERTEX && sd.pts && sd.n && !(sd.pts == s.pts && sd.n == s.n && sd.stride == s.stride);
+			if (own_down && sd.stride < MULLS_POINT_BYTES)
+			{
+				ctx->err = "src_down cloud with stride < 48";
+				return MULLS_E_INVALID;
+			}
+			d.sd_stage = own_down ? (uint32_t)stage_rec : d.src_stage;
+			d.sd_n0 = own_down ? sd.n : s.n;
+			if (own_down)
+				stage_rec += sd.n;
+			d.src_cap = std::max(d.src_n0, d.sd_n0);
+			d.src_off = (uint32_t)so;
+			d.tgt_off = (uint32_t)to;
+			so += d.src_cap;
+			to += t.n;
+			for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
+			{
+				Job j = {(uint32_t)p, (uint32_t)c, k, 0};
+				B->setup_jobs_h.push_back(j);
+			}
+		}
+		rows12(pairs[p].init_guess, B->setup_h[p].guess);
+		std::memcpy(B->setup_h[p].tgt_bound, pairs[p].tgt_bound, sizeof(double) * 6);
+		{
+			// inverse(initial_guess) as quaternion + translation (cregistration.hpp:1248, cfilter.hpp:497-500)
+			Mat4 g;
+			std::memcpy(g.v, pairs[p].init_guess, sizeof(g.v));
+			const Mat4 gi = mulls::invert4(g);
+			mulls::rotation_quaternion(gi, B->setup_h[p].inv_q);
+			B->setup_h[p].inv_t[0] = gi.at(0, 3);
+			B->setup_h[p].inv_t[1] = gi.at(1, 3);
+			B->setup_h[p].inv_t[2] = gi.at(2, 3);
+			B->setup_h[p].inv_t[3] = 0.0;
+		}
+	}
+	if (stage_rec >= (1ull << 31))
+	{
+		ctx->err = "batch too large (>= 2^31 points)";
+		return MULLS_E_INVALID;
+	}
+	B->n_src = so;
+	B->n_tgt = to;
+
+	int rc = MULLS_OK;
+	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
+	bool winner_grew = false;
+	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec * 3));
+	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so));
+	A(grow(ctx, &B->tmp_nrm, &B->cap_src[1], so));
+	A(grow(ctx, &B->spos, &B->cap_src[2], so));
+	A(grow(ctx, &B->snrm, &B->cap_src[3], so));
+	A(grow(ctx, &B->flag, &B->cap_src[4], so));
+	A(grow(ctx, &B->match, &B->cap_src[5], so));
+	A(grow(ctx, &B->nn_idx, &B->cap_src[6], so));
+	A(grow(ctx, &B->wd, &B->cap_src[7], so));
+	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so));
+	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
+	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
+	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to));
+	A(grow(ctx, &B->winner, &B->cap_tgt[3], to, &winner_grew));
+	A(grow(ctx, &B->descs, &B->cap_pairs[0], (size_t)n * MULLS_NC));
+	A(grow(ctx, &B->setup, &B->cap_pairs[1], (size_t)n));
+	A(grow(ctx, &B->states, &B->cap_pairs[2], (size_t)n));
+	A(grow(ctx, &B->bbox, &B->cap_pairs[3], (size_t)n * 6));
+	A(grow(ctx, &B->grids, &B->cap_pairs[4], (size_t)n * MULLS_NC));
+	A(grow(ctx, &B->setup_jobs, &B->cap_setup_jobs, B->setup_jobs_h.size()));
+	if (!B->ticket)
+	{
+		A(dmalloc(ctx, &B->ticket, 1));
+		if (rc == MULLS_OK && hipMemset(B->ticket, 0, sizeof(uint32_t)) != hipSuccess)
+			rc = MULLS_E_HIP;
+	}
+	A(grow_pinned(ctx, &B->states_h, &B->cap_pin[0], (size_t)n, hipHostMallocMapped));
+	A(grow_pinned(ctx, &B->outs_h, &B->cap_pin[1], (size_t)n, hipHostMallocMapped));
+	A(grow_pinned(ctx, &B->bbox_h, &B->cap_pin[2], (size_t)n * 6, hipHostMallocDefault));
+	A(grow_pinned(ctx, &B->upload_h, &B->cap_pin[3], std::max<size_t>(stage_rec, 1) * MULLS_POINT_BYTES, hipHostMallocDefault));
+	if (rc == MULLS_OK && !B->epoch_h)
+	{
+		if (hipHostMalloc((void **)&B->epoch_h, 64, hipHostMallocMapped) != hipSuccess)
+			rc = MULLS_E_HIP;
+		else
+			*B->epoch_h = 0;
+	}
+	if (rc != MULLS_OK)
+		return rc;
+	if (hipHostGetDevicePointer((void **)&B->states_pin, B->states_h, 0) != hipSuccess ||
+		hipHostGetDevicePointer((void **)&B->outs, B->outs_h, 0) != hipSuccess ||
+		hipHostGetDevicePointer((void **)&B->epoch_dev, (void *)B->epoch_h, 0) != hipSuccess)
+	{
+		ctx->err = "pinned host memory setup failed";
+		return MULLS_E_HIP;
+	}
+	std::memset(B->states_h, 0, sizeof(PairState) * n);
+	for (int p = 0; p < n; p++)
+		for (int k = 0; k < 6; k++)
+			B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
+
+	// stage the caller's AoS records (48-B PointXYZINormal) contiguously in pinned memory, then one H2D copy
+	for (int p = 0; p < n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			const mulls_cloud *cl[3] = {&pairs[p].src[c], &pairs[p].tgt[c], &pairs[p].src_down[c]};
+			const uint32_t off[3] = {d.src_stage, d.tgt_stage, d.sd_stage};
+			for (int k = 0; k < (d.sd_stage != d.src_stage ? 3 : 2); k++)
+			{
+				uint8_t *dst = B->upload_h + (size_t)off[k] * MULLS_POINT_BYTES;
+				const uint8_t *src = (const uint8_t *)cl[k]->pts;
+				if (cl[k]->stride == MULLS_POINT_BYTES)
+					std::memcpy(dst, src, (size_t)cl[k]->n * MULLS_POINT_BYTES);
+				else
+					for (uint32_t i = 0; i < cl[k]->n; i++)
+						std::memcpy(dst + (size_t)i * MULLS_POINT_BYTES, src + (size_t)i * cl[k]->stride, MULLS_POINT_BYTES);
+			}
+		}
+	hipStream_t st = ctx->stream;
+	hipError_t e = hipMemcpyAsync(B->stage, B->upload_h, stage_rec * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(B->setup, B->setup_h.data(), sizeof(PairSetup) * n, hipMemcpyHostToDevice, st);
+	if (e == hipSuccess && winner_grew) // later epochs always sort below older entries (k_nn), so only fresh memory needs the fill
+		e = hipMemsetAsync(B->winner, 0xff, B->cap_tgt[3] * sizeof(unsigned long long), st);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(st); // setup_jobs_h / setup_h / upload_h may be rewritten by the next fill
+	if (e != hipSuccess)
+	{
+		ctx->err = std::string("staging upload: ") + hipGetErrorString(e);
+		return MULLS_E_HIP;
+	}
+	return MULLS_OK;
+}
+
 struct EvTimer
 {
 	mulls_ctx *ctx;
@@ -420,6 +620,8 @@ extern "C"
 		if (!ctx)
 			return;
 		(void)hipSetDevice(ctx->device);
+		if (ctx->scratch)
+			mulls_batch_destroy(ctx, ctx->scratch);
 		for (auto &e : ctx->ev)
 			if (e)
 				(void)hipEventDestroy(e);
@@ -476,6 +678,8 @@ extern "C"
 			(void)hipHostFree(B->bbox_h);
 		if (B->epoch_h)
 			(void)hipHostFree((void *)B->epoch_h);
+		if (B->upload_h)
+			(void)hipHostFree(B->upload_h);
 		delete B;
 	}
 
@@ -484,158 +688,12 @@ extern "C"
 		if (!ctx || !pairs || n <= 0 || !out)
 			return MULLS_E_INVALID;
 		*out = nullptr;
-		HIPCHK(ctx, hipSetDevice(ctx->device));
 		mulls_batch *B = new mulls_batch();
-		B->n = n;
-		B->descs_h.resize((size_t)n * MULLS_NC);
-		B->setup_h.resize(n);
-		size_t stage_rec = 0, so = 0, to = 0;
-		for (int p = 0; p < n; p++)
-		{
-			for (int c = 0; c < MULLS_NC; c++)
-			{
-				CloudDesc &d = B->descs_h[p * MULLS_NC + c];
-				std::memset(&d, 0, sizeof(d));
-				const mulls_cloud &s = pairs[p].src[c], &t = pairs[p].tgt[c];
-				if ((s.n && (!s.pts || s.stride < MULLS_POINT_BYTES)) || (t.n && (!t.pts || t.stride < MULLS_POINT_BYTES)))
-				{
-					ctx->err = "cloud with points but null pointer or stride < 48";
-					delete B;
-					return MULLS_E_INVALID;
-				}
-				d.src_stage = (uint32_t)stage_rec;
-				d.src_n0 = s.n;
-				stage_rec += s.n;
-				d.tgt_stage = (uint32_t)stage_rec;
-				d.tgt_n0 = t.n;
-				stage_rec += t.n;
-				// block2->pc_*_down for the undistortion branch: staged separately only when it is a different cloud
-				const mulls_cloud &sd = pairs[p].src_down[c];
-				const bool own_down = c != MULLS_VERTEX && sd.pts && sd.n && !(sd.pts == s.pts && sd.n == s.n && sd.stride == s.stride);
-				if (own_down && sd.stride < MULLS_POINT_BYTES)
-				{
-					ctx->err = "src_down cloud with stride < 48";
-					delete B;
-					return MULLS_E_INVALID;
-				}
-				d.sd_stage = own_down ? (uint32_t)stage_rec : d.src_stage;
-				d.sd_n0 = own_down ? sd.n : s.n;
-				if (own_down)
-					stage_rec += sd.n;
-				d.src_cap = std::max(d.src_n0, d.sd_n0);
-				d.src_off = (uint32_t)so;
-				d.tgt_off = (uint32_t)to;
-				so += d.src_cap;
-				to += t.n;
-				for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
-				{
-					Job j = {(uint32_t)p, (uint32_t)c, k, 0};
-					B->setup_jobs_h.push_back(j);
-				}
-			}
-			rows12(pairs[p].init_guess, B->setup_h[p].guess);
-			std::memcpy(B->setup_h[p].tgt_bound, pairs[p].tgt_bound, sizeof(double) * 6);
-			{
-				// inverse(initial_guess) as quaternion + translation (cregistration.hpp:1248, cfilter.hpp:497-500)
-				Mat4 g;
-				std::memcpy(g.v, pairs[p].init_guess, sizeof(g.v));
-				const Mat4 gi = mulls::invert4(g);
-				mulls::rotation_quaternion(gi, B->setup_h[p].inv_q);
-				B->setup_h[p].inv_t[0] = gi.at(0, 3);
-				B->setup_h[p].inv_t[1] = gi.at(1, 3);
-				B->setup_h[p].inv_t[2] = gi.at(2, 3);
-				B->setup_h[p].inv_t[3] = 0.0;
-			}
-		}
-		if (stage_rec >= (1ull << 31))
-		{
-			ctx->err = "batch too large (>= 2^31 points)";
-			delete B;
-			return MULLS_E_INVALID;
-		}
-		B->n_src = so;
-		B->n_tgt = to;
-
-		int rc = MULLS_OK;
-		auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
-		A(dmalloc(ctx, &B->stage, stage_rec * 3));
-		A(dmalloc(ctx, &B->tmp_pos, so));
-		A(dmalloc(ctx, &B->tmp_nrm, so));
-		A(dmalloc(ctx, &B->spos, so));
-		A(dmalloc(ctx, &B->snrm, so));
-		A(dmalloc(ctx, &B->tpos, to));
-		A(dmalloc(ctx, &B->tnrm, to));
-		A(dmalloc(ctx, &B->flag, so));
-		A(dmalloc(ctx, &B->match, so));
-		A(dmalloc(ctx, &B->nn_idx, so));
-		A(dmalloc(ctx, &B->wd, so));
-		A(dmalloc(ctx, &B->nn_d2, so));
-		A(dmalloc(ctx, &B->winner, to));
-		A(dmalloc(ctx, &B->descs, (size_t)n * MULLS_NC));
-		A(dmalloc(ctx, &B->setup, (size_t)n));
-		A(dmalloc(ctx, &B->ticket, 1));
-		A(dmalloc(ctx, &B->states, (size_t)n));
-		A(dmalloc(ctx, &B->bbox, (size_t)n * 6));
-		A(dmalloc(ctx, &B->setup_jobs, B->setup_jobs_h.size()));
-		A(dmalloc(ctx, &B->grids, (size_t)n * MULLS_NC));
-		A(dmalloc(ctx, &B->tsorted, to));
+		const int rc = batch_fill(ctx, B, pairs, n);
 		if (rc != MULLS_OK)
 		{
 			mulls_batch_destroy(ctx, B);
 			return rc;
-		}
-		if (hipHostMalloc((void **)&B->states_h, sizeof(PairState) * n, hipHostMallocMapped) != hipSuccess ||
-			hipHostMalloc((void **)&B->outs_h, sizeof(PairOut) * n, hipHostMallocMapped) != hipSuccess ||
-			hipHostMalloc((void **)&B->epoch_h, 64, hipHostMallocMapped) != hipSuccess ||
-			hipHostMalloc((void **)&B->bbox_h, sizeof(uint32_t) * 6 * n, hipHostMallocDefault) != hipSuccess ||
-			hipHostGetDevicePointer((void **)&B->states_pin, B->states_h, 0) != hipSuccess ||
-			hipHostGetDevicePointer((void **)&B->outs, B->outs_h, 0) != hipSuccess ||
-			hipHostGetDevicePointer((void **)&B->epoch_dev, (void *)B->epoch_h, 0) != hipSuccess ||
-			hipMemset(B->ticket, 0, sizeof(uint32_t)) != hipSuccess)
-		{
-			ctx->err = "pinned host memory setup failed";
-			mulls_batch_destroy(ctx, B);
-			return MULLS_E_HIP;
-		}
-		*B->epoch_h = 0;
-		std::memset(B->states_h, 0, sizeof(PairState) * n);
-		for (int p = 0; p < n; p++)
-			for (int k = 0; k < 6; k++)
-				B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
-
-		// stage the caller's AoS records (48-B PointXYZINormal) contiguously, then one H2D copy
-		{
-			std::vector<uint8_t> host(std::max<size_t>(stage_rec, 1) * MULLS_POINT_BYTES);
-			for (int p = 0; p < n; p++)
-				for (int c = 0; c < MULLS_NC; c++)
-				{
-					const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
-					const mulls_cloud *cl[3] = {&pairs[p].src[c], &pairs[p].tgt[c], &pairs[p].src_down[c]};
-					const uint32_t off[3] = {d.src_stage, d.tgt_stage, d.sd_stage};
-					for (int k = 0; k < (d.sd_stage != d.src_stage ? 3 : 2); k++)
-					{
-						uint8_t *dst = host.data() + (size_t)off[k] * MULLS_POINT_BYTES;
-						const uint8_t *src = (const uint8_t *)cl[k]->pts;
-						if (cl[k]->stride == MULLS_POINT_BYTES)
-							std::memcpy(dst, src, (size_t)cl[k]->n * MULLS_POINT_BYTES);
-						else
-							for (uint32_t i = 0; i < cl[k]->n; i++)
-								std::memcpy(dst + (size_t)i * MULLS_POINT_BYTES, src + (size_t)i * cl[k]->stride, MULLS_POINT_BYTES);
-					}
-				}
-			hipError_t e = hipMemcpy(B->stage, host.data(), stage_rec * MULLS_POINT_BYTES, hipMemcpyHostToDevice);
-			if (e == hipSuccess)
-				e = hipMemcpy(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice);
-			if (e == hipSuccess)
-				e = hipMemcpy(B->setup, B->setup_h.data(), sizeof(PairSetup) * n, hipMemcpyHostToDevice);
-			if (e == hipSuccess)
-				e = hipMemset(B->winner, 0xff, std::max<size_t>(to, 1) * sizeof(unsigned long long));
-			if (e != hipSuccess)
-			{
-				ctx->err = std::string("staging upload: ") + hipGetErrorString(e);
-				mulls_batch_destroy(ctx, B);
-				return MULLS_E_HIP;
-			}
 		}
 		*out = B;
 		return MULLS_OK;
@@ -1058,13 +1116,14 @@ extern "C"
 		int rc = check_params(ctx, params);
 		if (rc != MULLS_OK)
 			return rc;
-		mulls_batch *B = nullptr;
-		rc = mulls_batch_create(ctx, pairs, n, &B);
+		if (!pairs || n <= 0 || !results)
+			return MULLS_E_INVALID;
+		if (!ctx->scratch)
+			ctx->scratch = new mulls_batch();
+		rc = batch_fill(ctx, ctx->scratch, pairs, n);
 		if (rc != MULLS_OK)
 			return rc;
-		rc = mulls_batch_run(ctx, B, params, results);
-		mulls_batch_destroy(ctx, B);
-		return rc;
+		return mulls_batch_run(ctx, ctx->scratch, params, results);
 	}
 
 	int mulls_icp(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result)
