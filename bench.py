@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=256, help="scan pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nn-mode", type=int, default=0, help="0 auto (grid staged in LDS), 1 brute force, 2 grid in global memory, 3 grid in LDS")
     args = ap.parse_args()

@@ -17,6 +17,7 @@
 #define MULLS_MAXROWS 4096u   // (cy,cz) rows of one grid
 #define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
 #define MULLS_LDS_MAXPTS 10240u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB)
+#define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
 #define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
 

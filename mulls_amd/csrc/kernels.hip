@@ -928,8 +928,12 @@ __device__ __forceinline__ void row16_min(float &best, int &bi)
 {
 	dpp_min_step<0xB1>(best, bi);  // quad_perm [1,0,3,2]
 	dpp_min_step<0x4E>(best, bi);  // quad_perm [2,3,0,1]
-	dpp_min_step<0x141>(best, bi); // row_half_mirror
-	dpp_min_step<0x140>(best, bi); // row_mirror
+#if MULLS_LDS_GROUP >= 8
+	dpp_min_step<0x141>(best, bi); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
+#endif
+#if MULLS_LDS_GROUP == 16
+	dpp_min_step<0x140>(best, bi); // row_mirror: lanes i <-> 15 - i
+#endif
 }
 
 __device__ __forceinline__ void lds_eval(const LdsGrid &L, uint32_t t, float px, float py, float pz, float &best, int &bi)
@@ -1013,7 +1017,7 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 		}
 #pragma unroll
 		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++) // ranges holding more than 16 candidates
-			for (uint32_t t = lo[jj] + sub + MULLS_GRID_GROUP; t < hi[jj]; t += MULLS_GRID_GROUP)
+			for (uint32_t t = lo[jj] + sub + MULLS_LDS_GROUP; t < hi[jj]; t += MULLS_LDS_GROUP)
 				lds_eval(L, t, px, py, pz, best, bi);
 	}
 }
@@ -1131,9 +1135,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const bool gate = alive_cur >= 500u;
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
-	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
+	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
 	uint32_t matched_cnt = 0;
-	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_GRID_GROUP)
+	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
 	{
 		const uint32_t s = job.start + k;
 		if (s >= src_n)
@@ -1150,9 +1154,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		{
 			const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
 			const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
-			for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_GRID_GROUP) // two candidates in flight per lane and trip
+			for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 			{
-				const uint32_t t2 = t + MULLS_GRID_GROUP;
+				const uint32_t t2 = t + MULLS_LDS_GROUP;
 				const bool ok2 = t2 < hi;
 				const uint32_t tt2 = ok2 ? t2 : t;
 				const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
