@@ -196,6 +196,89 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 	return R.code;
 }
 
+// lls_icp_3dof_ground (cregistration.hpp:1443-1445), verbatim signature.  Like the reference it returns the process code cast
+// to bool (true for 1, -1 and -2 alike) and only writes registration_cons.Trans1_2.
+template <typename PointT>
+bool lls_icp_3dof_ground(constraint_t &registration_cons, int max_iter_num = 20, float dis_thre_unit = 1.5, float converge_translation = 0.002,
+						 float converge_rotation_d = 0.01, float dis_thre_min = 0.4, float dis_thre_update_rate = 1.1,
+						 std::string weight_strategy = "1111", Eigen::Matrix4d initial_guess = Eigen::Matrix4d::Identity(),
+						 bool keep_less_source_points = false, float max_bearable_rotation_d = 10.0)
+{
+	mulls_ctx *ctx = thread_context();
+	mulls_pair pair;
+	std::memset(&pair, 0, sizeof(pair));
+	pair.tgt[MULLS_GROUND] = borrow(registration_cons.block1->pc_ground);
+	pair.src[MULLS_GROUND] = borrow(registration_cons.block2->pc_ground_down);
+	std::memcpy(pair.init_guess, initial_guess.data(), sizeof(pair.init_guess));
+	mulls_params P;
+	mulls_default_params(&P);
+	P.max_iter_num = max_iter_num;
+	P.dis_thre_unit = dis_thre_unit;
+	P.converge_translation = converge_translation;
+	P.converge_rotation_d = converge_rotation_d;
+	P.dis_thre_min = dis_thre_min;
+	P.dis_thre_update_rate = dis_thre_update_rate;
+	std::memset(P.weight_strategy, 0, sizeof(P.weight_strategy));
+	std::strncpy(P.weight_strategy, weight_strategy.c_str(), sizeof(P.weight_strategy) - 1);
+	P.keep_less_source_points = keep_less_source_points;
+	P.max_bearable_rotation_d = max_bearable_rotation_d;
+	mulls_result R;
+	std::memset(&R, 0, sizeof(R));
+	const int rc = mulls_icp_3dof_ground(ctx, &pair, &P, &R);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_icp_3dof_ground failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	std::memcpy(registration_cons.Trans1_2.data(), R.T, sizeof(R.T));
+	return R.code != 0;
+}
+
+// mm_lls_icp_4dof_global (cregistration.hpp:1584-1586), verbatim signature: all heading trials run as one batch.
+template <typename PointT>
+bool mm_lls_icp_4dof_global(constraint_t &registration_con, float heading_step_d, int max_iter_num = 20, float dis_thre_unit = 1.5,
+							float converge_translation = 0.005, float converge_rotation_d = 0.05, float dis_thre_min = 0.5,
+							float dis_thre_update_rate = 1.05, float max_bearable_rotation_d = 15.0)
+{
+	mulls_ctx *ctx = thread_context();
+	cloudblock_t &b1 = *registration_con.block1;
+	cloudblock_t &b2 = *registration_con.block2;
+	mulls_pair pair;
+	std::memset(&pair, 0, sizeof(pair));
+	pair.tgt[MULLS_GROUND] = borrow(b1.pc_ground);
+	pair.tgt[MULLS_PILLAR] = borrow(b1.pc_pillar);
+	pair.tgt[MULLS_FACADE] = borrow(b1.pc_facade);
+	pair.tgt[MULLS_BEAM] = borrow(b1.pc_beam);
+	pair.tgt[MULLS_ROOF] = borrow(b1.pc_roof);
+	pair.tgt[MULLS_VERTEX] = borrow(b1.pc_vertex);
+	pair.src[MULLS_GROUND] = borrow(b2.pc_ground_down);
+	pair.src[MULLS_PILLAR] = borrow(b2.pc_pillar_down);
+	pair.src[MULLS_FACADE] = borrow(b2.pc_facade_down);
+	pair.src[MULLS_BEAM] = borrow(b2.pc_beam_down);
+	pair.src[MULLS_ROOF] = borrow(b2.pc_roof_down);
+	pair.src[MULLS_VERTEX] = borrow(b2.pc_vertex);
+	pair.tgt_bound[0] = b1.local_bound.min_x;
+	pair.tgt_bound[1] = b1.local_bound.min_y;
+	pair.tgt_bound[2] = b1.local_bound.min_z;
+	pair.tgt_bound[3] = b1.local_bound.max_x;
+	pair.tgt_bound[4] = b1.local_bound.max_y;
+	pair.tgt_bound[5] = b1.local_bound.max_z;
+	const double station[3] = {b2.local_station.x, b2.local_station.y, b2.local_station.z};
+	mulls_result R;
+	std::memset(&R, 0, sizeof(R));
+	int success = 0;
+	float best_heading = 0.0f;
+	const int rc = mulls_icp_4dof_global(ctx, &pair, heading_step_d, station, max_iter_num, dis_thre_unit, converge_translation, converge_rotation_d,
+										 dis_thre_min, dis_thre_update_rate, max_bearable_rotation_d, &R, &success, &best_heading);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_icp_4dof_global failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	if (success) // the reference only touches registration_con when at least one trial succeeded (:1645-1657)
+	{
+		std::memcpy(registration_con.Trans1_2.data(), R.T, sizeof(R.T));
+		std::memcpy(registration_con.information_matrix.data(), R.info, sizeof(R.info));
+		registration_con.sigma = R.sigma;
+		registration_con.confidence = R.confidence;
+	}
+	return success != 0;
+}
+
 } // namespace hip
 } // namespace lo
 

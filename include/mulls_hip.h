@@ -192,6 +192,26 @@ int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_bat
 int mulls_batch_run(mulls_ctx *ctx, mulls_batch *batch, const mulls_params *params, mulls_result *results);
 void mulls_batch_destroy(mulls_ctx *ctx, mulls_batch *batch);
 
+/* ---- variants of the path ---- */
+
+/* lls_icp_3dof_ground (cregistration.hpp:1443-1582): ground class only, unknowns (roll, pitch, z).  Reads the like-named
+ * fields of mulls_params: max_iter_num, dis_thre_unit, converge_translation, converge_rotation_d, dis_thre_min,
+ * dis_thre_update_rate, weight_strategy[1..3], keep_less_source_points (+ rng_seed), max_bearable_rotation_d (the
+ * reference's default for it is 10).  Only result->T and result->code are outputs of this variant (the reference
+ * returns the code cast to bool). */
+int mulls_icp_3dof_ground(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result);
+int mulls_icp_3dof_ground_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
+
+/* mm_lls_icp_4dof_global (cregistration.hpp:1584-1681): sweeps the heading of the source about `station`
+ * (block2->local_station) in steps of heading_step_d degrees; every trial is a full mm_lls_icp with classes "111110" and
+ * weights "1001", all trials run as one lock-step batch; the trial maximising confidence / sigma wins.  pair->init_guess
+ * is ignored.  converge_rotation_d and max_bearable_rotation_d are accepted for signature fidelity; the reference does
+ * not use them (it passes converge_translation twice).  result->iters returns the number of trials. */
+int mulls_icp_4dof_global(mulls_ctx *ctx, const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num,
+						  float dis_thre_unit, float converge_translation, float converge_rotation_d, float dis_thre_min,
+						  float dis_thre_update_rate, float max_bearable_rotation_d, mulls_result *result, int *success,
+						  float *best_heading_d);
+
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 
 /* batch_transform_feature_points (cregistration.hpp:1685-1696): in place on a host cloud via the device kernel */

@@ -118,6 +118,7 @@ struct RunParams
 	uint8_t pad_[1];
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
+	int32_t resid_from_iter; // residual weighting applies when iter_num > this (2 for mm_lls_icp, cregistration.hpp:1905-1907; -1 for the 3-DoF variant)
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging
 	uint32_t cell_stride;	// entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned), >= grid_maxcells + 1
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)

@@ -181,6 +181,22 @@ inline Mat4 invert4(const Mat4 &in)
 	return out;
 }
 
+// inverse of a 3x3 (column-major) by cofactors over the determinant, as Eigen 3.3 does for fixed 3x3 matrices
+inline void invert3(const double m[9], double out[9])
+{
+	auto M = [&](int r, int c) { return m[r + 3 * c]; };
+	auto cof = [&](int i, int j) {
+		const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+		return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+	};
+	const double c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+	const double det = (c0 * M(0, 0) + c1 * M(1, 0)) + c2 * M(2, 0);
+	const double invdet = 1.0 / det;
+	out[0] = c0 * invdet, out[3] = c1 * invdet, out[6] = c2 * invdet;
+	out[1] = cof(0, 1) * invdet, out[4] = cof(1, 1) * invdet, out[7] = cof(2, 1) * invdet;
+	out[2] = cof(0, 2) * invdet, out[5] = cof(1, 2) * invdet, out[8] = cof(2, 2) * invdet;
+}
+
 // unit quaternion (w,x,y,z) of the upper-left 3x3 (Shepperd branches, as Eigen::Quaterniond(Matrix3d))
 inline void rotation_quaternion(const Mat4 &T, double q[4])
 {

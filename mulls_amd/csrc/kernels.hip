@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 		class_w = (float)((0.01 > v) ? 0.01 : v);
 	}
 	const int iter_num = ps.iter;
-	const bool resid_w = rp.w_resid && iter_num > 2;
+	const bool resid_w = rp.w_resid && iter_num > rp.resid_from_iter;
 	const bool dist_w = rp.w_dist, inten_w = rp.w_inten;
 	const float window = metric == 0 ? rp.win_pl : (metric == 1 ? rp.win_li : rp.win_pt);
 

@@ -47,6 +47,10 @@ def load():
     lib.mulls_batch_run.argtypes = [vp, vp, C.POINTER(abi.Params), C.POINTER(abi.Result)]
     lib.mulls_batch_destroy.argtypes = [vp, vp]
     lib.mulls_batch_destroy.restype = None
+    lib.mulls_icp_3dof_ground.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_icp_3dof_ground_batch.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_icp_4dof_global.argtypes = [vp, C.POINTER(abi.Pair), C.c_float, C.POINTER(C.c_double), C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.POINTER(abi.Result), C.POINTER(C.c_int), C.POINTER(C.c_float)]
     lib.mulls_stage_transform.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     lib.mulls_stage_correspond.argtypes = [vp, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), C.c_float, C.c_int, C.c_float, vp, vp, vp]
     lib.mulls_stage_accumulate.argtypes = [vp, C.c_int, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), vp, vp, vp, C.c_uint32, C.c_int,
@@ -58,7 +62,8 @@ def load():
 EXPORTS = [
     "mulls_default_params", "mulls_create", "mulls_destroy", "mulls_last_error", "mulls_set_profiling", "mulls_get_profile",
     "mulls_stream", "mulls_set_nn_mode", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
-    "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate",
+    "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate", "mulls_icp_3dof_ground", "mulls_icp_3dof_ground_batch",
+    "mulls_icp_4dof_global",
 ]
 
 
@@ -117,6 +122,27 @@ class Context:
 
     def batch(self, pairs):
         return Batch(self, pairs)
+
+    # --- variants ------------------------------------------------------------------------------------
+    def icp_3dof_ground(self, pairs, params, trace_cap=0):
+        """lls_icp_3dof_ground on one PairData or a list of them."""
+        plist = pairs if isinstance(pairs, (list, tuple)) else [pairs]
+        arr = abi.make_pair_array(plist)
+        res = abi.make_result_array(len(plist), trace_cap)
+        self._check(self.lib.mulls_icp_3dof_ground_batch(self.h, arr, len(plist), C.byref(params), res), "mulls_icp_3dof_ground_batch")
+        return res
+
+    def icp_4dof_global(self, pair, heading_step_d, station, max_iter_num=20, dis_thre_unit=1.5, converge_translation=0.005,
+                        converge_rotation_d=0.05, dis_thre_min=0.5, dis_thre_update_rate=1.05, max_bearable_rotation_d=15.0):
+        """mm_lls_icp_4dof_global.  Returns (results, success, best_heading_deg)."""
+        res = abi.make_result_array(1, 0)
+        p = pair.as_pair()
+        ok, best = C.c_int(0), C.c_float(0)
+        st = (C.c_double * 3)(*station)
+        self._check(self.lib.mulls_icp_4dof_global(self.h, C.byref(p), heading_step_d, st, int(max_iter_num), dis_thre_unit, converge_translation,
+                                                   converge_rotation_d, dis_thre_min, dis_thre_update_rate, max_bearable_rotation_d, res,
+                                                   C.byref(ok), C.byref(best)), "mulls_icp_4dof_global")
+        return res, bool(ok.value), float(best.value)
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

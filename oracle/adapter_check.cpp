@@ -107,6 +107,21 @@ int main(int argc, char **argv)
 	Eigen::Matrix4d initial_guess_tran;
 	std::memcpy(initial_guess_tran.data(), guess_raw, sizeof(guess_raw));
 
+	if (std::string(argv[2]) == "variants")
+	{
+		// lls_icp_3dof_ground and mm_lls_icp_4dof_global: reference members vs the bridge functions of the same names
+		lo::CRegistration<Point_T> cr;
+		const bool a3 = cr.lls_icp_3dof_ground(con_ref, 20, 1.5, 0.002, 0.01, 0.4, 1.1, "1111", initial_guess_tran);
+		const bool b3 = lo::hip::lls_icp_3dof_ground<Point_T>(con_hip, 20, 1.5, 0.002, 0.01, 0.4, 1.1, "1111", initial_guess_tran);
+		print_result("reference_3dof", a3 ? 1 : 0, con_ref, 0);
+		print_result("hip_3dof", b3 ? 1 : 0, con_hip, 0);
+		con_ref.block2->local_station.x = con_hip.block2->local_station.x = 0.5;
+		const bool a4 = cr.mm_lls_icp_4dof_global(con_ref, 60.0f, 8, 2.0);
+		const bool b4 = lo::hip::mm_lls_icp_4dof_global<Point_T>(con_hip, 60.0f, 8, 2.0);
+		print_result("reference_4dof", a4 ? 1 : 0, con_ref, 0);
+		print_result("hip_4dof", b4 ? 1 : 0, con_hip, 0);
+		return 0;
+	}
 	const bool kitti = std::string(argv[2]) == "kitti";
 	lo::CRegistration<Point_T> cReg;
 	int code[2];

@@ -43,8 +43,10 @@ extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
 extract cfilter.hpp 2613 2655 "bool get_cloud_pair_intersection" cfilter_body.inc
 # cregistration.hpp: the driver and every helper on the path
 extract cregistration.hpp 1114 1440 "int mm_lls_icp(constraint_t &registration_cons" creg_body.inc
+extract cregistration.hpp 1443 1681 "bool lls_icp_3dof_ground" creg_body.inc
 extract cregistration.hpp 1685 1967 "void batch_transform_feature_points" creg_body.inc
 extract cregistration.hpp 1976 2275 "bool pt2pt_lls_summation" creg_body.inc
+extract cregistration.hpp 2278 2386 "bool ground_3dof_lls_tran_estimation" creg_body.inc
 extract cregistration.hpp 2518 2722 "bool get_multi_metrics_lls_residual" creg_body.inc
 extract cregistration.hpp 2740 2764 "bool construct_trans_a" creg_body.inc
 extract cregistration.hpp 2795 2836 "bool get_quat_euler_jacobi" creg_body.inc

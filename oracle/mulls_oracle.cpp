@@ -160,6 +160,28 @@ bool lu_inverse(const double *A, double *Ainv, int n)
 	return ok;
 }
 
+// Eigen 3.3 inverse of a fixed 3x3 (compute_inverse_size3_helper): cofactors over the determinant, no pivoting
+void inverse3_cofactor(const double m[9] /* col-major */, double out[9])
+{
+	auto M = [&](int r, int c) { return m[r + 3 * c]; };
+	auto cof = [&](int i, int j) {
+		const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+		return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+	};
+	const double c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+	const double det = (c0 * M(0, 0) + c1 * M(1, 0)) + c2 * M(2, 0);
+	const double invdet = 1.0 / det;
+	out[0 + 3 * 0] = c0 * invdet;
+	out[0 + 3 * 1] = c1 * invdet;
+	out[0 + 3 * 2] = c2 * invdet;
+	out[1 + 3 * 0] = cof(0, 1) * invdet;
+	out[1 + 3 * 1] = cof(1, 1) * invdet;
+	out[1 + 3 * 2] = cof(2, 1) * invdet;
+	out[2 + 3 * 0] = cof(0, 2) * invdet;
+	out[2 + 3 * 1] = cof(1, 2) * invdet;
+	out[2 + 3 * 2] = cof(2, 2) * invdet;
+}
+
 // Eigen::AngleAxisd(Matrix3d).angle(): rotation matrix -> quaternion (Shepperd branches) -> 2*atan2(|v|,|w|)
 double angle_of_rotation(const M4 &T)
 {
@@ -1067,6 +1089,7 @@ void apply_motion_compensation(const Cloud &in, Cloud &out, const M4 &Tran)
 	}
 }
 
+void mulls_oracle_default_params_impl(mulls_params *p);
 inline bool used(const mulls_params *p, int c) { return p->used_feature_type[c] == '1'; }
 inline int metric_of(int c) { return (c == MULLS_PILLAR || c == MULLS_BEAM) ? 1 : (c == MULLS_VERTEX ? 2 : 0); }
 
@@ -1389,12 +1412,247 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 	return MULLS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// lls_icp_3dof_ground (cregistration.hpp:1443-1582) with ground_3dof_lls_tran_estimation / pt2pl_ground_3dof_lls_summation
+// (:2278-2386): ground class only, unknowns (roll, pitch, z).  Parameters are read from the mulls_params fields of the
+// same names (max_iter_num, dis_thre_unit, converge_*, dis_thre_min, dis_thre_update_rate, weight_strategy,
+// keep_less_source_points, max_bearable_rotation_d).
+int icp_3dof_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int brute)
+{
+	int process_code = 0;
+	const int min_total_corr_num = 100, down_rate = 3;
+	M4 S2T = m4_identity(), TempTran = m4_identity();
+	float dis_thre_ground = P->dis_thre_unit;
+	float max_bearable_translation = (float)(2.0 * P->dis_thre_unit);
+	float converge_rotation = (float)(P->converge_rotation_d / 180.0 * M_PI);
+	float max_bearable_rotation = (float)(P->max_bearable_rotation_d / 180.0 * M_PI);
+	Cloud sc, tc;
+	load_cloud(pair->src[MULLS_GROUND], sc);
+	load_cloud(pair->tgt[MULLS_GROUND], tc);
+	M4 guess;
+	std::memcpy(guess.a, pair->init_guess, sizeof(guess.a));
+	transform_cloud(sc, guess);
+	if (P->keep_less_source_points)
+		random_downsample(sc, (int)(tc.size() / down_rate), P->rng_seed, 1 * 6 + MULLS_GROUND);
+	std::vector<int> orig(sc.size());
+	for (size_t i = 0; i < sc.size(); i++)
+		orig[i] = (int)i;
+	std::memset(R->nsrc0, 0, sizeof(R->nsrc0));
+	std::memset(R->ntgt0, 0, sizeof(R->ntgt0));
+	std::memset(R->ncorr, 0, sizeof(R->ncorr));
+	R->nsrc0[0] = (uint32_t)sc.size();
+	R->ntgt0[0] = (uint32_t)tc.size();
+	KdTree tree;
+	if (!brute)
+		tree.build(tc);
+	Corrs corr;
+	int iters = 0;
+	R->trace_len = 0;
+	for (int i = 0; i < P->max_iter_num; i++)
+	{
+		const float thr_used = dis_thre_ground;
+		determine_corres(sc, orig, tc, &tree, dis_thre_ground, corr, false, true, 40.0f, brute != 0);
+		iters = i + 1;
+		R->ncorr[0] = (uint32_t)corr.size();
+		mulls_iter_trace *tr = nullptr;
+		if (R->trace && R->trace_len < R->trace_cap)
+		{
+			tr = &R->trace[R->trace_len++];
+			std::memset(tr, 0, sizeof(*tr));
+			tr->iter = i;
+			tr->ncorr[0] = (uint32_t)corr.size();
+			tr->nsrc[0] = (uint32_t)sc.size();
+			tr->thr[0] = thr_used;
+		}
+		if ((int)corr.size() < min_total_corr_num)
+		{
+			process_code = -2;
+			break;
+		}
+		{
+			double v = 1.0 * dis_thre_ground / P->dis_thre_update_rate;
+			dis_thre_ground = (float)((v > P->dis_thre_min) ? v : (double)P->dis_thre_min);
+		}
+		// ground_3dof_lls_tran_estimation: residual weighting has no iteration gate here, window = 0.1 (default argument)
+		const bool resid_w = P->weight_strategy[1] == '1', dist_w = P->weight_strategy[2] == '1', inten_w = P->weight_strategy[3] == '1';
+		double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b3[3] = {0, 0, 0};
+		for (size_t k = 0; k < corr.size(); k++)
+		{
+			const Pt &s = sc[corr[k].q];
+			const Pt &t = tc[corr[k].m];
+			float px = s.x, py = s.y, pz = s.z, qx = t.x, qy = t.y, qz = t.z, ntx = t.nx, nty = t.ny, ntz = t.nz;
+			float pi = s.intensity, qi = t.intensity;
+			float w = 1.0f;
+			float a = ntz * py - nty * pz;
+			float b = ntx * pz - ntz * px;
+			float d = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+			float dist = std::sqrt(qx * qx + qy * qy + qz * qz);
+			if (dist_w)
+				w = w * get_weight_by_dist_adaptive(dist, i);
+			if (resid_w)
+				w = w * get_weight_by_residual(std::fabs(d), 0.1f);
+			if (inten_w)
+				w = w * get_weight_by_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			corr[k].dw = w;
+			A[0] += w * a * a;
+			A[1] += w * a * b;
+			A[2] += w * a * ntz;
+			A[4] += w * b * b;
+			A[5] += w * b * ntz;
+			A[8] += w * ntz * ntz;
+			b3[0] += w * d * a;
+			b3[1] += w * d * b;
+			b3[2] += w * d * ntz;
+		}
+		A[3] = A[1];
+		A[6] = A[2];
+		A[7] = A[5];
+		double Ainv[9], x3[3];
+		inverse3_cofactor(A, Ainv);
+		for (int r = 0; r < 3; r++)
+			x3[r] = (Ainv[r + 0] * b3[0] + Ainv[r + 3] * b3[1]) + Ainv[r + 6] * b3[2];
+		double x6[6] = {0, 0, x3[2], x3[0], x3[1], 0};
+		construct_trans_a(x6, TempTran);
+		if (tr)
+		{
+			std::memcpy(tr->x, x6, sizeof(x6));
+			for (int k = 0; k < 9; k++)
+				tr->atpa[k] = A[k];
+			std::memcpy(tr->atpb, b3, sizeof(b3));
+		}
+		double ts_norm = std::sqrt(TempTran(0, 3) * TempTran(0, 3) + TempTran(1, 3) * TempTran(1, 3) + TempTran(2, 3) * TempTran(2, 3));
+		double rs_angle = angle_of_rotation(TempTran);
+		if (ts_norm > max_bearable_translation || std::fabs(rs_angle) > max_bearable_rotation)
+		{
+			process_code = -1;
+			TempTran = m4_identity();
+			break;
+		}
+		if (i == P->max_iter_num - 1 || (i > 2 && ts_norm < P->converge_translation && std::fabs(rs_angle) < converge_rotation))
+		{
+			process_code = 1;
+			break;
+		}
+		transform_cloud(sc, TempTran);
+		S2T = m4_mul(TempTran, S2T);
+	}
+	S2T = m4_mul(TempTran, S2T);
+	S2T = m4_mul(S2T, guess);
+	R->code = process_code;
+	R->iters = iters;
+	std::memcpy(R->T, S2T.a, sizeof(R->T));
+	for (int k = 0; k < 36; k++)
+		R->info[k] = (k % 7 == 0) ? 1.0 : 0.0; // constraint_t::information_matrix is not touched by this variant
+	R->sigma = FLT_MAX;							   // nor are sigma (constraint_t default) and confidence
+	R->confidence = 0.0f;
+	R->singular = 0;
+	R->cropped = 0;
+	return MULLS_OK;
+}
+
+// mm_lls_icp_4dof_global (cregistration.hpp:1584-1681): heading sweep about the source station, each trial a full
+// mm_lls_icp with weights "1001" and classes "111110"; keeps the trial maximising confidence / sigma.
+int icp_4dof_impl(const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num, float dis_thre_unit,
+				  float converge_translation, float dis_thre_min, float dis_thre_update_rate, mulls_result *R, int *success, float *best_heading,
+				  int brute, int use_omp)
+{
+	float current_best_score = 0, current_best_heading_d = 0;
+	float heading_d = 0.0f;
+	bool successful_reg = false;
+	mulls_result best;
+	std::memset(&best, 0, sizeof(best));
+	for (int k = 0; k < 4; k++)
+		best.T[5 * k] = 1.0; // registration_con.Trans1_2 keeps its constructor value (identity) when no trial succeeds
+	for (int k = 0; k < 6; k++)
+		best.info[7 * k] = 1.0;
+	best.sigma = FLT_MAX;
+	int count = 0;
+	while (heading_d < 360.0)
+	{
+		float heading_rad = (float)(heading_d * M_PI / 180.0);
+		M4 rot = m4_identity(), g2s = m4_identity(), s2g = m4_identity();
+		// `cos(heading_rad)` with a float argument under `using namespace std` resolves to std::cos(float)
+		rot(0, 0) = std::cos(heading_rad);
+		rot(0, 1) = std::sin(heading_rad);
+		rot(1, 0) = -std::sin(heading_rad);
+		rot(1, 1) = std::cos(heading_rad);
+		g2s(0, 3) = -station[0];
+		g2s(1, 3) = -station[1];
+		g2s(2, 3) = -station[2];
+		s2g(0, 3) = station[0];
+		s2g(1, 3) = station[1];
+		s2g(2, 3) = station[2];
+		M4 guess = m4_mul(m4_mul(s2g, rot), g2s);
+		mulls_pair trial = *pair;
+		std::memcpy(trial.init_guess, guess.a, sizeof(guess.a));
+		mulls_params P;
+		mulls_oracle_default_params_impl(&P);
+		P.max_iter_num = max_iter_num;
+		P.dis_thre_unit = dis_thre_unit;
+		P.converge_translation = converge_translation;
+		P.converge_rotation_d = converge_translation; // the reference passes converge_translation twice (:1640-1642)
+		P.dis_thre_min = dis_thre_min;
+		P.dis_thre_update_rate = dis_thre_update_rate;
+		std::strcpy(P.used_feature_type, "111110");
+		std::strcpy(P.weight_strategy, "1001");
+		mulls_result r;
+		std::memset(&r, 0, sizeof(r));
+		icp_impl(&trial, &P, &r, brute, use_omp);
+		if (r.code > 0)
+		{
+			float cur_score = r.confidence / r.sigma;
+			if (cur_score > current_best_score)
+			{
+				best = r;
+				current_best_score = cur_score;
+				current_best_heading_d = heading_d;
+			}
+			successful_reg = true;
+		}
+		heading_d += heading_step_d;
+		count++;
+	}
+	mulls_iter_trace *keep_trace = R->trace;
+	int keep_cap = R->trace_cap;
+	*R = best;
+	R->trace = keep_trace;
+	R->trace_cap = keep_cap;
+	R->trace_len = 0;
+	R->iters = count; // number of heading trials
+	if (success)
+		*success = successful_reg ? 1 : 0;
+	if (best_heading)
+		*best_heading = current_best_heading_d;
+	return MULLS_OK;
+}
+
 } // namespace
 
 extern "C"
 {
 
-	void mulls_oracle_default_params(mulls_params *p)
+	void mulls_oracle_default_params(mulls_params *p) { mulls_oracle_default_params_impl(p); }
+	int mulls_oracle_icp_3dof_ground(const mulls_pair *pair, const mulls_params *params, mulls_result *result, int nn_mode)
+	{
+		if (!pair || !params || !result)
+			return MULLS_E_INVALID;
+		return icp_3dof_impl(pair, params, result, nn_mode);
+	}
+	int mulls_oracle_icp_4dof_global(const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num, float dis_thre_unit,
+									 float converge_translation, float dis_thre_min, float dis_thre_update_rate, mulls_result *result, int *success,
+									 float *best_heading_d, int nn_mode, int use_omp)
+	{
+		if (!pair || !result || !(heading_step_d > 0.0f))
+			return MULLS_E_INVALID;
+		return icp_4dof_impl(pair, heading_step_d, station, max_iter_num, dis_thre_unit, converge_translation, dis_thre_min, dis_thre_update_rate,
+							 result, success, best_heading_d, nn_mode, use_omp);
+	}
+}
+
+namespace
+{
+	void mulls_oracle_default_params_impl(mulls_params *p)
 	{
 		std::memset(p, 0, sizeof(*p));
 		p->max_iter_num = 20;
@@ -1416,6 +1674,10 @@ extern "C"
 		p->min_neccessary_corr_ratio = 0.03f;
 		p->max_bearable_rotation_d = 45.0f;
 	}
+} // namespace
+
+extern "C"
+{
 
 	// nn_mode: 0 = kd-tree (the PCL/FLANN cost model), 1 = brute force (cross-check).  use_omp: 1 = the reference's
 	// 3-wide OpenMP sections, 0 = serial.

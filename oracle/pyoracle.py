@@ -103,3 +103,28 @@ def solve(atpa, atpb):
 def rotation_angle(T):
     Tc = (C.c_double * 16)(*np.asarray(T, dtype=np.float64).T.reshape(-1))
     return float(lib().mulls_oracle_rotation_angle(Tc))
+
+
+def icp_3dof_ground(pair, params, trace_cap=0, nn_mode=0):
+    """lls_icp_3dof_ground (cregistration.hpp:1443-1582); reads the like-named fields of `params`."""
+    res = abi.make_result_array(1, trace_cap)
+    p = pair.as_pair()
+    rc = lib().mulls_oracle_icp_3dof_ground(C.byref(p), C.byref(params), C.byref(res[0]), nn_mode)
+    if rc != 0:
+        raise RuntimeError("oracle returned %d" % rc)
+    return res
+
+
+def icp_4dof_global(pair, heading_step_d, station, max_iter_num=20, dis_thre_unit=1.5, converge_translation=0.005, dis_thre_min=0.5,
+                    dis_thre_update_rate=1.05, nn_mode=0, use_omp=1):
+    """mm_lls_icp_4dof_global (cregistration.hpp:1584-1681).  Returns (results, success, best_heading_deg)."""
+    res = abi.make_result_array(1, 0)
+    p = pair.as_pair()
+    ok, best = C.c_int(0), C.c_float(0)
+    st = (C.c_double * 3)(*station)
+    rc = lib().mulls_oracle_icp_4dof_global(C.byref(p), C.c_float(heading_step_d), st, int(max_iter_num), C.c_float(dis_thre_unit),
+                                            C.c_float(converge_translation), C.c_float(dis_thre_min), C.c_float(dis_thre_update_rate),
+                                            C.byref(res[0]), C.byref(ok), C.byref(best), nn_mode, use_omp)
+    if rc != 0:
+        raise RuntimeError("oracle returned %d" % rc)
+    return res, bool(ok.value), float(best.value)

@@ -30,3 +30,26 @@ def icp(pair, params, trace_cap=0):
     if rc != 0:
         raise RuntimeError("reference returned %d" % rc)
     return res
+
+
+def icp_3dof_ground(pair, params):
+    res = abi.make_result_array(1, 0)
+    p = pair.as_pair()
+    rc = lib().mulls_ref_icp_3dof_ground(C.byref(p), C.byref(params), C.byref(res[0]))
+    if rc != 0:
+        raise RuntimeError("reference returned %d" % rc)
+    return res
+
+
+def icp_4dof_global(pair, heading_step_d, station, max_iter_num=20, dis_thre_unit=1.5, converge_translation=0.005, dis_thre_min=0.5,
+                    dis_thre_update_rate=1.05):
+    res = abi.make_result_array(1, 0)
+    p = pair.as_pair()
+    ok = C.c_int(0)
+    st = (C.c_double * 3)(*station)
+    rc = lib().mulls_ref_icp_4dof_global(C.byref(p), C.c_float(heading_step_d), st, int(max_iter_num), C.c_float(dis_thre_unit),
+                                         C.c_float(converge_translation), C.c_float(dis_thre_min), C.c_float(dis_thre_update_rate),
+                                         C.byref(res[0]), C.byref(ok))
+    if rc != 0:
+        raise RuntimeError("reference returned %d" % rc)
+    return res, bool(ok.value)

@@ -56,9 +56,50 @@ void fill_cloud(const mulls_cloud &c, pcTPtr &out)
 }
 } // namespace
 
-extern "C" int mulls_ref_icp(const mulls_pair *pair, const mulls_params *P, mulls_result *R)
+static void fill_constraint(const mulls_pair *pair, lo::constraint_t &con);
+
+extern "C" int mulls_ref_icp_3dof_ground(const mulls_pair *pair, const mulls_params *P, mulls_result *R)
 {
 	lo::constraint_t con;
+	fill_constraint(pair, con);
+	Eigen::Matrix4d guess;
+	std::memcpy(guess.data(), pair->init_guess, sizeof(double) * 16);
+	lo::CRegistration<Point_T> creg;
+	const bool ok = creg.lls_icp_3dof_ground(con, P->max_iter_num, P->dis_thre_unit, P->converge_translation, P->converge_rotation_d, P->dis_thre_min,
+												P->dis_thre_update_rate, std::string(P->weight_strategy), guess, P->keep_less_source_points != 0,
+												P->max_bearable_rotation_d);
+	R->code = ok ? 1 : 0; // the reference casts its process code to bool: only "nonzero" is observable
+	R->iters = -1;
+	std::memcpy(R->T, con.Trans1_2.data(), sizeof(R->T));
+	std::memcpy(R->info, con.information_matrix.data(), sizeof(R->info));
+	R->sigma = con.sigma;
+	R->confidence = con.confidence;
+	return 0;
+}
+
+extern "C" int mulls_ref_icp_4dof_global(const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num,
+										 float dis_thre_unit, float converge_translation, float dis_thre_min, float dis_thre_update_rate,
+										 mulls_result *R, int *success)
+{
+	lo::constraint_t con;
+	fill_constraint(pair, con);
+	con.block2->local_station.x = station[0];
+	con.block2->local_station.y = station[1];
+	con.block2->local_station.z = station[2];
+	lo::CRegistration<Point_T> creg;
+	const bool ok = creg.mm_lls_icp_4dof_global(con, heading_step_d, max_iter_num, dis_thre_unit, converge_translation, converge_translation,
+												   dis_thre_min, dis_thre_update_rate);
+	*success = ok ? 1 : 0;
+	R->code = ok ? 1 : 0;
+	std::memcpy(R->T, con.Trans1_2.data(), sizeof(R->T));
+	std::memcpy(R->info, con.information_matrix.data(), sizeof(R->info));
+	R->sigma = con.sigma;
+	R->confidence = con.confidence;
+	return 0;
+}
+
+static void fill_constraint(const mulls_pair *pair, lo::constraint_t &con)
+{
 	lo::cloudblock_t &b1 = *con.block1, &b2 = *con.block2;
 	fill_cloud(pair->tgt[MULLS_GROUND], b1.pc_ground);
 	fill_cloud(pair->tgt[MULLS_PILLAR], b1.pc_pillar);
@@ -86,6 +127,12 @@ extern "C" int mulls_ref_icp(const mulls_pair *pair, const mulls_params *P, mull
 	b1.local_bound.max_x = pair->tgt_bound[3];
 	b1.local_bound.max_y = pair->tgt_bound[4];
 	b1.local_bound.max_z = pair->tgt_bound[5];
+}
+
+extern "C" int mulls_ref_icp(const mulls_pair *pair, const mulls_params *P, mulls_result *R)
+{
+	lo::constraint_t con;
+	fill_constraint(pair, con);
 	Eigen::Matrix4d guess;
 	std::memcpy(guess.data(), pair->init_guess, sizeof(double) * 16);
 

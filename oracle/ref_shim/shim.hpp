@@ -80,6 +80,7 @@ struct Matrix
 			m(i, i) = 1;
 		return m;
 	}
+	static Matrix Identity(int, int) { return Identity(); }
 	static Matrix Zero() { return Matrix(); }
 	void setIdentity() { *this = Identity(); }
 	void setZero() { std::memset(v, 0, sizeof(v)); }
@@ -138,10 +139,36 @@ struct Matrix
 				b(r, c) = (*this)(r0 + r, c0 + c);
 		return b;
 	}
+	// Eigen 3.3 fixed 3x3 inverse (compute_inverse_size3_helper): cofactors over the determinant
+	Matrix inverse3() const
+	{
+		Matrix out;
+		auto M = [&](int r, int c) { return v[(r % R) + R * (c % C)]; };
+		auto cof = [&](int i, int j) {
+			const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+			return M(i1, j1) * M(i2, j2) - M(i1, j2) * M(i2, j1);
+		};
+		const T c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+		const T det = (c0 * M(0, 0) + c1 * M(1, 0)) + c2 * M(2, 0);
+		const T invdet = T(1) / det;
+		T *o = out.v;
+		o[(0) + R * (0 % C)] = c0 * invdet;
+		o[(0) + R * (1 % C)] = c1 * invdet;
+		o[(0) + R * (2 % C)] = c2 * invdet;
+		o[(1 % R) + R * (0 % C)] = cof(0, 1) * invdet;
+		o[(1 % R) + R * (1 % C)] = cof(1, 1) * invdet;
+		o[(1 % R) + R * (2 % C)] = cof(2, 1) * invdet;
+		o[(2 % R) + R * (0 % C)] = cof(0, 2) * invdet;
+		o[(2 % R) + R * (1 % C)] = cof(1, 2) * invdet;
+		o[(2 % R) + R * (2 % C)] = cof(2, 2) * invdet;
+		return out;
+	}
 	// partial-pivot LU inverse (what Eigen 3.3 does for fixed sizes > 4; the 4x4 cofactor path agrees to rounding)
 	Matrix inverse() const
 	{
 		static_assert(R == C, "square");
+		if (R == 3)
+			return inverse3();
 		const int n = R;
 		T a[R * C];
 		int perm[R];

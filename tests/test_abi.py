@@ -23,7 +23,7 @@ def so():
 def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mulls_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mulls_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_is_plain_c():

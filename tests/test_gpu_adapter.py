@@ -49,3 +49,21 @@ def test_adapter_matches_reference_class(pairs_small, mode):
         assert ref["tree_points"] == hip["tree_points"] > 0
         gt_t, gt_r = synth.pose_error(Th, T_gt)
         assert gt_t < 0.05 and gt_r < 2e-3
+
+
+def test_adapter_variants_match_reference_members(pairs_small):
+    """lo::hip::lls_icp_3dof_ground / mm_lls_icp_4dof_global vs the reference members, same constraint_t, same arguments."""
+    pair, _ = pairs_small[1]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "pair.bin")
+        dump(pair, path)
+        out = subprocess.check_output([BIN, path, "variants"], timeout=300).decode().strip().split("\n")
+    rows = {json.loads(l)["who"]: json.loads(l) for l in out}
+    for v in ("3dof", "4dof"):
+        ref, hip = rows["reference_" + v], rows["hip_" + v]
+        assert ref["code"] == hip["code"]
+        Tr, Th = np.array(ref["T"]).reshape(4, 4).T, np.array(hip["T"]).reshape(4, 4).T
+        dt, dr = synth.pose_error(Th, Tr)
+        assert dt <= 1e-7 and dr <= 1e-7, (v, dt, dr)
+        if v == "4dof" and ref["code"]:
+            assert abs(ref["sigma"] - hip["sigma"]) <= 1e-6 and ref["confidence"] == hip["confidence"]

@@ -1,0 +1,53 @@
+"""GPU parity of the two variants of the path against the oracle (itself pinned bit-for-bit against the
+reference's own lines by tests/test_ref_pin.py)."""
+import numpy as np
+import pytest
+
+from mulls_amd import abi, synth
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(weight_strategy="0000"), dict(weight_strategy="0110", max_iter_num=5),
+                                dict(keep_less_source_points=1, rng_seed=11), dict(dis_thre_unit=0.5, max_bearable_rotation_d=0.01)],
+                         ids=["default", "unweighted", "w0110_5it", "keep_less", "step_too_large"])
+def test_3dof_ground(ctx, pairs_small, kw):
+    P = abi.default_params(weight_strategy="1111", max_bearable_rotation_d=10.0)
+    for k, v in kw.items():
+        setattr(P, k, v.encode() if isinstance(v, str) else v)
+    res = ctx.icp_3dof_ground([p for p, _ in pairs_small], P, trace_cap=32)
+    for i, (pair, _) in enumerate(pairs_small):
+        ro = pyoracle.icp_3dof_ground(pair, P, trace_cap=32)[0]
+        rg = res[i]
+        assert ro.code == rg.code and ro.iters == rg.iters
+        assert list(ro.ncorr) == list(rg.ncorr) and list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
+        assert ro.trace_len == rg.trace_len
+        for k in range(ro.trace_len):
+            assert list(ro.trace[k].ncorr) == list(rg.trace[k].ncorr) and list(ro.trace[k].nsrc) == list(rg.trace[k].nsrc), k
+            assert ro.trace[k].thr[0] == rg.trace[k].thr[0]
+        dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
+        assert dt <= 1e-7 and dr <= 1e-7, (dt, dr)
+
+
+def test_4dof_global(ctx, pairs_small):
+    pair, T_gt = pairs_small[0]
+    yaw = np.deg2rad(135.0)
+    spun = [pyoracle.transform(c, synth.se3(0, 0, 0, 0, 0, yaw)) for c in pair.src]
+    pr = abi.PairData(pair.tgt, spun, tgt_bound=pair.tgt_bound)
+    station = (0.0, 0.0, 0.0)
+    (ro,), ok_o, best_o = pyoracle.icp_4dof_global(pr, 45.0, station, max_iter_num=12, dis_thre_unit=2.0)
+    rg_arr, ok_g, best_g = ctx.icp_4dof_global(pr, 45.0, station, max_iter_num=12, dis_thre_unit=2.0)
+    rg = rg_arr[0]
+    assert ok_o == ok_g and best_o == best_g and rg.iters == 8
+    assert ro.code == rg.code
+    dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
+    assert dt <= 1e-7 and dr <= 1e-7
+    assert abs(ro.sigma - rg.sigma) <= 1e-6 and ro.confidence == rg.confidence
+    # a station away from the origin and a finer sweep
+    station = (1.5, -0.5, 0.2)
+    (ro,), ok_o, best_o = pyoracle.icp_4dof_global(pr, 30.0, station, max_iter_num=8, dis_thre_unit=2.5)
+    rg_arr, ok_g, best_g = ctx.icp_4dof_global(pr, 30.0, station, max_iter_num=8, dis_thre_unit=2.5)
+    assert ok_o == ok_g and best_o == best_g and rg_arr[0].iters == 12
+    dt, dr = synth.pose_error(rg_arr[0].T_matrix(), ro.T_matrix())
+    assert dt <= 1e-7 and dr <= 1e-7

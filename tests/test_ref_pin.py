@@ -95,3 +95,35 @@ def test_golden_fixtures_agree_with_reference():
         rr = pyref.icp(pair, P)[0]
         assert rr.code == int(z["code"]) and np.array_equal(rr.T_matrix(), z["T"]) and np.array_equal(rr.info_matrix(), z["info"])
         assert rr.sigma == float(z["sigma"])
+
+
+def test_3dof_ground_variant(pairs_small):
+    """lls_icp_3dof_ground (cregistration.hpp:1443-1582): ground-only (roll, pitch, z) ICP.  The reference returns its
+    process code cast to bool, so only Trans1_2 and "code != 0" are observable."""
+    for pair, _ in pairs_small:
+        for kw in (dict(), dict(weight_strategy="0000"), dict(max_iter_num=3), dict(dis_thre_unit=0.5, max_bearable_rotation_d=0.01)):
+            P = abi.default_params(weight_strategy="1111", max_bearable_rotation_d=10.0)
+            for k, v in kw.items():
+                setattr(P, k, v.encode() if isinstance(v, str) else v)
+            ro = pyoracle.icp_3dof_ground(pair, P)[0]
+            rr = pyref.icp_3dof_ground(pair, P)[0]
+            assert (ro.code != 0) == (rr.code != 0)
+            assert np.array_equal(ro.T_matrix(), rr.T_matrix())
+
+
+def test_4dof_global_variant(pairs_small):
+    """mm_lls_icp_4dof_global (cregistration.hpp:1584-1681): 8 heading trials of 45 degrees about the source station."""
+    pair, T_gt = pairs_small[0]
+    # rotate the source about its station so that only one heading trial can succeed
+    yaw = np.deg2rad(135.0)
+    spun = [pyoracle.transform(c, synth.se3(0, 0, 0, 0, 0, yaw)) for c in pair.src]
+    pr = abi.PairData(pair.tgt, spun, tgt_bound=pair.tgt_bound)
+    station = (0.0, 0.0, 0.0)
+    (ro,), ok_o, best = pyoracle.icp_4dof_global(pr, 45.0, station, max_iter_num=12, dis_thre_unit=2.0)
+    (rr,), ok_r = pyref.icp_4dof_global(pr, 45.0, station, max_iter_num=12, dis_thre_unit=2.0)
+    assert ok_o == ok_r
+    assert np.array_equal(ro.T_matrix(), rr.T_matrix()) and np.array_equal(ro.info_matrix(), rr.info_matrix())
+    assert ro.sigma == rr.sigma and ro.confidence == rr.confidence
+    if ok_o:
+        dt, dr = synth.pose_error(ro.T_matrix() @ synth.se3(0, 0, 0, 0, 0, yaw), T_gt)
+        assert dt < 0.3 and dr < 0.02, (dt, dr, best)
