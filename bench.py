@@ -157,6 +157,14 @@ def main():
         alg_bytes = (72.0 * prof_acc["src"] + 16.0 * prof_acc["tgt_unique"]) / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         valu = prof_acc["evals"] * OPS_PER_EVAL / (prof_acc["ms_nn"] * 1e-3) / 1e12 if prof_acc["ms_nn"] > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes, only if they describe this very configuration
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc["config"]["pairs_per_gpu_per_step"] == len(pairs) and prof_acc["evals"] == 0 and args.nn_mode in (0, 3):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "scan-pair registrations/sec (64-beam ~120k pts, 20 ICP iters)",
             "value": n_reg / elapsed,
@@ -184,7 +192,9 @@ def main():
                 "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS)"
                           if prof_acc["evals"] == 0 else "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
+                                "(profiles/r01_f_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide); null when the run differs from it",
                 "avg_launch_ms": avg_ms, "launches": prof_acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "the search is an irregular exact query, bound by dependent LDS/L2 access latency and VALU issue, not by HBM "
                         "bandwidth (DESIGN.md section 4, profiles/r01_c_pmc_grid.txt); the HBM fraction is reported as the contract asks",
