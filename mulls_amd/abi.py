@@ -125,6 +125,9 @@ class Profile(C.Structure):
         ("nn_pair_evals", C.c_uint64),
         ("nn_src_pts", C.c_uint64),
         ("nn_tgt_pts", C.c_uint64),
+        ("ms_host_step", C.c_double),
+        ("ms_host_wait", C.c_double),
+        ("ms_host_launch", C.c_double),
         ("nn_tgt_unique", C.c_uint64),
     ]
 

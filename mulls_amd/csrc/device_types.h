@@ -100,7 +100,7 @@ struct Job
 	uint32_t pair;
 	uint32_t cls;
 	uint32_t start; // first source point (relative to the cloud) handled by this workgroup
-	uint32_t pad_;
+	uint32_t count; // LDS-tier jobs only: number of consecutive source points this workgroup searches (0 = MULLS_SRC_PER_BLOCK)
 };
 
 // Run-wide constants (kernel argument, by value).

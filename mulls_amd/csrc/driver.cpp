@@ -48,6 +48,7 @@ struct mulls_batch
 	std::vector<PairSetup> setup_h;
 	std::vector<Job> setup_jobs_h;
 	std::vector<Job> jobs_h;
+	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
 	std::string jobs_key;
 	uint32_t njobs = 0;
@@ -68,13 +69,11 @@ struct mulls_batch
 	Job *setup_jobs = nullptr;
 	Job *jobs = nullptr;
 	double *partial = nullptr;
-	uint32_t jobs_cap = 0;
 	Job *tjobs = nullptr;
-	uint32_t tjobs_cap = 0;
+	Job *cjobs = nullptr;
 	GridDesc *grids = nullptr;
 	float4 *tsorted = nullptr;
 	uint32_t *cell_cnt = nullptr, *cell_start = nullptr;
-	size_t cells_cap = 0; // entries allocated in each of the two cell tables
 	// pinned, device-mapped host memory (zero-copy): per-iteration pair states in, per-pair sums out, completion epoch
 	PairState *states_h = nullptr;
 	PairOut *outs_h = nullptr;
@@ -84,6 +83,10 @@ struct mulls_batch
 	uint32_t *ticket = nullptr; // device: arrival counter of k_finish
 	uint32_t *bbox_h = nullptr;
 	uint8_t *upload_h = nullptr; // pinned staging buffer of the caller's point records
+	CloudDesc *descs_init = nullptr; // pristine descriptors (device): restored into `descs` by a D2D copy every run
+	uint32_t *bbox_init = nullptr;
+	std::string dev_key;			 // jobs_key of the tables currently resident on the device
+	size_t cap_jobs[6] = {}, cap_cells[2] = {};
 	// capacities (elements) of the grow-only arrays
 	size_t cap_stage = 0, cap_src[9] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
@@ -231,6 +234,27 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 				}
 			d.job_end = (uint32_t)B->jobs_h.size();
 		}
+	B->cjobs_h.clear();
+	for (int p = 0; p < B->n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+			if (P->used_feature_type[c] == '1' && B->descs_h[p * MULLS_NC + c].src_cap > 0)
+			{
+				Job j = {(uint32_t)p, (uint32_t)c, 0u, B->descs_h[p * MULLS_NC + c].src_cap};
+				B->cjobs_h.push_back(j);
+			}
+	if (B->cjobs_h.size() < 512)
+	{
+		// too few class clouds to fill 256 CUs: split them into 512-query jobs (each stages its target cloud itself)
+		B->cjobs_h.clear();
+		for (int p = 0; p < B->n; p++)
+			for (int c = 0; c < MULLS_NC; c++)
+				if (P->used_feature_type[c] == '1')
+					for (uint32_t s = 0; s < B->descs_h[p * MULLS_NC + c].src_cap; s += MULLS_SRC_PER_BLOCK)
+					{
+						Job j = {(uint32_t)p, (uint32_t)c, s, MULLS_SRC_PER_BLOCK};
+						B->cjobs_h.push_back(j);
+					}
+	}
 	B->tjobs_h.clear();
 	for (int p = 0; p < B->n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
@@ -381,6 +405,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	B->setup_h.assign(n, PairSetup());
 	B->setup_jobs_h.clear();
 	B->jobs_key.clear(); // the job table depends on the layout
+	B->dev_key.clear();
 	size_t stage_rec = 0, so = 0, to = 0;
 	for (int p = 0; p < n; p++)
 	{
@@ -535,6 +560,71 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	return MULLS_OK;
 }
 
+// Per-run device tables.  Job tables and the pristine descriptor block only change with the batch layout or the set of
+// used classes, so they are uploaded once (pinned copies would not help: they are simply not re-sent) and every run
+// restores the mutable descriptors / box keys with device-to-device copies — no pageable H2D traffic per run.
+int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out)
+{
+	hipStream_t st = ctx->stream;
+	const int n = B->n;
+	const std::string old_key = B->jobs_key;
+	build_jobs(B, P_jobs);
+	uint32_t lds_cap = 0;
+	const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
+	if (tier < 0)
+	{
+		ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
+		return MULLS_E_INVALID;
+	}
+	*lds_cap_out = lds_cap;
+	*tier_out = tier;
+	// global-memory tier: about four cells per target point of the largest searched cloud, so dense clouds get finer cells
+	rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * lds_cap));
+	rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+
+	bool grew = false, g2 = false;
+	int rc = MULLS_OK;
+	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
+	A(grow(ctx, &B->jobs, &B->cap_jobs[0], (size_t)B->njobs, &g2));
+	grew |= g2;
+	A(grow(ctx, &B->partial, &B->cap_jobs[1], (size_t)B->njobs * MULLS_NTERM));
+	A(grow(ctx, &B->tjobs, &B->cap_jobs[2], B->tjobs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->cjobs, &B->cap_jobs[3], B->cjobs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->descs_init, &B->cap_jobs[4], B->descs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->bbox_init, &B->cap_jobs[5], (size_t)n * 6, &g2));
+	grew |= g2;
+	if (tier != 0)
+	{
+		int n_used = 0;
+		for (int c = 0; c < MULLS_NC; c++)
+			n_used += rp.used[c];
+		const size_t cells = (size_t)n * n_used * rp.cell_stride;
+		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
+		A(grow(ctx, &B->cell_start, &B->cap_cells[1], cells));
+		if (rc == MULLS_OK)
+			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
+	}
+	if (rc != MULLS_OK)
+		return rc;
+	if (grew || B->dev_key != B->jobs_key || B->dev_key.empty())
+	{
+		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_h.data(), sizeof(Job) * B->cjobs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipStreamSynchronize(st)); // the host vectors may be rebuilt by a later call
+		B->dev_key = B->jobs_key;
+	}
+	HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_init, sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyDeviceToDevice, st));
+	HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_init, sizeof(uint32_t) * 6 * n, hipMemcpyDeviceToDevice, st));
+	(void)old_key;
+	return MULLS_OK;
+}
+
 struct EvTimer
 {
 	mulls_ctx *ctx;
@@ -666,7 +756,7 @@ extern "C"
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
-					   B->tjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start};
+					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->descs_init, B->bbox_init};
 		for (void *p : dev)
 			if (p)
 				(void)hipFree(p);
@@ -736,64 +826,12 @@ extern "C"
 		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
 			rp.debug_stop = (uint32_t)std::atoi(dbg);
 
-		// job table (static for a given used_feature_type) + fresh descriptors
-		build_jobs(B, P);
-		if (B->njobs > B->jobs_cap)
-		{
-			if (B->jobs)
-				(void)hipFree(B->jobs);
-			if (B->partial)
-				(void)hipFree(B->partial);
-			B->jobs = nullptr;
-			B->partial = nullptr;
-			if (dmalloc(ctx, &B->jobs, B->njobs) != MULLS_OK || dmalloc(ctx, &B->partial, (size_t)B->njobs * MULLS_NTERM) != MULLS_OK)
-				return MULLS_E_HIP;
-			B->jobs_cap = B->njobs;
-		}
-		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
 		uint32_t lds_cap = 0;
-		const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
-		if (tier < 0)
-		{
-			ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
-			return MULLS_E_INVALID;
-		}
-		// global-memory tier: about four cells per target point of the largest searched cloud, so dense clouds get finer cells
-		rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * lds_cap));
-		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+		int tier = 0;
+		rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier);
+		if (rc != MULLS_OK)
+			return rc;
 		const bool use_grid = tier != 0;
-		if (use_grid)
-		{
-			int n_used = 0;
-			for (int c = 0; c < MULLS_NC; c++)
-				n_used += rp.used[c];
-			const size_t cells = (size_t)n * n_used * rp.cell_stride;
-			if (cells > B->cells_cap)
-			{
-				if (B->cell_cnt)
-					(void)hipFree(B->cell_cnt);
-				if (B->cell_start)
-					(void)hipFree(B->cell_start);
-				B->cell_cnt = B->cell_start = nullptr;
-				B->cells_cap = 0;
-				if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK)
-					return MULLS_E_HIP;
-				B->cells_cap = cells;
-			}
-			if (B->tjobs_h.size() > B->tjobs_cap)
-			{
-				if (B->tjobs)
-					(void)hipFree(B->tjobs);
-				B->tjobs = nullptr;
-				if (dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
-					return MULLS_E_HIP;
-				B->tjobs_cap = (uint32_t)B->tjobs_h.size();
-			}
-			HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
-			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
-		}
 
 		// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188), then the target grids
 		evt.begin(&ctx->prof.ms_setup);
@@ -918,13 +956,14 @@ extern "C"
 				s.want_residual = h.want_residual ? 1 : 0;
 				s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
 			}
+			const auto t_launch0 = std::chrono::steady_clock::now();
 			launch_push_states(st, B->states_pin, B->states, (uint32_t)n);
 			if (any_active)
 			{
 				evt.begin(&ctx->prof.ms_nn);
 				if (tier == 2)
 				{
-					if (launch_nn_lds(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+					if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 									  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
@@ -951,8 +990,12 @@ extern "C"
 			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
 			evt.end();
+			const auto t_wait0 = std::chrono::steady_clock::now();
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
+			const auto t_step0 = std::chrono::steady_clock::now();
+			ctx->prof.ms_host_launch += std::chrono::duration<double>(t_wait0 - t_launch0).count() * 1e3;
+			ctx->prof.ms_host_wait += std::chrono::duration<double>(t_step0 - t_wait0).count() * 1e3;
 			evt.collect();
 
 			uint64_t acc_evals = 0, acc_src = 0, acc_tgt = 0, acc_tgtu = 0;
@@ -1085,6 +1128,7 @@ extern "C"
 				}
 				h.guess = h.temp * h.guess; // :1400
 			}
+			ctx->prof.ms_host_step += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_step0).count() * 1e3;
 			ctx->prof.nn_pair_evals += acc_evals;
 			ctx->prof.nn_src_pts += acc_src;
 			ctx->prof.nn_tgt_pts += acc_tgt;
@@ -1168,58 +1212,11 @@ extern "C"
 		mulls_params Pj = *P;
 		std::memset(Pj.used_feature_type, 0, sizeof(Pj.used_feature_type));
 		std::strcpy(Pj.used_feature_type, "100000");
-		build_jobs(B, &Pj);
-		if (B->njobs > B->jobs_cap)
-		{
-			if (B->jobs)
-				(void)hipFree(B->jobs);
-			if (B->partial)
-				(void)hipFree(B->partial);
-			B->jobs = nullptr;
-			B->partial = nullptr;
-			if (dmalloc(ctx, &B->jobs, B->njobs) != MULLS_OK || dmalloc(ctx, &B->partial, (size_t)B->njobs * MULLS_NTERM) != MULLS_OK)
-				return MULLS_E_HIP;
-			B->jobs_cap = B->njobs;
-		}
-		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
 		uint32_t lds_cap = 0;
-		const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
-		if (tier < 0)
-		{
-			ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
-			return MULLS_E_INVALID;
-		}
-		rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * lds_cap));
-		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
-		if (tier != 0)
-		{
-			const size_t cells = (size_t)n * rp.cell_stride;
-			if (cells > B->cells_cap)
-			{
-				if (B->cell_cnt)
-					(void)hipFree(B->cell_cnt);
-				if (B->cell_start)
-					(void)hipFree(B->cell_start);
-				B->cell_cnt = B->cell_start = nullptr;
-				B->cells_cap = 0;
-				if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK)
-					return MULLS_E_HIP;
-				B->cells_cap = cells;
-			}
-			if (B->tjobs_h.size() > B->tjobs_cap)
-			{
-				if (B->tjobs)
-					(void)hipFree(B->tjobs);
-				B->tjobs = nullptr;
-				if (dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
-					return MULLS_E_HIP;
-				B->tjobs_cap = (uint32_t)B->tjobs_h.size();
-			}
-			HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
-			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
-		}
+		int tier = 0;
+		rc = prepare_run(ctx, B, &Pj, rp, &lds_cap, &tier);
+		if (rc != MULLS_OK)
+			return rc;
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, rp);
 		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
 					B->match, B->wd, rp, B->grids);
@@ -1297,7 +1294,7 @@ extern "C"
 			launch_push_states(st, B->states_pin, B->states, (uint32_t)n);
 			if (tier == 2)
 			{
-				if (launch_nn_lds(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 								  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
 					return MULLS_E_HIP;
 			}
@@ -1551,42 +1548,23 @@ extern "C"
 		mulls_params P;
 		mulls_default_params(&P);
 		std::strcpy(P.used_feature_type, used6);
-		build_jobs(B, &P);
-		if (dmalloc(ctx, &B->jobs, B->njobs) != MULLS_OK || dmalloc(ctx, &B->partial, (size_t)B->njobs * MULLS_NTERM) != MULLS_OK)
-			return MULLS_E_HIP;
-		B->jobs_cap = B->njobs;
 		hipStream_t st = ctx->stream;
 		std::memset(rp, 0, sizeof(*rp));
 		rp->used[cls] = 1;
 		rp->faithful = 1;
 		rp->resid_from_iter = 2;
-		{
-			uint32_t cap_unused = 0;
-			rp->grid_maxcells = choose_tier(ctx, B, rp->used, &cap_unused) == 2
-									? lds_cells_for(cap_unused)
-									: std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * cap_unused));
-			rp->cell_stride = ((rp->grid_maxcells + 1u + 15u) & ~15u);
-		}
 		rp->tick_base = ctx->tick;
 		ctx->tick += 4;
-		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_h, sizeof(uint32_t) * 6, hipMemcpyHostToDevice, st));
+		uint32_t lds_cap = 0;
+		int tier = 0;
+		rc = prepare_run(ctx, B, &P, *rp, &lds_cap, &tier);
+		if (rc != MULLS_OK)
+			return rc;
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, *rp);
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
 					B->wd, *rp, B->grids);
-		if (ctx->nn_mode != 1)
-		{
-			const size_t cells = rp->cell_stride;
-			if (dmalloc(ctx, &B->cell_cnt, cells) != MULLS_OK || dmalloc(ctx, &B->cell_start, cells) != MULLS_OK ||
-				dmalloc(ctx, &B->tjobs, B->tjobs_h.size()) != MULLS_OK)
-				return MULLS_E_HIP;
-			B->cells_cap = cells;
-			B->tjobs_cap = (uint32_t)B->tjobs_h.size();
-			HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
-			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, cells * sizeof(uint32_t), st));
+		if (tier != 0)
 			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->cell_cnt, B->cell_start, B->tsorted);
-		}
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)
@@ -1622,7 +1600,7 @@ extern "C"
 			uint32_t lds_cap = 0;
 			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 			if (tier == 2)
-				launch_nn_lds(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 							  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,

@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 }
 } // namespace
 
-__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															 const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															 float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
 															 const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
@@ -1036,7 +1036,10 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	uint16_t *IDX = reinterpret_cast<uint16_t *>(Z + cap);				  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
 
-	const Job job = jobs[blockIdx.x];
+	// one workgroup per (pair, class): the target class cloud is staged ONCE and every 512-query chunk of the source
+	// class cloud is searched against it (the first version staged it once per chunk: 2.3x the algorithmic HBM bytes,
+	// profiles/r01_f_pmc_traffic.txt)
+	const Job job = cjobs[blockIdx.x];
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
@@ -1045,35 +1048,10 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const bool called = class_called(rp, d, job.cls);
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 
-	// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
-	if (threadIdx.x < MULLS_SRC_PER_BLOCK)
+	if (called)
 	{
-		const uint32_t s = job.start + threadIdx.x;
-		float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
-		{
-			const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
-			const double *T = ps.T;
-			const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
-			out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
-			out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
-			out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-			out.w = 1.0f;
-			const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
-			const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
-			const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
-			spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
-			snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
-		}
-		qpos[threadIdx.x] = out;
-	}
-	if (!called || rp.debug_stop == 1u)
-		return; // correspondences of the previous iteration stay in force
-
-	// stage the cell-sorted target cloud and its cell table (coalesced reads, each byte of the cloud once per workgroup).
-	// Loads are issued in batches of 8 / 4 per lane before the first LDS write: one memory latency per batch instead of
-	// one per element (the serial version spent ~90 us per workgroup in s_waitcnt, profiles/r01_c_pmc_grid.txt).
-	{
+		// stage the cell-sorted target cloud and its cell table (coalesced reads).  Loads are issued in batches of 8 / 4
+		// per lane before the first LDS write: one memory latency per batch instead of one per element.
 		const float4 *__restrict__ ts = tsorted + d.tgt_off;
 		for (uint32_t k0 = threadIdx.x; k0 < tgt_n; k0 += 8 * MULLS_LDS_BLOCK)
 		{
@@ -1124,9 +1102,6 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			}
 		}
 	}
-	__syncthreads();
-	if (rp.debug_stop == 2u)
-		return;
 
 	const LdsGrid L = {X, Y, Z, IDX, CS};
 	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
@@ -1137,71 +1112,106 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
 	uint32_t matched_cnt = 0;
-	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
+
+	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
+	for (uint32_t chunk = job.start; chunk < q_end; chunk += MULLS_SRC_PER_BLOCK)
 	{
-		const uint32_t s = job.start + k;
-		if (s >= src_n)
-			break;
-		const float4 q = qpos[k];
-		if (q.w == 0.0f)
-			continue;
-		float best = __builtin_inff();
-		int bi = -1;
-		if (rp.debug_stop == 5u)
-			continue;
-		// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
-		const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
+		// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
+		if (threadIdx.x < MULLS_SRC_PER_BLOCK)
 		{
-			const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
-			const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
-			for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
+			const uint32_t s = chunk + threadIdx.x;
+			float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (s < q_end && (flag[d.src_off + s] & MULLS_F_ALIVE))
 			{
-				const uint32_t t2 = t + MULLS_LDS_GROUP;
-				const bool ok2 = t2 < hi;
-				const uint32_t tt2 = ok2 ? t2 : t;
-				const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
-				const int ia = (int)L.IDX[t], ib = (int)L.IDX[tt2];
-				float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
-				const float da = (dx * dx + dy * dy) + dz * dz;
-				dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
-				const float db = (dx * dx + dy * dy) + dz * dz;
-				if (da < best || (da == best && ia < bi))
+				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+				const double *T = ps.T;
+				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+				out.w = 1.0f;
+				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+				spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
+				snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+			}
+			qpos[threadIdx.x] = out;
+		}
+		if (!called || rp.debug_stop == 1u)
+			continue; // correspondences of the previous iteration stay in force; the points still move
+		__syncthreads();
+		if (rp.debug_stop == 2u)
+			continue;
+
+		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
+		for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
+		{
+			const uint32_t s = chunk + k;
+			if (s >= q_end)
+				break;
+			const float4 q = qpos[k];
+			if (q.w == 0.0f)
+				continue;
+			float best = __builtin_inff();
+			int bi = -1;
+			if (rp.debug_stop == 5u)
+				continue;
+			// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
+			const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+			{
+				const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
+				const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
+				for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 				{
-					best = da;
-					bi = ia;
-				}
-				if (ok2 && (db < best || (db == best && ib < bi)))
-				{
-					best = db;
-					bi = ib;
+					const uint32_t t2 = t + MULLS_LDS_GROUP;
+					const bool ok2 = t2 < hi;
+					const uint32_t tt2 = ok2 ? t2 : t;
+					const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
+					const int ia = (int)L.IDX[t], ib = (int)L.IDX[tt2];
+					float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
+					const float da = (dx * dx + dy * dy) + dz * dz;
+					dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
+					const float db = (dx * dx + dy * dy) + dz * dz;
+					if (da < best || (da == best && ia < bi))
+					{
+						best = da;
+						bi = ia;
+					}
+					if (ok2 && (db < best || (db == best && ib < bi)))
+					{
+						best = db;
+						bi = ib;
+					}
 				}
 			}
-		}
-		row16_min(best, bi);
-		// probe 1: every other cell within min(first-probe radius, current best distance) of the query
-		if (rp.debug_stop != 3u)
-		{
-			const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
-			lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, cx, cy, cz, best, bi);
 			row16_min(best, bi);
-		}
-		if (rp.debug_stop < 3u && !(bi >= 0 && best <= m * m))
-		{
-			// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
-			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
-			lds_scan_box(g, L, q.x, q.y, q.z, R, sub, -1, -1, -1, best, bi);
-			row16_min(best, bi);
-		}
-		if (sub == 0)
-		{
-			const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
-			nn_idx[d.src_off + s] = matched ? bi : -1;
-			nn_d2[d.src_off + s] = best;
-			if (matched)
+			// probe 1: every other cell within min(first-probe radius, current best distance) of the query
+			if (rp.debug_stop != 3u)
 			{
-				matched_cnt++;
-				if (gate)
-					atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
+				const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
+				lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, cx, cy, cz, best, bi);
+				row16_min(best, bi);
+			}
+			if (rp.debug_stop < 3u && !(bi >= 0 && best <= m * m))
+			{
+				// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
+				const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
+				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, -1, -1, -1, best, bi);
+				row16_min(best, bi);
+			}
+			if (sub == 0)
+			{
+				const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
+				nn_idx[d.src_off + s] = matched ? bi : -1;
+				nn_d2[d.src_off + s] = best;
+				if (matched)
+				{
+					matched_cnt++;
+					if (gate)
+						atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
+				}
 			}
 		}
 	}

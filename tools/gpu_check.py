@@ -44,6 +44,8 @@ for mode, name in modes:
     print("batch %4d: %.2f ms/run  %.1f reg/s  iters %d code %d" % (nb, dt * 1e3, nb / dt, res[0].iters, res[0].code))
     if nb >= 256:
         ctx.set_profiling(True); batch.run(Pb); pf = ctx.profile(); ctx.set_profiling(False)
-        print("   profile ms: setup %.3f nn %.3f filter %.3f accum %.3f resid %.3f launches %d" % (
-            pf.ms_setup, pf.ms_nn, pf.ms_filter, pf.ms_accum, pf.ms_residual, pf.launches_nn))
+        print("   profile ms: setup %.3f nn %.3f filter %.3f accum %.3f resid %.3f launches %d | host: step %.3f wait %.3f launch %.3f" % (
+            pf.ms_setup, pf.ms_nn, pf.ms_filter, pf.ms_accum, pf.ms_residual, pf.launches_nn, pf.ms_host_step, pf.ms_host_wait, pf.ms_host_launch))
+        batch.run(Pb); pf = ctx.profile()
+        print("   unprofiled run host ms: step %.3f wait %.3f launch %.3f" % (pf.ms_host_step, pf.ms_host_wait, pf.ms_host_launch))
     batch.close()
