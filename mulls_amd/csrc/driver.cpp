@@ -34,7 +34,7 @@ struct mulls_ctx
 	std::string err;
 	bool profiling = false;
 	mulls_profile prof{};
-	hipEvent_t ev[10] = {};
+	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
 	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
@@ -79,8 +79,9 @@ struct mulls_batch
 	PairOut *outs_h = nullptr;
 	volatile uint32_t *epoch_h = nullptr;
 	uint32_t *epoch_dev = nullptr;
-	uint32_t epoch = 0;
-	uint32_t *ticket = nullptr; // device: arrival counter of k_finish
+	uint32_t epoch = 0;			// last epoch issued on word 0 (sub-batch 0 and the single-shot entry points)
+	uint32_t epoch1 = 0;		// last epoch issued on word 16 (sub-batch 1)
+	uint32_t *ticket = nullptr; // device: arrival counters of k_finish (one per sub-batch, 16 words apart)
 	uint32_t *bbox_h = nullptr;
 	uint8_t *upload_h = nullptr; // pinned staging buffer of the caller's point records
 	CloudDesc *descs_init = nullptr; // pristine descriptors (device): restored into `descs` by a D2D copy every run
@@ -271,15 +272,27 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 // Wait until k_finish has published the current epoch.  The host spins on the pinned word (a few microseconds of latency
 // instead of an interrupt-driven stream synchronisation); a stalled device is caught by falling back to
 // hipStreamSynchronize, which also surfaces asynchronous HIP errors.
-int wait_epoch(mulls_ctx *ctx, mulls_batch *B)
+int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last = nullptr);
+int wait_epoch(mulls_ctx *ctx, mulls_batch *B) { return wait_epoch_word(ctx, B->epoch_h, B->epoch); }
+// `last`: while profiling, the event recorded behind the k_finish that publishes `want` — waiting on it (instead of the
+// whole stream) leaves the other sub-batch's kernels running
+int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last)
 {
-	const uint32_t want = B->epoch;
-	if (!ctx->profiling)
+	if (ctx->profiling && last)
+	{
+		HIPCHK(ctx, hipEventSynchronize(last));
+		if (*word == want)
+		{
+			std::atomic_thread_fence(std::memory_order_acquire);
+			return MULLS_OK;
+		}
+	}
+	else if (!ctx->profiling)
 	{
 		const auto t0 = std::chrono::steady_clock::now();
 		for (uint64_t spins = 0;; spins++)
 		{
-			if (*B->epoch_h == want)
+			if (*word == want)
 			{
 				std::atomic_thread_fence(std::memory_order_acquire);
 				return MULLS_OK;
@@ -289,7 +302,7 @@ int wait_epoch(mulls_ctx *ctx, mulls_batch *B)
 		}
 	}
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-	if (*B->epoch_h != want)
+	if (*word != want)
 	{
 		ctx->err = "device did not publish the iteration epoch";
 		return MULLS_E_HIP;
@@ -495,8 +508,8 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->setup_jobs, &B->cap_setup_jobs, B->setup_jobs_h.size()));
 	if (!B->ticket)
 	{
-		A(dmalloc(ctx, &B->ticket, 1));
-		if (rc == MULLS_OK && hipMemset(B->ticket, 0, sizeof(uint32_t)) != hipSuccess)
+		A(dmalloc(ctx, &B->ticket, 32));
+		if (rc == MULLS_OK && hipMemset(B->ticket, 0, 32 * sizeof(uint32_t)) != hipSuccess)
 			rc = MULLS_E_HIP;
 	}
 	A(grow_pinned(ctx, &B->states_h, &B->cap_pin[0], (size_t)n, hipHostMallocMapped));
@@ -505,10 +518,10 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow_pinned(ctx, &B->upload_h, &B->cap_pin[3], std::max<size_t>(stage_rec, 1) * MULLS_POINT_BYTES, hipHostMallocDefault));
 	if (rc == MULLS_OK && !B->epoch_h)
 	{
-		if (hipHostMalloc((void **)&B->epoch_h, 64, hipHostMallocMapped) != hipSuccess)
+		if (hipHostMalloc((void **)&B->epoch_h, 256, hipHostMallocMapped) != hipSuccess)
 			rc = MULLS_E_HIP;
 		else
-			*B->epoch_h = 0;
+			std::memset((void *)B->epoch_h, 0, 256);
 	}
 	if (rc != MULLS_OK)
 		return rc;
@@ -628,6 +641,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 struct EvTimer
 {
 	mulls_ctx *ctx;
+	int base = 0; // first event of this timer's set in ctx->ev
 	int used = 0;
 	double *slot[5];
 	void begin(double *acc)
@@ -635,21 +649,22 @@ struct EvTimer
 		if (!ctx->profiling)
 			return;
 		slot[used / 2] = acc;
-		(void)hipEventRecord(ctx->ev[used], ctx->stream);
+		(void)hipEventRecord(ctx->ev[base + used], ctx->stream);
 	}
 	void end()
 	{
 		if (!ctx->profiling)
 			return;
-		(void)hipEventRecord(ctx->ev[used + 1], ctx->stream);
+		(void)hipEventRecord(ctx->ev[base + used + 1], ctx->stream);
 		used += 2;
 	}
-	void collect() // after a stream sync
+	hipEvent_t last() const { return (ctx->profiling && used) ? ctx->ev[base + used - 1] : nullptr; }
+	void collect() // after the last recorded event completed
 	{
 		for (int i = 0; i < used; i += 2)
 		{
 			float ms = 0;
-			(void)hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]);
+			(void)hipEventElapsedTime(&ms, ctx->ev[base + i], ctx->ev[base + i + 1]);
 			*slot[i / 2] += ms;
 		}
 		used = 0;
@@ -931,18 +946,66 @@ extern "C"
 			}
 		}
 
-		int lock_iter = 0;
-		for (;; lock_iter++)
+		// Two sub-batches share the stream: while the device runs one sub-batch's iteration the host solves the other's 6x6
+		// systems and queues its next launch set behind it, so neither side idles (a single sub-batch when the batch is small).
+		// Each sub-batch has its own iteration counter, arrival ticket, epoch word and contiguous slice of the job tables.
+		struct Sub
 		{
+			int lo = 0, hi = 0;
+			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
+			int iter = 0;
+			bool inflight = false;
+			uint64_t seq = 0;
+			uint32_t *epoch_ctr = nullptr;
+			volatile uint32_t *word = nullptr;
+			uint32_t *word_dev = nullptr, *ticket = nullptr;
+			EvTimer evt{nullptr};
+		};
+		int nsub = n >= 128 ? 2 : 1;
+		if (const char *e = std::getenv("MULLS_SUBBATCHES"))
+			nsub = std::max(1, std::min(2, std::atoi(e)));
+		if (n < 2)
+			nsub = 1;
+		Sub subs[2];
+		for (int k = 0; k < nsub; k++)
+		{
+			Sub &S = subs[k];
+			S.lo = (int)((long)n * k / nsub);
+			S.hi = (int)((long)n * (k + 1) / nsub);
+			auto first_of = [](const std::vector<Job> &v, uint32_t pair) {
+				return (uint32_t)(std::lower_bound(v.begin(), v.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; }) - v.begin());
+			};
+			S.job_lo = first_of(B->jobs_h, (uint32_t)S.lo);
+			S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
+			S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
+			S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
+			S.epoch_ctr = k == 0 ? &B->epoch : &B->epoch1;
+			S.word = B->epoch_h + 16 * k;
+			S.word_dev = B->epoch_dev + 16 * k;
+			S.ticket = B->ticket + 16 * k;
+			S.evt.ctx = ctx;
+			S.evt.base = 10 * k;
+		}
+		// the setup events were recorded on sub-batch 0's set
+		subs[0].evt.used = evt.used;
+		for (int k = 0; k < 5; k++)
+			subs[0].evt.slot[k] = evt.slot[k];
+		evt.used = 0;
+		uint64_t launch_seq = 0;
+
+		// queue one iteration (search, filter, accumulation, publication) of a sub-batch; 0 = nothing left to do for it
+		auto launch = [&](Sub &S) -> int {
 			bool any_active = false, any_resid = false;
-			for (int p = 0; p < n; p++)
+			for (int p = S.lo; p < S.hi; p++)
 			{
 				any_active |= H[p].active;
 				any_resid |= H[p].want_residual;
 			}
+			S.inflight = false;
 			if (!any_active && !any_resid)
-				break;
-			for (int p = 0; p < n; p++)
+				return MULLS_OK;
+			const auto t_launch0 = std::chrono::steady_clock::now();
+			for (int p = S.lo; p < S.hi; p++)
 			{
 				PairState &s = B->states_h[p];
 				const PairHost &h = H[p];
@@ -951,57 +1014,60 @@ extern "C"
 						s.T[r * 4 + c] = h.temp.at(r, c);
 				std::memcpy(s.x, h.x, sizeof(s.x));
 				std::memcpy(s.thr, h.thr, sizeof(s.thr));
-				s.iter = h.want_residual ? h.iters - 1 : lock_iter;
+				s.iter = h.want_residual ? h.iters - 1 : S.iter;
 				s.active = h.active ? 1 : 0;
 				s.want_residual = h.want_residual ? 1 : 0;
 				s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
 			}
-			const auto t_launch0 = std::chrono::steady_clock::now();
-			launch_push_states(st, B->states_pin, B->states, (uint32_t)n);
+			EvTimer &ev = S.evt;
+			const Job *jobs = B->jobs + S.job_lo;
+			launch_push_states(st, B->states_pin + S.lo, B->states + S.lo, (uint32_t)(S.hi - S.lo));
 			if (any_active)
 			{
-				evt.begin(&ctx->prof.ms_nn);
+				ev.begin(&ctx->prof.ms_nn);
 				if (tier == 2)
 				{
-					if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-									  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
+					if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
+									  B->flag, B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 						return MULLS_E_HIP;
 					}
 				}
 				else if (tier == 1)
-					launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								   B->nn_idx, B->nn_d2, B->winner);
+					launch_nn_grid(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx,
+								   B->nn_d2, B->winner);
 				else
-					launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+					launch_nn(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 				if (rp.normal_shooting)
-					launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2,
-									B->winner);
-				evt.end();
-				evt.begin(&ctx->prof.ms_filter);
-				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
-							  B->winner);
-				evt.end();
+					launch_nn_shoot(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				ev.end();
+				ev.begin(&ctx->prof.ms_filter);
+				launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
+				ev.end();
 				ctx->prof.launches_nn++;
-				ctx->prof.iterations++;
+				if (&S == &subs[0])
+					ctx->prof.iterations++;
 			}
-			evt.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
-			evt.end();
-			const auto t_wait0 = std::chrono::steady_clock::now();
-			if (wait_epoch(ctx, B) != MULLS_OK)
-				return MULLS_E_HIP;
-			const auto t_step0 = std::chrono::steady_clock::now();
-			ctx->prof.ms_host_launch += std::chrono::duration<double>(t_wait0 - t_launch0).count() * 1e3;
-			ctx->prof.ms_host_wait += std::chrono::duration<double>(t_step0 - t_wait0).count() * 1e3;
-			evt.collect();
+			ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
+			launch_accum(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, S.job_lo);
+			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
+						  (uint32_t)S.lo);
+			ev.end();
+			S.inflight = true;
+			S.seq = ++launch_seq;
+			ctx->prof.ms_host_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_launch0).count() * 1e3;
+			return MULLS_OK;
+		};
 
+		// the host half of one iteration for a sub-batch whose sums have been published
+		auto host_step = [&](Sub &S) {
+			const auto t_step0 = std::chrono::steady_clock::now();
 			uint64_t acc_evals = 0, acc_src = 0, acc_tgt = 0, acc_tgtu = 0;
-			const int host_threads = std::max(1, std::min(16, n / 32));
+			const int host_threads = std::max(1, std::min(16, (S.hi - S.lo) / 32));
+			(void)host_threads;
 #pragma omp parallel for num_threads(host_threads) schedule(static) reduction(+ : acc_evals, acc_src, acc_tgt, acc_tgtu) if (host_threads > 1)
-			for (int p = 0; p < n; p++)
+			for (int p = S.lo; p < S.hi; p++)
 			{
 				PairHost &h = H[p];
 				const PairOut &o = B->outs_h[p];
@@ -1030,7 +1096,7 @@ extern "C"
 				}
 				if (!h.active)
 					continue;
-				const int i = lock_iter;
+				const int i = S.iter;
 				h.iters = i + 1;
 				if (h.first)
 				{
@@ -1133,6 +1199,28 @@ extern "C"
 			ctx->prof.nn_src_pts += acc_src;
 			ctx->prof.nn_tgt_pts += acc_tgt;
 			ctx->prof.nn_tgt_unique += acc_tgtu;
+			S.iter++;
+		};
+
+		for (int k = 0; k < nsub; k++)
+			if ((rc = launch(subs[k])) != MULLS_OK)
+				return rc;
+		for (;;)
+		{
+			Sub *next = nullptr; // stream order: the sub-batch queued first publishes first
+			for (int k = 0; k < nsub; k++)
+				if (subs[k].inflight && (!next || subs[k].seq < next->seq))
+					next = &subs[k];
+			if (!next)
+				break;
+			const auto t_wait0 = std::chrono::steady_clock::now();
+			if (wait_epoch_word(ctx, next->word, *next->epoch_ctr, next->evt.last()) != MULLS_OK)
+				return MULLS_E_HIP;
+			ctx->prof.ms_host_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() * 1e3;
+			next->evt.collect();
+			host_step(*next);
+			if ((rc = launch(*next)) != MULLS_OK)
+				return rc;
 		}
 
 		HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1304,8 +1392,8 @@ extern "C"
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
-			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
+			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
+			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
 			for (int p = 0; p < n; p++)
@@ -1683,8 +1771,8 @@ extern "C"
 				// clear every flag to "alive, not a correspondence", then switch the requested ones on
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
-				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial);
-				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch);
+				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
+				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}
 			std::vector<float> wall(src->n);
 			if (e == hipSuccess)

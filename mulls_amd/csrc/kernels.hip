@@ -1477,7 +1477,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 														const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
 														const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm,
 														const uint8_t *__restrict__ flag, const int32_t *__restrict__ match, float *__restrict__ wd,
-														double *__restrict__ partial)
+														double *__restrict__ partial, uint32_t job_base)
 {
 	__shared__ double red[4][MULLS_NTERM];
 	const Job job = jobs[blockIdx.x];
@@ -1738,7 +1738,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 	}
 	__syncthreads();
 	if (threadIdx.x < MULLS_NTERM)
-		partial[(size_t)blockIdx.x * MULLS_NTERM + threadIdx.x] =
+		partial[(size_t)(job_base + blockIdx.x) * MULLS_NTERM + threadIdx.x] = // job_base: first job of this sub-batch in the batch-wide table
 			((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
@@ -1794,9 +1794,9 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 
 __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
 														 const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
-														 uint32_t *__restrict__ ticket, volatile uint32_t *host_epoch, uint32_t epoch)
+														 uint32_t *__restrict__ ticket, volatile uint32_t *host_epoch, uint32_t epoch, uint32_t pair_base)
 {
-	const uint32_t pair = blockIdx.x;
+	const uint32_t pair = pair_base + blockIdx.x;
 	const int active = states[pair].active, want_residual = states[pair].want_residual;
 	if (active || want_residual) // uniform per workgroup
 		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
@@ -1941,16 +1941,18 @@ void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *d
 }
 void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
 				  const float4 *spos, const float4 *tpos, const float4 *tnrm, const uint8_t *flag, const int32_t *match, float *wd,
-				  double *partial)
+				  double *partial, uint32_t job_base)
 {
 	if (njobs)
-		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial);
+		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial,
+						   job_base);
 }
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
-				   PairOut *out, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch)
+				   PairOut *out, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch, uint32_t pair_base)
 {
 	if (npairs)
-		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, ticket, host_epoch, epoch);
+		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, ticket, host_epoch, epoch,
+						   pair_base);
 }
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)
 {

@@ -90,6 +90,25 @@ def test_batch_equals_single(ctx, pairs_small):
         assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma  # bit-identical
 
 
+def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
+    """n >= 128 runs as two sub-batches pipelined on the stream (driver.cpp): per-pair results stay bit-identical to the
+    single-pair call, whichever half a pair lands in and whenever its neighbours converge or fail."""
+    rng = np.random.default_rng(3)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    base = [p for p, _ in pairs_small] + [far]
+    P = abi.kitti_params(dis_thre_unit=2.4)
+    single = [ctx.icp(pr, P)[0] for pr in base]
+    assert len({r.iters for r in single}) > 1  # sub-batches do not finish together
+    order = [int(k) for k in rng.integers(0, len(base), 150)]
+    order[0], order[75], order[149] = 3, 3, 3
+    rb = ctx.icp_batch([base[k] for k in order], P)
+    for i, k in enumerate(order):
+        r1 = single[k]
+        assert (r1.code, r1.iters, list(r1.ncorr)) == (rb[i].code, rb[i].iters, list(rb[i].ncorr)), i
+        assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma, i
+
+
 def test_resident_batch_is_repeatable(ctx, pairs_small):
     """mulls_batch_run re-clones the staged clouds every run: identical results run after run, run-to-run deterministic."""
     P = abi.kitti_params(dis_thre_unit=2.4)
