@@ -82,10 +82,12 @@ struct PairSetup // written once per run
 	double inv_t[4];	 // its translation (x,y,z,-)
 };
 
-// Per-pair output of one lock-step iteration (D2H once per iteration for the whole batch).
+// Per-pair output of one lock-step iteration.  k_finish fills it in HBM; k_pull_outs sends the 128-B counter block and
+// the sums of the USED classes (224 B each) to pinned host memory as one packed record per pair.
+#define MULLS_NTERM_PAD 28 // class rows padded to whole uint4 words
 struct PairOut
 {
-	double sums[MULLS_NC][MULLS_NTERM]; // per class: 21 packed terms (row-major upper enumeration) + 6 rhs; residual pass: [0]=VTPV [1]=n
+	double sums[MULLS_NC][MULLS_NTERM_PAD]; // per class: 21 packed terms (row-major upper enumeration) + 6 rhs; residual pass: [0]=VTPV [1]=n
 	uint32_t n_valid[MULLS_NC];
 	uint32_t n_alive[MULLS_NC];
 	uint32_t src_n[MULLS_NC];

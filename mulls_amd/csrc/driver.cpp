@@ -64,7 +64,9 @@ struct mulls_batch
 	PairSetup *setup = nullptr;
 	PairState *states = nullptr;	 // HBM copy of the pair states (filled by k_push_states every iteration)
 	PairState *states_pin = nullptr; // device address of the pinned host array states_h
-	PairOut *outs = nullptr;
+	PairOut *outs = nullptr;	   // HBM: filled by k_finish
+	size_t cap_outs = 0;
+	PairOut *outs_pin = nullptr; // device address of the pinned host array outs_h (packed records, k_pull_outs)
 	uint32_t *bbox = nullptr;
 	Job *setup_jobs = nullptr;
 	Job *jobs = nullptr;
@@ -182,7 +184,8 @@ void assemble_normal(const PairOut &o, const uint8_t used[MULLS_NC], bool faithf
 	{
 		double acc = 0.0;
 		for (int i = 0; i < 6; i++)
-			acc += o.sums[order[i]][21 + j];
+			if (used[order[i]])
+				acc += o.sums[order[i]][21 + j];
 		b[j] = acc;
 	}
 }
@@ -308,6 +311,26 @@ int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipE
 		return MULLS_E_HIP;
 	}
 	return MULLS_OK;
+}
+
+// one pair's packed record (k_pull_outs: 128-B counter block, then the used classes' 224-B rows) -> PairOut
+void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairOut &o)
+{
+	int n_used = 0;
+	for (int c = 0; c < MULLS_NC; c++)
+		n_used += used[c] ? 1 : 0;
+	const size_t row = sizeof(double) * MULLS_NTERM_PAD, rec = 128 + row * (size_t)n_used;
+	const unsigned char *src = reinterpret_cast<const unsigned char *>(B->outs_h) + rec * (size_t)p;
+	std::memcpy(o.n_valid, src, 128); // n_valid, n_alive, src_n, tgt_n, bbox, pad_: contiguous
+	src += 128;
+	for (int c = 0; c < MULLS_NC; c++)
+		if (used[c])
+		{
+			std::memcpy(o.sums[c], src, row);
+			src += row;
+		}
+		else
+			std::memset(o.sums[c], 0, row); // never sent; contributes nothing
 }
 
 // cell budget of the LDS tier: whatever the 160 KiB leave free next to the staged points (14 B each) and the query block
@@ -503,6 +526,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->descs, &B->cap_pairs[0], (size_t)n * MULLS_NC));
 	A(grow(ctx, &B->setup, &B->cap_pairs[1], (size_t)n));
 	A(grow(ctx, &B->states, &B->cap_pairs[2], (size_t)n));
+	A(grow(ctx, &B->outs, &B->cap_outs, (size_t)n));
 	A(grow(ctx, &B->bbox, &B->cap_pairs[3], (size_t)n * 6));
 	A(grow(ctx, &B->grids, &B->cap_pairs[4], (size_t)n * MULLS_NC));
 	A(grow(ctx, &B->setup_jobs, &B->cap_setup_jobs, B->setup_jobs_h.size()));
@@ -526,7 +550,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	if (rc != MULLS_OK)
 		return rc;
 	if (hipHostGetDevicePointer((void **)&B->states_pin, B->states_h, 0) != hipSuccess ||
-		hipHostGetDevicePointer((void **)&B->outs, B->outs_h, 0) != hipSuccess ||
+		hipHostGetDevicePointer((void **)&B->outs_pin, B->outs_h, 0) != hipSuccess ||
 		hipHostGetDevicePointer((void **)&B->epoch_dev, (void *)B->epoch_h, 0) != hipSuccess)
 	{
 		ctx->err = "pinned host memory setup failed";
@@ -770,7 +794,7 @@ extern "C"
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
-					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
+					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
 					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->descs_init, B->bbox_init};
 		for (void *p : dev)
 			if (p)
@@ -961,7 +985,7 @@ extern "C"
 			uint32_t *word_dev = nullptr, *ticket = nullptr;
 			EvTimer evt{nullptr};
 		};
-		int nsub = n >= 128 ? 2 : 1;
+		int nsub = n >= 512 ? 2 : 1; // below that the half-size launches cost more than the overlap returns
 		if (const char *e = std::getenv("MULLS_SUBBATCHES"))
 			nsub = std::max(1, std::min(2, std::atoi(e)));
 		if (n < 2)
@@ -1051,7 +1075,7 @@ extern "C"
 			}
 			ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 			launch_accum(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, S.job_lo);
-			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
+			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 						  (uint32_t)S.lo);
 			ev.end();
 			S.inflight = true;
@@ -1070,7 +1094,8 @@ extern "C"
 			for (int p = S.lo; p < S.hi; p++)
 			{
 				PairHost &h = H[p];
-				const PairOut &o = B->outs_h[p];
+				PairOut o;
+				unpack_out(B, rp.used, p, o);
 				mulls_result &R = results[p];
 				if (h.want_residual)
 				{
@@ -1393,7 +1418,7 @@ extern "C"
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
 			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
-			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
+			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
 			for (int p = 0; p < n; p++)
@@ -1401,7 +1426,8 @@ extern "C"
 				H3 &h = H[p];
 				if (!h.active)
 					continue;
-				const PairOut &o = B->outs_h[p];
+				PairOut o;
+				unpack_out(B, rp.used, p, o);
 				mulls_result &R = results[p];
 				h.iters = it + 1;
 				if (it == 0)
@@ -1772,7 +1798,7 @@ extern "C"
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
 				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
-				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
+				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}
 			std::vector<float> wall(src->n);
 			if (e == hipSuccess)
@@ -1786,7 +1812,9 @@ extern "C"
 			}
 			else
 			{
-				std::memcpy(out27, B->outs_h[0].sums[cls], sizeof(double) * 27);
+				PairOut o;
+				unpack_out(B, rp.used, 0, o);
+				std::memcpy(out27, o.sums[cls], sizeof(double) * 27);
 				if (weight_out)
 					for (uint32_t i = 0; i < ncorr; i++)
 						weight_out[i] = wall[corr_src[i]];

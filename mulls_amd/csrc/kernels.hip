@@ -1746,10 +1746,6 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 // One workgroup per pair: sum the per-job partials of every class in job order, then roll the per-class counters
 // over to the next iteration.
 //
-// `states` and `out` live in pinned host memory (zero-copy): the per-pair records cross PCIe directly, with no
-// copy-engine command and no stream synchronisation per iteration.  Completion is published through a host-visible
-// epoch word: every workgroup makes its stores system-visible, takes a ticket, and the last one to arrive writes the
-// epoch the host is spinning on.
 namespace
 {
 __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, const RunParams &rp, const double *__restrict__ partial,
@@ -1794,12 +1790,50 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 
 __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
 														 const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
-														 uint32_t *__restrict__ ticket, volatile uint32_t *host_epoch, uint32_t epoch, uint32_t pair_base)
+														 uint32_t pair_base)
 {
 	const uint32_t pair = pair_base + blockIdx.x;
 	const int active = states[pair].active, want_residual = states[pair].want_residual;
 	if (active || want_residual) // uniform per workgroup
 		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
+}
+
+// Results to the host: the records of pairs [pair_base, pair_base + npairs) go from HBM to pinned host memory as
+// coalesced 16-B stores over PCIe (no copy-engine command, no stream synchronisation per iteration), packed to the
+// counter block + the used classes.  Completion is published through a host-visible epoch word: every workgroup makes
+// its stores system-visible, takes a ticket, and the last one to arrive writes the epoch the host is spinning on.
+static_assert(sizeof(PairOut) == MULLS_NC * MULLS_NTERM_PAD * 8 + 128, "PairOut = class rows + one 128-B counter block");
+__global__ __launch_bounds__(MULLS_BLOCK) void k_pull_outs(const uint4 *__restrict__ dev_words, uint4 *__restrict__ host_words, RunParams rp,
+															uint32_t pair_base, uint32_t npairs, uint32_t *__restrict__ ticket,
+															volatile uint32_t *host_epoch, uint32_t epoch)
+{
+	const uint32_t row_words = MULLS_NTERM_PAD / 2, head_words = 8, rec_words = sizeof(PairOut) / 16;
+	uint32_t n_used = 0;
+	for (int c = 0; c < MULLS_NC; c++)
+		n_used += rp.used[c] ? 1u : 0u;
+	const uint32_t wpp = head_words + row_words * n_used;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < npairs * wpp)
+	{
+		const uint32_t p = pair_base + i / wpp, w = i % wpp;
+		uint32_t src = MULLS_NC * row_words + w; // counter block
+		if (w >= head_words)
+		{
+			uint32_t rank = (w - head_words) / row_words, cls = 0;
+			for (uint32_t c = 0; c < MULLS_NC; c++)
+				if (rp.used[c])
+				{
+					if (rank == 0)
+					{
+						cls = c;
+						break;
+					}
+					rank--;
+				}
+			src = cls * row_words + (w - head_words) % row_words;
+		}
+		host_words[(size_t)p * wpp + w] = dev_words[(size_t)p * rec_words + src];
+	}
 	__threadfence_system();
 	__syncthreads();
 	if (threadIdx.x == 0)
@@ -1948,11 +1982,18 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 						   job_base);
 }
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
-				   PairOut *out, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch, uint32_t pair_base)
+				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
+				   uint32_t pair_base)
 {
-	if (npairs)
-		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, ticket, host_epoch, epoch,
-						   pair_base);
+	if (!npairs)
+		return;
+	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, pair_base);
+	uint32_t n_used = 0;
+	for (int c = 0; c < MULLS_NC; c++)
+		n_used += rp.used[c] ? 1u : 0u;
+	const uint32_t nwords = npairs * (8u + (MULLS_NTERM_PAD / 2u) * n_used);
+	hipLaunchKernelGGL(k_pull_outs, dim3((nwords + MULLS_BLOCK - 1) / MULLS_BLOCK), dim3(MULLS_BLOCK), 0, st, reinterpret_cast<const uint4 *>(out),
+					   reinterpret_cast<uint4 *>(out_host), rp, pair_base, npairs, ticket, host_epoch, epoch);
 }
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)
 {

@@ -33,7 +33,8 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 				  const float4 *spos, const float4 *tpos, const float4 *tnrm, const uint8_t *flag, const int32_t *match, float *wd,
 				  double *partial, uint32_t job_base);
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
-				   PairOut *out, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch, uint32_t pair_base);
+				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
+				   uint32_t pair_base);
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs);
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
