@@ -639,10 +639,13 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		for (int c = 0; c < MULLS_NC; c++)
 			n_used += rp.used[c];
 		const size_t cells = (size_t)n * n_used * rp.cell_stride;
-		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
 		A(grow(ctx, &B->cell_start, &B->cap_cells[1], cells));
-		if (rc == MULLS_OK)
-			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
+		if (tier == 1) // the LDS tier builds its grids by sorting (k_grid_build_sort): no histogram
+		{
+			A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
+			if (rc == MULLS_OK)
+				HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
+		}
 	}
 	if (rc != MULLS_OK)
 		return rc;
@@ -920,7 +923,7 @@ extern "C"
 		}
 		if (use_grid)
 			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
-							  B->tsorted);
+							  B->tsorted, tier == 2);
 		evt.end();
 
 		std::vector<PairHost> H(n);
@@ -1363,7 +1366,7 @@ extern "C"
 		}
 		if (tier != 0)
 			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
-							  B->tsorted);
+							  B->tsorted, tier == 2);
 
 		struct H3
 		{
@@ -1678,7 +1681,8 @@ extern "C"
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
 					B->wd, *rp, B->grids);
 		if (tier != 0)
-			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->cell_cnt, B->cell_start, B->tsorted);
+			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->cell_cnt, B->cell_start, B->tsorted,
+							  tier == 2);
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)

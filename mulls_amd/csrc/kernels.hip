@@ -753,6 +753,76 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scatter(const Job *__restr
 	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS tier grid build: one workgroup per target class cloud (<= MULLS_LDS_MAXPTS points, <= MULLS_MAXCELLS cells).  The
+// cloud is sorted by (cell id, original index) with a bitonic network in LDS — packed 32-bit keys, cell id < 2^16,
+// index < 2^14 — then the cell table is filled by binary search of every cell id in the sorted keys.  Replaces the
+// count / scan / scatter kernels (global atomics on every point, 1.2 ms for 3072 clouds) for clouds that fit; the
+// cell-sorted order also becomes deterministic (index order inside a cell).
+__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const CloudDesc *__restrict__ descs, const GridDesc *__restrict__ grids,
+																	  RunParams rp, const float4 *__restrict__ tpos,
+																	  uint32_t *__restrict__ cell_start, float4 *__restrict__ tsorted)
+{
+	__shared__ uint32_t K[16384];
+	const uint32_t cls = blockIdx.x % MULLS_NC;
+	if (!rp.used[cls])
+		return;
+	const CloudDesc &d = descs[blockIdx.x];
+	const GridDesc g = grids[blockIdx.x];
+	const uint32_t n = d.tgt_n;
+	if (g.ncell == 0)
+		return;
+	uint32_t npow = 64;
+	while (npow < n)
+		npow <<= 1;
+	for (uint32_t i = threadIdx.x; i < npow; i += MULLS_LDS_BLOCK)
+	{
+		uint32_t key = 0xffffffffu;
+		if (i < n)
+		{
+			const float4 p = tpos[d.tgt_off + i];
+			key = (grid_cell_id(g, p.x, p.y, p.z) << 14) | i;
+		}
+		K[i] = key;
+	}
+	__syncthreads();
+	for (uint32_t kk = 2; kk <= npow; kk <<= 1)
+		for (uint32_t j = kk >> 1; j > 0; j >>= 1)
+		{
+			for (uint32_t i = threadIdx.x; i < (npow >> 1); i += MULLS_LDS_BLOCK)
+			{
+				const uint32_t a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
+				const uint32_t x = K[a], y = K[b];
+				if ((x > y) == ((a & kk) == 0u))
+				{
+					K[a] = y;
+					K[b] = x;
+				}
+			}
+			__syncthreads();
+		}
+	for (uint32_t pos = threadIdx.x; pos < n; pos += MULLS_LDS_BLOCK)
+	{
+		const uint32_t idx = K[pos] & 16383u;
+		const float4 p = tpos[d.tgt_off + idx];
+		tsorted[d.tgt_off + pos] = make_float4(p.x, p.y, p.z, __int_as_float((int)idx));
+	}
+	// cell_start[c] = first sorted position whose cell id is >= c (c = ncell gives n)
+	for (uint32_t c = threadIdx.x; c <= g.ncell; c += MULLS_LDS_BLOCK)
+	{
+		uint32_t lo = 0, hi = n;
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+			if ((K[mid] >> 14) < c)
+				lo = mid + 1u;
+			else
+				hi = mid;
+		}
+		cell_start[g.cell_off + c] = lo;
+	}
+}
+
 // Correspondence search, grid tier.  Phase 1: every lane applies this iteration's rigid step to two source points
 // (coalesced 16-B traffic, double math once per point) and parks the transformed position in LDS.  Phase 2: a 16-lane
 // sub-group (4 per wave64, 16 per workgroup) owns one query at a time: it sweeps the candidate rows of the 3x3x3 cell
@@ -1916,10 +1986,15 @@ void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_
 		hipLaunchKernelGGL(k_thin, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, src_keep, tgt_keep, spos, snrm, tpos, tnrm);
 }
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
-					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted)
+					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted, bool lds_tier)
 {
 	if (!ntjobs || !npairs)
 		return;
+	if (lds_tier)
+	{
+		hipLaunchKernelGGL(k_grid_build_sort, dim3(npairs * MULLS_NC), dim3(MULLS_LDS_BLOCK), 0, st, descs, grids, rp, tpos, cell_start, tsorted);
+		return;
+	}
 	hipLaunchKernelGGL(k_grid_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt);
 	hipLaunchKernelGGL(k_grid_scan, dim3(npairs * MULLS_NC), dim3(MULLS_BLOCK), 0, st, grids, rp, cell_cnt, cell_start);
 	hipLaunchKernelGGL(k_grid_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt, cell_start, tsorted);

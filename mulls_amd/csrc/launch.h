@@ -14,7 +14,7 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
 				 float4 *tpos, float4 *tnrm);
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
-					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted);
+					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted, bool lds_tier);
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells);
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx,
