@@ -17,13 +17,23 @@ def block_partition(n_items, world_size, rank):
 
 
 def pack_results(results, n):
-    """ctypes Result array -> (n, RECORD) float64 table."""
-    out = np.zeros((n, RECORD), np.float64)
-    for i in range(n):
-        r = results[i]
-        out[i, :16] = r.T[:]
-        out[i, 16:52] = r.info[:]
-        out[i, 52:] = (r.code, r.iters, r.sigma, r.confidence)
+    """ctypes Result array -> (n, RECORD) float64 table (column slices of the raw struct bytes, no per-record Python)."""
+    from . import abi
+
+    rec = abi.C.sizeof(abi.Result)
+    raw = np.frombuffer(results, dtype=np.uint8, count=n * rec).reshape(n, rec)
+
+    def col(field, dtype, count):
+        off = getattr(abi.Result, field).offset
+        return np.ascontiguousarray(raw[:, off:off + count * np.dtype(dtype).itemsize]).view(dtype).reshape(n, count)
+
+    out = np.empty((n, RECORD), np.float64)
+    out[:, :16] = col("T", np.float64, 16)
+    out[:, 16:52] = col("info", np.float64, 36)
+    out[:, 52] = col("code", np.int32, 1)[:, 0]
+    out[:, 53] = col("iters", np.int32, 1)[:, 0]
+    out[:, 54] = col("sigma", np.float32, 1)[:, 0]
+    out[:, 55] = col("confidence", np.float32, 1)[:, 0]
     return out
 
 

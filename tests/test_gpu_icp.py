@@ -91,7 +91,7 @@ def test_batch_equals_single(ctx, pairs_small):
 
 
 def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
-    """n >= 512 runs as two sub-batches pipelined on the stream (driver.cpp): per-pair results stay bit-identical to the
+    """n >= 2048 runs as two sub-batches pipelined on the stream (driver.cpp): per-pair results stay bit-identical to the
     single-pair call, whichever half a pair lands in and whenever its neighbours converge or fail."""
     rng = np.random.default_rng(3)
     tgt = planes_scene(rng)
@@ -100,8 +100,8 @@ def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
     P = abi.kitti_params(dis_thre_unit=2.4)
     single = [ctx.icp(pr, P)[0] for pr in base]
     assert len({r.iters for r in single}) > 1  # sub-batches do not finish together
-    order = [int(k) for k in rng.integers(0, len(base), 600)]
-    order[0], order[299], order[300], order[599] = 3, 3, 3, 3
+    order = [int(k) for k in rng.integers(0, len(base), 2100)]
+    order[0], order[1049], order[1050], order[2099] = 3, 3, 3, 3
     rb = ctx.icp_batch([base[k] for k in order], P)
     for i, k in enumerate(order):
         r1 = single[k]

@@ -82,3 +82,24 @@ def test_two_rank_gather_matches_single_process():
         r = pyoracle.icp(pair, P)[0]
         assert np.array_equal(full[p, :16], np.array(r.T[:]))
         assert full[p, 52] == r.code and full[p, 53] == r.iters
+
+
+def test_pack_results_matches_field_access():
+    """The vectorised packing reads the same bytes as per-record ctypes access."""
+    from mulls_amd import abi, shard
+
+    rng = np.random.default_rng(5)
+    n = 7
+    res = abi.make_result_array(n)
+    for i in range(n):
+        res[i].code, res[i].iters = int(rng.integers(-3, 2)), int(rng.integers(0, 21))
+        res[i].sigma, res[i].confidence = float(rng.random()), float(rng.random())
+        for k in range(16):
+            res[i].T[k] = rng.normal()
+        for k in range(36):
+            res[i].info[k] = rng.normal()
+    tab = shard.pack_results(res, n)
+    for i in range(n):
+        assert list(tab[i, :16]) == list(res[i].T[:]) and list(tab[i, 16:52]) == list(res[i].info[:])
+        assert tab[i, 52] == res[i].code and tab[i, 53] == res[i].iters
+        assert tab[i, 54] == res[i].sigma and tab[i, 55] == res[i].confidence
