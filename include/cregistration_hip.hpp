@@ -24,6 +24,7 @@
 #define MULLS_CREGISTRATION_HIP_HPP
 
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 
@@ -77,6 +78,72 @@ inline bool &build_cpu_trees()
 	return on;
 }
 
+// ---- device-resident local map -------------------------------------------------------------------------
+// A cloudblock_t that acts as the scan-to-map target can be given a mirror in HBM: lo::hip::update_local_map() (below)
+// creates it on first use and keeps it up to date; lo::hip::mm_lls_icp() then takes block1's six class clouds straight
+// from the device (no upload of the 20 k - 1 M point target per frame) and remembers which part of them the registration
+// indexed, which is what MapManager::map_based_dynamic_close_removal looks at on the next frame (block1->tree_*).
+struct MapMirror
+{
+	mulls_map *map = nullptr;
+	int tree_mode = 0; // 0: no registration against this map yet; 1: whole clouds; 2: cropped to tree_box
+	char tree_used[8] = {'0', '0', '0', '0', '0', '0', 0, 0};
+	double tree_box[6] = {0, 0, 0, 0, 0, 0};
+};
+inline std::map<const cloudblock_t *, MapMirror> &map_mirrors()
+{
+	struct Holder
+	{
+		std::map<const cloudblock_t *, MapMirror> m;
+		~Holder() // after thread_context()'s holder was constructed, so destroyed before it
+		{
+			for (auto &kv : m)
+				if (kv.second.map)
+					mulls_map_destroy(thread_context(), kv.second.map);
+		}
+	};
+	thread_context();
+	static thread_local Holder holder;
+	return holder.m;
+}
+// When set (default), update_local_map copies the updated class clouds back into local_map->pc_* so that every other
+// consumer of the block (viewer, sub-map cloning, loop closure) sees what the reference would have left there.
+inline bool &sync_host_map()
+{
+	static bool on = true;
+	return on;
+}
+// forget the mirror of a block whose host clouds were changed behind the bridge's back (it is rebuilt from them on next use)
+inline void invalidate_map_mirror(const cloudblock_t *block)
+{
+	auto &m = map_mirrors();
+	auto it = m.find(block);
+	if (it != m.end())
+	{
+		mulls_map_destroy(thread_context(), it->second.map);
+		m.erase(it);
+	}
+}
+inline MapMirror &attach_local_map(const cloudblock_Ptr &block)
+{
+	auto &m = map_mirrors();
+	auto it = m.find(block.get());
+	if (it != m.end())
+		return it->second;
+	mulls_ctx *ctx = thread_context();
+	MapMirror mir;
+	int rc = mulls_map_create(ctx, &mir.map);
+	if (rc == MULLS_OK)
+	{
+		const mulls_cloud clouds[6] = {borrow(block->pc_ground), borrow(block->pc_pillar), borrow(block->pc_facade),
+									   borrow(block->pc_beam),	 borrow(block->pc_roof),   borrow(block->pc_vertex)};
+		rc = mulls_map_set(ctx, mir.map, clouds, block->pose_lo.data());
+	}
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("local map mirror failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	return m.emplace(block.get(), mir).first->second;
+}
+
 template <typename PointT>
 int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud), cblock_2 (source point cloud)
 			   int max_iter_num = 20, float dis_thre_unit = 1.5, float converge_translation = 0.002, float converge_rotation_d = 0.01,
@@ -101,6 +168,18 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 	pair.tgt[MULLS_BEAM] = borrow(b1.pc_beam);
 	pair.tgt[MULLS_ROOF] = borrow(b1.pc_roof);
 	pair.tgt[MULLS_VERTEX] = borrow(b1.pc_vertex);
+	MapMirror *mirror = nullptr;
+	{
+		auto &mm = map_mirrors();
+		auto it = mm.find(&b1);
+		if (it != mm.end())
+		{
+			mirror = &it->second; // block1 is a device-resident local map: its clouds are already in HBM
+			for (int c = 0; c < 6; c++)
+				if (mulls_map_cloud(ctx, mirror->map, c, &pair.tgt[c]) != MULLS_OK)
+					throw std::runtime_error(std::string("mulls_map_cloud: ") + mulls_last_error(ctx));
+		}
+	}
 	// clone_feature(..., !use_more_points): down-sampled features unless use_more_points; vertex always pc_vertex (utility.hpp:524-550)
 	pair.src[MULLS_GROUND] = borrow(use_more_points ? b2.pc_ground : b2.pc_ground_down);
 	pair.src[MULLS_PILLAR] = borrow(use_more_points ? b2.pc_pillar : b2.pc_pillar_down);
@@ -162,7 +241,15 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 	registration_cons.sigma = R.sigma;
 	registration_cons.confidence = R.confidence;
 
-	if (build_cpu_trees())
+	if (mirror && max_iter_num > 0)
+	{
+		// what block1->tree_* hold from here on (cregistration.hpp:1209-1232), for the next update_local_map
+		mirror->tree_mode = R.cropped ? 2 : 1;
+		std::memcpy(mirror->tree_box, R.crop_box, sizeof(mirror->tree_box));
+		for (int c = 0; c < 6; c++)
+			mirror->tree_used[c] = (used_feature_type[c] == '1' && R.ntgt0[c] > 0) ? '1' : '0';
+	}
+	if (build_cpu_trees() && !mirror)
 	{
 		// kd-tree side effect of cregistration.hpp:1209-1232: trees over the intersection-filtered target clouds
 		typedef typename pcl::PointCloud<PointT> Cloud;
@@ -277,6 +364,84 @@ bool mm_lls_icp_4dof_global(constraint_t &registration_con, float heading_step_d
 		registration_con.confidence = R.confidence;
 	}
 	return success != 0;
+}
+
+// MapManager::update_local_map (include/pgo/map_manager.h:21-31, src/map_manager.cpp:18-140), verbatim signature.  The binding
+// a maintainer adds is one early return at the top of the member function:
+//     #ifdef MULLS_USE_HIP
+//         return lo::hip::update_local_map(local_map, last_target_cblock, local_map_radius, max_num_pts, ...);
+//     #endif
+// Differences: pcl::RandomSample is seeded with time(NULL) upstream, here with `map_rng_seed()`; recalculate_feature_on
+// (PCA refresh of pillar / beam points, pca.hpp) is not available on the device and throws.
+inline uint64_t &map_rng_seed()
+{
+	static uint64_t seed = 0;
+	return seed;
+}
+inline bool update_local_map(cloudblock_Ptr local_map, cloudblock_Ptr last_target_cblock, float local_map_radius = 80, int max_num_pts = 20000,
+							 int kept_vertex_num = 800, float last_frame_reliable_radius = 60, bool map_based_dynamic_removal_on = false,
+							 std::string used_feature_type = "111110", float dynamic_removal_center_radius = 30.0,
+							 float dynamic_dist_thre_min = 0.3, float dynamic_dist_thre_max = 3.0, float near_dist_thre = 0.03,
+							 bool recalculate_feature_on = false)
+{
+	mulls_ctx *ctx = thread_context();
+	MapMirror &mir = attach_local_map(local_map);
+	cloudblock_t &f = *last_target_cblock;
+	const mulls_cloud frame[6] = {borrow(f.pc_ground_down), borrow(f.pc_pillar_down), borrow(f.pc_facade_down),
+								  borrow(f.pc_beam_down),	borrow(f.pc_roof_down),	  borrow(f.pc_vertex)};
+	mulls_map_params P;
+	mulls_map_default_params(&P);
+	P.local_map_radius = local_map_radius;
+	P.max_num_pts = max_num_pts;
+	P.kept_vertex_num = kept_vertex_num;
+	P.last_frame_reliable_radius = last_frame_reliable_radius;
+	P.map_based_dynamic_removal_on = map_based_dynamic_removal_on;
+	std::memset(P.used_feature_type, 0, sizeof(P.used_feature_type));
+	std::strncpy(P.used_feature_type, used_feature_type.c_str(), sizeof(P.used_feature_type) - 1);
+	P.dynamic_removal_center_radius = dynamic_removal_center_radius;
+	P.dynamic_dist_thre_min = dynamic_dist_thre_min;
+	P.dynamic_dist_thre_max = dynamic_dist_thre_max;
+	P.near_dist_thre = near_dist_thre;
+	P.recalculate_feature_on = recalculate_feature_on;
+	P.rng_seed = map_rng_seed()++;
+	P.tree_mode = mir.tree_mode;
+	std::memcpy(P.tree_used, mir.tree_used, sizeof(P.tree_used));
+	std::memcpy(P.tree_box, mir.tree_box, sizeof(P.tree_box));
+	mulls_map_report rep;
+	const int rc = mulls_map_update(ctx, mir.map, frame, f.pose_lo.data(), &P, &rep);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_map_update failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+
+	typedef typename std::remove_reference<decltype(*f.pc_ground_down)>::type Cloud;
+	auto fetch = [&](int (*fn)(mulls_ctx *, const mulls_map *, int, void *, uint32_t, uint32_t *), int cls, Cloud &dst, uint32_t n) {
+		dst.points.resize(n);
+		uint32_t got = 0;
+		if (fn(ctx, mir.map, cls, n ? static_cast<void *>(dst.points.data()) : nullptr, n, &got) != MULLS_OK || got != n)
+			throw std::runtime_error(std::string("local map download: ") + mulls_last_error(ctx));
+	};
+	static_assert(sizeof(f.pc_ground_down->points[0]) == MULLS_POINT_BYTES, "download expects 48-byte point records");
+	// last_target_cblock->pc_*_down were moved to the map frame and filtered in place by the reference (:32, :37-47)
+	Cloud *fd[5] = {f.pc_ground_down.get(), f.pc_pillar_down.get(), f.pc_facade_down.get(), f.pc_beam_down.get(), f.pc_roof_down.get()};
+	for (int c = 0; c < 5; c++)
+		fetch(mulls_map_frame_download, c, *fd[c], rep.frame_n[c]);
+	cloudblock_t &m = *local_map;
+	if (sync_host_map())
+	{
+		Cloud *mc[6] = {m.pc_ground.get(), m.pc_pillar.get(), m.pc_facade.get(), m.pc_beam.get(), m.pc_roof.get(), m.pc_vertex.get()};
+		for (int c = 0; c < 6; c++)
+			fetch(mulls_map_download, c, *mc[c], rep.n[c]);
+	}
+	m.pose_lo = f.pose_lo; // :58-59
+	m.pose_gt = f.pose_gt;
+	m.local_bound.min_x = rep.local_bound[0], m.local_bound.min_y = rep.local_bound[1], m.local_bound.min_z = rep.local_bound[2];
+	m.local_bound.max_x = rep.local_bound[3], m.local_bound.max_y = rep.local_bound[4], m.local_bound.max_z = rep.local_bound[5];
+	m.bound.min_x = rep.bound[0], m.bound.min_y = rep.bound[1], m.bound.min_z = rep.bound[2];
+	m.bound.max_x = rep.bound[3], m.bound.max_y = rep.bound[4], m.bound.max_z = rep.bound[5];
+	m.feature_point_num = rep.feature_point_num; // :128-130
+	m.free_tree();								 // :132-133
+	m.free_raw_cloud();
+	mir.tree_mode = 0; // the kd-trees are gone until the next registration against this map
+	return true;
 }
 
 } // namespace hip

@@ -58,6 +58,7 @@ enum mulls_error
 };
 
 /* One feature-class cloud, borrowed from the caller (AoS of 48-byte PointXYZINormal records). */
+/* pts may also be a device pointer obtained from mulls_map_cloud() (stride 48 only). */
 typedef struct mulls_cloud
 {
 	const void *pts;
@@ -214,6 +215,64 @@ int mulls_icp_4dof_global(mulls_ctx *ctx, const mulls_pair *pair, float heading_
 						  float dis_thre_unit, float converge_translation, float converge_rotation_d, float dis_thre_min,
 						  float dis_thre_update_rate, float max_bearable_rotation_d, mulls_result *result, int *success,
 						  float *best_heading_d);
+
+/* ---- device-resident local map ----
+ * MapManager::update_local_map (src/map_manager.cpp:18-140) with the six undown class clouds of `local_map` kept in HBM
+ * between frames: the scan-to-map target is never re-uploaded (mulls_map_cloud() yields device clouds that mulls_pair.tgt
+ * accepts), and map-based dynamic-object removal (map_manager.cpp:149-256) runs as an exact nearest-neighbour pass on the
+ * device instead of querying the kd-trees mm_lls_icp left on block1. */
+typedef struct mulls_map mulls_map;
+
+typedef struct mulls_map_params
+{
+	/* the positional arguments of update_local_map after the two blocks, in order (map_manager.h:21-31) */
+	float local_map_radius;			   /* 80 */
+	int max_num_pts;				   /* 20000 */
+	int kept_vertex_num;			   /* 800 */
+	float last_frame_reliable_radius;  /* 60; unused by the reference too */
+	int map_based_dynamic_removal_on;  /* false */
+	char used_feature_type[8];		   /* "111110" */
+	float dynamic_removal_center_radius; /* 30.0 */
+	float dynamic_dist_thre_min;	   /* 0.3 */
+	float dynamic_dist_thre_max;	   /* 3.0 */
+	float near_dist_thre;			   /* 0.03 */
+	int recalculate_feature_on;		   /* false; true = MULLS_E_UNSUPPORTED (PCA refresh belongs to feature extraction, 8f-3) */
+	/* not in the reference's signature */
+	uint64_t rng_seed; /* random_downsample_pcl: the ABI's seeded selection sampling (see mulls_params.rng_seed) */
+	int tree_mode;	   /* what block1->tree_* held after the last mm_lls_icp against this map (cregistration.hpp:1209-1232):
+						* 0 = nothing (dynamic removal is skipped), 1 = the whole class clouds, 2 = the class clouds cropped to
+						* tree_box (mulls_result.crop_box of that registration) */
+	char tree_used[8]; /* used_feature_type of that registration: a class without a tree is left alone */
+	double tree_box[6];
+} mulls_map_params;
+
+typedef struct mulls_map_report
+{
+	uint32_t n[6];			/* class cloud sizes of the map after the update */
+	uint32_t frame_n[6];	/* sizes of the frame's clouds as appended (pc_*_down after dynamic removal; [5] = pc_vertex) */
+	int feature_point_num;	/* ground + facade + roof + pillar + beam */
+	int dynamic_removal_ran;
+	double local_bound[6];	/* local_map->local_bound (min xyz, max xyz) */
+	double bound[6];		/* local_map->bound: the same points moved by pose_lo */
+	float ms_total;
+} mulls_map_report;
+
+void mulls_map_default_params(mulls_map_params *p);
+int mulls_map_create(mulls_ctx *ctx, mulls_map **out);
+void mulls_map_destroy(mulls_ctx *ctx, mulls_map *map);
+/* (re)initialise the map from host clouds (e.g. the first frame's undown features) and its pose_lo (column-major) */
+int mulls_map_set(mulls_ctx *ctx, mulls_map *map, const mulls_cloud clouds[6], const double pose_lo[16]);
+/* update_local_map(local_map = map, last_target_cblock = {frame_down, frame_pose_lo}).  frame_down[0..4] = pc_*_down,
+ * frame_down[5] = pc_vertex, all in the frame's own coordinates; they are not modified (the reference transforms and
+ * filters last_target_cblock->pc_*_down in place: mulls_map_frame_download returns that state). */
+int mulls_map_update(mulls_ctx *ctx, mulls_map *map, const mulls_cloud frame_down[6], const double frame_pose_lo[16],
+					 const mulls_map_params *params, mulls_map_report *report);
+/* class cloud c of the map as a device cloud (48-B records); valid until the next mulls_map_set / _update / _destroy */
+int mulls_map_cloud(mulls_ctx *ctx, const mulls_map *map, int cls, mulls_cloud *out);
+int mulls_map_pose(mulls_ctx *ctx, const mulls_map *map, double pose_lo[16]);
+/* copy class cloud c back to the host (48-B records); *n receives its size, at most cap records are written */
+int mulls_map_download(mulls_ctx *ctx, const mulls_map *map, int cls, void *pts, uint32_t cap, uint32_t *n);
+int mulls_map_frame_download(mulls_ctx *ctx, const mulls_map *map, int cls, void *pts, uint32_t cap, uint32_t *n);
 
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 

@@ -113,6 +113,62 @@ class Result(C.Structure):
         return np.array(self.info[:], dtype=np.float64).reshape(6, 6).T.copy()
 
 
+
+class MapParams(C.Structure):
+    """mulls_map_params: MapManager::update_local_map's positional arguments (map_manager.h:21-31) + seed + tree state."""
+    _fields_ = [
+        ("local_map_radius", C.c_float),
+        ("max_num_pts", C.c_int32),
+        ("kept_vertex_num", C.c_int32),
+        ("last_frame_reliable_radius", C.c_float),
+        ("map_based_dynamic_removal_on", C.c_int32),
+        ("used_feature_type", C.c_char * 8),
+        ("dynamic_removal_center_radius", C.c_float),
+        ("dynamic_dist_thre_min", C.c_float),
+        ("dynamic_dist_thre_max", C.c_float),
+        ("near_dist_thre", C.c_float),
+        ("recalculate_feature_on", C.c_int32),
+        ("rng_seed", C.c_uint64),
+        ("tree_mode", C.c_int32),
+        ("tree_used", C.c_char * 8),
+        ("tree_box", C.c_double * 6),
+    ]
+
+
+class MapReport(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint32 * NCLASS),
+        ("frame_n", C.c_uint32 * NCLASS),
+        ("feature_point_num", C.c_int32),
+        ("dynamic_removal_ran", C.c_int32),
+        ("local_bound", C.c_double * 6),
+        ("bound", C.c_double * 6),
+        ("ms_total", C.c_float),
+    ]
+
+
+def map_params(**kw):
+    """update_local_map defaults (map_manager.h:21-31), overridden by keyword."""
+    p = MapParams()
+    p.local_map_radius, p.max_num_pts, p.kept_vertex_num, p.last_frame_reliable_radius = 80.0, 20000, 800, 60.0
+    p.map_based_dynamic_removal_on = 0
+    p.used_feature_type = b"111110"
+    p.dynamic_removal_center_radius, p.dynamic_dist_thre_min, p.dynamic_dist_thre_max, p.near_dist_thre = 30.0, 0.3, 3.0, 0.03
+    p.recalculate_feature_on, p.rng_seed, p.tree_mode, p.tree_used = 0, 0, 0, b"000000"
+    for k, v in kw.items():
+        if k == "tree_box":
+            for i in range(6):
+                p.tree_box[i] = float(v[i])
+        elif k in ("used_feature_type", "tree_used"):
+            setattr(p, k, v.encode() if isinstance(v, str) else v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def colmajor16(M):
+    return (C.c_double * 16)(*np.asarray(M, dtype=np.float64).T.reshape(-1))
+
 class Profile(C.Structure):
     _fields_ = [
         ("ms_setup", C.c_double),

@@ -1,0 +1,123 @@
+// ctx.h — pieces of the host driver shared by driver.cpp (registration) and map.cpp (device-resident local map)
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mulls_hip.h"
+
+struct mulls_batch;
+struct mulls_map;
+
+struct mulls_ctx
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	bool profiling = false;
+	mulls_profile prof{};
+	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
+	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
+	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
+	std::vector<mulls_map *> maps; // live local maps: their buffers are the device clouds mulls_pair may point to
+	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
+};
+
+
+namespace
+{
+
+#define HIPCHK(ctx, call)                                                                                                   \
+	do                                                                                                                      \
+	{                                                                                                                       \
+		hipError_t e_ = (call);                                                                                             \
+		if (e_ != hipSuccess)                                                                                               \
+		{                                                                                                                   \
+			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                                 \
+			return MULLS_E_HIP;                                                                                             \
+		}                                                                                                                   \
+	} while (0)
+
+template <typename T>
+int dmalloc(mulls_ctx *ctx, T **p, size_t count)
+{
+	*p = nullptr;
+	HIPCHK(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
+	return MULLS_OK;
+}
+
+// seeded order-preserving selection sampling shared with the oracle's definition (include/mulls_hip.h: rng_seed)
+inline uint64_t splitmix64(uint64_t &x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	uint64_t z = x;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+// CFilter::random_downsample_pcl semantics (cfilter.hpp:606-628) expressed as a keep mask; returns the new size
+uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, int cloud_id)
+{
+	if ((long)n <= (long)keep_number)
+	{
+		std::memset(mask, 1, n);
+		return n;
+	}
+	std::memset(mask, 0, n);
+	if (keep_number == 0)
+		return 0;
+	uint64_t state = seed ^ (0x100000001B3ull * (uint64_t)(cloud_id + 1));
+	uint32_t need = (uint32_t)keep_number;
+	for (uint32_t i = 0; i < n && need > 0; i++)
+	{
+		const double u = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
+		if (u * (double)(n - i) < (double)need)
+		{
+			mask[i] = 1;
+			need--;
+		}
+	}
+	return (uint32_t)keep_number;
+}
+
+// grow-only device / pinned arrays: a batch object can be refilled with new pairs without touching the allocator when
+// the previous capacity suffices (mulls_icp / mulls_icp_batch reuse one cached batch per context)
+template <typename T>
+int grow(mulls_ctx *ctx, T **p, size_t *cap, size_t need, bool *grew = nullptr)
+{
+	if (grew)
+		*grew = false;
+	if (*p && *cap >= need)
+		return MULLS_OK;
+	if (*p)
+		(void)hipFree(*p);
+	*p = nullptr;
+	const size_t want = std::max<size_t>(need + need / 4, 64);
+	HIPCHK(ctx, hipMalloc((void **)p, want * sizeof(T)));
+	*cap = want;
+	if (grew)
+		*grew = true;
+	return MULLS_OK;
+}
+template <typename T>
+int grow_pinned(mulls_ctx *ctx, T **p, size_t *cap, size_t need, unsigned flags)
+{
+	if (*p && *cap >= need)
+		return MULLS_OK;
+	if (*p)
+		(void)hipHostFree((void *)*p);
+	*p = nullptr;
+	const size_t want = std::max<size_t>(need + need / 4, 64);
+	HIPCHK(ctx, hipHostMalloc((void **)p, want * sizeof(T), flags));
+	*cap = want;
+	return MULLS_OK;
+}
+
+} // namespace
+
+// is [p, p + bytes) inside a live local map's device buffers? (mulls_cloud.pts of a map-resident target, map.cpp)
+bool mulls_is_map_memory(const mulls_ctx *ctx, const void *p, size_t bytes);

@@ -23,22 +23,10 @@
 #include "device_types.h"
 #include "hostmath.h"
 #include "launch.h"
+#include "ctx.h"
 
 using mulls::Mat4;
 using mulls::Mat6;
-
-struct mulls_ctx
-{
-	int device = 0;
-	hipStream_t stream = nullptr;
-	std::string err;
-	bool profiling = false;
-	mulls_profile prof{};
-	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
-	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
-	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
-	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
-};
 
 struct mulls_batch
 {
@@ -96,25 +84,6 @@ struct mulls_batch
 
 namespace
 {
-
-#define HIPCHK(ctx, call)                                                                                                   \
-	do                                                                                                                      \
-	{                                                                                                                       \
-		hipError_t e_ = (call);                                                                                             \
-		if (e_ != hipSuccess)                                                                                               \
-		{                                                                                                                   \
-			(ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                                 \
-			return MULLS_E_HIP;                                                                                             \
-		}                                                                                                                   \
-	} while (0)
-
-template <typename T>
-int dmalloc(mulls_ctx *ctx, T **p, size_t count)
-{
-	*p = nullptr;
-	HIPCHK(ctx, hipMalloc((void **)p, std::max<size_t>(count, 1) * sizeof(T)));
-	return MULLS_OK;
-}
 
 inline float ord_to_float(uint32_t k)
 {
@@ -367,73 +336,6 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	}
 }
 
-// seeded order-preserving selection sampling shared with the oracle's definition (include/mulls_hip.h: rng_seed)
-inline uint64_t splitmix64(uint64_t &x)
-{
-	x += 0x9E3779B97F4A7C15ull;
-	uint64_t z = x;
-	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-	return z ^ (z >> 31);
-}
-// CFilter::random_downsample_pcl semantics (cfilter.hpp:606-628) expressed as a keep mask; returns the new size
-uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, int cloud_id)
-{
-	if ((long)n <= (long)keep_number)
-	{
-		std::memset(mask, 1, n);
-		return n;
-	}
-	std::memset(mask, 0, n);
-	if (keep_number == 0)
-		return 0;
-	uint64_t state = seed ^ (0x100000001B3ull * (uint64_t)(cloud_id + 1));
-	uint32_t need = (uint32_t)keep_number;
-	for (uint32_t i = 0; i < n && need > 0; i++)
-	{
-		const double u = (double)(splitmix64(state) >> 11) * (1.0 / 9007199254740992.0);
-		if (u * (double)(n - i) < (double)need)
-		{
-			mask[i] = 1;
-			need--;
-		}
-	}
-	return (uint32_t)keep_number;
-}
-
-// grow-only device / pinned arrays: a batch object can be refilled with new pairs without touching the allocator when
-// the previous capacity suffices (mulls_icp / mulls_icp_batch reuse one cached batch per context)
-template <typename T>
-int grow(mulls_ctx *ctx, T **p, size_t *cap, size_t need, bool *grew = nullptr)
-{
-	if (grew)
-		*grew = false;
-	if (*p && *cap >= need)
-		return MULLS_OK;
-	if (*p)
-		(void)hipFree(*p);
-	*p = nullptr;
-	const size_t want = std::max<size_t>(need + need / 4, 64);
-	HIPCHK(ctx, hipMalloc((void **)p, want * sizeof(T)));
-	*cap = want;
-	if (grew)
-		*grew = true;
-	return MULLS_OK;
-}
-template <typename T>
-int grow_pinned(mulls_ctx *ctx, T **p, size_t *cap, size_t need, unsigned flags)
-{
-	if (*p && *cap >= need)
-		return MULLS_OK;
-	if (*p)
-		(void)hipHostFree((void *)*p);
-	*p = nullptr;
-	const size_t want = std::max<size_t>(need + need / 4, 64);
-	HIPCHK(ctx, hipHostMalloc((void **)p, want * sizeof(T), flags));
-	*cap = want;
-	return MULLS_OK;
-}
-
 // lay the pairs out in the batch arenas, (re)allocate what is too small and stage the caller's clouds in HBM
 int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 {
@@ -564,6 +466,13 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
 
 	// stage the caller's AoS records (48-B PointXYZINormal) contiguously in pinned memory, then one H2D copy
+	struct DevCopy
+	{
+		size_t dst;
+		const void *src;
+		size_t bytes;
+	};
+	std::vector<DevCopy> dev_copies;
 	for (int p = 0; p < n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
 		{
@@ -574,6 +483,17 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			{
 				uint8_t *dst = B->upload_h + (size_t)off[k] * MULLS_POINT_BYTES;
 				const uint8_t *src = (const uint8_t *)cl[k]->pts;
+				if (cl[k]->n && mulls_is_map_memory(ctx, src, (size_t)cl[k]->n * MULLS_POINT_BYTES))
+				{
+					// a class cloud of a device-resident local map (mulls_map_cloud): staged by a device-to-device copy below
+					if (cl[k]->stride != MULLS_POINT_BYTES)
+					{
+						ctx->err = "device-resident cloud with stride != 48";
+						return MULLS_E_INVALID;
+					}
+					dev_copies.push_back({(size_t)off[k] * MULLS_POINT_BYTES, src, (size_t)cl[k]->n * MULLS_POINT_BYTES});
+					continue;
+				}
 				if (cl[k]->stride == MULLS_POINT_BYTES)
 					std::memcpy(dst, src, (size_t)cl[k]->n * MULLS_POINT_BYTES);
 				else
@@ -583,6 +503,9 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 		}
 	hipStream_t st = ctx->stream;
 	hipError_t e = hipMemcpyAsync(B->stage, B->upload_h, stage_rec * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st);
+	for (const DevCopy &dc : dev_copies)
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + dc.dst, dc.src, dc.bytes, hipMemcpyDeviceToDevice, st);
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
 	if (e == hipSuccess)

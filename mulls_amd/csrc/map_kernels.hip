@@ -1,0 +1,204 @@
+// map_kernels.hip — device side of the local map (MapManager::update_local_map, src/map_manager.cpp:18-140; dynamic
+// object removal :149-268).  Clouds stay 48-B PointXYZINormal records (3 float4: x y z -, nx ny nz -, intensity
+// curvature - -) so that a map class cloud can be handed to mulls_icp as a device-resident target unchanged.
+#include <hip/hip_runtime.h>
+
+#include "map_launch.h"
+
+namespace
+{
+__device__ __forceinline__ uint32_t float_ord(float f)
+{
+	const uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+} // namespace
+
+// Stable compaction of up to six clouds, one 1024-lane workgroup each: chunks of 1024 records, wave ballots + a 16-entry
+// LDS scan give every kept record its slot.  The order of the survivors is the input order (the reference pushes them
+// back one by one).
+__global__ __launch_bounds__(1024) void k_map_compact(MapCompactArgs a)
+{
+	__shared__ uint32_t wave_cnt[16];
+	const MapCloudArg c = a.cloud[blockIdx.x];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const double r2 = a.radius * a.radius;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < c.n; base += 1024)
+	{
+		const uint32_t i = base + threadIdx.x;
+		bool keep = false;
+		float4 r0, r1, r2v;
+		if (i < c.n)
+		{
+			r0 = c.in[(size_t)i * 3];
+			r1 = c.in[(size_t)i * 3 + 1];
+			r2v = c.in[(size_t)i * 3 + 2];
+			if (a.mode == 0)
+				keep = c.mask[i] != 0;
+			else
+			{
+				const double dis_square = (double)(r0.x * r0.x + r0.y * r0.y); // float products and sum, then widened
+				keep = dis_square < r2 && r0.z < 1.7976931348623157e308 && r0.z > -1.7976931348623157e308;
+			}
+		}
+		const unsigned long long b = __ballot(keep);
+		const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+		__syncthreads();
+		if (lane == 0)
+			wave_cnt[wave] = (uint32_t)__popcll(b);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 16; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			const size_t o = (size_t)(running + wbase + before) * 3;
+			c.out[o] = r0;
+			c.out[o + 1] = r1;
+			c.out[o + 2] = r2v;
+		}
+		running += total;
+	}
+	if (threadIdx.x == 0)
+		a.out_n[blockIdx.x] = running;
+}
+
+// get_cloud_bbx (utility.hpp:817-848) over the six class clouds, and over the same points moved by pose_lo
+// (pcl::transformPointCloud: double arithmetic, float store) — ordered-uint atomics; NaN coordinates never win a
+// comparison in the reference and are skipped here.
+__global__ __launch_bounds__(256) void k_map_bbox(MapBoxArgs a)
+{
+	const uint32_t cls = blockIdx.y;
+	const float4 *recs = a.recs[cls];
+	float lo[6], hi[6];
+	for (int k = 0; k < 6; k++)
+	{
+		lo[k] = __builtin_inff();
+		hi[k] = -__builtin_inff();
+	}
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[cls]; i += gridDim.x * blockDim.x)
+	{
+		const float4 p = recs[(size_t)i * 3];
+		const double x = p.x, y = p.y, z = p.z;
+		const float v[6] = {p.x, p.y, p.z, (float)(a.pose[0] * x + a.pose[1] * y + a.pose[2] * z + a.pose[3]),
+							(float)(a.pose[4] * x + a.pose[5] * y + a.pose[6] * z + a.pose[7]),
+							(float)(a.pose[8] * x + a.pose[9] * y + a.pose[10] * z + a.pose[11])};
+		for (int k = 0; k < 6; k++)
+		{
+			lo[k] = fminf(lo[k], v[k]);
+			hi[k] = fmaxf(hi[k], v[k]);
+		}
+	}
+	for (int k = 0; k < 6; k++)
+	{
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			lo[k] = fminf(lo[k], __shfl_down(lo[k], off));
+			hi[k] = fmaxf(hi[k], __shfl_down(hi[k], off));
+		}
+		if ((threadIdx.x & 63) == 0)
+		{
+			// slot layout: [0..2] min xyz, [3..5] max xyz, [6..8] posed min, [9..11] posed max
+			const int base = k < 3 ? 0 : 6, ax = k % 3;
+			if (lo[k] <= hi[k])
+			{
+				atomicMin(&a.keys[base + ax], float_ord(lo[k]));
+				atomicMax(&a.keys[base + 3 + ax], float_ord(hi[k]));
+			}
+		}
+	}
+}
+
+// Exact nearest tree point (FLANN L2_Simple<float> distance) of every frame point, brute force: blockIdx.y splits the tree
+// into chunks of 16384 points staged through LDS, atomicMin on the float bits combines the chunks (distances are >= 0).
+#define MAP_NN_CHUNK 16384u
+#define MAP_NN_TILE 1024u
+__global__ __launch_bounds__(256) void k_map_nn(const float4 *__restrict__ frame, uint32_t n_frame, const float4 *__restrict__ tree, uint32_t n_tree,
+												 int use_box, double b0, double b1, double b2, double b3, double b4, double b5,
+												 uint32_t *__restrict__ best)
+{
+	__shared__ float4 tile[MAP_NN_TILE];
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	float qx = 0, qy = 0, qz = 0;
+	if (q < n_frame)
+	{
+		const float4 p = frame[(size_t)q * 3];
+		qx = p.x, qy = p.y, qz = p.z;
+	}
+	float d_best = __builtin_inff();
+	const uint32_t t0 = blockIdx.y * MAP_NN_CHUNK, t1 = min(n_tree, t0 + MAP_NN_CHUNK);
+	for (uint32_t base = t0; base < t1; base += MAP_NN_TILE)
+	{
+		__syncthreads();
+		for (uint32_t k = threadIdx.x; k < MAP_NN_TILE; k += blockDim.x)
+		{
+			float4 t = make_float4(0, 0, 0, 0); // w = 1: member of the tree
+			if (base + k < t1)
+			{
+				t = tree[(size_t)(base + k) * 3];
+				const bool in = !use_box || (t.x > b0 && t.x < b3 && t.y > b1 && t.y < b4 && t.z > b2 && t.z < b5); // bbx_filter, cfilter.hpp:950-981
+				t.w = in ? 1.0f : 0.0f;
+			}
+			tile[k] = t;
+		}
+		__syncthreads();
+		const uint32_t cnt = min(MAP_NN_TILE, t1 - base);
+		for (uint32_t k = 0; k < cnt; k++)
+		{
+			const float4 t = tile[k];
+			float diff = qx - t.x;
+			float d = diff * diff;
+			diff = qy - t.y;
+			d += diff * diff;
+			diff = qz - t.z;
+			d += diff * diff;
+			if (t.w != 0.0f && d < d_best)
+				d_best = d;
+		}
+	}
+	if (q < n_frame && d_best < __builtin_inff())
+		atomicMin(&best[q], __float_as_uint(d_best));
+}
+
+// map_scan_feature_pts_distance_removal's keep rule (map_manager.cpp:246-256), all in float as written there
+__global__ void k_map_keep(const float4 *__restrict__ frame, uint32_t n_frame, const uint32_t *__restrict__ best, float center_radius, float dmin,
+						   float dmax, float near, uint8_t *__restrict__ keep)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_frame)
+		return;
+	const float4 p = frame[(size_t)q * 3];
+	bool k = true;
+	if (!(p.x * p.x + p.y * p.y > center_radius * center_radius))
+	{
+		const uint32_t bits = best[q];
+		if (bits != 0x7f800000u) // an empty tree leaves the cloud alone (see oracle)
+		{
+			const float d2 = __uint_as_float(bits);
+			k = (d2 > near * near && d2 < dmin * dmin) || d2 > dmax * dmax;
+		}
+	}
+	keep[q] = k ? 1 : 0;
+}
+
+void launch_map_compact(hipStream_t st, const MapCompactArgs &a) { hipLaunchKernelGGL(k_map_compact, dim3(6), dim3(1024), 0, st, a); }
+void launch_map_bbox(hipStream_t st, const MapBoxArgs &a) { hipLaunchKernelGGL(k_map_bbox, dim3(64, 6), dim3(256), 0, st, a); }
+void launch_map_nn(hipStream_t st, const float4 *frame, uint32_t n_frame, const float4 *tree, uint32_t n_tree, int use_box, const double box[6],
+				   uint32_t *best)
+{
+	if (!n_frame || !n_tree)
+		return;
+	hipLaunchKernelGGL(k_map_nn, dim3((n_frame + 255) / 256, (n_tree + MAP_NN_CHUNK - 1) / MAP_NN_CHUNK), dim3(256), 0, st, frame, n_frame, tree,
+					   n_tree, use_box, box[0], box[1], box[2], box[3], box[4], box[5], best);
+}
+void launch_map_keep(hipStream_t st, const float4 *frame, uint32_t n_frame, const uint32_t *best, float center_radius, float dmin, float dmax,
+					 float near, uint8_t *keep)
+{
+	if (n_frame)
+		hipLaunchKernelGGL(k_map_keep, dim3((n_frame + 255) / 256), dim3(256), 0, st, frame, n_frame, best, center_radius, dmin, dmax, near, keep);
+}

@@ -55,6 +55,17 @@ def load():
     lib.mulls_stage_correspond.argtypes = [vp, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), C.c_float, C.c_int, C.c_float, vp, vp, vp]
     lib.mulls_stage_accumulate.argtypes = [vp, C.c_int, C.POINTER(abi.Cloud), C.POINTER(abi.Cloud), vp, vp, vp, C.c_uint32, C.c_int,
                                            C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+    lib.mulls_map_default_params.argtypes = [C.POINTER(abi.MapParams)]
+    lib.mulls_map_default_params.restype = None
+    lib.mulls_map_create.argtypes = [vp, C.POINTER(vp)]
+    lib.mulls_map_destroy.argtypes = [vp, vp]
+    lib.mulls_map_destroy.restype = None
+    lib.mulls_map_set.argtypes = [vp, vp, C.POINTER(abi.Cloud), C.POINTER(C.c_double)]
+    lib.mulls_map_update.argtypes = [vp, vp, C.POINTER(abi.Cloud), C.POINTER(C.c_double), C.POINTER(abi.MapParams), C.POINTER(abi.MapReport)]
+    lib.mulls_map_cloud.argtypes = [vp, vp, C.c_int, C.POINTER(abi.Cloud)]
+    lib.mulls_map_pose.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.mulls_map_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_map_frame_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     _LIB = lib
     return lib
 
@@ -63,7 +74,8 @@ EXPORTS = [
     "mulls_default_params", "mulls_create", "mulls_destroy", "mulls_last_error", "mulls_set_profiling", "mulls_get_profile",
     "mulls_stream", "mulls_set_nn_mode", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
     "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate", "mulls_icp_3dof_ground", "mulls_icp_3dof_ground_batch",
-    "mulls_icp_4dof_global",
+    "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
+    "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download",
 ]
 
 
@@ -122,6 +134,10 @@ class Context:
 
     def batch(self, pairs):
         return Batch(self, pairs)
+
+    def local_map(self, clouds=None, pose=None):
+        """Device-resident local map (mulls_map_*), optionally initialised from six host class clouds and a pose_lo."""
+        return LocalMap(self, clouds, pose)
 
     # --- variants (SURVEY 8f-1) ------------------------------------------------------------------------------------
     def icp_3dof_ground(self, pairs, params, trace_cap=0):
@@ -200,3 +216,87 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class LocalMap:
+    """mulls_map: the six undown class clouds of the reference's local_map cloudblock, kept in HBM between frames."""
+
+    def __init__(self, ctx, clouds=None, pose=None):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._check(ctx.lib.mulls_map_create(ctx.h, C.byref(self.h)), "mulls_map_create")
+        if clouds is not None:
+            self.set(clouds, np.eye(4) if pose is None else pose)
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.mulls_map_destroy(self.ctx.h, self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _clouds(clouds):
+        keep = [abi.as_points(c) for c in clouds]
+        arr = (abi.Cloud * abi.NCLASS)()
+        for c in range(abi.NCLASS):
+            arr[c] = abi.as_cloud(keep[c])
+        return arr, keep
+
+    def set(self, clouds, pose):
+        arr, keep = self._clouds(clouds)
+        self.ctx._check(self.ctx.lib.mulls_map_set(self.ctx.h, self.h, arr, abi.colmajor16(pose)), "mulls_map_set")
+
+    def update(self, frame_down, frame_pose, params):
+        """update_local_map with last_target_cblock = (frame_down[0..4] = pc_*_down, frame_down[5] = pc_vertex, frame_pose)."""
+        arr, keep = self._clouds(frame_down)
+        rep = abi.MapReport()
+        self.ctx._check(self.ctx.lib.mulls_map_update(self.ctx.h, self.h, arr, abi.colmajor16(frame_pose), C.byref(params), C.byref(rep)),
+                        "mulls_map_update")
+        return rep
+
+    def cloud(self, cls):
+        """Device-resident mulls_cloud of class `cls` (usable as a registration target until the next set / update)."""
+        c = abi.Cloud()
+        self.ctx._check(self.ctx.lib.mulls_map_cloud(self.ctx.h, self.h, cls, C.byref(c)), "mulls_map_cloud")
+        return c
+
+    def pose(self):
+        m = (C.c_double * 16)()
+        self.ctx._check(self.ctx.lib.mulls_map_pose(self.ctx.h, self.h, m), "mulls_map_pose")
+        return np.array(m[:]).reshape(4, 4).T.copy()
+
+    def _download(self, fn, name, cls):
+        n = C.c_uint32(0)
+        self.ctx._check(fn(self.ctx.h, self.h, cls, None, 0, C.byref(n)), name)
+        out = np.zeros(n.value, abi.POINT_DTYPE)
+        if n.value:
+            self.ctx._check(fn(self.ctx.h, self.h, cls, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), name)
+        return out
+
+    def download(self, cls):
+        return self._download(self.ctx.lib.mulls_map_download, "mulls_map_download", cls)
+
+    def frame_download(self, cls):
+        return self._download(self.ctx.lib.mulls_map_frame_download, "mulls_map_frame_download", cls)
+
+    def icp(self, src, params, init_guess=None, tgt_bound=None, trace_cap=0):
+        """mm_lls_icp with this map as block1 (target clouds stay on the device) and `src` as block2's six source clouds."""
+        keep = [abi.as_points(s) for s in src]
+        pair = abi.Pair()
+        for c in range(abi.NCLASS):
+            pair.tgt[c] = self.cloud(c)
+            pair.src[c] = abi.as_cloud(keep[c])
+            pair.src_down[c] = abi.as_cloud(None)
+        for k in range(6):
+            pair.tgt_bound[k] = float(tgt_bound[k])
+        g = np.asarray(np.eye(4) if init_guess is None else init_guess, dtype=np.float64).T.reshape(-1)
+        for k in range(16):
+            pair.init_guess[k] = float(g[k])
+        res = abi.make_result_array(1, trace_cap)
+        self.ctx._check(self.ctx.lib.mulls_icp(self.ctx.h, C.byref(pair), C.byref(params), res), "mulls_icp")
+        return res

@@ -6,7 +6,7 @@
 // called with the positional arguments of test/mulls_slam.cpp:642-648 / test/mulls_reg.cpp:194-195, and their
 // constraint_t outputs are printed side by side as JSON for tests/test_gpu_adapter.py to compare.
 //
-// usage: adapter_check <dump file written by the test> <kitti|reg>
+// usage: adapter_check <dump file written by the test> <kitti|reg|variants|map>
 #include <chrono>
 #include <cstdio>
 
@@ -44,6 +44,9 @@ class CRegistration : public CloudUtility<PointT>
   public:
 #include "creg_body.inc"
 };
+#include "map_decl.inc"
+#include "map_body.inc"
+bool MapManager::update_cloud_vectors(pcTPtr, const pcTreePtr, float, int, int, float, float, float) { std::abort(); }
 } // namespace lo
 
 #include "cregistration_hip.hpp" // the adapter under test: sees exactly the types a MULLS translation unit has at this point
@@ -107,6 +110,57 @@ int main(int argc, char **argv)
 	Eigen::Matrix4d initial_guess_tran;
 	std::memcpy(initial_guess_tran.data(), guess_raw, sizeof(guess_raw));
 
+	if (std::string(argv[2]) == "map")
+	{
+		// scan-to-map step of test/mulls_slam.cpp: mm_lls_icp against the local map (block1), then update_local_map with the
+		// registered frame (block2) and map-based dynamic removal on — the reference through the kd-trees its mm_lls_icp left
+		// on block1, the bridge through the device-resident mirror of block1
+		lo::CRegistration<Point_T> cr;
+		lo::MapManager mm;
+		auto fnv = [](const pcTPtr &c) {
+			unsigned long long h = 1469598103934665603ull;
+			const unsigned char *b = (const unsigned char *)c->points.data();
+			for (size_t i = 0; i < c->points.size(); i++)
+				for (int k = 0; k < 40; k++) // x..curvature, not the trailing padding
+					h = (h ^ b[i * sizeof(Point_T) + k]) * 1099511628211ull;
+			return h;
+		};
+		lo::hip::attach_local_map(con_hip.block1);
+		for (int w = 0; w < 2; w++)
+		{
+			lo::constraint_t &con = *cons[w];
+			int code;
+			if (w == 0)
+				code = cr.mm_lls_icp(con, 20, 2.0, 0.002, 0.01, 0.4, 1.1, "111000", "1101", 1.0, 0.1, 0.1, 0.1, initial_guess_tran);
+			else
+				code = lo::hip::mm_lls_icp<Point_T>(con, 20, 2.0, 0.002, 0.01, 0.4, 1.1, "111000", "1101", 1.0, 0.1, 0.1, 0.1, initial_guess_tran);
+			con.block1->pose_lo.setIdentity();
+			// both runs continue from the reference's pose (the two Trans1_2 agree to ~1e-12, not to the bit: float rounding of the
+			// transformed map could then differ in a last place and hide a real mismatch behind a tolerance)
+			con.block2->pose_lo = con.block1->pose_lo * con_ref.Trans1_2;
+			con.block1->feature_point_num = (int)(con.block1->pc_ground->points.size() + con.block1->pc_facade->points.size() +
+												  con.block1->pc_roof->points.size() + con.block1->pc_pillar->points.size() +
+												  con.block1->pc_beam->points.size());
+			const int max_pts = 4 * con.block1->feature_point_num;
+			if (w == 0)
+				mm.update_local_map(con.block1, con.block2, 60.0f, max_pts, 100000, 60, true, "111000", 25.0f, 0.25f, 1.0f, 0.05f, false);
+			else
+				lo::hip::update_local_map(con.block1, con.block2, 60.0f, max_pts, 100000, 60, true, "111000", 25.0f, 0.25f, 1.0f, 0.05f, false);
+			lo::cloudblock_t &m = *con.block1, &fr = *con.block2;
+			printf("{\"who\": \"%s\", \"code\": %d, \"n\": [%zu, %zu, %zu, %zu, %zu, %zu], \"frame_n\": [%zu, %zu, %zu, %zu, %zu], ",
+				   w == 0 ? "reference_map" : "hip_map", code, m.pc_ground->points.size(), m.pc_pillar->points.size(), m.pc_facade->points.size(),
+				   m.pc_beam->points.size(), m.pc_roof->points.size(), m.pc_vertex->points.size(), fr.pc_ground_down->points.size(),
+				   fr.pc_pillar_down->points.size(), fr.pc_facade_down->points.size(), fr.pc_beam_down->points.size(),
+				   fr.pc_roof_down->points.size());
+			printf("\"hash\": [\"%llx\", \"%llx\", \"%llx\", \"%llx\", \"%llx\", \"%llx\"], \"frame_hash\": [\"%llx\", \"%llx\", \"%llx\"], ",
+				   fnv(m.pc_ground), fnv(m.pc_pillar), fnv(m.pc_facade), fnv(m.pc_beam), fnv(m.pc_roof), fnv(m.pc_vertex), fnv(fr.pc_ground_down),
+				   fnv(fr.pc_pillar_down), fnv(fr.pc_facade_down));
+			printf("\"feature_point_num\": %d, \"local_bound\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"bound\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g]}\n",
+				   m.feature_point_num, m.local_bound.min_x, m.local_bound.min_y, m.local_bound.min_z, m.local_bound.max_x, m.local_bound.max_y,
+				   m.local_bound.max_z, m.bound.min_x, m.bound.min_y, m.bound.min_z, m.bound.max_x, m.bound.max_y, m.bound.max_z);
+		}
+		return 0;
+	}
 	if (std::string(argv[2]) == "variants")
 	{
 		// lls_icp_3dof_ground and mm_lls_icp_4dof_global: reference members vs the bridge functions of the same names

@@ -21,13 +21,14 @@ trap 'rm -rf "$TMP"' EXIT
 
 # extract <file> <first> <last> <expected substring of first line> <out>
 extract() {
-	local first_line
-	first_line="$(sed -n "${2}p" "$INC/$1")"
+	local first_line src="$INC/$1"
+	[[ "$1" == /* ]] && src="$1"
+	first_line="$(sed -n "${2}p" "$src")"
 	if [[ "$first_line" != *"$4"* ]]; then
 		echo "build_ref: $1:$2 does not look like '$4' (reference revision changed?)" >&2
 		exit 1
 	fi
-	sed -n "${2},${3}p" "$INC/$1" >>"$TMP/$5"
+	sed -n "${2},${3}p" "$src" >>"$TMP/$5"
 }
 
 # utility.hpp: Vector6d/Matrix6d, centerpoint_t, bounds_t, enums, cloudblock_t, constraint_t, CloudUtility (bbox helpers)
@@ -39,6 +40,7 @@ extract utility.hpp 795 886 "template <typename PointT>" util_cloudutility.inc
 # cfilter.hpp: motion compensation, random down-sampling, box filter, pair intersection
 extract cfilter.hpp 470 549 "void apply_motion_compensation" cfilter_body.inc
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
+extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
 extract cfilter.hpp 2613 2655 "bool get_cloud_pair_intersection" cfilter_body.inc
 # cregistration.hpp: the driver and every helper on the path
@@ -51,6 +53,11 @@ extract cregistration.hpp 2518 2722 "bool get_multi_metrics_lls_residual" creg_b
 extract cregistration.hpp 2740 2764 "bool construct_trans_a" creg_body.inc
 extract cregistration.hpp 2795 2836 "bool get_quat_euler_jacobi" creg_body.inc
 extract cregistration.hpp 2866 2922 "bool keep_less_source_pts" creg_body.inc
+# local map manager: class declaration, update_local_map, dynamic removal (update_cloud_vectors = PCA, not extracted)
+extract "$REF/include/pgo/map_manager.h" 19 52 "class MapManager" map_decl.inc
+extract "$REF/src/map_manager.cpp" 18 140 "bool MapManager::update_local_map" map_body.inc
+extract "$REF/src/map_manager.cpp" 149 218 "bool MapManager::map_based_dynamic_close_removal" map_body.inc
+extract "$REF/src/map_manager.cpp" 222 256 "bool MapManager::map_scan_feature_pts_distance_removal" map_body.inc
 
 mkdir -p "$HERE/_ref"
 # same flags as the reference's Release build (CMakeLists.txt:43: -O3, no -march); no OpenMP: the only pragmas on the path

@@ -1807,3 +1807,171 @@ extern "C"
 		return angle_of_rotation(m);
 	}
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// MapManager::update_local_map (src/map_manager.cpp:18-140) and map_based_dynamic_close_removal (:149-256),
+// restated on plain clouds.  Class order as everywhere: ground, pillar, facade, beam, roof, vertex.
+namespace
+{
+// CFilter::dist_filter(cloud, xy_dis_thre, keep_inside = true) (cfilter.hpp:834-871): float products summed in float,
+// widened to double; z compared against +-DBL_MAX (drops NaN / inf heights)
+void dist_filter_inside(Cloud &c, double xy_dis_thre)
+{
+	Cloud out;
+	for (size_t i = 0; i < c.size(); i++)
+	{
+		const double dis_square = c[i].x * c[i].x + c[i].y * c[i].y;
+		if (dis_square < xy_dis_thre * xy_dis_thre && c[i].z < DBL_MAX && c[i].z > -DBL_MAX)
+			out.push_back(c[i]);
+	}
+	c.swap(out);
+}
+
+// pcl::transformPointCloud<PointT,double> (positions only)
+void transform_positions(Cloud &c, const M4 &T)
+{
+	for (size_t i = 0; i < c.size(); i++)
+	{
+		Pt &p = c[i];
+		const double x = p.x, y = p.y, z = p.z;
+		p.x = static_cast<float>(T(0, 0) * x + T(0, 1) * y + T(0, 2) * z + T(0, 3));
+		p.y = static_cast<float>(T(1, 0) * x + T(1, 1) * y + T(1, 2) * z + T(1, 3));
+		p.z = static_cast<float>(T(2, 0) * x + T(2, 1) * y + T(2, 2) * z + T(2, 3));
+	}
+}
+
+// MapManager::map_scan_feature_pts_distance_removal (map_manager.cpp:233-268); `tree` holds what mm_lls_icp indexed
+void distance_removal(Cloud &pts, const Cloud &tree_pts, float center_radius, float dmin, float dmax, float near)
+{
+	if (pts.size() <= 10 || tree_pts.empty())
+		return; // the reference would query an empty kd-tree here (undefined); defined as "leave the cloud alone"
+	Cloud out;
+	for (size_t i = 0; i < pts.size(); i++)
+	{
+		if (pts[i].x * pts[i].x + pts[i].y * pts[i].y > center_radius * center_radius)
+			out.push_back(pts[i]);
+		else
+		{
+			float d2;
+			brute_nearest(tree_pts, pts[i], d2);
+			if ((d2 > near * near && d2 < dmin * dmin) || d2 > dmax * dmax)
+				out.push_back(pts[i]);
+		}
+	}
+	pts.swap(out);
+}
+} // namespace
+
+extern "C"
+{
+	void mulls_oracle_map_default_params(mulls_map_params *p)
+	{
+		std::memset(p, 0, sizeof(*p));
+		p->local_map_radius = 80;
+		p->max_num_pts = 20000;
+		p->kept_vertex_num = 800;
+		p->last_frame_reliable_radius = 60;
+		std::strcpy(p->used_feature_type, "111110");
+		p->dynamic_removal_center_radius = 30.0f;
+		p->dynamic_dist_thre_min = 0.3f;
+		p->dynamic_dist_thre_max = 3.0f;
+		p->near_dist_thre = 0.03f;
+		std::strcpy(p->tree_used, "000000");
+	}
+
+	// map_out[c] / frame_out[c]: caller buffers of (map_in[c].n + frame_down[c].n) and frame_down[c].n 48-B records
+	int mulls_oracle_map_update(const mulls_cloud map_in[6], const double map_pose[16], const mulls_cloud frame_down[6],
+								const double frame_pose[16], const mulls_map_params *P, void *const map_out[6], uint32_t map_out_n[6],
+								void *const frame_out[6], uint32_t frame_out_n[6], mulls_map_report *rep)
+	{
+		if (!map_in || !map_pose || !frame_down || !frame_pose || !P || !rep)
+			return MULLS_E_INVALID;
+		if (P->recalculate_feature_on)
+			return MULLS_E_UNSUPPORTED;
+		Cloud M[6], F[6];
+		for (int c = 0; c < 6; c++)
+		{
+			load_cloud(map_in[c], M[c]);
+			load_cloud(frame_down[c], F[c]);
+		}
+		M4 map_T, frame_T;
+		std::memcpy(map_T.a, map_pose, sizeof(map_T.a));
+		std::memcpy(frame_T.a, frame_pose, sizeof(frame_T.a));
+		const M4 tran_target_map = m4_mul(m4_inverse(frame_T), map_T); // :28
+		const M4 inv = m4_inverse(tran_target_map);
+		for (int c = 0; c < 5; c++) // transform_feature(inv, true, false): the five *_down clouds, not the vertex cloud (:32)
+			transform_cloud(F[c], inv);
+
+		float dmax = P->dynamic_dist_thre_max;
+		{
+			const double lo = P->dynamic_dist_thre_min + 0.1; // max_(a, b) on (float, double) operands (:34)
+			dmax = (float)(((double)dmax > lo) ? (double)dmax : lo);
+		}
+		int feature_point_num = 0;
+		{
+			static const int five[5] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM};
+			for (int k = 0; k < 5; k++)
+				feature_point_num += (int)M[five[k]].size();
+		}
+		rep->dynamic_removal_ran = 0;
+		if (P->map_based_dynamic_removal_on && feature_point_num > P->max_num_pts / 5 && P->tree_mode != 0) // :37
+		{
+			rep->dynamic_removal_ran = 1;
+			static const int order[3] = {MULLS_PILLAR, MULLS_BEAM, MULLS_FACADE};
+			for (int k = 0; k < 3; k++)
+			{
+				const int c = order[k];
+				if (P->used_feature_type[c] != '1' || P->tree_used[c] != '1')
+					continue;
+				Cloud tree_pts = M[c];
+				if (P->tree_mode == 2)
+					bbx_filter(tree_pts, P->tree_box);
+				distance_removal(F[c], tree_pts, P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, dmax, P->near_dist_thre);
+			}
+		}
+		for (int c = 0; c < 6; c++)
+		{
+			frame_out_n[c] = (uint32_t)F[c].size();
+			rep->frame_n[c] = frame_out_n[c];
+			if (frame_out && frame_out[c])
+				for (size_t i = 0; i < F[c].size(); i++)
+					std::memcpy((uint8_t *)frame_out[c] + i * sizeof(Pt), &F[c][i], sizeof(Pt));
+		}
+		for (int c = 0; c < 6; c++) // append_feature(last_target, true, used) (:54, utility.hpp:438-469): the vertex cloud always
+			if (c == MULLS_VERTEX || P->used_feature_type[c] == '1')
+				M[c].insert(M[c].end(), F[c].begin(), F[c].end());
+		for (int c = 0; c < 6; c++) // transform_feature(tran_target_map, false): all six undown clouds (:57)
+			transform_cloud(M[c], tran_target_map);
+		for (int c = 0; c < 6; c++) // :62-67
+			dist_filter_inside(M[c], P->local_map_radius);
+		const int cur = (int)(M[MULLS_GROUND].size() + M[MULLS_FACADE].size() + M[MULLS_ROOF].size() + M[MULLS_PILLAR].size() +
+							  M[MULLS_BEAM].size());
+		for (int c = 0; c < 5; c++) // :75-85 (a division by zero points makes kept = INT_MIN: nothing to thin anyway)
+		{
+			const int kept = cur > 0 ? (int)(1.0 * P->max_num_pts / cur * M[c].size() + 1) : 1;
+			random_downsample(M[c], kept, P->rng_seed, 20 + c);
+		}
+		random_downsample(M[MULLS_VERTEX], P->kept_vertex_num, P->rng_seed, 20 + MULLS_VERTEX);
+
+		Cloud raw; // merge_feature_points(pc_raw, false): ground, facade, pillar, beam, roof, vertex (utility.hpp:471-481)
+		static const int merge_order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_PILLAR, MULLS_BEAM, MULLS_ROOF, MULLS_VERTEX};
+		for (int k = 0; k < 6; k++)
+			raw.insert(raw.end(), M[merge_order[k]].begin(), M[merge_order[k]].end());
+		cloud_bbx(raw, rep->local_bound);
+		transform_positions(raw, frame_T); // local_map->pose_lo = last_target_cblock->pose_lo (:58), then :92
+		cloud_bbx(raw, rep->bound);
+
+		rep->feature_point_num = (int)(M[MULLS_GROUND].size() + M[MULLS_FACADE].size() + M[MULLS_ROOF].size() + M[MULLS_PILLAR].size() +
+									   M[MULLS_BEAM].size());
+		for (int c = 0; c < 6; c++)
+		{
+			map_out_n[c] = (uint32_t)M[c].size();
+			rep->n[c] = map_out_n[c];
+			if (map_out && map_out[c])
+				for (size_t i = 0; i < M[c].size(); i++)
+					std::memcpy((uint8_t *)map_out[c] + i * sizeof(Pt), &M[c][i], sizeof(Pt));
+		}
+		rep->ms_total = 0.0f;
+		return MULLS_OK;
+	}
+}

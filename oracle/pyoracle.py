@@ -128,3 +128,27 @@ def icp_4dof_global(pair, heading_step_d, station, max_iter_num=20, dis_thre_uni
     if rc != 0:
         raise RuntimeError("oracle returned %d" % rc)
     return res, bool(ok.value), float(best.value)
+
+
+def map_update(map_clouds, map_pose, frame_down, frame_pose, params, fn=None):
+    """MapManager::update_local_map on host clouds.  Returns (new map clouds[6], frame clouds as appended[6], abi.MapReport).
+    `fn`: entry point with the signature of mulls_oracle_map_update (oracle/pyref.py passes the reference-lines build)."""
+    mc = [abi.as_points(c) for c in map_clouds]
+    fc = [abi.as_points(c) for c in frame_down]
+    m_arr, f_arr = (abi.Cloud * 6)(), (abi.Cloud * 6)()
+    out_m = [np.zeros(len(mc[c]) + len(fc[c]), abi.POINT_DTYPE) for c in range(6)]
+    out_f = [np.zeros(len(fc[c]), abi.POINT_DTYPE) for c in range(6)]
+    pm, pf = (C.c_void_p * 6)(), (C.c_void_p * 6)()
+    for c in range(6):
+        m_arr[c], f_arr[c] = abi.as_cloud(mc[c]), abi.as_cloud(fc[c])
+        pm[c] = out_m[c].ctypes.data if len(out_m[c]) else None
+        pf[c] = out_f[c].ctypes.data if len(out_f[c]) else None
+    nm, nf = (C.c_uint32 * 6)(), (C.c_uint32 * 6)()
+    rep = abi.MapReport()
+    if fn is None:
+        fn = lib().mulls_oracle_map_update
+    fn.restype = C.c_int
+    rc = fn(m_arr, abi.colmajor16(map_pose), f_arr, abi.colmajor16(frame_pose), C.byref(params), pm, nm, pf, nf, C.byref(rep))
+    if rc != 0:
+        raise RuntimeError("oracle map_update returned %d" % rc)
+    return [out_m[c][: nm[c]].copy() for c in range(6)], [out_f[c][: nf[c]].copy() for c in range(6)], rep

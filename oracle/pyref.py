@@ -53,3 +53,10 @@ def icp_4dof_global(pair, heading_step_d, station, max_iter_num=20, dis_thre_uni
     if rc != 0:
         raise RuntimeError("reference returned %d" % rc)
     return res, bool(ok.value)
+
+
+def map_update(map_clouds, map_pose, frame_down, frame_pose, params):
+    """MapManager::update_local_map, the reference's own lines (src/map_manager.cpp:18-256)."""
+    from oracle import pyoracle
+
+    return pyoracle.map_update(map_clouds, map_pose, frame_down, frame_pose, params, fn=lib().mulls_ref_map_update)

@@ -43,6 +43,11 @@ class CRegistration : public CloudUtility<PointT>
   public:
 #include "creg_body.inc"
 };
+
+#include "map_decl.inc" // class MapManager { ... };
+#include "map_body.inc" // MapManager::update_local_map, ::map_based_dynamic_close_removal, ::map_scan_feature_pts_distance_removal
+// the PCA refresh of the linear features belongs to feature extraction (pca.hpp); never reached: recalculate_feature_on = false
+bool MapManager::update_cloud_vectors(pcTPtr, const pcTreePtr, float, int, int, float, float, float) { std::abort(); }
 } // namespace lo
 
 namespace
@@ -151,5 +156,74 @@ extern "C" int mulls_ref_icp(const mulls_pair *pair, const mulls_params *P, mull
 	R->sigma = con.sigma;
 	R->confidence = con.confidence;
 	R->trace_len = 0;
+	return 0;
+}
+
+
+// MapManager::update_local_map on plain clouds (same signature as mulls_oracle_map_update).  block1->tree_* are
+// prepared the way mm_lls_icp leaves them (cregistration.hpp:1209-1232): whole class clouds or their bbx_filter'ed clones.
+extern "C" int mulls_ref_map_update(const mulls_cloud map_in[6], const double map_pose[16], const mulls_cloud frame_down[6],
+									 const double frame_pose[16], const mulls_map_params *P, void *const map_out[6], uint32_t map_out_n[6],
+									 void *const frame_out[6], uint32_t frame_out_n[6], mulls_map_report *rep)
+{
+	lo::cloudblock_Ptr map(new lo::cloudblock_t()), frame(new lo::cloudblock_t());
+	pcTPtr *mc[6] = {&map->pc_ground, &map->pc_pillar, &map->pc_facade, &map->pc_beam, &map->pc_roof, &map->pc_vertex};
+	pcTPtr *fc[6] = {&frame->pc_ground_down, &frame->pc_pillar_down, &frame->pc_facade_down, &frame->pc_beam_down, &frame->pc_roof_down,
+					 &frame->pc_vertex};
+	pcTreePtr *trees[6] = {&map->tree_ground, &map->tree_pillar, &map->tree_facade, &map->tree_beam, &map->tree_roof, &map->tree_vertex};
+	for (int c = 0; c < 6; c++)
+	{
+		fill_cloud(map_in[c], *mc[c]);
+		fill_cloud(frame_down[c], *fc[c]);
+	}
+	std::memcpy(map->pose_lo.data(), map_pose, sizeof(double) * 16);
+	std::memcpy(frame->pose_lo.data(), frame_pose, sizeof(double) * 16);
+	map->feature_point_num = (int)(map->pc_ground->points.size() + map->pc_facade->points.size() + map->pc_roof->points.size() +
+								   map->pc_pillar->points.size() + map->pc_beam->points.size());
+	bool trees_ready = P->tree_mode != 0;
+	lo::CFilter<Point_T> cf;
+	for (int c = 0; c < 6 && trees_ready; c++)
+		if (P->tree_used[c] == '1')
+		{
+			pcTPtr clone(new pcT());
+			clone->points = (*mc[c])->points;
+			if (P->tree_mode == 2)
+			{
+				lo::bounds_t b;
+				b.min_x = P->tree_box[0], b.min_y = P->tree_box[1], b.min_z = P->tree_box[2];
+				b.max_x = P->tree_box[3], b.max_y = P->tree_box[4], b.max_z = P->tree_box[5];
+				cf.bbx_filter(clone, b);
+			}
+			if (clone->points.size() > 0)
+				(*trees[c])->setInputCloud(clone);
+		}
+	// an empty kd-tree makes nearestKSearch undefined upstream (the restatement defines "leave the cloud alone"): this
+	// entry point refuses configurations in which a class the removal visits has no tree
+	const bool removal = P->map_based_dynamic_removal_on && trees_ready;
+	if (removal)
+		for (int c : {1, 2, 3})
+			if (P->used_feature_type[c] == '1' && !(*trees[c])->cloud && (*fc[c])->points.size() > 10)
+				return -1;
+	lo::MapManager mm;
+	rep->dynamic_removal_ran = (removal && map->feature_point_num > P->max_num_pts / 5) ? 1 : 0;
+	mm.update_local_map(map, frame, P->local_map_radius, P->max_num_pts, P->kept_vertex_num, P->last_frame_reliable_radius, removal,
+						std::string(P->used_feature_type, 6), P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, P->dynamic_dist_thre_max,
+						P->near_dist_thre, false);
+	for (int c = 0; c < 6; c++)
+	{
+		map_out_n[c] = (uint32_t)(*mc[c])->points.size();
+		frame_out_n[c] = (uint32_t)(*fc[c])->points.size();
+		rep->n[c] = map_out_n[c];
+		rep->frame_n[c] = frame_out_n[c];
+		if (map_out && map_out[c])
+			std::memcpy(map_out[c], (*mc[c])->points.data(), sizeof(Point_T) * map_out_n[c]);
+		if (frame_out && frame_out[c])
+			std::memcpy(frame_out[c], (*fc[c])->points.data(), sizeof(Point_T) * frame_out_n[c]);
+	}
+	rep->feature_point_num = map->feature_point_num;
+	rep->local_bound[0] = map->local_bound.min_x, rep->local_bound[1] = map->local_bound.min_y, rep->local_bound[2] = map->local_bound.min_z;
+	rep->local_bound[3] = map->local_bound.max_x, rep->local_bound[4] = map->local_bound.max_y, rep->local_bound[5] = map->local_bound.max_z;
+	rep->bound[0] = map->bound.min_x, rep->bound[1] = map->bound.min_y, rep->bound[2] = map->bound.min_z;
+	rep->bound[3] = map->bound.max_x, rep->bound[4] = map->bound.max_y, rep->bound[5] = map->bound.max_z;
 	return 0;
 }

@@ -594,6 +594,22 @@ void transformPointCloudWithNormals(const PointCloud<PointT> &in, PointCloud<Poi
 	}
 }
 
+// transformPointCloud<PointT, double>(in, out, T): positions only
+template <typename PointT>
+void transformPointCloud(const PointCloud<PointT> &in, PointCloud<PointT> &out, const Eigen::Matrix4d &tf)
+{
+	if (&in != &out)
+		out.points = in.points;
+	for (size_t i = 0; i < out.points.size(); i++)
+	{
+		PointT &p = out.points[i];
+		double x = p.x, y = p.y, z = p.z;
+		p.x = static_cast<float>(tf(0, 0) * x + tf(0, 1) * y + tf(0, 2) * z + tf(0, 3));
+		p.y = static_cast<float>(tf(1, 0) * x + tf(1, 1) * y + tf(1, 2) * z + tf(1, 3));
+		p.z = static_cast<float>(tf(2, 0) * x + tf(2, 1) * y + tf(2, 2) * z + tf(2, 3));
+	}
+}
+
 // pcl::RandomSample (selection sampling driven by rand()); the reference seeds it with time(NULL), this stand-in
 // with a fixed seed — results of keep_less_source_points are not reproducible upstream either (SURVEY B-13)
 template <typename PointT>

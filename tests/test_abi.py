@@ -50,6 +50,8 @@ def test_ctypes_layout_matches_header():
         "mulls_iter_trace": (abi.IterTrace, [f[0] for f in abi.IterTrace._fields_]),
         "mulls_result": (abi.Result, [f[0] for f in abi.Result._fields_]),
         "mulls_profile": (abi.Profile, [f[0] for f in abi.Profile._fields_]),
+        "mulls_map_params": (abi.MapParams, [f[0] for f in abi.MapParams._fields_]),
+        "mulls_map_report": (abi.MapReport, [f[0] for f in abi.MapReport._fields_]),
     }
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "mulls_hip.h"', "int main(void){"]
     for cname, (_, names) in fields.items():

@@ -67,3 +67,19 @@ def test_adapter_variants_match_reference_members(pairs_small):
         assert dt <= 1e-7 and dr <= 1e-7, (v, dt, dr)
         if v == "4dof" and ref["code"]:
             assert abs(ref["sigma"] - hip["sigma"]) <= 1e-6 and ref["confidence"] == hip["confidence"]
+
+
+def test_adapter_local_map_matches_reference_map_manager(pairs_small):
+    """Scan-to-map step: mm_lls_icp against the local map, then MapManager::update_local_map with map-based dynamic removal —
+    the reference class with the kd-trees its registration left on block1, the bridge with the device-resident mirror."""
+    for pair, _ in pairs_small[:2]:
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "pair.bin")
+            dump(pair, path)
+            out = subprocess.check_output([BIN, path, "map"], timeout=300).decode().strip().split("\n")
+        rows = {json.loads(l)["who"]: json.loads(l) for l in out}
+        ref, hip = rows["reference_map"], rows["hip_map"]
+        assert ref["code"] == hip["code"] == 1
+        for key in ("n", "frame_n", "hash", "frame_hash", "feature_point_num", "local_bound", "bound"):
+            assert ref[key] == hip[key], key
+        assert sum(ref["frame_n"]) < sum(len(pair.src[c]) for c in range(5))  # the removal filtered something

@@ -1,0 +1,127 @@
+"""Local map: MapManager::update_local_map / map-based dynamic removal.
+
+CPU part: the oracle restatement against the reference's own lines (oracle/_ref, built from src/map_manager.cpp where
+/root/reference exists) and against properties that hold by construction.  GPU part (tests/test_gpu_map.py) compares the
+device-resident map with the oracle."""
+import numpy as np
+import pytest
+
+from mulls_amd import abi, synth
+from oracle import pyoracle, pyref
+
+
+def small_frames(seed, n_frames=3):
+    """A short synthetic drive: per frame the six class clouds (as pc_*_down + pc_vertex) and the pose_lo."""
+    frames = []
+    pose = np.eye(4)
+    for k in range(n_frames):
+        src = {abi.GROUND: 500, abi.PILLAR: 200, abi.FACADE: 600, abi.BEAM: 120, abi.ROOF: 60}
+        pair, T_gt = synth.make_pair(seed + k, n_beams=32, n_az=700, src_counts=src, tgt_counts=src, vertex_count=150)
+        frames.append(([pair.src[c] for c in range(6)], pose.copy()))
+        pose = pose @ np.linalg.inv(T_gt)
+    return frames
+
+
+def same_cloud(a, b):
+    assert len(a) == len(b)
+    for f in abi.POINT_DTYPE.names:
+        if f.startswith("pad"):
+            continue
+        assert np.array_equal(a[f], b[f], equal_nan=True), f
+
+
+def run_sequence(update, params_of, frames):
+    clouds, pose = [c.copy() for c in frames[0][0]], frames[0][1]
+    reports = []
+    for k, (fc, fp) in enumerate(frames[1:], 1):
+        clouds, appended, rep = update(clouds, pose, fc, fp, params_of(k))
+        pose = fp
+        reports.append((appended, rep))
+    return clouds, reports
+
+
+needs_ref = pytest.mark.skipif(not pyref.available(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+@needs_ref
+@pytest.mark.parametrize("used", ["111110", "101000", "111111"])
+def test_oracle_equals_reference_lines_without_thinning(used):
+    """No cloud exceeds its share of max_num_pts, so pcl::RandomSample (unseeded upstream) never runs: bit-identical maps."""
+    frames = small_frames(40)
+    P = lambda k: abi.map_params(used_feature_type=used, max_num_pts=10**7, kept_vertex_num=10**6, local_map_radius=45.0)
+    mo, ro = run_sequence(pyoracle.map_update, P, frames)
+    mr, rr = run_sequence(pyref.map_update, P, frames)
+    for c in range(6):
+        same_cloud(mo[c], mr[c])
+    for (ao, po), (ar, pr) in zip(ro, rr):
+        assert list(po.n) == list(pr.n) and list(po.frame_n) == list(pr.frame_n) and po.feature_point_num == pr.feature_point_num
+        assert list(po.local_bound) == list(pr.local_bound) and list(po.bound) == list(pr.bound)
+        for c in range(6):
+            same_cloud(ao[c], ar[c])
+
+
+@needs_ref
+@pytest.mark.parametrize("tree_mode", [1, 2])
+def test_oracle_equals_reference_lines_with_dynamic_removal(tree_mode):
+    frames = small_frames(50)
+    box = [-28.0, -14.0, -3.0, 30.0, 14.0, 8.0]
+
+    def P(k):
+        # removal needs feature_point_num > max_num_pts / 5; no class outgrows its share of 6000 within three frames
+        return abi.map_params(max_num_pts=6000, kept_vertex_num=10**6, map_based_dynamic_removal_on=1, dynamic_removal_center_radius=25.0,
+                              dynamic_dist_thre_min=0.25, dynamic_dist_thre_max=1.0, near_dist_thre=0.05, tree_mode=tree_mode,
+                              tree_used="111110", tree_box=box)
+
+    mo, ro = run_sequence(pyoracle.map_update, P, frames)
+    mr, rr = run_sequence(pyref.map_update, P, frames)
+    assert all(rep.dynamic_removal_ran == 1 for _, rep in ro)
+    removed = 0
+    for (ao, po), (ar, pr), (fc, _) in zip(ro, rr, frames[1:]):
+        assert list(po.frame_n) == list(pr.frame_n)
+        removed += sum(len(fc[c]) - po.frame_n[c] for c in (1, 2, 3))
+        for c in range(6):
+            same_cloud(ao[c], ar[c])
+    assert removed > 0  # the rule did filter something
+    for c in range(6):
+        same_cloud(mo[c], mr[c])
+
+
+@needs_ref
+def test_thinning_sizes_match_reference_lines():
+    """With thinning the kept COUNTS are the reference's (the selection itself is seeded by time(NULL) upstream)."""
+    frames = small_frames(60)
+    P = lambda k: abi.map_params(max_num_pts=900, kept_vertex_num=100)
+    mo, ro = run_sequence(pyoracle.map_update, P, frames[:2])
+    mr, rr = run_sequence(pyref.map_update, P, frames[:2])
+    assert list(ro[0][1].n) == list(rr[0][1].n)
+    assert ro[0][1].n[5] == 100 and ro[0][1].feature_point_num <= 900 + 5
+
+
+def test_oracle_properties():
+    frames = small_frames(70)
+    P = abi.map_params(max_num_pts=1500, kept_vertex_num=120, local_map_radius=30.0, rng_seed=7)
+    m0 = [c.copy() for c in frames[0][0]]
+    m1, app, rep = pyoracle.map_update(m0, frames[0][1], frames[1][0], frames[1][1], P)
+    # inputs untouched, report consistent with the clouds
+    for c in range(6):
+        same_cloud(m0[c], frames[0][0][c])
+        assert rep.n[c] == len(m1[c])
+        assert np.all(m1[c]["x"].astype(np.float32) ** 2 + m1[c]["y"].astype(np.float32) ** 2 < 30.0 ** 2)
+    assert rep.feature_point_num == sum(len(m1[c]) for c in range(5))
+    allp = np.concatenate([m1[c] for c in range(6)])
+    assert list(rep.local_bound) == [float(allp[k].min()) for k in "xyz"] + [float(allp[k].max()) for k in "xyz"]
+    # seeded thinning: same seed -> same map, other seed -> same sizes
+    m1b, _, _ = pyoracle.map_update(m0, frames[0][1], frames[1][0], frames[1][1], P)
+    for c in range(6):
+        same_cloud(m1[c], m1b[c])
+    m1c, _, repc = pyoracle.map_update(m0, frames[0][1], frames[1][0], frames[1][1], abi.map_params(max_num_pts=1500, kept_vertex_num=120,
+                                                                                                    local_map_radius=30.0, rng_seed=8))
+    assert list(repc.n) == list(rep.n)
+    # the vertex cloud is appended untransformed and then moved with the map (upstream quirk, map_manager.cpp:32/57)
+    Pq = abi.map_params(max_num_pts=10**7, kept_vertex_num=10**6, local_map_radius=1e6, used_feature_type="000000")
+    mq, _, _ = pyoracle.map_update([None] * 6, frames[0][1], frames[1][0], frames[1][1], Pq)
+    T = np.linalg.inv(frames[1][1]) @ frames[0][1]
+    v = frames[1][0][5]
+    expect = pyoracle.transform(v, T)
+    same_cloud(mq[5], expect)
+    assert all(len(mq[c]) == 0 for c in range(5))
