@@ -12,9 +12,10 @@
 #define MULLS_NN_PTS 4		  // ... x 4 register-blocked source points per lane = the same 512 points per job
 #define MULLS_TILE 2048		  // target points staged per LDS tile (3 planar float arrays -> 24 KiB)
 
-#define MULLS_MAXCELLS 65536u // default cell budget of one target-class grid (256 KiB per cloud); grows with the cloud, see driver.cpp
-#define MULLS_MAXCELLS_CAP (1u << 22)
-#define MULLS_MAXROWS 4096u   // (cy,cz) rows of one grid
+#define MULLS_MAXCELLS 65536u // most cells of one LDS-tier target grid (what fits next to the points decides, see driver.cpp)
+#define MULLS_BM_MAXWORDS (1u << 22) // global-memory tier: most 64-cell occupancy words of one grid (268 M cells)
+#define MULLS_BM_TOTALWORDS (1u << 28) // ... and of all grids of a batch together (2 GiB of bitmap + 1 GiB of ranks)
+#define MULLS_BM_H0 0.25f // ... smallest cell edge in metres (dense maps); sparse clouds start from their mean point spacing, up to 0.7 m
 #define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
 #define MULLS_LDS_MAXPTS 10240u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
@@ -57,9 +58,10 @@ struct GridDesc
 	float ox, oy, oz; // origin = minimum corner of the cloud
 	float inv_h, h;
 	uint32_t nx, ny, nz;
-	uint32_t ncell;
-	uint32_t cell_off; // first entry of this cloud in the batch-wide cell tables (ncell + 1 entries are used)
-	uint32_t pad_[2];
+	uint32_t ncell;	   // LDS tier: number of cells.  Global-memory tier: number of 64-cell occupancy words (= ny * nz * wpr)
+	uint32_t cell_off; // first entry of this cloud in the batch-wide cell table (LDS tier: ncell + 1 entries) / bitmap + rank arrays
+	uint32_t wpr;	   // global-memory tier: occupancy words per (cy,cz) row = ceil(nx / 64); bit = ((cz*ny + cy)*wpr)*64 + cx
+	uint32_t nocc;	   // global-memory tier: occupied cells (k_bm_scan)
 };
 
 // Per-pair state rewritten by the host before every lock-step iteration (one H2D copy for the whole batch).
@@ -117,12 +119,13 @@ struct RunParams
 	float z_xy_ratio;
 	float win_pt, win_pl, win_li;
 	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule
-	uint8_t pad_[1];
+	uint8_t bm_auto; // global-memory tier: cell edge = clamp(sqrt(dx * dy / n), bm_h0, 2.8 * bm_h0) per cloud instead of bm_h0
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
 	int32_t resid_from_iter; // residual weighting applies when iter_num > this (2 for mm_lls_icp, cregistration.hpp:1905-1907; -1 for the 3-DoF variant)
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging
 	uint32_t cell_stride;	// entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned), >= grid_maxcells + 1
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
+	float bm_h0;		// > 0: global-memory tier — k_crop sizes occupancy-bitmap grids from this cell edge (grid_maxcells = word budget)
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

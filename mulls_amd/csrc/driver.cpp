@@ -63,7 +63,10 @@ struct mulls_batch
 	Job *cjobs = nullptr;
 	GridDesc *grids = nullptr;
 	float4 *tsorted = nullptr;
-	uint32_t *cell_cnt = nullptr, *cell_start = nullptr;
+	uint32_t *cell_cnt = nullptr, *cell_start = nullptr; // global tier: per-occupied-cell counters / start positions; LDS tier: dense cell table
+	unsigned long long *bm = nullptr;					  // global tier: occupancy words of every grid
+	uint32_t *pf = nullptr;								  // global tier: occupied cells before each word
+	size_t cap_bm = 0, cap_pf = 0;
 	// pinned, device-mapped host memory (zero-copy): per-iteration pair states in, per-pair sums out, completion epoch
 	PairState *states_h = nullptr;
 	PairOut *outs_h = nullptr;
@@ -540,9 +543,36 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	}
 	*lds_cap_out = lds_cap;
 	*tier_out = tier;
-	// global-memory tier: about four cells per target point of the largest searched cloud, so dense clouds get finer cells
-	rp.grid_maxcells = tier == 2 ? lds_cells_for(lds_cap) : std::min<uint32_t>(MULLS_MAXCELLS_CAP, std::max<uint32_t>(MULLS_MAXCELLS, 4u * lds_cap));
-	rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+	int n_used = 0;
+	for (int c = 0; c < MULLS_NC; c++)
+		n_used += rp.used[c];
+	rp.bm_h0 = 0.0f;
+	if (tier == 2)
+	{
+		rp.grid_maxcells = lds_cells_for(lds_cap);
+		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+	}
+	else if (tier == 1)
+	{
+		// occupancy-bitmap grids: grid_maxcells / cell_stride count 64-cell words per cloud
+		rp.bm_h0 = MULLS_BM_H0;
+		rp.bm_auto = 1;
+		if (const char *e = std::getenv("MULLS_BM_H0")) // diagnostics: one fixed cell edge for every cloud
+		{
+			rp.bm_h0 = std::max(0.05f, (float)std::atof(e));
+			rp.bm_auto = 0;
+		}
+		const size_t clouds = std::max<size_t>((size_t)n * std::max(n_used, 1), 1);
+		size_t words = std::min<size_t>(MULLS_BM_MAXWORDS, MULLS_BM_TOTALWORDS / clouds);
+		words = std::max<size_t>(words & ~(size_t)15, 4096);
+		rp.grid_maxcells = (uint32_t)words;
+		rp.cell_stride = (uint32_t)words;
+	}
+	else
+	{
+		rp.grid_maxcells = MULLS_MAXCELLS;
+		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+	}
 
 	bool grew = false, g2 = false;
 	int rc = MULLS_OK;
@@ -558,18 +588,19 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	grew |= g2;
 	A(grow(ctx, &B->bbox_init, &B->cap_jobs[5], (size_t)n * 6, &g2));
 	grew |= g2;
-	if (tier != 0)
+	if (tier == 2)
+		A(grow(ctx, &B->cell_start, &B->cap_cells[1], (size_t)n * n_used * rp.cell_stride));
+	else if (tier == 1)
 	{
-		int n_used = 0;
-		for (int c = 0; c < MULLS_NC; c++)
-			n_used += rp.used[c];
-		const size_t cells = (size_t)n * n_used * rp.cell_stride;
+		const size_t words = (size_t)n * n_used * rp.cell_stride, cells = B->n_tgt + (size_t)n * MULLS_NC + 1;
+		A(grow(ctx, &B->bm, &B->cap_bm, words));
+		A(grow(ctx, &B->pf, &B->cap_pf, words));
 		A(grow(ctx, &B->cell_start, &B->cap_cells[1], cells));
-		if (tier == 1) // the LDS tier builds its grids by sorting (k_grid_build_sort): no histogram
+		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
+		if (rc == MULLS_OK)
 		{
-			A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
-			if (rc == MULLS_OK)
-				HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, std::max<size_t>(cells, 1) * sizeof(uint32_t), st));
+			HIPCHK(ctx, hipMemsetAsync(B->bm, 0, std::max<size_t>(words, 1) * sizeof(unsigned long long), st));
+			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, cells * sizeof(uint32_t), st));
 		}
 	}
 	if (rc != MULLS_OK)
@@ -723,7 +754,7 @@ extern "C"
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
-					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->descs_init, B->bbox_init};
+					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
 		for (void *p : dev)
 			if (p)
 				(void)hipFree(p);
@@ -847,7 +878,7 @@ extern "C"
 			}
 		}
 		if (use_grid)
-			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
+			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
 							  B->tsorted, tier == 2);
 		evt.end();
 
@@ -987,7 +1018,7 @@ extern "C"
 					}
 				}
 				else if (tier == 1)
-					launch_nn_grid(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx,
+					launch_nn_grid(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
 								   B->nn_d2, B->winner);
 				else
 					launch_nn(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
@@ -1290,7 +1321,7 @@ extern "C"
 			}
 		}
 		if (tier != 0)
-			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->cell_cnt, B->cell_start,
+			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
 							  B->tsorted, tier == 2);
 
 		struct H3
@@ -1340,7 +1371,7 @@ extern "C"
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
-				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
@@ -1606,8 +1637,8 @@ extern "C"
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
 					B->wd, *rp, B->grids);
 		if (tier != 0)
-			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->cell_cnt, B->cell_start, B->tsorted,
-							  tier == 2);
+			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
+							  B->tsorted, tier == 2);
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)
@@ -1646,7 +1677,7 @@ extern "C"
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 							  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
-				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
 			else if (tier < 0)
 				rc = MULLS_E_INVALID;

@@ -282,7 +282,29 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			g.h = MULLS_GRID_H0;
 			g.nx = g.ny = g.nz = 1;
 			g.ncell = 0;
-			if (running > 0)
+			g.wpr = 1;
+			g.nocc = 0;
+			uint32_t nwords = 1;
+			if (running > 0 && rp.bm_h0 > 0.0f)
+			{
+				// global-memory tier: occupancy bitmap over fine cells; rows are padded to whole 64-cell words
+				g.h = rp.bm_h0;
+				if (rp.bm_auto) // points lie on surfaces: mean spacing ~ sqrt(footprint / count); measured optimum 0.25 m (1 M points) .. 0.7 m (5 k)
+					g.h = fminf(fmaxf(sqrtf((hi3[0] - lo3[0]) * (hi3[1] - lo3[1]) / (float)running), rp.bm_h0), 2.8f * rp.bm_h0);
+				for (;;)
+				{
+					g.inv_h = 1.0f / g.h;
+					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
+					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
+					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+					g.wpr = (g.nx + 63u) >> 6;
+					if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
+						break;
+					g.h *= 1.25f;
+				}
+				nwords = g.ny * g.nz * g.wpr;
+			}
+			else if (running > 0)
 				for (;;)
 				{
 					g.inv_h = 1.0f / g.h;
@@ -290,8 +312,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
 					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
 					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
-					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells &&
-						(unsigned long long)g.ny * g.nz <= (unsigned long long)MULLS_MAXROWS)
+					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
 						break;
 					g.h *= 1.25f;
 				}
@@ -305,9 +326,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 					rank++;
 				n_used += rp.used[c] ? 1u : 0u;
 			}
-			g.ncell = (running > 0 && rp.used[cls]) ? g.nx * g.ny * g.nz : 0u;
+			g.ncell = (running > 0 && rp.used[cls]) ? (rp.bm_h0 > 0.0f ? nwords : g.nx * g.ny * g.nz) : 0u;
 			g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
-			g.pad_[0] = g.pad_[1] = 0;
 			grids[pair * MULLS_NC + cls] = g;
 		}
 	}
@@ -564,10 +584,32 @@ __device__ __forceinline__ uint32_t grid_cell_id(const GridDesc &g, float x, flo
 }
 // Evaluate every target in the cells intersecting the cube [p - R, p + R].  The MULLS_GRID_GROUP (= 16) lanes of a
 // sub-group share one query.  Rows (fixed cy,cz; cells x0..x1 are one contiguous range of the cell-sorted array) are
-// taken 16 at a time: lane j fetches the bounds of row j (16 rows per memory latency), then every lane issues its
+// taken 16 at a time: lane j fetches the bounds of row j (occupancy words and ranks, then — only for rows that hold points —
+// the two start positions: 16 rows per two memory latencies), then every lane issues its
 // first candidate load of 8 rows back to back (coalesced 256-B segments), and only rows holding more than 16
 // candidates loop further.  Chunks whose 16 rows are all empty cost one latency and no candidate work.
-__device__ __forceinline__ void grid_scan_box(const GridDesc &g, const uint32_t *__restrict__ cstart, const float4 *__restrict__ ts,
+struct BmGrid
+{
+	const unsigned long long *bm; // [nw] occupancy words of this cloud
+	const uint32_t *pf;			  // [nw] occupied cells before each word
+	const uint32_t *cs;			  // [nocc + 1] first sorted position of every occupied cell
+};
+// sorted candidates [lo, hi) of cells xa..xb of the row whose first word is `rowword` (cells of a row are consecutive in the
+// cell-sorted order, occupied or not): ranks of the first and one-past-last occupied cell, then their start positions
+__device__ __forceinline__ void bm_row_range(const BmGrid &B, uint32_t rowword, uint32_t xa, uint32_t xb, uint32_t &lo, uint32_t &hi)
+{
+	const uint32_t wa = rowword + (xa >> 6), wb = rowword + (xb >> 6);
+	const unsigned long long A = B.bm[wa], Z = B.bm[wb];
+	const uint32_t r0 = B.pf[wa] + (uint32_t)__popcll(A & ((1ull << (xa & 63u)) - 1ull));
+	const uint32_t r1 = B.pf[wb] + (uint32_t)__popcll(Z & (~0ull >> (63u - (xb & 63u))));
+	lo = hi = 0;
+	if (r1 > r0)
+	{
+		lo = B.cs[r0];
+		hi = B.cs[r1];
+	}
+}
+__device__ __forceinline__ void grid_scan_box(const GridDesc &g, const BmGrid &B, const float4 *__restrict__ ts,
 											   float px, float py, float pz, float R, uint32_t sub, float &best, int &bi)
 {
 	const float Rm = R * 1.0001f + 1e-4f;
@@ -582,9 +624,8 @@ __device__ __forceinline__ void grid_scan_box(const GridDesc &g, const uint32_t 
 		uint32_t lo = 0, hi = 0;
 		if (j < nrows)
 		{
-			const uint32_t row = ((uint32_t)(z0 + j / nyc) * g.ny + (uint32_t)(y0 + j % nyc)) * g.nx;
-			lo = cstart[row + (uint32_t)x0];
-			hi = cstart[row + (uint32_t)x1 + 1u];
+			const uint32_t rowword = ((uint32_t)(z0 + j / nyc) * g.ny + (uint32_t)(y0 + j % nyc)) * g.wpr;
+			bm_row_range(B, rowword, (uint32_t)x0, (uint32_t)x1, lo, hi);
 		}
 		const uint32_t nonempty = (uint32_t)(__ballot(hi > lo) >> gshift) & 0xffffu; // per sub-group: which of its 16 rows hold points
 		if (!nonempty)
@@ -666,10 +707,28 @@ __device__ __forceinline__ void group_min(float &best, int &bi)
 }
 } // namespace
 
-// histogram of target points per grid cell (one 256-point chunk of one target cloud per workgroup)
-__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_count(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
-															 const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
-															 uint32_t *__restrict__ cell_cnt)
+// Global-memory tier grid build (clouds too large for LDS).  Fine cells make a dense cell table impossible (a 1 M-point
+// map at 0.35 m cells spans ~50 M cells, of which <1 % hold points), so the grid is an occupancy bitmap + ranks:
+//   bm  one bit per cell, 64 cells of a row per word          k_bm_mark   (atomicOr per point)
+//   pf  per word: occupied cells before it                    k_bm_scan   (one workgroup per cloud)
+//   cs  per occupied cell: first sorted position (+ end)      k_bm_count -> k_bm_starts -> k_bm_scatter (counting sort by rank)
+// cs / cnt are indexed from cs_off = tgt_off + cloud index (every cloud needs tgt_n + 1 entries).
+namespace
+{
+__device__ __forceinline__ uint32_t bm_bit(const GridDesc &g, float x, float y, float z)
+{
+	const uint32_t row = (uint32_t)grid_cell(z, g.oz, g.inv_h, g.nz) * g.ny + (uint32_t)grid_cell(y, g.oy, g.inv_h, g.ny);
+	return row * (g.wpr * 64u) + (uint32_t)grid_cell(x, g.ox, g.inv_h, g.nx);
+}
+__device__ __forceinline__ uint32_t bm_rank(const unsigned long long *bm, const uint32_t *pf, uint32_t bit)
+{
+	return pf[bit >> 6] + (uint32_t)__popcll(bm[bit >> 6] & ((1ull << (bit & 63u)) - 1ull));
+}
+} // namespace
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+														  const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
+														  unsigned long long *__restrict__ bm)
 {
 	const Job job = tjobs[blockIdx.x];
 	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
@@ -678,29 +737,24 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_count(const Job *__restric
 		return;
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	const float4 p = tpos[d.tgt_off + t];
-	atomicAdd(&cell_cnt[g.cell_off + grid_cell_id(g, p.x, p.y, p.z)], 1u);
+	const uint32_t bit = bm_bit(g, p.x, p.y, p.z);
+	atomicOr(&bm[g.cell_off + (bit >> 6)], 1ull << (bit & 63u));
 }
 
-// exclusive scan of one cloud's cell histogram (one workgroup per (pair, class)); leaves the counters zeroed so that
-// k_grid_scatter can reuse them as insertion cursors
-__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scan(const GridDesc *__restrict__ grids, RunParams rp,
-															uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ cell_start)
+// exclusive scan of a uint32 sequence produced by `value(i)`, one 1024-lane workgroup, four items per lane and trip
+template <typename F, typename G>
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t n, F value, G store)
 {
-	__shared__ uint32_t wave_tot[4];
-	const uint32_t cls = blockIdx.x % MULLS_NC;
-	if (!rp.used[cls])
-		return;
-	const GridDesc g = grids[blockIdx.x];
+	__shared__ uint32_t wave_tot[16];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t running = 0;
-	for (uint32_t base = 0; base < g.ncell; base += MULLS_BLOCK * 4)
+	for (uint32_t base = 0; base < n; base += 4096u)
 	{
-		// four consecutive cells per lane
-		const uint32_t c0 = base + threadIdx.x * 4;
+		const uint32_t i0 = base + threadIdx.x * 4u;
 		uint32_t v[4], sum = 0;
 		for (int k = 0; k < 4; k++)
 		{
-			v[k] = (c0 + k < g.ncell) ? cell_cnt[g.cell_off + c0 + k] : 0u;
+			v[k] = (i0 + k < n) ? value(i0 + k) : 0u;
 			sum += v[k];
 		}
 		uint32_t incl = sum;
@@ -715,7 +769,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scan(const GridDesc *__res
 			wave_tot[wave] = incl;
 		__syncthreads();
 		uint32_t wbase = 0, total = 0;
-		for (int w = 0; w < 4; w++)
+		for (int w = 0; w < 16; w++)
 		{
 			if (w < wave)
 				wbase += wave_tot[w];
@@ -723,33 +777,83 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scan(const GridDesc *__res
 		}
 		uint32_t ex = running + wbase + incl - sum;
 		for (int k = 0; k < 4; k++)
-			if (c0 + k < g.ncell)
+			if (i0 + k < n)
 			{
-				cell_start[g.cell_off + c0 + k] = ex;
-				cell_cnt[g.cell_off + c0 + k] = 0u;
+				store(i0 + k, ex);
 				ex += v[k];
 			}
 		running += total;
 	}
-	if (threadIdx.x == 0)
-		cell_start[g.cell_off + g.ncell] = running;
+	return running;
 }
 
-// counting-sort scatter: target positions ordered by cell, original index carried in .w
-__global__ __launch_bounds__(MULLS_BLOCK) void k_grid_scatter(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
-															   const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
-															   uint32_t *__restrict__ cell_cnt, const uint32_t *__restrict__ cell_start,
-															   float4 *__restrict__ tsorted)
+__global__ __launch_bounds__(1024) void k_bm_scan(GridDesc *__restrict__ grids, RunParams rp, const unsigned long long *__restrict__ bm,
+												  uint32_t *__restrict__ pf)
+{
+	const uint32_t cls = blockIdx.x % MULLS_NC;
+	if (!rp.used[cls])
+		return;
+	const GridDesc g = grids[blockIdx.x];
+	const unsigned long long *b = bm + g.cell_off;
+	uint32_t *p = pf + g.cell_off;
+	const uint32_t nocc = block_scan_1024(
+		g.ncell, [&](uint32_t w) { return (uint32_t)__popcll(b[w]); }, [&](uint32_t w, uint32_t ex) { p[w] = ex; });
+	if (threadIdx.x == 0)
+		grids[blockIdx.x].nocc = nocc;
+}
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+														   const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
+														   const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
+														   uint32_t *__restrict__ cnt)
 {
 	const Job job = tjobs[blockIdx.x];
-	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t ci = job.pair * MULLS_NC + job.cls;
+	const CloudDesc &d = descs[ci];
 	const uint32_t t = job.start + threadIdx.x;
 	if (t >= d.tgt_n)
 		return;
-	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+	const GridDesc g = grids[ci];
 	const float4 p = tpos[d.tgt_off + t];
-	const uint32_t cell = g.cell_off + grid_cell_id(g, p.x, p.y, p.z);
-	const uint32_t slot = cell_start[cell] + atomicAdd(&cell_cnt[cell], 1u);
+	atomicAdd(&cnt[d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z))], 1u);
+}
+
+// counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors
+__global__ __launch_bounds__(1024) void k_bm_starts(const CloudDesc *__restrict__ descs, const GridDesc *__restrict__ grids, RunParams rp,
+													uint32_t *__restrict__ cnt, uint32_t *__restrict__ cs)
+{
+	const uint32_t cls = blockIdx.x % MULLS_NC;
+	if (!rp.used[cls])
+		return;
+	const GridDesc g = grids[blockIdx.x];
+	const uint32_t off = descs[blockIdx.x].tgt_off + blockIdx.x;
+	uint32_t *c = cnt + off, *s = cs + off;
+	const uint32_t total = block_scan_1024(
+		g.nocc, [&](uint32_t r) { return c[r]; },
+		[&](uint32_t r, uint32_t ex) {
+			s[r] = ex;
+			c[r] = 0u;
+		});
+	if (threadIdx.x == 0)
+		s[g.nocc] = total;
+}
+
+// counting-sort scatter: target positions ordered by cell, original index carried in .w
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+															 const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
+															 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
+															 uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cs, float4 *__restrict__ tsorted)
+{
+	const Job job = tjobs[blockIdx.x];
+	const uint32_t ci = job.pair * MULLS_NC + job.cls;
+	const CloudDesc &d = descs[ci];
+	const uint32_t t = job.start + threadIdx.x;
+	if (t >= d.tgt_n)
+		return;
+	const GridDesc g = grids[ci];
+	const float4 p = tpos[d.tgt_off + t];
+	const uint32_t r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
+	const uint32_t slot = cs[r] + atomicAdd(&cnt[r], 1u);
 	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
@@ -823,33 +927,36 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 	}
 }
 
-// Correspondence search, grid tier.  Phase 1: every lane applies this iteration's rigid step to two source points
-// (coalesced 16-B traffic, double math once per point) and parks the transformed position in LDS.  Phase 2: a 16-lane
-// sub-group (4 per wave64, 16 per workgroup) owns one query at a time: it sweeps the candidate rows of the 3x3x3 cell
-// neighbourhood with coalesced loads, reduces (distance, index) with 4 xor-shuffles, and — only when nothing lies
-// within one cell edge — widens the sweep to the current best distance or the rejection radius.
-// Outputs are identical to k_nn.
+// Correspondence search, global-memory grid tier (target class clouds too large for LDS).  Phase 1: the workgroup applies
+// this iteration's rigid step to its slice of a 512-point job (coalesced 16-B traffic, double math once per point) and
+// parks the transformed positions in LDS.  Phase 2: a 16-lane sub-group owns one query at a time: own cell, then the cube
+// of min(cell edge, distance found), then — while nothing lies inside the probed radius — one last cube of the distance
+// found, or cubes of twice the radius up to the rejection radius; rows are swept 16 at a time with coalesced candidate
+// loads, 4 xor-shuffles reduce (distance, index).  `split` workgroups share one job (batches with few jobs would leave
+// most CUs idle otherwise).  Outputs are identical to k_nn.
 __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
 														  const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 														  float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
-														  const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
+														  const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
+														  const uint32_t *__restrict__ cs, const float4 *__restrict__ tsorted,
 														  const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
-														  unsigned long long *__restrict__ winner)
+														  unsigned long long *__restrict__ winner, uint32_t split)
 {
 	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = 1 for live points, 0 for dead / out of range
-	const Job job = jobs[blockIdx.x];
+	const Job job = jobs[blockIdx.x / split];
+	const uint32_t per = MULLS_SRC_PER_BLOCK / split, q0 = (blockIdx.x % split) * per; // this workgroup's queries of the job: [q0, q0 + per)
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
-	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t ci = job.pair * MULLS_NC + job.cls;
+	CloudDesc &d = descs[ci];
 	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
 	const bool called = class_called(rp, d, job.cls);
 	{
 		const double *T = ps.T;
-#pragma unroll
-		for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+		for (uint32_t k = threadIdx.x; k < per; k += MULLS_BLOCK)
 		{
-			const uint32_t k = threadIdx.x + u * MULLS_BLOCK, s = job.start + k;
+			const uint32_t s = job.start + q0 + k;
 			float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
 			{
@@ -873,8 +980,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 		return; // correspondences of the previous iteration stay in force
 	__syncthreads();
 
-	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	const uint32_t *__restrict__ cstart = cell_start + g.cell_off;
+	const GridDesc g = grids[ci];
+	const BmGrid B = {bm + g.cell_off, pf + g.cell_off, cs + d.tgt_off + ci};
 	const float4 *__restrict__ ts = tsorted + d.tgt_off;
 	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
 	const double maxd = (double)r;
@@ -884,9 +991,9 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
 	uint32_t matched_cnt = 0;
-	for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_BLOCK / MULLS_GRID_GROUP)
+	for (uint32_t k = grp; k < per; k += MULLS_BLOCK / MULLS_GRID_GROUP)
 	{
-		const uint32_t s = job.start + k;
+		const uint32_t s = job.start + q0 + k;
 		if (s >= src_n)
 			break;
 		const float4 q = qpos[k];
@@ -894,11 +1001,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 			continue;
 		float best = __builtin_inff();
 		int bi = -1;
-		// probe 0: the query's own cell (dense clouds hold tens to hundreds of targets per cell: this alone gives a tight bound)
+		// probe 0: the query's own cell
 		const int ocx = grid_cell(q.x, g.ox, g.inv_h, g.nx), ocy = grid_cell(q.y, g.oy, g.inv_h, g.ny), ocz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 		{
-			const uint32_t cell = ((uint32_t)ocz * g.ny + (uint32_t)ocy) * g.nx + (uint32_t)ocx;
-			const uint32_t lo = cstart[cell], hi = cstart[cell + 1u];
+			uint32_t lo, hi;
+			bm_row_range(B, ((uint32_t)ocz * g.ny + (uint32_t)ocy) * g.wpr, (uint32_t)ocx, (uint32_t)ocx, lo, hi);
 			for (uint32_t t = lo + sub; t < hi; t += 4 * MULLS_GRID_GROUP)
 			{
 				float4 c[4];
@@ -935,16 +1042,20 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 								  grid_cell(q.z - Rm, g.oz, g.inv_h, g.nz) == ocz && grid_cell(q.z + Rm, g.oz, g.inv_h, g.nz) == ocz;
 			if (!own_only)
 			{
-				grid_scan_box(g, cstart, ts, q.x, q.y, q.z, R1, sub, best, bi);
+				grid_scan_box(g, B, ts, q.x, q.y, q.z, R1, sub, best, bi);
 				group_min(best, bi);
 			}
 		}
-		if (!(bi >= 0 && best <= m * m))
+		// nothing inside the probed radius yet: one last probe at the distance found, else double the radius (up to r)
+		float Rc = m;
+		while (!(bi >= 0 && best <= Rc * Rc) && Rc < r)
 		{
-			// nothing inside the first probe: widen to the current best distance, or to the rejection radius
-			const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
-			grid_scan_box(g, cstart, ts, q.x, q.y, q.z, R, sub, best, bi);
+			const bool last = bi >= 0;
+			Rc = last ? fminf(r, sqrtf(best)) : fminf(r, 2.0f * Rc);
+			grid_scan_box(g, B, ts, q.x, q.y, q.z, Rc, sub, best, bi);
 			group_min(best, bi);
+			if (last)
+				break;
 		}
 		if (sub == 0)
 		{
@@ -1985,8 +2096,9 @@ void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_
 	if (npairs)
 		hipLaunchKernelGGL(k_thin, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, src_keep, tgt_keep, spos, snrm, tpos, tnrm);
 }
-void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, const GridDesc *grids,
-					   const RunParams &rp, const float4 *tpos, uint32_t *cell_cnt, uint32_t *cell_start, float4 *tsorted, bool lds_tier)
+void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
+					   const RunParams &rp, const float4 *tpos, unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cell_start,
+					   float4 *tsorted, bool lds_tier)
 {
 	if (!ntjobs || !npairs)
 		return;
@@ -1995,9 +2107,12 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 		hipLaunchKernelGGL(k_grid_build_sort, dim3(npairs * MULLS_NC), dim3(MULLS_LDS_BLOCK), 0, st, descs, grids, rp, tpos, cell_start, tsorted);
 		return;
 	}
-	hipLaunchKernelGGL(k_grid_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt);
-	hipLaunchKernelGGL(k_grid_scan, dim3(npairs * MULLS_NC), dim3(MULLS_BLOCK), 0, st, grids, rp, cell_cnt, cell_start);
-	hipLaunchKernelGGL(k_grid_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, cell_cnt, cell_start, tsorted);
+	// global-memory tier: occupancy bitmap + ranks + counting sort by rank (cell_start holds the start positions)
+	hipLaunchKernelGGL(k_bm_mark, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm);
+	hipLaunchKernelGGL(k_bm_scan, dim3(npairs * MULLS_NC), dim3(1024), 0, st, grids, rp, bm, pf);
+	hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
+	hipLaunchKernelGGL(k_bm_starts, dim3(npairs * MULLS_NC), dim3(1024), 0, st, descs, grids, rp, cnt, cell_start);
+	hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cell_start, tsorted);
 }
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells)
 {
@@ -2020,12 +2135,17 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	return 0;
 }
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
-					float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag,
-					int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
+					float4 *spos, float4 *snrm, const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs,
+					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
 {
-	if (njobs)
-		hipLaunchKernelGGL(k_nn_grid, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted, flag,
-						   nn_idx, nn_d2, winner);
+	if (!njobs)
+		return;
+	// few jobs (one scan against a big map): several workgroups share a 512-query job so that the chip is not left idle
+	uint32_t split = 1;
+	while (split < 16 && njobs * split < 1024u)
+		split <<= 1;
+	hipLaunchKernelGGL(k_nn_grid, dim3(njobs * split), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, bm, pf, cs, tsorted,
+					   flag, nn_idx, nn_d2, winner, split);
 }
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 			   float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
