@@ -335,7 +335,9 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	case 3:
 		return fits ? 2 : -1;
 	default:
-		return fits ? 2 : 1;
+		// up to 8 pairs the LDS tier cannot fill the chip (one workgroup per class cloud, each staging its whole target):
+		// the global-memory tier with its jobs split over workgroups is faster there (1.13 vs 1.35 ms for one KITTI pair)
+		return (fits && B->n > 8) ? 2 : 1;
 	}
 }
 
