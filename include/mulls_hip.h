@@ -54,7 +54,8 @@ enum mulls_error
 	MULLS_E_INVALID = -100,	   /* bad argument */
 	MULLS_E_HIP = -101,		   /* a HIP runtime call failed (see mulls_last_error) */
 	MULLS_E_NO_DEVICE = -102,  /* no gfx950 device / kernels could not be loaded */
-	MULLS_E_UNSUPPORTED = -103 /* option not implemented by this build */
+	MULLS_E_UNSUPPORTED = -103, /* option not implemented by this build */
+	MULLS_E_IO = -104		   /* file could not be opened / is not in the expected format */
 };
 
 /* One feature-class cloud, borrowed from the caller (AoS of 48-byte PointXYZINormal records). */
@@ -273,6 +274,19 @@ int mulls_map_pose(mulls_ctx *ctx, const mulls_map *map, double pose_lo[16]);
 /* copy class cloud c back to the host (48-B records); *n receives its size, at most cap records are written */
 int mulls_map_download(mulls_ctx *ctx, const mulls_map *map, int cls, void *pts, uint32_t cap, uint32_t *n);
 int mulls_map_frame_download(mulls_ctx *ctx, const mulls_map *map, int cls, void *pts, uint32_t cap, uint32_t *n);
+
+/* ---- on-disk formats either side of the path; host code, no context needed ----
+ * Readers follow the two-call pattern: *n receives the number of points, at most `cap` 48-byte records are written. */
+/* DataIo::read_bin_file (dataio.hpp:357-378): KITTI x y z intensity float32 quadruples, intensity * 255; like the
+ * reference the cloud ends with one extra all-zero point (its read loop tests the stream after pushing). */
+int mulls_io_read_kitti_bin(const char *path, void *pts, uint32_t cap, uint32_t *n);
+/* DataIo::read_pcd_file (dataio.hpp:279-287) = pcl::io::loadPCDFile<PointXYZINormal>: PCD v0.7, DATA ascii or binary,
+ * float32 fields matched by name (x y z intensity normal_x normal_y normal_z curvature), others ignored / left 0. */
+int mulls_io_read_pcd(const char *path, void *pts, uint32_t cap, uint32_t *n);
+/* DataIo::write_pcd_file (dataio.hpp:288-312): WIDTH 1, HEIGHT n, eight float32 fields, binary or ascii */
+int mulls_io_write_pcd(const char *path, const void *pts, uint32_t n, uint32_t stride, int as_binary);
+/* DataIo::write_lo_pose_overwrite / _append (dataio.hpp:1896-1926): the top three rows of T (column-major), 8 significant digits */
+int mulls_io_write_pose(const char *path, const double T[16], int append);
 
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 

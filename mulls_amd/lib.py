@@ -66,6 +66,10 @@ def load():
     lib.mulls_map_pose.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.mulls_map_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_map_frame_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
+    lib.mulls_io_write_pose.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int]
     _LIB = lib
     return lib
 
@@ -75,8 +79,45 @@ EXPORTS = [
     "mulls_stream", "mulls_set_nn_mode", "mulls_icp", "mulls_icp_batch", "mulls_batch_create", "mulls_batch_run", "mulls_batch_destroy",
     "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate", "mulls_icp_3dof_ground", "mulls_icp_3dof_ground_batch",
     "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
-    "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download",
+    "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
+    "mulls_io_write_pcd", "mulls_io_write_pose",
 ]
+
+
+def _read(fn, name, path):
+    n = C.c_uint32(0)
+    rc = fn(path.encode(), None, 0, C.byref(n))
+    if rc != 0:
+        raise MullsError("%s(%s) failed with %d" % (name, path, rc))
+    out = np.zeros(n.value, abi.POINT_DTYPE)
+    if n.value:
+        rc = fn(path.encode(), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        if rc != 0:
+            raise MullsError("%s(%s) failed with %d" % (name, path, rc))
+    return out
+
+
+def read_kitti_bin(path):
+    """DataIo::read_bin_file: KITTI .bin -> POINT_DTYPE array (intensity * 255, trailing zero point like the reference)."""
+    return _read(load().mulls_io_read_kitti_bin, "mulls_io_read_kitti_bin", path)
+
+
+def read_pcd(path):
+    """DataIo::read_pcd_file: PCD v0.7 (ascii / binary) of PointXYZINormal -> POINT_DTYPE array."""
+    return _read(load().mulls_io_read_pcd, "mulls_io_read_pcd", path)
+
+
+def write_pcd(path, pts, binary=True):
+    pts = abi.as_points(pts)
+    rc = load().mulls_io_write_pcd(path.encode(), pts.ctypes.data_as(C.c_void_p), len(pts), abi.POINT_BYTES, int(binary))
+    if rc != 0:
+        raise MullsError("mulls_io_write_pcd(%s) failed with %d" % (path, rc))
+
+
+def write_pose(path, T, append=False):
+    rc = load().mulls_io_write_pose(path.encode(), abi.colmajor16(T), int(append))
+    if rc != 0:
+        raise MullsError("mulls_io_write_pose(%s) failed with %d" % (path, rc))
 
 
 class Context:
