@@ -21,6 +21,15 @@
 
 #include "device_types.h"
 
+// Workgroups are handed to the 8 XCDs round-robin by blockIdx, and every XCD has its own L2.  Job tables are sorted by
+// pair, so consecutive jobs gather from the same target clouds: this bijection gives XCD x the x-th eighth of the table,
+// in order, instead of every eighth job — the jobs of one pair then share one L2 (affinity only, never correctness).
+__device__ __forceinline__ uint32_t xcd_job(uint32_t b, uint32_t n)
+{
+	const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
+	return x * q + min(x, r) + (b >> 3);
+}
+
 #pragma clang fp contract(off)
 
 namespace
@@ -943,8 +952,9 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 														  unsigned long long *__restrict__ winner, uint32_t split)
 {
 	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = 1 for live points, 0 for dead / out of range
-	const Job job = jobs[blockIdx.x / split];
-	const uint32_t per = MULLS_SRC_PER_BLOCK / split, q0 = (blockIdx.x % split) * per; // this workgroup's queries of the job: [q0, q0 + per)
+	const uint32_t wg = xcd_job(blockIdx.x, gridDim.x);
+	const Job job = jobs[wg / split];
+	const uint32_t per = MULLS_SRC_PER_BLOCK / split, q0 = (wg % split) * per; // this workgroup's queries of the job: [q0, q0 + per)
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
@@ -1220,7 +1230,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	// one workgroup per (pair, class): the target class cloud is staged ONCE and every 512-query chunk of the source
 	// class cloud is searched against it (the first version staged it once per chunk: 2.3x the algorithmic HBM bytes,
 	// profiles/r01_f_pmc_traffic.txt)
-	const Job job = cjobs[blockIdx.x];
+	const Job job = cjobs[xcd_job(blockIdx.x, gridDim.x)];
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
@@ -1543,7 +1553,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 														 const unsigned long long *__restrict__ winner)
 {
 	__shared__ uint32_t red4[4];
-	const Job job = jobs[blockIdx.x];
+	const Job job = jobs[xcd_job(blockIdx.x, gridDim.x)];
 	const PairState &ps = states[job.pair];
 	if (!ps.active)
 		return;
@@ -1654,14 +1664,15 @@ __device__ __forceinline__ int metric_of(int cls) { return (cls == 1 || cls == 3
 // Normal-equation accumulation (active pairs) or posterior residual (pairs flagged want_residual).  27 double
 // accumulators per lane -> wave64 shuffle tree -> 4-wave LDS combine -> one 27-double partial per workgroup, summed
 // in fixed order by k_finish (run-to-run deterministic, unlike atomicAdd(double)).
-__global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+__global__ __launch_bounds__(MULLS_BLOCK, 4) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
 														const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
 														const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm,
 														const uint8_t *__restrict__ flag, const int32_t *__restrict__ match, float *__restrict__ wd,
 														double *__restrict__ partial, uint32_t job_base)
 {
 	__shared__ double red[4][MULLS_NTERM];
-	const Job job = jobs[blockIdx.x];
+	const uint32_t job_idx = xcd_job(blockIdx.x, gridDim.x);
+	const Job job = jobs[job_idx];
 	const PairState &ps = states[job.pair];
 	if (!ps.active && !ps.want_residual)
 		return;
@@ -1919,7 +1930,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_accum(const Job *__restrict__ j
 	}
 	__syncthreads();
 	if (threadIdx.x < MULLS_NTERM)
-		partial[(size_t)(job_base + blockIdx.x) * MULLS_NTERM + threadIdx.x] = // job_base: first job of this sub-batch in the batch-wide table
+		partial[(size_t)(job_base + job_idx) * MULLS_NTERM + threadIdx.x] = // job_base: first job of this sub-batch in the batch-wide table
 			((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
