@@ -260,6 +260,7 @@ typedef struct mulls_map_report
 
 void mulls_map_default_params(mulls_map_params *p);
 int mulls_map_create(mulls_ctx *ctx, mulls_map **out);
+/* a map belongs to its context: mulls_destroy(ctx) also destroys the maps still alive (their handles become invalid) */
 void mulls_map_destroy(mulls_ctx *ctx, mulls_map *map);
 /* (re)initialise the map from host clouds (e.g. the first frame's undown features) and its pose_lo (column-major) */
 int mulls_map_set(mulls_ctx *ctx, mulls_map *map, const mulls_cloud clouds[6], const double pose_lo[16]);

@@ -712,6 +712,8 @@ extern "C"
 		(void)hipSetDevice(ctx->device);
 		if (ctx->scratch)
 			mulls_batch_destroy(ctx, ctx->scratch);
+		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
+			mulls_map_destroy(ctx, ctx->maps.back());
 		for (auto &e : ctx->ev)
 			if (e)
 				(void)hipEventDestroy(e);

@@ -214,6 +214,23 @@ def make_pair(seed, n_beams=64, n_az=1900, elev_deg=(-24.8, 2.0), src_counts=Non
     return pair, T_gt
 
 
+def drive(seed, n_frames, n_beams=32, n_az=700, elev_deg=(-24.8, 2.0), counts=None, vertex_count=150, step=0.8):
+    """A short drive through ONE scene: per frame the six class clouds in the sensor frame and the ground-truth pose
+    (frame -> world, world = frame 0).  Consecutive frames differ by about `step` metres and a degree of heading."""
+    rng = np.random.default_rng(seed)
+    scene = Scene(seed)
+    counts = R_SOURCE if counts is None else counts
+    world0 = se3(0, 0, scene.sensor_height)
+    pose = np.eye(4)
+    frames = []
+    for k in range(n_frames):
+        scan = raycast(scene, world0 @ pose, n_beams, n_az, elev_deg, seed=seed * 7 + k)
+        frames.append((class_clouds(scan, counts, seed=seed * 11 + k, vertex_count=vertex_count), pose.copy()))
+        pose = pose @ se3(rng.uniform(0.7, 1.3) * step, rng.normal(0, 0.03), rng.normal(0, 0.01), np.deg2rad(rng.normal(0, 0.1)),
+                          np.deg2rad(rng.normal(0, 0.1)), np.deg2rad(rng.normal(0, 1.0)))
+    return frames
+
+
 def pose_error(T, T_ref):
     """(translation error in m, rotation geodesic in rad) between two 4x4 transforms."""
     dT = np.linalg.inv(T_ref) @ T

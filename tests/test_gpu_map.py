@@ -97,3 +97,40 @@ def test_map_argument_errors(ctx_auto):
     rep = m.update(frames[1][0], frames[1][1], abi.map_params())  # empty map + first frame
     assert rep.n[0] == len(frames[1][0][0])
     m.close()
+
+
+def test_scan_to_map_odometry_loop(ctx_auto):
+    """The scan-to-map loop of test/mulls_slam.cpp on a synthetic drive: register every new frame against the
+    device-resident local map, then fold it into the map (with map-based dynamic removal driven by that registration's
+    crop box).  The oracle runs the same loop on the host from the same poses; registrations and maps must agree."""
+    counts = {abi.GROUND: 500, abi.PILLAR: 200, abi.FACADE: 600, abi.BEAM: 120, abi.ROOF: 60}
+    frames = synth.drive(5, 6, counts=counts)
+    dev = ctx_auto.local_map(frames[0][0], np.eye(4))
+    host_map, host_pose = [c.copy() for c in frames[0][0]], np.eye(4)
+    P = abi.kitti_params(dis_thre_unit=2.0, used_feature_type="111110")
+    pose = np.eye(4)  # estimated pose of the last frame folded into the map
+    for k in range(1, len(frames)):
+        clouds, gt = frames[k]
+        guess = np.linalg.inv(frames[k - 1][1]) @ gt @ synth.se3(0.15, -0.1, 0.02, 0, 0, np.deg2rad(0.4))  # perturbed relative motion
+        bound = abi.PairData(host_map, clouds).tgt_bound
+        rg = dev.icp(clouds, P, init_guess=guess, tgt_bound=bound)[0]
+        ro = pyoracle.icp(abi.PairData(host_map, clouds, init_guess=guess, tgt_bound=bound), P)[0]
+        assert (rg.code, rg.iters, list(rg.ncorr)) == (ro.code, ro.iters, list(ro.ncorr)) and rg.code == 1
+        dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
+        assert dt <= 1e-7 and dr <= 1e-7
+        assert list(rg.crop_box) == list(ro.crop_box) and rg.cropped == ro.cropped
+        pose = pose @ rg.T_matrix()  # both sides continue from the device's estimate (bit-identical inputs for the map update)
+        et, er = synth.pose_error(pose, gt)
+        assert et < 0.15 and er < 0.01, (k, et, er)
+        M = abi.map_params(max_num_pts=4000, kept_vertex_num=300, local_map_radius=60.0, map_based_dynamic_removal_on=1, rng_seed=k,
+                           dynamic_dist_thre_min=0.3, dynamic_dist_thre_max=1.5, tree_mode=2 if rg.cropped else 1,
+                           tree_used="".join("1" if (P.used_feature_type[c:c + 1] == b"1" and rg.ntgt0[c] > 0) else "0" for c in range(6)),
+                           tree_box=list(rg.crop_box))
+        rep = dev.update(clouds, pose, M)
+        host_map, _, rep_o = pyoracle.map_update(host_map, host_pose, clouds, pose, M)
+        host_pose = pose
+        assert list(rep.n) == list(rep_o.n) and list(rep.frame_n) == list(rep_o.frame_n) and rep.dynamic_removal_ran == rep_o.dynamic_removal_ran
+        for c in range(6):
+            same_cloud(dev.download(c), host_map[c])
+    assert rep.feature_point_num <= 4005
+    dev.close()
