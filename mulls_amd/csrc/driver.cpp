@@ -478,7 +478,17 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 		size_t bytes;
 	};
 	std::vector<DevCopy> dev_copies;
+	struct HostCopy
+	{
+		uint8_t *dst;
+		const uint8_t *src;
+		uint32_t n, stride;
+	};
+	std::vector<HostCopy> host_copies;
+	std::vector<size_t> first_copy_of_pair(n + 1, 0);
 	for (int p = 0; p < n; p++)
+	{
+		first_copy_of_pair[p] = host_copies.size();
 		for (int c = 0; c < MULLS_NC; c++)
 		{
 			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
@@ -488,7 +498,9 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			{
 				uint8_t *dst = B->upload_h + (size_t)off[k] * MULLS_POINT_BYTES;
 				const uint8_t *src = (const uint8_t *)cl[k]->pts;
-				if (cl[k]->n && mulls_is_map_memory(ctx, src, (size_t)cl[k]->n * MULLS_POINT_BYTES))
+				if (!cl[k]->n)
+					continue;
+				if (mulls_is_map_memory(ctx, src, (size_t)cl[k]->n * MULLS_POINT_BYTES))
 				{
 					// a class cloud of a device-resident local map (mulls_map_cloud): staged by a device-to-device copy below
 					if (cl[k]->stride != MULLS_POINT_BYTES)
@@ -499,15 +511,38 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 					dev_copies.push_back({(size_t)off[k] * MULLS_POINT_BYTES, src, (size_t)cl[k]->n * MULLS_POINT_BYTES});
 					continue;
 				}
-				if (cl[k]->stride == MULLS_POINT_BYTES)
-					std::memcpy(dst, src, (size_t)cl[k]->n * MULLS_POINT_BYTES);
-				else
-					for (uint32_t i = 0; i < cl[k]->n; i++)
-						std::memcpy(dst + (size_t)i * MULLS_POINT_BYTES, src + (size_t)i * cl[k]->stride, MULLS_POINT_BYTES);
+				host_copies.push_back({dst, src, cl[k]->n, cl[k]->stride});
 			}
 		}
+	}
+	first_copy_of_pair[n] = host_copies.size();
+	// blocks of pairs: the host threads pack block k into pinned memory while the copy engine moves block k - 1
 	hipStream_t st = ctx->stream;
-	hipError_t e = hipMemcpyAsync(B->stage, B->upload_h, stage_rec * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st);
+	hipError_t e = hipSuccess;
+	const int block = 64;
+	for (int p0 = 0; p0 < n && e == hipSuccess; p0 += block)
+	{
+		const int p1 = std::min(n, p0 + block);
+		const long c0 = (long)first_copy_of_pair[p0], c1 = (long)first_copy_of_pair[p1];
+		const int threads = (int)std::max<long>(1, std::min<long>(16, (c1 - c0) / 8));
+		(void)threads;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) if (threads > 1)
+		for (long i = c0; i < c1; i++)
+		{
+			const HostCopy &hc = host_copies[i];
+			if (hc.stride == MULLS_POINT_BYTES)
+				std::memcpy(hc.dst, hc.src, (size_t)hc.n * MULLS_POINT_BYTES);
+			else
+				for (uint32_t k = 0; k < hc.n; k++)
+					std::memcpy(hc.dst + (size_t)k * MULLS_POINT_BYTES, hc.src + (size_t)k * hc.stride, MULLS_POINT_BYTES);
+		}
+		// staged records of pairs [p0, p1) are one contiguous range (offsets grow with the pair index)
+		const size_t r0 = B->descs_h[(size_t)p0 * MULLS_NC].src_stage;
+		const size_t r1 = p1 < n ? B->descs_h[(size_t)p1 * MULLS_NC].src_stage : stage_rec;
+		if (r1 > r0)
+			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + r0 * MULLS_POINT_BYTES, B->upload_h + r0 * MULLS_POINT_BYTES,
+							   (r1 - r0) * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st);
+	}
 	for (const DevCopy &dc : dev_copies)
 		if (e == hipSuccess)
 			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + dc.dst, dc.src, dc.bytes, hipMemcpyDeviceToDevice, st);
