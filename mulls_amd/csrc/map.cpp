@@ -32,6 +32,8 @@ struct mulls_map
 	uint32_t *best = nullptr;
 	uint8_t *keep = nullptr;
 	size_t cap_best = 0, cap_keep = 0;
+	uint32_t *seg = nullptr; // per-segment counters of the stable compactions
+	size_t cap_seg = 0;
 };
 
 bool mulls_is_map_memory(const mulls_ctx *ctx, const void *p, size_t bytes)
@@ -101,6 +103,22 @@ int upload_cloud(mulls_ctx *ctx, const mulls_cloud &c, float4 **dst, size_t *cap
 	return MULLS_OK;
 }
 
+int compact(mulls_ctx *ctx, mulls_map *m, const MapCompactArgs &a)
+{
+	const size_t need = (size_t)map_compact_segments(a) + 8;
+	if (m->cap_seg < need)
+	{
+		if (m->seg)
+			(void)hipFree(m->seg);
+		m->seg = nullptr;
+		if (dmalloc(ctx, &m->seg, need * 2) != MULLS_OK)
+			return MULLS_E_HIP;
+		m->cap_seg = need * 2;
+	}
+	launch_map_compact(ctx->stream, a, m->seg);
+	return MULLS_OK;
+}
+
 double key_to_double(uint32_t k, bool is_min)
 {
 	const bool none = is_min ? k == 0xffffffffu : k == 0u;
@@ -164,7 +182,7 @@ extern "C"
 				if (q)
 					(void)hipFree(q);
 		}
-		void *p[] = {m->counts, m->keys, m->T12, m->best, m->keep};
+		void *p[] = {m->counts, m->keys, m->T12, m->best, m->keep, m->seg};
 		for (void *q : p)
 			if (q)
 				(void)hipFree(q);
@@ -274,7 +292,8 @@ extern "C"
 				a.cloud[0].n = nf;
 				a.out_n = m->counts;
 				a.mode = 0;
-				launch_map_compact(st, a); // slots 1..5 are empty clouds
+				if (compact(ctx, m, a) != MULLS_OK) // slots 1..5 are empty clouds
+					return MULLS_E_HIP;
 				uint32_t cnt[6];
 				HIPCHK(ctx, hipMemcpyAsync(cnt, m->counts, sizeof(cnt), hipMemcpyDeviceToHost, st));
 				HIPCHK(ctx, hipStreamSynchronize(st));
@@ -317,7 +336,8 @@ extern "C"
 		a.out_n = m->counts;
 		a.mode = 1;
 		a.radius = (double)P->local_map_radius;
-		launch_map_compact(st, a);
+		if (compact(ctx, m, a) != MULLS_OK)
+			return MULLS_E_HIP;
 		uint32_t cnt[6];
 		HIPCHK(ctx, hipMemcpyAsync(cnt, m->counts, sizeof(cnt), hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
@@ -367,8 +387,10 @@ extern "C"
 			hipError_t e = hipMemcpyAsync(dmask, mask.data(), mask_total, hipMemcpyHostToDevice, st);
 			if (e == hipSuccess)
 			{
-				launch_map_compact(st, a);
-				e = hipStreamSynchronize(st);
+				if (compact(ctx, m, a) != MULLS_OK)
+					e = hipErrorOutOfMemory;
+				else
+					e = hipStreamSynchronize(st);
 			}
 			(void)hipFree(dmask);
 			if (e != hipSuccess)

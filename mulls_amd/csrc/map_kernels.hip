@@ -14,33 +14,109 @@ __device__ __forceinline__ uint32_t float_ord(float f)
 }
 } // namespace
 
-// Stable compaction of up to six clouds, one 1024-lane workgroup each: chunks of 1024 records, wave ballots + a 16-entry
-// LDS scan give every kept record its slot.  The order of the survivors is the input order (the reference pushes them
-// back one by one).
-__global__ __launch_bounds__(1024) void k_map_compact(MapCompactArgs a)
+// Stable compaction of up to six clouds in three steps, so that a 400 k-point class cloud is not left to one CU's memory
+// bandwidth: (1) every 256-lane workgroup counts the survivors of one 4096-record segment, (2) one workgroup per cloud
+// turns the segment counts into segment bases (and the cloud's new size), (3) every workgroup rewrites its segment behind
+// its base.  The order of the survivors is the input order (the reference pushes them back one by one).
+#define MAP_SEG 4096u
+namespace
 {
-	__shared__ uint32_t wave_cnt[16];
-	const MapCloudArg c = a.cloud[blockIdx.x];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const double r2 = a.radius * a.radius;
-	uint32_t running = 0;
-	for (uint32_t base = 0; base < c.n; base += 1024)
+__device__ __forceinline__ bool map_keep(const MapCompactArgs &a, const MapCloudArg &c, uint32_t i, const float4 &r0, double r2)
+{
+	if (a.mode == 0)
+		return c.mask[i] != 0;
+	const double dis_square = (double)(r0.x * r0.x + r0.y * r0.y); // float products and sum, then widened (cfilter.hpp:845)
+	return dis_square < r2 && r0.z < 1.7976931348623157e308 && r0.z > -1.7976931348623157e308;
+}
+// which cloud and which of its segments a workgroup owns
+__device__ __forceinline__ bool map_segment(const MapCompactArgs &a, uint32_t b, uint32_t &cloud, uint32_t &seg)
+{
+	for (cloud = 0; cloud < 6; cloud++)
 	{
-		const uint32_t i = base + threadIdx.x;
+		const uint32_t ns = (a.cloud[cloud].n + MAP_SEG - 1u) / MAP_SEG;
+		if (b < ns)
+		{
+			seg = b;
+			return true;
+		}
+		b -= ns;
+	}
+	return false;
+}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_map_seg_count(MapCompactArgs a, uint32_t *__restrict__ seg_cnt)
+{
+	__shared__ uint32_t wave_cnt[4];
+	uint32_t cloud, seg;
+	if (!map_segment(a, blockIdx.x, cloud, seg))
+		return;
+	const MapCloudArg c = a.cloud[cloud];
+	const double r2 = a.radius * a.radius;
+	uint32_t mine = 0;
+	for (uint32_t k = 0; k < MAP_SEG; k += 256)
+	{
+		const uint32_t i = seg * MAP_SEG + k + threadIdx.x;
+		if (i < c.n)
+			mine += map_keep(a, c, i, c.in[(size_t)i * 3], r2) ? 1u : 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		mine += __shfl_down(mine, off);
+	if ((threadIdx.x & 63) == 0)
+		wave_cnt[threadIdx.x >> 6] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		seg_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// exclusive scan of each cloud's segment counts (in place), cloud totals to out_n; segments per cloud are few (<= a few hundred)
+__global__ __launch_bounds__(64) void k_map_seg_scan(MapCompactArgs a, uint32_t *__restrict__ seg_cnt)
+{
+	uint32_t first = 0;
+	for (uint32_t c = 0; c < blockIdx.x; c++)
+		first += (a.cloud[c].n + MAP_SEG - 1u) / MAP_SEG;
+	const uint32_t ns = (a.cloud[blockIdx.x].n + MAP_SEG - 1u) / MAP_SEG;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < ns; base += 64)
+	{
+		const uint32_t s = base + threadIdx.x;
+		const uint32_t v = s < ns ? seg_cnt[first + s] : 0u;
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if ((int)threadIdx.x >= off)
+				incl += o;
+		}
+		if (s < ns)
+			seg_cnt[first + s] = running + incl - v;
+		running += __shfl(incl, 63);
+	}
+	if (threadIdx.x == 0)
+		a.out_n[blockIdx.x] = running;
+}
+
+__global__ __launch_bounds__(256) void k_map_seg_scatter(MapCompactArgs a, const uint32_t *__restrict__ seg_base)
+{
+	__shared__ uint32_t wave_cnt[4];
+	uint32_t cloud, seg;
+	if (!map_segment(a, blockIdx.x, cloud, seg))
+		return;
+	const MapCloudArg c = a.cloud[cloud];
+	const double r2 = a.radius * a.radius;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = seg_base[blockIdx.x];
+	for (uint32_t k = 0; k < MAP_SEG; k += 256)
+	{
+		const uint32_t i = seg * MAP_SEG + k + threadIdx.x;
 		bool keep = false;
-		float4 r0, r1, r2v;
+		float4 r0, r1, rr;
 		if (i < c.n)
 		{
 			r0 = c.in[(size_t)i * 3];
 			r1 = c.in[(size_t)i * 3 + 1];
-			r2v = c.in[(size_t)i * 3 + 2];
-			if (a.mode == 0)
-				keep = c.mask[i] != 0;
-			else
-			{
-				const double dis_square = (double)(r0.x * r0.x + r0.y * r0.y); // float products and sum, then widened
-				keep = dis_square < r2 && r0.z < 1.7976931348623157e308 && r0.z > -1.7976931348623157e308;
-			}
+			rr = c.in[(size_t)i * 3 + 2];
+			keep = map_keep(a, c, i, r0, r2);
 		}
 		const unsigned long long b = __ballot(keep);
 		const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -49,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_map_compact(MapCompactArgs a)
 			wave_cnt[wave] = (uint32_t)__popcll(b);
 		__syncthreads();
 		uint32_t wbase = 0, total = 0;
-		for (int w = 0; w < 16; w++)
+		for (int w = 0; w < 4; w++)
 		{
 			if (w < wave)
 				wbase += wave_cnt[w];
@@ -60,12 +136,10 @@ __global__ __launch_bounds__(1024) void k_map_compact(MapCompactArgs a)
 			const size_t o = (size_t)(running + wbase + before) * 3;
 			c.out[o] = r0;
 			c.out[o + 1] = r1;
-			c.out[o + 2] = r2v;
+			c.out[o + 2] = rr;
 		}
 		running += total;
 	}
-	if (threadIdx.x == 0)
-		a.out_n[blockIdx.x] = running;
 }
 
 // get_cloud_bbx (utility.hpp:817-848) over the six class clouds, and over the same points moved by pose_lo
@@ -186,7 +260,22 @@ __global__ void k_map_keep(const float4 *__restrict__ frame, uint32_t n_frame, c
 	keep[q] = k ? 1 : 0;
 }
 
-void launch_map_compact(hipStream_t st, const MapCompactArgs &a) { hipLaunchKernelGGL(k_map_compact, dim3(6), dim3(1024), 0, st, a); }
+uint32_t map_compact_segments(const MapCompactArgs &a)
+{
+	uint32_t ns = 0;
+	for (int c = 0; c < 6; c++)
+		ns += (a.cloud[c].n + MAP_SEG - 1u) / MAP_SEG;
+	return ns;
+}
+void launch_map_compact(hipStream_t st, const MapCompactArgs &a, uint32_t *seg_scratch)
+{
+	const uint32_t ns = map_compact_segments(a);
+	if (ns)
+		hipLaunchKernelGGL(k_map_seg_count, dim3(ns), dim3(256), 0, st, a, seg_scratch);
+	hipLaunchKernelGGL(k_map_seg_scan, dim3(6), dim3(64), 0, st, a, seg_scratch);
+	if (ns)
+		hipLaunchKernelGGL(k_map_seg_scatter, dim3(ns), dim3(256), 0, st, a, seg_scratch);
+}
 void launch_map_bbox(hipStream_t st, const MapBoxArgs &a) { hipLaunchKernelGGL(k_map_bbox, dim3(64, 6), dim3(256), 0, st, a); }
 void launch_map_nn(hipStream_t st, const float4 *frame, uint32_t n_frame, const float4 *tree, uint32_t n_tree, int use_box, const double box[6],
 				   uint32_t *best)

@@ -28,7 +28,9 @@ struct MapBoxArgs
 	uint32_t *keys;	 // [12] ordered-uint min xyz / max xyz of the points, then of the posed points
 };
 
-void launch_map_compact(hipStream_t st, const MapCompactArgs &a);
+// seg_scratch: device array of at least map_compact_segments(a) uint32 (one counter per 4096-record segment)
+uint32_t map_compact_segments(const MapCompactArgs &a);
+void launch_map_compact(hipStream_t st, const MapCompactArgs &a, uint32_t *seg_scratch);
 void launch_map_bbox(hipStream_t st, const MapBoxArgs &a);
 // nearest tree point of every frame point: best[i] = float bits of the smallest squared distance (0x7f800000 if the tree
 // is empty); tree = map class cloud, optionally restricted to the open box (strict inequalities, float vs double)
