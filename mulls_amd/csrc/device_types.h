@@ -19,6 +19,8 @@
 #define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
 #define MULLS_LDS_MAXPTS 10240u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
+#define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)
+#define MULLS_SEG 4096u		  // ... in segments of this many points
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
 #define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
 
@@ -48,7 +50,8 @@ struct CloudDesc
 	uint32_t sd_stage; // staged block2->pc_*_down records (motion undistortion regenerates the source from them); may alias src_stage
 	uint32_t sd_n0;
 	uint32_t src_cap; // slots reserved for this source cloud in the working arenas = max(src_n0, sd_n0)
-	uint32_t pad_[2];
+	uint32_t big_slot; // target clouds beyond MULLS_BIG_CLOUD points are cropped by many workgroups: 1-based slot, 0 = small
+	uint32_t pad_[1];
 };
 
 // Uniform grid over one cropped target-class cloud (exact fixed-radius search tier).  cell id = (cz*ny + cy)*nx + cx,

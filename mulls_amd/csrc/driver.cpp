@@ -35,6 +35,7 @@ struct mulls_batch
 	std::vector<CloudDesc> descs_h;
 	std::vector<PairSetup> setup_h;
 	std::vector<Job> setup_jobs_h;
+	std::vector<Job> big_segs_h, big_clouds_h; // target class clouds cropped segment-wise (k_crop_big_*): segments, clouds
 	std::vector<Job> jobs_h;
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
@@ -57,6 +58,9 @@ struct mulls_batch
 	PairOut *outs_pin = nullptr; // device address of the pinned host array outs_h (packed records, k_pull_outs)
 	uint32_t *bbox = nullptr;
 	Job *setup_jobs = nullptr;
+	Job *big_segs = nullptr, *big_clouds = nullptr;
+	uint32_t *seg_cnt = nullptr, *big_box = nullptr;
+	size_t cap_big[4] = {};
 	Job *jobs = nullptr;
 	double *partial = nullptr;
 	Job *tjobs = nullptr;
@@ -349,6 +353,8 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	B->descs_h.assign((size_t)n * MULLS_NC, CloudDesc());
 	B->setup_h.assign(n, PairSetup());
 	B->setup_jobs_h.clear();
+	B->big_segs_h.clear();
+	B->big_clouds_h.clear();
 	B->jobs_key.clear(); // the job table depends on the layout
 	B->dev_key.clear();
 	size_t stage_rec = 0, so = 0, to = 0;
@@ -387,6 +393,14 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			d.tgt_off = (uint32_t)to;
 			so += d.src_cap;
 			to += t.n;
+			if (t.n > MULLS_BIG_CLOUD)
+			{
+				const uint32_t slot = (uint32_t)B->big_clouds_h.size(), first = (uint32_t)B->big_segs_h.size();
+				d.big_slot = slot + 1u;
+				for (uint32_t k = 0; k < t.n; k += MULLS_SEG)
+					B->big_segs_h.push_back({(uint32_t)p, (uint32_t)c, k, slot});
+				B->big_clouds_h.push_back({(uint32_t)p, (uint32_t)c, first, (uint32_t)B->big_segs_h.size() - first});
+			}
 			for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
 			{
 				Job j = {(uint32_t)p, (uint32_t)c, k, 0};
@@ -439,6 +453,10 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->bbox, &B->cap_pairs[3], (size_t)n * 6));
 	A(grow(ctx, &B->grids, &B->cap_pairs[4], (size_t)n * MULLS_NC));
 	A(grow(ctx, &B->setup_jobs, &B->cap_setup_jobs, B->setup_jobs_h.size()));
+	A(grow(ctx, &B->big_segs, &B->cap_big[0], B->big_segs_h.size()));
+	A(grow(ctx, &B->big_clouds, &B->cap_big[1], B->big_clouds_h.size()));
+	A(grow(ctx, &B->seg_cnt, &B->cap_big[2], B->big_segs_h.size()));
+	A(grow(ctx, &B->big_box, &B->cap_big[3], B->big_clouds_h.size() * 6));
 	if (!B->ticket)
 	{
 		A(dmalloc(ctx, &B->ticket, 32));
@@ -548,6 +566,10 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + dc.dst, dc.src, dc.bytes, hipMemcpyDeviceToDevice, st);
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess && !B->big_segs_h.empty())
+		e = hipMemcpyAsync(B->big_segs, B->big_segs_h.data(), B->big_segs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
+	if (e == hipSuccess && !B->big_clouds_h.empty())
+		e = hipMemcpyAsync(B->big_clouds, B->big_clouds_h.data(), B->big_clouds_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(B->setup, B->setup_h.data(), sizeof(PairSetup) * n, hipMemcpyHostToDevice, st);
 	if (e == hipSuccess && winner_grew) // later epochs always sort below older entries (k_nn), so only fresh memory needs the fill
@@ -792,7 +814,7 @@ extern "C"
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
-					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->jobs, B->partial,
+					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
 					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
 		for (void *p : dev)
 			if (p)
@@ -874,7 +896,8 @@ extern "C"
 		evt.begin(&ctx->prof.ms_setup);
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, rp);
 		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
-					B->match, B->wd, rp, B->grids);
+					B->match, B->wd, rp, B->grids, (uint32_t)B->big_segs_h.size(), B->big_segs, (uint32_t)B->big_clouds_h.size(), B->big_clouds, B->seg_cnt,
+					B->big_box);
 		if (P->keep_less_source_points && !rp.undistort)
 		{
 			// keep_less_source_pts (cregistration.hpp:2866-2892): needs the post-filter sizes, so this (map-to-map only) option
@@ -1330,7 +1353,8 @@ extern "C"
 			return rc;
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, rp);
 		launch_crop(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag,
-					B->match, B->wd, rp, B->grids);
+					B->match, B->wd, rp, B->grids, (uint32_t)B->big_segs_h.size(), B->big_segs, (uint32_t)B->big_clouds_h.size(), B->big_clouds, B->seg_cnt,
+					B->big_box);
 		if (P->keep_less_source_points)
 		{
 			// random_downsample_pcl(pc_ground_sc, tc.size() / down_rate), down_rate = 3 (:1462, :1485): no filter ran, sizes are known
@@ -1674,7 +1698,8 @@ extern "C"
 			return rc;
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, *rp);
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
-					B->wd, *rp, B->grids);
+					B->wd, *rp, B->grids, (uint32_t)B->big_segs_h.size(), B->big_segs, (uint32_t)B->big_clouds_h.size(), B->big_clouds, B->seg_cnt,
+					B->big_box);
 		if (tier != 0)
 			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
 							  B->tsorted, tier == 2);

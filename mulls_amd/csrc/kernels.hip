@@ -167,6 +167,89 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 	}
 }
 
+// the intersection box of get_cloud_pair_intersection (cfilter.hpp:2613-2655): union box of the transformed source clouds
+// (ordered keys from k_clone_src) against block1->local_bound, padded by 1 m
+namespace
+{
+__device__ __forceinline__ void crop_box(uint32_t pair, const uint32_t *__restrict__ bbox, const PairSetup *__restrict__ setup, double lo[3],
+										  double hi[3])
+{
+	for (int k = 0; k < 3; k++)
+	{
+		uint32_t kmin = bbox[pair * 6 + k], kmax = bbox[pair * 6 + 3 + k];
+		// an empty union keeps (+DBL_MAX, -DBL_MAX) like CloudUtility::merge_bbx (utility.hpp:867-884)
+		double mmin = (kmin == 0xffffffffu && kmax == 0u) ? 1.7976931348623157e308 : (double)ord2f(kmin);
+		double mmax = (kmin == 0xffffffffu && kmax == 0u) ? -1.7976931348623157e308 : (double)ord2f(kmax);
+		double b1min = setup[pair].tgt_bound[k], b1max = setup[pair].tgt_bound[3 + k];
+		const float pad = 1.0f;
+		lo[k] = ((b1min > mmin) ? b1min : mmin) - pad; // get_intersection_bbx, utility.hpp:857-865
+		hi[k] = ((b1max < mmax) ? b1max : mmax) + pad;
+	}
+}
+// strict inequalities, float coordinate promoted to double (cfilter.hpp:959-961)
+__device__ __forceinline__ bool crop_keep(const float4 &p, const double lo[3], const double hi[3])
+{
+	return (double)p.x > lo[0] && (double)p.x < hi[0] && (double)p.y > lo[1] && (double)p.y < hi[1] && (double)p.z > lo[2] && (double)p.z < hi[2];
+}
+// grid descriptor of a cropped target cloud with bounding box [lo3, hi3] and `running` points
+__device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi3[3], uint32_t running, const RunParams &rp, uint32_t pair,
+											   uint32_t cls)
+{
+	GridDesc g;
+	g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
+	g.h = MULLS_GRID_H0;
+	g.nx = g.ny = g.nz = 1;
+	g.ncell = 0;
+	g.wpr = 1;
+	g.nocc = 0;
+	uint32_t nwords = 1;
+	if (running > 0 && rp.bm_h0 > 0.0f)
+	{
+		// global-memory tier: occupancy bitmap over fine cells; rows are padded to whole 64-cell words
+		g.h = rp.bm_h0;
+		if (rp.bm_auto) // points lie on surfaces: mean spacing ~ sqrt(footprint / count); measured optimum 0.25 m (1 M points) .. 0.7 m (5 k)
+			g.h = fminf(fmaxf(sqrtf((hi3[0] - lo3[0]) * (hi3[1] - lo3[1]) / (float)running), rp.bm_h0), 2.8f * rp.bm_h0);
+		for (;;)
+		{
+			g.inv_h = 1.0f / g.h;
+			g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
+			g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
+			g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+			g.wpr = (g.nx + 63u) >> 6;
+			if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
+				break;
+			g.h *= 1.25f;
+		}
+		nwords = g.ny * g.nz * g.wpr;
+	}
+	else if (running > 0)
+		for (;;)
+		{
+			g.inv_h = 1.0f / g.h;
+			// same float expression as grid_cell() so that the largest coordinate lands in the last cell
+			g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
+			g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
+			g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+			if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
+				break;
+			g.h *= 1.25f;
+		}
+	else
+		g.inv_h = 1.0f;
+	// cell tables are laid out over the USED classes only: slot = pair * n_used + rank of this class among them
+	uint32_t n_used = 0, rank = 0;
+	for (uint32_t c = 0; c < MULLS_NC; c++)
+	{
+		if (c < cls && rp.used[c])
+			rank++;
+		n_used += rp.used[c] ? 1u : 0u;
+	}
+	g.ncell = (running > 0 && rp.used[cls]) ? (rp.bm_h0 > 0.0f ? nwords : g.nx * g.ny * g.nz) : 0u;
+	g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
+	return g;
+}
+} // namespace
+
 // Setup 2: order-preserving compaction of one cloud by the intersection box.  One workgroup per (pair, class, side);
 // side 0 = source (reads the SoA written by k_clone_src), side 1 = target (reads the staged AoS records).
 __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ descs, const PairSetup *__restrict__ setup,
@@ -174,7 +257,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 													   const float4 *__restrict__ tmp_pos, const float4 *__restrict__ tmp_nrm,
 													   float4 *__restrict__ spos, float4 *__restrict__ snrm, float4 *__restrict__ tpos,
 													   float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, int32_t *__restrict__ match,
-													   float *__restrict__ wd, RunParams rp, GridDesc *__restrict__ grids)
+													   float *__restrict__ wd, RunParams rp, GridDesc *__restrict__ grids, uint32_t *__restrict__ big_box)
 {
 	const int crop = rp.crop;
 	__shared__ uint32_t wave_cnt[4];
@@ -185,21 +268,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 	CloudDesc &d = descs[pair * MULLS_NC + cls];
 	const uint32_t n0 = side ? d.tgt_n0 : ((rp.undistort && cls != 5) ? d.sd_n0 : d.src_n0);
 	const uint32_t off = side ? d.tgt_off : d.src_off;
+	if (side && d.big_slot)
+	{
+		// cropped by k_crop_big_* (many workgroups); this one only arms the cloud's bounding-box keys
+		if (threadIdx.x < 6)
+			big_box[(d.big_slot - 1u) * 6u + threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+		return;
+	}
 	double lo[3], hi[3];
 	if (crop)
-	{
-		for (int k = 0; k < 3; k++)
-		{
-			uint32_t kmin = bbox[pair * 6 + k], kmax = bbox[pair * 6 + 3 + k];
-			// an empty union keeps (+DBL_MAX, -DBL_MAX) like CloudUtility::merge_bbx (utility.hpp:867-884)
-			double mmin = (kmin == 0xffffffffu && kmax == 0u) ? 1.7976931348623157e308 : (double)ord2f(kmin);
-			double mmax = (kmin == 0xffffffffu && kmax == 0u) ? -1.7976931348623157e308 : (double)ord2f(kmax);
-			double b1min = setup[pair].tgt_bound[k], b1max = setup[pair].tgt_bound[3 + k];
-			const float pad = 1.0f;
-			lo[k] = ((b1min > mmin) ? b1min : mmin) - pad; // get_intersection_bbx, utility.hpp:857-865
-			hi[k] = ((b1max < mmax) ? b1max : mmax) + pad;
-		}
-	}
+		crop_box(pair, bbox, setup, lo, hi);
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t running = 0;
 	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -224,9 +302,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			}
 		}
 		bool keep = in;
-		if (crop && in) // strict inequalities, float coordinate promoted to double (cfilter.hpp:959-961)
-			keep = (double)p.x > lo[0] && (double)p.x < hi[0] && (double)p.y > lo[1] && (double)p.y < hi[1] && (double)p.z > lo[2] &&
-				   (double)p.z < hi[2];
+		if (crop && in)
+			keep = crop_keep(p, lo, hi);
 		const unsigned long long bal = __ballot(keep);
 		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
 		__syncthreads();
@@ -286,58 +363,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 				lo3[k] = fminf(fminf(box_red[0][k], box_red[1][k]), fminf(box_red[2][k], box_red[3][k]));
 				hi3[k] = fmaxf(fmaxf(box_red[0][3 + k], box_red[1][3 + k]), fmaxf(box_red[2][3 + k], box_red[3][3 + k]));
 			}
-			GridDesc g;
-			g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
-			g.h = MULLS_GRID_H0;
-			g.nx = g.ny = g.nz = 1;
-			g.ncell = 0;
-			g.wpr = 1;
-			g.nocc = 0;
-			uint32_t nwords = 1;
-			if (running > 0 && rp.bm_h0 > 0.0f)
-			{
-				// global-memory tier: occupancy bitmap over fine cells; rows are padded to whole 64-cell words
-				g.h = rp.bm_h0;
-				if (rp.bm_auto) // points lie on surfaces: mean spacing ~ sqrt(footprint / count); measured optimum 0.25 m (1 M points) .. 0.7 m (5 k)
-					g.h = fminf(fmaxf(sqrtf((hi3[0] - lo3[0]) * (hi3[1] - lo3[1]) / (float)running), rp.bm_h0), 2.8f * rp.bm_h0);
-				for (;;)
-				{
-					g.inv_h = 1.0f / g.h;
-					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
-					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
-					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
-					g.wpr = (g.nx + 63u) >> 6;
-					if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
-						break;
-					g.h *= 1.25f;
-				}
-				nwords = g.ny * g.nz * g.wpr;
-			}
-			else if (running > 0)
-				for (;;)
-				{
-					g.inv_h = 1.0f / g.h;
-					// same float expression as grid_cell() so that the largest coordinate lands in the last cell
-					g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
-					g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
-					g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
-					if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
-						break;
-					g.h *= 1.25f;
-				}
-			else
-				g.inv_h = 1.0f;
-			// cell tables are laid out over the USED classes only: slot = pair * n_used + rank of this class among them
-			uint32_t n_used = 0, rank = 0;
-			for (uint32_t c = 0; c < MULLS_NC; c++)
-			{
-				if (c < cls && rp.used[c])
-					rank++;
-				n_used += rp.used[c] ? 1u : 0u;
-			}
-			g.ncell = (running > 0 && rp.used[cls]) ? (rp.bm_h0 > 0.0f ? nwords : g.nx * g.ny * g.nz) : 0u;
-			g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
-			grids[pair * MULLS_NC + cls] = g;
+			grids[pair * MULLS_NC + cls] = make_grid(lo3, hi3, running, rp, pair, cls);
 		}
 	}
 	if (threadIdx.x == 0)
@@ -353,6 +379,141 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			d.valid_next = 0;
 			d.n_valid = 0;
 		}
+	}
+}
+
+// Setup 2, target class clouds beyond MULLS_BIG_CLOUD points (scan-to-map against a large local map): one workgroup per
+// 4096-point segment instead of one per cloud (a single CU's memory bandwidth made a 400 k-point crop take 1.7 ms).
+// count -> per-cloud scan of the segment counts (+ bounding box -> grid descriptor) -> scatter; same stable order.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
+																 const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
+																 const float4 *__restrict__ stage, RunParams rp, uint32_t *__restrict__ seg_cnt,
+																 uint32_t *__restrict__ big_box)
+{
+	__shared__ uint32_t red4[4];
+	const Job sg = segs[blockIdx.x]; // count = big slot
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	double lo[3], hi[3];
+	if (rp.crop)
+		crop_box(sg.pair, bbox, setup, lo, hi);
+	uint32_t mine = 0;
+	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+	for (uint32_t k = 0; k < MULLS_SEG; k += MULLS_BLOCK)
+	{
+		const uint32_t i = sg.start + k + threadIdx.x;
+		if (i < d.tgt_n0)
+		{
+			const float4 p = stage[(size_t)(d.tgt_stage + i) * 3];
+			if (!rp.crop || crop_keep(p, lo, hi))
+			{
+				mine++;
+				bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+				bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+			}
+		}
+	}
+	for (int k = 0; k < 3; k++)
+	{
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
+			bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
+		}
+		if ((threadIdx.x & 63) == 0 && bmin[k] <= bmax[k])
+		{
+			atomicMin(&big_box[sg.count * 6u + k], f2ord(bmin[k]));
+			atomicMax(&big_box[sg.count * 6u + 3 + k], f2ord(bmax[k]));
+		}
+	}
+	const uint32_t total = block_sum_u32(mine, red4);
+	if (threadIdx.x == 0)
+		seg_cnt[blockIdx.x] = total;
+}
+
+// one wave per big cloud: segment counts -> segment bases, cloud size, grid descriptor
+__global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ clouds, CloudDesc *__restrict__ descs, RunParams rp,
+													   uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ big_box,
+													   GridDesc *__restrict__ grids)
+{
+	const Job bc = clouds[blockIdx.x]; // start = first segment, count = number of segments
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < bc.count; base += 64)
+	{
+		const uint32_t s = base + threadIdx.x;
+		const uint32_t v = s < bc.count ? seg_cnt[bc.start + s] : 0u;
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if ((int)threadIdx.x >= off)
+				incl += o;
+		}
+		if (s < bc.count)
+			seg_cnt[bc.start + s] = running + incl - v;
+		running += __shfl(incl, 63);
+	}
+	if (threadIdx.x == 0)
+	{
+		descs[bc.pair * MULLS_NC + bc.cls].tgt_n = running;
+		if (grids)
+		{
+			float lo3[3], hi3[3];
+			for (int k = 0; k < 3; k++)
+			{
+				lo3[k] = running ? ord2f(big_box[blockIdx.x * 6u + k]) : __builtin_inff();
+				hi3[k] = running ? ord2f(big_box[blockIdx.x * 6u + 3 + k]) : -__builtin_inff();
+			}
+			grids[bc.pair * MULLS_NC + bc.cls] = make_grid(lo3, hi3, running, rp, bc.pair, bc.cls);
+		}
+	}
+}
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
+																   const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
+																   const float4 *__restrict__ stage, RunParams rp,
+																   const uint32_t *__restrict__ seg_base, float4 *__restrict__ tpos,
+																   float4 *__restrict__ tnrm)
+{
+	__shared__ uint32_t wave_cnt[4];
+	const Job sg = segs[blockIdx.x];
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	double lo[3], hi[3];
+	if (rp.crop)
+		crop_box(sg.pair, bbox, setup, lo, hi);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = seg_base[blockIdx.x];
+	for (uint32_t k = 0; k < MULLS_SEG; k += MULLS_BLOCK)
+	{
+		const uint32_t i = sg.start + k + threadIdx.x;
+		bool keep = false;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		if (i < d.tgt_n0)
+		{
+			const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
+			const float4 a = rec[0], b = rec[1], c = rec[2];
+			p = make_float4(a.x, a.y, a.z, c.x);
+			q = make_float4(b.x, b.y, b.z, c.y);
+			keep = !rp.crop || crop_keep(p, lo, hi);
+		}
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads();
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			tpos[d.tgt_off + running + wbase + before] = p;
+			tnrm[d.tgt_off + running + wbase + before] = q;
+		}
+		running += total;
 	}
 }
 
@@ -747,7 +908,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	const float4 p = tpos[d.tgt_off + t];
 	const uint32_t bit = bm_bit(g, p.x, p.y, p.z);
-	atomicOr(&bm[g.cell_off + (bit >> 6)], 1ull << (bit & 63u));
+	unsigned long long *word = &bm[g.cell_off + (bit >> 6)];
+	const unsigned long long b = 1ull << (bit & 63u);
+	if (!(__builtin_nontemporal_load(word) & b)) // dense maps put tens of points in a cell: most find their bit set already
+		atomicOr(word, b);
 }
 
 // exclusive scan of a uint32 sequence produced by `value(i)`, one 1024-lane workgroup, four items per lane and trip
@@ -2095,11 +2259,20 @@ void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const Clo
 }
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
-				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids)
+				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids, uint32_t nbig_segs, const Job *big_segs, uint32_t nbig_clouds,
+				 const Job *big_clouds, uint32_t *seg_cnt, uint32_t *big_box)
 {
-	if (npairs)
-		hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm,
-						   tpos, tnrm, flag, match, wd, rp, grids);
+	if (!npairs)
+		return;
+	hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm, tpos,
+					   tnrm, flag, match, wd, rp, grids, big_box);
+	if (nbig_clouds)
+	{
+		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, big_box);
+		hipLaunchKernelGGL(k_crop_big_scan, dim3(nbig_clouds), dim3(64), 0, st, big_clouds, descs, rp, seg_cnt, big_box, grids);
+		hipLaunchKernelGGL(k_crop_big_scatter, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, tpos,
+						   tnrm);
+	}
 }
 void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
 				 float4 *tpos, float4 *tnrm)

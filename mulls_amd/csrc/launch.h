@@ -10,7 +10,8 @@ void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const Clo
 					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp);
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
-				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids);
+				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids, uint32_t nbig_segs, const Job *big_segs, uint32_t nbig_clouds,
+				 const Job *big_clouds, uint32_t *seg_cnt, uint32_t *big_box);
 void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
 				 float4 *tpos, float4 *tnrm);
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
