@@ -48,3 +48,38 @@ def test_hip_reproduces_golden(ctx, name):
     pair, P, z = mg.load(name)
     r = ctx.icp(pair, P, trace_cap=64)[0]
     check(r, z, exact=False)
+
+
+# ---- local map: tests/golden/map_update_small.npz, written by the reference's own map_manager.cpp lines ----
+spec_m = importlib.util.spec_from_file_location("make_map_golden", os.path.join(HERE, "golden", "make_map_golden.py"))
+mmg = importlib.util.module_from_spec(spec_m)
+spec_m.loader.exec_module(mmg)
+
+
+def check_map(z, k, clouds, appended, rep):
+    for c in range(6):
+        assert np.array_equal(mmg.table(clouds[c]), z["map%d_%d" % (k, c)], equal_nan=True), (k, c)
+        assert np.array_equal(mmg.table(appended[c]), z["app%d_%d" % (k, c)], equal_nan=True), (k, c)
+    assert list(rep.local_bound) + list(rep.bound) == list(z["bounds%d" % k])
+
+
+def test_oracle_reproduces_map_golden():
+    from oracle import pyoracle
+
+    z, fr, P = mmg.load()
+    assert int(z["removed1"]) > 0
+    clouds, pose = [c.copy() for c in fr[0][0]], fr[0][1]
+    for k in range(1, len(fr)):
+        clouds, appended, rep = pyoracle.map_update(clouds, pose, fr[k][0], fr[k][1], P)
+        pose = fr[k][1]
+        check_map(z, k, clouds, appended, rep)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_map_golden(ctx_auto):
+    z, fr, P = mmg.load()
+    dev = ctx_auto.local_map(fr[0][0], fr[0][1])
+    for k in range(1, len(fr)):
+        rep = dev.update(fr[k][0], fr[k][1], P)
+        check_map(z, k, [dev.download(c) for c in range(6)], [dev.frame_download(c) for c in range(6)], rep)
+    dev.close()
