@@ -129,6 +129,7 @@ struct RunParams
 	uint32_t debug_stop;	// diagnostics only (env MULLS_DEBUG_STOP): 1 = k_nn_lds returns after the transform, 2 = after staging
 	uint32_t cell_stride;	// entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned), >= grid_maxcells + 1
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
+	float grid_h0;		// LDS tier: preferred cell edge (MULLS_GRID_H0; grows until the cloud's box fits grid_maxcells)
 	float bm_h0;		// > 0: global-memory tier — k_crop sizes occupancy-bitmap grids from this cell edge (grid_maxcells = word budget)
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

@@ -606,6 +606,9 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += rp.used[c];
 	rp.bm_h0 = 0.0f;
+	rp.grid_h0 = MULLS_GRID_H0;
+	if (const char *e = std::getenv("MULLS_GRID_H0")) // diagnostics
+		rp.grid_h0 = std::max(0.05f, (float)std::atof(e));
 	if (tier == 2)
 	{
 		rp.grid_maxcells = lds_cells_for(lds_cap);

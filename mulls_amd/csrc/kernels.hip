@@ -197,7 +197,7 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 {
 	GridDesc g;
 	g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
-	g.h = MULLS_GRID_H0;
+	g.h = rp.grid_h0;
 	g.nx = g.ny = g.nz = 1;
 	g.ncell = 0;
 	g.wpr = 1;
