@@ -17,6 +17,9 @@ struct mulls_ctx
 {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream2 = nullptr; // second sub-batch of a large batch iterates here, so that its latency-bound filter / accumulate
+								   // kernels overlap the issue-bound search of the other sub-batch
+	hipEvent_t ev_setup = nullptr; // setup done on `stream` -> stream2 may start
 	std::string err;
 	bool profiling = false;
 	mulls_profile prof{};

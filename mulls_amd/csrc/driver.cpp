@@ -251,11 +251,11 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 // Wait until k_finish has published the current epoch.  The host spins on the pinned word (a few microseconds of latency
 // instead of an interrupt-driven stream synchronisation); a stalled device is caught by falling back to
 // hipStreamSynchronize, which also surfaces asynchronous HIP errors.
-int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last = nullptr);
+int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last = nullptr, hipStream_t stream = nullptr);
 int wait_epoch(mulls_ctx *ctx, mulls_batch *B) { return wait_epoch_word(ctx, B->epoch_h, B->epoch); }
 // `last`: while profiling, the event recorded behind the k_finish that publishes `want` — waiting on it (instead of the
 // whole stream) leaves the other sub-batch's kernels running
-int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last)
+int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last, hipStream_t stream)
 {
 	const auto t0 = std::chrono::steady_clock::now();
 	bool seen = false;
@@ -282,7 +282,7 @@ int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipE
 		if (e == hipSuccess)
 			return MULLS_OK;
 	}
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(stream ? stream : ctx->stream));
 	if (*word != want)
 	{
 		ctx->err = "device did not publish the iteration epoch";
@@ -686,6 +686,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 struct EvTimer
 {
 	mulls_ctx *ctx;
+	hipStream_t stream = nullptr; // where its events are recorded (default: ctx->stream)
 	int base = 0; // first event of this timer's set in ctx->ev
 	int used = 0;
 	double *slot[5];
@@ -694,13 +695,13 @@ struct EvTimer
 		if (!ctx->profiling)
 			return;
 		slot[used / 2] = acc;
-		(void)hipEventRecord(ctx->ev[base + used], ctx->stream);
+		(void)hipEventRecord(ctx->ev[base + used], stream ? stream : ctx->stream);
 	}
 	void end()
 	{
 		if (!ctx->profiling)
 			return;
-		(void)hipEventRecord(ctx->ev[base + used + 1], ctx->stream);
+		(void)hipEventRecord(ctx->ev[base + used + 1], stream ? stream : ctx->stream);
 		used += 2;
 	}
 	hipEvent_t last() const { return (ctx->profiling && used) ? ctx->ev[base + used - 1] : nullptr; }
@@ -754,7 +755,9 @@ extern "C"
 			return MULLS_E_NO_DEVICE;
 		mulls_ctx *ctx = new mulls_ctx();
 		ctx->device = device;
-		if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+		if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+			hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+			hipEventCreateWithFlags(&ctx->ev_setup, hipEventDisableTiming) != hipSuccess)
 		{
 			delete ctx;
 			return MULLS_E_NO_DEVICE;
@@ -777,6 +780,10 @@ extern "C"
 		for (auto &e : ctx->ev)
 			if (e)
 				(void)hipEventDestroy(e);
+		if (ctx->ev_setup)
+			(void)hipEventDestroy(ctx->ev_setup);
+		if (ctx->stream2)
+			(void)hipStreamDestroy(ctx->stream2);
 		if (ctx->stream)
 			(void)hipStreamDestroy(ctx->stream);
 		delete ctx;
@@ -1007,6 +1014,7 @@ extern "C"
 			uint32_t *epoch_ctr = nullptr;
 			volatile uint32_t *word = nullptr;
 			uint32_t *word_dev = nullptr, *ticket = nullptr;
+			hipStream_t st = nullptr;
 			EvTimer evt{nullptr};
 		};
 		int nsub = n >= 2048 ? 2 : 1; // below that the half-size launches cost more (k_nn_lds tail) than the overlap returns
@@ -1033,6 +1041,21 @@ extern "C"
 			S.ticket = B->ticket + 16 * k;
 			S.evt.ctx = ctx;
 			S.evt.base = 10 * k;
+			S.st = ctx->stream;
+		}
+		// two streams: the second sub-batch's filter / accumulate kernels (latency-bound, few registers and no LDS to speak of)
+		// run under the first one's search (issue-bound, one workgroup per CU) and vice versa
+		// Opt-in (MULLS_TWO_STREAMS=1): measured +4.8 % registrations/s at 4096 pairs, but the two searches then share the CUs and
+		// every kernel's own duration doubles, which would blur the per-kernel accounting bench.py and the profiles report.
+		bool two_streams = false;
+		if (const char *e = std::getenv("MULLS_TWO_STREAMS"))
+			two_streams = nsub == 2 && std::atoi(e) != 0;
+		if (two_streams)
+		{
+			subs[1].st = ctx->stream2;
+			subs[1].evt.stream = ctx->stream2;
+			HIPCHK(ctx, hipEventRecord(ctx->ev_setup, ctx->stream));
+			HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_setup, 0));
 		}
 		// the setup events were recorded on sub-batch 0's set
 		subs[0].evt.used = evt.used;
@@ -1043,6 +1066,7 @@ extern "C"
 
 		// queue one iteration (search, filter, accumulation, publication) of a sub-batch; 0 = nothing left to do for it
 		auto launch = [&](Sub &S) -> int {
+			hipStream_t st = S.st;
 			bool any_active = false, any_resid = false;
 			for (int p = S.lo; p < S.hi; p++)
 			{
@@ -1256,14 +1280,27 @@ extern "C"
 				return rc;
 		for (;;)
 		{
-			Sub *next = nullptr; // stream order: the sub-batch queued first publishes first
+			// whichever sub-batch in flight publishes first (one stream: the one queued first; two streams: either)
+			bool any = false;
 			for (int k = 0; k < nsub; k++)
-				if (subs[k].inflight && (!next || subs[k].seq < next->seq))
-					next = &subs[k];
-			if (!next)
+				any |= subs[k].inflight;
+			if (!any)
 				break;
 			const auto t_wait0 = std::chrono::steady_clock::now();
-			if (wait_epoch_word(ctx, next->word, *next->epoch_ctr, next->evt.last()) != MULLS_OK)
+			Sub *next = nullptr;
+			for (uint64_t spins = 0; !next; spins++)
+			{
+				for (int k = 0; k < nsub && !next; k++)
+					if (subs[k].inflight && *subs[k].word == *subs[k].epoch_ctr)
+						next = &subs[k];
+				if (!next && (spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() > 2.0)
+				{
+					for (int k = 0; k < nsub; k++) // something is wrong: fall back to a blocking wait on the oldest launch
+						if (subs[k].inflight && (!next || subs[k].seq < next->seq))
+							next = &subs[k];
+				}
+			}
+			if (wait_epoch_word(ctx, next->word, *next->epoch_ctr, next->evt.last(), next->st) != MULLS_OK)
 				return MULLS_E_HIP;
 			ctx->prof.ms_host_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() * 1e3;
 			next->evt.collect();
@@ -1273,6 +1310,8 @@ extern "C"
 		}
 
 		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (two_streams)
+			HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
 		const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
 		for (int p = 0; p < n; p++)
 		{
