@@ -131,5 +131,6 @@ struct RunParams
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
 	float grid_h0;		// LDS tier: preferred cell edge (MULLS_GRID_H0; grows until the cloud's box fits grid_maxcells)
 	float bm_h0;		// > 0: global-memory tier — k_crop sizes occupancy-bitmap grids from this cell edge (grid_maxcells = word budget)
+	uint32_t lds_dedup;	// LDS tier with class-level jobs: the duplicate rule is resolved inside k_nn_lds (winner table in LDS), losers get nn_idx = -1
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

@@ -609,9 +609,19 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	rp.grid_h0 = MULLS_GRID_H0;
 	if (const char *e = std::getenv("MULLS_GRID_H0")) // diagnostics
 		rp.grid_h0 = std::max(0.05f, (float)std::atof(e));
+	rp.lds_dedup = 0;
 	if (tier == 2)
 	{
 		rp.grid_maxcells = lds_cells_for(lds_cap);
+		// class-level jobs (one workgroup sees every query of a class cloud): keep the duplicate table in LDS if 4 B per target
+		// still leave a useful cell budget next to the staged cloud
+		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
+		const long left = 160L * 1024L - 64L - (long)MULLS_SRC_PER_BLOCK * 16L - (long)lds_cap * 18L;
+		if (class_level && !rp.normal_shooting && left / 2 - 8 >= 8192 && !std::getenv("MULLS_NO_LDS_DEDUP")) // k_nn_shoot uses the global table
+		{
+			rp.lds_dedup = 1;
+			rp.grid_maxcells = (uint32_t)std::min<long>(left / 2 - 8, (long)MULLS_MAXCELLS);
+		}
 		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
 	}
 	else if (tier == 1)

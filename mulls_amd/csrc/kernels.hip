@@ -1390,6 +1390,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	float *X = reinterpret_cast<float *>(qpos + MULLS_SRC_PER_BLOCK), *Y = X + cap, *Z = Y + cap; // [cap] each
 	uint16_t *IDX = reinterpret_cast<uint16_t *>(Z + cap);				  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
+	uint32_t *W = reinterpret_cast<uint32_t *>(CS + ((rp.grid_maxcells + 8u) & ~1u)); // [cap] lowest source index matched to each target (lds_dedup)
 
 	// one workgroup per (pair, class): the target class cloud is staged ONCE and every 512-query chunk of the source
 	// class cloud is searched against it (the first version staged it once per chunk: 2.3x the algorithmic HBM bytes,
@@ -1458,6 +1459,10 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		}
 	}
 
+	const bool dedup = rp.lds_dedup != 0u && called && alive_cur >= 500u;
+	if (dedup)
+		for (uint32_t t = threadIdx.x; t < tgt_n; t += MULLS_LDS_BLOCK)
+			W[t] = 0xffffffffu;
 	const LdsGrid L = {X, Y, Z, IDX, CS};
 	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
 	const double maxd = (double)r;
@@ -1564,11 +1569,27 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				if (matched)
 				{
 					matched_cnt++;
-					if (gate)
+					if (dedup)
+						atomicMin(&W[bi], s); // this workgroup sees every query of the class cloud: the duplicate table stays on chip
+					else if (gate)
 						atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
 				}
 			}
 		}
+	}
+	if (dedup)
+	{
+		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched,
+		// which is what k_filter does with them anyway (it skips its winner-table check when rp.lds_dedup is set)
+		__threadfence_block();
+		__syncthreads();
+		for (uint32_t s = job.start + threadIdx.x; s < q_end; s += MULLS_LDS_BLOCK)
+			if (flag[d.src_off + s] & MULLS_F_ALIVE)
+			{
+				const int m = nn_idx[d.src_off + s];
+				if (m >= 0 && W[m] != s)
+					nn_idx[d.src_off + s] = -1;
+			}
 	}
 	for (int off = 32; off > 0; off >>= 1)
 		matched_cnt += __shfl_down(matched_cnt, off);
@@ -1748,7 +1769,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 		{
 			m = nn_idx[g];
 			valid = m >= 0;
-			if (gate && (m < 0 || winner[d.tgt_off + m] != (key_hi | (unsigned long long)s)))
+			if (gate && (m < 0 || (!rp.lds_dedup && winner[d.tgt_off + m] != (key_hi | (unsigned long long)s))))
 			{
 				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
 				valid = false;
@@ -2298,9 +2319,10 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 	hipLaunchKernelGGL(k_bm_starts, dim3(npairs * MULLS_NC), dim3(1024), 0, st, descs, grids, rp, cnt, cell_start);
 	hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cell_start, tsorted);
 }
-size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells)
+size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 {
-	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)cap * 14u + ((size_t)maxcells + 8u) * 2u;
+	// query block, planar points + index, cell table, and (lds_dedup) the on-chip duplicate table
+	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx,
@@ -2314,7 +2336,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 		attr_set = true;
 	}
 	if (njobs)
-		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells), st, jobs, descs, states, rp, spos, snrm, grids,
+		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, rp.lds_dedup != 0u), st, jobs, descs, states, rp, spos, snrm, grids,
 						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, cap);
 	return 0;
 }
