@@ -1110,7 +1110,7 @@ extern "C"
 				if (tier == 2)
 				{
 					if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
-									  B->flag, B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
+									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 						return MULLS_E_HIP;
@@ -1125,7 +1125,8 @@ extern "C"
 					launch_nn_shoot(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 				ev.end();
 				ev.begin(&ctx->prof.ms_filter);
-				launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
+				if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
+					launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
 				ev.end();
 				ctx->prof.launches_nn++;
 				if (&S == &subs[0])
@@ -1482,7 +1483,7 @@ extern "C"
 			if (tier == 2)
 			{
 				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells) != 0)
+								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells) != 0)
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
@@ -1490,7 +1491,8 @@ extern "C"
 							   B->nn_idx, B->nn_d2, B->winner);
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
+			if (!rp.lds_dedup)
+				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
 			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
@@ -1791,7 +1793,7 @@ extern "C"
 			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 			if (tier == 2)
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-							  B->nn_idx, B->nn_d2, B->winner, lds_cap, rp.grid_maxcells);
+							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
@@ -1799,7 +1801,8 @@ extern "C"
 				rc = MULLS_E_INVALID;
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
+			if (!rp.lds_dedup)
+				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
 						  B->winner);
 			const uint32_t off = B->descs_h[cls].src_off;
 			if (e == hipSuccess)

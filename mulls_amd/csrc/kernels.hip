@@ -1251,6 +1251,111 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Rejection chain of determine_corres after the search (cregistration.hpp:1755-1830), one source point.
+// `dedup_done`: the duplicate rule has been applied already (losers carry nn_idx = -1, k_nn_lds with rp.lds_dedup).
+struct FilterCtx
+{
+	bool gate, any_match, normal_check, dedup_done;
+	float max_sqr;	 // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	double cos_thre; // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
+	unsigned long long key_hi;
+};
+__device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc &d, uint32_t s, const float4 *__restrict__ snrm,
+											  const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, const int32_t *__restrict__ nn_idx,
+											  const float *__restrict__ nn_d2, int32_t *__restrict__ match, float *__restrict__ wd,
+											  const unsigned long long *__restrict__ winner, uint32_t &n_alive, uint32_t &n_valid)
+{
+	const uint32_t g = d.src_off + s;
+	const uint32_t f = flag[g];
+	if (!(f & MULLS_F_ALIVE))
+		return;
+	bool alive = true, valid;
+	int m;
+	if (F.any_match)
+	{
+		m = nn_idx[g];
+		valid = m >= 0;
+		if (F.gate && (m < 0 || (!F.dedup_done && winner[d.tgt_off + m] != (F.key_hi | (unsigned long long)s))))
+		{
+			alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+			valid = false;
+		}
+		if (valid)
+		{
+			const float dist = nn_d2[g];
+			valid = !(dist > F.max_sqr);
+			if (valid)
+			{
+				match[g] = m;
+				wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+			}
+		}
+	}
+	else if (F.gate)
+	{
+		alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+		valid = false;
+		m = -1;
+	}
+	else
+	{
+		// CorrespondenceRejectorDistance::getCorrespondences returned early on the empty input: the previous
+		// Corr_f is still in place (SURVEY B-4) and goes through the direction check again.
+		valid = (f & MULLS_F_VALID) != 0;
+		m = match[g];
+	}
+	if (valid && F.normal_check)
+	{
+		const float4 n1 = snrm[g], n2 = tnrm[d.tgt_off + m];
+		const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+		const float c = (float)fabs(dot);
+		if ((double)c < F.cos_thre)
+			valid = false;
+	}
+	flag[g] = (uint8_t)((alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u));
+	n_alive += alive ? 1u : 0u;
+	n_valid += valid ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
+														 const PairState *__restrict__ states, RunParams rp,
+														 const float4 *__restrict__ snrm, const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag,
+														 const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
+														 int32_t *__restrict__ match, float *__restrict__ wd,
+														 const unsigned long long *__restrict__ winner)
+{
+	__shared__ uint32_t red4[4];
+	const Job job = jobs[xcd_job(blockIdx.x, gridDim.x)];
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	if (!class_called(rp, d, job.cls))
+		return;
+	const float thr = ps.thr[job.cls];
+	// vertex correspondences skip the direction check (cregistration.hpp:1292)
+	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u, thr * thr, rp.cos_bearing,
+						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32};
+	uint32_t n_alive = 0, n_valid = 0;
+#pragma unroll
+	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	{
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		if (s < d.src_n)
+			filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, n_alive, n_valid);
+	}
+	const uint32_t ta = block_sum_u32(n_alive, red4);
+	const uint32_t tv = block_sum_u32(n_valid, red4);
+	if (threadIdx.x == 0)
+	{
+		if (ta)
+			atomicAdd(&d.alive_next, ta);
+		if (tv)
+			atomicAdd(&d.valid_next, tv);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Correspondence search, LDS grid tier — the default whenever every searched target class cloud holds at most
 // MULLS_LDS_MAXPTS points (the reference-default KITTI sizes).  Rationale (profiles/r01_c_pmc_grid.txt): the global-memory
 // grid tier is neither HBM- nor VALU-bound, it waits (69 % s_waitcnt) on chains of 64-B sector gathers with ~2 us
@@ -1382,8 +1487,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 															 const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															 float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
 															 const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
-															 const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
-															 unsigned long long *__restrict__ winner, uint32_t cap)
+															 uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+															 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
+															 float *__restrict__ wd, uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
@@ -1593,8 +1699,53 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	}
 	for (int off = 32; off > 0; off >>= 1)
 		matched_cnt += __shfl_down(matched_cnt, off);
-	if ((threadIdx.x & 63) == 0 && matched_cnt)
-		atomicAdd(&d.n_matched, matched_cnt);
+	if (!rp.lds_dedup)
+	{
+		if ((threadIdx.x & 63) == 0 && matched_cnt)
+			atomicAdd(&d.n_matched, matched_cnt);
+		return;
+	}
+	// Class-level jobs: this workgroup holds every correspondence of the class cloud, so the rejection chain (k_filter) runs
+	// right here while the results are still in cache — one launch and one pass over nn_idx / nn_d2 less per iteration.
+	if (!called)
+		return;
+	uint32_t *red = reinterpret_cast<uint32_t *>(lds_raw); // the query block is free now: [0..15] matched, [16..31] alive, [32..47] valid
+	__threadfence_block(); // this workgroup's nn_idx / nn_d2 / snrm stores, read back below by other lanes
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = matched_cnt;
+	__syncthreads();
+	uint32_t total_matched = 0;
+	for (int w = 0; w < MULLS_LDS_BLOCK / 64; w++)
+		total_matched += red[w];
+	const float thr = ps.thr[job.cls];
+	const FilterCtx F = {gate, total_matched > 0u, job.cls != 5, true, thr * thr, rp.cos_bearing, key_hi};
+	uint32_t n_alive = 0, n_valid = 0;
+	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += MULLS_LDS_BLOCK)
+		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, n_alive, n_valid);
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		n_alive += __shfl_down(n_alive, off);
+		n_valid += __shfl_down(n_valid, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		red[16 + (threadIdx.x >> 6)] = n_alive;
+		red[32 + (threadIdx.x >> 6)] = n_valid;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t ta = 0, tv = 0;
+		for (int w = 0; w < MULLS_LDS_BLOCK / 64; w++)
+		{
+			ta += red[16 + w];
+			tv += red[32 + w];
+		}
+		d.n_matched = total_matched; // k_finish reset it to 0 after the previous iteration
+		d.alive_next = ta;
+		d.valid_next = tv;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1726,99 +1877,6 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_shoot(const Job *__restrict_
 		matched_cnt += __shfl_down(matched_cnt, off);
 	if ((threadIdx.x & 63) == 0 && matched_cnt)
 		atomicAdd(&d.n_matched, matched_cnt);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Rejection chain of determine_corres after the search (cregistration.hpp:1755-1830).
-__global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
-														 const PairState *__restrict__ states, RunParams rp,
-														 const float4 *__restrict__ snrm, const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag,
-														 const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
-														 int32_t *__restrict__ match, float *__restrict__ wd,
-														 const unsigned long long *__restrict__ winner)
-{
-	__shared__ uint32_t red4[4];
-	const Job job = jobs[xcd_job(blockIdx.x, gridDim.x)];
-	const PairState &ps = states[job.pair];
-	if (!ps.active)
-		return;
-	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
-	if (!class_called(rp, d, job.cls))
-		return;
-	const bool gate = d.alive_cur >= 500u;
-	const bool any_match = d.n_matched > 0u;
-	const bool normal_check = job.cls != 5; // vertex correspondences skip the direction check (cregistration.hpp:1292)
-	const float thr = ps.thr[job.cls];
-	const float max_sqr = thr * thr;							   // CorrespondenceRejectorDistance::setMaximumDistance (float)
-	const double cos_thre = rp.cos_bearing;						   // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
-	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
-	uint32_t n_alive = 0, n_valid = 0;
-#pragma unroll
-	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
-	{
-		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
-		if (s >= d.src_n)
-			continue;
-		const uint32_t g = d.src_off + s;
-		uint32_t f = flag[g];
-		if (!(f & MULLS_F_ALIVE))
-			continue;
-		bool alive = true, valid;
-		int m;
-		if (any_match)
-		{
-			m = nn_idx[g];
-			valid = m >= 0;
-			if (gate && (m < 0 || (!rp.lds_dedup && winner[d.tgt_off + m] != (key_hi | (unsigned long long)s))))
-			{
-				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
-				valid = false;
-			}
-			if (valid)
-			{
-				const float dist = nn_d2[g];
-				valid = !(dist > max_sqr);
-				if (valid)
-				{
-					match[g] = m;
-					wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
-				}
-			}
-		}
-		else if (gate)
-		{
-			alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
-			valid = false;
-			m = -1;
-		}
-		else
-		{
-			// CorrespondenceRejectorDistance::getCorrespondences returned early on the empty input: the previous
-			// Corr_f is still in place (SURVEY B-4) and goes through the direction check again.
-			valid = (f & MULLS_F_VALID) != 0;
-			m = match[g];
-		}
-		if (valid && normal_check)
-		{
-			const float4 n1 = snrm[g], n2 = tnrm[d.tgt_off + m];
-			const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
-			const float c = (float)fabs(dot);
-			if ((double)c < cos_thre)
-				valid = false;
-		}
-		flag[g] = (uint8_t)((alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u));
-		n_alive += alive ? 1u : 0u;
-		n_valid += valid ? 1u : 0u;
-	}
-	const uint32_t ta = block_sum_u32(n_alive, red4);
-	const uint32_t tv = block_sum_u32(n_valid, red4);
-	if (threadIdx.x == 0)
-	{
-		if (ta)
-			atomicAdd(&d.alive_next, ta);
-		if (tv)
-			atomicAdd(&d.valid_next, tv);
-	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2325,8 +2383,8 @@ size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
-				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx,
-				  float *nn_d2, unsigned long long *winner, uint32_t cap, uint32_t maxcells)
+				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
+				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, uint32_t cap, uint32_t maxcells)
 {
 	static bool attr_set = false;
 	if (!attr_set)
@@ -2337,7 +2395,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	}
 	if (njobs)
 		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, rp.lds_dedup != 0u), st, jobs, descs, states, rp, spos, snrm, grids,
-						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, cap);
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, cap);
 	return 0;
 }
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
