@@ -189,12 +189,12 @@ def main():
                 "mean_iterations": float(np.mean(iters)),
             },
             "roofline": {
-                "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS)"
+                "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS + on-chip duplicate rule and rejection chain)"
                           if prof_acc["evals"] == 0 else "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
-                                "(profiles/r01_i_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide); null when the run differs from it",
+                                "(profiles/r01_j_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide; the launch includes the fused rejection chain); null when the run differs from it",
                 "avg_launch_ms": avg_ms, "launches": prof_acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "the search is an irregular exact query, bound by dependent LDS/L2 access latency and VALU issue, not by HBM "
                         "bandwidth (DESIGN.md section 4, profiles/r01_c_pmc_grid.txt); the HBM fraction is reported as the contract asks",
