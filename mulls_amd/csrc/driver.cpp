@@ -671,7 +671,6 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
 		if (rc == MULLS_OK)
 		{
-			HIPCHK(ctx, hipMemsetAsync(B->bm, 0, std::max<size_t>(words, 1) * sizeof(unsigned long long), st));
 			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, cells * sizeof(uint32_t), st));
 		}
 	}

@@ -896,6 +896,16 @@ __device__ __forceinline__ uint32_t bm_rank(const unsigned long long *bm, const 
 }
 } // namespace
 
+// only the words a cloud's grid really uses are cleared (the arena reserves the worst case per cloud)
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const GridDesc *__restrict__ grids, RunParams rp, unsigned long long *__restrict__ bm)
+{
+	if (!rp.used[blockIdx.x % MULLS_NC])
+		return;
+	const GridDesc g = grids[blockIdx.x];
+	for (uint32_t w = blockIdx.y * MULLS_BLOCK + threadIdx.x; w < g.ncell; w += gridDim.y * MULLS_BLOCK)
+		bm[g.cell_off + w] = 0ull;
+}
+
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
 														  const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 														  unsigned long long *__restrict__ bm)
@@ -2371,6 +2381,7 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 		return;
 	}
 	// global-memory tier: occupancy bitmap + ranks + counting sort by rank (cell_start holds the start positions)
+	hipLaunchKernelGGL(k_bm_clear, dim3(npairs * MULLS_NC, npairs >= 64 ? 4 : 64), dim3(MULLS_BLOCK), 0, st, grids, rp, bm);
 	hipLaunchKernelGGL(k_bm_mark, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm);
 	hipLaunchKernelGGL(k_bm_scan, dim3(npairs * MULLS_NC), dim3(1024), 0, st, grids, rp, bm, pf);
 	hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
