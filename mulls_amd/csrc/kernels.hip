@@ -1041,7 +1041,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS tier grid build: one workgroup per target class cloud (<= MULLS_LDS_MAXPTS points, <= MULLS_MAXCELLS cells).  The
+// LDS tier grid build: one workgroup per target class cloud (<= MULLS_LDS_MAXPTS points, <= MULLS_MAXCELLS cells).  Grids of
+// fewer than 16384 cells (the usual case) are counting-sorted with LDS atomics; otherwise the
 // cloud is sorted by (cell id, original index) with a bitonic network in LDS — packed 32-bit keys, cell id < 2^16,
 // index < 2^14 — then the cell table is filled by binary search of every cell id in the sorted keys.  Replaces the
 // count / scan / scatter kernels (global atomics on every point, 1.2 ms for 3072 clouds) for clouds that fit; the
@@ -1059,6 +1060,57 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 	const uint32_t n = d.tgt_n;
 	if (g.ncell == 0)
 		return;
+	if (g.ncell < 16384u)
+	{
+		// few enough cells for an on-chip histogram: counting sort with LDS atomics (a fraction of the bitonic network's passes).
+		// The order inside a cell is whatever the atomics give; every consumer breaks distance ties by original index.
+		__shared__ uint32_t wave_tot[MULLS_LDS_BLOCK / 64];
+		uint32_t *cnt = K; // [ncell + 1]
+		for (uint32_t c = threadIdx.x; c <= g.ncell; c += MULLS_LDS_BLOCK)
+			cnt[c] = 0u;
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < n; i += MULLS_LDS_BLOCK)
+		{
+			const float4 p = tpos[d.tgt_off + i];
+			atomicAdd(&cnt[grid_cell_id(g, p.x, p.y, p.z)], 1u);
+		}
+		__syncthreads();
+		// exclusive scan over the cells: consecutive cells per lane, wave scan, wave totals
+		const uint32_t per = (g.ncell + 1u + MULLS_LDS_BLOCK - 1u) / MULLS_LDS_BLOCK;
+		const uint32_t c0 = threadIdx.x * per, c1 = min(g.ncell + 1u, c0 + per);
+		uint32_t sum = 0;
+		for (uint32_t c = c0; c < c1; c++)
+			sum += cnt[c];
+		const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+		uint32_t incl = sum;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if (lane >= off)
+				incl += o;
+		}
+		if (lane == 63)
+			wave_tot[wave] = incl;
+		__syncthreads();
+		uint32_t before = incl - sum;
+		for (int w = 0; w < wave; w++)
+			before += wave_tot[w];
+		for (uint32_t c = c0; c < c1; c++)
+		{
+			const uint32_t v = cnt[c];
+			cnt[c] = before; // becomes the insertion cursor of the cell
+			cell_start[g.cell_off + c] = before;
+			before += v;
+		}
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < n; i += MULLS_LDS_BLOCK)
+		{
+			const float4 p = tpos[d.tgt_off + i];
+			const uint32_t pos = atomicAdd(&cnt[grid_cell_id(g, p.x, p.y, p.z)], 1u);
+			tsorted[d.tgt_off + pos] = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
+		}
+		return;
+	}
 	uint32_t npow = 64;
 	while (npow < n)
 		npow <<= 1;
