@@ -1054,7 +1054,7 @@ extern "C"
 		}
 		// two streams: the second sub-batch's filter / accumulate kernels (latency-bound, few registers and no LDS to speak of)
 		// run under the first one's search (issue-bound, one workgroup per CU) and vice versa
-		// Opt-in (MULLS_TWO_STREAMS=1): measured +4.8 % registrations/s at 4096 pairs, but the two searches then share the CUs and
+		// Opt-in (MULLS_TWO_STREAMS=1): measured +4 % registrations/s at 4096 pairs, but the two searches then share the CUs and
 		// every kernel's own duration doubles, which would blur the per-kernel accounting bench.py and the profiles report.
 		bool two_streams = false;
 		if (const char *e = std::getenv("MULLS_TWO_STREAMS"))
