@@ -1900,7 +1900,12 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_shoot(const Job *__restrict_
 			continue;
 		double min_dist = 1.7976931348623157e308;
 		int min_index = 0;
-		const int found = (int)min(10u, tgt_n);
+		// entries are filled from the front; with a NaN query (a singular solve upstream propagates NaNs, SURVEY B-11) no distance
+		// compares below infinity and nothing is found — the oracle's kd-tree returns an empty list there, too
+		int found = 0;
+#pragma unroll
+		for (int j = 0; j < 10; j++)
+			found += ki[j] != 0x7fffffff ? 1 : 0;
 #pragma unroll
 		for (int j = 0; j < 10; j++)
 			if (j < found)

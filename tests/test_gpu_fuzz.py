@@ -55,3 +55,28 @@ def test_random_option_points_match_oracle(ctx, pairs_small, block):
         compare(ro, rg)
         codes.add(ro.code)
     assert 1 in codes
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_options_large_batch_equals_single(ctx_auto, pairs_small, block):
+    """Batches big enough for class-level LDS jobs (duplicate rule and rejection chain inside the search kernel) and, from
+    2048 pairs, two sub-batches in flight: per-pair results must be bit-identical to the single-pair path (chunk-level
+    jobs, separate k_filter) for random option points, including the options that switch the fused path off."""
+    rng = np.random.default_rng(1300 + block)
+    n = [700, 1100, 2300][block]
+    pairs = []
+    for k in range(n):
+        base, T_gt = pairs_small[int(rng.integers(0, len(pairs_small)))]
+        pert = synth.se3(*rng.normal(0, 0.25, 3), *np.deg2rad(rng.normal(0, 0.6, 3)))
+        pairs.append(abi.PairData(base.tgt, base.src, init_guess=pert @ T_gt, tgt_bound=base.tgt_bound))
+    for trial in range(2):
+        P = random_params(rng)
+        if block == 0 and trial == 1:
+            P.normal_shooting_on = 1
+        rb = ctx_auto.icp_batch(pairs, P)
+        for i in rng.choice(n, 25, replace=False):
+            r1 = ctx_auto.icp(pairs[int(i)], P)[0]
+            assert (r1.code, r1.iters, list(r1.ncorr), r1.singular) == (rb[i].code, rb[i].iters, list(rb[i].ncorr), rb[i].singular), (trial, i)
+            assert np.array_equal(np.array(r1.T[:]), np.array(rb[i].T[:]), equal_nan=True), (trial, i)
+            assert np.array_equal(np.array(r1.info[:]), np.array(rb[i].info[:]), equal_nan=True), (trial, i)
+            assert r1.sigma == rb[i].sigma or (np.isnan(r1.sigma) and np.isnan(rb[i].sigma))

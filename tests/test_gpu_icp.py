@@ -226,3 +226,17 @@ def test_normal_shooting(ctx, pairs_small, used):
         ro = pyoracle.icp(pair, P, trace_cap=32)[0]
         rg = ctx.icp(pair, P, trace_cap=32)[0]
         compare(ro, rg)
+
+
+def test_normal_shooting_survives_nan_queries(ctx, pairs_small):
+    """A class set that leaves the normal matrix singular (facades only) makes the reference propagate inf / NaN into the
+    transform (SURVEY B-11); the next iteration's normal-shooting search then runs on NaN queries.  The 10-NN list stays
+    empty there (as in the oracle's kd-tree) — it used to be read as if it were full."""
+    P = abi.default_params(max_iter_num=6, dis_thre_unit=1.95, used_feature_type="001000", weight_strategy="0010", normal_shooting_on=1,
+                           normal_bearing=33.0, min_neccessary_corr_ratio=0.0)
+    for pair, _ in pairs_small:
+        ro = pyoracle.icp(pair, P, trace_cap=16)[0]
+        rg = ctx.icp(pair, P, trace_cap=16)[0]
+        compare(ro, rg)
+    rb = ctx.icp_batch([p for p, _ in pairs_small] * 40, P)
+    assert [r.code for r in rb[:3]] == [ctx.icp(p, P)[0].code for p, _ in pairs_small]
