@@ -1,5 +1,7 @@
 """Randomised differential test: seeded random points in the 23-dimensional option space of mm_lls_icp, on small pairs with
 random initial guesses, HIP (every search tier) against the oracle.  Same comparison as tests/test_gpu_icp.py::compare."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -80,3 +82,52 @@ def test_random_options_large_batch_equals_single(ctx_auto, pairs_small, block):
             assert np.array_equal(np.array(r1.T[:]), np.array(rb[i].T[:]), equal_nan=True), (trial, i)
             assert np.array_equal(np.array(r1.info[:]), np.array(rb[i].info[:]), equal_nan=True), (trial, i)
             assert r1.sigma == rb[i].sigma or (np.isnan(r1.sigma) and np.isnan(rb[i].sigma))
+
+
+def degenerate_pair(rng, kind):
+    """Small pathological inputs (finite values): the reference has no special cases for them, neither may the device."""
+    n_t, n_s = int(rng.integers(3, 900)), int(rng.integers(3, 700))
+
+    def cloud(n, spread, offset=0.0):
+        xyz = rng.normal(0, spread, (n, 3)) + offset
+        nrm = rng.normal(0, 1, (n, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        return abi.make_points(xyz, nrm, rng.uniform(0, 255, n))
+
+    if kind == "duplicates":  # many identical points: distance ties everywhere, the lowest target index must win
+        base = cloud(7, 3.0)
+        tgt = [base[rng.integers(0, 7, n_t)] for _ in range(6)]
+        src = [base[rng.integers(0, 7, n_s)] for _ in range(6)]
+    elif kind == "one_cell":  # everything inside a few centimetres
+        tgt = [cloud(n_t, 0.01) for _ in range(6)]
+        src = [cloud(n_s, 0.01) for _ in range(6)]
+    elif kind == "far_origin":  # coordinates around 1e5 m: float cell arithmetic at its coarsest
+        tgt = [cloud(n_t, 5.0, 1e5) for _ in range(6)]
+        src = [cloud(n_s, 5.0, 1e5) for _ in range(6)]
+    elif kind == "collinear":
+        def line(n):
+            t = rng.uniform(-20, 20, n)
+            return abi.make_points(np.column_stack([t, 0.5 * t, 0 * t]), np.tile([0, 0, 1.0], (n, 1)), rng.uniform(0, 255, n))
+        tgt = [line(n_t) for _ in range(6)]
+        src = [line(n_s) for _ in range(6)]
+    elif kind == "sparse_far":  # nothing within any search radius
+        tgt = [cloud(n_t, 2.0) for _ in range(6)]
+        src = [cloud(n_s, 2.0, 500.0) for _ in range(6)]
+    else:  # "ragged": empty and tiny clouds mixed with normal ones
+        sizes_t = rng.choice([0, 1, 2, 3, 50, 600], 6)
+        sizes_s = rng.choice([0, 1, 2, 3, 40, 550], 6)
+        tgt = [cloud(int(k), 4.0) if k else None for k in sizes_t]
+        src = [cloud(int(k), 4.0) if k else None for k in sizes_s]
+    return abi.PairData(tgt, src)
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "one_cell", "far_origin", "collinear", "sparse_far", "ragged"])
+def test_degenerate_inputs_match_oracle(ctx, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))  # str hashes are salted per process: not a seed
+    for k in range(10):
+        pair = degenerate_pair(rng, kind)
+        P = random_params(rng)
+        P.apply_motion_undistortion = 0  # needs time stamps in the curvature field
+        ro = pyoracle.icp(pair, P, trace_cap=32)[0]
+        rg = ctx.icp(pair, P, trace_cap=32)[0]
+        compare(ro, rg, x_tol=1e-6)  # these normal matrices are badly conditioned by construction

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL_T, TOL_R = 1e-7, 1e-7
 
 
-def compare(ro, rg, check_trace=True):
+def compare(ro, rg, check_trace=True, x_tol=1e-9):
     assert ro.code == rg.code and ro.iters == rg.iters
     assert list(ro.ncorr) == list(rg.ncorr)
     assert list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
@@ -41,10 +41,14 @@ def compare(ro, rg, check_trace=True):
             assert list(a.ncorr) == list(b.ncorr) and list(a.nsrc) == list(b.nsrc), k
             assert list(a.thr) == list(b.thr)
             if any(a.atpa[:]):
-                sa = np.abs(np.array(a.atpa[:])).max()
-                assert np.abs(np.array(a.atpa[:]) - np.array(b.atpa[:])).max() <= 1e-10 * sa
+                A, Bm = np.array(a.atpa[:]), np.array(b.atpa[:])
+                assert np.array_equal(np.isfinite(A), np.isfinite(Bm))  # 0/0 weights etc. turn up in the same places
+                fin = np.isfinite(A)
+                if fin.any():
+                    assert np.abs(A[fin] - Bm[fin]).max() <= 1e-10 * np.abs(A[fin]).max()
                 if np.isfinite(np.array(a.x[:])).all():
-                    assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() <= 1e-9
+                    # the solve amplifies the 1e-12 differences of the sums by the condition number of the normal matrix
+                    assert np.abs(np.array(a.x[:]) - np.array(b.x[:])).max() <= x_tol * max(1.0, np.abs(np.array(a.x[:])).max())
                 else:
                     assert not np.isfinite(np.array(b.x[:])).all()
 
