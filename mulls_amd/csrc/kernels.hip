@@ -191,6 +191,14 @@ __device__ __forceinline__ bool crop_keep(const float4 &p, const double lo[3], c
 {
 	return (double)p.x > lo[0] && (double)p.x < hi[0] && (double)p.y > lo[1] && (double)p.y < hi[1] && (double)p.z > lo[2] && (double)p.z < hi[2];
 }
+// cells along one axis for an extent and a cell edge — the same float expression as grid_cell(), so that the largest
+// coordinate lands in the last cell; an absurd extent (the bounding box only sees coordinates within 1e18 m)
+// saturates instead of overflowing the conversion, and the caller then grows the cell edge until the grid fits
+__device__ __forceinline__ uint32_t grid_dim(float extent, float inv_h)
+{
+	const float c = floorf(extent * inv_h);
+	return c >= 0.0f ? (uint32_t)fminf(c, 4.0e9f) + 1u : 1u; // also false for NaN
+}
 // grid descriptor of a cropped target cloud with bounding box [lo3, hi3] and `running` points
 __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi3[3], uint32_t running, const RunParams &rp, uint32_t pair,
 											   uint32_t cls)
@@ -212,9 +220,9 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 		for (;;)
 		{
 			g.inv_h = 1.0f / g.h;
-			g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
-			g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
-			g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+			g.nx = grid_dim(hi3[0] - g.ox, g.inv_h);
+			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
+			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
 			g.wpr = (g.nx + 63u) >> 6;
 			if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
 				break;
@@ -227,9 +235,9 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 		{
 			g.inv_h = 1.0f / g.h;
 			// same float expression as grid_cell() so that the largest coordinate lands in the last cell
-			g.nx = (uint32_t)floorf((hi3[0] - g.ox) * g.inv_h) + 1u;
-			g.ny = (uint32_t)floorf((hi3[1] - g.oy) * g.inv_h) + 1u;
-			g.nz = (uint32_t)floorf((hi3[2] - g.oz) * g.inv_h) + 1u;
+			g.nx = grid_dim(hi3[0] - g.ox, g.inv_h);
+			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
+			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
 			if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
 				break;
 			g.h *= 1.25f;
@@ -324,8 +332,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			{
 				tpos[dst] = p;
 				tnrm[dst] = q;
-				bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
-				bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				if (fabsf(p.x) <= 1.0e18f && fabsf(p.y) <= 1.0e18f && fabsf(p.z) <= 1.0e18f) // the grid covers the finite points; others clamp into its border cells
+				{
+					bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+					bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				}
 			}
 			else
 			{
@@ -407,8 +418,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 			if (!rp.crop || crop_keep(p, lo, hi))
 			{
 				mine++;
-				bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
-				bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				if (fabsf(p.x) <= 1.0e18f && fabsf(p.y) <= 1.0e18f && fabsf(p.z) <= 1.0e18f) // the grid covers the finite points; others clamp into its border cells
+				{
+					bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+					bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				}
 			}
 		}
 	}

@@ -131,3 +131,37 @@ def test_degenerate_inputs_match_oracle(ctx, kind):
         ro = pyoracle.icp(pair, P, trace_cap=32)[0]
         rg = ctx.icp(pair, P, trace_cap=32)[0]
         compare(ro, rg, x_tol=1e-6)  # these normal matrices are badly conditioned by construction
+
+
+@pytest.mark.timeout(90, method="thread")
+def test_non_finite_inputs_do_not_take_the_device_down(ctx, pairs_small):
+    """NaN / inf / 1e38 coordinates are outside the contract (results are unspecified), but every kernel must stay inside
+    its buffers and terminate: the grids are sized from the finite points only and saturate instead of overflowing."""
+    base = pairs_small[0][0]
+    rng = np.random.default_rng(5)
+
+    def poison(clouds, vals, fields):
+        out = []
+        for c in clouds:
+            c = c.copy()
+            if len(c) > 10:
+                for v in vals:
+                    for f in fields:
+                        c[f][rng.integers(0, len(c), 3)] = v
+            out.append(c)
+        return out
+
+    cases = [
+        abi.PairData(base.tgt, poison(base.src, [np.nan], "xyz")),
+        abi.PairData(poison(base.tgt, [np.nan], "xyz"), base.src),
+        abi.PairData(base.tgt, poison(base.src, [np.inf, -np.inf], "xyz")),
+        abi.PairData(poison(base.tgt, [np.inf, -np.inf], "xyz"), base.src, tgt_bound=base.tgt_bound),
+        abi.PairData(poison(base.tgt, [3e38, -3e38], "xyz"), base.src, tgt_bound=base.tgt_bound),
+        abi.PairData(poison(base.tgt, [np.nan], ["nx", "ny", "nz"]), poison(base.src, [np.nan], ["nx", "ny", "nz"])),
+    ]
+    for pair in cases:
+        for P in (abi.kitti_params(), abi.default_params(used_feature_type="111111", apply_intersection_filter=0),
+                  abi.default_params(normal_shooting_on=1)):
+            r = ctx.icp(pair, P)[0]
+            rb = ctx.icp_batch([pair] * 12, P)
+            assert r.code in (1, -1, -2, -3, 0) and all(x.code in (1, -1, -2, -3, 0) for x in rb)
