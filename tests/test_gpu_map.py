@@ -134,3 +134,38 @@ def test_scan_to_map_odometry_loop(ctx_auto):
             same_cloud(dev.download(c), host_map[c])
     assert rep.feature_point_num <= 4005
     dev.close()
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_update_sequences_match_oracle(ctx_auto, block):
+    """Seeded random sequences: frames with empty / tiny / duplicated class clouds, random radii, caps small enough to thin,
+    dynamic removal with every tree state, class sets with holes.  Device and oracle must agree bit for bit after every update."""
+    rng = np.random.default_rng(4200 + block)
+    frames = small_frames(100 + block, n_frames=5)
+
+    def mutate(clouds):
+        out = []
+        for c in clouds:
+            roll = rng.random()
+            if roll < 0.15:
+                out.append(c[:0])
+            elif roll < 0.3:
+                out.append(c[: int(rng.integers(1, 12))])
+            elif roll < 0.4:
+                out.append(np.concatenate([c, c[: len(c) // 2]]))  # exact duplicates
+            else:
+                out.append(c)
+        return out
+
+    def params(k):
+        used = "".join(rng.choice(["0", "1"], p=[0.25, 0.75]) for _ in range(6))
+        box = sorted(rng.uniform(-40, 40, 2)) + sorted(rng.uniform(-20, 20, 2)) + sorted(rng.uniform(-4, 8, 2))
+        return abi.map_params(used_feature_type=used, max_num_pts=int(rng.choice([300, 1500, 6000, 10**7])),
+                              kept_vertex_num=int(rng.choice([0, 50, 10**6])), local_map_radius=float(rng.uniform(15, 80)),
+                              map_based_dynamic_removal_on=int(rng.random() < 0.7), dynamic_removal_center_radius=float(rng.uniform(5, 40)),
+                              dynamic_dist_thre_min=float(rng.uniform(0.1, 0.6)), dynamic_dist_thre_max=float(rng.uniform(0.2, 3.0)),
+                              near_dist_thre=float(rng.uniform(0.0, 0.1)), rng_seed=int(rng.integers(0, 2**31)), tree_mode=int(rng.integers(0, 3)),
+                              tree_used="".join(rng.choice(["0", "1"]) for _ in range(6)), tree_box=[box[0], box[2], box[4], box[1], box[3], box[5]])
+
+    frames = [(mutate(fc), fp) for fc, fp in frames]
+    drive(ctx_auto, frames, params)[0].close()
