@@ -51,3 +51,56 @@ def test_4dof_global(ctx, pairs_small):
     assert ok_o == ok_g and best_o == best_g and rg_arr[0].iters == 12
     dt, dr = synth.pose_error(rg_arr[0].T_matrix(), ro.T_matrix())
     assert dt <= 1e-7 and dr <= 1e-7
+
+
+def _same(ro, rg, x_tol=1e-7):
+    assert ro.code == rg.code and ro.iters == rg.iters, (ro.code, rg.code, ro.iters, rg.iters)
+    assert list(ro.ncorr) == list(rg.ncorr) and list(ro.nsrc0) == list(rg.nsrc0) and list(ro.ntgt0) == list(rg.ntgt0)
+    To, Tg = ro.T_matrix(), rg.T_matrix()
+    assert np.array_equal(np.isnan(To), np.isnan(Tg))
+    if not np.isnan(To).any():
+        dt, dr = synth.pose_error(Tg, To)
+        assert dt <= x_tol and dr <= x_tol, (dt, dr)
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_3dof_ground_random_options(ctx, pairs_small, block):
+    """Seeded random option points and initial tilts for the ground-only variant, well-posed and degenerate inputs."""
+    from test_gpu_fuzz import degenerate_pair, random_params
+
+    rng = np.random.default_rng(7700 + block)
+    for k in range(10):
+        if k % 3 == 2:
+            pair = degenerate_pair(rng, ["duplicates", "one_cell", "collinear", "ragged", "sparse_far"][int(rng.integers(0, 5))])
+        else:
+            base, _ = pairs_small[int(rng.integers(0, len(pairs_small)))]
+            tilt = synth.se3(0, 0, rng.normal(0, 0.1), *np.deg2rad(rng.normal(0, 0.5, 2)), 0)
+            pair = abi.PairData(base.tgt, [pyoracle.transform(c, tilt) if c is not None and len(c) else c for c in base.src], tgt_bound=base.tgt_bound)
+        P = random_params(rng)
+        P.apply_motion_undistortion = 0
+        ro = pyoracle.icp_3dof_ground(pair, P, trace_cap=32)[0]
+        rg = ctx.icp_3dof_ground([pair], P, trace_cap=32)[0]
+        _same(ro, rg, x_tol=1e-6 if k % 3 == 2 else 1e-7)
+        assert ro.trace_len == rg.trace_len
+        for j in range(ro.trace_len):
+            assert list(ro.trace[j].ncorr) == list(rg.trace[j].ncorr), j
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_4dof_global_random(ctx, pairs_small, block):
+    rng = np.random.default_rng(8800 + block)
+    for k in range(4):
+        base, _ = pairs_small[int(rng.integers(0, len(pairs_small)))]
+        spin = synth.se3(*rng.normal(0, 0.3, 3), 0, 0, rng.uniform(-np.pi, np.pi))
+        pr = abi.PairData(base.tgt, [pyoracle.transform(c, spin) for c in base.src], tgt_bound=base.tgt_bound)
+        station = tuple(rng.normal(0, 1.0, 3))
+        step = float(rng.choice([20.0, 45.0, 72.0, 90.0, 180.0]))
+        kw = dict(max_iter_num=int(rng.integers(3, 15)), dis_thre_unit=float(rng.uniform(1.0, 3.0)))
+        (ro,), ok_o, best_o = pyoracle.icp_4dof_global(pr, step, station, **kw)
+        rg_arr, ok_g, best_g = ctx.icp_4dof_global(pr, step, station, **kw)
+        assert (ok_o, best_o) == (ok_g, best_g), (step, station)
+        assert ro.code == rg_arr[0].code and ro.iters == rg_arr[0].iters
+        if ok_o:
+            dt, dr = synth.pose_error(rg_arr[0].T_matrix(), ro.T_matrix())
+            assert dt <= 1e-7 and dr <= 1e-7
+            assert abs(ro.sigma - rg_arr[0].sigma) <= 1e-6
