@@ -165,3 +165,33 @@ def test_non_finite_inputs_do_not_take_the_device_down(ctx, pairs_small):
             r = ctx.icp(pair, P)[0]
             rb = ctx.icp_batch([pair] * 12, P)
             assert r.code in (1, -1, -2, -3, 0) and all(x.code in (1, -1, -2, -3, 0) for x in rb)
+
+
+EDGE_PARAMS = {
+    "zero_iterations": dict(max_iter_num=0),
+    "negative_iterations": dict(max_iter_num=-3),
+    "many_iterations": dict(max_iter_num=300, converge_translation=0.0, converge_rotation_d=0.0),
+    "zero_threshold": dict(dis_thre_unit=0.0, dis_thre_min=0.0),
+    "min_above_unit": dict(dis_thre_unit=0.5, dis_thre_min=2.0),
+    "growing_threshold": dict(dis_thre_update_rate=0.8, max_iter_num=12),
+    "zero_windows": dict(pt2pt_residual_window=0.0, pt2pl_residual_window=0.0, pt2li_residual_window=0.0),
+    "zero_balance": dict(z_xy_balanced_ratio=0.0),
+    "negative_bearing": dict(normal_bearing=-10.0),
+    "bearing_180": dict(normal_bearing=180.0, normal_shooting_on=1),
+    "nothing_used": dict(used_feature_type="000000"),
+    "only_vertex": dict(used_feature_type="000001"),
+    "odd_flags": dict(used_feature_type="1x1 01", weight_strategy="2a01"),
+    "zero_rate": dict(dis_thre_update_rate=0.0, max_iter_num=4),
+    "huge_threshold": dict(dis_thre_unit=400.0, dis_thre_min=100.0, max_iter_num=3),
+}
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("name", sorted(EDGE_PARAMS))
+def test_edge_parameter_values_match_oracle(ctx, pairs_small, name):
+    """Parameter values nobody would configure but the reference accepts without a check: same outcome on the device."""
+    P = abi.default_params(**EDGE_PARAMS[name])
+    for pair, _ in pairs_small[:2]:
+        ro = pyoracle.icp(pair, P, trace_cap=32)[0]
+        rg = ctx.icp(pair, P, trace_cap=32)[0]
+        compare(ro, rg, x_tol=1e-6)
