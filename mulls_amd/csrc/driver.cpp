@@ -46,7 +46,7 @@ struct mulls_batch
 	float4 *tmp_pos = nullptr, *tmp_nrm = nullptr;
 	float4 *spos = nullptr, *snrm = nullptr, *tpos = nullptr, *tnrm = nullptr;
 	uint8_t *flag = nullptr;
-	int32_t *match = nullptr, *nn_idx = nullptr;
+	int32_t *match = nullptr, *nn_idx = nullptr, *nn_hint = nullptr;
 	float *wd = nullptr, *nn_d2 = nullptr;
 	unsigned long long *winner = nullptr;
 	CloudDesc *descs = nullptr;
@@ -86,7 +86,7 @@ struct mulls_batch
 	std::string dev_key;			 // jobs_key of the tables currently resident on the device
 	size_t cap_jobs[6] = {}, cap_cells[2] = {};
 	// capacities (elements) of the grow-only arrays
-	size_t cap_stage = 0, cap_src[9] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
+	size_t cap_stage = 0, cap_src[10] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
 
 namespace
@@ -442,6 +442,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->nn_idx, &B->cap_src[6], so));
 	A(grow(ctx, &B->wd, &B->cap_src[7], so));
 	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so));
+	A(grow(ctx, &B->nn_hint, &B->cap_src[9], so));
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
 	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to));
@@ -832,7 +833,7 @@ extern "C"
 			return;
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
-		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->wd,
+		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
 					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
 		for (void *p : dev)
@@ -1109,7 +1110,7 @@ extern "C"
 				if (tier == 2)
 				{
 					if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
-									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells) != 0)
+									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 						return MULLS_E_HIP;
@@ -1482,7 +1483,7 @@ extern "C"
 			if (tier == 2)
 			{
 				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells) != 0)
+								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells) != 0)
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
@@ -1792,7 +1793,7 @@ extern "C"
 			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 			if (tier == 2)
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, lds_cap, rp.grid_maxcells);
+							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);

@@ -1449,112 +1449,87 @@ struct LdsGrid
 	const uint16_t *IDX, *CS;
 };
 
-// (distance, index) lexicographic minimum over the 16 lanes of a DPP row, VALU only (no LDS-crossbar shuffles):
-// quad xor-1, quad xor-2, half-row mirror, row mirror.  Result in every lane.
+// Search state of a query: (distance bits << 32) | target index.  Distances are sums of squares (>= +0, or NaN), so the
+// unsigned order of the key is the lexicographic (distance, index) order the tie rule asks for, NaN keys sort after
+// NNKEY_NONE and are never taken, and one 64-bit compare + two selects update the running minimum.
+typedef unsigned long long nnkey;
+#define NNKEY_NONE 0x7f800000ffffffffull
+__device__ __forceinline__ nnkey nn_key(float dist, uint32_t idx) { return ((nnkey)__float_as_uint(dist) << 32) | idx; }
+__device__ __forceinline__ float key_dist(nnkey k) { return __uint_as_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ bool key_found(nnkey k) { return (uint32_t)k != 0xffffffffu; }
+
+// minimum over the lanes of a sub-group, VALU only (DPP; no LDS-crossbar shuffles): quad xor-1, quad xor-2, half-row
+// mirror (8 lanes), row mirror (16 lanes).  Result in every lane.
 template <int CTRL>
-__device__ __forceinline__ void dpp_min_step(float &best, int &bi)
+__device__ __forceinline__ void dpp_min_step(nnkey &bk)
 {
-	const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), CTRL, 0xf, 0xf, false));
-	const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, false);
-	const bool take = oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi));
-	best = take ? ob : best;
-	bi = take ? oi : bi;
+	const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bk >> 32), CTRL, 0xf, 0xf, false);
+	const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bk, CTRL, 0xf, 0xf, false);
+	const nnkey o = ((nnkey)oh << 32) | ol;
+	bk = o < bk ? o : bk;
 }
-__device__ __forceinline__ void row16_min(float &best, int &bi)
+__device__ __forceinline__ void row16_min(nnkey &bk)
 {
-	dpp_min_step<0xB1>(best, bi);  // quad_perm [1,0,3,2]
-	dpp_min_step<0x4E>(best, bi);  // quad_perm [2,3,0,1]
+	dpp_min_step<0xB1>(bk);	 // quad_perm [1,0,3,2]
+	dpp_min_step<0x4E>(bk);	 // quad_perm [2,3,0,1]
 #if MULLS_LDS_GROUP >= 8
-	dpp_min_step<0x141>(best, bi); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
+	dpp_min_step<0x141>(bk); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
 #endif
 #if MULLS_LDS_GROUP == 16
-	dpp_min_step<0x140>(best, bi); // row_mirror: lanes i <-> 15 - i
+	dpp_min_step<0x140>(bk); // row_mirror: lanes i <-> 15 - i
 #endif
-}
-
-__device__ __forceinline__ void lds_eval(const LdsGrid &L, uint32_t t, float px, float py, float pz, float &best, int &bi)
-{
-	const float dx = px - L.X[t], dy = py - L.Y[t], dz = pz - L.Z[t];
-	const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
-	const int idx = (int)L.IDX[t];
-	if (dist < best || (dist == best && idx < bi))
-	{
-		best = dist;
-		bi = idx;
-	}
 }
 
 // Evaluate every staged target in the cells intersecting the cube [p - R, p + R] (same exactness argument as
-// grid_scan_box), optionally skipping one cell that has been swept already.  Candidate ranges (rows; the row of the
-// skipped cell splits in two) are taken three at a time; all lanes read the range bounds themselves (same address
-// within the sub-group: LDS broadcast), then the first candidate of each range is fetched before any is consumed.
-// When the box is just the skipped cell nothing is touched at all (the common case after the own-cell probe).
-#define MULLS_LDS_CHUNK 3
+// grid_scan_box).  The rows (x-runs of cells, contiguous in the sorted cloud) are taken four at a time: every lane of the
+// sub-group reads their bounds (same addresses: LDS broadcast), the four candidate ranges are laid end to end and the
+// sub-group strides over the concatenation, two candidates per lane in flight — the trip count is that of the total, not
+// the sum of the per-row round-ups, and the only per-row work is two table reads and a running sum.
+#define MULLS_LDS_CHUNK 4
 __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
-											  int skip_x, int skip_y, int skip_z, float &best, int &bi)
+											  nnkey &bk, bool own_done = false)
 {
 	const float Rm = R * 1.0001f + 1e-4f;
-	const int x0 = grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = grid_cell(px + Rm, g.ox, g.inv_h, g.nx);
+	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
 	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
 	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
-	if (x0 == x1 && y0 == y1 && z0 == z1 && x0 == skip_x && y0 == skip_y && z0 == skip_z)
-		return;
+	if (own_done && x1 - x0 == 1u && y0 == y1 && z0 == z1)
+		return; // the cube stays inside the query's own cell, which has been swept already
 	int cy = y0, cz = z0;
-	bool second_half = false; // the skipped cell's row is visited twice: cells left of it, then cells right of it
 	while (cz <= z1)
 	{
-		uint32_t lo[MULLS_LDS_CHUNK], hi[MULLS_LDS_CHUNK];
+		uint32_t lo[MULLS_LDS_CHUNK], pre[MULLS_LDS_CHUNK], acc = 0;
 #pragma unroll
 		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
 		{
 			const bool valid = cz <= z1;
 			const uint32_t row = ((uint32_t)(valid ? cz : z0) * g.ny + (uint32_t)cy) * g.nx;
-			const bool split = valid && cy == skip_y && cz == skip_z && skip_x >= x0 && skip_x <= x1;
-			const uint32_t a = (split && second_half) ? (uint32_t)skip_x + 1u : (uint32_t)x0;
-			const uint32_t e = (split && !second_half) ? (uint32_t)skip_x : (uint32_t)x1 + 1u;
-			lo[jj] = L.CS[row + a];
-			hi[jj] = valid ? (uint32_t)L.CS[row + e] : lo[jj];
-			if (split && !second_half)
-				second_half = true;
-			else
+			const uint32_t a = L.CS[row + x0], e = L.CS[row + x1];
+			lo[jj] = a - acc; // candidate f of the concatenation lives at lo[jj] + f while f < pre[jj]
+			acc += valid ? e - a : 0u;
+			pre[jj] = acc;
+			if (++cy > y1)
 			{
-				second_half = false;
-				if (++cy > y1)
-				{
-					cy = y0;
-					cz++;
-				}
+				cy = y0;
+				cz++;
 			}
 		}
-		float tx[MULLS_LDS_CHUNK], ty[MULLS_LDS_CHUNK], tz[MULLS_LDS_CHUNK];
-		uint32_t ti[MULLS_LDS_CHUNK];
-#pragma unroll
-		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
 		{
-			const uint32_t t = lo[jj] + sub;
-			const bool ok = t < hi[jj];
-			const uint32_t tt = ok ? t : 0u;
-			tx[jj] = L.X[tt];
-			ty[jj] = L.Y[tt];
-			tz[jj] = L.Z[tt];
-			ti[jj] = ok ? (uint32_t)L.IDX[tt] : 0xffffffffu;
+			const uint32_t f2 = f + MULLS_LDS_GROUP;
+			const bool ok2 = f2 < acc;
+			const uint32_t ff = ok2 ? f2 : f;
+			const uint32_t ta = f + (f < pre[0] ? lo[0] : f < pre[1] ? lo[1] : f < pre[2] ? lo[2] : lo[3]);
+			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : ff < pre[1] ? lo[1] : ff < pre[2] ? lo[2] : lo[3]);
+			const float ax = L.X[ta], ay = L.Y[ta], az = L.Z[ta], bx = L.X[tb], by = L.Y[tb], bz = L.Z[tb];
+			const uint32_t ia = L.IDX[ta], ib = L.IDX[tb];
+			float dx = px - ax, dy = py - ay, dz = pz - az;
+			const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia); // L2_Simple<float>, no FMA
+			dx = px - bx, dy = py - by, dz = pz - bz;
+			const nnkey kb = nn_key((dx * dx + dy * dy) + dz * dz, ib); // !ok2: the same candidate again, no effect
+			bk = ka < bk ? ka : bk;
+			bk = kb < bk ? kb : bk;
 		}
-#pragma unroll
-		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
-		{
-			const float dx = px - tx[jj], dy = py - ty[jj], dz = pz - tz[jj];
-			const float dist = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
-			const int idx = (int)ti[jj];
-			if (idx >= 0 && (dist < best || (dist == best && idx < bi)))
-			{
-				best = dist;
-				bi = idx;
-			}
-		}
-#pragma unroll
-		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++) // ranges holding more than 16 candidates
-			for (uint32_t t = lo[jj] + sub + MULLS_LDS_GROUP; t < hi[jj]; t += MULLS_LDS_GROUP)
-				lds_eval(L, t, px, py, pz, best, bi);
 	}
 }
 } // namespace
@@ -1565,7 +1540,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 															 const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
 															 uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 															 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
-															 float *__restrict__ wd, uint32_t cap)
+															 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
@@ -1653,6 +1628,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+	const bool use_hint = called && ps.iter > 0 && rp.debug_stop != 6u; // hints of this run exist from its second iteration on
 	uint32_t matched_cnt = 0;
 
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
@@ -1663,7 +1639,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		if (threadIdx.x < MULLS_SRC_PER_BLOCK)
 		{
 			const uint32_t s = chunk + threadIdx.x;
-			float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
 			if (s < q_end && (flag[d.src_off + s] & MULLS_F_ALIVE))
 			{
 				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
@@ -1672,12 +1648,27 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
 				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
 				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-				out.w = 1.0f;
 				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
 				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
 				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
 				spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
 				snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
+				// temporal coherence: the target this point found in the previous iteration is very likely still its nearest one.
+				// Its distance is an exact upper bound (any target point gives one), so the search below can skip the own-cell
+				// probe and sweep the cube of that radius straight away.  w: bound (squared), +inf = none, -1 = dead point.
+				out.w = __builtin_inff();
+				if (use_hint)
+				{
+					const uint32_t h = (uint32_t)nn_hint[d.src_off + s];
+					if (h < tgt_n)
+					{
+						const float4 t = tpos[d.tgt_off + h];
+						const float dx = out.x - t.x, dy = out.y - t.y, dz = out.z - t.z;
+						const float d0 = (dx * dx + dy * dy) + dz * dz;
+						if (d0 >= 0.0f)
+							out.w = d0;
+					}
+				}
 			}
 			qpos[threadIdx.x] = out;
 		}
@@ -1694,60 +1685,60 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			if (s >= q_end)
 				break;
 			const float4 q = qpos[k];
-			if (q.w == 0.0f)
+			if (q.w < 0.0f)
 				continue;
-			float best = __builtin_inff();
-			int bi = -1;
+			nnkey bk = NNKEY_NONE;
 			if (rp.debug_stop == 5u)
 				continue;
-			// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
-			const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+			if (q.w < __builtin_inff())
 			{
+				// bounded by last iteration's correspondence: one sweep of the cube of that radius (it contains that target)
+				lds_scan_box(g, L, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, bk);
+				row16_min(bk);
+			}
+			else
+			{
+				// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
+				const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 				const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
 				const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
 				for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 				{
 					const uint32_t t2 = t + MULLS_LDS_GROUP;
-					const bool ok2 = t2 < hi;
-					const uint32_t tt2 = ok2 ? t2 : t;
+					const uint32_t tt2 = t2 < hi ? t2 : t;
 					const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
-					const int ia = (int)L.IDX[t], ib = (int)L.IDX[tt2];
+					const uint32_t ia = L.IDX[t], ib = L.IDX[tt2];
 					float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
-					const float da = (dx * dx + dy * dy) + dz * dz;
+					const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia);
 					dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
-					const float db = (dx * dx + dy * dy) + dz * dz;
-					if (da < best || (da == best && ia < bi))
-					{
-						best = da;
-						bi = ia;
-					}
-					if (ok2 && (db < best || (db == best && ib < bi)))
-					{
-						best = db;
-						bi = ib;
-					}
+					const nnkey kb = nn_key((dx * dx + dy * dy) + dz * dz, ib);
+					bk = ka < bk ? ka : bk;
+					bk = kb < bk ? kb : bk;
+				}
+				row16_min(bk);
+				// probe 1: every cell within min(first-probe radius, current best distance) of the query
+				if (rp.debug_stop != 3u)
+				{
+					const float R1 = key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m;
+					lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, bk, true);
+					row16_min(bk);
 				}
 			}
-			row16_min(best, bi);
-			// probe 1: every other cell within min(first-probe radius, current best distance) of the query
-			if (rp.debug_stop != 3u)
-			{
-				const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
-				lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, cx, cy, cz, best, bi);
-				row16_min(best, bi);
-			}
-			if (rp.debug_stop < 3u && !(bi >= 0 && best <= m * m))
+			if (rp.debug_stop < 3u && !(key_found(bk) && key_dist(bk) <= m * m))
 			{
 				// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
-				const float R = bi >= 0 ? fminf(r, sqrtf(best)) : r;
-				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, -1, -1, -1, best, bi);
-				row16_min(best, bi);
+				const float R = key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r;
+				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, bk);
+				row16_min(bk);
 			}
 			if (sub == 0)
 			{
+				const float best = key_dist(bk);
+				const int bi = (int)(uint32_t)bk; // -1: nothing found
 				const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
 				nn_idx[d.src_off + s] = matched ? bi : -1;
 				nn_d2[d.src_off + s] = best;
+				nn_hint[d.src_off + s] = bi;
 				if (matched)
 				{
 					matched_cnt++;
@@ -2466,7 +2457,7 @@ size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
-				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, uint32_t cap, uint32_t maxcells)
+				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, uint32_t cap, uint32_t maxcells)
 {
 	static bool attr_set = false;
 	if (!attr_set)
@@ -2477,7 +2468,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	}
 	if (njobs)
 		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, rp.lds_dedup != 0u), st, jobs, descs, states, rp, spos, snrm, grids,
-						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, cap);
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, cap);
 	return 0;
 }
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
