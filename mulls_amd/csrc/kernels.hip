@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 		{
 			const uint32_t v = cnt[c];
 			cnt[c] = before; // becomes the insertion cursor of the cell
-			cell_start[g.cell_off + c] = before;
+			reinterpret_cast<uint16_t *>(cell_start)[g.cell_off + c] = (uint16_t)before; // LDS tier: 16-bit table (n <= MULLS_LDS_MAXPTS), half the bytes to stage
 			before += v;
 		}
 		__syncthreads();
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 			else
 				hi = mid;
 		}
-		cell_start[g.cell_off + c] = lo;
+		reinterpret_cast<uint16_t *>(cell_start)[g.cell_off + c] = (uint16_t)lo;
 	}
 }
 
@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void row16_min(nnkey &bk)
 // sub-group reads their bounds (same addresses: LDS broadcast), the four candidate ranges are laid end to end and the
 // sub-group strides over the concatenation, two candidates per lane in flight — the trip count is that of the total, not
 // the sum of the per-row round-ups, and the only per-row work is two table reads and a running sum.
-#define MULLS_LDS_CHUNK 4
+#define MULLS_LDS_CHUNK 2
 __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
 											  nnkey &bk, bool own_done = false)
 {
@@ -1519,8 +1519,12 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 			const uint32_t f2 = f + MULLS_LDS_GROUP;
 			const bool ok2 = f2 < acc;
 			const uint32_t ff = ok2 ? f2 : f;
-			const uint32_t ta = f + (f < pre[0] ? lo[0] : f < pre[1] ? lo[1] : f < pre[2] ? lo[2] : lo[3]);
-			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : ff < pre[1] ? lo[1] : ff < pre[2] ? lo[2] : lo[3]);
+#if MULLS_LDS_CHUNK == 1
+			const uint32_t ta = f + lo[0], tb = ff + lo[0];
+#else
+			const uint32_t ta = f + (f < pre[0] ? lo[0] : lo[1]);
+			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : lo[1]);
+#endif
 			const float ax = L.X[ta], ay = L.Y[ta], az = L.Z[ta], bx = L.X[tb], by = L.Y[tb], bz = L.Z[tb];
 			const uint32_t ia = L.IDX[ta], ib = L.IDX[tb];
 			float dx = px - ax, dy = py - ay, dz = pz - az;
@@ -1589,9 +1593,10 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				}
 			}
 		}
-		// cell table: (ncell + 1) uint32 -> uint16, moved as uint4 words (cell_off is a multiple of 4 entries)
-		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(cell_start + g.cell_off);
-		const uint32_t nw = (g.ncell + 1u + 3u) >> 2;
+		// cell table: (ncell + 1) uint16 entries written by k_grid_build_sort, moved as uint4 words of 8 (the table slot of a
+		// cloud is uint4-aligned and padded)
+		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off);
+		const uint32_t nw = (g.ncell + 1u + 7u) >> 3;
 		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 4 * MULLS_LDS_BLOCK)
 		{
 			uint4 v[4];
@@ -1607,11 +1612,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			{
 				const uint32_t w = w0 + u * MULLS_LDS_BLOCK;
 				if (w < nw)
-				{
-					// two packed uint16 pairs per word (entries past ncell are padding and never read)
-					reinterpret_cast<uint32_t *>(CS)[2 * w] = (v[u].x & 0xffffu) | (v[u].y << 16);
-					reinterpret_cast<uint32_t *>(CS)[2 * w + 1] = (v[u].z & 0xffffu) | (v[u].w << 16);
-				}
+					reinterpret_cast<uint4 *>(CS)[w] = v[u];
 			}
 		}
 	}
