@@ -1445,7 +1445,7 @@ namespace
 {
 struct LdsGrid
 {
-	const float *X, *Y, *Z;
+	const float *P;	// staged target positions, 12-B records (x, y, z): one address, three immediate offsets, conflict-free stride
 	const uint16_t *IDX, *CS;
 };
 
@@ -1525,7 +1525,8 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 			const uint32_t ta = f + (f < pre[0] ? lo[0] : lo[1]);
 			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : lo[1]);
 #endif
-			const float ax = L.X[ta], ay = L.Y[ta], az = L.Z[ta], bx = L.X[tb], by = L.Y[tb], bz = L.Z[tb];
+			const float *pa = L.P + 3u * ta, *pb = L.P + 3u * tb;
+			const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
 			const uint32_t ia = L.IDX[ta], ib = L.IDX[tb];
 			float dx = px - ax, dy = py - ay, dz = pz - az;
 			const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia); // L2_Simple<float>, no FMA
@@ -1548,8 +1549,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
-	float *X = reinterpret_cast<float *>(qpos + MULLS_SRC_PER_BLOCK), *Y = X + cap, *Z = Y + cap; // [cap] each
-	uint16_t *IDX = reinterpret_cast<uint16_t *>(Z + cap);				  // [cap]
+	float *P = reinterpret_cast<float *>(qpos + MULLS_SRC_PER_BLOCK);	  // [3 * cap] x, y, z records
+	uint16_t *IDX = reinterpret_cast<uint16_t *>(P + 3u * cap);			  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
 	uint32_t *W = reinterpret_cast<uint32_t *>(CS + ((rp.grid_maxcells + 8u) & ~1u)); // [cap] lowest source index matched to each target (lds_dedup)
 
@@ -1586,9 +1587,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const uint32_t k = k0 + u * MULLS_LDS_BLOCK;
 				if (k < tgt_n)
 				{
-					X[k] = t[u].x;
-					Y[k] = t[u].y;
-					Z[k] = t[u].z;
+					P[3u * k] = t[u].x;
+					P[3u * k + 1u] = t[u].y;
+					P[3u * k + 2u] = t[u].z;
 					IDX[k] = (uint16_t)__float_as_int(t[u].w);
 				}
 			}
@@ -1621,7 +1622,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	if (dedup)
 		for (uint32_t t = threadIdx.x; t < tgt_n; t += MULLS_LDS_BLOCK)
 			W[t] = 0xffffffffu;
-	const LdsGrid L = {X, Y, Z, IDX, CS};
+	const LdsGrid L = {P, IDX, CS};
 	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
 	const double maxd = (double)r;
 	const double max_dist_sqr = maxd * maxd;
@@ -1707,7 +1708,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				{
 					const uint32_t t2 = t + MULLS_LDS_GROUP;
 					const uint32_t tt2 = t2 < hi ? t2 : t;
-					const float ax = L.X[t], ay = L.Y[t], az = L.Z[t], bx = L.X[tt2], by = L.Y[tt2], bz = L.Z[tt2];
+					const float *pa = L.P + 3u * t, *pb = L.P + 3u * tt2;
+					const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
 					const uint32_t ia = L.IDX[t], ib = L.IDX[tt2];
 					float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
 					const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia);

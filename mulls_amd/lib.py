@@ -13,6 +13,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmulls_hip.so")
+LIB_PATH = os.environ.get("MULLS_HIP_LIB", LIB_PATH)  # A/B timing of two builds of the same library on one box (tools/)
 _LIB = None
 
 
