@@ -1487,7 +1487,7 @@ __device__ __forceinline__ void row16_min(nnkey &bk)
 // the sum of the per-row round-ups, and the only per-row work is two table reads and a running sum.
 #define MULLS_LDS_CHUNK 2
 __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
-											  nnkey &bk, bool own_done = false)
+											  nnkey &bk, uint32_t &trips, bool own_done = false)
 {
 	const float Rm = R * 1.0001f + 1e-4f;
 	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
@@ -1514,6 +1514,7 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 				cz++;
 			}
 		}
+		trips += (acc + 2u * MULLS_LDS_GROUP - 1u) / (2u * MULLS_LDS_GROUP);
 		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
 		{
 			const uint32_t f2 = f + MULLS_LDS_GROUP;
@@ -1549,7 +1550,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
-	float *P = reinterpret_cast<float *>(qpos + MULLS_SRC_PER_BLOCK);	  // [3 * cap] x, y, z records
+	uint32_t *HIST = reinterpret_cast<uint32_t *>(qpos + MULLS_SRC_PER_BLOCK); // [32] cost histogram, [32] bucket bases, [64] live queries of the chunk
+	uint16_t *ORDER = reinterpret_cast<uint16_t *>(HIST + 80);				  // [MULLS_SRC_PER_BLOCK] query slots, most expensive first
+	float *P = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(HIST) + MULLS_LDS_AUX); // [3 * cap] x, y, z records
 	uint16_t *IDX = reinterpret_cast<uint16_t *>(P + 3u * cap);			  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
 	uint32_t *W = reinterpret_cast<uint32_t *>(CS + ((rp.grid_maxcells + 8u) & ~1u)); // [cap] lowest source index matched to each target (lds_dedup)
@@ -1634,9 +1637,12 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	uint32_t matched_cnt = 0;
 
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
+	if (threadIdx.x < 32u)
+		HIST[threadIdx.x] = 0u;
 	for (uint32_t chunk = job.start; chunk < q_end; chunk += MULLS_SRC_PER_BLOCK)
 	{
 		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
+		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
 		// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
 		if (threadIdx.x < MULLS_SRC_PER_BLOCK)
 		{
@@ -1661,7 +1667,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				out.w = __builtin_inff();
 				if (use_hint)
 				{
-					const uint32_t h = (uint32_t)nn_hint[d.src_off + s];
+					const uint32_t hv = (uint32_t)nn_hint[d.src_off + s], h = hv & 0xffffu;
+					bucket = 31u - ((hv >> 16) & 31u);
 					if (h < tgt_n)
 					{
 						const float4 t = tpos[d.tgt_off + h];
@@ -1671,6 +1678,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 							out.w = d0;
 					}
 				}
+				if (called)
+					rank = atomicAdd(&HIST[bucket], 1u);
 			}
 			qpos[threadIdx.x] = out;
 		}
@@ -1679,23 +1688,43 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		__syncthreads();
 		if (rp.debug_stop == 2u)
 			continue;
+		// queries of the chunk in order of the work they took in the previous iteration (candidate trips, kept next to the hint):
+		// the eight sub-groups of a wave run in lock step, so a wave is as slow as its most expensive query — neighbours in
+		// this order cost about the same.  Counting sort over 32 classes; dead points drop out.
+		if (threadIdx.x < 32u)
+		{
+			const uint32_t v = HIST[threadIdx.x];
+			uint32_t incl = v;
+			for (int off = 1; off < 32; off <<= 1)
+			{
+				const uint32_t o = __shfl_up(incl, off);
+				if ((int)threadIdx.x >= off)
+					incl += o;
+			}
+			HIST[32u + threadIdx.x] = incl - v;
+			HIST[threadIdx.x] = 0u; // ready for the next chunk
+			if (threadIdx.x == 31u)
+				HIST[64] = incl;
+		}
+		__syncthreads();
+		if (rank != 0xffffffffu)
+			ORDER[HIST[32u + bucket] + rank] = (uint16_t)threadIdx.x;
+		__syncthreads();
+		const uint32_t n_live = HIST[64];
 
 		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
-		for (uint32_t k = grp; k < MULLS_SRC_PER_BLOCK; k += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
+		for (uint32_t i = grp; i < n_live; i += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
 		{
-			const uint32_t s = chunk + k;
-			if (s >= q_end)
-				break;
+			const uint32_t k = ORDER[i], s = chunk + k;
 			const float4 q = qpos[k];
-			if (q.w < 0.0f)
-				continue;
 			nnkey bk = NNKEY_NONE;
+			uint32_t trips = 0;
 			if (rp.debug_stop == 5u)
 				continue;
 			if (q.w < __builtin_inff())
 			{
 				// bounded by last iteration's correspondence: one sweep of the cube of that radius (it contains that target)
-				lds_scan_box(g, L, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, bk);
+				lds_scan_box(g, L, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, bk, trips);
 				row16_min(bk);
 			}
 			else
@@ -1704,6 +1733,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 				const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
 				const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
+				trips += (hi - lo + 2u * MULLS_LDS_GROUP - 1u) / (2u * MULLS_LDS_GROUP);
 				for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 				{
 					const uint32_t t2 = t + MULLS_LDS_GROUP;
@@ -1723,7 +1753,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				if (rp.debug_stop != 3u)
 				{
 					const float R1 = key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m;
-					lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, bk, true);
+					lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, bk, trips, true);
 					row16_min(bk);
 				}
 			}
@@ -1731,7 +1761,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			{
 				// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
 				const float R = key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r;
-				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, bk);
+				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, bk, trips);
 				row16_min(bk);
 			}
 			if (sub == 0)
@@ -1741,7 +1771,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
 				nn_idx[d.src_off + s] = matched ? bi : -1;
 				nn_d2[d.src_off + s] = best;
-				nn_hint[d.src_off + s] = bi;
+				nn_hint[d.src_off + s] = (int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)); // hint and cost class of the next iteration
 				if (matched)
 				{
 					matched_cnt++;
@@ -2456,7 +2486,7 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 {
 	// query block, planar points + index, cell table, and (lds_dedup) the on-chip duplicate table
-	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
+	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)MULLS_LDS_AUX + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
