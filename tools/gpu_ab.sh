@@ -8,6 +8,6 @@ for r in $(seq 1 "$R"); do
 	for v in a b; do
 		L=$1; [ $v = b ] && L=$2
 		MULLS_HIP_LIB=$PWD/$L MULLS_SUBBATCHES=1 timeout 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ab_${v}_$r -- python tools/gpu_one.py 0 1024 2 >/dev/null 2>&1
-		echo "$v $r $(python tools/kernel_stats.py gpurun_out/ab_${v}_$r | sed -n 2,2p)"
+		echo "$v $r $(python tools/kernel_stats.py gpurun_out/ab_${v}_$r | sed -n 2,4p | tr "\n" "|")"
 	done
 done
