@@ -178,7 +178,7 @@ const char *mulls_last_error(const mulls_ctx *ctx);
 int mulls_set_profiling(mulls_ctx *ctx, int on);
 int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
 /* correspondence-search tier: 0 = auto (uniform grid staged in LDS when every searched target class cloud holds
- * <= 10240 points, otherwise the uniform grid in global memory), 1 = LDS-tiled brute force, 2 = uniform grid in global
+ * <= 9728 points, otherwise the uniform grid in global memory), 1 = LDS-tiled brute force, 2 = uniform grid in global
  * memory, 3 = uniform grid staged in LDS (MULLS_E_INVALID when a cloud is too large).  All tiers are exact and return
  * identical correspondences (tests/test_gpu_stages.py). */
 int mulls_set_nn_mode(mulls_ctx *ctx, int mode);

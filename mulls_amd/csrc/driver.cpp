@@ -314,7 +314,7 @@ void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairO
 // cell budget of the LDS tier: whatever the 160 KiB leave free next to the staged points (14 B each) and the query block
 uint32_t lds_cells_for(uint32_t cap)
 {
-	const long free_bytes = 160L * 1024L - (long)MULLS_SRC_PER_BLOCK * 16L - (long)MULLS_LDS_AUX - (long)cap * 14L - 64L;
+	const long free_bytes = 160L * 1024L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)cap * 14L - 64L;
 	long cells = free_bytes / 2 - 8;
 	cells = std::min<long>(cells, (long)MULLS_MAXCELLS);
 	return (uint32_t)std::max<long>(cells, 4096);
@@ -598,7 +598,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 	if (tier < 0)
 	{
-		ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 10240 points";
+		ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 9728 points";
 		return MULLS_E_INVALID;
 	}
 	*lds_cap_out = lds_cap;
@@ -617,7 +617,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		// class-level jobs (one workgroup sees every query of a class cloud): keep the duplicate table in LDS if 4 B per target
 		// still leave a useful cell budget next to the staged cloud
 		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
-		const long left = 160L * 1024L - 64L - (long)MULLS_SRC_PER_BLOCK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
+		const long left = 160L * 1024L - 64L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
 		if (class_level && !rp.normal_shooting && left / 2 - 8 >= 8192 && !std::getenv("MULLS_NO_LDS_DEDUP")) // k_nn_shoot uses the global table
 		{
 			rp.lds_dedup = 1;

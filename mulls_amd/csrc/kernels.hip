@@ -1550,8 +1550,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
-	uint32_t *HIST = reinterpret_cast<uint32_t *>(qpos + MULLS_SRC_PER_BLOCK); // [32] cost histogram, [32] bucket bases, [64] live queries of the chunk
-	uint16_t *ORDER = reinterpret_cast<uint16_t *>(HIST + 80);				  // [MULLS_SRC_PER_BLOCK] query slots, most expensive first
+	uint32_t *HIST = reinterpret_cast<uint32_t *>(qpos + MULLS_LDS_QCHUNK); // [32] cost histogram, [32] bucket bases, [64] live queries of the chunk
+	uint16_t *ORDER = reinterpret_cast<uint16_t *>(HIST + 80);				  // [MULLS_LDS_QCHUNK] query slots, most expensive first
 	float *P = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(HIST) + MULLS_LDS_AUX); // [3 * cap] x, y, z records
 	uint16_t *IDX = reinterpret_cast<uint16_t *>(P + 3u * cap);			  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
@@ -1639,12 +1639,12 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	if (threadIdx.x < 32u)
 		HIST[threadIdx.x] = 0u;
-	for (uint32_t chunk = job.start; chunk < q_end; chunk += MULLS_SRC_PER_BLOCK)
+	for (uint32_t chunk = job.start; chunk < q_end; chunk += MULLS_LDS_QCHUNK)
 	{
 		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
 		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
 		// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
-		if (threadIdx.x < MULLS_SRC_PER_BLOCK)
+		if (threadIdx.x < MULLS_LDS_QCHUNK)
 		{
 			const uint32_t s = chunk + threadIdx.x;
 			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
@@ -2486,7 +2486,7 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 {
 	// query block, planar points + index, cell table, and (lds_dedup) the on-chip duplicate table
-	return (size_t)MULLS_SRC_PER_BLOCK * 16u + (size_t)MULLS_LDS_AUX + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
+	return (size_t)MULLS_LDS_QCHUNK * 16u + (size_t)MULLS_LDS_AUX + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
