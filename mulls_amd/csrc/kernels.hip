@@ -1639,8 +1639,12 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	if (threadIdx.x < 32u)
 		HIST[threadIdx.x] = 0u;
-	for (uint32_t chunk = job.start; chunk < q_end; chunk += MULLS_LDS_QCHUNK)
+	// chunks of equal size (1200 queries: 2 x 600, not 1024 + 176: the last chunk would leave most sub-groups idle)
+	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
+	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
+	for (uint32_t chunk = job.start; chunk < q_end; chunk += q_step)
 	{
+		const uint32_t c_end = min(q_end, chunk + q_step);
 		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
 		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
 		// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
@@ -1648,7 +1652,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		{
 			const uint32_t s = chunk + threadIdx.x;
 			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-			if (s < q_end && (flag[d.src_off + s] & MULLS_F_ALIVE))
+			if (s < c_end && (flag[d.src_off + s] & MULLS_F_ALIVE))
 			{
 				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
 				const double *T = ps.T;
