@@ -38,6 +38,7 @@ struct mulls_batch
 	std::vector<Job> big_segs_h, big_clouds_h; // target class clouds cropped segment-wise (k_crop_big_*): segments, clouds
 	std::vector<Job> jobs_h;
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
+	std::vector<Job> cjobs_dev_h; // the same entries as uploaded: inside each sub-batch's slice the most expensive class clouds come first
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
 	std::string jobs_key;
 	uint32_t njobs = 0;
@@ -195,6 +196,15 @@ int check_params(mulls_ctx *ctx, const mulls_params *P)
 	return MULLS_OK;
 }
 
+// sub-batches in flight of a lock-step batch of n pairs (mulls_icp_batch / mulls_batch_run)
+int subbatch_count(int n)
+{
+	int nsub = n >= 2048 ? 2 : 1; // below that the half-size launches cost more (k_nn_lds tail) than the overlap returns
+	if (const char *e = std::getenv("MULLS_SUBBATCHES"))
+		nsub = std::max(1, std::min(2, std::atoi(e)));
+	return n < 2 ? 1 : nsub;
+}
+
 void build_jobs(mulls_batch *B, const mulls_params *P)
 {
 	std::string key(P->used_feature_type, 6);
@@ -234,6 +244,22 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 						Job j = {(uint32_t)p, (uint32_t)c, s, MULLS_SRC_PER_BLOCK};
 						B->cjobs_h.push_back(j);
 					}
+	}
+	// device order of the class-level jobs: longest first inside each sub-batch's slice, so that the last round of workgroups
+	// of a launch is made of the cheap class clouds (cost ~ queries x log(targets); ties keep the pair order)
+	B->cjobs_dev_h = B->cjobs_h;
+	{
+		const int nsub = subbatch_count(B->n);
+		auto first_of = [&](uint32_t pair) {
+			return std::lower_bound(B->cjobs_dev_h.begin(), B->cjobs_dev_h.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; });
+		};
+		auto cost = [&](const Job &j) {
+			const CloudDesc &d = B->descs_h[j.pair * MULLS_NC + j.cls];
+			return (uint64_t)j.count * (uint64_t)(64u + d.tgt_n0 / 64u);
+		};
+		for (int k = 0; k < nsub; k++)
+			std::stable_sort(first_of((uint32_t)((long)B->n * k / nsub)), first_of((uint32_t)((long)B->n * (k + 1) / nsub)),
+							 [&](const Job &a, const Job &b) { return cost(a) > cost(b); });
 	}
 	B->tjobs_h.clear();
 	for (int p = 0; p < B->n; p++)
@@ -681,7 +707,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	{
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_h.data(), sizeof(Job) * B->cjobs_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipStreamSynchronize(st)); // the host vectors may be rebuilt by a later call
@@ -1027,11 +1053,7 @@ extern "C"
 			hipStream_t st = nullptr;
 			EvTimer evt{nullptr};
 		};
-		int nsub = n >= 2048 ? 2 : 1; // below that the half-size launches cost more (k_nn_lds tail) than the overlap returns
-		if (const char *e = std::getenv("MULLS_SUBBATCHES"))
-			nsub = std::max(1, std::min(2, std::atoi(e)));
-		if (n < 2)
-			nsub = 1;
+		const int nsub = subbatch_count(n);
 		Sub subs[2];
 		for (int k = 0; k < nsub; k++)
 		{

@@ -1560,7 +1560,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	// one workgroup per (pair, class): the target class cloud is staged ONCE and every 512-query chunk of the source
 	// class cloud is searched against it (the first version staged it once per chunk: 2.3x the algorithmic HBM bytes,
 	// profiles/r01_f_pmc_traffic.txt)
-	const Job job = cjobs[xcd_job(blockIdx.x, gridDim.x)];
+	const Job job = cjobs[blockIdx.x]; // host order: most expensive class clouds first (round-robin over the XCDs)
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
 		return;
