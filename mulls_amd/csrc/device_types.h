@@ -18,6 +18,7 @@
 #define MULLS_BM_H0 0.25f // ... smallest cell edge in metres (dense maps); sparse clouds start from their mean point spacing, up to 0.7 m
 #define MULLS_LDS_BLOCK 1024		// LDS grid tier: 16 wave64 = 64 sub-groups per workgroup, one 512-point job
 #define MULLS_LDS_MAXPTS 9728u // largest target class cloud staged in LDS (14 B per point; the uint16 cell table takes what is left of 160 KiB, >= 4096 cells)
+#define MULLS_ACC_BLOCK 128	   // k_accum: two waves per 512-point job, four points per lane
 #define MULLS_LDS_QCHUNK 1024u // LDS tier: queries searched between two workgroup barriers (one per lane in the rigid-step phase)
 #define MULLS_LDS_AUX (320u + 2u * MULLS_LDS_QCHUNK) // LDS tier: cost histogram and query order of a chunk
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)

@@ -48,6 +48,7 @@ struct mulls_batch
 	float4 *spos = nullptr, *snrm = nullptr, *tpos = nullptr, *tnrm = nullptr;
 	uint8_t *flag = nullptr;
 	int32_t *match = nullptr, *nn_idx = nullptr, *nn_hint = nullptr;
+	float4 *mq = nullptr; // per source point: position and direction of its matched target (2 records), written with match[]
 	float *wd = nullptr, *nn_d2 = nullptr;
 	unsigned long long *winner = nullptr;
 	CloudDesc *descs = nullptr;
@@ -87,7 +88,7 @@ struct mulls_batch
 	std::string dev_key;			 // jobs_key of the tables currently resident on the device
 	size_t cap_jobs[6] = {}, cap_cells[2] = {};
 	// capacities (elements) of the grow-only arrays
-	size_t cap_stage = 0, cap_src[10] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
+	size_t cap_stage = 0, cap_src[11] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
 
 namespace
@@ -469,6 +470,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->wd, &B->cap_src[7], so));
 	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so));
 	A(grow(ctx, &B->nn_hint, &B->cap_src[9], so));
+	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so));
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
 	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to));
@@ -859,7 +861,7 @@ extern "C"
 			return;
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
-		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->wd,
+		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->mq, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
 					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
 		for (void *p : dev)
@@ -1132,7 +1134,7 @@ extern "C"
 				if (tier == 2)
 				{
 					if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
-									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells) != 0)
+									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 						return MULLS_E_HIP;
@@ -1148,14 +1150,14 @@ extern "C"
 				ev.end();
 				ev.begin(&ctx->prof.ms_filter);
 				if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
-					launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
+					launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
 				ev.end();
 				ctx->prof.launches_nn++;
 				if (&S == &subs[0])
 					ctx->prof.iterations++;
 			}
 			ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-			launch_accum(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, S.job_lo);
+			launch_accum(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, S.job_lo);
 			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 						  (uint32_t)S.lo);
 			ev.end();
@@ -1505,7 +1507,7 @@ extern "C"
 			if (tier == 2)
 			{
 				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells) != 0)
+								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells) != 0)
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
@@ -1514,8 +1516,8 @@ extern "C"
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
-				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner);
-			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
+				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
+			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, 0);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
@@ -1815,7 +1817,7 @@ extern "C"
 			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 			if (tier == 2)
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, lds_cap, rp.grid_maxcells);
+							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner);
@@ -1825,7 +1827,7 @@ extern "C"
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd,
-						  B->winner);
+						  B->winner, B->tpos, B->mq);
 			const uint32_t off = B->descs_h[cls].src_off;
 			if (e == hipSuccess)
 				e = hipMemcpyAsync(match, B->nn_idx + off, sizeof(int32_t) * src->n, hipMemcpyDeviceToHost, st);
@@ -1897,8 +1899,8 @@ extern "C"
 			{
 				// clear every flag to "alive, not a correspondence", then switch the requested ones on
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
-				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd);
-				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->tpos, B->tnrm, B->flag, B->match, B->wd, B->partial, 0);
+				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd, B->descs_h[cls].tgt_off, B->tpos, B->tnrm, B->mq);
+				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, 0);
 				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}
 			std::vector<float> wall(src->n);

@@ -1339,14 +1339,16 @@ struct FilterCtx
 __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc &d, uint32_t s, const float4 *__restrict__ snrm,
 											  const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, const int32_t *__restrict__ nn_idx,
 											  const float *__restrict__ nn_d2, int32_t *__restrict__ match, float *__restrict__ wd,
-											  const unsigned long long *__restrict__ winner, uint32_t &n_alive, uint32_t &n_valid)
+											  const unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos,
+											  float4 *__restrict__ mq, uint32_t &n_alive, uint32_t &n_valid)
 {
 	const uint32_t g = d.src_off + s;
 	const uint32_t f = flag[g];
 	if (!(f & MULLS_F_ALIVE))
 		return;
-	bool alive = true, valid;
+	bool alive = true, valid, fresh = false;
 	int m;
+	float4 n2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if (F.any_match)
 	{
 		m = nn_idx[g];
@@ -1364,6 +1366,12 @@ __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc
 			{
 				match[g] = m;
 				wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+				// the matched target travels with the source point from here on: k_accum streams (position, direction) records
+				// instead of gathering two cache lines per correspondence (its launches were bound by exactly that traffic)
+				n2 = tnrm[d.tgt_off + m];
+				mq[2u * g] = tpos[d.tgt_off + m];
+				mq[2u * g + 1u] = n2;
+				fresh = true;
 			}
 		}
 	}
@@ -1382,7 +1390,9 @@ __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc
 	}
 	if (valid && F.normal_check)
 	{
-		const float4 n1 = snrm[g], n2 = tnrm[d.tgt_off + m];
+		const float4 n1 = snrm[g];
+		if (!fresh)
+			n2 = mq[2u * g + 1u]; // the standing correspondence's target direction
 		const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
 		const float c = (float)fabs(dot);
 		if ((double)c < F.cos_thre)
@@ -1398,7 +1408,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 														 const float4 *__restrict__ snrm, const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag,
 														 const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
 														 int32_t *__restrict__ match, float *__restrict__ wd,
-														 const unsigned long long *__restrict__ winner)
+														 const unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos,
+														 float4 *__restrict__ mq)
 {
 	__shared__ uint32_t red4[4];
 	const Job job = jobs[xcd_job(blockIdx.x, gridDim.x)];
@@ -1418,7 +1429,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 	{
 		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
 		if (s < d.src_n)
-			filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, n_alive, n_valid);
+			filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq, n_alive, n_valid);
 	}
 	const uint32_t ta = block_sum_u32(n_alive, red4);
 	const uint32_t tv = block_sum_u32(n_valid, red4);
@@ -1546,7 +1557,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 															 const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted,
 															 uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 															 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
-															 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, uint32_t cap)
+															 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
@@ -1826,7 +1837,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const FilterCtx F = {gate, total_matched > 0u, job.cls != 5, true, thr * thr, rp.cos_bearing, key_hi};
 	uint32_t n_alive = 0, n_valid = 0;
 	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += MULLS_LDS_BLOCK)
-		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, n_alive, n_valid);
+		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq, n_alive, n_valid);
 	for (int off = 32; off > 0; off >>= 1)
 	{
 		n_alive += __shfl_down(n_alive, off);
@@ -2016,13 +2027,12 @@ __device__ __forceinline__ int metric_of(int cls) { return (cls == 1 || cls == 3
 // Normal-equation accumulation (active pairs) or posterior residual (pairs flagged want_residual).  27 double
 // accumulators per lane -> wave64 shuffle tree -> 4-wave LDS combine -> one 27-double partial per workgroup, summed
 // in fixed order by k_finish (run-to-run deterministic, unlike atomicAdd(double)).
-__global__ __launch_bounds__(MULLS_BLOCK, 4) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+__global__ __launch_bounds__(MULLS_ACC_BLOCK, 4) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
 														const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
-														const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm,
-														const uint8_t *__restrict__ flag, const int32_t *__restrict__ match, float *__restrict__ wd,
+														const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd,
 														double *__restrict__ partial, uint32_t job_base)
 {
-	__shared__ double red[4][MULLS_NTERM];
+	__shared__ double red[MULLS_ACC_BLOCK / 64][MULLS_NTERM];
 	const uint32_t job_idx = xcd_job(blockIdx.x, gridDim.x);
 	const Job job = jobs[job_idx];
 	const PairState &ps = states[job.pair];
@@ -2057,16 +2067,15 @@ __global__ __launch_bounds__(MULLS_BLOCK, 4) void k_accum(const Job *__restrict_
 		acc[k] = 0.0;
 
 #pragma unroll
-	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
+	for (int u = 0; u < MULLS_SRC_PER_BLOCK / MULLS_ACC_BLOCK; u++)
 	{
-		const uint32_t s = job.start + threadIdx.x + u * MULLS_BLOCK;
+		const uint32_t s = job.start + threadIdx.x + u * MULLS_ACC_BLOCK;
 		if (s >= d.src_n)
 			continue;
 		const uint32_t g = d.src_off + s;
 		if ((flag[g] & (MULLS_F_ALIVE | MULLS_F_VALID)) != (MULLS_F_ALIVE | MULLS_F_VALID))
 			continue;
-		const int m = match[g];
-		const float4 P = spos[g], Q = tpos[d.tgt_off + m], N = tnrm[d.tgt_off + m];
+		const float4 P = spos[g], Q = mq[2u * g], N = mq[2u * g + 1u]; // the matched target's position and direction (filter_point)
 		const float px = P.x, py = P.y, pz = P.z, pi = P.w;
 		const float qx = Q.x, qy = Q.y, qz = Q.z, qi = Q.w;
 
@@ -2283,7 +2292,7 @@ __global__ __launch_bounds__(MULLS_BLOCK, 4) void k_accum(const Job *__restrict_
 	__syncthreads();
 	if (threadIdx.x < MULLS_NTERM)
 		partial[(size_t)(job_base + job_idx) * MULLS_NTERM + threadIdx.x] = // job_base: first job of this sub-batch in the batch-wide table
-			((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+			red[0][threadIdx.x] + red[1][threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2424,7 +2433,8 @@ __global__ void k_transform_aos(float4 *__restrict__ recs, uint32_t n, const dou
 
 // force a given correspondence list into the flag/match/wd arrays (mulls_stage_accumulate)
 __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, const int32_t *__restrict__ ct, const float *__restrict__ cd,
-						   uint32_t n, uint8_t *__restrict__ flag, int32_t *__restrict__ match, float *__restrict__ wd)
+						   uint32_t n, uint8_t *__restrict__ flag, int32_t *__restrict__ match, float *__restrict__ wd, uint32_t tgt_off,
+						   const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm, float4 *__restrict__ mq)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n)
@@ -2432,6 +2442,8 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 	const uint32_t g = src_off + (uint32_t)cs[i];
 	flag[g] = MULLS_F_ALIVE | MULLS_F_VALID;
 	match[g] = ct[i];
+	mq[2u * g] = tpos[tgt_off + (uint32_t)ct[i]];
+	mq[2u * g + 1u] = tnrm[tgt_off + (uint32_t)ct[i]];
 	wd[g] = cd ? cd[i] : 0.0f;
 }
 
@@ -2494,7 +2506,7 @@ size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
-				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, uint32_t cap, uint32_t maxcells)
+				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells)
 {
 	static bool attr_set = false;
 	if (!attr_set)
@@ -2505,7 +2517,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	}
 	if (njobs)
 		hipLaunchKernelGGL(k_nn_lds, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, rp.lds_dedup != 0u), st, jobs, descs, states, rp, spos, snrm, grids,
-						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, cap);
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap);
 	return 0;
 }
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
@@ -2536,19 +2548,17 @@ void launch_nn_shoot(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc 
 }
 void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,
-				   const unsigned long long *winner)
+				   const unsigned long long *winner, const float4 *tpos, float4 *mq)
 {
 	if (njobs)
 		hipLaunchKernelGGL(k_filter, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, snrm, tnrm, flag, nn_idx, nn_d2, match, wd,
-						   winner);
+						   winner, tpos, mq);
 }
 void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *tpos, const float4 *tnrm, const uint8_t *flag, const int32_t *match, float *wd,
-				  double *partial, uint32_t job_base)
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, uint32_t job_base)
 {
 	if (njobs)
-		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, tpos, tnrm, flag, match, wd, partial,
-						   job_base);
+		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_ACC_BLOCK), 0, st, jobs, descs, states, rp, spos, mq, flag, wd, partial, job_base);
 }
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
 				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
@@ -2577,8 +2587,8 @@ void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double
 		hipLaunchKernelGGL(k_transform_aos, dim3((n + 255) / 256), dim3(256), 0, st, recs, n, T12);
 }
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
-					 int32_t *match, float *wd)
+					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq)
 {
 	if (n)
-		hipLaunchKernelGGL(k_set_corr, dim3((n + 255) / 256), dim3(256), 0, st, src_off, cs, ct, cd, n, flag, match, wd);
+		hipLaunchKernelGGL(k_set_corr, dim3((n + 255) / 256), dim3(256), 0, st, src_off, cs, ct, cd, n, flag, match, wd, tgt_off, tpos, tnrm, mq);
 }

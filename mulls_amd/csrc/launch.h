@@ -20,7 +20,7 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells);
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
-				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, uint32_t cap, uint32_t maxcells);
+				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells);
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 					float4 *spos, float4 *snrm, const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs,
 					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner);
@@ -30,14 +30,13 @@ void launch_nn_shoot(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc 
 					 float4 *spos, float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner);
 void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,
-				   const unsigned long long *winner);
+				   const unsigned long long *winner, const float4 *tpos, float4 *mq);
 void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *tpos, const float4 *tnrm, const uint8_t *flag, const int32_t *match, float *wd,
-				  double *partial, uint32_t job_base);
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, uint32_t job_base);
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
 				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
 				   uint32_t pair_base);
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs);
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
-					 int32_t *match, float *wd);
+					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq);
