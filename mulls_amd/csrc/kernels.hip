@@ -1580,6 +1580,35 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const bool called = class_called(rp, d, job.cls);
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 
+	// The rigid-step phase of a chunk needs four global loads per lane and, with a hint, a dependent gather: they are issued one
+	// chunk ahead (the first chunk's before the target cloud is staged) so that their latency hides behind the staging / the search.
+	const bool use_hint = called && ps.iter > 0 && rp.debug_stop != 6u; // hints of this run exist from its second iteration on
+	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
+	// chunks of equal size (1200 queries: 2 x 600, not 1024 + 176: the last chunk would leave most sub-groups idle)
+	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
+	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
+	float4 pf_p = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_n = pf_p, pf_t = pf_p;
+	uint32_t pf_hv = 0xffffu, pf_f = 0u;
+	auto prefetch = [&](uint32_t chunk) {
+		const uint32_t s = chunk + threadIdx.x;
+		pf_f = 0u;
+		pf_hv = 0xffffu;
+		if (chunk < q_end && s < min(q_end, chunk + q_step))
+		{
+			pf_f = flag[d.src_off + s];
+			pf_p = spos[d.src_off + s];
+			pf_n = snrm[d.src_off + s];
+			if (use_hint)
+				pf_hv = (uint32_t)nn_hint[d.src_off + s];
+		}
+	};
+	auto prefetch_hint = [&]() {
+		const uint32_t h = pf_hv & 0xffffu;
+		if (h < tgt_n)
+			pf_t = tpos[d.tgt_off + h];
+	};
+	prefetch(job.start);
+
 	if (called)
 	{
 		// stage the cell-sorted target cloud and its cell table (coalesced reads).  Loads are issued in batches of 8 / 4
@@ -1608,6 +1637,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				}
 			}
 		}
+		prefetch_hint(); // the first chunk's hinted targets, in flight while the cell table is staged
 		// cell table: (ncell + 1) uint16 entries written by k_grid_build_sort, moved as uint4 words of 8 (the table slot of a
 		// cloud is uint4-aligned and padded)
 		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off);
@@ -1644,15 +1674,10 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
-	const bool use_hint = called && ps.iter > 0 && rp.debug_stop != 6u; // hints of this run exist from its second iteration on
 	uint32_t matched_cnt = 0;
 
-	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	if (threadIdx.x < 32u)
 		HIST[threadIdx.x] = 0u;
-	// chunks of equal size (1200 queries: 2 x 600, not 1024 + 176: the last chunk would leave most sub-groups idle)
-	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
-	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
 	for (uint32_t chunk = job.start; chunk < q_end; chunk += q_step)
 	{
 		const uint32_t c_end = min(q_end, chunk + q_step);
@@ -1663,9 +1688,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		{
 			const uint32_t s = chunk + threadIdx.x;
 			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-			if (s < c_end && (flag[d.src_off + s] & MULLS_F_ALIVE))
+			if (s < c_end && (pf_f & MULLS_F_ALIVE))
 			{
-				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
+				const float4 p = pf_p, n = pf_n;
 				const double *T = ps.T;
 				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
 				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
@@ -1680,24 +1705,20 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				// Its distance is an exact upper bound (any target point gives one), so the search below can skip the own-cell
 				// probe and sweep the cube of that radius straight away.  w: bound (squared), +inf = none, -1 = dead point.
 				out.w = __builtin_inff();
-				if (use_hint)
+				bucket = 31u - ((pf_hv >> 16) & 31u);
+				if ((pf_hv & 0xffffu) < tgt_n)
 				{
-					const uint32_t hv = (uint32_t)nn_hint[d.src_off + s], h = hv & 0xffffu;
-					bucket = 31u - ((hv >> 16) & 31u);
-					if (h < tgt_n)
-					{
-						const float4 t = tpos[d.tgt_off + h];
-						const float dx = out.x - t.x, dy = out.y - t.y, dz = out.z - t.z;
-						const float d0 = (dx * dx + dy * dy) + dz * dz;
-						if (d0 >= 0.0f)
-							out.w = d0;
-					}
+					const float dx = out.x - pf_t.x, dy = out.y - pf_t.y, dz = out.z - pf_t.z;
+					const float d0 = (dx * dx + dy * dy) + dz * dz;
+					if (d0 >= 0.0f)
+						out.w = d0;
 				}
 				if (called)
 					rank = atomicAdd(&HIST[bucket], 1u);
 			}
 			qpos[threadIdx.x] = out;
 		}
+		prefetch(chunk + q_step); // the next chunk's loads, consumed after this chunk's search
 		if (!called || rp.debug_stop == 1u)
 			continue; // correspondences of the previous iteration stay in force; the points still move
 		__syncthreads();
@@ -1726,6 +1747,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			ORDER[HIST[32u + bucket] + rank] = (uint16_t)threadIdx.x;
 		__syncthreads();
 		const uint32_t n_live = HIST[64];
+		prefetch_hint(); // gather of the next chunk's hinted targets (its hint words have landed during the sort above)
 
 		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
 		for (uint32_t i = grp; i < n_live; i += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
