@@ -189,15 +189,15 @@ def main():
                 "mean_iterations": float(np.mean(iters)),
             },
             "roofline": {
-                "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS + on-chip duplicate rule and rejection chain)"
+                "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS, bounded by the previous iteration's correspondence + on-chip duplicate rule and rejection chain)"
                           if prof_acc["evals"] == 0 else "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
-                                "(profiles/r01_j_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide; the launch includes the fused rejection chain); null when the run differs from it",
+                                "(profiles/r01_m_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide; the launch includes the fused rejection chain, the correspondence records written for k_accum and the hint gathers); null when the run differs from it",
                 "avg_launch_ms": avg_ms, "launches": prof_acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "the search is an irregular exact query, bound by dependent LDS/L2 access latency and VALU issue, not by HBM "
-                        "bandwidth (DESIGN.md section 4, profiles/r01_c_pmc_grid.txt); the HBM fraction is reported as the contract asks",
+                "note": "the search is an irregular exact query, bound by VALU issue (instruction count) and dependent LDS access, not by HBM "
+                        "bandwidth (DESIGN.md section 4, profiles/r01_h_pmc_sq.txt, r01_m_search_steps.txt); the HBM fraction is reported as the contract asks",
                 "valu_view": None if prof_acc["evals"] == 0 else {
                     "achieved": valu, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": valu / VALU_PEAK_TLOPS,
                     "distance_evals_per_launch": prof_acc["evals"] / launches},
