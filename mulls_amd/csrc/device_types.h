@@ -96,6 +96,7 @@ struct PairSetup // written once per run
 struct PairOut
 {
 	double sums[MULLS_NC][MULLS_NTERM_PAD]; // per class: 21 packed terms (row-major upper enumeration) + 6 rhs; residual pass: [0]=VTPV [1]=n
+	double comb[MULLS_NTERM_PAD];			// rp.pull_comb: the classes combined as the reference assembles them (k_finish) — the only row sent to the host
 	uint32_t n_valid[MULLS_NC];
 	uint32_t n_alive[MULLS_NC];
 	uint32_t src_n[MULLS_NC];
@@ -134,6 +135,7 @@ struct RunParams
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
 	float grid_h0;		// LDS tier: preferred cell edge (MULLS_GRID_H0; grows until the cloud's box fits grid_maxcells)
 	float bm_h0;		// > 0: global-memory tier — k_crop sizes occupancy-bitmap grids from this cell edge (grid_maxcells = word budget)
+	uint32_t pull_comb;	// mm_lls_icp loop: k_finish combines the class rows (normal matrix + rhs, or VTPV + count) and k_pull_outs sends that one row
 	uint32_t lds_dedup;	// LDS tier with class-level jobs: the duplicate rule is resolved inside k_nn_lds (winner table in LDS), losers get nn_idx = -1
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
 };

@@ -132,40 +132,19 @@ struct PairHost
 // packed index of (r,c), r <= c, in the row-major-upper enumeration used by k_accum
 inline int packed(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
 
-// The 6x6 the reference inverts: pt2pl / pt2pt wrote the lower triangle, pt2li the upper one, then the mirror copies
-// lower -> upper (cregistration.hpp:1924-1938).  Class order of the += chain on shared slots: ground, facade, roof
-// (pl), pillar, beam (li), vertex (pt) (:1914-1921).
-void assemble_normal(const PairOut &o, const uint8_t used[MULLS_NC], bool faithful, Mat6 &N, double b[6])
+// The 6x6 the reference inverts and its right-hand side, as k_finish combined them from the class rows (lower / upper triangle
+// bookkeeping of cregistration.hpp:1914-1938 happens there)
+void normal_from_comb(const PairOut &o, Mat6 &N, double b[6])
 {
-	static const int order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM, MULLS_VERTEX};
 	for (int r = 0; r < 6; r++)
 		for (int c = r; c < 6; c++)
 		{
-			const int k = packed(r, c);
-			double lower = 0.0, upper = 0.0;
-			for (int i = 0; i < 6; i++)
-			{
-				const int cls = order[i];
-				if (!used[cls])
-					continue;
-				const double v = o.sums[cls][k];
-				if (metric_of(cls) == 1 && r != c)
-					upper += v;
-				else
-					lower += v;
-			}
-			const double val = (r == c) ? lower : (faithful ? lower : lower + upper);
+			const double val = o.comb[packed(r, c)];
 			N.at(c, r) = val;
 			N.at(r, c) = val;
 		}
 	for (int j = 0; j < 6; j++)
-	{
-		double acc = 0.0;
-		for (int i = 0; i < 6; i++)
-			if (used[order[i]])
-				acc += o.sums[order[i]][21 + j];
-		b[j] = acc;
-	}
+		b[j] = o.comb[21 + j];
 }
 
 // the intersection box the device used (cregistration.hpp:2912-2916, utility.hpp:857-865), re-derived for the caller
@@ -318,16 +297,22 @@ int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipE
 	return MULLS_OK;
 }
 
-// one pair's packed record (k_pull_outs: 128-B counter block, then the used classes' 224-B rows) -> PairOut
-void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairOut &o)
+// one pair's packed record (k_pull_outs: 128-B counter block, then the used classes' 224-B rows — or, with `comb`, the single
+// combined row k_finish assembled) -> PairOut
+void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairOut &o, bool comb = false)
 {
 	int n_used = 0;
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += used[c] ? 1 : 0;
-	const size_t row = sizeof(double) * MULLS_NTERM_PAD, rec = 128 + row * (size_t)n_used;
+	const size_t row = sizeof(double) * MULLS_NTERM_PAD, rec = 128 + row * (size_t)(comb ? 1 : n_used);
 	const unsigned char *src = reinterpret_cast<const unsigned char *>(B->outs_h) + rec * (size_t)p;
 	std::memcpy(o.n_valid, src, 128); // n_valid, n_alive, src_n, tgt_n, bbox, pad_: contiguous
 	src += 128;
+	if (comb)
+	{
+		std::memcpy(o.comb, src, row);
+		return;
+	}
 	for (int c = 0; c < MULLS_NC; c++)
 		if (used[c])
 		{
@@ -912,6 +897,7 @@ extern "C"
 
 		RunParams rp;
 		std::memset(&rp, 0, sizeof(rp));
+		rp.pull_comb = 1; // the host only needs the assembled system (or VTPV and the observation count) of each pair
 		for (int c = 0; c < MULLS_NC; c++)
 			rp.used[c] = P->used_feature_type[c] == '1';
 		rp.w_balance = P->weight_strategy[0] == '1';
@@ -1178,20 +1164,13 @@ extern "C"
 			{
 				PairHost &h = H[p];
 				PairOut o;
-				unpack_out(B, rp.used, p, o);
+				unpack_out(B, rp.used, p, o, true);
 				mulls_result &R = results[p];
 				if (h.want_residual)
 				{
 					// get_multi_metrics_lls_residual (cregistration.hpp:2518-2544) + information matrix (:1386)
-					static const int order[6] = {MULLS_GROUND, MULLS_FACADE, MULLS_ROOF, MULLS_PILLAR, MULLS_BEAM, MULLS_VERTEX};
-					double VTPV = 0.0;
-					long obs = 0;
-					for (int i = 0; i < 6; i++)
-						if (rp.used[order[i]])
-						{
-							VTPV += o.sums[order[i]][0];
-							obs += (long)o.sums[order[i]][1];
-						}
+					const double VTPV = o.comb[0]; // summed over the used classes in the reference's order by k_finish
+					const long obs = (long)o.comb[1];
 					h.sigma2 = VTPV / (double)((int)obs - 6);
 					h.code = (std::sqrt(h.sigma2) < (double)P->sigma_thre) ? 1 : -3;
 					Mat6 cinv;
@@ -1274,7 +1253,7 @@ extern "C"
 				}
 				Mat6 N;
 				double b[6];
-				assemble_normal(o, rp.used, rp.faithful != 0, N, b);
+				normal_from_comb(o, N, b);
 				if (!mulls::solve_step(N, b, h.x, h.cofactor))
 					h.singular = 1;
 				if (tr)

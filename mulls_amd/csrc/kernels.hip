@@ -2340,6 +2340,56 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 		}
 	}
 	__syncthreads();
+	if (rp.pull_comb && threadIdx.x >= 64 && threadIdx.x < 64 + MULLS_NTERM)
+	{
+		// The 6x6 the reference inverts: pt2pl / pt2pt wrote the lower triangle, pt2li the upper one, then the mirror copies
+		// lower -> upper (cregistration.hpp:1924-1938).  Class order of the += chain on shared slots: ground, facade, roof (pl),
+		// pillar, beam (li), vertex (pt) (:1914-1921).  Same additions in the same order as the host did them from the class
+		// rows; only this row crosses PCIe (224 B instead of 224 B per used class).
+		const int order[MULLS_NC] = {0, 2, 4, 1, 3, 5};
+		const int t = (int)threadIdx.x - 64;
+		double val;
+		if (ps.want_residual)
+		{
+			// get_multi_metrics_lls_residual: [0] = sum of the weighted squared residuals, [1] = number of observations
+			val = 0.0;
+			if (t < 2)
+				for (int i = 0; i < MULLS_NC; i++)
+					if (rp.used[order[i]])
+						val += o.sums[order[i]][t];
+		}
+		else if (t < 21)
+		{
+			int r = 0, rem = t;
+			while (rem >= 6 - r)
+			{
+				rem -= 6 - r;
+				r++;
+			}
+			const bool diag = rem == 0;
+			double lower = 0.0, upper = 0.0;
+			for (int i = 0; i < MULLS_NC; i++)
+			{
+				const int cls = order[i];
+				if (!rp.used[cls])
+					continue;
+				const double v = o.sums[cls][t];
+				if (metric_of(cls) == 1 && !diag)
+					upper += v;
+				else
+					lower += v;
+			}
+			val = diag ? lower : (rp.faithful ? lower : lower + upper);
+		}
+		else
+		{
+			val = 0.0;
+			for (int i = 0; i < MULLS_NC; i++)
+				if (rp.used[order[i]])
+					val += o.sums[order[i]][t];
+		}
+		o.comb[t] = val;
+	}
 	if (threadIdx.x < MULLS_NC)
 	{
 		const int c = threadIdx.x;
@@ -2377,7 +2427,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ 
 // coalesced 16-B stores over PCIe (no copy-engine command, no stream synchronisation per iteration), packed to the
 // counter block + the used classes.  Completion is published through a host-visible epoch word: every workgroup makes
 // its stores system-visible, takes a ticket, and the last one to arrive writes the epoch the host is spinning on.
-static_assert(sizeof(PairOut) == MULLS_NC * MULLS_NTERM_PAD * 8 + 128, "PairOut = class rows + one 128-B counter block");
+static_assert(sizeof(PairOut) == (MULLS_NC + 1) * MULLS_NTERM_PAD * 8 + 128, "PairOut = class rows + combined row + one 128-B counter block");
 __global__ __launch_bounds__(MULLS_BLOCK) void k_pull_outs(const uint4 *__restrict__ dev_words, uint4 *__restrict__ host_words, RunParams rp,
 															uint32_t pair_base, uint32_t npairs, uint32_t *__restrict__ ticket,
 															volatile uint32_t *host_epoch, uint32_t epoch)
@@ -2386,13 +2436,15 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_pull_outs(const uint4 *__restri
 	uint32_t n_used = 0;
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += rp.used[c] ? 1u : 0u;
-	const uint32_t wpp = head_words + row_words * n_used;
+	const uint32_t wpp = head_words + row_words * (rp.pull_comb ? 1u : n_used);
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < npairs * wpp)
 	{
 		const uint32_t p = pair_base + i / wpp, w = i % wpp;
-		uint32_t src = MULLS_NC * row_words + w; // counter block
-		if (w >= head_words)
+		uint32_t src = (MULLS_NC + 1u) * row_words + w; // counter block
+		if (w >= head_words && rp.pull_comb)
+			src = MULLS_NC * row_words + (w - head_words); // the combined row
+		else if (w >= head_words)
 		{
 			uint32_t rank = (w - head_words) / row_words, cls = 0;
 			for (uint32_t c = 0; c < MULLS_NC; c++)
@@ -2592,7 +2644,7 @@ void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const Pair
 	uint32_t n_used = 0;
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += rp.used[c] ? 1u : 0u;
-	const uint32_t nwords = npairs * (8u + (MULLS_NTERM_PAD / 2u) * n_used);
+	const uint32_t nwords = npairs * (8u + (MULLS_NTERM_PAD / 2u) * (rp.pull_comb ? 1u : n_used));
 	hipLaunchKernelGGL(k_pull_outs, dim3((nwords + MULLS_BLOCK - 1) / MULLS_BLOCK), dim3(MULLS_BLOCK), 0, st, reinterpret_cast<const uint4 *>(out),
 					   reinterpret_cast<uint4 *>(out_host), rp, pair_base, npairs, ticket, host_epoch, epoch);
 }
