@@ -195,3 +195,26 @@ def test_edge_parameter_values_match_oracle(ctx, pairs_small, name):
         ro = pyoracle.icp(pair, P, trace_cap=32)[0]
         rg = ctx.icp(pair, P, trace_cap=32)[0]
         compare(ro, rg, x_tol=1e-6)
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_resident_batch_random_option_sequence(ctx_auto, pairs_small, block):
+    """One staged batch of 700 pairs (class-level LDS jobs: on-chip duplicate rule, hints and cost classes kept from iteration to
+    iteration, correspondence records) run with a sequence of random option points: whatever the previous run left in the scratch
+    arenas (hints, records, flags, cost bits) must not leak — every run equals a fresh single-pair call bit for bit."""
+    rng = np.random.default_rng(2600 + block)
+    pairs = []
+    for k in range(700):
+        base, T_gt = pairs_small[int(rng.integers(0, len(pairs_small)))]
+        pert = synth.se3(*rng.normal(0, 0.25, 3), *np.deg2rad(rng.normal(0, 0.6, 3)))
+        pairs.append(abi.PairData(base.tgt, base.src, init_guess=pert @ T_gt, tgt_bound=base.tgt_bound))
+    b = ctx_auto.batch(pairs)
+    for trial in range(4):
+        P = random_params(rng)
+        rb = b.run(P)
+        for i in rng.choice(len(pairs), 12, replace=False):
+            r1 = ctx_auto.icp(pairs[int(i)], P)[0]
+            assert (r1.code, r1.iters, list(r1.ncorr), r1.singular) == (rb[i].code, rb[i].iters, list(rb[i].ncorr), rb[i].singular), (trial, i)
+            assert np.array_equal(np.array(r1.T[:]), np.array(rb[i].T[:]), equal_nan=True), (trial, i)
+            assert np.array_equal(np.array(r1.info[:]), np.array(rb[i].info[:]), equal_nan=True), (trial, i)
+    b.close()
