@@ -1364,13 +1364,20 @@ __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc
 			valid = !(dist > F.max_sqr);
 			if (valid)
 			{
-				match[g] = m;
 				wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
 				// the matched target travels with the source point from here on: k_accum streams (position, direction) records
-				// instead of gathering two cache lines per correspondence (its launches were bound by exactly that traffic)
-				n2 = tnrm[d.tgt_off + m];
-				mq[2u * g] = tpos[d.tgt_off + m];
-				mq[2u * g + 1u] = n2;
+				// instead of gathering two cache lines per correspondence (its launches were bound by exactly that traffic).
+				// From the second iteration on most points keep their target: the record is already there (it is only ever
+				// written together with match[]), so neither gather nor store is needed — one coalesced 16-B read instead.
+				if (match[g] == m)
+					n2 = mq[2u * g + 1u];
+				else
+				{
+					match[g] = m;
+					n2 = tnrm[d.tgt_off + m];
+					mq[2u * g] = tpos[d.tgt_off + m];
+					mq[2u * g + 1u] = n2;
+				}
 				fresh = true;
 			}
 		}
