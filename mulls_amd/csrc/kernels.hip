@@ -1595,24 +1595,32 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
 	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
 	float4 pf_p = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_n = pf_p, pf_t = pf_p;
-	uint32_t pf_hv = 0xffffu, pf_f = 0u;
+	uint32_t pf_hv = 0xffffu, pf_f = 0u, pf_g = 0u;
+	int32_t pf_m = -1;
 	auto prefetch = [&](uint32_t chunk) {
 		const uint32_t s = chunk + threadIdx.x;
 		pf_f = 0u;
 		pf_hv = 0xffffu;
+		pf_m = -1;
+		pf_g = d.src_off + s;
 		if (chunk < q_end && s < min(q_end, chunk + q_step))
 		{
-			pf_f = flag[d.src_off + s];
-			pf_p = spos[d.src_off + s];
-			pf_n = snrm[d.src_off + s];
+			pf_f = flag[pf_g];
+			pf_p = spos[pf_g];
+			pf_n = snrm[pf_g];
 			if (use_hint)
-				pf_hv = (uint32_t)nn_hint[d.src_off + s];
+			{
+				pf_hv = (uint32_t)nn_hint[pf_g];
+				pf_m = match[pf_g];
+			}
 		}
 	};
 	auto prefetch_hint = [&]() {
+		// the hinted target's position: for a point whose hint is its standing correspondence it sits in the point's own
+		// record (coalesced), otherwise it is gathered
 		const uint32_t h = pf_hv & 0xffffu;
 		if (h < tgt_n)
-			pf_t = tpos[d.tgt_off + h];
+			pf_t = (int32_t)h == pf_m ? mq[2u * pf_g] : tpos[d.tgt_off + h];
 	};
 	prefetch(job.start);
 
