@@ -1453,12 +1453,22 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 // Correspondence search, LDS grid tier — the default whenever every searched target class cloud holds at most
 // MULLS_LDS_MAXPTS points (the reference-default KITTI sizes).  Rationale (profiles/r01_c_pmc_grid.txt): the global-memory
 // grid tier is neither HBM- nor VALU-bound, it waits (69 % s_waitcnt) on chains of 64-B sector gathers with ~2 us
-// latency.  Here one workgroup (512 lanes, one 512-point job) first brings the whole cell-sorted target class cloud
-// on chip with coalesced 16-B loads — planar X[] Y[] Z[] floats, a uint16 original index per point, a uint16 cell
-// table (as many cells as the rest of the 160 KiB allows) — and then runs exactly the cooperative sweep of k_nn_grid against
-// LDS: lane j of a 16-lane sub-group reads the bounds of row j, the sub-group strides over each row's contiguous
-// candidates (consecutive LDS addresses: conflict-free), 4 xor-shuffles reduce (distance, index).  Same exactness
-// argument, same outputs as k_nn / k_nn_grid.
+// latency.  Here one 1024-lane workgroup per (pair, class) — class-level jobs; 512-query jobs when a batch has too few
+// class clouds to fill the chip — brings the whole cell-sorted target class cloud on chip once with coalesced 16-B
+// loads: 12-B position records, a uint16 original index per point, a uint16 cell table (as many cells as the rest of the
+// 160 KiB allows), and then searches the source class cloud against it in equal chunks of at most MULLS_LDS_QCHUNK queries:
+//   rigid step   one lane per query: this iteration's transform (loads issued one chunk ahead), and the distance to the
+//                target the point found in the previous iteration — an exact upper bound that travels as a 4-B hint;
+//   cost order   counting sort of the chunk's queries by the candidate trips they took last time (kept next to the hint):
+//                the eight sub-groups of a wave run in lock step, so neighbours should cost the same;
+//   search       8-lane sub-groups, one query each: the cube of the bound's radius, two rows of cells per step, their
+//                candidate ranges laid end to end, two candidates per lane in flight, state = one 64-bit
+//                (distance bits, index) key, DPP minima.  Unhinted queries probe their own cell first; the 2.5*thr ball
+//                is swept only if nothing lies within one cell edge;
+//   tail         with class-level jobs: duplicate rule in an LDS table, then the rejection chain (filter_point) on the
+//                results while they are still in cache, and the matched target's record for k_accum.
+// Same exactness argument, same outputs as k_nn / k_nn_grid.  The time of this kernel follows its VALU instruction
+// count (profiles/r01_h_pmc_sq.txt); profiles/r01_m_search_steps.txt lists what each of the choices above bought.
 namespace
 {
 struct LdsGrid
@@ -2590,7 +2600,7 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 }
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 {
-	// query block, planar points + index, cell table, and (lds_dedup) the on-chip duplicate table
+	// query block, cost-sort tables, position records + index, cell table, and (lds_dedup) the on-chip duplicate table
 	return (size_t)MULLS_LDS_QCHUNK * 16u + (size_t)MULLS_LDS_AUX + (size_t)cap * 14u + (((size_t)maxcells + 8u) & ~(size_t)1) * 2u + (dedup ? (size_t)cap * 4u : 0u);
 }
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
