@@ -103,3 +103,41 @@ def test_forward_backward_round_trip(ctx_auto):
     assert fwd.code == 1 and bwd.code == 1
     dt, dr = synth.pose_error(fwd.T_matrix() @ bwd.T_matrix(), np.eye(4))
     assert dt < 0.05 and dr < 2e-3  # two independent registrations of noisy scans: within the noise floor
+
+
+@pytest.fixture(scope="module")
+def lds_limit_pair():
+    """Class clouds at the edges of the LDS tier: targets of exactly MULLS_LDS_MAXPTS = 9728 points (the cell table then gets the
+    minimum budget), source class clouds of 2500 / 5000 / 1030 queries (3, 5 and 2 equal chunks of <= 1024)."""
+    src = {abi.GROUND: 2500, abi.PILLAR: 1030, abi.FACADE: 5000, abi.BEAM: 300, abi.ROOF: 200}
+    tgt = {abi.GROUND: 9728, abi.PILLAR: 3000, abi.FACADE: 9728, abi.BEAM: 900, abi.ROOF: 600}
+    pair, T_gt = synth.make_pair(303, n_beams=128, n_az=1875, elev_deg=(-25.0, 15.0), src_counts=src, tgt_counts=tgt, vertex_count=1500)
+    assert len(pair.tgt[abi.GROUND]) == 9728 and len(pair.tgt[abi.FACADE]) == 9728 and len(pair.src[abi.FACADE]) == 5000
+    return pair, T_gt
+
+
+@pytest.mark.parametrize("used", ["111000", "111111"])
+def test_lds_tier_at_its_limits(lds_limit_pair, used):
+    """Forced LDS tier (mode 3): one pair (512-query jobs) and 200 copies (class-level jobs: duplicate rule, rejection chain, hints,
+    cost order and correspondence records on chip) against the oracle; one point more in a target is refused in mode 3."""
+    from mulls_amd import lib
+
+    pair, _ = lds_limit_pair
+    P = abi.default_params(used_feature_type=used, max_iter_num=12, converge_translation=0.0, converge_rotation_d=0.0)
+    ro = pyoracle.icp(pair, P, trace_cap=32)[0]
+    assert ro.iters == 12
+    c = lib.Context(0)
+    c.set_nn_mode(3)
+    try:
+        close(ro, c.icp(pair, P, trace_cap=32)[0])
+        rb = c.icp_batch([pair] * 200, P)
+        for i in (0, 57, 199):
+            assert (rb[i].code, rb[i].iters, list(rb[i].ncorr)) == (ro.code, ro.iters, list(ro.ncorr))
+            dt, dr = synth.pose_error(rb[i].T_matrix(), ro.T_matrix())
+            assert dt <= 1e-7 and dr <= 1e-7
+        big = list(pair.tgt)
+        big[abi.GROUND] = np.concatenate([big[abi.GROUND], big[abi.GROUND][:1]])
+        with pytest.raises(lib.MullsError):
+            c.icp(abi.PairData(big, pair.src, init_guess=pair.init_guess, tgt_bound=pair.tgt_bound), P)
+    finally:
+        c.close()
