@@ -1,4 +1,4 @@
-// device_types.h — plain structs shared by the HIP kernels (kernels.hip) and the host driver (driver.cpp).
+// device_types.h — plain structs shared by the HIP kernels (k_*.hip) and the host driver (driver.cpp).
 // Layouts live in HBM exactly as declared here; see DESIGN.md §"Data layout in HBM".
 #pragma once
 #include <stdint.h>

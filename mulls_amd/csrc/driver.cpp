@@ -2,7 +2,7 @@
 // lock-step ICP iteration loop (reference: CRegistration::mm_lls_icp, include/common/cregistration.hpp:1114-1440).
 //
 // Division of labour (BASELINE.json north_star): correspondences, rejection and the normal-equation reduction run in
-// the HIP kernels of kernels.hip; per iteration and per pair the host receives 6 x 27 doubles + a few counters, mirrors
+// the HIP kernels of k_setup / k_grid / k_search / k_reduce .hip; per iteration and per pair the host receives 6 x 27 doubles + a few counters, mirrors
 // and solves the 6x6 system, builds the rigid step, applies the convergence / health tests and writes the next
 // PairState.  One H2D copy, three to four launches, one D2H copy and one stream sync advance the whole batch by one
 // ICP iteration.  There is no CPU fallback anywhere in this file: without a usable HIP device every entry point

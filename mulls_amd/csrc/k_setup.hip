@@ -1,0 +1,562 @@
+// k_setup.hip — once per registration: clone + initial guess, intersection crop, keep-less thinning
+// (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
+#include "device_util.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Setup 1: clone the staged source clouds into SoA and apply the initial guess (double math, float store); reduce
+// the bounding box of the transformed ground / pillar / facade source clouds (cregistration.hpp:2912-2915).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+															const PairSetup *__restrict__ setup, const float4 *__restrict__ stage,
+															float4 *__restrict__ tmp_pos, float4 *__restrict__ tmp_nrm,
+															uint32_t *__restrict__ bbox /* [pair][6] ordered keys */, RunParams rp)
+{
+	const Job job = jobs[blockIdx.x];
+	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const uint32_t s = job.start + threadIdx.x;
+	// motion undistortion regenerates the five non-vertex clouds from block2->pc_*_down (cregistration.hpp:1251-1253)
+	const bool regen = rp.undistort && job.cls != 5;
+	const uint32_t n_in = regen ? d.sd_n0 : d.src_n0;
+	const bool in = s < n_in;
+	const PairSetup &su = setup[job.pair];
+	const double *G = su.guess;
+	float x = 0, y = 0, z = 0;
+	if (in)
+	{
+		const float4 *rec = stage + (size_t)((regen ? d.sd_stage : d.src_stage) + s) * 3;
+		float4 a = rec[0], b = rec[1], c = rec[2]; // (x y z _) (nx ny nz _) (intensity curvature _ _)
+		if (regen)
+		{
+			// CFilter::apply_motion_compensation(in, out, inverse(initial_guess)) (cfilter.hpp:493-516): the point is moved
+			// by the fraction `curvature` (its time stamp in [0,1]) of the inverse guess — slerp from the identity
+			// quaternion, linear translation — in double, stored as float; normals are copied unrotated.
+			const float sc = c.y;
+			if (!(sc < 0.0f || (double)sc > 1.0 - 0.0f))
+			{
+				const double t = (double)sc, one = 1.0 - 2.220446049250313e-16;
+				const double dq = su.inv_q[0], absD = fabs(dq);
+				double s0, s1;
+				if (absD >= one)
+				{
+					s0 = 1.0 - t;
+					s1 = t;
+				}
+				else
+				{
+					const double theta = acos(absD), sinTheta = sin(theta);
+					s0 = sin((1.0 - t) * theta) / sinTheta;
+					s1 = sin((t * theta)) / sinTheta;
+				}
+				if (dq < 0)
+					s1 = -s1;
+				const double qw = s0 + s1 * su.inv_q[0], qx = s1 * su.inv_q[1], qy = s1 * su.inv_q[2], qz = s1 * su.inv_q[3];
+				const double vx = a.x, vy = a.y, vz = a.z;
+				const double uvx = 2.0 * (qy * vz - qz * vy), uvy = 2.0 * (qz * vx - qx * vz), uvz = 2.0 * (qx * vy - qy * vx);
+				const double rx = vx + qw * uvx + (qy * uvz - qz * uvy);
+				const double ry = vy + qw * uvy + (qz * uvx - qx * uvz);
+				const double rz = vz + qw * uvz + (qx * uvy - qy * uvx);
+				a.x = (float)(rx + t * su.inv_t[0]);
+				a.y = (float)(ry + t * su.inv_t[1]);
+				a.z = (float)(rz + t * su.inv_t[2]);
+			}
+		}
+		const int reps = (rp.undistort && job.cls == 5) ? 2 : 1; // the vertex cloud is not regenerated: it receives the guess twice
+		float onx = b.x, ony = b.y, onz = b.z;					  // (cregistration.hpp:1183 and :1257)
+		x = a.x, y = a.y, z = a.z;
+		for (int rep = 0; rep < reps; rep++)
+		{
+			const double px = x, py = y, pz = z, nx = onx, ny = ony, nz = onz;
+			x = (float)(G[0] * px + G[1] * py + G[2] * pz + G[3]);
+			y = (float)(G[4] * px + G[5] * py + G[6] * pz + G[7]);
+			z = (float)(G[8] * px + G[9] * py + G[10] * pz + G[11]);
+			onx = (float)(G[0] * nx + G[1] * ny + G[2] * nz);
+			ony = (float)(G[4] * nx + G[5] * ny + G[6] * nz);
+			onz = (float)(G[8] * nx + G[9] * ny + G[10] * nz);
+		}
+		tmp_pos[d.src_off + s] = make_float4(x, y, z, c.x);
+		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, c.y);
+	}
+	if (job.cls == 0 || job.cls == 1 || job.cls == 2)
+	{
+		uint32_t k[6];
+		k[0] = in ? f2ord(x) : 0xffffffffu;
+		k[1] = in ? f2ord(y) : 0xffffffffu;
+		k[2] = in ? f2ord(z) : 0xffffffffu;
+		k[3] = in ? f2ord(x) : 0u;
+		k[4] = in ? f2ord(y) : 0u;
+		k[5] = in ? f2ord(z) : 0u;
+		for (int off = 32; off > 0; off >>= 1)
+			for (int j = 0; j < 3; j++)
+			{
+				k[j] = min(k[j], (uint32_t)__shfl_down(k[j], off));
+				k[3 + j] = max(k[3 + j], (uint32_t)__shfl_down(k[3 + j], off));
+			}
+		if ((threadIdx.x & 63) == 0)
+			for (int j = 0; j < 3; j++)
+			{
+				atomicMin(&bbox[job.pair * 6 + j], k[j]);
+				atomicMax(&bbox[job.pair * 6 + 3 + j], k[3 + j]);
+			}
+	}
+}
+
+// the intersection box of get_cloud_pair_intersection (cfilter.hpp:2613-2655): union box of the transformed source clouds
+// (ordered keys from k_clone_src) against block1->local_bound, padded by 1 m
+namespace
+{
+__device__ __forceinline__ void crop_box(uint32_t pair, const uint32_t *__restrict__ bbox, const PairSetup *__restrict__ setup, double lo[3],
+										  double hi[3])
+{
+	for (int k = 0; k < 3; k++)
+	{
+		uint32_t kmin = bbox[pair * 6 + k], kmax = bbox[pair * 6 + 3 + k];
+		// an empty union keeps (+DBL_MAX, -DBL_MAX) like CloudUtility::merge_bbx (utility.hpp:867-884)
+		double mmin = (kmin == 0xffffffffu && kmax == 0u) ? 1.7976931348623157e308 : (double)ord2f(kmin);
+		double mmax = (kmin == 0xffffffffu && kmax == 0u) ? -1.7976931348623157e308 : (double)ord2f(kmax);
+		double b1min = setup[pair].tgt_bound[k], b1max = setup[pair].tgt_bound[3 + k];
+		const float pad = 1.0f;
+		lo[k] = ((b1min > mmin) ? b1min : mmin) - pad; // get_intersection_bbx, utility.hpp:857-865
+		hi[k] = ((b1max < mmax) ? b1max : mmax) + pad;
+	}
+}
+// strict inequalities, float coordinate promoted to double (cfilter.hpp:959-961)
+__device__ __forceinline__ bool crop_keep(const float4 &p, const double lo[3], const double hi[3])
+{
+	return (double)p.x > lo[0] && (double)p.x < hi[0] && (double)p.y > lo[1] && (double)p.y < hi[1] && (double)p.z > lo[2] && (double)p.z < hi[2];
+}
+// cells along one axis for an extent and a cell edge — the same float expression as grid_cell(), so that the largest
+// coordinate lands in the last cell; an absurd extent (the bounding box only sees coordinates within 1e18 m)
+// saturates instead of overflowing the conversion, and the caller then grows the cell edge until the grid fits
+__device__ __forceinline__ uint32_t grid_dim(float extent, float inv_h)
+{
+	const float c = floorf(extent * inv_h);
+	return c >= 0.0f ? (uint32_t)fminf(c, 4.0e9f) + 1u : 1u; // also false for NaN
+}
+// grid descriptor of a cropped target cloud with bounding box [lo3, hi3] and `running` points
+__device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi3[3], uint32_t running, const RunParams &rp, uint32_t pair,
+											   uint32_t cls)
+{
+	GridDesc g;
+	g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
+	g.h = rp.grid_h0;
+	g.nx = g.ny = g.nz = 1;
+	g.ncell = 0;
+	g.wpr = 1;
+	g.nocc = 0;
+	uint32_t nwords = 1;
+	if (running > 0 && rp.bm_h0 > 0.0f)
+	{
+		// global-memory tier: occupancy bitmap over fine cells; rows are padded to whole 64-cell words
+		g.h = rp.bm_h0;
+		if (rp.bm_auto) // points lie on surfaces: mean spacing ~ sqrt(footprint / count); measured optimum 0.25 m (1 M points) .. 0.7 m (5 k)
+			g.h = fminf(fmaxf(sqrtf((hi3[0] - lo3[0]) * (hi3[1] - lo3[1]) / (float)running), rp.bm_h0), 2.8f * rp.bm_h0);
+		for (;;)
+		{
+			g.inv_h = 1.0f / g.h;
+			g.nx = grid_dim(hi3[0] - g.ox, g.inv_h);
+			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
+			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
+			g.wpr = (g.nx + 63u) >> 6;
+			if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
+				break;
+			g.h *= 1.25f;
+		}
+		nwords = g.ny * g.nz * g.wpr;
+	}
+	else if (running > 0)
+		for (;;)
+		{
+			g.inv_h = 1.0f / g.h;
+			// same float expression as grid_cell() so that the largest coordinate lands in the last cell
+			g.nx = grid_dim(hi3[0] - g.ox, g.inv_h);
+			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
+			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
+			if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
+				break;
+			g.h *= 1.25f;
+		}
+	else
+		g.inv_h = 1.0f;
+	// cell tables are laid out over the USED classes only: slot = pair * n_used + rank of this class among them
+	uint32_t n_used = 0, rank = 0;
+	for (uint32_t c = 0; c < MULLS_NC; c++)
+	{
+		if (c < cls && rp.used[c])
+			rank++;
+		n_used += rp.used[c] ? 1u : 0u;
+	}
+	g.ncell = (running > 0 && rp.used[cls]) ? (rp.bm_h0 > 0.0f ? nwords : g.nx * g.ny * g.nz) : 0u;
+	g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
+	return g;
+}
+} // namespace
+
+// Setup 2: order-preserving compaction of one cloud by the intersection box.  One workgroup per (pair, class, side);
+// side 0 = source (reads the SoA written by k_clone_src), side 1 = target (reads the staged AoS records).
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ descs, const PairSetup *__restrict__ setup,
+													   const uint32_t *__restrict__ bbox, const float4 *__restrict__ stage,
+													   const float4 *__restrict__ tmp_pos, const float4 *__restrict__ tmp_nrm,
+													   float4 *__restrict__ spos, float4 *__restrict__ snrm, float4 *__restrict__ tpos,
+													   float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, int32_t *__restrict__ match,
+													   float *__restrict__ wd, RunParams rp, GridDesc *__restrict__ grids, uint32_t *__restrict__ big_box)
+{
+	const int crop = rp.crop;
+	__shared__ uint32_t wave_cnt[4];
+	__shared__ float box_red[4][6];
+	const uint32_t pair = blockIdx.x / (MULLS_NC * 2);
+	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
+	const uint32_t side = blockIdx.x & 1;
+	CloudDesc &d = descs[pair * MULLS_NC + cls];
+	const uint32_t n0 = side ? d.tgt_n0 : ((rp.undistort && cls != 5) ? d.sd_n0 : d.src_n0);
+	const uint32_t off = side ? d.tgt_off : d.src_off;
+	if (side && d.big_slot)
+	{
+		// cropped by k_crop_big_* (many workgroups); this one only arms the cloud's bounding-box keys
+		if (threadIdx.x < 6)
+			big_box[(d.big_slot - 1u) * 6u + threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+		return;
+	}
+	double lo[3], hi[3];
+	if (crop)
+		crop_box(pair, bbox, setup, lo, hi);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = 0;
+	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+	for (uint32_t base = 0; base < n0; base += MULLS_BLOCK)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const bool in = i < n0;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		if (in)
+		{
+			if (side)
+			{
+				const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
+				float4 a = rec[0], b = rec[1], c = rec[2];
+				p = make_float4(a.x, a.y, a.z, c.x);
+				q = make_float4(b.x, b.y, b.z, c.y);
+			}
+			else
+			{
+				p = tmp_pos[off + i];
+				q = tmp_nrm[off + i];
+			}
+		}
+		bool keep = in;
+		if (crop && in)
+			keep = crop_keep(p, lo, hi);
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads();
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			const uint32_t dst = off + running + wbase + before;
+			if (side)
+			{
+				tpos[dst] = p;
+				tnrm[dst] = q;
+				if (fabsf(p.x) <= 1.0e18f && fabsf(p.y) <= 1.0e18f && fabsf(p.z) <= 1.0e18f) // the grid covers the finite points; others clamp into its border cells
+				{
+					bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+					bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				}
+			}
+			else
+			{
+				spos[dst] = p;
+				snrm[dst] = q;
+				flag[dst] = MULLS_F_ALIVE;
+				match[dst] = -1;
+				wd[dst] = 0.0f;
+			}
+		}
+		running += total;
+	}
+	if (side && grids)
+	{
+		// bounding box of the surviving target points -> uniform grid descriptor for the grid search tier
+		for (int k = 0; k < 3; k++)
+			for (int off = 32; off > 0; off >>= 1)
+			{
+				bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
+				bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
+			}
+		__syncthreads();
+		if (lane == 0)
+			for (int k = 0; k < 3; k++)
+			{
+				box_red[wave][k] = bmin[k];
+				box_red[wave][3 + k] = bmax[k];
+			}
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			float lo3[3], hi3[3];
+			for (int k = 0; k < 3; k++)
+			{
+				lo3[k] = fminf(fminf(box_red[0][k], box_red[1][k]), fminf(box_red[2][k], box_red[3][k]));
+				hi3[k] = fmaxf(fmaxf(box_red[0][3 + k], box_red[1][3 + k]), fmaxf(box_red[2][3 + k], box_red[3][3 + k]));
+			}
+			grids[pair * MULLS_NC + cls] = make_grid(lo3, hi3, running, rp, pair, cls);
+		}
+	}
+	if (threadIdx.x == 0)
+	{
+		if (side)
+			d.tgt_n = running;
+		else
+		{
+			d.src_n = running;
+			d.alive_cur = running;
+			d.alive_next = 0;
+			d.n_matched = 0;
+			d.valid_next = 0;
+			d.n_valid = 0;
+		}
+	}
+}
+
+// Setup 2, target class clouds beyond MULLS_BIG_CLOUD points (scan-to-map against a large local map): one workgroup per
+// 4096-point segment instead of one per cloud (a single CU's memory bandwidth made a 400 k-point crop take 1.7 ms).
+// count -> per-cloud scan of the segment counts (+ bounding box -> grid descriptor) -> scatter; same stable order.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
+																 const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
+																 const float4 *__restrict__ stage, RunParams rp, uint32_t *__restrict__ seg_cnt,
+																 uint32_t *__restrict__ big_box)
+{
+	__shared__ uint32_t red4[4];
+	const Job sg = segs[blockIdx.x]; // count = big slot
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	double lo[3], hi[3];
+	if (rp.crop)
+		crop_box(sg.pair, bbox, setup, lo, hi);
+	uint32_t mine = 0;
+	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+	for (uint32_t k = 0; k < MULLS_SEG; k += MULLS_BLOCK)
+	{
+		const uint32_t i = sg.start + k + threadIdx.x;
+		if (i < d.tgt_n0)
+		{
+			const float4 p = stage[(size_t)(d.tgt_stage + i) * 3];
+			if (!rp.crop || crop_keep(p, lo, hi))
+			{
+				mine++;
+				if (fabsf(p.x) <= 1.0e18f && fabsf(p.y) <= 1.0e18f && fabsf(p.z) <= 1.0e18f) // the grid covers the finite points; others clamp into its border cells
+				{
+					bmin[0] = fminf(bmin[0], p.x), bmin[1] = fminf(bmin[1], p.y), bmin[2] = fminf(bmin[2], p.z);
+					bmax[0] = fmaxf(bmax[0], p.x), bmax[1] = fmaxf(bmax[1], p.y), bmax[2] = fmaxf(bmax[2], p.z);
+				}
+			}
+		}
+	}
+	for (int k = 0; k < 3; k++)
+	{
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
+			bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
+		}
+		if ((threadIdx.x & 63) == 0 && bmin[k] <= bmax[k])
+		{
+			atomicMin(&big_box[sg.count * 6u + k], f2ord(bmin[k]));
+			atomicMax(&big_box[sg.count * 6u + 3 + k], f2ord(bmax[k]));
+		}
+	}
+	const uint32_t total = block_sum_u32(mine, red4);
+	if (threadIdx.x == 0)
+		seg_cnt[blockIdx.x] = total;
+}
+
+// one wave per big cloud: segment counts -> segment bases, cloud size, grid descriptor
+__global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ clouds, CloudDesc *__restrict__ descs, RunParams rp,
+													   uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ big_box,
+													   GridDesc *__restrict__ grids)
+{
+	const Job bc = clouds[blockIdx.x]; // start = first segment, count = number of segments
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < bc.count; base += 64)
+	{
+		const uint32_t s = base + threadIdx.x;
+		const uint32_t v = s < bc.count ? seg_cnt[bc.start + s] : 0u;
+		uint32_t incl = v;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if ((int)threadIdx.x >= off)
+				incl += o;
+		}
+		if (s < bc.count)
+			seg_cnt[bc.start + s] = running + incl - v;
+		running += __shfl(incl, 63);
+	}
+	if (threadIdx.x == 0)
+	{
+		descs[bc.pair * MULLS_NC + bc.cls].tgt_n = running;
+		if (grids)
+		{
+			float lo3[3], hi3[3];
+			for (int k = 0; k < 3; k++)
+			{
+				lo3[k] = running ? ord2f(big_box[blockIdx.x * 6u + k]) : __builtin_inff();
+				hi3[k] = running ? ord2f(big_box[blockIdx.x * 6u + 3 + k]) : -__builtin_inff();
+			}
+			grids[bc.pair * MULLS_NC + bc.cls] = make_grid(lo3, hi3, running, rp, bc.pair, bc.cls);
+		}
+	}
+}
+
+__global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
+																   const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
+																   const float4 *__restrict__ stage, RunParams rp,
+																   const uint32_t *__restrict__ seg_base, float4 *__restrict__ tpos,
+																   float4 *__restrict__ tnrm)
+{
+	__shared__ uint32_t wave_cnt[4];
+	const Job sg = segs[blockIdx.x];
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	double lo[3], hi[3];
+	if (rp.crop)
+		crop_box(sg.pair, bbox, setup, lo, hi);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = seg_base[blockIdx.x];
+	for (uint32_t k = 0; k < MULLS_SEG; k += MULLS_BLOCK)
+	{
+		const uint32_t i = sg.start + k + threadIdx.x;
+		bool keep = false;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		if (i < d.tgt_n0)
+		{
+			const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
+			const float4 a = rec[0], b = rec[1], c = rec[2];
+			p = make_float4(a.x, a.y, a.z, c.x);
+			q = make_float4(b.x, b.y, b.z, c.y);
+			keep = !rp.crop || crop_keep(p, lo, hi);
+		}
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads();
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			tpos[d.tgt_off + running + wbase + before] = p;
+			tnrm[d.tgt_off + running + wbase + before] = q;
+		}
+		running += total;
+	}
+}
+
+// Setup 2b (keep_less_source_points only): order-preserving in-place compaction of one cloud by a host-made keep mask
+// (cregistration.hpp:2866-2892).  One workgroup per (pair, class, side); destinations never overtake unread sources.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_thin(CloudDesc *__restrict__ descs, const uint8_t *__restrict__ src_keep,
+													   const uint8_t *__restrict__ tgt_keep, float4 *__restrict__ spos, float4 *__restrict__ snrm,
+													   float4 *__restrict__ tpos, float4 *__restrict__ tnrm)
+{
+	__shared__ uint32_t wave_cnt[4];
+	const uint32_t pair = blockIdx.x / (MULLS_NC * 2);
+	const uint32_t cls = (blockIdx.x / 2) % MULLS_NC;
+	const uint32_t side = blockIdx.x & 1;
+	CloudDesc &d = descs[pair * MULLS_NC + cls];
+	const uint32_t n0 = side ? d.tgt_n : d.src_n;
+	const uint32_t off = side ? d.tgt_off : d.src_off;
+	const uint8_t *keepm = (side ? tgt_keep : src_keep) + off;
+	float4 *pos = side ? tpos : spos, *nrm = side ? tnrm : snrm;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < n0; base += MULLS_BLOCK)
+	{
+		const uint32_t i = base + threadIdx.x;
+		const bool in = i < n0;
+		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+		bool keep = false;
+		if (in)
+		{
+			p = pos[off + i];
+			q = nrm[off + i];
+			keep = keepm[i] != 0;
+		}
+		const unsigned long long bal = __ballot(keep);
+		const uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+		__syncthreads(); // every load of this chunk has completed before any store of it
+		if (lane == 0)
+			wave_cnt[wave] = __popcll(bal);
+		__syncthreads();
+		uint32_t wbase = 0, total = 0;
+		for (int w = 0; w < 4; w++)
+		{
+			if (w < wave)
+				wbase += wave_cnt[w];
+			total += wave_cnt[w];
+		}
+		if (keep)
+		{
+			const uint32_t dst = off + running + wbase + before;
+			pos[dst] = p;
+			nrm[dst] = q;
+		}
+		running += total;
+	}
+	if (threadIdx.x == 0)
+	{
+		if (side)
+			d.tgt_n = running;
+		else
+		{
+			d.src_n = running;
+			d.alive_cur = running;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
+#include "launch.h"
+
+void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
+					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp)
+{
+	if (njobs)
+		hipLaunchKernelGGL(k_clone_src, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, setup, stage, tmp_pos, tmp_nrm, bbox, rp);
+}
+
+void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,
+				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
+				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids, uint32_t nbig_segs, const Job *big_segs, uint32_t nbig_clouds,
+				 const Job *big_clouds, uint32_t *seg_cnt, uint32_t *big_box)
+{
+	if (!npairs)
+		return;
+	hipLaunchKernelGGL(k_crop, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, setup, bbox, stage, tmp_pos, tmp_nrm, spos, snrm, tpos,
+					   tnrm, flag, match, wd, rp, grids, big_box);
+	if (nbig_clouds)
+	{
+		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, big_box);
+		hipLaunchKernelGGL(k_crop_big_scan, dim3(nbig_clouds), dim3(64), 0, st, big_clouds, descs, rp, seg_cnt, big_box, grids);
+		hipLaunchKernelGGL(k_crop_big_scatter, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, tpos,
+						   tnrm);
+	}
+}
+
+void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
+				 float4 *tpos, float4 *tnrm)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_thin, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, src_keep, tgt_keep, spos, snrm, tpos, tnrm);
+}

@@ -1,4 +1,4 @@
-// launch.h — host-callable wrappers around the kernels in kernels.hip.
+// launch.h — host-callable wrappers around the kernels in k_setup / k_grid / k_search / k_reduce .hip (each unit defines its own).
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>

@@ -1,6 +1,6 @@
 // map.cpp — device-resident local map (include/mulls_hip.h, "mulls_map_*"): MapManager::update_local_map
 // (src/map_manager.cpp:18-140) and map-based dynamic-object removal (:149-268) on class clouds that stay in HBM between
-// frames.  Kernels: map_kernels.hip (+ k_transform_aos of kernels.hip).  As everywhere in this library there is no CPU
+// frames.  Kernels: map_kernels.hip (+ k_transform_aos of k_reduce.hip).  As everywhere in this library there is no CPU
 // fallback: the only host-side arithmetic is the pose algebra, the kept-point counts and the seeded selection masks.
 #include <hip/hip_runtime_api.h>
 
