@@ -1128,7 +1128,7 @@ extern "C"
 				}
 				else if (tier == 1)
 					launch_nn_grid(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
-								   B->nn_d2, B->winner);
+								   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
 				else
 					launch_nn(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 				if (rp.normal_shooting)
@@ -1491,7 +1491,7 @@ extern "C"
 			}
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
-							   B->nn_idx, B->nn_d2, B->winner);
+							   B->nn_idx, B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
@@ -1799,7 +1799,7 @@ extern "C"
 							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
-							   B->nn_idx, B->nn_d2, B->winner);
+							   B->nn_idx, B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
 			else if (tier < 0)
 				rc = MULLS_E_INVALID;
 			else

@@ -167,9 +167,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 														  const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
 														  const uint32_t *__restrict__ cs, const float4 *__restrict__ tsorted,
 														  const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
-														  unsigned long long *__restrict__ winner, uint32_t split)
+														  unsigned long long *__restrict__ winner, uint32_t split, const float4 *__restrict__ tpos,
+														  int32_t *__restrict__ nn_hint, const int32_t *__restrict__ match, const float4 *__restrict__ mq)
 {
-	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = 1 for live points, 0 for dead / out of range
+	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = upper bound on the squared NN distance (+inf: none), -1 = dead / out of range
 	const uint32_t wg = xcd_job(blockIdx.x, gridDim.x);
 	const Job job = jobs[wg / split];
 	const uint32_t per = MULLS_SRC_PER_BLOCK / split, q0 = (wg % split) * per; // this workgroup's queries of the job: [q0, q0 + per)
@@ -180,12 +181,17 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 	CloudDesc &d = descs[ci];
 	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
 	const bool called = class_called(rp, d, job.cls);
+	// temporal coherence, as in k_nn_lds: the target a point found in the previous iteration bounds this iteration's search
+	// exactly (any target is an upper bound).  Here every probe is a chain of dependent global loads (occupancy word -> rank /
+	// start -> candidates), so starting with the cube of that radius instead of the own-cell probe saves a whole chain.
+	const bool use_hint = called && ps.iter > 0;
+	const uint32_t tgt_n = d.tgt_n;
 	{
 		const double *T = ps.T;
 		for (uint32_t k = threadIdx.x; k < per; k += MULLS_BLOCK)
 		{
 			const uint32_t s = job.start + q0 + k;
-			float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
 			if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
 			{
 				// pcl::transformPointCloudWithNormals<PointT,double> (cregistration.hpp:1690-1695)
@@ -194,7 +200,20 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
 				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
 				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-				out.w = 1.0f;
+				out.w = __builtin_inff();
+				if (use_hint)
+				{
+					const uint32_t h = (uint32_t)nn_hint[d.src_off + s];
+					if (h < tgt_n)
+					{
+						// a point whose hint is its standing correspondence carries that target's position in its own record
+						const float4 t = (int32_t)h == match[d.src_off + s] ? mq[2u * (d.src_off + s)] : tpos[d.tgt_off + h];
+						const float dx = out.x - t.x, dy = out.y - t.y, dz = out.z - t.z;
+						const float d0 = (dx * dx + dy * dy) + dz * dz;
+						if (d0 >= 0.0f)
+							out.w = d0;
+					}
+				}
 				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
 				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
 				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
@@ -225,10 +244,18 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 		if (s >= src_n)
 			break;
 		const float4 q = qpos[k];
-		if (q.w == 0.0f)
+		if (q.w < 0.0f)
 			continue;
 		float best = __builtin_inff();
 		int bi = -1;
+		if (q.w < __builtin_inff())
+		{
+			// bounded by last iteration's correspondence: one sweep of the cube of that radius (it contains that target)
+			grid_scan_box(g, B, ts, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, best, bi);
+			group_min(best, bi);
+		}
+		else
+		{
 		// probe 0: the query's own cell
 		const int ocx = grid_cell(q.x, g.ox, g.inv_h, g.nx), ocy = grid_cell(q.y, g.oy, g.inv_h, g.ny), ocz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 		{
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 				group_min(best, bi);
 			}
 		}
+		}
 		// nothing inside the probed radius yet: one last probe at the distance found, else double the radius (up to r)
 		float Rc = m;
 		while (!(bi >= 0 && best <= Rc * Rc) && Rc < r)
@@ -290,6 +318,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__
 			const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
 			nn_idx[d.src_off + s] = matched ? bi : -1;
 			nn_d2[d.src_off + s] = best;
+			nn_hint[d.src_off + s] = bi;
 			if (matched)
 			{
 				matched_cnt++;
@@ -1053,7 +1082,8 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 
 void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 					float4 *spos, float4 *snrm, const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs,
-					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner)
+					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tpos,
+					int32_t *nn_hint, const int32_t *match, const float4 *mq)
 {
 	if (!njobs)
 		return;
@@ -1062,7 +1092,7 @@ void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *
 	while (split < 16 && njobs * split < 1024u)
 		split <<= 1;
 	hipLaunchKernelGGL(k_nn_grid, dim3(njobs * split), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, bm, pf, cs, tsorted,
-					   flag, nn_idx, nn_d2, winner, split);
+					   flag, nn_idx, nn_d2, winner, split, tpos, nn_hint, match, mq);
 }
 
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
