@@ -676,14 +676,12 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		const uint32_t nw = (g.ncell + 1u + 7u) >> 3;
 		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 4 * MULLS_LDS_BLOCK)
 		{
+			// unconditional loads at clamped indices: a predicated `if (w < nw) v[u] = ...` makes the compiler park v[] in scratch
+			// and wait for every load on its own (four serialised round trips per workgroup, seen in the ISA listing)
 			uint4 v[4];
 #pragma unroll
 			for (int u = 0; u < 4; u++)
-			{
-				const uint32_t w = w0 + u * MULLS_LDS_BLOCK;
-				if (w < nw)
-					v[u] = cs4[w];
-			}
+				v[u] = cs4[min(w0 + u * MULLS_LDS_BLOCK, nw - 1u)];
 #pragma unroll
 			for (int u = 0; u < 4; u++)
 			{
