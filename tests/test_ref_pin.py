@@ -127,3 +127,31 @@ def test_4dof_global_variant(pairs_small):
     if ok_o:
         dt, dr = synth.pose_error(ro.T_matrix() @ synth.se3(0, 0, 0, 0, 0, yaw), T_gt)
         assert dt < 0.3 and dr < 0.02, (dt, dr, best)
+
+
+EDGE_PARAMS = {  # the values tests/test_gpu_fuzz.py::test_edge_parameter_values_match_oracle runs on the device
+    "zero_iterations": dict(max_iter_num=0),
+    "negative_iterations": dict(max_iter_num=-3),
+    "many_iterations": dict(max_iter_num=300, converge_translation=0.0, converge_rotation_d=0.0),
+    "zero_threshold": dict(dis_thre_unit=0.0, dis_thre_min=0.0),
+    "min_above_unit": dict(dis_thre_unit=0.5, dis_thre_min=2.0),
+    "growing_threshold": dict(dis_thre_update_rate=0.8, max_iter_num=12),
+    # zero residual windows are left out: every weight becomes 0/0, the transform NaN, and the searches that follow run on NaN queries,
+    # where the kd-tree stand-in of oracle/ref_shim and the oracle's own tree need not visit nodes alike (FLANN itself is unspecified there)
+    "zero_balance": dict(z_xy_balanced_ratio=0.0),
+    "negative_bearing": dict(normal_bearing=-10.0),
+    "nothing_used": dict(used_feature_type="000000"),
+    "only_vertex": dict(used_feature_type="000001"),
+    "odd_flags": dict(used_feature_type="1x1 01", weight_strategy="2a01"),
+    "zero_rate": dict(dis_thre_update_rate=0.0, max_iter_num=4),
+    "huge_threshold": dict(dis_thre_unit=400.0, dis_thre_min=100.0, max_iter_num=3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_PARAMS))
+def test_edge_parameter_values_oracle_equals_reference(pairs_small, name):
+    """Parameter values nobody would configure but the reference accepts without a check: the restatement follows the reference's
+    own lines there too (the device is compared with the oracle on the same values)."""
+    P = abi.default_params(**EDGE_PARAMS[name])
+    pair, _ = pairs_small[0]
+    same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
