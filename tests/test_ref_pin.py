@@ -155,3 +155,21 @@ def test_edge_parameter_values_oracle_equals_reference(pairs_small, name):
     P = abi.default_params(**EDGE_PARAMS[name])
     pair, _ = pairs_small[0]
     same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_option_points_oracle_equals_reference(pairs_small, block):
+    """The seeded random points of the 23-dimensional option space that tests/test_gpu_fuzz.py runs on the device (same generator):
+    here the oracle against the reference's own lines, bit for bit.  `faithful` is forced on (the reference has no other mode) and
+    `keep_less_source_points` off (upstream thins with a time-seeded pcl::RandomSample; the ABI defines its own seeded selection)."""
+    from test_gpu_fuzz import random_params
+
+    rng = np.random.default_rng(900 + block)
+    for k in range(12):
+        base, T_gt = pairs_small[int(rng.integers(0, len(pairs_small)))]
+        pert = synth.se3(*rng.normal(0, 0.25, 3), *np.deg2rad(rng.normal(0, 0.6, 3)))
+        pair = abi.PairData(base.tgt, base.src, init_guess=pert @ T_gt, tgt_bound=base.tgt_bound)
+        P = random_params(rng)
+        P.faithful = 1
+        P.keep_less_source_points = 0
+        same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
