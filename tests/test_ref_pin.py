@@ -173,3 +173,22 @@ def test_random_option_points_oracle_equals_reference(pairs_small, block):
         P.faithful = 1
         P.keep_less_source_points = 0
         same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "one_cell", "far_origin", "collinear", "sparse_far", "ragged"])
+def test_degenerate_inputs_oracle_equals_reference(kind):
+    """The pathological inputs of tests/test_gpu_fuzz.py (exact duplicates, everything in one cell, coordinates around 1e5 m,
+    collinear clouds, nothing within reach, empty and tiny class clouds): the reference's lines have no special cases for them,
+    the oracle must follow them bit for bit."""
+    import zlib
+
+    from test_gpu_fuzz import degenerate_pair, random_params
+
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 1)
+    for k in range(8):
+        pair = degenerate_pair(rng, kind)
+        P = random_params(rng)
+        P.apply_motion_undistortion = 0
+        P.faithful = 1
+        P.keep_less_source_points = 0
+        same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
