@@ -125,3 +125,59 @@ def test_oracle_properties():
     expect = pyoracle.transform(v, T)
     same_cloud(mq[5], expect)
     assert all(len(mq[c]) == 0 for c in range(5))
+
+
+@needs_ref
+@pytest.mark.parametrize("block", range(3))
+def test_random_update_sequences_oracle_equals_reference_lines(block):
+    """Seeded random sequences (frames with empty / tiny / duplicated class clouds, random radii, dynamic removal with every tree
+    state, class sets with holes) — without thinning, which is time-seeded upstream: bit-identical maps and appended frames."""
+    rng = np.random.default_rng(5200 + block)
+    frames = small_frames(200 + block, n_frames=5)
+
+    def mutate(clouds):
+        out = []
+        for c in clouds:
+            roll = rng.random()
+            if roll < 0.15:
+                out.append(c[:0])
+            elif roll < 0.3:
+                out.append(c[: int(rng.integers(1, 12))])
+            elif roll < 0.4:
+                out.append(np.concatenate([c, c[: len(c) // 2]]))
+            else:
+                out.append(c)
+        return out
+
+    frames = [(mutate(fc), fp) for fc, fp in frames]
+    plist = []
+    for k in range(len(frames)):
+        used = "".join(rng.choice(["0", "1"], p=[0.25, 0.75]) for _ in range(6))
+        box = sorted(rng.uniform(-40, 40, 2)) + sorted(rng.uniform(-20, 20, 2)) + sorted(rng.uniform(-4, 8, 2))
+        plist.append(abi.map_params(used_feature_type=used, max_num_pts=int(rng.choice([20000, 10**7])), kept_vertex_num=10**6,
+                                    local_map_radius=float(rng.uniform(15, 80)), map_based_dynamic_removal_on=int(rng.random() < 0.7),
+                                    dynamic_removal_center_radius=float(rng.uniform(5, 40)), dynamic_dist_thre_min=float(rng.uniform(0.1, 0.6)),
+                                    dynamic_dist_thre_max=float(rng.uniform(0.2, 3.0)), near_dist_thre=float(rng.uniform(0.0, 0.1)),
+                                    tree_mode=int(rng.integers(0, 3)), tree_used="".join(rng.choice(["0", "1"]) for _ in range(6)),
+                                    tree_box=[box[0], box[2], box[4], box[1], box[3], box[5]]))
+    mo, mr, pose = [c.copy() for c in frames[0][0]], [c.copy() for c in frames[0][0]], frames[0][1]
+    compared = 0
+    for k, (fc, fp) in enumerate(frames[1:], 1):
+        P = plist[k]
+        try:
+            mr2, ar, pr = pyref.map_update(mr, pose, fc, fp, P)
+        except RuntimeError:
+            # upstream is undefined here (removal visiting a class without a tree) and the reference entry point refuses it:
+            # the same frame without the removal
+            P.map_based_dynamic_removal_on = 0
+            mr2, ar, pr = pyref.map_update(mr, pose, fc, fp, P)
+        mr = mr2
+        mo, ao, po = pyoracle.map_update(mo, pose, fc, fp, P)
+        pose = fp
+        assert list(po.n) == list(pr.n) and list(po.frame_n) == list(pr.frame_n) and po.feature_point_num == pr.feature_point_num
+        assert po.dynamic_removal_ran == pr.dynamic_removal_ran
+        for c in range(6):
+            same_cloud(ao[c], ar[c])
+            same_cloud(mo[c], mr[c])
+        compared += 1
+    assert compared == len(frames) - 1
