@@ -192,3 +192,38 @@ def test_degenerate_inputs_oracle_equals_reference(kind):
         P.faithful = 1
         P.keep_less_source_points = 0
         same(pyoracle.icp(pair, P)[0], pyref.icp(pair, P)[0])
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_variants_random_oracle_equals_reference(pairs_small, block):
+    """The two variants under seeded random options / headings / stations (the cases tests/test_gpu_variants.py runs on the device)."""
+    from test_gpu_fuzz import degenerate_pair, random_params
+
+    rng = np.random.default_rng(7700 + block)
+    for k in range(10):  # lls_icp_3dof_ground
+        if k % 3 == 2:
+            pair = degenerate_pair(rng, ["duplicates", "one_cell", "collinear", "ragged", "sparse_far"][int(rng.integers(0, 5))])
+        else:
+            base, _ = pairs_small[int(rng.integers(0, len(pairs_small)))]
+            tilt = synth.se3(0, 0, rng.normal(0, 0.1), *np.deg2rad(rng.normal(0, 0.5, 2)), 0)
+            pair = abi.PairData(base.tgt, [pyoracle.transform(c, tilt) if c is not None and len(c) else c for c in base.src], tgt_bound=base.tgt_bound)
+        P = random_params(rng)
+        P.apply_motion_undistortion = 0
+        P.keep_less_source_points = 0
+        ro = pyoracle.icp_3dof_ground(pair, P)[0]
+        rr = pyref.icp_3dof_ground(pair, P)[0]
+        assert (ro.code != 0) == (rr.code != 0)
+        assert np.array_equal(ro.T_matrix(), rr.T_matrix(), equal_nan=True)
+    rng = np.random.default_rng(8800 + block)
+    for k in range(4):  # mm_lls_icp_4dof_global
+        base, _ = pairs_small[int(rng.integers(0, len(pairs_small)))]
+        spin = synth.se3(*rng.normal(0, 0.3, 3), 0, 0, rng.uniform(-np.pi, np.pi))
+        pr = abi.PairData(base.tgt, [pyoracle.transform(c, spin) for c in base.src], tgt_bound=base.tgt_bound)
+        station = tuple(rng.normal(0, 1.0, 3))
+        step = float(rng.choice([20.0, 45.0, 72.0, 90.0, 180.0]))
+        kw = dict(max_iter_num=int(rng.integers(3, 15)), dis_thre_unit=float(rng.uniform(1.0, 3.0)))
+        (ro,), ok_o, _ = pyoracle.icp_4dof_global(pr, step, station, **kw)
+        (rr,), ok_r = pyref.icp_4dof_global(pr, step, station, **kw)
+        assert ok_o == ok_r
+        assert np.array_equal(ro.T_matrix(), rr.T_matrix(), equal_nan=True) and np.array_equal(ro.info_matrix(), rr.info_matrix(), equal_nan=True)
+        assert ro.sigma == rr.sigma or (np.isnan(ro.sigma) and np.isnan(rr.sigma))
