@@ -14,10 +14,12 @@
 // is compiled with -ffp-contract=off (the reference build has no FMA: CMakeLists.txt:43, no -march), float sqrt and
 // division are IEEE-correct (hipcc default), accumulators are double.  No MFMA: this is a search plus a reduction.
 //
-// Launch geometry: 256-thread workgroups (4 wave64).  The search / filter / accumulate kernels share one static job
-// table (one job = 512 consecutive source points of one feature class of one pair); dead source points keep their
-// slot and are masked by a flag byte instead of being physically compacted, which makes the job table iteration-
-// invariant and the whole batch advance with three launches per ICP iteration.
+// Launch geometry: 256-thread workgroups (4 wave64) unless a kernel says otherwise (k_nn_lds: 1024 lanes per class cloud,
+// k_accum: 128).  The search / filter / accumulate kernels share one static job table (one job = 512 consecutive source
+// points of one feature class of one pair; the LDS tier's class-level jobs are whole class clouds); dead source points keep
+// their slot and are masked by a flag byte instead of being physically compacted, which makes the job tables iteration-
+// invariant and the whole batch advance with a handful of launches per ICP iteration (push states, search (+ rejection
+// chain), accumulate, finish (+ pull)).
 
 #pragma once
 #include <hip/hip_runtime.h>

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(MULLS_NN_BLOCK) void k_nn(const Job *__restrict__ j
 
 // Correspondence search, global-memory grid tier (target class clouds too large for LDS).  Phase 1: the workgroup applies
 // this iteration's rigid step to its slice of a 512-point job (coalesced 16-B traffic, double math once per point) and
-// parks the transformed positions in LDS.  Phase 2: a 16-lane sub-group owns one query at a time: own cell, then the cube
-// of min(cell edge, distance found), then — while nothing lies inside the probed radius — one last cube of the distance
+// parks the transformed positions in LDS, together with the distance to the target the point found in the previous iteration
+// (an exact upper bound, as in k_nn_lds).  Phase 2: a 16-lane sub-group owns one query at a time: the cube of that bound —
+// or, without one, the own cell and then the cube of min(cell edge, distance found) —, then — while nothing lies inside the probed radius — one last cube of the distance
 // found, or cubes of twice the radius up to the rejection radius; rows are swept 16 at a time with coalesced candidate
 // loads, 4 xor-shuffles reduce (distance, index).  `split` workgroups share one job (batches with few jobs would leave
 // most CUs idle otherwise).  Outputs are identical to k_nn.
