@@ -550,7 +550,7 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 				cz++;
 			}
 		}
-		trips += (acc + 2u * MULLS_LDS_GROUP - 1u) / (2u * MULLS_LDS_GROUP);
+		trips += (acc + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
 		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
 		{
 			const uint32_t f2 = f + MULLS_LDS_GROUP;
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 				const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
 				const uint32_t lo = L.CS[cell], hi = L.CS[cell + 1u];
-				trips += (hi - lo + 2u * MULLS_LDS_GROUP - 1u) / (2u * MULLS_LDS_GROUP);
+				trips += (hi - lo + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
 				for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 				{
 					const uint32_t t2 = t + MULLS_LDS_GROUP;
