@@ -323,6 +323,9 @@ void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairO
 			std::memset(o.sums[c], 0, row); // never sent; contributes nothing
 }
 
+// the largest class cloud the LDS tier accepts must leave room for the 4096-cell floor lds_cells_for() promises
+static_assert(160L * 1024L - 64L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)MULLS_LDS_MAXPTS * 14L >= (4096L + 8L) * 2L,
+			  "MULLS_LDS_MAXPTS does not fit next to the query block, the cost-sort tables and a 4096-cell table in 160 KiB of LDS");
 // cell budget of the LDS tier: whatever the 160 KiB leave free next to the staged points (14 B each) and the query block
 uint32_t lds_cells_for(uint32_t cap)
 {
