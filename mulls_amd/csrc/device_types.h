@@ -54,7 +54,7 @@ struct CloudDesc
 	uint32_t sd_n0;
 	uint32_t src_cap; // slots reserved for this source cloud in the working arenas = max(src_n0, sd_n0)
 	uint32_t big_slot; // target clouds beyond MULLS_BIG_CLOUD points are cropped by many workgroups: 1-based slot, 0 = small
-	uint32_t pad_[1];
+	uint32_t n_search; // LDS tier: queries of this class cloud that went through the grid search in the last iteration (the others were certified)
 };
 
 // Uniform grid over one cropped target-class cloud (exact fixed-radius search tier).  cell id = (cz*ny + cy)*nx + cx,
@@ -138,4 +138,9 @@ struct RunParams
 	uint32_t pull_comb;	// mm_lls_icp loop: k_finish combines the class rows (normal matrix + rhs, or VTPV + count) and k_pull_outs sends that one row
 	uint32_t lds_dedup;	// LDS tier with class-level jobs: the duplicate rule is resolved inside k_nn_lds (winner table in LDS), losers get nn_idx = -1
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)
+	// LDS tier, certified correspondences (k_nn_lds): a query whose previous nearest target is provably still the nearest skips the
+	// search.  The sweep of a searched query is widened by slack = clamp(rate * (distance the point moved), min, max) metres so that
+	// the bound it leaves behind survives the next (smaller) step.  cert = 0 switches the whole mechanism off (diagnostics).
+	uint32_t cert;
+	float cert_slack_min, cert_slack_max, cert_slack_rate;
 };

@@ -176,6 +176,26 @@ int check_params(mulls_ctx *ctx, const mulls_params *P)
 	return MULLS_OK;
 }
 
+// certified correspondences of the LDS tier (k_nn_lds): on unless MULLS_NO_CERT is set; MULLS_CERT_SLACK="min,max,rate" (metres,
+// metres, factor on the distance a point moved) tunes how much farther than the hinted target a searched query sweeps
+void init_cert(RunParams &rp)
+{
+	rp.cert = std::getenv("MULLS_NO_CERT") ? 0u : 1u;
+	rp.cert_slack_min = 0.02f;
+	rp.cert_slack_max = 0.10f;
+	rp.cert_slack_rate = 1.0f;
+	if (const char *e = std::getenv("MULLS_CERT_SLACK"))
+	{
+		float a = 0, b = 0, c = 0;
+		if (std::sscanf(e, "%f,%f,%f", &a, &b, &c) == 3 && a >= 0.0f && b >= a && c >= 0.0f)
+		{
+			rp.cert_slack_min = a;
+			rp.cert_slack_max = b;
+			rp.cert_slack_rate = c;
+		}
+	}
+}
+
 // sub-batches in flight of a lock-step batch of n pairs (mulls_icp_batch / mulls_batch_run)
 int subbatch_count(int n)
 {
@@ -457,7 +477,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow(ctx, &B->nn_idx, &B->cap_src[6], so));
 	A(grow(ctx, &B->wd, &B->cap_src[7], so));
 	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so));
-	A(grow(ctx, &B->nn_hint, &B->cap_src[9], so));
+	A(grow(ctx, &B->nn_hint, &B->cap_src[9], 2 * so)); // LDS tier: (hint word, bound) records
 	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so));
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
@@ -917,6 +937,7 @@ extern "C"
 		rp.win_li = P->pt2li_residual_window;
 		rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
 		rp.resid_from_iter = 2;
+		init_cert(rp);
 		rp.tick_base = ctx->tick;
 		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
 		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
@@ -1400,6 +1421,7 @@ extern "C"
 		rp.win_pl = rp.win_li = rp.win_pt = 0.1f;			  // residual_window_size default of pt2pl_ground_3dof_lls_summation (:2323)
 		rp.cos_bearing = std::cos(40.0f / 180.0 * M_PI); // determine_corres' default angle_thre_degree (:1704)
 		rp.resid_from_iter = -1;							  // no iteration gate in ground_3dof_lls_tran_estimation (:2294)
+		init_cert(rp);
 		rp.tick_base = ctx->tick;
 		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
 		mulls_params Pj = *P;

@@ -516,21 +516,49 @@ __device__ __forceinline__ void row16_min(nnkey &bk)
 #endif
 }
 
+// (best key, second-best distance) over the lanes of a sub-group.  Every lane enters with the best key and the second-smallest
+// distance among ITS candidates; a lane whose best lost the sub-group minimum contributes that best's distance instead.
+template <int CTRL>
+__device__ __forceinline__ void dpp_fmin_step(float &v)
+{
+	const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+	v = fminf(o, v);
+}
+__device__ __forceinline__ void row16_min2(nnkey &bk, float &sec)
+{
+	nnkey g = bk;
+	row16_min(g);
+	float c = (bk == g) ? sec : key_dist(bk);
+	dpp_fmin_step<0xB1>(c);
+	dpp_fmin_step<0x4E>(c);
+#if MULLS_LDS_GROUP >= 8
+	dpp_fmin_step<0x141>(c);
+#endif
+#if MULLS_LDS_GROUP == 16
+	dpp_fmin_step<0x140>(c);
+#endif
+	sec = c;
+	bk = g;
+}
+
 // Evaluate every staged target in the cells intersecting the cube [p - R, p + R] (same exactness argument as
-// grid_scan_box).  The rows (x-runs of cells, contiguous in the sorted cloud) are taken four at a time: every lane of the
-// sub-group reads their bounds (same addresses: LDS broadcast), the four candidate ranges are laid end to end and the
+// grid_scan_box).  The rows (x-runs of cells, contiguous in the sorted cloud) are taken two at a time: every lane of the
+// sub-group reads their bounds (same addresses: LDS broadcast), the candidate ranges are laid end to end and the
 // sub-group strides over the concatenation, two candidates per lane in flight — the trip count is that of the total, not
 // the sum of the per-row round-ups, and the only per-row work is two table reads and a running sum.
+// `sec` follows the second-smallest distance this lane has seen (one v_med3_f32 per candidate: the median of (second, candidate,
+// best) is the new second whichever of the three orders holds); returns false when the cube lies inside the query's own cell
+// and `own_done` says that cell has been swept already.
 #define MULLS_LDS_CHUNK 2
-__device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
-											  nnkey &bk, uint32_t &trips, bool own_done = false)
+__device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const LdsGrid &L, float px, float py, float pz, float R, uint32_t sub,
+											  nnkey &bk, float &sec, uint32_t &trips, bool own_done = false)
 {
 	const float Rm = R * 1.0001f + 1e-4f;
 	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
 	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
 	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
 	if (own_done && x1 - x0 == 1u && y0 == y1 && z0 == z1)
-		return; // the cube stays inside the query's own cell, which has been swept already
+		return false; // the cube stays inside the query's own cell, which has been swept already
 	int cy = y0, cz = z0;
 	while (cz <= z1)
 	{
@@ -566,13 +594,18 @@ __device__ __forceinline__ void lds_scan_box(const GridDesc &g, const LdsGrid &L
 			const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
 			const uint32_t ia = L.IDX[ta], ib = L.IDX[tb];
 			float dx = px - ax, dy = py - ay, dz = pz - az;
-			const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia); // L2_Simple<float>, no FMA
+			const float da = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+			const nnkey ka = nn_key(da, ia);
 			dx = px - bx, dy = py - by, dz = pz - bz;
-			const nnkey kb = nn_key((dx * dx + dy * dy) + dz * dz, ib); // !ok2: the same candidate again, no effect
+			const float db = (dx * dx + dy * dy) + dz * dz;
+			const nnkey kb = nn_key(db, ib); // !ok2: the same candidate again, no effect on the best ...
+			sec = __builtin_amdgcn_fmed3f(sec, da, key_dist(bk));
 			bk = ka < bk ? ka : bk;
+			sec = __builtin_amdgcn_fmed3f(sec, ok2 ? db : __builtin_inff(), key_dist(bk)); // ... and kept away from the second-best
 			bk = kb < bk ? kb : bk;
 		}
 	}
+	return true;
 }
 } // namespace
 
@@ -585,15 +618,16 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 															 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [512] transformed queries, w = 1 live / 0 dead
+	float4 *qpos = reinterpret_cast<float4 *>(lds_raw);					  // [MULLS_LDS_QCHUNK] transformed queries, w = sweep radius of a hinted query / +inf
 	uint32_t *HIST = reinterpret_cast<uint32_t *>(qpos + MULLS_LDS_QCHUNK); // [32] cost histogram, [32] bucket bases, [64] live queries of the chunk
 	uint16_t *ORDER = reinterpret_cast<uint16_t *>(HIST + 80);				  // [MULLS_LDS_QCHUNK] query slots, most expensive first
 	float *P = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(HIST) + MULLS_LDS_AUX); // [3 * cap] x, y, z records
 	uint16_t *IDX = reinterpret_cast<uint16_t *>(P + 3u * cap);			  // [cap]
 	uint16_t *CS = IDX + cap;											  // [rp.grid_maxcells + 1]
 	uint32_t *W = reinterpret_cast<uint32_t *>(CS + ((rp.grid_maxcells + 8u) & ~1u)); // [cap] lowest source index matched to each target (lds_dedup)
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint); // per source point: (hint word, bound on every OTHER target's distance)
 
-	// one workgroup per (pair, class): the target class cloud is staged ONCE and every 512-query chunk of the source
+	// one workgroup per (pair, class): the target class cloud is staged at most ONCE and every chunk of the source
 	// class cloud is searched against it (the first version staged it once per chunk: 2.3x the algorithmic HBM bytes,
 	// profiles/r01_f_pmc_traffic.txt)
 	const Job job = cjobs[blockIdx.x]; // host order: most expensive class clouds first (round-robin over the XCDs)
@@ -605,20 +639,23 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const bool called = class_called(rp, d, job.cls);
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 
-	// The rigid-step phase of a chunk needs four global loads per lane and, with a hint, a dependent gather: they are issued one
+	// The rigid-step phase of a chunk needs a handful of global loads per lane and, with a hint, a dependent gather: they are issued one
 	// chunk ahead (the first chunk's before the target cloud is staged) so that their latency hides behind the staging / the search.
-	const bool use_hint = called && ps.iter > 0 && rp.debug_stop != 6u; // hints of this run exist from its second iteration on
+	const bool have_prev = ps.iter > 0;									// hint records of this run exist from its second iteration on
+	const bool use_hint = called && have_prev && rp.debug_stop != 6u;
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	// chunks of equal size (1200 queries: 2 x 600, not 1024 + 176: the last chunk would leave most sub-groups idle)
 	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
 	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
 	float4 pf_p = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_n = pf_p, pf_t = pf_p;
 	uint32_t pf_hv = 0xffffu, pf_f = 0u, pf_g = 0u;
+	float pf_lb = 0.0f;
 	int32_t pf_m = -1;
 	auto prefetch = [&](uint32_t chunk) {
 		const uint32_t s = chunk + threadIdx.x;
 		pf_f = 0u;
 		pf_hv = 0xffffu;
+		pf_lb = 0.0f;
 		pf_m = -1;
 		pf_g = d.src_off + s;
 		if (chunk < q_end && s < min(q_end, chunk + q_step))
@@ -626,10 +663,15 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			pf_f = flag[pf_g];
 			pf_p = spos[pf_g];
 			pf_n = snrm[pf_g];
-			if (use_hint)
+			if (have_prev)
 			{
-				pf_hv = (uint32_t)nn_hint[pf_g];
-				pf_m = match[pf_g];
+				const int2 h = hint2[pf_g];
+				pf_lb = __int_as_float(h.y);
+				if (use_hint)
+				{
+					pf_hv = (uint32_t)h.x;
+					pf_m = match[pf_g];
+				}
 			}
 		}
 	};
@@ -642,10 +684,9 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	};
 	prefetch(job.start);
 
-	if (called)
-	{
-		// stage the cell-sorted target cloud and its cell table (coalesced reads).  Loads are issued in batches of 8 / 4
-		// per lane before the first LDS write: one memory latency per batch instead of one per element.
+	// stage the cell-sorted target cloud and its cell table (coalesced reads).  Loads are issued in batches of 8 / 4
+	// per lane before the first LDS write: one memory latency per batch instead of one per element.
+	auto stage = [&](bool first_hint) {
 		const float4 *__restrict__ ts = tsorted + d.tgt_off;
 		for (uint32_t k0 = threadIdx.x; k0 < tgt_n; k0 += 8 * MULLS_LDS_BLOCK)
 		{
@@ -670,28 +711,35 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				}
 			}
 		}
-		prefetch_hint(); // the first chunk's hinted targets, in flight while the cell table is staged
+		if (first_hint)
+			prefetch_hint(); // the first chunk's hinted targets, in flight while the cell table is staged
 		// cell table: (ncell + 1) uint16 entries written by k_grid_build_sort, moved as uint4 words of 8 (the table slot of a
 		// cloud is uint4-aligned and padded)
 		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off);
 		const uint32_t nw = (g.ncell + 1u + 7u) >> 3;
-		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 4 * MULLS_LDS_BLOCK)
+		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 2 * MULLS_LDS_BLOCK)
 		{
-			// unconditional loads at clamped indices: a predicated `if (w < nw) v[u] = ...` makes the compiler park v[] in scratch
-			// and wait for every load on its own (four serialised round trips per workgroup, seen in the ISA listing)
-			uint4 v[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-				v[u] = cs4[min(w0 + u * MULLS_LDS_BLOCK, nw - 1u)];
-#pragma unroll
-			for (int u = 0; u < 4; u++)
-			{
-				const uint32_t w = w0 + u * MULLS_LDS_BLOCK;
-				if (w < nw)
-					reinterpret_cast<uint4 *>(CS)[w] = v[u];
-			}
+			// unconditional loads at clamped indices: a predicated `if (w < nw) v = ...` makes the compiler wait for every load on
+			// its own (serialised round trips, seen in the ISA listing)
+			const uint32_t w1 = w0 + MULLS_LDS_BLOCK;
+			const uint4 va = cs4[w0], vb = cs4[min(w1, nw - 1u)];
+			reinterpret_cast<uint4 *>(CS)[w0] = va;
+			if (w1 < nw)
+				reinterpret_cast<uint4 *>(CS)[w1] = vb;
 		}
+	};
+	// Certified correspondences (below) leave most class clouds without a single query to search from the third or fourth
+	// iteration on: the target cloud is then staged lazily, by the first chunk that has live queries.  A class cloud that
+	// searched more than a handful of queries last time is staged right away, under the first chunk's loads, as before.
+	const bool class_level = rp.lds_dedup != 0u;
+	bool staged = false;
+	if (called && (!rp.cert || !have_prev || !class_level || d.n_search > 32u))
+	{
+		stage(true);
+		staged = true;
 	}
+	else if (called)
+		prefetch_hint();
 
 	const bool dedup = rp.lds_dedup != 0u && called && alive_cur >= 500u;
 	if (dedup)
@@ -705,7 +753,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
 	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
-	uint32_t matched_cnt = 0;
+	uint32_t matched_cnt = 0, searched = 0;
 
 	if (threadIdx.x < 32u)
 		HIST[threadIdx.x] = 0u;
@@ -714,7 +762,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		const uint32_t c_end = min(q_end, chunk + q_step);
 		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
 		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
-		// phase 1: one source point per lane (lanes 0..511) — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
+		// phase 1: one source point per lane — fused rigid step (cregistration.hpp:1690-1695), coalesced 16-B traffic
 		if (threadIdx.x < MULLS_LDS_QCHUNK)
 		{
 			const uint32_t s = chunk + threadIdx.x;
@@ -732,19 +780,55 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
 				spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
 				snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
-				// temporal coherence: the target this point found in the previous iteration is very likely still its nearest one.
-				// Its distance is an exact upper bound (any target point gives one), so the search below can skip the own-cell
-				// probe and sweep the cube of that radius straight away.  w: bound (squared), +inf = none, -1 = dead point.
+				// How far this step moved the point (float positions before and after: both exact, the arithmetic below carries a few
+				// ulp).  Every bound on "the distance to any target other than the hinted one" shrinks by exactly that much.
+				const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
+				const float moved = sqrtf((mx * mx + my * my) + mz * mz);
+				const float lb_next = pf_lb - moved * 1.00001f;
+				// Temporal coherence: the target this point found in the previous iteration is very likely still its nearest one.
+				// Its distance is an exact upper bound (any target point gives one), so a search can skip the own-cell probe and
+				// sweep the cube of that radius straight away.  w: radius of that sweep, +inf = no hint.
 				out.w = __builtin_inff();
 				bucket = 31u - ((pf_hv >> 16) & 31u);
-				if ((pf_hv & 0xffffu) < tgt_n)
+				bool certified = false;
+				const uint32_t hj = pf_hv & 0xffffu;
+				if (hj < tgt_n)
 				{
 					const float dx = out.x - pf_t.x, dy = out.y - pf_t.y, dz = out.z - pf_t.z;
-					const float d0 = (dx * dx + dy * dy) + dz * dz;
+					const float d0 = (dx * dx + dy * dy) + dz * dz; // the very expression a search evaluates for this candidate
 					if (d0 >= 0.0f)
-						out.w = d0;
+					{
+						// Certified correspondence: the last search of this point (or the chain of certifications since) left a lower
+						// bound lb on the distance from the point to every target OTHER than the hinted one.  By the triangle
+						// inequality those targets are now at least lb - moved away; if the hinted target is strictly closer than
+						// that — with 1e-5 relative slack on either side, two orders of magnitude above the rounding of the float
+						// expressions involved — it is the unique nearest neighbour and d0 is the distance a search would report,
+						// bit for bit.  Ties and near-ties fail the test and are searched.  NaN anywhere fails the test.
+						const float dh = sqrtf(d0);
+						certified = rp.cert != 0u && (dh * 1.00001f + moved * 1.00001f < pf_lb * 0.99999f);
+						// a searched query sweeps a little farther than the hinted target: what lies beyond the sweep is what bounds
+						// the next iterations' certificates, and the steps shrink as the registration converges
+						out.w = dh + fminf(fmaxf(rp.cert_slack_rate * moved, rp.cert_slack_min), rp.cert_slack_max);
+						if (certified)
+						{
+							const bool matched = !((double)d0 > max_dist_sqr);
+							nn_idx[d.src_off + s] = matched ? (int32_t)hj : -1;
+							nn_d2[d.src_off + s] = d0;
+							hint2[d.src_off + s] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
+							if (matched)
+							{
+								matched_cnt++;
+								if (dedup)
+									atomicMin(&W[hj], s);
+								else if (gate)
+									atomicMin(&winner[d.tgt_off + hj], key_hi | (unsigned long long)s);
+							}
+						}
+					}
 				}
-				if (called)
+				if (!called) // the points still move: keep the bounds of a class that sits this iteration out valid (none exist at iteration 0)
+					nn_hint[2u * (d.src_off + s) + 1u] = __float_as_int(have_prev ? lb_next : 0.0f);
+				else if (!certified)
 					rank = atomicAdd(&HIST[bucket], 1u);
 			}
 			qpos[threadIdx.x] = out;
@@ -757,7 +841,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			continue;
 		// queries of the chunk in order of the work they took in the previous iteration (candidate trips, kept next to the hint):
 		// the eight sub-groups of a wave run in lock step, so a wave is as slow as its most expensive query — neighbours in
-		// this order cost about the same.  Counting sort over 32 classes; dead points drop out.
+		// this order cost about the same.  Counting sort over 32 classes; dead and certified points drop out.
 		if (threadIdx.x < 32u)
 		{
 			const uint32_t v = HIST[threadIdx.x];
@@ -779,6 +863,13 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		__syncthreads();
 		const uint32_t n_live = HIST[64];
 		prefetch_hint(); // gather of the next chunk's hinted targets (its hint words have landed during the sort above)
+		searched += n_live;
+		if (n_live && !staged) // uniform: every lane reads the same count
+		{
+			stage(false);
+			staged = true;
+			__syncthreads();
+		}
 
 		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
 		for (uint32_t i = grp; i < n_live; i += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
@@ -786,15 +877,31 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 			const uint32_t k = ORDER[i], s = chunk + k;
 			const float4 q = qpos[k];
 			nnkey bk = NNKEY_NONE;
+			float sec = __builtin_inff(), Rfin = 0.0f; // second-smallest distance seen by the last sweep, and that sweep's radius
 			uint32_t trips = 0;
 			if (rp.debug_stop == 5u)
 				continue;
+			// One sweep of the cube of radius R.  Its cells are a superset of every earlier sweep's cells, so its own (best, second)
+			// pair replaces the standing one; only when the radius was clipped to the rejection radius can the standing best lie
+			// outside — it stays the answer then (as before), and nothing is claimed about the other targets.
+			auto sweep = [&](float R, bool own_done) {
+				nnkey lk = NNKEY_NONE;
+				float ls = __builtin_inff();
+				if (lds_scan_box(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
+				{
+					row16_min2(lk, ls);
+					if (bk < lk)
+						sec = 0.0f;
+					else
+					{
+						bk = lk;
+						sec = ls;
+					}
+				}
+				Rfin = R;
+			};
 			if (q.w < __builtin_inff())
-			{
-				// bounded by last iteration's correspondence: one sweep of the cube of that radius (it contains that target)
-				lds_scan_box(g, L, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, bk, trips);
-				row16_min(bk);
-			}
+				sweep(fminf(m, q.w), false); // bounded by last iteration's correspondence: the cube contains that target
 			else
 			{
 				// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
@@ -805,32 +912,31 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
 				{
 					const uint32_t t2 = t + MULLS_LDS_GROUP;
-					const uint32_t tt2 = t2 < hi ? t2 : t;
+					const bool ok2 = t2 < hi;
+					const uint32_t tt2 = ok2 ? t2 : t;
 					const float *pa = L.P + 3u * t, *pb = L.P + 3u * tt2;
 					const float ax = pa[0], ay = pa[1], az = pa[2], bx = pb[0], by = pb[1], bz = pb[2];
 					const uint32_t ia = L.IDX[t], ib = L.IDX[tt2];
 					float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
-					const nnkey ka = nn_key((dx * dx + dy * dy) + dz * dz, ia);
+					const float da = (dx * dx + dy * dy) + dz * dz;
+					const nnkey ka = nn_key(da, ia);
 					dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
-					const nnkey kb = nn_key((dx * dx + dy * dy) + dz * dz, ib);
+					const float db = (dx * dx + dy * dy) + dz * dz;
+					const nnkey kb = nn_key(db, ib);
+					sec = __builtin_amdgcn_fmed3f(sec, da, key_dist(bk));
 					bk = ka < bk ? ka : bk;
+					sec = __builtin_amdgcn_fmed3f(sec, ok2 ? db : __builtin_inff(), key_dist(bk));
 					bk = kb < bk ? kb : bk;
 				}
-				row16_min(bk);
+				row16_min2(bk, sec);
 				// probe 1: every cell within min(first-probe radius, current best distance) of the query
 				if (rp.debug_stop != 3u)
-				{
-					const float R1 = key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m;
-					lds_scan_box(g, L, q.x, q.y, q.z, R1, sub, bk, trips, true);
-					row16_min(bk);
-				}
+					sweep(key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m, true);
 			}
 			if (rp.debug_stop < 3u && !(key_found(bk) && key_dist(bk) <= m * m))
 			{
 				// nothing within the first-probe radius: widen to the current best distance, or to the rejection radius
-				const float R = key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r;
-				lds_scan_box(g, L, q.x, q.y, q.z, R, sub, bk, trips);
-				row16_min(bk);
+				sweep(key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r, false);
 			}
 			if (sub == 0)
 			{
@@ -839,7 +945,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 				const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
 				nn_idx[d.src_off + s] = matched ? bi : -1;
 				nn_d2[d.src_off + s] = best;
-				nn_hint[d.src_off + s] = (int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)); // hint and cost class of the next iteration
+				// hint and cost class of the next iteration; every target but the one found is at least min(second, radius swept) away
+				hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(fminf(sqrtf(sec), Rfin))); // sec is a squared distance
 				if (matched)
 				{
 					matched_cnt++;
@@ -913,6 +1020,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		d.n_matched = total_matched; // k_finish reset it to 0 after the previous iteration
 		d.alive_next = ta;
 		d.valid_next = tv;
+		d.n_search = searched;
 	}
 }
 
