@@ -21,6 +21,8 @@
 #define MULLS_ACC_BLOCK 128	   // k_accum: two waves per 512-point job, four points per lane
 #define MULLS_LDS_QCHUNK 1024u // LDS tier: queries searched between two workgroup barriers (one per lane in the rigid-step phase)
 #define MULLS_LDS_AUX (320u + 2u * MULLS_LDS_QCHUNK) // LDS tier: cost histogram and query order of a chunk
+#define MULLS_CERT_BLOCK 512	   // k_cert: lanes per class cloud (one source point per lane and trip); several workgroups per CU
+#define MULLS_CERT_SMALL 64u   // k_cert searches up to this many uncertified points of a class cloud itself, against the grid in global memory
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
 #define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)
 #define MULLS_SEG 4096u		  // ... in segments of this many points

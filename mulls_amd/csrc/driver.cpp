@@ -67,6 +67,9 @@ struct mulls_batch
 	double *partial = nullptr;
 	Job *tjobs = nullptr;
 	Job *cjobs = nullptr;
+	uint32_t *wl = nullptr;		// LDS tier: class clouds k_cert queued for k_nn_lds (one slot per class-level job)
+	uint32_t *wl_ctr = nullptr; // ... and the queue counters: per sub-batch 8 words = (queued, taken) x launch parity
+	size_t cap_wl = 0;
 	GridDesc *grids = nullptr;
 	float4 *tsorted = nullptr;
 	uint32_t *cell_cnt = nullptr, *cell_start = nullptr; // global tier: per-occupied-cell counters / start positions; LDS tier: dense cell table
@@ -693,6 +696,11 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	grew |= g2;
 	A(grow(ctx, &B->cjobs, &B->cap_jobs[3], B->cjobs_h.size(), &g2));
 	grew |= g2;
+	A(grow(ctx, &B->wl, &B->cap_wl, B->cjobs_h.size()));
+	if (!B->wl_ctr)
+		A(dmalloc(ctx, &B->wl_ctr, 16));
+	if (rc == MULLS_OK)
+		HIPCHK(ctx, hipMemsetAsync(B->wl_ctr, 0, 16 * sizeof(uint32_t), st));
 	A(grow(ctx, &B->descs_init, &B->cap_jobs[4], B->descs_h.size(), &g2));
 	grew |= g2;
 	A(grow(ctx, &B->bbox_init, &B->cap_jobs[5], (size_t)n * 6, &g2));
@@ -871,7 +879,7 @@ extern "C"
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->mq, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
-					   B->tjobs, B->cjobs, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
+					   B->tjobs, B->cjobs, B->wl, B->wl_ctr, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
 		for (void *p : dev)
 			if (p)
 				(void)hipFree(p);
@@ -1058,6 +1066,7 @@ extern "C"
 			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
 			int iter = 0;
 			bool inflight = false;
+			uint32_t nn_launches = 0; // parity of the LDS tier's queue counters
 			uint64_t seq = 0;
 			uint32_t *epoch_ctr = nullptr;
 			volatile uint32_t *word = nullptr;
@@ -1144,7 +1153,8 @@ extern "C"
 				if (tier == 2)
 				{
 					if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
-									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells) != 0)
+									  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells,
+									  B->wl + S.cjob_lo, B->wl_ctr + 8 * (int)(&S - subs), S.nn_launches++) != 0)
 					{
 						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 						return MULLS_E_HIP;
@@ -1511,7 +1521,8 @@ extern "C"
 			if (tier == 2)
 			{
 				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells) != 0)
+								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr,
+							  (uint32_t)it) != 0)
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
@@ -1821,7 +1832,7 @@ extern "C"
 			const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 			if (tier == 2)
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells);
+							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr, 0u);
 			else if (tier == 1)
 				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
 							   B->nn_idx, B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
