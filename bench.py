@@ -1,24 +1,41 @@
 #!/usr/bin/env python
 """bench.py — MULLS-ICP hot path throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs B | --total-pairs T]
 
-Metric (BASELINE.json): scan-pair registrations / second on synthetic 64-beam ~120k-point scans, 20 ICP iterations,
-workload = configs[1] (KITTI-like scan-to-scan: classes ground+pillar+facade, source 800/400/1200 fixed-number
-down-sampled, target = the previous frame's un-down-sampled features).  One "step" = one lock-step batch of B
-independent scan pairs per GPU, clouds already staged in HBM (mulls_batch_create), each step re-cloning them like
-cloudblock_t::clone_feature does.  value = (N * B * K) / T with T the max over ranks of the barrier-bracketed time.
+With --gpus N > 1 and no torch.distributed environment, bench.py starts its N ranks itself (python -m
+torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...); started under torch.distributed.run
+by somebody else it checks WORLD_SIZE == N.  One rank per GPU, rank r on device LOCAL_RANK.
+
+Metric (BASELINE.json): scan-pair registrations / second on synthetic 64-beam ~120k-point scans, 20 ICP iterations;
+dT vs ref.  Workload = configs[1] (KITTI-like scan-to-scan: classes ground+pillar+facade, source 800/400/1200
+fixed-number down-sampled, target = the previous frame's un-down-sampled features, 5-15 k points, sizes drawn per
+scene).  There is ONE seeded global pair list: pair g = scene (g mod 64) with the g-th initial guess.
+  default            weak scaling: rank r registers pairs [r*B, (r+1)*B) of the list, B = --pairs per GPU and step
+  --total-pairs T    strong scaling = configs[3]: the T first pairs of the list, block-partitioned over the ranks
+                     (mulls_amd/shard.py::block_partition), so N = 1 and N = 8 register the very same pairs; rank 0
+                     gathers every rank's result table and reports its SHA-256 — equal for every N.
+One "step" = one lock-step registration of the rank's pairs, clouds already staged in HBM (mulls_batch_create), each
+step re-cloning them like cloudblock_t::clone_feature does.  value = registrations of all ranks / T, T = max over
+ranks of the barrier-bracketed time of the K steps.
 
 The JSON line also carries
-  roofline     — dominant kernel (the correspondence search, k_nn_lds by default): algorithmic HBM bytes per launch / average launch
-                 duration (hipEvents on the library's own stream, live in the timed region) against the 8 TB/s HBM peak.
-  cpu_baseline — the CPU oracle (restatement of the reference, kd-tree NN, the reference's 3-wide OpenMP sections)
-                 timed on this box's host cores on a bounded sample of the same workload.
+  roofline      — the dominant kernel: algorithmic HBM bytes per launch / average launch duration (hipEvents on the
+                  library's own stream, live in the timed region) against the 8 TB/s HBM peak; traffic and the VALU
+                  issue view from the committed rocprofv3 --pmc passes of this very configuration.
+  cpu_baseline  — the CPU oracle (restatement of the reference, kd-tree NN, the reference's 3-wide OpenMP sections)
+                  timed on this box's host cores on a bounded sample of the same workload; cpu_baseline_manycore: 8
+                  oracle processes side by side.
+  delta_T_vs_ref — pairs of the timed workload against the oracle (checker): max |dt|, max rotation geodesic, integer
+                  outputs equal.
+  value_end_to_end — the same registrations from host buffers (mulls_icp_batch: staging upload included).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,39 +44,149 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from mulls_amd import abi, lib, shard, synth  # noqa: E402
+from mulls_amd import abi, shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_TLOPS = 78.6     # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, non-FMA lane-ops/s
 OPS_PER_EVAL = 9.3         # 3 sub + 3 mul + 2 add + ~1.3 min/compare/select per source-target distance evaluation
-N_SCENES = 8               # distinct synthetic scenes per rank; batch entries cycle through them with fresh initial guesses
+N_SCENES = 64              # distinct synthetic scenes of the global pair list
+SEED0 = 20260924
 
 
-def bench_params():
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=4096, help="weak scaling: scan pairs per GPU per step (>= 2048: two sub-batches in flight)")
+    ap.add_argument("--total-pairs", type=int, default=0, help="strong scaling (configs[3]): this many pairs of the global list, block-partitioned over the GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--nn-mode", type=int, default=0, help="0 auto (grid staged in LDS), 1 brute force, 2 grid in global memory, 3 grid in LDS")
+    ap.add_argument("--tiny", action="store_true", help="plumbing-test sizes (12-beam scans, 4 scenes, 3 iterations): never a bench line")
+    ap.add_argument("--dump-table", default="", help="rank 0 writes the gathered result table (npy) here")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the global pair list
+def bench_params(tiny=False):
     # test/mulls_slam.cpp:642-648 with script/config/lo_gflag_list_kitti_urban.txt values; convergence thresholds at 0 so
     # that every registration executes exactly the 20 iterations the metric is quoted on
+    if tiny:
+        return abi.kitti_params(dis_thre_unit=2.4, max_iter_num=3, converge_translation=0.0, converge_rotation_d=0.0)
     return abi.kitti_params(converge_translation=0.0, converge_rotation_d=0.0)
 
 
-def make_workload(n_pairs, rank, seed0=1000):
-    rng = np.random.default_rng(seed0 + 7919 * rank)
+def _scene_sizes(k, tiny):
+    """Target class-cloud sizes of scene k: KITTI scan-to-scan targets hold 5-15 k feature points."""
+    rng = np.random.default_rng(SEED0 + 31 * k)
+    if tiny:
+        return ({abi.GROUND: 200, abi.PILLAR: 100, abi.FACADE: 250},
+                {abi.GROUND: int(rng.integers(400, 800)), abi.PILLAR: int(rng.integers(150, 350)), abi.FACADE: int(rng.integers(500, 900))})
+    tgt = {abi.GROUND: int(rng.integers(2000, 6001)), abi.PILLAR: int(rng.integers(500, 2001)), abi.FACADE: int(rng.integers(2500, 7001))}
+    return ({abi.GROUND: 800, abi.PILLAR: 400, abi.FACADE: 1200}, tgt)
+
+
+def _make_scene(job):
+    k, tiny = job
+    src_counts, tgt_counts = _scene_sizes(k, tiny)
+    if tiny:
+        pair, T_gt = synth.make_pair(SEED0 + k, n_beams=12, n_az=300, src_counts=src_counts, tgt_counts=tgt_counts, vertex_count=0)
+    else:
+        pair, T_gt = synth.make_pair(SEED0 + k, src_counts=src_counts, tgt_counts=tgt_counts, vertex_count=0)
+    return pair.tgt, pair.src, pair.init_guess, pair.tgt_bound, T_gt, pair.n_raw
+
+
+def build_scenes(n_scenes, tiny, workers):
+    """The distinct scenes of the pair list (ray-cast in a process pool: 1.7 s each)."""
+    jobs = [(k, tiny) for k in range(n_scenes)]
+    if workers > 1 and n_scenes > 1:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(min(workers, n_scenes)) as pool:
+            raw = pool.map(_make_scene, jobs)
+    else:
+        raw = [_make_scene(j) for j in jobs]
     scenes = []
-    for k in range(min(N_SCENES, n_pairs)):
-        pair, T_gt = synth.make_pair(seed0 + 100 * rank + k)
-        scenes.append((pair, T_gt))
-    pairs = []
-    for i in range(n_pairs):
-        base, T_gt = scenes[i % len(scenes)]
-        if i < len(scenes):
-            pairs.append(base)
-            continue
-        pert = synth.se3(*(rng.normal(0, 0.3 / np.sqrt(3), 3)), *(np.deg2rad(rng.normal(0, 0.5 / np.sqrt(3), 3))))
-        pairs.append(abi.PairData(base.tgt, base.src, init_guess=pert @ T_gt, tgt_bound=base.tgt_bound))
-    return pairs, scenes
+    for tgt, src, guess, bound, T_gt, n_raw in raw:
+        p = abi.PairData(tgt, src, init_guess=guess, tgt_bound=bound)
+        p.n_raw = n_raw
+        scenes.append((p, T_gt))
+    return scenes
 
 
-def cpu_baseline(scenes, P, budget_s=12.0):
-    """Oracle timed on the host cores: bounded sample of the same workload."""
+def global_pair(scenes, g):
+    """Pair g of the global list: scene g mod S; beyond the first S pairs the initial guess is the ground truth perturbed
+    by (0.3 m, 0.5 deg) with a seed that depends on g only — the list does not depend on the number of ranks."""
+    base, T_gt = scenes[g % len(scenes)]
+    if g < len(scenes):
+        return base
+    rng = np.random.default_rng([SEED0, g])
+    pert = synth.se3(*(rng.normal(0, 0.3 / np.sqrt(3), 3)), *(np.deg2rad(rng.normal(0, 0.5 / np.sqrt(3), 3))))
+    p = abi.PairData(base.tgt, base.src, init_guess=pert @ T_gt, tgt_bound=base.tgt_bound)
+    p.n_raw = base.n_raw
+    return p
+
+
+def rank_span(args, world, rank):
+    if args.total_pairs:
+        return shard.block_partition(args.total_pairs, world, rank)
+    return rank * args.pairs, (rank + 1) * args.pairs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the engine: libmulls_hip.so through its C ABI.  No fallback: without the library or a gfx950 device this raises.
+class HipEngine:
+    name = "libmulls_hip.so"
+
+    def __init__(self, device_index, nn_mode):
+        from mulls_amd import lib
+
+        self.ctx = lib.Context(device_index)
+        self.ctx.set_nn_mode(nn_mode)
+        self.batch = None
+
+    def stage(self, pairs):
+        self.batch = self.ctx.batch(pairs)  # H2D staging happens here, outside the timed region
+
+    def run(self, P, results):
+        self.batch.run(P, results=results)
+
+    def run_from_host(self, pairs, P):
+        return self.ctx.icp_batch(pairs, P)
+
+    def set_profiling(self, on):
+        self.ctx.set_profiling(on)
+
+    def profile(self):
+        return self.ctx.profile()
+
+    def close(self):
+        if self.batch is not None:
+            self.batch.close()
+        self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU legs (rank 0): the oracle as the reported baseline and as the checker of the timed workload
+def _oracle_many(job):
+    from oracle import pyoracle
+
+    idx, budget_s, tiny = job  # the scenes are inherited through fork (cpu_baseline_manycore)
+    P = bench_params(tiny)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        pyoracle.icp(_MC_SCENES[(idx + n) % len(_MC_SCENES)][0], P, nn_mode=0, use_omp=1)
+        n += 1
+    return n, time.perf_counter() - t0
+
+
+_MC_SCENES = None
+
+
+def cpu_baseline(scenes, P, budget_s=10.0):
+    """Oracle timed on the host cores: bounded sample of the same workload, back to back like the reference's caller."""
     from oracle import pyoracle
 
     pyoracle.icp(scenes[0][0], P)  # warm-up (thread pool, page-in)
@@ -77,96 +204,205 @@ def cpu_baseline(scenes, P, budget_s=12.0):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=4096, help="scan pairs per GPU per step (>= 2048: two sub-batches in flight)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--nn-mode", type=int, default=0, help="0 auto (grid staged in LDS), 1 brute force, 2 grid in global memory, 3 grid in LDS")
-    args = ap.parse_args()
+def cpu_baseline_manycore(scenes, tiny, procs=8, budget_s=6.0):
+    """'8 processes in parallel for a fair many-core number' — 8 oracle processes, 3 OpenMP sections each."""
+    import multiprocessing as mp
 
-    import torch
-    import torch.distributed as dist
+    global _MC_SCENES
+    _MC_SCENES = scenes
+    os.environ.setdefault("OMP_NUM_THREADS", "3")
+    with mp.get_context("fork").Pool(procs) as pool:
+        out = pool.map(_oracle_many, [(7 * i, budget_s, tiny) for i in range(procs)])
+    total = sum(n for n, _ in out)
+    wall = max(t for _, t in out)
+    return {"value": total / wall, "unit": "registrations/s", "cores": 3 * procs, "kind": "port",
+            "sample": "%d oracle processes x 3 OpenMP sections side by side, %d registrations in %.1f s" % (procs, total, wall)}
+
+
+def oracle_check_prepare(pairs, P, n_check):
+    """Oracle results of n_check pairs spread over this rank's workload (computed before the device is touched)."""
+    from oracle import pyoracle
+
+    idx = sorted(set(int(i) for i in np.linspace(0, len(pairs) - 1, min(n_check, len(pairs)))))
+    return [(i, pyoracle.icp(pairs[i], P)[0]) for i in idx]
+
+
+def oracle_check_compare(checks, results):
+    dt_max = dr_max = 0.0
+    ints_equal = True
+    for i, ro in checks:
+        rg = results[i]
+        dt, dr = synth.pose_error(abi_T(rg), abi_T(ro))
+        dt_max, dr_max = max(dt_max, dt), max(dr_max, dr)
+        ints_equal &= rg.code == ro.code and rg.iters == ro.iters and list(rg.ncorr) == list(ro.ncorr)
+    return {"pairs_checked": len(checks), "max_abs_dt_m": dt_max, "max_drot_rad": dr_max, "integer_outputs_equal": bool(ints_equal),
+            "tolerance": "1e-4 m / 1e-4 rad (north_star)", "within_tolerance": bool(dt_max <= 1e-4 and dr_max <= 1e-4),
+            "checker": "oracle/mulls_oracle.cpp on the same pairs of the timed workload, outside the timed region"}
+
+
+def abi_T(r):
+    return np.array(r.T[:]).reshape(4, 4).T
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def respawn(args, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks ourselves."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(sys.argv[0])] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None, engine_factory=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn(args, argv))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # --- workload (CPU, before the device is touched: the scene pool and the oracle legs fork) --------------------------------
+    P = bench_params(args.tiny)
+    n_scenes = 4 if args.tiny else N_SCENES
+    lo, hi = rank_span(args, world, rank)
+    n_total = args.total_pairs if args.total_pairs else world * args.pairs
+    workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    scenes = build_scenes(min(n_scenes, max(n_total, 1)), args.tiny, workers)
+    pairs = [global_pair(scenes, g) for g in range(lo, hi)]
+    checks, cpu, cpu_mc = None, None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        if world == 1:  # first: its children fork, and libgomp does not survive a fork once this process has run a parallel region
+            cpu_mc = cpu_baseline_manycore(scenes, args.tiny, budget_s=1.0 if args.tiny else 6.0)
+            cpu = cpu_baseline(scenes, P, budget_s=2.0 if args.tiny else 10.0)
+        checks = oracle_check_prepare(pairs, P, 16) if pairs else []
+
+    import torch
+    import torch.distributed as dist
+
+    use_cuda = torch.cuda.is_available()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        else:
+            dist.init_process_group(backend="gloo")  # CPU plumbing tests only: the engine below still needs a GPU unless a test injects one
+        assert dist.get_world_size() == args.gpus
+    elif use_cuda:
         torch.cuda.set_device(0)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if world > 1 else 0) if use_cuda else None
 
-    P = bench_params()
-    pairs, scenes = make_workload(args.pairs, rank)
-    ctx = lib.Context(device.index)
-    ctx.set_nn_mode(args.nn_mode)
-    batch = ctx.batch(pairs)          # H2D staging happens here, outside the timed region
-    results = abi.make_result_array(len(pairs))
+    engine = (engine_factory or HipEngine)(local_rank if world > 1 else 0, args.nn_mode)
+    engine.stage(pairs)
+    results = abi.make_result_array(max(len(pairs), 1))
 
     def step():
-        batch.run(P, results=results)
+        if pairs:
+            engine.run(P, results)
         return shard.gather_results(shard.pack_results(results, len(pairs)), device=device)
-
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_cuda:
+            torch.cuda.synchronize()
 
-    ctx.set_profiling(True)  # hipEvent pairs around every kernel launch on the library's stream
-    prof_acc = dict(ms_nn=0.0, launches=0, evals=0, src=0, tgt_unique=0, tgt_streamed=0, ms_setup=0.0, ms_filter=0.0, ms_accum=0.0,
-                    ms_residual=0.0)
+    for _ in range(args.warmup):
+        step()
+
+    # hipEvent pairs around every kernel launch on the library's stream stay ON in the timed region: roofline.achieved is the
+    # dominant kernel's launch duration measured live in the very steps that are timed (value_profiling_off: the same steps without)
+    engine.set_profiling(True)
+    prof_keys = ("ms_nn", "launches_nn", "nn_pair_evals", "nn_src_pts", "nn_tgt_unique", "nn_tgt_pts", "ms_setup", "ms_filter", "ms_accum", "ms_residual")
+    acc = {k: 0.0 for k in prof_keys}
     barrier()
     t0 = time.perf_counter()
     gathered = None
     for _ in range(args.steps):
         gathered = step()
-        pf = ctx.profile()
-        prof_acc["ms_nn"] += pf.ms_nn
-        prof_acc["launches"] += pf.launches_nn
-        prof_acc["evals"] += pf.nn_pair_evals
-        prof_acc["src"] += pf.nn_src_pts
-        prof_acc["tgt_unique"] += pf.nn_tgt_unique
-        prof_acc["tgt_streamed"] += pf.nn_tgt_pts
-        prof_acc["ms_setup"] += pf.ms_setup
-        prof_acc["ms_filter"] += pf.ms_filter
-        prof_acc["ms_accum"] += pf.ms_accum
-        prof_acc["ms_residual"] += pf.ms_residual
+        pf = engine.profile()
+        for k in prof_keys:
+            acc[k] += getattr(pf, k)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    engine.set_profiling(False)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_off = time.perf_counter() - t1
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if use_cuda else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed, elapsed_off = max_over_ranks(elapsed), max_over_ranks(elapsed_off)
+
+    e2e = None
+    if rank == 0 and world == 1 and pairs and not args.no_end_to_end:
+        sub = pairs[: min(1024, len(pairs))]
+        engine.run_from_host(sub, P)
+        t2 = time.perf_counter()
+        r2 = engine.run_from_host(sub, P)
+        e2e_dt = time.perf_counter() - t2
+        same = all(list(r2[i].T[:]) == list(results[i].T[:]) for i in range(len(sub)))
+        staged_mb = sum(len(c) for p in sub for c in p.tgt + p.src) * abi.POINT_BYTES / 1e6
+        e2e = {"value": len(sub) / e2e_dt, "unit": "registrations/s", "pairs": len(sub), "ms": e2e_dt * 1e3, "staged_MB": staged_mb,
+               "equals_resident_results": bool(same),
+               "note": "mulls_icp_batch: class clouds in host memory -> results; staging upload (PCIe), clone, crop, index build, iterations, residual"}
 
     if rank == 0:
-        n_reg = world * len(pairs) * args.steps
-        codes = gathered[:, 52] if gathered is not None else np.array([r.code for r in results])
-        iters = gathered[:, 53] if gathered is not None else np.array([r.iters for r in results])
-        # dominant kernel: k_nn.  Algorithmic bytes per launch: per live source point 64 B (pos+nrm read and
-        # written back by the fused transform) + 8 B (index, d2 out); per target point of a searched class cloud 16 B (pos).
-        launches = max(prof_acc["launches"], 1)
-        avg_ms = prof_acc["ms_nn"] / launches
-        alg_bytes = (72.0 * prof_acc["src"] + 16.0 * prof_acc["tgt_unique"]) / launches
+        n_reg = n_total * args.steps
+        codes, iters = gathered[:, 52], gathered[:, 53]
+        tsha = hashlib.sha256(np.ascontiguousarray(gathered).tobytes()).hexdigest()
+        if args.dump_table:
+            np.save(args.dump_table, gathered)
+        launches = max(acc["launches_nn"], 1)
+        avg_ms = acc["ms_nn"] / launches
+        # Algorithmic bytes per launch of the search (SURVEY.md 8d): per live source point 64 B (pos+nrm read and written back by
+        # the fused transform) + 8 B (index, d2 out); per target point of a searched class cloud 16 B (pos).
+        alg_bytes = (72.0 * acc["nn_src_pts"] + 16.0 * acc["nn_tgt_unique"]) / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        valu = prof_acc["evals"] * OPS_PER_EVAL / (prof_acc["ms_nn"] * 1e-3) / 1e12 if prof_acc["ms_nn"] > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes, only if they describe this very configuration
+        brute = acc["nn_pair_evals"] > 0
+        valu = acc["nn_pair_evals"] * OPS_PER_EVAL / (acc["ms_nn"] * 1e-3) / 1e12 if brute and acc["ms_nn"] > 0 else 0.0
+        pmc = None
+        try:  # the committed PMC passes, only if they describe this very configuration
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if pmc["config"]["pairs_per_gpu_per_step"] == len(pairs) and prof_acc["evals"] == 0 and args.nn_mode in (0, 3):
-                traffic = pmc["traffic_bytes_per_launch"]
+            if not (pmc["config"]["pairs_per_gpu_per_step"] == len(pairs) and not brute and args.nn_mode in (0, 3) and not args.tiny
+                    and pmc["config"].get("workload_seed") == SEED0):
+                pmc = None
         except Exception:
-            traffic = None
+            pmc = None
+        valu_view = None
+        if brute:
+            valu_view = {"achieved": valu, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": valu / VALU_PEAK_TLOPS,
+                         "distance_evals_per_launch": acc["nn_pair_evals"] / launches}
+        elif pmc and pmc.get("valu_wave_insts_per_launch") and avg_ms > 0:
+            # a wave64 VALU instruction holds its SIMD for 4 cycles: issue time = instructions x 4 / (SIMDs x clock)
+            issue_ms = pmc["valu_wave_insts_per_launch"] * 4.0 / (1024 * 2.4e9) * 1e3
+            valu_view = {"valu_wave_insts_per_launch": pmc["valu_wave_insts_per_launch"], "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
+                         "source": pmc.get("source_sq"), "note": "SQ_INSTS_VALU of the committed pass x 4 cycles / (1024 SIMDs x 2.4 GHz) against the live launch duration"}
+        sizes = sorted(sum(len(c) for c in s[0].tgt) for s in scenes)
         out = {
-            "metric": "scan-pair registrations/sec (64-beam ~120k pts, 20 ICP iters)",
+            "metric": "scan-pair registrations/sec (64-beam ~120k pts, 20 ICP iters); dT vs ref",
             "value": n_reg / elapsed,
             "unit": "registrations/s",
             "n_gpus": world,
@@ -174,42 +410,57 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_pairs else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "profiling_events_on": True,
+            "value_profiling_off": n_reg / elapsed_off,
             "config": {
-                "workload": "configs[1]: KITTI-like scan-to-scan, synthetic 64-beam scans (~%dk returns each), classes ground+pillar+facade "
-                            "(used_feature_type 111000), source 800/400/1200, target %d/%d/%d, 20 ICP iterations, weights 1111, clouds resident in HBM"
-                            % (pairs[0].n_raw[0] // 1000, len(pairs[0].tgt[0]), len(pairs[0].tgt[1]), len(pairs[0].tgt[2])),
+                "workload": ("tiny plumbing test (not a bench line)" if args.tiny else
+                             ("configs[3]: %d independent KITTI-like scan pairs block-partitioned over %d GPU(s); pairs as in configs[1]: " % (n_total, world)
+                              if args.total_pairs else "configs[1]: ") +
+                             "KITTI-like scan-to-scan, synthetic 64-beam scans (~%dk returns each), classes ground+pillar+facade (used_feature_type 111000), "
+                             "source 800/400/1200, target sizes drawn per scene (%d scenes, %d-%d points, median %d), 20 ICP iterations, weights 1111, "
+                             "clouds resident in HBM" % (scenes[0][0].n_raw[0] // 1000, len(scenes), sizes[0], sizes[-1], sizes[len(sizes) // 2])),
                 "pairs_per_gpu_per_step": len(pairs),
+                "pairs_per_step": n_total,
                 "registrations_timed": n_reg,
-                "parallelism": "%d independent lock-step batch(es), one per GPU; result gather on rank 0" % world,
+                "pair_list": "one global list, seed %d: pair g = scene g mod %d with the g-th initial guess; rank r takes %s" % (
+                    SEED0, len(scenes), "block_partition(total, N, r)" if args.total_pairs else "[r*B, (r+1)*B)"),
+                "parallelism": "%d lock-step batch(es), one process per GPU, no data-path collective; result gather (%s) on rank 0" % (
+                    world, "RCCL" if use_cuda else "gloo"),
+                "engine": engine.name,
                 "all_converged_code_1": bool((codes == 1).all()),
                 "mean_iterations": float(np.mean(iters)),
+                "result_table_sha256": tsha,
             },
             "roofline": {
-                "kernel": "k_nn_lds (fused source transform + exact fixed-radius 1-NN search on a uniform grid staged in LDS, bounded by the previous iteration's correspondence + on-chip duplicate rule and rejection chain)"
-                          if prof_acc["evals"] == 0 else "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)",
+                "kernel": "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)" if brute else
+                          "correspondence search of one ICP iteration, LDS tier: k_cert (rigid step, certificates, rejection chain) + k_nn_lds (exact "
+                          "fixed-radius 1-NN of the uncertified queries on a uniform grid staged in LDS)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration "
-                                "(profiles/r01_m_pmc_traffic.txt, 2 x FETCH + WRITE per the gfx950 guide; the launch includes the fused rejection chain, the correspondence records written for k_accum and the hint gathers); null when the run differs from it",
-                "avg_launch_ms": avg_ms, "launches": prof_acc["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "the search is an irregular exact query, bound by VALU issue (instruction count) and dependent LDS access, not by HBM "
-                        "bandwidth (DESIGN.md section 4, profiles/r01_h_pmc_sq.txt, r01_m_search_steps.txt); the HBM fraction is reported as the contract asks",
-                "valu_view": None if prof_acc["evals"] == 0 else {
-                    "achieved": valu, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": valu / VALU_PEAK_TLOPS,
-                    "distance_evals_per_launch": prof_acc["evals"] / launches},
-                "kernel_ms_per_step": {k: prof_acc[k] / args.steps for k in ("ms_setup", "ms_nn", "ms_filter", "ms_accum", "ms_residual")},
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (%s; 2 x FETCH + WRITE "
+                                "per the gfx950 guide); null when the run differs from it" % (pmc.get("source") if pmc else "profiles/pmc_traffic.json"),
+                "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "the search is an irregular exact query, bound by VALU issue (instruction count) and dependent memory access, not by HBM "
+                        "bandwidth (DESIGN.md section 4); the HBM fraction is reported as the contract asks",
+                "valu_view": valu_view,
+                "kernel_ms_per_step": {k: acc[k] / args.steps for k in ("ms_setup", "ms_nn", "ms_filter", "ms_accum", "ms_residual")},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scenes, P)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if checks is not None:
+            out["delta_T_vs_ref"] = oracle_check_compare(checks, results)
+        if e2e:
+            out["value_end_to_end"] = e2e
+        if cpu:
+            out["cpu_baseline"] = cpu
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cpu["value"]
+        if cpu_mc:
+            out["cpu_baseline_manycore"] = cpu_mc
         print(json.dumps(out))
-    batch.close()
-    ctx.close()
+    engine.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

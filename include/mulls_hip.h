@@ -55,7 +55,8 @@ enum mulls_error
 	MULLS_E_HIP = -101,		   /* a HIP runtime call failed (see mulls_last_error) */
 	MULLS_E_NO_DEVICE = -102,  /* no gfx950 device / kernels could not be loaded */
 	MULLS_E_UNSUPPORTED = -103, /* option not implemented by this build */
-	MULLS_E_IO = -104		   /* file could not be opened / is not in the expected format */
+	MULLS_E_IO = -104,		   /* file could not be opened / is not in the expected format */
+	MULLS_E_NOMEM = -105	   /* a host allocation failed (e.g. sizes that cannot be real) */
 };
 
 /* One feature-class cloud, borrowed from the caller (AoS of 48-byte PointXYZINormal records). */

@@ -18,6 +18,8 @@ MULLS_E_INVALID = -100
 MULLS_E_HIP = -101
 MULLS_E_NO_DEVICE = -102
 MULLS_E_UNSUPPORTED = -103
+MULLS_E_IO = -104
+MULLS_E_NOMEM = -105
 
 # numpy view of pcl::PointXYZINormal (48 B)
 POINT_DTYPE = np.dtype(

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -24,12 +26,46 @@ struct mulls_ctx
 	bool profiling = false;
 	mulls_profile prof{};
 	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
-	uint32_t tick = 1; // duplicate-table epoch counter, monotone over the context lifetime
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	std::vector<mulls_map *> maps; // live local maps: their buffers are the device clouds mulls_pair may point to
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 
+namespace mulls
+{
+// Handler of every extern "C" entry point's function-try-block: nothing is thrown across the ABI (include/mulls_hip.h).
+// A failed host allocation (std::vector growth on an absurd size) becomes MULLS_E_NOMEM, anything else MULLS_E_INVALID.
+inline int abi_caught(mulls_ctx *ctx) noexcept
+{
+	int rc = MULLS_E_INVALID;
+	const char *what = "unknown C++ exception";
+	try
+	{
+		throw;
+	}
+	catch (const std::bad_alloc &)
+	{
+		rc = MULLS_E_NOMEM;
+		what = "host allocation failed";
+	}
+	catch (const std::exception &e)
+	{
+		what = e.what();
+	}
+	catch (...)
+	{
+	}
+	if (ctx)
+		try
+		{
+			ctx->err = what;
+		}
+		catch (...)
+		{
+		}
+	return rc;
+}
+} // namespace mulls
 
 namespace
 {

@@ -51,6 +51,7 @@ struct mulls_batch
 	float4 *mq = nullptr; // per source point: position and direction of its matched target (2 records), written with match[]
 	float *wd = nullptr, *nn_d2 = nullptr;
 	unsigned long long *winner = nullptr;
+	uint32_t tick = 1; // duplicate-table epoch counter of THIS batch's winner table, monotone between resets (take_epochs)
 	CloudDesc *descs = nullptr;
 	PairSetup *setup = nullptr;
 	PairState *states = nullptr;	 // HBM copy of the pair states (filled by k_push_states every iteration)
@@ -773,6 +774,25 @@ struct EvTimer
 
 } // namespace
 
+// Reserve `n` consecutive epochs of the batch's duplicate table.  The winner key is (descending epoch << 32 | source index)
+// under atomicMin, so newer epochs must sort below older ones: before the 32-bit counter would wrap, the table is refilled
+// with 0xff and the count restarts (stream order puts the fill before this run's kernels).
+static int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, uint32_t *base)
+{
+	if (const char *e = std::getenv("MULLS_DEBUG_TICK")) // tests only: put a fresh batch's counter next to the wrap
+		if (B->tick == 1)
+			B->tick = (uint32_t)std::strtoul(e, nullptr, 0);
+	if (B->tick > 0xfffffff0u - n)
+	{
+		if (B->winner)
+			HIPCHK(ctx, hipMemsetAsync(B->winner, 0xff, B->cap_tgt[3] * sizeof(unsigned long long), ctx->stream));
+		B->tick = 1;
+	}
+	*base = B->tick;
+	B->tick += n;
+	return MULLS_OK;
+}
+
 extern "C"
 {
 
@@ -800,6 +820,7 @@ extern "C"
 	}
 
 	int mulls_create(int device, mulls_ctx **out)
+	try
 	{
 		if (!out)
 			return MULLS_E_INVALID;
@@ -820,6 +841,10 @@ extern "C"
 			(void)hipEventCreate(&e);
 		*out = ctx;
 		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(nullptr); // nothing is thrown across the ABI
 	}
 
 	void mulls_destroy(mulls_ctx *ctx)
@@ -846,29 +871,44 @@ extern "C"
 	const char *mulls_last_error(const mulls_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 	int mulls_set_profiling(mulls_ctx *ctx, int on)
+	try
 	{
 		if (!ctx)
 			return MULLS_E_INVALID;
 		ctx->profiling = on != 0;
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out)
+	try
 	{
 		if (!ctx || !out)
 			return MULLS_E_INVALID;
 		*out = ctx->prof;
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	void *mulls_stream(mulls_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 	int mulls_set_nn_mode(mulls_ctx *ctx, int mode)
+	try
 	{
 		if (!ctx || mode < 0 || mode > 3)
 			return MULLS_E_INVALID;
 		ctx->nn_mode = mode;
 		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
 	void mulls_batch_destroy(mulls_ctx *ctx, mulls_batch *B)
@@ -897,6 +937,7 @@ extern "C"
 	}
 
 	int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_batch **out)
+	try
 	{
 		if (!ctx || !pairs || n <= 0 || !out)
 			return MULLS_E_INVALID;
@@ -911,8 +952,13 @@ extern "C"
 		*out = B;
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_batch_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P, mulls_result *results)
+	try
 	{
 		if (!ctx || !B || !results)
 			return MULLS_E_INVALID;
@@ -946,8 +992,8 @@ extern "C"
 		rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
 		rp.resid_from_iter = 2;
 		init_cert(rp);
-		rp.tick_base = ctx->tick;
-		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
+		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
+			return rc;
 		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
 			rp.debug_stop = (uint32_t)std::atoi(dbg);
 
@@ -1323,6 +1369,21 @@ extern "C"
 			S.iter++;
 		};
 
+		// an error from here on leaves kernels in flight that still write the pinned result / epoch buffers: drain both streams
+		// before the caller can refill or free them
+		struct DrainOnError
+		{
+			mulls_ctx *ctx;
+			bool armed = true;
+			~DrainOnError()
+			{
+				if (armed)
+				{
+					(void)hipStreamSynchronize(ctx->stream);
+					(void)hipStreamSynchronize(ctx->stream2);
+				}
+			}
+		} drain{ctx};
 		for (int k = 0; k < nsub; k++)
 			if ((rc = launch(subs[k])) != MULLS_OK)
 				return rc;
@@ -1360,6 +1421,7 @@ extern "C"
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		if (two_streams)
 			HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+		drain.armed = false;
 		const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
 		for (int p = 0; p < n; p++)
 		{
@@ -1377,8 +1439,13 @@ extern "C"
 		}
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_icp_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results)
+	try
 	{
 		if (!ctx)
 			return MULLS_E_INVALID;
@@ -1394,10 +1461,19 @@ extern "C"
 			return rc;
 		return mulls_batch_run(ctx, ctx->scratch, params, results);
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_icp(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result)
+	try
 	{
 		return mulls_icp_batch(ctx, pair, 1, params, result);
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
 
@@ -1407,6 +1483,7 @@ extern "C"
 	// lls_icp_3dof_ground (cregistration.hpp:1443-1582): ground class only, unknowns (roll, pitch, z); same kernels, the
 	// 3x3 system is a sub-block of the point-to-plane accumulation (rows/columns a, b, ntz — identical float products).
 	int mulls_icp_3dof_ground_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *P, mulls_result *results)
+	try
 	{
 		if (!ctx || !pairs || n <= 0 || !results)
 			return MULLS_E_INVALID;
@@ -1432,8 +1509,8 @@ extern "C"
 		rp.cos_bearing = std::cos(40.0f / 180.0 * M_PI); // determine_corres' default angle_thre_degree (:1704)
 		rp.resid_from_iter = -1;							  // no iteration gate in ground_3dof_lls_tran_estimation (:2294)
 		init_cert(rp);
-		rp.tick_base = ctx->tick;
-		ctx->tick += (uint32_t)std::max(P->max_iter_num, 0) + 2u;
+		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
+			return rc;
 		mulls_params Pj = *P;
 		std::memset(Pj.used_feature_type, 0, sizeof(Pj.used_feature_type));
 		std::strcpy(Pj.used_feature_type, "100000");
@@ -1630,10 +1707,19 @@ extern "C"
 		}
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_icp_3dof_ground(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params, mulls_result *result)
+	try
 	{
 		return mulls_icp_3dof_ground_batch(ctx, pair, 1, params, result);
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
 	// mm_lls_icp_4dof_global (cregistration.hpp:1584-1681): the heading trials are independent registrations that share
@@ -1641,6 +1727,7 @@ extern "C"
 	int mulls_icp_4dof_global(mulls_ctx *ctx, const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num,
 							  float dis_thre_unit, float converge_translation, float converge_rotation_d, float dis_thre_min,
 							  float dis_thre_update_rate, float max_bearable_rotation_d, mulls_result *result, int *success, float *best_heading_d)
+	try
 	{
 		(void)converge_rotation_d;		// the reference passes converge_translation in its place (:1640-1642) ...
 		(void)max_bearable_rotation_d; // ... and never uses this one
@@ -1724,10 +1811,15 @@ extern "C"
 			*best_heading_d = best_heading;
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	// ------------------------------------------------------------------------------------------------------------
 	// stage-level entry points
 	int mulls_stage_transform(mulls_ctx *ctx, void *pts, uint32_t n, uint32_t stride, const double T[16])
+	try
 	{
 		if (!ctx || (n && !pts) || stride != MULLS_POINT_BYTES || !T)
 			return MULLS_E_INVALID;
@@ -1757,6 +1849,10 @@ extern "C"
 		}
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	namespace
 	{
@@ -1782,8 +1878,8 @@ extern "C"
 		rp->used[cls] = 1;
 		rp->faithful = 1;
 		rp->resid_from_iter = 2;
-		rp->tick_base = ctx->tick;
-		ctx->tick += 4;
+		if ((rc = take_epochs(ctx, B, 4u, &rp->tick_base)) != MULLS_OK)
+			return rc;
 		uint32_t lds_cap = 0;
 		int tier = 0;
 		rc = prepare_run(ctx, B, &P, *rp, &lds_cap, &tier);
@@ -1809,6 +1905,7 @@ extern "C"
 
 	int mulls_stage_correspond(mulls_ctx *ctx, const mulls_cloud *src, const mulls_cloud *tgt, float dis_thre, int normal_check,
 							   float angle_thre_degree, int32_t *match, float *d2, uint8_t *flags)
+	try
 	{
 		if (!ctx || !src || !tgt || !match || !d2 || !flags)
 			return MULLS_E_INVALID;
@@ -1867,10 +1964,15 @@ extern "C"
 		mulls_batch_destroy(ctx, B);
 		return rc;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_stage_accumulate(mulls_ctx *ctx, int metric, const mulls_cloud *src, const mulls_cloud *tgt, const int32_t *corr_src,
 							   const int32_t *corr_tgt, const float *corr_d2, uint32_t ncorr, int iter_num, float class_weight, int dist_w,
 							   int resid_w, int inten_w, float window, double *out27, float *weight_out)
+	try
 	{
 		if (!ctx || !src || !tgt || !out27 || metric < 0 || metric > 2 || (ncorr && (!corr_src || !corr_tgt)))
 			return MULLS_E_INVALID;
@@ -1946,5 +2048,9 @@ extern "C"
 			(void)hipFree(dcd);
 		mulls_batch_destroy(ctx, B);
 		return rc;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 }

@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -39,6 +41,23 @@ int field_offset(const std::string &name)
 	return -1;
 }
 
+// handler of the entry points' function-try-blocks: nothing is thrown across the ABI
+int io_caught() noexcept
+{
+	try
+	{
+		throw;
+	}
+	catch (const std::bad_alloc &)
+	{
+		return MULLS_E_NOMEM;
+	}
+	catch (...)
+	{
+		return MULLS_E_IO;
+	}
+}
+
 int deliver(const std::vector<Rec> &v, void *pts, uint32_t cap, uint32_t *n)
 {
 	if (n)
@@ -55,6 +74,7 @@ int deliver(const std::vector<Rec> &v, void *pts, uint32_t cap, uint32_t *n)
 extern "C"
 {
 	int mulls_io_read_kitti_bin(const char *path, void *pts, uint32_t cap, uint32_t *n)
+	try
 	{
 		if (!path)
 			return MULLS_E_INVALID;
@@ -74,8 +94,13 @@ extern "C"
 		}
 		return deliver(v, pts, cap, n);
 	}
+	catch (...)
+	{
+		return io_caught(); // nothing is thrown across the ABI
+	}
 
 	int mulls_io_read_pcd(const char *path, void *pts, uint32_t cap, uint32_t *n)
+	try
 	{
 		if (!path)
 			return MULLS_E_INVALID;
@@ -130,8 +155,17 @@ extern "C"
 			counts.assign(fields.size(), 1);
 		if (counts.size() != fields.size())
 			return MULLS_E_IO;
+		// The header is untrusted input: PCD v0.7 field sizes are 1, 2, 4 or 8 bytes and counts are positive; nothing is
+		// allocated before the record size and the point count have been checked against what the file can hold.
+		for (size_t f = 0; f < fields.size(); f++)
+			if ((sizes[f] != 1 && sizes[f] != 2 && sizes[f] != 4 && sizes[f] != 8) || counts[f] < 1 || counts[f] > (1 << 16))
+				return MULLS_E_IO;
 		if (!have_points)
+		{
+			if (height != 0 && width > SIZE_MAX / height)
+				return MULLS_E_IO;
 			points = width * height;
+		}
 		size_t step = 0;
 		std::vector<size_t> foff(fields.size());
 		for (size_t f = 0; f < fields.size(); f++)
@@ -139,6 +173,17 @@ extern "C"
 			foff[f] = step;
 			step += (size_t)sizes[f] * (size_t)counts[f];
 		}
+		const std::streamoff data_begin = in.tellg();
+		in.seekg(0, std::ios::end);
+		const std::streamoff file_end = in.tellg();
+		in.seekg(data_begin);
+		if (data_begin < 0 || file_end < data_begin || step == 0)
+			return MULLS_E_IO;
+		const size_t remaining = (size_t)(file_end - data_begin);
+		// binary: points * step bytes follow; ascii: at least one character and a separator per value
+		const size_t min_bytes_per_point = data_kind == "binary" ? step : 2 * fields.size() - 1;
+		if (points > remaining / min_bytes_per_point || points > 0xffffffffu)
+			return MULLS_E_IO;
 		std::vector<Rec> v(points);
 		if (data_kind == "binary")
 		{
@@ -180,8 +225,13 @@ extern "C"
 			return MULLS_E_UNSUPPORTED; // binary_compressed (LZF): the reference never writes it
 		return deliver(v, pts, cap, n);
 	}
+	catch (...)
+	{
+		return io_caught(); // nothing is thrown across the ABI
+	}
 
 	int mulls_io_write_pcd(const char *path, const void *pts, uint32_t n, uint32_t stride, int as_binary)
+	try
 	{
 		if (!path || (n && !pts) || stride < MULLS_POINT_BYTES)
 			return MULLS_E_INVALID;
@@ -215,8 +265,13 @@ extern "C"
 		out.close();
 		return out ? MULLS_OK : MULLS_E_IO;
 	}
+	catch (...)
+	{
+		return io_caught(); // nothing is thrown across the ABI
+	}
 
 	int mulls_io_write_pose(const char *path, const double T[16], int append)
+	try
 	{
 		if (!path || !T)
 			return MULLS_E_INVALID;
@@ -229,5 +284,9 @@ extern "C"
 				out << T[r + 4 * c] << ((r == 2 && c == 3) ? "\n" : " ");
 		out.close();
 		return out ? MULLS_OK : MULLS_E_IO;
+	}
+	catch (...)
+	{
+		return io_caught(); // nothing is thrown across the ABI
 	}
 }

@@ -149,6 +149,7 @@ extern "C"
 	}
 
 	int mulls_map_create(mulls_ctx *ctx, mulls_map **out)
+	try
 	{
 		if (!ctx || !out)
 			return MULLS_E_INVALID;
@@ -163,6 +164,10 @@ extern "C"
 		ctx->maps.push_back(m);
 		*out = m;
 		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
 	void mulls_map_destroy(mulls_ctx *ctx, mulls_map *m)
@@ -190,6 +195,7 @@ extern "C"
 	}
 
 	int mulls_map_set(mulls_ctx *ctx, mulls_map *m, const mulls_cloud clouds[6], const double pose_lo[16])
+	try
 	{
 		if (!ctx || !m || !clouds || !pose_lo)
 			return MULLS_E_INVALID;
@@ -206,9 +212,14 @@ extern "C"
 		std::memcpy(m->pose, pose_lo, sizeof(m->pose));
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_map_update(mulls_ctx *ctx, mulls_map *m, const mulls_cloud frame_down[6], const double frame_pose_lo[16], const mulls_map_params *P,
 						 mulls_map_report *rep)
+	try
 	{
 		if (!ctx || !m || !frame_down || !frame_pose_lo || !P || !rep)
 			return MULLS_E_INVALID;
@@ -434,8 +445,13 @@ extern "C"
 		rep->ms_total = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3);
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_map_cloud(mulls_ctx *ctx, const mulls_map *m, int cls, mulls_cloud *out)
+	try
 	{
 		if (!ctx || !m || !out || cls < 0 || cls >= MULLS_NC)
 			return MULLS_E_INVALID;
@@ -444,13 +460,22 @@ extern "C"
 		out->stride = (uint32_t)REC;
 		return MULLS_OK;
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 
 	int mulls_map_pose(mulls_ctx *ctx, const mulls_map *m, double pose_lo[16])
+	try
 	{
 		if (!ctx || !m || !pose_lo)
 			return MULLS_E_INVALID;
 		std::memcpy(pose_lo, m->pose, sizeof(m->pose));
 		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
 	static int download(mulls_ctx *ctx, const float4 *src, uint32_t have, void *pts, uint32_t cap, uint32_t *n)
@@ -469,15 +494,25 @@ extern "C"
 		return MULLS_OK;
 	}
 	int mulls_map_download(mulls_ctx *ctx, const mulls_map *m, int cls, void *pts, uint32_t cap, uint32_t *n)
+	try
 	{
 		if (!ctx || !m || cls < 0 || cls >= MULLS_NC)
 			return MULLS_E_INVALID;
 		return download(ctx, m->rec[cls], m->n[cls], pts, cap, n);
 	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
 	int mulls_map_frame_download(mulls_ctx *ctx, const mulls_map *m, int cls, void *pts, uint32_t cap, uint32_t *n)
+	try
 	{
 		if (!ctx || !m || cls < 0 || cls >= MULLS_NC)
 			return MULLS_E_INVALID;
 		return download(ctx, m->frame[cls], m->frame_n[cls], pts, cap, n);
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 }

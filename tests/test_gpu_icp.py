@@ -132,6 +132,21 @@ def test_resident_batch_is_repeatable(ctx, pairs_small):
     b.close()
 
 
+def test_duplicate_table_epoch_wrap(ctx, pairs_small, monkeypatch):
+    """The duplicate table's 32-bit epoch counter: runs on either side of the wrap give the results of a fresh batch
+    (stale winner entries of older epochs must not beat the keys of the restarted count)."""
+    P = abi.kitti_params(dis_thre_unit=2.4)
+    plist = [p for p, _ in pairs_small]
+    b0 = ctx.batch(plist)
+    want = [(r.code, r.iters, tuple(r.ncorr), tuple(r.T)) for r in b0.run(P)]
+    b0.close()
+    monkeypatch.setenv("MULLS_DEBUG_TICK", str(0xfffffff0 - 3 * 22 - 5))  # the fourth run of 22 epochs crosses the limit
+    b = ctx.batch(plist)
+    for _ in range(6):
+        assert [(r.code, r.iters, tuple(r.ncorr), tuple(r.T)) for r in b.run(P)] == want
+    b.close()
+
+
 def test_mixed_outcomes_in_one_batch(ctx):
     """Pairs that fail early (-2), step too far (-1), exceed sigma (-3) or never iterate sit next to healthy ones."""
     rng = np.random.default_rng(7)

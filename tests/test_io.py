@@ -96,3 +96,41 @@ def test_reference_demo_pcd():
     assert (p["x"][0], p["y"][0], p["z"][0], p["intensity"][0], p["nx"][0], p["ny"][0], p["nz"][0]) == first[:7]
     rng = np.sqrt(p["x"].astype(np.float64) ** 2 + p["y"] ** 2 + p["z"] ** 2)
     assert 9.0 < np.median(rng) < 11.5 and p["intensity"].max() <= 255  # median range 10.1 m, intensity 0-252
+
+
+def _pcd(tmp_path, header, payload=b""):
+    p = tmp_path / "bad.pcd"
+    p.write_bytes(header.encode() + payload)
+    return str(p)
+
+
+def test_pcd_reader_rejects_hostile_headers(tmp_path):
+    """The header is untrusted: negative sizes / counts, point counts the file cannot hold and overflowing products are
+    refused with an error code — no out-of-bounds read, no exception across the ABI."""
+    import ctypes as C
+
+    from mulls_amd import lib
+
+    L = lib.load()
+    n = C.c_uint32(0)
+    base = "# .PCD v0.7\nVERSION 0.7\nFIELDS x y z intensity\n%s\nTYPE F F F F\n%s\nWIDTH %s\nHEIGHT 1\nPOINTS %s\nDATA binary\n"
+    cases = [
+        base % ("SIZE 4 -4 4 4", "COUNT 1 1 1 1", "4", "4"),            # step would wrap to 8 -> reads past the blob
+        base % ("SIZE 4 4 4 3", "COUNT 1 1 1 1", "4", "4"),             # not a PCD field size
+        base % ("SIZE 4 4 4 4", "COUNT 1 0 1 1", "4", "4"),             # zero count
+        base % ("SIZE 4 4 4 4", "COUNT 1 -1 1 1", "4", "4"),            # negative count
+        base % ("SIZE 4 4 4 4", "COUNT 1 1 1 1", "4", "4000000000000"),  # more points than the file (or memory) can hold
+        base % ("SIZE 4 4 4 4", "COUNT 1 1 1 1", "4", "18446744073709551615"),  # points * step overflows size_t
+    ]
+    for hdr in cases:
+        path = _pcd(tmp_path, hdr, b"\0" * 64)
+        rc = L.mulls_io_read_pcd(path.encode(), None, 0, C.byref(n))
+        assert rc in (abi.MULLS_E_IO, abi.MULLS_E_NOMEM), (rc, hdr)
+    # WIDTH * HEIGHT overflow without a POINTS line
+    hdr = "VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 4294967296\nHEIGHT 4294967296\nDATA ascii\n"
+    assert L.mulls_io_read_pcd(_pcd(tmp_path, hdr).encode(), None, 0, C.byref(n)) == abi.MULLS_E_IO
+    # a well-formed file of the same shape still reads
+    good = base % ("SIZE 4 4 4 4", "COUNT 1 1 1 1", "2", "2")
+    path = _pcd(tmp_path, good, np.arange(8, dtype=np.float32).tobytes())
+    pts = lib.read_pcd(path)
+    assert len(pts) == 2 and pts["x"][1] == 4.0 and pts["intensity"][1] == 7.0
