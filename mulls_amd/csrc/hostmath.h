@@ -8,15 +8,17 @@
 #include <cmath>
 #include <cstring>
 
+#include "detmath.h" // sin / cos / atan2 shared bit for bit by the host driver and the device-resident loop
+
 namespace mulls
 {
 
 struct Mat4 // column-major 4x4
 {
 	double v[16];
-	double &at(int r, int c) { return v[r + 4 * c]; }
-	double at(int r, int c) const { return v[r + 4 * c]; }
-	static Mat4 identity()
+	MULLS_HD double &at(int r, int c) { return v[r + 4 * c]; }
+	MULLS_HD double at(int r, int c) const { return v[r + 4 * c]; }
+	MULLS_HD static Mat4 identity()
 	{
 		Mat4 m;
 		std::memset(m.v, 0, sizeof(m.v));
@@ -25,7 +27,7 @@ struct Mat4 // column-major 4x4
 	}
 };
 
-inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
+MULLS_HD inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
 {
 	Mat4 c;
 	for (int col = 0; col < 4; col++)
@@ -42,9 +44,9 @@ inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
 struct Mat6 // column-major 6x6
 {
 	double v[36];
-	double &at(int r, int c) { return v[r + 6 * c]; }
-	double at(int r, int c) const { return v[r + 6 * c]; }
-	static Mat6 identity()
+	MULLS_HD double &at(int r, int c) { return v[r + 6 * c]; }
+	MULLS_HD double at(int r, int c) const { return v[r + 6 * c]; }
+	MULLS_HD static Mat6 identity()
 	{
 		Mat6 m;
 		std::memset(m.v, 0, sizeof(m.v));
@@ -56,7 +58,7 @@ struct Mat6 // column-major 6x6
 
 // inverse through a row-pivoted LU factorisation, solved against the identity column by column.
 // Returns false when a zero pivot was met (the result then carries inf/NaN exactly like Eigen's would).
-inline bool invert6(const Mat6 &in, Mat6 &out)
+MULLS_HD inline bool invert6(const Mat6 &in, Mat6 &out)
 {
 	const int n = 6;
 	double a[36];
@@ -120,7 +122,7 @@ inline bool invert6(const Mat6 &in, Mat6 &out)
 }
 
 // general 4x4 inverse by the same row-pivoted LU (used for inverse(initial_guess) in the undistortion branch)
-inline Mat4 invert4(const Mat4 &in)
+MULLS_HD inline Mat4 invert4(const Mat4 &in)
 {
 	const int n = 4;
 	double a[16];
@@ -182,7 +184,7 @@ inline Mat4 invert4(const Mat4 &in)
 }
 
 // inverse of a 3x3 (column-major) by cofactors over the determinant, as Eigen 3.3 does for fixed 3x3 matrices
-inline void invert3(const double m[9], double out[9])
+MULLS_HD inline void invert3(const double m[9], double out[9])
 {
 	auto M = [&](int r, int c) { return m[r + 3 * c]; };
 	auto cof = [&](int i, int j) {
@@ -198,7 +200,7 @@ inline void invert3(const double m[9], double out[9])
 }
 
 // unit quaternion (w,x,y,z) of the upper-left 3x3 (Shepperd branches, as Eigen::Quaterniond(Matrix3d))
-inline void rotation_quaternion(const Mat4 &T, double q[4])
+MULLS_HD inline void rotation_quaternion(const Mat4 &T, double q[4])
 {
 	const double r00 = T.at(0, 0), r11 = T.at(1, 1), r22 = T.at(2, 2);
 	const double tr = r00 + r11 + r22;
@@ -233,11 +235,11 @@ inline void rotation_quaternion(const Mat4 &T, double q[4])
 }
 
 // tx ty tz roll pitch yaw -> [Rz(yaw) Ry(pitch) Rx(roll) | t]
-inline Mat4 euler_step_to_matrix(const double x[6])
+MULLS_HD inline Mat4 euler_step_to_matrix(const double x[6])
 {
-	const double sa = std::sin(x[3]), ca = std::cos(x[3]);
-	const double sb = std::sin(x[4]), cb = std::cos(x[4]);
-	const double sg = std::sin(x[5]), cg = std::cos(x[5]);
+	const double sa = det::sin_cr(x[3]), ca = det::cos_cr(x[3]);
+	const double sb = det::sin_cr(x[4]), cb = det::cos_cr(x[4]);
+	const double sg = det::sin_cr(x[5]), cg = det::cos_cr(x[5]);
 	Mat4 m;
 	std::memset(m.v, 0, sizeof(m.v));
 	m.at(0, 0) = cg * cb;
@@ -257,7 +259,7 @@ inline Mat4 euler_step_to_matrix(const double x[6])
 }
 
 // rotation angle in [0, pi] of the upper-left 3x3, through the unit quaternion (what Eigen::AngleAxisd(R).angle() does)
-inline double rotation_angle(const Mat4 &T)
+MULLS_HD inline double rotation_angle(const Mat4 &T)
 {
 	const double r00 = T.at(0, 0), r11 = T.at(1, 1), r22 = T.at(2, 2);
 	double qw, qx, qy, qz;
@@ -291,14 +293,14 @@ inline double rotation_angle(const Mat4 &T)
 		qz = q[2];
 	}
 	const double vn = std::sqrt(qx * qx + qy * qy + qz * qz);
-	return vn != 0.0 ? 2.0 * std::atan2(vn, std::fabs(qw)) : 0.0;
+	return vn != 0.0 ? 2.0 * det::atan2_cr(vn, std::fabs(qw)) : 0.0;
 }
 
 // d(q1,q2,q3)/d(roll,pitch,yaw); the half-angle sines/cosines are float locals in the reference (:2797-2804)
-inline void quat_euler_jacobian(const double e[3], double J[3][3])
+MULLS_HD inline void quat_euler_jacobian(const double e[3], double J[3][3])
 {
-	const float sr = (float)std::sin(0.5 * e[0]), sp = (float)std::sin(0.5 * e[1]), sy = (float)std::sin(0.5 * e[2]);
-	const float cr = (float)std::cos(0.5 * e[0]), cp = (float)std::cos(0.5 * e[1]), cy = (float)std::cos(0.5 * e[2]);
+	const float sr = (float)det::sin_cr(0.5 * e[0]), sp = (float)det::sin_cr(0.5 * e[1]), sy = (float)det::sin_cr(0.5 * e[2]);
+	const float cr = (float)det::cos_cr(0.5 * e[0]), cp = (float)det::cos_cr(0.5 * e[1]), cy = (float)det::cos_cr(0.5 * e[2]);
 	J[0][0] = 0.5 * (cr * cp * cy + sr * sp * sy);
 	J[0][1] = 0.5 * (-sr * sp * cy - cr * cp * sy);
 	J[0][2] = 0.5 * (-sr * cp * sy - cr * sp * cy);
@@ -312,7 +314,7 @@ inline void quat_euler_jacobian(const double e[3], double J[3][3])
 
 // x = N^-1 b ; cofactor = N^-1 with its rotational blocks propagated to quaternion space.  Returns false if the
 // solve produced a non-finite step.
-inline bool solve_step(const Mat6 &N, const double b[6], double x[6], Mat6 &cofactor)
+MULLS_HD inline bool solve_step(const Mat6 &N, const double b[6], double x[6], Mat6 &cofactor)
 {
 	Mat6 Ninv;
 	bool ok = invert6(N, Ninv);
