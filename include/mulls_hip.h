@@ -166,6 +166,7 @@ typedef struct mulls_profile
 	double ms_host_wait;	/* host time spent waiting for the device epoch, summed over iterations */
 	double ms_host_launch;	/* host time spent enqueueing the launch set, summed over iterations */
 	uint64_t nn_tgt_unique; /* target points of the searched class clouds (once per cloud), summed over launches */
+	uint64_t nn_corr_pts;	/* device-resident loop: correspondences that entered the estimation, summed over the iterations */
 } mulls_profile;
 
 typedef struct mulls_ctx mulls_ctx;		/* one per host thread / HIP stream */
@@ -178,10 +179,12 @@ void mulls_destroy(mulls_ctx *ctx);
 const char *mulls_last_error(const mulls_ctx *ctx);
 int mulls_set_profiling(mulls_ctx *ctx, int on);
 int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
-/* correspondence-search tier: 0 = auto (uniform grid staged in LDS when every searched target class cloud holds
- * <= 9728 points, otherwise the uniform grid in global memory), 1 = LDS-tiled brute force, 2 = uniform grid in global
- * memory, 3 = uniform grid staged in LDS (MULLS_E_INVALID when a cloud is too large).  All tiers are exact and return
- * identical correspondences (tests/test_gpu_stages.py). */
+/* correspondence-search tier: 0 = auto (target class clouds of <= 9728 points: uniform grid staged in LDS, run by the
+ * device-resident loop — one launch iterates every pair of the batch to the end — for batches of more than 8 pairs;
+ * otherwise the uniform grid in global memory with lock-step launches), 1 = LDS-tiled brute force, 2 = uniform grid in
+ * global memory, 3 = uniform grid staged in LDS with lock-step launches (MULLS_E_INVALID when a cloud is too large),
+ * 4 = device-resident loop (the lock-step LDS tier where the loop does not apply: normal shooting, source class clouds
+ * above 16384 points).  All tiers are exact and return bit-identical results (tests/test_gpu_stages.py, test_gpu_icp.py). */
 int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
 /* raw hipStream_t the library launches on (so callers can bracket it with their own events) */
 void *mulls_stream(mulls_ctx *ctx);

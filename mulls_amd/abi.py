@@ -187,6 +187,7 @@ class Profile(C.Structure):
         ("ms_host_wait", C.c_double),
         ("ms_host_launch", C.c_double),
         ("nn_tgt_unique", C.c_uint64),
+        ("nn_corr_pts", C.c_uint64),
     ]
 
 

@@ -107,6 +107,19 @@ struct PairOut
 	uint32_t pad_[2];
 };
 
+// Result of one pair of the device-resident loop (k_icp), read back by the host after the launch.
+struct IcpOut
+{
+	double T[16];	 // Trans1_2, column-major
+	double info[36]; // information matrix, column-major
+	double sigma2;
+	unsigned long long src_pts, tgt_pts, corr_pts; // profile counters: live source points / target points of the searched class clouds / valid correspondences, summed over the iterations
+	float ratio;
+	int32_t code, iters, singular, trace_len;
+	uint32_t ncorr[MULLS_NC], nsrc0[MULLS_NC], ntgt0[MULLS_NC], bbox[6];
+	uint32_t pad_;
+};
+
 // One workgroup's worth of the correspondence search / filter / accumulation.
 struct Job
 {

@@ -22,6 +22,7 @@
 #include "../../include/mulls_hip.h"
 #include "device_types.h"
 #include "hostmath.h"
+#include "icp_step.h"
 #include "launch.h"
 #include "ctx.h"
 
@@ -40,6 +41,11 @@ struct mulls_batch
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> cjobs_dev_h; // the same entries as uploaded: inside each sub-batch's slice the most expensive class clouds come first
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
+	// device-resident loop (k_icp): class-level jobs in pair order, each pair's range in them, the pairs most expensive first
+	std::vector<Job> rjobs_h;
+	std::vector<uint32_t> pair_rjob_h, order_h;
+	std::vector<IcpOut> icp_outs_h;
+	std::vector<mulls_iter_trace> trace_h;
 	std::string jobs_key;
 	uint32_t njobs = 0;
 	// device
@@ -68,6 +74,11 @@ struct mulls_batch
 	double *partial = nullptr;
 	Job *tjobs = nullptr;
 	Job *cjobs = nullptr;
+	Job *rjobs = nullptr;
+	uint32_t *pair_rjob = nullptr, *order = nullptr, *icp_queue = nullptr;
+	IcpOut *icp_outs = nullptr;
+	mulls_iter_trace *trace_dev = nullptr;
+	size_t cap_icp[5] = {};
 	uint32_t *wl = nullptr;		// LDS tier: class clouds k_cert queued for k_nn_lds (one slot per class-level job)
 	uint32_t *wl_ctr = nullptr; // ... and the queue counters: per sub-batch 8 words = (queued, taken) x launch parity
 	size_t cap_wl = 0;
@@ -115,21 +126,10 @@ void rows12(const double colmajor[16], double out[12])
 			out[r * 4 + c] = colmajor[r + 4 * c];
 }
 
-// host-side life of one pair during a run
-struct PairHost
+// host-side life of one pair during a run: the shared per-iteration state (icp_step.h) + host-only bookkeeping
+struct PairHost : mulls::PairIter
 {
-	Mat4 guess, temp;
-	float thr[MULLS_NC];
-	int code = 0;
-	int iters = 0;
-	bool active = true, want_residual = false, done = false;
 	bool first = true;
-	double x[6] = {0, 0, 0, 0, 0, 0};
-	Mat6 cofactor, info;
-	double sigma2 = 1.0;
-	float ratio = 1.0f;
-	int src_feature_count = 0;
-	int singular = 0;
 	uint32_t alive_prev[MULLS_NC];
 };
 
@@ -265,6 +265,30 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 			std::stable_sort(first_of((uint32_t)((long)B->n * k / nsub)), first_of((uint32_t)((long)B->n * (k + 1) / nsub)),
 							 [&](const Job &a, const Job &b) { return cost(a) > cost(b); });
 	}
+	// device-resident loop: one class-level job per (pair, used class with source points), in pair order; pairs taken from the
+	// queue most expensive first (same cost model), so that the last pairs in flight are the cheap ones
+	B->rjobs_h.clear();
+	B->pair_rjob_h.assign((size_t)B->n + 1, 0u);
+	std::vector<uint64_t> pair_cost(B->n, 0);
+	for (int p = 0; p < B->n; p++)
+	{
+		B->pair_rjob_h[p] = (uint32_t)B->rjobs_h.size();
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			if (P->used_feature_type[c] == '1' && d.src_cap > 0)
+			{
+				Job j = {(uint32_t)p, (uint32_t)c, 0u, d.src_cap};
+				B->rjobs_h.push_back(j);
+				pair_cost[p] += (uint64_t)d.src_cap * (uint64_t)(64u + d.tgt_n0 / 64u);
+			}
+		}
+	}
+	B->pair_rjob_h[B->n] = (uint32_t)B->rjobs_h.size();
+	B->order_h.resize(B->n);
+	for (int p = 0; p < B->n; p++)
+		B->order_h[p] = (uint32_t)p;
+	std::stable_sort(B->order_h.begin(), B->order_h.end(), [&](uint32_t a, uint32_t b) { return pair_cost[a] > pair_cost[b]; });
 	B->tjobs_h.clear();
 	for (int p = 0; p < B->n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
@@ -376,6 +400,7 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	case 2:
 		return 1;
 	case 3:
+	case 4:
 		return fits ? 2 : -1;
 	default:
 		// up to 8 pairs the LDS tier cannot fill the chip (one workgroup per class cloud, each staging its whole target):
@@ -628,7 +653,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 // Per-run device tables.  Job tables and the pristine descriptor block only change with the batch layout or the set of
 // used classes, so they are uploaded once (pinned copies would not help: they are simply not re-sent) and every run
 // restores the mutable descriptors / box keys with device-to-device copies — no pageable H2D traffic per run.
-int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out)
+int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr)
 {
 	hipStream_t st = ctx->stream;
 	const int n = B->n;
@@ -651,14 +676,25 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	if (const char *e = std::getenv("MULLS_GRID_H0")) // diagnostics
 		rp.grid_h0 = std::max(0.05f, (float)std::atof(e));
 	rp.lds_dedup = 0;
+	bool resident = false;
 	if (tier == 2)
 	{
 		rp.grid_maxcells = lds_cells_for(lds_cap);
 		// class-level jobs (one workgroup sees every query of a class cloud): keep the duplicate table in LDS if 4 B per target
-		// still leave a useful cell budget next to the staged cloud
+		// still leave a useful cell budget next to the staged cloud (6 KiB stay free for the static LDS of k_icp)
 		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
-		const long left = 160L * 1024L - 64L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
-		if (class_level && !rp.normal_shooting && left / 2 - 8 >= 8192 && !std::getenv("MULLS_NO_LDS_DEDUP")) // k_nn_shoot uses the global table
+		const long left = 160L * 1024L - 64L - 6144L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
+		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 8192 && !std::getenv("MULLS_NO_LDS_DEDUP"); // k_nn_shoot uses the global table
+		// Device-resident loop (k_icp: one workgroup carries a pair through all its iterations): the default whenever the LDS tier
+		// applies with its on-chip duplicate table, the loop is the plain mm_lls_icp one (resident_out) and no source class cloud is
+		// so large that one workgroup per pair would be the wrong shape (those pairs are spread over many workgroups by the
+		// lock-step path).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the resident loop (and gets the lock-step LDS
+		// tier where the loop does not apply).
+		uint32_t max_src = 0;
+		for (const Job &j : B->rjobs_h)
+			max_src = std::max(max_src, j.count);
+		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && !std::getenv("MULLS_NO_RESIDENT")));
+		if ((class_level || resident) && dedup_fits)
 		{
 			rp.lds_dedup = 1;
 			rp.grid_maxcells = (uint32_t)std::min<long>(left / 2 - 8, (long)MULLS_MAXCELLS);
@@ -687,6 +723,9 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
 	}
 
+	if (resident_out)
+		*resident_out = resident;
+
 	bool grew = false, g2 = false;
 	int rc = MULLS_OK;
 	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
@@ -698,6 +737,20 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	A(grow(ctx, &B->cjobs, &B->cap_jobs[3], B->cjobs_h.size(), &g2));
 	grew |= g2;
 	A(grow(ctx, &B->wl, &B->cap_wl, B->cjobs_h.size()));
+	if (resident)
+	{
+		A(grow(ctx, &B->rjobs, &B->cap_icp[0], B->rjobs_h.size(), &g2));
+		grew |= g2;
+		A(grow(ctx, &B->pair_rjob, &B->cap_icp[1], (size_t)n + 1, &g2));
+		grew |= g2;
+		A(grow(ctx, &B->order, &B->cap_icp[2], (size_t)n, &g2));
+		grew |= g2;
+		A(grow(ctx, &B->icp_outs, &B->cap_icp[3], (size_t)n));
+		if (!B->icp_queue)
+			A(dmalloc(ctx, &B->icp_queue, 16));
+		if (rc == MULLS_OK)
+			HIPCHK(ctx, hipMemsetAsync(B->icp_queue, 0, 16 * sizeof(uint32_t), st));
+	}
 	if (!B->wl_ctr)
 		A(dmalloc(ctx, &B->wl_ctr, 16));
 	if (rc == MULLS_OK)
@@ -722,15 +775,22 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	}
 	if (rc != MULLS_OK)
 		return rc;
-	if (grew || B->dev_key != B->jobs_key || B->dev_key.empty())
+	const std::string want_key = B->jobs_key + (resident ? "R" : "");
+	if (grew || B->dev_key != want_key || B->dev_key.empty())
 	{
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size(), hipMemcpyHostToDevice, st));
+		if (resident)
+		{
+			HIPCHK(ctx, hipMemcpyAsync(B->rjobs, B->rjobs_h.data(), sizeof(Job) * B->rjobs_h.size(), hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemcpyAsync(B->pair_rjob, B->pair_rjob_h.data(), sizeof(uint32_t) * B->pair_rjob_h.size(), hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemcpyAsync(B->order, B->order_h.data(), sizeof(uint32_t) * B->order_h.size(), hipMemcpyHostToDevice, st));
+		}
 		HIPCHK(ctx, hipMemcpyAsync(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipStreamSynchronize(st)); // the host vectors may be rebuilt by a later call
-		B->dev_key = B->jobs_key;
+		B->dev_key = want_key;
 	}
 	HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_init, sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyDeviceToDevice, st));
 	HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_init, sizeof(uint32_t) * 6 * n, hipMemcpyDeviceToDevice, st));
@@ -773,6 +833,23 @@ struct EvTimer
 };
 
 } // namespace
+
+// run-wide constants of the per-iteration algebra (the float conversions of cregistration.hpp:1150-1157)
+static mulls::IcpConst icp_const(const mulls_params *P)
+{
+	mulls::IcpConst K;
+	K.max_iter_num = P->max_iter_num;
+	K.converge_translation = P->converge_translation;
+	K.converge_rotation = (float)(P->converge_rotation_d / 180.0 * M_PI);
+	K.max_bearable_translation = (float)(2.0 * P->dis_thre_unit);
+	K.max_bearable_rotation = (float)(P->max_bearable_rotation_d / 180.0 * M_PI);
+	K.dis_thre_unit = P->dis_thre_unit;
+	K.dis_thre_min = P->dis_thre_min;
+	K.dis_thre_update_rate = P->dis_thre_update_rate;
+	K.min_neccessary_corr_ratio = P->min_neccessary_corr_ratio;
+	K.sigma_thre = P->sigma_thre;
+	return K;
+}
 
 // Reserve `n` consecutive epochs of the batch's duplicate table.  The winner key is (descending epoch << 32 | source index)
 // under atomicMin, so newer epochs must sort below older ones: before the 32-bit counter would wrap, the table is refilled
@@ -901,7 +978,7 @@ extern "C"
 	int mulls_set_nn_mode(mulls_ctx *ctx, int mode)
 	try
 	{
-		if (!ctx || mode < 0 || mode > 3)
+		if (!ctx || mode < 0 || mode > 4)
 			return MULLS_E_INVALID;
 		ctx->nn_mode = mode;
 		return MULLS_OK;
@@ -999,7 +1076,8 @@ extern "C"
 
 		uint32_t lds_cap = 0;
 		int tier = 0;
-		rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier);
+		bool resident = false;
+		rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident);
 		if (rc != MULLS_OK)
 			return rc;
 		const bool use_grid = tier != 0;
@@ -1056,25 +1134,82 @@ extern "C"
 							  B->tsorted, tier == 2);
 		evt.end();
 
+		const mulls::IcpConst K = icp_const(P);
+		if (resident)
+		{
+			// ---- device-resident loop: ONE launch iterates every pair to the end (k_icp.hip) ------------------------------------------
+			uint32_t trace_cap = 0;
+			for (int p = 0; p < n; p++)
+				if (results[p].trace && results[p].trace_cap > 0)
+					trace_cap = std::max(trace_cap, (uint32_t)results[p].trace_cap);
+			if (trace_cap)
+			{
+				trace_cap = std::min(trace_cap, (uint32_t)std::max(P->max_iter_num, 1));
+				if (grow(ctx, &B->trace_dev, &B->cap_icp[4], (size_t)n * trace_cap) != MULLS_OK)
+					return MULLS_E_HIP;
+			}
+			evt.begin(&ctx->prof.ms_nn);
+			if (launch_icp(st, (uint32_t)n, 0u, B->rjobs, B->pair_rjob, B->order, B->icp_queue, B->descs, B->setup, rp, K, B->spos, B->snrm, B->grids, B->cell_start,
+						   B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, B->bbox, lds_cap, rp.grid_maxcells,
+						   B->icp_outs, trace_cap ? B->trace_dev : nullptr, trace_cap) != 0)
+			{
+				ctx->err = "could not raise the dynamic LDS limit of k_icp";
+				return MULLS_E_HIP;
+			}
+			evt.end();
+			B->icp_outs_h.resize(n);
+			HIPCHK(ctx, hipMemcpyAsync(B->icp_outs_h.data(), B->icp_outs, sizeof(IcpOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+			if (trace_cap)
+			{
+				B->trace_h.resize((size_t)n * trace_cap);
+				HIPCHK(ctx, hipMemcpyAsync(B->trace_h.data(), B->trace_dev, sizeof(mulls_iter_trace) * (size_t)n * trace_cap, hipMemcpyDeviceToHost, st));
+			}
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			evt.collect();
+			const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
+			ctx->prof.launches_nn = 1;
+			int max_it = 0;
+			for (int p = 0; p < n; p++)
+			{
+				const IcpOut &o = B->icp_outs_h[p];
+				mulls_result &R = results[p];
+				R.code = o.code;
+				R.iters = o.iters;
+				std::memcpy(R.T, o.T, sizeof(R.T));
+				std::memcpy(R.info, o.info, sizeof(R.info));
+				R.sigma = (float)std::sqrt(o.sigma2);
+				R.confidence = o.ratio;
+				R.singular = o.singular;
+				R.ms_total = (float)(wall_ms / n);
+				for (int c = 0; c < MULLS_NC; c++)
+				{
+					R.ncorr[c] = o.ncorr[c];
+					R.nsrc0[c] = o.nsrc0[c];
+					R.ntgt0[c] = o.ntgt0[c];
+				}
+				R.cropped = 0;
+				std::memset(R.crop_box, 0, sizeof(R.crop_box));
+				fill_crop_box(rp, B->setup_h[p].tgt_bound, o.bbox, R);
+				R.trace_len = 0;
+				if (R.trace && R.trace_cap > 0)
+				{
+					R.trace_len = std::min(o.trace_len, R.trace_cap);
+					std::memcpy(R.trace, &B->trace_h[(size_t)p * trace_cap], sizeof(mulls_iter_trace) * (size_t)R.trace_len);
+				}
+				ctx->prof.nn_src_pts += o.src_pts;
+				ctx->prof.nn_tgt_unique += o.tgt_pts;
+				ctx->prof.nn_tgt_pts += o.tgt_pts;
+				ctx->prof.nn_corr_pts += o.corr_pts;
+				max_it = std::max(max_it, o.iters);
+			}
+			ctx->prof.iterations = max_it;
+			return MULLS_OK;
+		}
 		std::vector<PairHost> H(n);
-		const float max_bearable_translation = (float)(2.0 * P->dis_thre_unit);
-		const float converge_rotation = (float)(P->converge_rotation_d / 180.0 * M_PI);
-		const float max_bearable_rotation = (float)(P->max_bearable_rotation_d / 180.0 * M_PI);
 		for (int p = 0; p < n; p++)
 		{
 			PairHost &h = H[p];
-			for (int r = 0; r < 3; r++)
-				for (int c = 0; c < 4; c++)
-					h.guess.at(r, c) = B->setup_h[p].guess[r * 4 + c];
-			h.guess.at(3, 0) = h.guess.at(3, 1) = h.guess.at(3, 2) = 0.0;
-			h.guess.at(3, 3) = 1.0;
-			h.temp = Mat4::identity();
-			for (int c = 0; c < MULLS_NC; c++)
-				h.thr[c] = P->dis_thre_unit;
-			h.cofactor = Mat6::identity();
-			h.info = Mat6::identity();
-			h.active = P->max_iter_num > 0;
-			h.done = !h.active;
+			mulls::pair_iter_init(h, B->setup_h[p].guess, K);
 			results[p].trace_len = 0;
 			std::memset(results[p].ncorr, 0, sizeof(results[p].ncorr));
 			std::memset(results[p].nsrc0, 0, sizeof(results[p].nsrc0));
@@ -1248,17 +1383,9 @@ extern "C"
 				mulls_result &R = results[p];
 				if (h.want_residual)
 				{
-					// get_multi_metrics_lls_residual (cregistration.hpp:2518-2544) + information matrix (:1386)
-					const double VTPV = o.comb[0]; // summed over the used classes in the reference's order by k_finish
-					const long obs = (long)o.comb[1];
-					h.sigma2 = VTPV / (double)((int)obs - 6);
-					h.code = (std::sqrt(h.sigma2) < (double)P->sigma_thre) ? 1 : -3;
-					Mat6 cinv;
-					mulls::invert6(h.cofactor, cinv);
-					for (int k = 0; k < 36; k++)
-						h.info.v[k] = (1.0 / h.sigma2) * cinv.v[k];
-					h.want_residual = false;
-					h.done = true;
+					// get_multi_metrics_lls_residual (cregistration.hpp:2518-2544) + information matrix (:1386); VTPV and the number of
+					// observations were summed over the used classes in the reference's order by k_finish
+					mulls::step_residual(h, K, o.comb[0], o.comb[1]);
 					continue;
 				}
 				if (!h.active)
@@ -1298,12 +1425,6 @@ extern "C"
 					h.alive_prev[c] = o.n_alive[c];
 					R.ncorr[c] = o.n_valid[c];
 				}
-				int total = 0;
-				for (int c = 0; c < MULLS_NC; c++)
-					total += (int)o.n_valid[c];
-				const int necessary = (int)(o.n_valid[MULLS_PILLAR] + o.n_valid[MULLS_BEAM] + o.n_valid[MULLS_FACADE]);
-				h.ratio = (float)(1.0 * necessary / h.src_feature_count);
-
 				mulls_iter_trace *tr = nullptr;
 				if (R.trace && R.trace_len < R.trace_cap)
 				{
@@ -1317,49 +1438,18 @@ extern "C"
 						tr->thr[c] = h.thr[c];
 					}
 				}
-
-				if (total < 40 || necessary < 20 || h.ratio < P->min_neccessary_corr_ratio) // :1305-1311
-				{
-					h.code = -2;
-					h.temp = Mat4::identity();
-					h.active = false;
-					h.done = true;
+				if (!mulls::step_counts(h, K, o.n_valid)) // :1305-1311, then update_corr_dist_thre :1855-1866
 					continue;
-				}
-				for (int c = 0; c < MULLS_NC; c++) // update_corr_dist_thre :1855-1866
-				{
-					const double v = 1.0 * h.thr[c] / P->dis_thre_update_rate;
-					h.thr[c] = (float)((v > P->dis_thre_min) ? v : (double)P->dis_thre_min);
-				}
 				Mat6 N;
 				double b[6];
-				normal_from_comb(o, N, b);
-				if (!mulls::solve_step(N, b, h.x, h.cofactor))
-					h.singular = 1;
+				mulls::normal_from_row(o.comb, N, b);
+				mulls::step_solve(h, K, N, b, i); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
 				if (tr)
 				{
 					std::memcpy(tr->atpa, N.v, sizeof(tr->atpa));
 					std::memcpy(tr->atpb, b, sizeof(tr->atpb));
 					std::memcpy(tr->x, h.x, sizeof(tr->x));
 				}
-				h.temp = mulls::euler_step_to_matrix(h.x);
-				const double tsn = std::sqrt(h.x[0] * h.x[0] + h.x[1] * h.x[1] + h.x[2] * h.x[2]);
-				const double rsa = mulls::rotation_angle(h.temp);
-				if (tsn > max_bearable_translation || std::fabs(rsa) > max_bearable_rotation) // :1348-1354
-				{
-					h.code = -1;
-					h.temp = Mat4::identity();
-					h.active = false;
-					h.done = true;
-					continue;
-				}
-				if (i == P->max_iter_num - 1 || (i > 2 && tsn < P->converge_translation && std::fabs(rsa) < converge_rotation)) // :1357
-				{
-					h.active = false;
-					h.want_residual = true; // the residual pass runs on the device before anything else touches this pair
-					continue;
-				}
-				h.guess = h.temp * h.guess; // :1400
 			}
 			ctx->prof.ms_host_step += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_step0).count() * 1e3;
 			ctx->prof.nn_pair_evals += acc_evals;

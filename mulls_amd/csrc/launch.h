@@ -42,3 +42,15 @@ void launch_push_states(hipStream_t st, const PairState *host_states, PairState 
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
 					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq);
+
+// device-resident registration loop (k_icp.hip): one launch = every iteration of `npairs` pairs
+namespace mulls
+{
+struct IcpConst;
+}
+struct mulls_iter_trace;
+int launch_icp(hipStream_t st, uint32_t npairs, uint32_t pair_base, const Job *rjobs, const uint32_t *pair_rjob, const uint32_t *order, uint32_t *queue,
+			   CloudDesc *descs, const PairSetup *setup, const RunParams &rp, const mulls::IcpConst &K, float4 *spos, float4 *snrm, const GridDesc *grids,
+			   const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm,
+			   int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, const uint32_t *bbox, uint32_t cap, uint32_t maxcells, IcpOut *outs,
+			   mulls_iter_trace *trace, uint32_t trace_cap);

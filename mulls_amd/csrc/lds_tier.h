@@ -1,0 +1,788 @@
+// lds_tier.h — device code of the LDS grid tier of the correspondence search, shared by the lock-step kernels (k_cert / k_nn_lds /
+// k_filter in k_search.hip) and the device-resident registration loop (k_icp.hip): the rejection chain of one source point, the
+// exact grid search of one query by a sub-group of lanes, and the two per-class-cloud passes of an ICP iteration (cert_class:
+// rigid step + certificates + leftovers; lds_search_class: target cloud staged in LDS + search of the uncertified points).
+#pragma once
+#include "device_util.h"
+// ---------------------------------------------------------------------------------------------------------------
+// Rejection chain of determine_corres after the search (cregistration.hpp:1755-1830), one source point.
+// `dedup_done`: the duplicate rule has been applied already (losers carry nn_idx = -1, k_nn_lds with rp.lds_dedup).
+struct FilterCtx
+{
+	bool gate, any_match, normal_check, dedup_done;
+	float max_sqr;	 // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	double cos_thre; // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
+	unsigned long long key_hi;
+};
+__device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc &d, uint32_t s, const float4 *__restrict__ snrm,
+											  const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, const int32_t *__restrict__ nn_idx,
+											  const float *__restrict__ nn_d2, int32_t *__restrict__ match, float *__restrict__ wd,
+											  const unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos,
+											  float4 *__restrict__ mq, uint32_t &n_alive, uint32_t &n_valid)
+{
+	const uint32_t g = d.src_off + s;
+	const uint32_t f = flag[g];
+	if (!(f & MULLS_F_ALIVE))
+		return;
+	bool alive = true, valid, fresh = false;
+	int m;
+	float4 n2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (F.any_match)
+	{
+		m = nn_idx[g];
+		valid = m >= 0;
+		if (F.gate && (m < 0 || (!F.dedup_done && winner[d.tgt_off + m] != (F.key_hi | (unsigned long long)s))))
+		{
+			alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+			valid = false;
+		}
+		if (valid)
+		{
+			const float dist = nn_d2[g];
+			valid = !(dist > F.max_sqr);
+			if (valid)
+			{
+				wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+				// the matched target travels with the source point from here on: k_accum streams (position, direction) records
+				// instead of gathering two cache lines per correspondence (its launches were bound by exactly that traffic).
+				// From the second iteration on most points keep their target: the record is already there (it is only ever
+				// written together with match[]), so neither gather nor store is needed — one coalesced 16-B read instead.
+				if (match[g] == m)
+					n2 = mq[2u * g + 1u];
+				else
+				{
+					match[g] = m;
+					n2 = tnrm[d.tgt_off + m];
+					mq[2u * g] = tpos[d.tgt_off + m];
+					mq[2u * g + 1u] = n2;
+				}
+				fresh = true;
+			}
+		}
+	}
+	else if (F.gate)
+	{
+		alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+		valid = false;
+		m = -1;
+	}
+	else
+	{
+		// CorrespondenceRejectorDistance::getCorrespondences returned early on the empty input: the previous
+		// Corr_f is still in place (SURVEY B-4) and goes through the direction check again.
+		valid = (f & MULLS_F_VALID) != 0;
+		m = match[g];
+	}
+	if (valid && F.normal_check)
+	{
+		const float4 n1 = snrm[g];
+		if (!fresh)
+			n2 = mq[2u * g + 1u]; // the standing correspondence's target direction
+		const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+		const float c = (float)fabs(dot);
+		if ((double)c < F.cos_thre)
+			valid = false;
+	}
+	flag[g] = (uint8_t)((alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u));
+	n_alive += alive ? 1u : 0u;
+	n_valid += valid ? 1u : 0u;
+}
+// ---------------------------------------------------------------------------------------------------------------
+// Correspondence search, LDS grid tier — the default whenever every searched target class cloud holds at most
+// MULLS_LDS_MAXPTS points (the reference-default KITTI sizes).  Two kernels per ICP iteration:
+//
+//   k_cert     light pass, 512 lanes per (pair, class), several workgroups per CU.  One lane per source point: this
+//              iteration's rigid step (cregistration.hpp:1690-1695) and the CERTIFICATE — a point whose previous nearest
+//              target is provably still its nearest one (triangle inequality on a bound its last search left behind) gets its
+//              correspondence without a search.  As the registration converges the steps shrink and from the third or fourth
+//              iteration on 95-100 % of the points certify.  A class cloud with at most MULLS_CERT_SMALL points left over
+//              searches them right here against the grid in global memory (8-lane sub-groups) and runs the duplicate rule and
+//              the rejection chain; otherwise it queues itself for
+//   k_nn_lds   heavy pass, one persistent 1024-lane workgroup per CU taking class clouds from that queue: brings the whole
+//              cell-sorted target class cloud on chip once with coalesced 16-B loads (12-B position records, a uint16 original
+//              index per point, a uint16 cell table — as many cells as the rest of the 160 KiB allows) and searches the
+//              uncertified points against it in equal chunks of at most MULLS_LDS_QCHUNK queries:
+//     cost order   counting sort of the chunk's queries by the candidate trips they took last time (kept next to the hint):
+//                  the eight sub-groups of a wave run in lock step, so neighbours should cost the same;
+//     search       8-lane sub-groups, one query each: the cube around the query whose radius is the distance to last
+//                  iteration's nearest target (an exact upper bound: the hint) plus a slack, two rows of cells per step, their
+//                  candidate ranges laid end to end, two candidates per lane in flight, state = one 64-bit (distance bits,
+//                  index) key and the second-smallest distance, DPP minima.  Unhinted queries probe their own cell first;
+//                  the 2.5*thr ball is swept only if nothing lies within one cell edge;
+//     tail         duplicate rule in an LDS table, then the rejection chain (filter_point) on the results while they are
+//                  still in cache, and the matched target's record for k_accum.
+// Why the certificate is exact: a search examines every target whose cell meets the cube [p - R, p + R], i.e. every target
+// within distance R of p, and reports the nearest one j.  It leaves lb = min(second-smallest distance examined, R): every
+// target other than j is at least lb away from p.  When the point moves to p' (|p' - p| = moved, computed from the two float
+// positions), those targets are at least lb - moved away from p'.  If dist(p', j) < lb - moved — tested with 1e-5 relative
+// slack on both sides, two orders of magnitude above the rounding of the float expressions — j is the unique nearest
+// neighbour of p', and its squared distance is evaluated with the very expression a search uses: same index, same bits.
+// Ties and near-ties (equal distances, duplicate target points) fail the test and are searched, where the lowest index wins.
+// The bound then travels on as lb - moved.  Same exactness argument for the search itself, same outputs as k_nn / k_nn_grid.
+namespace
+{
+// Search state of a query: (distance bits << 32) | target index.  Distances are sums of squares (>= +0, or NaN), so the
+// unsigned order of the key is the lexicographic (distance, index) order the tie rule asks for, NaN keys sort after
+// NNKEY_NONE and are never taken, and one 64-bit compare + two selects update the running minimum.
+typedef unsigned long long nnkey;
+#define NNKEY_NONE 0x7f800000ffffffffull
+__device__ __forceinline__ nnkey nn_key(float dist, uint32_t idx) { return ((nnkey)__float_as_uint(dist) << 32) | idx; }
+__device__ __forceinline__ float key_dist(nnkey k) { return __uint_as_float((uint32_t)(k >> 32)); }
+__device__ __forceinline__ bool key_found(nnkey k) { return (uint32_t)k != 0xffffffffu; }
+
+// the target class cloud as the sub-groups see it: staged in LDS (k_nn_lds) ...
+struct LdsGrid
+{
+	const float *P;	// staged target positions, 12-B records (x, y, z): one address, three immediate offsets, conflict-free stride
+	const uint16_t *IDX, *CS;
+	__device__ __forceinline__ uint32_t cs(uint32_t i) const { return CS[i]; }
+	__device__ __forceinline__ void cand(uint32_t t, float &x, float &y, float &z, uint32_t &i) const
+	{
+		const float *p = P + 3u * t;
+		x = p[0], y = p[1], z = p[2];
+		i = IDX[t];
+	}
+};
+// ... or where k_grid_build_sort left it in global memory (k_cert's handful of leftover queries): cell-sorted float4 records with
+// the original index in .w, and the same uint16 cell table
+struct GlobGrid
+{
+	const float4 *ts;
+	const uint16_t *CS;
+	__device__ __forceinline__ uint32_t cs(uint32_t i) const { return CS[i]; }
+	__device__ __forceinline__ void cand(uint32_t t, float &x, float &y, float &z, uint32_t &i) const
+	{
+		const float4 v = ts[t];
+		x = v.x, y = v.y, z = v.z;
+		i = __float_as_uint(v.w);
+	}
+};
+
+// minimum over the lanes of a sub-group, VALU only (DPP; no LDS-crossbar shuffles): quad xor-1, quad xor-2, half-row
+// mirror (8 lanes), row mirror (16 lanes).  Result in every lane.
+template <int CTRL>
+__device__ __forceinline__ void dpp_min_step(nnkey &bk)
+{
+	const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(bk >> 32), CTRL, 0xf, 0xf, false);
+	const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)bk, CTRL, 0xf, 0xf, false);
+	const nnkey o = ((nnkey)oh << 32) | ol;
+	bk = o < bk ? o : bk;
+}
+__device__ __forceinline__ void row16_min(nnkey &bk)
+{
+	dpp_min_step<0xB1>(bk);	 // quad_perm [1,0,3,2]
+	dpp_min_step<0x4E>(bk);	 // quad_perm [2,3,0,1]
+#if MULLS_LDS_GROUP >= 8
+	dpp_min_step<0x141>(bk); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
+#endif
+#if MULLS_LDS_GROUP == 16
+	dpp_min_step<0x140>(bk); // row_mirror: lanes i <-> 15 - i
+#endif
+}
+// (best key, second-best distance) over the lanes of a sub-group.  Every lane enters with the best key and the second-smallest
+// distance among ITS candidates; a lane whose best lost the sub-group minimum contributes that best's distance instead.
+template <int CTRL>
+__device__ __forceinline__ void dpp_fmin_step(float &v)
+{
+	const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+	v = fminf(o, v);
+}
+__device__ __forceinline__ void row16_min2(nnkey &bk, float &sec)
+{
+	nnkey g = bk;
+	row16_min(g);
+	float c = (bk == g) ? sec : key_dist(bk);
+	dpp_fmin_step<0xB1>(c);
+	dpp_fmin_step<0x4E>(c);
+#if MULLS_LDS_GROUP >= 8
+	dpp_fmin_step<0x141>(c);
+#endif
+#if MULLS_LDS_GROUP == 16
+	dpp_fmin_step<0x140>(c);
+#endif
+	sec = c;
+	bk = g;
+}
+
+// one candidate pair of a lane: `sec` follows the second-smallest distance this lane has seen (one v_med3_f32 per candidate: the
+// median of (second, candidate, best) is the new second whichever of the three orders holds); with !ok2 the second candidate is
+// the first one again — no effect on the best, and kept away from the second-best
+__device__ __forceinline__ void take_pair(float da, uint32_t ia, float db, uint32_t ib, bool ok2, nnkey &bk, float &sec)
+{
+	const nnkey ka = nn_key(da, ia), kb = nn_key(db, ib);
+	sec = __builtin_amdgcn_fmed3f(sec, da, key_dist(bk));
+	bk = ka < bk ? ka : bk;
+	sec = __builtin_amdgcn_fmed3f(sec, ok2 ? db : __builtin_inff(), key_dist(bk));
+	bk = kb < bk ? kb : bk;
+}
+
+// Evaluate every target in the cells intersecting the cube [p - R, p + R] (same exactness argument as grid_scan_box).  The
+// rows (x-runs of cells, contiguous in the sorted cloud) are taken two at a time: every lane of the sub-group reads their
+// bounds (same addresses: LDS broadcast), the candidate ranges are laid end to end and the sub-group strides over the
+// concatenation, two candidates per lane in flight — the trip count is that of the total, not the sum of the per-row
+// round-ups, and the only per-row work is two table reads and a running sum.  Returns false when the cube lies inside the
+// query's own cell and `own_done` says that cell has been swept already.
+#define MULLS_LDS_CHUNK 2
+template <class G>
+__device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, float px, float py, float pz, float R, uint32_t sub, nnkey &bk,
+											  float &sec, uint32_t &trips, bool own_done = false)
+{
+	const float Rm = R * 1.0001f + 1e-4f;
+	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
+	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
+	const int z0 = grid_cell(pz - Rm, g.oz, g.inv_h, g.nz), z1 = grid_cell(pz + Rm, g.oz, g.inv_h, g.nz);
+	if (own_done && x1 - x0 == 1u && y0 == y1 && z0 == z1)
+		return false; // the cube stays inside the query's own cell, which has been swept already
+	int cy = y0, cz = z0;
+	while (cz <= z1)
+	{
+		uint32_t lo[MULLS_LDS_CHUNK], pre[MULLS_LDS_CHUNK], acc = 0;
+#pragma unroll
+		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		{
+			const bool valid = cz <= z1;
+			const uint32_t row = ((uint32_t)(valid ? cz : z0) * g.ny + (uint32_t)cy) * g.nx;
+			const uint32_t a = L.cs(row + x0), e = L.cs(row + x1);
+			lo[jj] = a - acc; // candidate f of the concatenation lives at lo[jj] + f while f < pre[jj]
+			acc += valid ? e - a : 0u;
+			pre[jj] = acc;
+			if (++cy > y1)
+			{
+				cy = y0;
+				cz++;
+			}
+		}
+		trips += (acc + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
+		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
+		{
+			const uint32_t f2 = f + MULLS_LDS_GROUP;
+			const bool ok2 = f2 < acc;
+			const uint32_t ff = ok2 ? f2 : f;
+#if MULLS_LDS_CHUNK == 1
+			const uint32_t ta = f + lo[0], tb = ff + lo[0];
+#else
+			const uint32_t ta = f + (f < pre[0] ? lo[0] : lo[1]);
+			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : lo[1]);
+#endif
+			float ax, ay, az, bx, by, bz;
+			uint32_t ia, ib;
+			L.cand(ta, ax, ay, az, ia);
+			L.cand(tb, bx, by, bz, ib);
+			float dx = px - ax, dy = py - ay, dz = pz - az;
+			const float da = (dx * dx + dy * dy) + dz * dz; // L2_Simple<float>, no FMA
+			dx = px - bx, dy = py - by, dz = pz - bz;
+			const float db = (dx * dx + dy * dy) + dz * dz;
+			take_pair(da, ia, db, ib, ok2, bk, sec);
+		}
+	}
+	return true;
+}
+
+// The exact nearest target of one query (q.xyz; q.w = radius of the hinted sweep, +inf = no hint) by the MULLS_LDS_GROUP lanes of
+// a sub-group.  Out: bk = (squared distance, original index) of the nearest target or NNKEY_NONE; sec = second-smallest squared
+// distance the last sweep saw (0 = unknown), Rfin = that sweep's radius: every target other than bk's is at least
+// min(sqrt(sec), Rfin) away; trips = candidate trips taken (cost class of the next iteration).
+template <class G>
+__device__ __forceinline__ void search_query(const GridDesc &g, const G &L, const float4 q, float r, float m, uint32_t sub, nnkey &bk, float &sec,
+											  float &Rfin, uint32_t &trips)
+{
+	bk = NNKEY_NONE;
+	sec = __builtin_inff();
+	Rfin = 0.0f;
+	trips = 0u;
+	// One sweep of the cube of radius R.  Its cells are a superset of every earlier sweep's cells, so its own (best, second)
+	// pair replaces the standing one; only when the radius was clipped to the rejection radius can the standing best lie
+	// outside — it stays the answer then, and nothing is claimed about the other targets.
+	auto sweep = [&](float R, bool own_done) {
+		nnkey lk = NNKEY_NONE;
+		float ls = __builtin_inff();
+		if (lds_scan_box(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
+		{
+			row16_min2(lk, ls);
+			if (bk < lk)
+				sec = 0.0f;
+			else
+			{
+				bk = lk;
+				sec = ls;
+			}
+		}
+		Rfin = R;
+	};
+	if (q.w < __builtin_inff())
+		sweep(fminf(m, q.w), false); // bounded by last iteration's correspondence: the cube contains that target
+	else
+	{
+		// probe 0: the query's own cell.  In dense regions (tens of targets per cell) this already yields a tight bound.
+		const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
+		const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
+		const uint32_t lo = L.cs(cell), hi = L.cs(cell + 1u);
+		trips += (hi - lo + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
+		for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
+		{
+			const uint32_t t2 = t + MULLS_LDS_GROUP;
+			const bool ok2 = t2 < hi;
+			float ax, ay, az, bx, by, bz;
+			uint32_t ia, ib;
+			L.cand(t, ax, ay, az, ia);
+			L.cand(ok2 ? t2 : t, bx, by, bz, ib);
+			float dx = q.x - ax, dy = q.y - ay, dz = q.z - az;
+			const float da = (dx * dx + dy * dy) + dz * dz;
+			dx = q.x - bx, dy = q.y - by, dz = q.z - bz;
+			const float db = (dx * dx + dy * dy) + dz * dz;
+			take_pair(da, ia, db, ib, ok2, bk, sec);
+		}
+		row16_min2(bk, sec);
+		// probe 1: every cell within min(first-probe radius, current best distance) of the query
+		sweep(key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m, true);
+	}
+	if (!(key_found(bk) && key_dist(bk) <= m * m))
+		sweep(key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r, false); // nothing within the first-probe radius: widen to the best distance, or to the rejection radius
+}
+
+// what the search of one class cloud needs to know about its iteration
+struct ClassCtx
+{
+	float r, m;			 // rejection radius 2.5 * thr (filter_dis_times * dis_thre, cregistration.hpp:1745) and first-probe radius
+	double max_dist_sqr; // (double)r squared: CorrespondenceEstimation's max_distance test
+	bool gate, dedup;	 // >= 500 live source points: duplicate rule in force; ... and resolved in this workgroup's LDS table
+	unsigned long long key_hi;
+};
+__device__ __forceinline__ ClassCtx class_ctx(const RunParams &rp, const PairState &ps, const GridDesc &g, int cls, uint32_t alive_cur, bool called)
+{
+	ClassCtx C;
+	C.r = 2.5f * ps.thr[cls];
+	const double maxd = (double)C.r;
+	C.max_dist_sqr = maxd * maxd;
+	C.m = fminf(C.r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
+	C.gate = alive_cur >= 500u;
+	C.dedup = rp.lds_dedup != 0u && called && C.gate;
+	C.key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	return C;
+}
+
+// lane `sub == 0` of a sub-group commits the result of a searched query; returns whether it is a match
+__device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc &d, uint32_t s, nnkey bk, float sec, float Rfin, uint32_t trips,
+											   int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, int2 *__restrict__ hint2, uint32_t *W,
+											   unsigned long long *__restrict__ winner)
+{
+	const float best = key_dist(bk);
+	const int bi = (int)(uint32_t)bk; // -1: nothing found
+	const bool matched = bi >= 0 && !((double)best > C.max_dist_sqr);
+	nn_idx[d.src_off + s] = matched ? bi : -1;
+	nn_d2[d.src_off + s] = best;
+	// hint and cost class of the next iteration; every target but the one found is at least min(second, radius swept) away
+	hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(fminf(sqrtf(sec), Rfin)));
+	if (matched)
+	{
+		if (C.dedup)
+			atomicMin(&W[bi], s); // this workgroup sees every query of the class cloud: the duplicate table stays on chip
+		else if (C.gate)
+			atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)s);
+	}
+	return matched;
+}
+
+// End of a class cloud's iteration, by the workgroup that holds all of its correspondences (k_cert when it searched the few
+// leftovers itself, else k_nn_lds): duplicate rule, then the rejection chain (k_filter's work) on the results while they are
+// still in cache, and the class's counters.  `red`: 3 * (BLK / 64) words of LDS.  Chunk-level jobs (no rp.lds_dedup) only
+// add their matches to the class counter; k_filter does the rest.
+template <int BLK>
+__device__ __forceinline__ void class_tail(const RunParams &rp, const PairState &ps, const ClassCtx &C, CloudDesc &d, const Job &job, uint32_t q_end,
+											uint32_t matched_cnt, uint32_t searched, const uint32_t *W, uint32_t *red, const float4 *__restrict__ snrm,
+											const float4 *__restrict__ tnrm, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+											int32_t *__restrict__ match, float *__restrict__ wd, const unsigned long long *__restrict__ winner,
+											const float4 *__restrict__ tpos, float4 *__restrict__ mq)
+{
+	if (C.dedup)
+	{
+		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched,
+		// which is what k_filter does with them anyway (it skips its winner-table check when rp.lds_dedup is set)
+		__threadfence_block();
+		__syncthreads();
+		for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
+			if (flag[d.src_off + s] & MULLS_F_ALIVE)
+			{
+				const int m = nn_idx[d.src_off + s];
+				if (m >= 0 && W[m] != s)
+					nn_idx[d.src_off + s] = -1;
+			}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if (!rp.lds_dedup)
+	{
+		if ((threadIdx.x & 63) == 0 && matched_cnt)
+			atomicAdd(&d.n_matched, matched_cnt);
+		return;
+	}
+	__threadfence_block(); // this workgroup's nn_idx / nn_d2 / snrm stores, read back below by other lanes
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = matched_cnt;
+	__syncthreads();
+	uint32_t total_matched = 0;
+	for (int w = 0; w < BLK / 64; w++)
+		total_matched += red[w];
+	const float thr = ps.thr[job.cls];
+	// vertex correspondences skip the direction check (cregistration.hpp:1292)
+	const FilterCtx F = {C.gate, total_matched > 0u, job.cls != 5, true, thr * thr, rp.cos_bearing, C.key_hi};
+	uint32_t n_alive = 0, n_valid = 0;
+	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
+		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq, n_alive, n_valid);
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		n_alive += __shfl_down(n_alive, off);
+		n_valid += __shfl_down(n_valid, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		red[BLK / 64 + (threadIdx.x >> 6)] = n_alive;
+		red[2 * (BLK / 64) + (threadIdx.x >> 6)] = n_valid;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t ta = 0, tv = 0;
+		for (int w = 0; w < BLK / 64; w++)
+		{
+			ta += red[BLK / 64 + w];
+			tv += red[2 * (BLK / 64) + w];
+		}
+		d.n_matched = total_matched; // k_finish reset it to 0 after the previous iteration
+		d.alive_next = ta;
+		d.valid_next = tv;
+		d.n_search = searched;
+	}
+}
+// nn_idx value of a live point that cert_class could not certify and left to lds_search_class (its sweep radius waits in nn_d2)
+#define MULLS_NEEDS_SEARCH (-2)
+
+// Light pass of one class cloud's iteration, BLK lanes, one source point per lane and trip (see the tier's description above):
+// rigid step, certificates, and — when at most MULLS_CERT_SMALL points are left over — their search against the grid in global
+// memory, the duplicate rule and the rejection chain.  Returns true when the class cloud is done for this iteration, false when
+// the caller has to stage the target cloud (lds_search_class).  W: LDS, tgt_n words (only touched with rp.lds_dedup).  Every lane
+// of the workgroup must call it (barriers inside).
+template <int BLK>
+__device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
+											float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
+											const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+											unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
+											float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+{
+	__shared__ float4 uq[MULLS_CERT_SMALL];				  // the few queries this workgroup searches itself
+	__shared__ uint32_t us[MULLS_CERT_SMALL];
+	__shared__ uint32_t ucount, red[3 * (BLK / 64)];
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint); // per source point: (hint word, bound on every OTHER target's distance)
+
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
+	const bool called = class_called(rp, d, job.cls);
+	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, called);
+	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
+	const bool use_hint = called && have_prev;
+	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
+	if (C.dedup)
+		for (uint32_t t = threadIdx.x; t < tgt_n; t += BLK)
+			W[t] = 0xffffffffu;
+	if (threadIdx.x == 0)
+		ucount = 0u;
+	__syncthreads();
+
+	uint32_t matched_cnt = 0;
+	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
+	{
+		const uint32_t gi = d.src_off + s;
+		if (!(flag[gi] & MULLS_F_ALIVE))
+			continue;
+		const float4 p = spos[gi], n = snrm[gi];
+		uint32_t hv = 0xffffu;
+		float lb = 0.0f;
+		int32_t pm = -1;
+		if (have_prev)
+		{
+			const int2 h = hint2[gi];
+			lb = __int_as_float(h.y);
+			if (use_hint)
+			{
+				hv = (uint32_t)h.x;
+				pm = match[gi];
+			}
+		}
+		// the hinted target's position: for a point whose hint is its standing correspondence it sits in the point's own
+		// record (coalesced), otherwise it is gathered
+		const uint32_t hj = hv & 0xffffu;
+		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (hj < tgt_n)
+			tj = (int32_t)hj == pm ? mq[2u * gi] : tpos[d.tgt_off + hj];
+		// fused rigid step (cregistration.hpp:1690-1695): double math, float store, in place
+		const double *T = ps.T;
+		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+		float4 out;
+		out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+		out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+		out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+		const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+		const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+		const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+		spos[gi] = make_float4(out.x, out.y, out.z, p.w);
+		snrm[gi] = make_float4(onx, ony, onz, n.w);
+		// How far this step moved the point (float positions before and after: both exact, the arithmetic below carries a few
+		// ulp).  Every bound on "the distance to any target other than the hinted one" shrinks by exactly that much.
+		const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
+		const float moved = sqrtf((mx * mx + my * my) + mz * mz);
+		const float lb_next = lb - moved * 1.00001f;
+		if (!called)
+		{
+			// the points still move: keep the bounds of a class that sits this iteration out valid (none exist at iteration 0)
+			nn_hint[2u * gi + 1u] = __float_as_int(have_prev ? lb_next : 0.0f);
+			continue;
+		}
+		out.w = __builtin_inff(); // sweep radius of a search: +inf = no hint
+		bool certified = false;
+		if (hj < tgt_n)
+		{
+			const float dx = out.x - tj.x, dy = out.y - tj.y, dz = out.z - tj.z;
+			const float d0 = (dx * dx + dy * dy) + dz * dz; // the very expression a search evaluates for this candidate
+			if (d0 >= 0.0f)
+			{
+				const float dh = sqrtf(d0);
+				certified = rp.cert != 0u && (dh * 1.00001f + moved * 1.00001f < lb * 0.99999f); // NaN anywhere fails the test
+				// a searched query sweeps a little farther than the hinted target: what lies beyond the sweep is what bounds the
+				// next iterations' certificates, and the steps shrink as the registration converges
+				out.w = dh + fminf(fmaxf(rp.cert_slack_rate * moved, rp.cert_slack_min), rp.cert_slack_max);
+				if (certified)
+				{
+					const bool matched = !((double)d0 > C.max_dist_sqr);
+					nn_idx[gi] = matched ? (int32_t)hj : -1;
+					nn_d2[gi] = d0;
+					hint2[gi] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
+					if (matched)
+					{
+						matched_cnt++;
+						if (C.dedup)
+							atomicMin(&W[hj], s);
+						else if (C.gate)
+							atomicMin(&winner[d.tgt_off + hj], C.key_hi | (unsigned long long)s);
+					}
+				}
+			}
+		}
+		if (!certified)
+		{
+			nn_idx[gi] = MULLS_NEEDS_SEARCH;
+			nn_d2[gi] = out.w;
+			const uint32_t k = atomicAdd(&ucount, 1u);
+			if (k < MULLS_CERT_SMALL)
+			{
+				uq[k] = out;
+				us[k] = s;
+			}
+		}
+	}
+	if (!called)
+		return true;
+	__syncthreads();
+	const uint32_t U = ucount;
+	if (U > MULLS_CERT_SMALL)
+		return false; // too many for the global-memory walk: the caller has the target cloud staged (lds_search_class), which counts the
+					  // matches certified here again from nn_idx; chunk-level jobs add theirs to the class counter there too
+	// the few leftovers against the grid where k_grid_build_sort left it (L2-resident): same sweeps, same keys
+	const GlobGrid L = {tsorted + d.tgt_off, reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off};
+	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+	for (uint32_t i = grp; i < U; i += BLK / MULLS_LDS_GROUP)
+	{
+		nnkey bk;
+		float sec, Rfin;
+		uint32_t trips;
+		search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
+		if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+			matched_cnt++;
+	}
+	class_tail<BLK>(rp, ps, C, d, job, q_end, matched_cnt, U, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+	return true;
+}
+
+// The LDS layout of the heavy pass: query block, cost-sort tables, the staged target class cloud (12-B position records, uint16
+// original index, uint16 cell table) and the duplicate table.  `cap`: points the staged cloud may hold (driver: lds_cap).
+struct LdsLayout
+{
+	float4 *qpos;	 // [MULLS_LDS_QCHUNK] queries of the chunk, w = sweep radius of a hinted query / +inf
+	uint32_t *HIST;	 // [32] cost histogram, [32] bucket bases, [64] live queries of the chunk, [65] queue ticket
+	uint16_t *ORDER; // [MULLS_LDS_QCHUNK] query slots, most expensive first
+	float *P;		 // [3 * cap] x, y, z records
+	uint16_t *IDX;	 // [cap]
+	uint16_t *CS;	 // [grid_maxcells + 1]
+	uint32_t *W;	 // [cap] lowest source index matched to each target (lds_dedup)
+};
+__device__ __forceinline__ LdsLayout lds_layout(unsigned char *lds_raw, uint32_t cap, uint32_t grid_maxcells)
+{
+	LdsLayout L;
+	L.qpos = reinterpret_cast<float4 *>(lds_raw);
+	L.HIST = reinterpret_cast<uint32_t *>(L.qpos + MULLS_LDS_QCHUNK);
+	L.ORDER = reinterpret_cast<uint16_t *>(L.HIST + 80);
+	L.P = reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(L.HIST) + MULLS_LDS_AUX);
+	L.IDX = reinterpret_cast<uint16_t *>(L.P + 3u * cap);
+	L.CS = L.IDX + cap;
+	L.W = reinterpret_cast<uint32_t *>(L.CS + ((grid_maxcells + 8u) & ~1u));
+	return L;
+}
+
+// Heavy pass of one class cloud's iteration, MULLS_LDS_BLOCK lanes: stage the cell-sorted target class cloud, search the points
+// cert_class left uncertified (nn_idx == MULLS_NEEDS_SEARCH) in equal chunks, then the class's tail (duplicate rule, rejection
+// chain, counters).  Every lane of the workgroup must call it; the caller puts a barrier between two calls.
+__device__ __forceinline__ void lds_search_class(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g,
+												  const LdsLayout &Y, unsigned char *lds_raw, const float4 *__restrict__ spos,
+												  const float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
+												  const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+												  unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
+												  float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+{
+	float4 *qpos = Y.qpos;
+	uint32_t *HIST = Y.HIST;
+	uint16_t *ORDER = Y.ORDER;
+	float *P = Y.P;
+	uint16_t *IDX = Y.IDX, *CS = Y.CS;
+	uint32_t *W = Y.W;
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
+	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, true);
+	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
+	// chunks of equal size (1200 points: 2 x 600, not 1024 + 176: the last chunk would leave most sub-groups idle)
+	const uint32_t q_cnt = q_end > job.start ? q_end - job.start : 0u, n_chunks = (q_cnt + MULLS_LDS_QCHUNK - 1u) / MULLS_LDS_QCHUNK;
+	const uint32_t q_step = n_chunks ? (q_cnt + n_chunks - 1u) / n_chunks : 1u;
+
+	// what k_cert left for the lanes of a chunk (one point per lane), loaded one chunk ahead — the first chunk's while the
+	// target cloud is staged
+	float4 pf_p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	float pf_w = 0.0f;
+	uint32_t pf_hv = 0u, pf_f = 0u;
+	int32_t pf_i = -1;
+	auto prefetch = [&](uint32_t chunk) {
+		const uint32_t s = chunk + threadIdx.x, gi = d.src_off + s;
+		pf_f = 0u;
+		pf_i = -1;
+		if (chunk < q_end && s < min(q_end, chunk + q_step))
+		{
+			pf_f = flag[gi];
+			pf_i = nn_idx[gi];
+			pf_p = spos[gi];
+			pf_w = nn_d2[gi];
+			pf_hv = (uint32_t)hint2[gi].x;
+		}
+	};
+	prefetch(job.start);
+
+	// stage the cell-sorted target cloud and its cell table (coalesced reads).  Loads are issued in batches of 8 / 2
+	// per lane before the first LDS write: one memory latency per batch instead of one per element.
+	{
+		const float4 *__restrict__ ts = tsorted + d.tgt_off;
+		for (uint32_t k0 = threadIdx.x; k0 < tgt_n; k0 += 8 * MULLS_LDS_BLOCK)
+		{
+			float4 t[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t k = k0 + u * MULLS_LDS_BLOCK;
+				if (k < tgt_n)
+					t[u] = ts[k];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+			{
+				const uint32_t k = k0 + u * MULLS_LDS_BLOCK;
+				if (k < tgt_n)
+				{
+					P[3u * k] = t[u].x;
+					P[3u * k + 1u] = t[u].y;
+					P[3u * k + 2u] = t[u].z;
+					IDX[k] = (uint16_t)__float_as_int(t[u].w);
+				}
+			}
+		}
+		// cell table: (ncell + 1) uint16 entries written by k_grid_build_sort, moved as uint4 words of 8 (the table slot of a
+		// cloud is uint4-aligned and padded)
+		const uint4 *__restrict__ cs4 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off);
+		const uint32_t nw = (g.ncell + 1u + 7u) >> 3;
+		for (uint32_t w0 = threadIdx.x; w0 < nw; w0 += 2 * MULLS_LDS_BLOCK)
+		{
+			// unconditional loads at clamped indices: a predicated `if (w < nw) v = ...` makes the compiler wait for every load on
+			// its own (serialised round trips, seen in the ISA listing)
+			const uint32_t w1 = w0 + MULLS_LDS_BLOCK;
+			const uint4 va = cs4[w0], vb = cs4[min(w1, nw - 1u)];
+			reinterpret_cast<uint4 *>(CS)[w0] = va;
+			if (w1 < nw)
+				reinterpret_cast<uint4 *>(CS)[w1] = vb;
+		}
+	}
+	if (C.dedup)
+		for (uint32_t t = threadIdx.x; t < tgt_n; t += MULLS_LDS_BLOCK)
+			W[t] = 0xffffffffu;
+	const LdsGrid L = {P, IDX, CS};
+	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+	uint32_t matched_cnt = 0, searched = 0;
+
+	if (threadIdx.x < 32u)
+		HIST[threadIdx.x] = 0u;
+	for (uint32_t chunk = job.start; chunk < q_end; chunk += q_step)
+	{
+		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
+		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
+		// phase 1: one source point per lane — uncertified points become the chunk's queries, certified matches enter the duplicate table
+		if (threadIdx.x < MULLS_LDS_QCHUNK && (pf_f & MULLS_F_ALIVE))
+		{
+			if (pf_i == MULLS_NEEDS_SEARCH)
+			{
+				qpos[threadIdx.x] = make_float4(pf_p.x, pf_p.y, pf_p.z, pf_w);
+				bucket = pf_w < __builtin_inff() ? 31u - ((pf_hv >> 16) & 31u) : 0u; // unhinted queries (the hint word is stale or absent) are the expensive ones
+				rank = atomicAdd(&HIST[bucket], 1u);
+			}
+			else if (pf_i >= 0)
+			{
+				matched_cnt++;
+				if (C.dedup)
+					atomicMin(&W[pf_i], chunk + threadIdx.x);
+			}
+		}
+		prefetch(chunk + q_step); // the next chunk's loads, consumed after this chunk's search
+		__syncthreads();
+		// queries of the chunk in order of the work they took in the previous iteration (candidate trips, kept next to the hint):
+		// the eight sub-groups of a wave run in lock step, so a wave is as slow as its most expensive query — neighbours in
+		// this order cost about the same.  Counting sort over 32 classes; dead and certified points are not in it.
+		if (threadIdx.x < 32u)
+		{
+			const uint32_t v = HIST[threadIdx.x];
+			uint32_t incl = v;
+			for (int off = 1; off < 32; off <<= 1)
+			{
+				const uint32_t o = __shfl_up(incl, off);
+				if ((int)threadIdx.x >= off)
+					incl += o;
+			}
+			HIST[32u + threadIdx.x] = incl - v;
+			HIST[threadIdx.x] = 0u; // ready for the next chunk
+			if (threadIdx.x == 31u)
+				HIST[64] = incl;
+		}
+		__syncthreads();
+		if (rank != 0xffffffffu)
+			ORDER[HIST[32u + bucket] + rank] = (uint16_t)threadIdx.x;
+		__syncthreads();
+		const uint32_t n_live = HIST[64];
+		searched += n_live;
+
+		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
+		for (uint32_t i = grp; i < n_live; i += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
+		{
+			const uint32_t k = ORDER[i];
+			nnkey bk;
+			float sec, Rfin;
+			uint32_t trips;
+			search_query(g, L, qpos[k], C.r, C.m, sub, bk, sec, Rfin, trips);
+			if (sub == 0 && commit_search(C, d, chunk + k, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+				matched_cnt++;
+		}
+	}
+	uint32_t *red = reinterpret_cast<uint32_t *>(lds_raw); // the query block is free once the tail's first barrier has passed
+	class_tail<MULLS_LDS_BLOCK>(rp, ps, C, d, job, q_end, matched_cnt, searched, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+}
+} // namespace

@@ -150,7 +150,7 @@ class Context:
         self._check(self.lib.mulls_set_profiling(self.h, int(on)), "mulls_set_profiling")
 
     def set_nn_mode(self, mode):
-        """0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS."""
+        """0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS (lock-step), 4 device-resident loop."""
         self._check(self.lib.mulls_set_nn_mode(self.h, int(mode)), "mulls_set_nn_mode")
 
     def profile(self):

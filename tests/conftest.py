@@ -28,9 +28,9 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(scope="session", params=[3, 2, 1], ids=["grid_lds", "grid_global", "brute"])
+@pytest.fixture(scope="session", params=[4, 3, 2, 1], ids=["resident", "grid_lds", "grid_global", "brute"])
 def ctx(request):
-    """HIP context on device 0, once per correspondence-search tier (uniform grid / LDS-tiled brute force).
+    """HIP context on device 0, once per tier (device-resident loop / lock-step uniform grids / LDS-tiled brute force).
     No fallback: if the library or the device is missing the gpu tests fail."""
     from mulls_amd import lib
 

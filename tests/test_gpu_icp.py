@@ -132,6 +132,26 @@ def test_resident_batch_is_repeatable(ctx, pairs_small):
     b.close()
 
 
+def test_resident_loop_equals_lock_step(ctx_auto, pairs_small):
+    """The device-resident loop (one launch, 6x6 solve on the device) and the lock-step path (host-stepped launches) run the same
+    arithmetic in the same order: every output bit-identical, trace included."""
+    from mulls_amd import lib
+
+    plist = [p for p, _ in pairs_small] * 4  # 12 pairs: more than the 8 below which auto mode keeps the global-memory tier
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.kitti_params(dis_thre_unit=2.4, faithful=0, weight_strategy="1011")):
+        out = {}
+        for mode in (4, 3, 2):
+            c = lib.Context(0)
+            c.set_nn_mode(mode)
+            r = c.icp_batch(plist, P, trace_cap=24)
+            out[mode] = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), tuple(x.ntgt0), tuple(x.T), tuple(x.info), x.sigma, x.confidence, x.trace_len,
+                          [(t.iter, tuple(t.ncorr), tuple(t.nsrc), tuple(t.thr), tuple(t.atpa), tuple(t.atpb), tuple(t.x)) for t in x.trace[:x.trace_len]])
+                         for x in r]
+            c.close()
+        assert out[4] == out[3] == out[2]
+        assert any(x[0] == 1 for x in out[4])
+
+
 def test_duplicate_table_epoch_wrap(ctx, pairs_small, monkeypatch):
     """The duplicate table's 32-bit epoch counter: runs on either side of the wrap give the results of a fresh batch
     (stale winner entries of older epochs must not beat the keys of the restarted count)."""
