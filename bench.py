@@ -326,7 +326,7 @@ def main(argv=None, engine_factory=None):
     # hipEvent pairs around every kernel launch on the library's stream stay ON in the timed region: roofline.achieved is the
     # dominant kernel's launch duration measured live in the very steps that are timed (value_profiling_off: the same steps without)
     engine.set_profiling(True)
-    prof_keys = ("ms_nn", "launches_nn", "nn_pair_evals", "nn_src_pts", "nn_tgt_unique", "nn_tgt_pts", "ms_setup", "ms_filter", "ms_accum", "ms_residual")
+    prof_keys = ("ms_nn", "launches_nn", "nn_pair_evals", "nn_src_pts", "nn_tgt_unique", "nn_tgt_pts", "ms_setup", "ms_filter", "ms_accum", "ms_residual", "nn_corr_pts", "icp_loop_ms")
     acc = {k: 0.0 for k in prof_keys}
     barrier()
     t0 = time.perf_counter()
@@ -335,7 +335,7 @@ def main(argv=None, engine_factory=None):
         gathered = step()
         pf = engine.profile()
         for k in prof_keys:
-            acc[k] += getattr(pf, k)
+            acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
     barrier()
     elapsed = time.perf_counter() - t0
     engine.set_profiling(False)
@@ -378,7 +378,8 @@ def main(argv=None, engine_factory=None):
         avg_ms = acc["ms_nn"] / launches
         # Algorithmic bytes per launch of the search: per live source point 64 B (pos+nrm read and written back by
         # the fused transform) + 8 B (index, d2 out); per target point of a searched class cloud 16 B (pos).
-        alg_bytes = (72.0 * acc["nn_src_pts"] + 16.0 * acc["nn_tgt_unique"]) / launches
+        resident = acc["icp_loop_ms"] > 0  # the device-resident loop ran (k_icp: search AND normal equations of every iteration in one launch)
+        alg_bytes = (72.0 * acc["nn_src_pts"] + 16.0 * acc["nn_tgt_unique"] + (72.0 * acc["nn_corr_pts"] if resident else 0.0)) / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         brute = acc["nn_pair_evals"] > 0
         valu = acc["nn_pair_evals"] * OPS_PER_EVAL / (acc["ms_nn"] * 1e-3) / 1e12 if brute and acc["ms_nn"] > 0 else 0.0
@@ -437,6 +438,8 @@ def main(argv=None, engine_factory=None):
             },
             "roofline": {
                 "kernel": "k_nn (fused source transform + exact LDS-tiled brute-force 1-NN search)" if brute else
+                          "k_icp (device-resident loop: every ICP iteration of every pair in one launch — rigid step, certificates / exact grid search, "
+                          "rejection chain, normal equations, 6x6 solve; algorithmic bytes = search + 72 B per correspondence and iteration)" if resident else
                           "correspondence search of one ICP iteration, LDS tier: k_cert (rigid step, certificates, rejection chain) + k_nn_lds (exact "
                           "fixed-radius 1-NN of the uncertified queries on a uniform grid staged in LDS)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -167,6 +167,11 @@ typedef struct mulls_profile
 	double ms_host_launch;	/* host time spent enqueueing the launch set, summed over iterations */
 	uint64_t nn_tgt_unique; /* target points of the searched class clouds (once per cloud), summed over launches */
 	uint64_t nn_corr_pts;	/* device-resident loop: correspondences that entered the estimation, summed over the iterations */
+	double icp_fused_ms[6];	/* device-resident loop: the fused class pass by stage (set-up, rigid step + certificates, leftover queries, rejection
+							   chain, normal-equation terms), summed over the pairs */
+	double icp_search_ms[24]; /* device-resident loop: the search phase by iteration (summed over the pairs) */
+	double icp_phase_ms[6]; /* device-resident loop: workgroup time summed over the pairs, by phase: search, counters + count test, normal
+							   equations, solve + step tests, residual pass, whole loop (one workgroup per CU: divide by the CUs for wall time) */
 } mulls_profile;
 
 typedef struct mulls_ctx mulls_ctx;		/* one per host thread / HIP stream */

@@ -188,6 +188,9 @@ class Profile(C.Structure):
         ("ms_host_launch", C.c_double),
         ("nn_tgt_unique", C.c_uint64),
         ("nn_corr_pts", C.c_uint64),
+        ("icp_fused_ms", C.c_double * 6),
+        ("icp_search_ms", C.c_double * 24),
+        ("icp_phase_ms", C.c_double * 6),
     ]
 
 

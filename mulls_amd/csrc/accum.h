@@ -30,11 +30,16 @@ __device__ __forceinline__ int metric_of(int cls) { return (cls == 1 || cls == 3
 } // namespace
 
 
+// get_weight_by_intensity of one correspondence (source intensity P.w, target intensity Q.w), cregistration.hpp:2710-2715
+__device__ __forceinline__ float point_wi(const float4 P, const float4 Q) { return w_intensity((float)(P.w + 0.0001), (float)(Q.w + 0.0001)); }
+
 // per-class constants of one iteration's accumulation
 struct AccumCtx
 {
 	int metric, iter_num;
 	bool residual_pass, dist_w, resid_w, inten_w, faithful;
+	bool li_diag; // point-to-line class, faithful mode, only the combined system is wanted: the mirror (cregistration.hpp:1924-1938) throws the
+				  // 15 off-diagonal terms of these classes away, so only the 6 diagonal terms and the right-hand side are summed
 	float class_w, window;
 };
 // w_ground = w_roof = max_(0.01, z_xy * (m2 + 2*m3 - m4) / (0.0001 + 2.0*m1)), the other classes 1   (cregistration.hpp:1886-1894);
@@ -61,6 +66,7 @@ __device__ __forceinline__ AccumCtx accum_ctx(const RunParams &rp, int cls, int 
 	A.resid_w = rp.w_resid && iter_num > rp.resid_from_iter;
 	A.inten_w = rp.w_inten;
 	A.faithful = rp.faithful;
+	A.li_diag = A.metric == 1 && rp.faithful && rp.pull_comb && !residual_pass;
 	A.class_w = class_w;
 	A.window = A.metric == 0 ? rp.win_pl : (A.metric == 1 ? rp.win_li : rp.win_pt);
 	return A;
@@ -68,25 +74,34 @@ __device__ __forceinline__ AccumCtx accum_ctx(const RunParams &rp, int cls, int 
 
 // One valid correspondence: source point P (current, transformed), matched target position Q and direction N (the record
 // filter_point wrote).  x: the solved step (residual pass only).  wdg: pcl::Correspondence's distance / weight union of this point.
-// The 27 terms are taken in two passes of MULLS_RED_TERMS = 14 and 13 (PASS = 0 / 1: terms PASS * 14 ...; the other terms'
-// arithmetic is dead code in that instantiation): 14 double accumulators per lane instead of 27 — the 1024-lane workgroups that
-// sum a class cloud have 128 registers per lane, and the reduction buffer holds 14 terms at a time anyway.
-#define MULLS_RED_TERMS 14
-#define ACC(k, v)                                    \
-	do                                               \
-	{                                                \
-		if ((k) / MULLS_RED_TERMS == PASS)           \
-			acc[(k) % MULLS_RED_TERMS] += (v);       \
+// Writes the terms T0 .. T0 + NT - 1 of the point's contribution into t[] (terms the metric does not have stay as they are: the
+// caller zeroes t[]); the arithmetic of the other terms is dead code in that instantiation.  wi: the point's intensity weight
+// (point_wi; evaluated by the caller, once per point and away from the terms' registers — a double-precision exp).  TS = float where every term is a
+// float expression of the reference (point-to-plane and point-to-point normal equations) — it converts to double exactly when
+// the sum is taken, as the reference's `double += float expression` does — and double elsewhere.
+// MODE 1 (point-to-line classes with AccumCtx::li_diag): t[0..11] = the six diagonal terms (0, 6, 11, 15, 18, 20) and the six
+// right-hand-side terms (21..26)
+__device__ __forceinline__ constexpr int li_slot(int k) { return k == 0 ? 0 : (k == 6 ? 1 : (k == 11 ? 2 : (k == 15 ? 3 : (k == 18 ? 4 : (k == 20 ? 5 : (k >= 21 ? k - 15 : -1)))))); }
+__device__ __forceinline__ constexpr int li_term(int slot) { return slot == 0 ? 0 : (slot == 1 ? 6 : (slot == 2 ? 11 : (slot == 3 ? 15 : (slot == 4 ? 18 : (slot == 5 ? 20 : slot + 15))))); }
+#define ACC(k, v)                                              \
+	do                                                         \
+	{                                                          \
+		if (MODE == 1)                                         \
+		{                                                      \
+			if (li_slot(k) >= 0)                               \
+				t[li_slot(k) >= 0 ? li_slot(k) : 0] = (TS)(v); \
+		}                                                      \
+		else if ((k) >= T0 && (k) < T0 + NT)                   \
+			t[(k)-T0] = (TS)(v);                               \
 	} while (0)
-template <int PASS>
-__device__ __forceinline__ void accum_point(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float &wdg,
-											 double acc[MULLS_RED_TERMS])
+template <typename TS, int T0, int NT, int MODE = 0>
+__device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS t[NT])
 {
 	const int metric = A.metric, iter_num = A.iter_num;
 	const bool residual_pass = A.residual_pass, dist_w = A.dist_w, resid_w = A.resid_w, inten_w = A.inten_w, faithful = A.faithful;
 	const float class_w = A.class_w, window = A.window;
-	const float px = P.x, py = P.y, pz = P.z, pi = P.w;
-	const float qx = Q.x, qy = Q.y, qz = Q.z, qi = Q.w;
+	const float px = P.x, py = P.y, pz = P.z;
+	const float qx = Q.x, qy = Q.y, qz = Q.z;
 
 	if (residual_pass)
 	{
@@ -166,7 +181,7 @@ __device__ __forceinline__ void accum_point(const AccumCtx &A, const double *x, 
 		if (resid_w)
 			w = w * w_residual(fabsf(dd), window);
 		if (inten_w)
-			w = w * w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			w = w * wi;
 		wdg = w;
 		ACC(0, w * ntx * ntx);
 		ACC(1, w * ntx * nty);
@@ -228,7 +243,7 @@ __device__ __forceinline__ void accum_point(const AccumCtx &A, const double *x, 
 		if (dist_w)
 			wx *= w_dist_adaptive(dist, iter_num);
 		if (inten_w)
-			wx *= w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			wx *= wi;
 		if (resid_w)
 			wx = wx * w_residual(ed, window);
 		wdg = wx;
@@ -261,7 +276,7 @@ __device__ __forceinline__ void accum_point(const AccumCtx &A, const double *x, 
 		if (resid_w)
 			wx = wx * w_residual(sqrtf(dx * dx + dy * dy + dz * dz), window);
 		if (inten_w)
-			wx = wx * w_intensity((float)(pi + 0.0001), (float)(qi + 0.0001));
+			wx = wx * wi;
 		wy = wx;
 		wz = wx;
 		if (!faithful)
@@ -294,14 +309,12 @@ __device__ __forceinline__ void accum_point(const AccumCtx &A, const double *x, 
 // ---------------------------------------------------------------------------------------------------------------
 // Summation order of a class cloud's row — the one order every path of the library uses (k_accum + k_finish in the lock-step
 // path, k_icp in the device-resident loop), so that they produce the same bits:
-//   the source slots are taken in chunks of MULLS_ACC_CHUNK = 8 x 1024; inside a chunk, virtual lane v (0..1023) adds the
-//   contributions of the slots v, v + 1024, ..., v + 7168 in that order (dead / invalid slots add nothing); for each of the 27
-//   terms the 1024 lane values are laid out in LDS, lane j of a wave adds the 16 values j, j + 64, ..., j + 960 in order, a
-//   butterfly adds the 64 partial sums ((xor 1, xor 2, mirror 8, mirror 16) inside the 16-lane rows, then (row0 + row1) +
-//   (row2 + row3)); chunk sums are added in chunk order.
+//   the source slots are taken in trips of MULLS_ACC_LANES = 1024; the term of slot trip * 1024 + v is value v of the trip (0 for
+//   a dead / invalid slot); for each of the 27 terms lane j of a wave adds the 16 values j, j + 64, ..., j + 960 in that order
+//   (in double), a butterfly adds the 64 partial sums ((xor 1, xor 2, mirror 8, mirror 16) inside the 16-lane rows, then
+//   (row0 + row1) + (row2 + row3)); the trip sums are added to 0.0 in trip order.
 #define MULLS_ACC_LANES 1024
-#define MULLS_ACC_CHUNK (8u * MULLS_ACC_LANES)
-#define MULLS_RED_BYTES ((size_t)MULLS_RED_TERMS * MULLS_ACC_LANES * sizeof(double))
+#define MULLS_RED_BYTES ((size_t)27 * MULLS_ACC_LANES * sizeof(float)) // the LDS term buffer: 27 float terms, or 13 double terms, of 1024 slots
 
 namespace
 {
@@ -322,79 +335,138 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 }
 } // namespace
 
-// one pass (MULLS_RED_TERMS terms) of the sums over the 1024 lanes of the workgroup (every lane calls; R: LDS, MULLS_RED_BYTES;
-// out: LDS, 27 doubles)
-template <int PASS>
-__device__ __forceinline__ void pass_reduce(const double acc[MULLS_RED_TERMS], double *R, double *out)
+// Terms T0 .. T0 + NT - 1 of one slot (lane) into the LDS term buffer R (NT x 1024 values of TS): zeros unless `valid`.
+template <typename TS, int T0, int NT, int MODE = 0>
+__device__ __forceinline__ void slot_terms(const AccumCtx &A, const double *x, bool valid, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS *R)
+{
+	static_assert(sizeof(TS) * NT * MULLS_ACC_LANES <= MULLS_RED_BYTES, "the term buffer holds NT terms of 1024 slots");
+	TS t[NT];
+#pragma unroll
+	for (int k = 0; k < NT; k++)
+		t[k] = (TS)0;
+	if (valid)
+		point_terms<TS, T0, NT, MODE>(A, x, P, Q, N, wi, wdg, t);
+#pragma unroll
+	for (int k = 0; k < NT; k++)
+		R[k * MULLS_ACC_LANES + threadIdx.x] = t[k];
+}
+// ... and their sums over the 1024 slots -> part[T0 ..] (LDS).  The caller puts a barrier between slot_terms and reduce_terms,
+// and another one before the buffer is written again.
+template <typename TS, int T0, int NT, int MODE = 0>
+__device__ __forceinline__ void reduce_terms(const TS *R, double *part)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int t0 = PASS * MULLS_RED_TERMS, nt = PASS ? MULLS_NTERM - MULLS_RED_TERMS : MULLS_RED_TERMS;
-	__syncthreads(); // the buffer is free
 #pragma unroll
-	for (int k = 0; k < nt; k++)
-		R[k * MULLS_ACC_LANES + threadIdx.x] = acc[k];
-	__syncthreads();
-	if (wave < nt)
+	for (int k0 = 0; k0 < NT; k0 += MULLS_ACC_LANES / 64)
 	{
-		const double *r = R + wave * MULLS_ACC_LANES;
-		double s = r[lane];
+		const int k = k0 + wave;
+		if (k < NT)
+		{
+			const TS *r = R + k * MULLS_ACC_LANES;
+			double sum = (double)r[lane];
 #pragma unroll
-		for (int k = 1; k < MULLS_ACC_LANES / 64; k++)
-			s += r[lane + 64 * k];
-		s = dpp_add_f64<0xB1>(s);  // quad_perm [1,0,3,2]
-		s = dpp_add_f64<0x4E>(s);  // quad_perm [2,3,0,1]
-		s = dpp_add_f64<0x141>(s); // row_half_mirror
-		s = dpp_add_f64<0x140>(s); // row_mirror: every lane of a row holds the row's sum
-		const double r0 = readlane_f64(s, 0), r1 = readlane_f64(s, 16), r2 = readlane_f64(s, 32), r3 = readlane_f64(s, 48);
-		if (lane == 0)
-			out[t0 + wave] = (r0 + r1) + (r2 + r3);
+			for (int i = 1; i < MULLS_ACC_LANES / 64; i++) // all 16 loads in flight, then the chain of adds (values beyond the cloud are +0.0)
+				sum += (double)r[lane + 64 * i];
+			sum = dpp_add_f64<0xB1>(sum);	// quad_perm [1,0,3,2]
+			sum = dpp_add_f64<0x4E>(sum);	// quad_perm [2,3,0,1]
+			sum = dpp_add_f64<0x141>(sum); // row_half_mirror
+			sum = dpp_add_f64<0x140>(sum); // row_mirror: every lane of a row holds the row's sum
+			const double r0 = readlane_f64(sum, 0), r1 = readlane_f64(sum, 16), r2 = readlane_f64(sum, 32), r3 = readlane_f64(sum, 48);
+			if (lane == 0)
+				part[MODE == 1 ? li_term(k) : T0 + k] = (r0 + r1) + (r2 + r3);
+		}
 	}
 }
 
-template <int PASS>
-__device__ __forceinline__ void chunk_pass(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t chunk, const float4 *__restrict__ spos,
-											const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, double *R, double *part)
+// The 27 sums of one trip of 1024 slots whose data the lanes hold in registers (valid, P, Q, N, wdg as slot_terms) -> part[0..26]
+// (LDS; every entry written).  R: LDS, MULLS_RED_BYTES.  Every lane calls; ends with a barrier.
+__device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x, bool valid, const float4 P, const float4 Q, const float4 N, float &wdg, void *R,
+											   double *part)
 {
-	double acc[MULLS_RED_TERMS];
-#pragma unroll
-	for (int k = 0; k < MULLS_RED_TERMS; k++)
-		acc[k] = 0.0;
-	const uint32_t end = min(d.src_n, chunk + MULLS_ACC_CHUNK);
-	if (PASS == 0 || !A.residual_pass) // the residual pass has two terms only
-		for (uint32_t s = chunk + threadIdx.x; s < end; s += MULLS_ACC_LANES)
-		{
-			const uint32_t g = d.src_off + s;
-			if ((flag[g] & (MULLS_F_ALIVE | MULLS_F_VALID)) != (MULLS_F_ALIVE | MULLS_F_VALID))
-				continue;
-			accum_point<PASS>(A, x, spos[g], mq[2u * g], mq[2u * g + 1u], wd[g], acc);
-		}
-	pass_reduce<PASS>(acc, R, part);
-}
-
-// the sum of one chunk of a class cloud's source slots [chunk, chunk + MULLS_ACC_CHUNK) -> part[0..26] (LDS); 1024 lanes
-__device__ __forceinline__ void chunk_sum(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t chunk, const float4 *__restrict__ spos,
-										   const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, double *R, double *part)
-{
-	chunk_pass<0>(A, x, d, chunk, spos, mq, flag, wd, R, part);
-	chunk_pass<1>(A, x, d, chunk, spos, mq, flag, wd, R, part);
+	const float wi = (valid && A.inten_w && !A.residual_pass) ? point_wi(P, Q) : 1.0f;
+	if (A.residual_pass)
+	{
+		__syncthreads(); // the buffer is free
+		slot_terms<double, 0, 2>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R)); // sum of w * r^2, number of observations
+		__syncthreads();
+		reduce_terms<double, 0, 2>(static_cast<const double *>(R), part);
+		if (threadIdx.x >= 2 && threadIdx.x < MULLS_NTERM)
+			part[threadIdx.x] = 0.0;
+	}
+	else if (A.li_diag)
+	{
+		// point-to-line, faithful: diagonal + right-hand side (the off-diagonal sums would be dropped by the mirror); the other entries are 0
+		__syncthreads();
+		slot_terms<double, 0, 12, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		if (threadIdx.x < 21 && li_slot((int)threadIdx.x) < 0)
+			part[threadIdx.x] = 0.0;
+		__syncthreads();
+		reduce_terms<double, 0, 12, 1>(static_cast<const double *>(R), part);
+	}
+	else if (A.metric == 1)
+	{
+		// point-to-line: the terms are products of doubles
+		__syncthreads();
+		slot_terms<double, 0, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 0, 13>(static_cast<const double *>(R), part);
+		__syncthreads();
+		slot_terms<double, 13, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 13, 13>(static_cast<const double *>(R), part);
+		__syncthreads();
+		slot_terms<double, 26, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 26, 1>(static_cast<const double *>(R), part);
+	}
+	else
+	{
+		__syncthreads();
+		slot_terms<float, 0, 27>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		__syncthreads();
+		reduce_terms<float, 0, 27>(static_cast<const float *>(R), part);
+	}
 	__syncthreads();
 }
 
-// one class cloud's whole row: chunk sums in chunk order -> row[0..26] (LDS)
+// the 27 sums of one trip of a class cloud's source slots [trip0, trip0 + 1024), read from memory (all loads issued before the
+// validity test: one memory round trip) -> part[0..26]
+__device__ __forceinline__ void trip_sum(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t trip0, const float4 *__restrict__ spos,
+										  const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, void *R, double *part)
+{
+	const uint32_t s = trip0 + threadIdx.x;
+	bool valid = false;
+	float4 P = make_float4(0.0f, 0.0f, 0.0f, 0.0f), Q = P, N = P;
+	float w = 0.0f, w0 = 0.0f;
+	uint32_t g = 0;
+	if (s < d.src_n)
+	{
+		g = d.src_off + s;
+		const uint32_t f = flag[g];
+		P = spos[g], Q = mq[2u * g], N = mq[2u * g + 1u];
+		w = w0 = wd[g];
+		valid = (f & (MULLS_F_ALIVE | MULLS_F_VALID)) == (MULLS_F_ALIVE | MULLS_F_VALID);
+	}
+	trip_sum_regs(A, x, valid, P, Q, N, w, R, part);
+	if (valid && __float_as_uint(w) != __float_as_uint(w0))
+		wd[g] = w; // pcl::Correspondence::weight
+}
+
+// one class cloud's whole row: trip sums in trip order -> row[0..26] (LDS)
 __device__ __forceinline__ void class_row(const AccumCtx &A, const double *x, const CloudDesc &d, const float4 *__restrict__ spos,
-										   const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, double *R, double *row)
+										   const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, void *R, double *row)
 {
 	__shared__ double part[MULLS_NTERM_PAD];
 	const uint32_t src_n = d.src_n;
-	uint32_t chunk = 0;
+	uint32_t trip0 = 0;
 	do
 	{
-		chunk_sum(A, x, d, chunk, spos, mq, flag, wd, R, part);
+		trip_sum(A, x, d, trip0, spos, mq, flag, wd, R, part);
 		if (threadIdx.x < MULLS_NTERM)
-			row[threadIdx.x] = chunk ? row[threadIdx.x] + part[threadIdx.x] : 0.0 + part[threadIdx.x]; // as k_finish adds the chunk partials to 0.0
+			row[threadIdx.x] = trip0 ? row[threadIdx.x] + part[threadIdx.x] : 0.0 + part[threadIdx.x]; // as k_finish adds the trip partials to 0.0
 		__syncthreads();
-		chunk += MULLS_ACC_CHUNK;
-	} while (chunk < src_n);
+		trip0 += MULLS_ACC_LANES;
+	} while (trip0 < src_n);
 }
 
 // Term t (0..26) of the one system the reference solves, from the class rows.  The 6x6 the reference inverts: pt2pl / pt2pt

@@ -15,6 +15,13 @@
 #else
 #define MULLS_HD
 #endif
+// Work arrays of the per-iteration algebra: plain locals on the host; on the device they live in LDS (the algebra is run by one
+// lane of a workgroup — k_icp — and dynamically indexed locals would otherwise sit in scratch memory, ~10x the latency).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MULLS_WORK static __shared__
+#else
+#define MULLS_WORK
+#endif
 
 namespace mulls
 {
@@ -86,7 +93,7 @@ MULLS_HD inline dd sqrt_dd(dd a) // a > 0
 // (+-) 1/k!, k = 0..33, with the sign the Taylor series of sin (odd k) and cos (even k) gives the term
 MULLS_HD inline dd inv_fact(int k)
 {
-	const dd t[34] = {
+	static const dd t[34] = {
 		{0x1.0000000000000p+0, 0x0.0p+0},
 		{0x1.0000000000000p+0, 0x0.0p+0},
 		{-0x1.0000000000000p-1, 0x0.0p+0},
@@ -126,7 +133,7 @@ MULLS_HD inline dd inv_fact(int k)
 // (-1)^k / (2k+1), k = 0..20 (atan)
 MULLS_HD inline dd inv_odd(int k)
 {
-	const dd t[21] = {
+	static const dd t[21] = {
 		{0x1.0000000000000p+0, 0x0.0p+0},
 		{-0x1.5555555555555p-2, -0x1.5555555555555p-56},
 		{0x1.999999999999ap-3, -0x1.999999999999ap-57},

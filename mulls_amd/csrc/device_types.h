@@ -23,6 +23,7 @@
 #define MULLS_LDS_AUX (320u + 2u * MULLS_LDS_QCHUNK) // LDS tier: cost histogram and query order of a chunk
 #define MULLS_CERT_BLOCK 512	   // k_cert: lanes per class cloud (one source point per lane and trip); several workgroups per CU
 #define MULLS_CERT_SMALL 64u   // k_cert searches up to this many uncertified points of a class cloud itself, against the grid in global memory
+#define MULLS_ICP_STATIC_LDS 9216 // LDS the device-resident loop keeps next to the dynamic block (pair state, class rows, ...; checked at its first launch)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
 #define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)
 #define MULLS_SEG 4096u		  // ... in segments of this many points
@@ -118,6 +119,9 @@ struct IcpOut
 	int32_t code, iters, singular, trace_len;
 	uint32_t ncorr[MULLS_NC], nsrc0[MULLS_NC], ntgt0[MULLS_NC], bbox[6];
 	uint32_t pad_;
+	unsigned long long t_fused[6]; // ... of the fused class pass by stage: set-up, stage 1, leftovers, stage 3, stage 4, (unused)
+	uint32_t t_search_it[24]; // ... and of the search phase of the first 24 iterations
+	unsigned long long t_phase[6]; // time of this pair in the loop's phases, 10-ns ticks (wall_clock64): search, counters + count test, normal equations, solve, residual pass, total
 };
 
 // One workgroup's worth of the correspondence search / filter / accumulation.

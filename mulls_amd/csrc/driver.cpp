@@ -26,6 +26,10 @@
 #include "launch.h"
 #include "ctx.h"
 
+// auto mode (nn_mode 0): batch sizes the device-resident loop takes (prepare_run)
+#define MULLS_RESIDENT_MIN_PAIRS 40
+#define MULLS_RESIDENT_MAX_PAIRS 1024
+
 using mulls::Mat4;
 using mulls::Mat6;
 
@@ -41,6 +45,7 @@ struct mulls_batch
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> cjobs_dev_h; // the same entries as uploaded: inside each sub-batch's slice the most expensive class clouds come first
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
+	std::vector<uint32_t> ajobs_h; // jobs that start a trip of 1024 source slots: k_accum's workgroups (indices into jobs_h, ascending)
 	// device-resident loop (k_icp): class-level jobs in pair order, each pair's range in them, the pairs most expensive first
 	std::vector<Job> rjobs_h;
 	std::vector<uint32_t> pair_rjob_h, order_h;
@@ -75,6 +80,8 @@ struct mulls_batch
 	Job *tjobs = nullptr;
 	Job *cjobs = nullptr;
 	Job *rjobs = nullptr;
+	uint32_t *ajobs = nullptr;
+	size_t cap_ajobs = 0;
 	uint32_t *pair_rjob = nullptr, *order = nullptr, *icp_queue = nullptr;
 	IcpOut *icp_outs = nullptr;
 	mulls_iter_trace *trace_dev = nullptr;
@@ -298,6 +305,10 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 					Job j = {(uint32_t)p, (uint32_t)c, s, 0};
 					B->tjobs_h.push_back(j);
 				}
+	B->ajobs_h.clear();
+	for (uint32_t j = 0; j < (uint32_t)B->jobs_h.size(); j++)
+		if (B->jobs_h[j].start % 1024u == 0u)
+			B->ajobs_h.push_back(j);
 	B->njobs = (uint32_t)B->jobs_h.size();
 	B->jobs_key = key;
 }
@@ -681,19 +692,22 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	{
 		rp.grid_maxcells = lds_cells_for(lds_cap);
 		// class-level jobs (one workgroup sees every query of a class cloud): keep the duplicate table in LDS if 4 B per target
-		// still leave a useful cell budget next to the staged cloud (6 KiB stay free for the static LDS of k_icp)
+		// still leave a useful cell budget next to the staged cloud (MULLS_ICP_STATIC_LDS bytes stay free for the static LDS of k_icp)
 		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
-		const long left = 160L * 1024L - 64L - 6144L - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
-		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 8192 && !std::getenv("MULLS_NO_LDS_DEDUP"); // k_nn_shoot uses the global table
+		const long left = 160L * 1024L - 64L - (long)MULLS_ICP_STATIC_LDS - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
+		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 4096 && !std::getenv("MULLS_NO_LDS_DEDUP"); // k_nn_shoot uses the global table
 		// Device-resident loop (k_icp: one workgroup carries a pair through all its iterations): the default whenever the LDS tier
 		// applies with its on-chip duplicate table, the loop is the plain mm_lls_icp one (resident_out) and no source class cloud is
 		// so large that one workgroup per pair would be the wrong shape (those pairs are spread over many workgroups by the
-		// lock-step path).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the resident loop (and gets the lock-step LDS
+		// lock-step path).  In auto mode it runs batches of MULLS_RESIDENT_MIN_PAIRS .. MAX_PAIRS pairs, where it is the faster of the two
+		// (measured, tools/gpu_modes.py: 60 k vs 45 k registrations/s at 128 pairs, 119 k vs 101 k at 512; the lock-step path wins from 2048
+		// pairs on — its light kernels run several workgroups per CU — and below ~40, where one pair spread over many workgroups beats one
+		// workgroup per pair).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the resident loop (and gets the lock-step LDS
 		// tier where the loop does not apply).
 		uint32_t max_src = 0;
 		for (const Job &j : B->rjobs_h)
 			max_src = std::max(max_src, j.count);
-		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && !std::getenv("MULLS_NO_RESIDENT")));
+		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && n >= MULLS_RESIDENT_MIN_PAIRS && n <= MULLS_RESIDENT_MAX_PAIRS && !std::getenv("MULLS_NO_RESIDENT")));
 		if ((class_level || resident) && dedup_fits)
 		{
 			rp.lds_dedup = 1;
@@ -737,6 +751,8 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	A(grow(ctx, &B->cjobs, &B->cap_jobs[3], B->cjobs_h.size(), &g2));
 	grew |= g2;
 	A(grow(ctx, &B->wl, &B->cap_wl, B->cjobs_h.size()));
+	A(grow(ctx, &B->ajobs, &B->cap_ajobs, B->ajobs_h.size(), &g2));
+	grew |= g2;
 	if (resident)
 	{
 		A(grow(ctx, &B->rjobs, &B->cap_icp[0], B->rjobs_h.size(), &g2));
@@ -781,6 +797,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size(), hipMemcpyHostToDevice, st));
+		HIPCHK(ctx, hipMemcpyAsync(B->ajobs, B->ajobs_h.data(), sizeof(uint32_t) * B->ajobs_h.size(), hipMemcpyHostToDevice, st));
 		if (resident)
 		{
 			HIPCHK(ctx, hipMemcpyAsync(B->rjobs, B->rjobs_h.data(), sizeof(Job) * B->rjobs_h.size(), hipMemcpyHostToDevice, st));
@@ -1200,6 +1217,12 @@ extern "C"
 				ctx->prof.nn_tgt_unique += o.tgt_pts;
 				ctx->prof.nn_tgt_pts += o.tgt_pts;
 				ctx->prof.nn_corr_pts += o.corr_pts;
+				for (int k = 0; k < 6; k++)
+					ctx->prof.icp_phase_ms[k] += (double)o.t_phase[k] * 1e-5; // 10-ns ticks -> ms (summed over the pairs)
+				for (int k = 0; k < 6; k++)
+					ctx->prof.icp_fused_ms[k] += (double)o.t_fused[k] * 1e-5;
+				for (int k = 0; k < 24 && k < o.iters; k++)
+					ctx->prof.icp_search_ms[k] += (double)o.t_search_it[k] * 1e-5;
 				max_it = std::max(max_it, o.iters);
 			}
 			ctx->prof.iterations = max_it;
@@ -1244,7 +1267,7 @@ extern "C"
 		struct Sub
 		{
 			int lo = 0, hi = 0;
-			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
+			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0, ajob_lo = 0, ajob_n = 0;
 			int iter = 0;
 			bool inflight = false;
 			uint32_t nn_launches = 0; // parity of the LDS tier's queue counters
@@ -1269,6 +1292,8 @@ extern "C"
 			S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
 			S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
 			S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
+			S.ajob_lo = (uint32_t)(std::lower_bound(B->ajobs_h.begin(), B->ajobs_h.end(), S.job_lo) - B->ajobs_h.begin());
+			S.ajob_n = (uint32_t)(std::lower_bound(B->ajobs_h.begin(), B->ajobs_h.end(), S.job_lo + S.job_n) - B->ajobs_h.begin()) - S.ajob_lo;
 			S.epoch_ctr = k == 0 ? &B->epoch : &B->epoch1;
 			S.word = B->epoch_h + 16 * k;
 			S.word_dev = B->epoch_dev + 16 * k;
@@ -1358,7 +1383,7 @@ extern "C"
 					ctx->prof.iterations++;
 			}
 			ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-			launch_accum(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, S.job_lo);
+			launch_accum(st, S.ajob_n, B->ajobs + S.ajob_lo, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 						  (uint32_t)S.lo);
 			ev.end();
@@ -1699,7 +1724,7 @@ extern "C"
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-			launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, 0);
+			launch_accum(st, (uint32_t)B->ajobs_h.size(), B->ajobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
@@ -2107,7 +2132,7 @@ extern "C"
 				// clear every flag to "alive, not a correspondence", then switch the requested ones on
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd, B->descs_h[cls].tgt_off, B->tpos, B->tnrm, B->mq);
-				launch_accum(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, 0);
+				launch_accum(st, (uint32_t)B->ajobs_h.size(), B->ajobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}
 			std::vector<float> wall(src->n);

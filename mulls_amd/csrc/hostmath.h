@@ -61,9 +61,10 @@ struct Mat6 // column-major 6x6
 MULLS_HD inline bool invert6(const Mat6 &in, Mat6 &out)
 {
 	const int n = 6;
-	double a[36];
-	int row_of[6];
-	std::memcpy(a, in.v, sizeof(a));
+	MULLS_WORK double a[36];
+	MULLS_WORK int row_of[6];
+	for (int k = 0; k < 36; k++)
+		a[k] = in.v[k];
 	for (int i = 0; i < n; i++)
 		row_of[i] = i;
 	bool regular = true;
@@ -101,9 +102,9 @@ MULLS_HD inline bool invert6(const Mat6 &in, Mat6 &out)
 				a[r + n * c] -= a[r + n * col] * top;
 		}
 	}
+	MULLS_WORK double y[6];
 	for (int c = 0; c < n; c++)
 	{
-		double y[6];
 		for (int r = 0; r < n; r++)
 			y[r] = (row_of[r] == c) ? 1.0 : 0.0;
 		for (int r = 1; r < n; r++)
@@ -316,7 +317,7 @@ MULLS_HD inline void quat_euler_jacobian(const double e[3], double J[3][3])
 // solve produced a non-finite step.
 MULLS_HD inline bool solve_step(const Mat6 &N, const double b[6], double x[6], Mat6 &cofactor)
 {
-	Mat6 Ninv;
+	MULLS_WORK Mat6 Ninv;
 	bool ok = invert6(N, Ninv);
 	for (int r = 0; r < 6; r++)
 	{
@@ -325,10 +326,10 @@ MULLS_HD inline bool solve_step(const Mat6 &N, const double b[6], double x[6], M
 			acc += Ninv.at(r, c) * b[c];
 		x[r] = acc;
 	}
-	double J[3][3];
+	MULLS_WORK double J[3][3];
 	quat_euler_jacobian(x + 3, J);
 	cofactor = Ninv;
-	double rr[3][3], tr[3][3], rt[3][3], tmp[3][3];
+	MULLS_WORK double rr[3][3], tr[3][3], rt[3][3], tmp[3][3];
 	for (int r = 0; r < 3; r++)
 		for (int c = 0; c < 3; c++)
 		{

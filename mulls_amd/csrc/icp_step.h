@@ -137,7 +137,7 @@ MULLS_HD inline void step_residual(PairIter &h, const IcpConst &K, double VTPV, 
 	const long obs = (long)observations;
 	h.sigma2 = VTPV / (double)((int)obs - 6);
 	h.code = (std::sqrt(h.sigma2) < (double)K.sigma_thre) ? 1 : -3;
-	Mat6 cinv;
+	MULLS_WORK Mat6 cinv;
 	invert6(h.cofactor, cinv);
 	for (int k = 0; k < 36; k++)
 		h.info.v[k] = (1.0 / h.sigma2) * cinv.v[k];

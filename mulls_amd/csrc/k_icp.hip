@@ -23,6 +23,550 @@
 #define MULLS_ICP_BLOCK MULLS_LDS_BLOCK
 static_assert(MULLS_ICP_BLOCK == MULLS_ACC_LANES, "one source point per lane and trip, in the reduction's lane order");
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused pass of one class cloud's iteration — the common case of the loop: the class is searched this iteration, its source
+// cloud has at most MULLS_FUSE_TRIPS x 1024 points and at most MULLS_CERT_SMALL of them fail their certificate.  A lane keeps its
+// points (one per trip) in registers from the rigid step to the normal-equation terms: one round trip to memory per point and
+// iteration instead of one per stage.  Stage by stage the arithmetic is that of cert_class, class_tail / filter_point and
+// trip_sum (the lock-step path's k_cert, k_filter, k_accum): same operations, same summation order, same bits.
+//   1  rigid step + certificate (cert_class)                 -> duplicate table, the few leftover queries
+//   2  leftovers against the grid in global memory, commit   -> nn_idx / nn_d2 / hint of those points
+//   3  duplicate rule + rejection chain (filter_point)       -> flags, match, records, class counters
+//   4  terms of the valid correspondences, trip by trip      -> row[0..26]   (skipped when `with_row` is false: the class weight of
+//                                                               this class waits for another class's count)
+// Returns 0: done, row summed; 1: done, row still to be summed from memory (class_row); 2: too many leftovers — the caller runs
+// lds_search_class (nn_idx / nn_d2 of every point are in memory as cert_class leaves them) and sums the row from memory.
+#define MULLS_FUSE_TRIPS 2
+__device__ __forceinline__ int fused_class(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc *pd, const GridDesc &g, const LdsLayout &Y,
+										   unsigned char *lds_raw, bool with_row, float4 *__restrict__ spos, float4 *__restrict__ snrm,
+										   const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx,
+										   float *__restrict__ nn_d2, unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm,
+										   int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint,
+										   float4 *__restrict__ mq, double *row, unsigned long long *tf)
+{
+#define FST(k)                                       \
+	do                                               \
+	{                                                \
+		if (threadIdx.x == 0)                        \
+		{                                            \
+			const unsigned long long now_ = wall_clock64(); \
+			tf[k] += now_ - tf[6];                   \
+			tf[6] = now_;                            \
+		}                                            \
+	} while (0)
+	if (threadIdx.x == 0)
+		tf[6] = wall_clock64();
+
+	__shared__ float4 uq[MULLS_CERT_SMALL];
+	__shared__ uint32_t us[MULLS_CERT_SMALL];
+	__shared__ uint32_t ucount, s_matched, s_alive, s_valid;
+	__shared__ double part[MULLS_NTERM_PAD];
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
+	uint32_t *W = Y.W;
+	const int cls = (int)job.cls;
+	CloudDesc &d = pd[cls];
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
+	const ClassCtx C = class_ctx(rp, ps, g, cls, d.alive_cur, true);
+	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
+	if (C.dedup)
+		for (uint32_t t = threadIdx.x; t < tgt_n; t += MULLS_ICP_BLOCK)
+			W[t] = 0xffffffffu;
+	if (threadIdx.x == 0)
+		ucount = s_matched = s_alive = s_valid = 0u;
+	__syncthreads();
+	FST(0);
+
+	// ---- stage 1 ------------------------------------------------------------------------------------------------------------------
+	uint32_t F[MULLS_FUSE_TRIPS];	 // flag byte as loaded; 0 for a slot beyond the cloud
+	float4 Pn[MULLS_FUSE_TRIPS];	 // the point after this iteration's rigid step (w = intensity)
+	float4 Nn[MULLS_FUSE_TRIPS];	 // ... its normal / direction
+	float4 Q0[MULLS_FUSE_TRIPS], Q1[MULLS_FUSE_TRIPS]; // the point's correspondence record (matched target position, direction)
+	int32_t M[MULLS_FUSE_TRIPS], PM[MULLS_FUSE_TRIPS];	// nearest target of this iteration (-1 none, MULLS_NEEDS_SEARCH), match[] as loaded
+	float D0[MULLS_FUSE_TRIPS];							// its squared distance (or the sweep radius of a leftover query)
+	uint32_t matched_cnt = 0;
+#pragma unroll
+	for (int k = 0; k < MULLS_FUSE_TRIPS; k++)
+	{
+		const uint32_t s = threadIdx.x + (uint32_t)k * MULLS_ICP_BLOCK;
+		F[k] = 0u;
+		M[k] = -1;
+		PM[k] = -1;
+		D0[k] = 0.0f;
+		Pn[k] = Nn[k] = Q0[k] = Q1[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (s >= src_n)
+			continue;
+		const uint32_t gi = d.src_off + s;
+		F[k] = flag[gi];
+		if (!(F[k] & MULLS_F_ALIVE))
+			continue;
+		const float4 p = spos[gi], n = snrm[gi];
+		const int2 h = hint2[gi];
+		PM[k] = match[gi];
+		Q0[k] = mq[2u * gi];
+		Q1[k] = mq[2u * gi + 1u];
+		const uint32_t hv = have_prev ? (uint32_t)h.x : 0xffffu;
+		const float lb = have_prev ? __int_as_float(h.y) : 0.0f;
+		const int32_t pm = have_prev ? PM[k] : -1;
+		// the hinted target's position: for a point whose hint is its standing correspondence it sits in the point's own record
+		const uint32_t hj = hv & 0xffffu;
+		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (hj < tgt_n)
+			tj = (int32_t)hj == pm ? Q0[k] : tpos[d.tgt_off + hj];
+		// rigid step (cregistration.hpp:1690-1695): double math, float store, in place
+		const double *T = ps.T;
+		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+		float4 out;
+		out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+		out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+		out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+		const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+		const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+		const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+		Pn[k] = make_float4(out.x, out.y, out.z, p.w);
+		Nn[k] = make_float4(onx, ony, onz, n.w);
+		spos[gi] = Pn[k];
+		snrm[gi] = Nn[k];
+		const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
+		const float moved = sqrtf((mx * mx + my * my) + mz * mz);
+		const float lb_next = lb - moved * 1.00001f;
+		out.w = __builtin_inff(); // sweep radius of a search: +inf = no hint
+		bool certified = false;
+		if (hj < tgt_n)
+		{
+			const float dx = out.x - tj.x, dy = out.y - tj.y, dz = out.z - tj.z;
+			const float d0 = (dx * dx + dy * dy) + dz * dz; // the very expression a search evaluates for this candidate
+			if (d0 >= 0.0f)
+			{
+				const float dh = sqrtf(d0);
+				certified = rp.cert != 0u && (dh * 1.00001f + moved * 1.00001f < lb * 0.99999f); // NaN anywhere fails the test
+				out.w = dh + fminf(fmaxf(rp.cert_slack_rate * moved, rp.cert_slack_min), rp.cert_slack_max);
+				if (certified)
+				{
+					const bool matched = !((double)d0 > C.max_dist_sqr);
+					M[k] = matched ? (int32_t)hj : -1;
+					D0[k] = d0;
+					hint2[gi] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
+					if (matched)
+					{
+						matched_cnt++;
+						if (C.dedup)
+							atomicMin(&W[hj], s);
+						else if (C.gate)
+							atomicMin(&winner[d.tgt_off + hj], C.key_hi | (unsigned long long)s);
+					}
+				}
+			}
+		}
+		if (!certified)
+		{
+			M[k] = MULLS_NEEDS_SEARCH;
+			D0[k] = out.w;
+			const uint32_t q = atomicAdd(&ucount, 1u);
+			if (q < MULLS_CERT_SMALL)
+			{
+				uq[q] = out;
+				us[q] = s;
+			}
+		}
+	}
+	__syncthreads();
+	FST(1);
+	const uint32_t U = ucount;
+	if (U > MULLS_CERT_SMALL)
+	{
+		// too many for the global-memory walk: leave nn_idx / nn_d2 as cert_class does and let the caller stage the target cloud
+#pragma unroll
+		for (int k = 0; k < MULLS_FUSE_TRIPS; k++)
+		{
+			const uint32_t s = threadIdx.x + (uint32_t)k * MULLS_ICP_BLOCK;
+			if (s < src_n && (F[k] & MULLS_F_ALIVE))
+			{
+				nn_idx[d.src_off + s] = M[k];
+				nn_d2[d.src_off + s] = D0[k];
+			}
+		}
+		__threadfence_block();
+		return 2;
+	}
+	// ---- stage 2: the few leftovers against the grid where k_grid_build_sort left it (L2-resident): same sweeps, same keys ------------
+	if (U)
+	{
+		const GlobGrid L = {tsorted + d.tgt_off, reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off};
+		const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+		for (uint32_t i = grp; i < U; i += MULLS_ICP_BLOCK / MULLS_LDS_GROUP)
+		{
+			nnkey bk;
+			float sec, Rfin;
+			uint32_t trips;
+			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
+			if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+				matched_cnt++;
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0 && matched_cnt)
+		atomicAdd(&s_matched, matched_cnt);
+	__threadfence_block(); // the leftovers' nn_idx / nn_d2, read back below by the lanes that own the points
+	__syncthreads();
+	FST(2);
+	// ---- stage 3: duplicate rule (cregistration.hpp:1762-1789) and rejection chain (:1794-1830) ---------------------------------------
+	const uint32_t total_matched = s_matched;
+	const float thr = ps.thr[cls];
+	const float max_sqr = thr * thr; // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	const bool any_match = total_matched > 0u, normal_check = cls != 5; // vertex correspondences skip the direction check (:1292)
+	bool V[MULLS_FUSE_TRIPS];
+	float WD[MULLS_FUSE_TRIPS];
+	uint32_t n_alive = 0, n_valid = 0;
+#pragma unroll
+	for (int k = 0; k < MULLS_FUSE_TRIPS; k++)
+	{
+		const uint32_t s = threadIdx.x + (uint32_t)k * MULLS_ICP_BLOCK;
+		V[k] = false;
+		WD[k] = 0.0f;
+		if (s >= src_n || !(F[k] & MULLS_F_ALIVE))
+			continue;
+		const uint32_t gi = d.src_off + s;
+		int32_t m = M[k];
+		float dist = D0[k];
+		if (m == MULLS_NEEDS_SEARCH)
+		{
+			m = nn_idx[gi];
+			dist = nn_d2[gi];
+		}
+		if (C.dedup && m >= 0 && W[m] != s)
+			m = -1; // first source (lowest index) matched to a target keeps it; the others become unmatched
+		bool alive = true, valid, fresh = false;
+		float4 n2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (any_match)
+		{
+			valid = m >= 0;
+			if (C.gate && m < 0)
+			{
+				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+				valid = false;
+			}
+			if (valid)
+			{
+				valid = !(dist > max_sqr);
+				if (valid)
+				{
+					WD[k] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+					if (PM[k] == m)
+						n2 = Q1[k];
+					else
+					{
+						match[gi] = m;
+						n2 = tnrm[d.tgt_off + m];
+						Q0[k] = tpos[d.tgt_off + m];
+						Q1[k] = n2;
+						mq[2u * gi] = Q0[k];
+						mq[2u * gi + 1u] = n2;
+					}
+					fresh = true;
+				}
+			}
+		}
+		else if (C.gate)
+		{
+			alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+			valid = false;
+		}
+		else
+			valid = (F[k] & MULLS_F_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
+		if (valid && normal_check)
+		{
+			if (!fresh)
+				n2 = Q1[k]; // the standing correspondence's target direction
+			const float4 n1 = Nn[k];
+			const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+			const float c = (float)fabs(dot);
+			if ((double)c < rp.cos_bearing)
+				valid = false;
+		}
+		const uint32_t nf = (alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u);
+		if (nf != F[k])
+			flag[gi] = (uint8_t)nf;
+		if (fresh)
+			wd[gi] = WD[k];
+		else if (valid)
+			WD[k] = wd[gi]; // stale correspondence: its distance / weight word as it stands
+		V[k] = alive && valid;
+		n_alive += alive ? 1u : 0u;
+		n_valid += valid ? 1u : 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		n_alive += __shfl_down(n_alive, off);
+		n_valid += __shfl_down(n_valid, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		if (n_alive)
+			atomicAdd(&s_alive, n_alive);
+		if (n_valid)
+			atomicAdd(&s_valid, n_valid);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		d.n_matched = total_matched;
+		d.alive_next = s_alive;
+		d.valid_next = s_valid;
+		d.n_search = U;
+	}
+	FST(3);
+	if (!with_row)
+		return 1;
+	// ---- stage 4: this class's row of the normal equations, from the registers ------------------------------------------------------
+	int cnt[MULLS_NC];
+	for (int c = 0; c < MULLS_NC; c++)
+		cnt[c] = c == cls ? (int)s_valid : (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
+	const AccumCtx A = accum_ctx(rp, cls, ps.iter, false, class_weight(rp, cls, false, cnt));
+#pragma unroll
+	for (int k = 0; k < MULLS_FUSE_TRIPS; k++)
+	{
+		if ((uint32_t)k * MULLS_ICP_BLOCK >= src_n && k > 0)
+			break;
+		float w = WD[k];
+		trip_sum_regs(A, ps.x, V[k], Pn[k], Q0[k], Q1[k], w, lds_raw, part);
+		if (V[k] && __float_as_uint(w) != __float_as_uint(WD[k]))
+			wd[d.src_off + threadIdx.x + (uint32_t)k * MULLS_ICP_BLOCK] = w; // pcl::Correspondence::weight
+		if (threadIdx.x < MULLS_NTERM)
+			row[threadIdx.x] = k ? row[threadIdx.x] + part[threadIdx.x] : 0.0 + part[threadIdx.x];
+		__syncthreads();
+	}
+	FST(4);
+	return 0;
+#undef FST
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// icp_step.h's step_solve, by the 64 lanes of ONE wave (the other waves of the workgroup wait at the next barrier): the same
+// operations on the same operands in the same order as the host functions it mirrors (hostmath.h: invert6, solve_step,
+// quat_euler_jacobian, euler_step_to_matrix, operator*), only spread over lanes wherever the host loops over independent
+// elements — so the result is bit-identical to the host's (tests/test_gpu_icp.py::test_resident_loop_equals_lock_step compares
+// every iteration's system, step and transform with the lock-step path's).  All data goes through LDS; a wave's LDS traffic is
+// executed in order, so a wavefront-scope fence between dependent steps is all the synchronisation needed.
+struct SolveWs
+{
+	double N[36], a[36], inv[36], b[6], sc[6], J[9], tmp[9], newg[16];
+	float scf[6];
+	int row_of[6], p, regular;
+};
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+__device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpConst &K, const double *comb, int i, SolveWs &w)
+{
+	const int l = (int)threadIdx.x; // 0..63
+	// normal_from_row
+	if (l < 36)
+	{
+		const int r = l % 6, c = l / 6;
+		const double val = comb[mulls::packed_index(r < c ? r : c, r < c ? c : r)];
+		w.N[l] = val;
+		w.a[l] = val;
+	}
+	if (l < 6)
+	{
+		w.b[l] = comb[21 + l];
+		w.row_of[l] = l;
+	}
+	if (l == 0)
+		w.regular = 1;
+	WSYNC();
+	// invert6: row-pivoted LU ...
+	for (int col = 0; col < 6; col++)
+	{
+		if (l == 0)
+		{
+			int p = col;
+			double big = fabs(w.a[col + 6 * col]);
+			for (int r = col + 1; r < 6; r++)
+				if (fabs(w.a[r + 6 * col]) > big)
+				{
+					big = fabs(w.a[r + 6 * col]);
+					p = r;
+				}
+			if (big == 0.0)
+				w.regular = 0;
+			w.p = p;
+		}
+		WSYNC();
+		const int p = w.p;
+		if (p != col)
+		{
+			if (l < 6)
+			{
+				const double t = w.a[col + 6 * l];
+				w.a[col + 6 * l] = w.a[p + 6 * l];
+				w.a[p + 6 * l] = t;
+			}
+			if (l == 6)
+			{
+				const int t = w.row_of[col];
+				w.row_of[col] = w.row_of[p];
+				w.row_of[p] = t;
+			}
+		}
+		WSYNC();
+		const double piv = w.a[col + 6 * col];
+		if (l < 6 && l > col)
+			w.a[l + 6 * col] /= piv;
+		WSYNC();
+		if (l < 36)
+		{
+			const int r = l % 6, c = l / 6;
+			if (r > col && c > col)
+				w.a[r + 6 * c] -= w.a[r + 6 * col] * w.a[col + 6 * c];
+		}
+		WSYNC();
+	}
+	// ... solved against the identity column by column (one lane per column, the factors in registers)
+	if (l < 6)
+	{
+		double A[36], y[6];
+#pragma unroll
+		for (int k = 0; k < 36; k++)
+			A[k] = w.a[k];
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+			y[r] = (w.row_of[r] == l) ? 1.0 : 0.0;
+#pragma unroll
+		for (int r = 1; r < 6; r++)
+#pragma unroll
+			for (int k = 0; k < r; k++)
+				y[r] -= A[r + 6 * k] * y[k];
+#pragma unroll
+		for (int r = 5; r >= 0; r--)
+		{
+#pragma unroll
+			for (int k = r + 1; k < 6; k++)
+				y[r] -= A[r + 6 * k] * y[k];
+			y[r] /= A[r + 6 * r];
+		}
+#pragma unroll
+		for (int r = 0; r < 6; r++)
+			w.inv[r + 6 * l] = y[r];
+	}
+	WSYNC();
+	// solve_step: x = N^-1 b
+	if (l < 6)
+	{
+		double acc = 0.0;
+		for (int c = 0; c < 6; c++)
+			acc += w.inv[l + 6 * c] * w.b[c];
+		h.x[l] = acc;
+	}
+	WSYNC();
+	// quat_euler_jacobian's half-angle sines / cosines (float locals in the reference, :2797-2804) and euler_step_to_matrix's
+	if (l < 12)
+	{
+		const int q = l < 6 ? l : l - 6;
+		const double v = mulls::det::trig(l < 6 ? 0.5 * h.x[3 + (q >> 1)] : h.x[3 + (q >> 1)], q & 1);
+		if (l < 6)
+			w.scf[q] = (float)v; // sr cr sp cp sy cy
+		else
+			w.sc[q] = v; // sa ca sb cb sg cg
+	}
+	WSYNC();
+	if (l == 0)
+	{
+		const float sr = w.scf[0], cr = w.scf[1], sp = w.scf[2], cp = w.scf[3], sy = w.scf[4], cy = w.scf[5];
+		w.J[0] = 0.5 * (cr * cp * cy + sr * sp * sy);
+		w.J[1] = 0.5 * (-sr * sp * cy - cr * cp * sy);
+		w.J[2] = 0.5 * (-sr * cp * sy - cr * sp * cy);
+		w.J[3] = 0.5 * (-sr * sp * cy + cr * cp * sy);
+		w.J[4] = 0.5 * (cr * cp * cy - sr * sp * sy);
+		w.J[5] = 0.5 * (-cr * sp * sy + sr * cp * cy);
+		w.J[6] = 0.5 * (-sr * cp * sy - cr * sp * cy);
+		w.J[7] = 0.5 * (-cr * sp * sy - sr * cp * cy);
+		w.J[8] = 0.5 * (cr * cp * cy + sr * sp * sy);
+	}
+	if (l == 1)
+	{
+		const double sa = w.sc[0], ca = w.sc[1], sb = w.sc[2], cb = w.sc[3], sg = w.sc[4], cg = w.sc[5];
+		mulls::Mat4 &m = h.temp;
+		for (int k = 0; k < 16; k++)
+			m.v[k] = 0.0;
+		m.at(0, 0) = cg * cb;
+		m.at(0, 1) = -sg * ca + cg * sb * sa;
+		m.at(0, 2) = sg * sa + cg * sb * ca;
+		m.at(1, 0) = sg * cb;
+		m.at(1, 1) = cg * ca + sg * sb * sa;
+		m.at(1, 2) = -cg * sa + sg * sb * ca;
+		m.at(2, 0) = -sb;
+		m.at(2, 1) = cb * sa;
+		m.at(2, 2) = cb * ca;
+		m.at(0, 3) = h.x[0];
+		m.at(1, 3) = h.x[1];
+		m.at(2, 3) = h.x[2];
+		m.at(3, 3) = 1.0;
+	}
+	WSYNC();
+	// cofactor = N^-1 with its rotational blocks propagated to quaternion space
+	if (l < 36)
+		h.cofactor.v[l] = w.inv[l];
+	if (l < 9)
+	{
+		const int r = l / 3, c = l % 3;
+		w.tmp[l] = w.J[r * 3 + 0] * w.inv[(3 + 0) + 6 * (3 + c)] + w.J[r * 3 + 1] * w.inv[(3 + 1) + 6 * (3 + c)] + w.J[r * 3 + 2] * w.inv[(3 + 2) + 6 * (3 + c)];
+	}
+	WSYNC();
+	if (l < 27)
+	{
+		const int blk = l / 9, r = (l % 9) / 3, c = l % 3;
+		if (blk == 0)
+			h.cofactor.v[(3 + r) + 6 * (3 + c)] = w.tmp[r * 3 + 0] * w.J[c * 3 + 0] + w.tmp[r * 3 + 1] * w.J[c * 3 + 1] + w.tmp[r * 3 + 2] * w.J[c * 3 + 2];
+		else if (blk == 1)
+			h.cofactor.v[r + 6 * (3 + c)] = w.inv[r + 6 * (3 + 0)] * w.J[c * 3 + 0] + w.inv[r + 6 * (3 + 1)] * w.J[c * 3 + 1] + w.inv[r + 6 * (3 + 2)] * w.J[c * 3 + 2];
+		else
+			h.cofactor.v[(3 + r) + 6 * c] = w.J[r * 3 + 0] * w.inv[(3 + 0) + 6 * c] + w.J[r * 3 + 1] * w.inv[(3 + 1) + 6 * c] + w.J[r * 3 + 2] * w.inv[(3 + 2) + 6 * c];
+	}
+	WSYNC();
+	// step-size and convergence tests (icp_step.h: step_solve)
+	if (l == 0)
+	{
+		bool ok = w.regular != 0;
+		for (int k = 0; k < 6; k++)
+			ok = ok && std::isfinite(h.x[k]);
+		if (!ok)
+			h.singular = 1;
+		const double tsn = std::sqrt(h.x[0] * h.x[0] + h.x[1] * h.x[1] + h.x[2] * h.x[2]);
+		const double rsa = mulls::rotation_angle(h.temp);
+		w.p = 0; // 1: advance the guess
+		if (tsn > K.max_bearable_translation || std::fabs(rsa) > K.max_bearable_rotation)
+		{
+			h.code = -1;
+			h.temp = mulls::Mat4::identity();
+			h.active = 0;
+			h.done = 1;
+		}
+		else if (i == K.max_iter_num - 1 || (i > 2 && tsn < K.converge_translation && std::fabs(rsa) < K.converge_rotation))
+		{
+			h.active = 0;
+			h.want_residual = 1;
+		}
+		else
+			w.p = 1;
+	}
+	WSYNC();
+	if (w.p == 1) // initial_guess = TempTran * initial_guess (:1400)
+	{
+		if (l < 16)
+		{
+			const int row = l % 4, col = l / 4;
+			double acc = 0.0;
+			for (int k = 0; k < 4; k++)
+				acc += h.temp.at(row, k) * h.guess.at(k, col);
+			w.newg[l] = acc;
+		}
+		WSYNC();
+		if (l < 16)
+			h.guess.v[l] = w.newg[l];
+	}
+	WSYNC();
+}
+
 __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__ rjobs, const uint32_t *__restrict__ pair_rjob, const uint32_t *__restrict__ order,
 														   uint32_t npairs, uint32_t pair_base, uint32_t *__restrict__ queue, CloudDesc *__restrict__ descs,
 														   const PairSetup *__restrict__ setup, RunParams rp, mulls::IcpConst K, float4 *__restrict__ spos,
@@ -35,13 +579,30 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const LdsLayout Y = lds_layout(lds_raw, cap, rp.grid_maxcells);
-	double *R = reinterpret_cast<double *>(lds_raw); // the reduction's transposition buffer: the staged cloud is dead while rows are summed
+	const bool fuse = rp.debug_stop != 7u; // diagnostics (MULLS_DEBUG_STOP=7): every class through the unfused passes
+	void *R = lds_raw; // the term buffer of the row sums: the staged cloud is dead while rows are summed
 	__shared__ PairState ps;
 	__shared__ mulls::PairIter h;
 	__shared__ double rows[MULLS_NC][MULLS_NTERM_PAD], comb[MULLS_NTERM_PAD];
 	__shared__ uint32_t s_ticket, s_nvalid[MULLS_NC], s_nalive[MULLS_NC];
+	__shared__ CloudDesc s_desc[MULLS_NC]; // the pair's class descriptors and grids live in LDS while the pair iterates: the per-class
+	__shared__ GridDesc s_grid[MULLS_NC];
+	__shared__ Job s_jobs[MULLS_NC];
+	__shared__ unsigned long long s_tf[8];
+	__shared__ SolveWs s_ws;  // counters are read and rolled over many times per iteration (a scalar load from memory each time otherwise)
 	__shared__ int s_go;
-	__shared__ unsigned long long s_src_pts, s_tgt_pts, s_corr_pts;
+	__shared__ unsigned long long s_src_pts, s_tgt_pts, s_corr_pts, s_t[6], s_mark;
+// phase clock: lane 0 charges the time since the last mark to phase k
+#define PHASE(k)                                    \
+	do                                              \
+	{                                               \
+		if (threadIdx.x == 0)                       \
+		{                                           \
+			const unsigned long long now_ = wall_clock64(); \
+			s_t[k] += now_ - s_mark;                \
+			s_mark = now_;                          \
+		}                                           \
+	} while (0)
 
 	for (;;)
 	{
@@ -52,8 +613,16 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 		if (s_ticket >= npairs)
 			return;
 		const uint32_t pair = pair_base + order[s_ticket];
-		CloudDesc *pd = descs + (size_t)pair * MULLS_NC;
+		CloudDesc *pd = s_desc;
 		const uint32_t j0 = pair_rjob[pair], j1 = pair_rjob[pair + 1u];
+		if (threadIdx.x < MULLS_NC)
+		{
+			s_desc[threadIdx.x] = descs[(size_t)pair * MULLS_NC + threadIdx.x];
+			s_grid[threadIdx.x] = grids[(size_t)pair * MULLS_NC + threadIdx.x];
+			if (j0 + threadIdx.x < j1)
+				s_jobs[threadIdx.x] = rjobs[j0 + threadIdx.x];
+		}
+		__syncthreads();
 		IcpOut &O = outs[pair];
 		if (threadIdx.x == 0)
 		{
@@ -84,6 +653,10 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 				O.bbox[k] = bbox[(size_t)pair * 6 + k];
 			s_src_pts = s_tgt_pts = s_corr_pts = 0ull;
 			O.trace_len = 0;
+			for (int k = 0; k < 6; k++)
+				s_t[k] = s_tf[k] = 0ull;
+			s_mark = wall_clock64();
+			s_t[5] = s_mark;
 		}
 		__syncthreads();
 
@@ -97,21 +670,50 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 						s_src_pts += pd[c].alive_cur;
 						s_tgt_pts += pd[c].tgt_n;
 					}
+			if (threadIdx.x < MULLS_NC * MULLS_NTERM_PAD)
+				rows[threadIdx.x / MULLS_NTERM_PAD][threadIdx.x % MULLS_NTERM_PAD] = 0.0;
+			// Class order: the classes whose weight is 1 first, then roof and ground (their weight needs the other classes' counts,
+			// cregistration.hpp:1886-1894).  `pend`: classes whose row is summed from memory after the count test (uniform).
+			uint32_t pend = 0u;
+			bool has_ground = false;
 			for (uint32_t j = j0; j < j1; j++)
-			{
-				const Job job = rjobs[j];
-				CloudDesc &d = pd[job.cls];
-				const GridDesc g = grids[(size_t)pair * MULLS_NC + job.cls];
-				__syncthreads(); // the previous class cloud's LDS contents (duplicate table, staged cloud) have been consumed
-				if (!cert_class<MULLS_ICP_BLOCK>(rp, ps, job, d, g, Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint,
-												 mq))
+				has_ground |= s_jobs[j - j0].cls == 0u;
+			for (int pass = 0; pass < 3; pass++)
+				for (uint32_t j = j0; j < j1; j++)
 				{
-					__syncthreads();
-					lds_search_class(rp, ps, job, d, g, Y, lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+					const Job job = s_jobs[j - j0];
+					const int cls = (int)job.cls;
+					if (pass == 0 ? (cls == 0 || cls == 4) : (pass == 1 ? cls != 4 : cls != 0))
+						continue;
+					CloudDesc &d = pd[cls];
+					const GridDesc g = s_grid[cls];
+					__syncthreads(); // the previous class cloud's LDS contents (duplicate table, staged cloud, term buffer) have been consumed
+					if (fuse && class_called(rp, d, cls) && d.src_n <= MULLS_FUSE_TRIPS * MULLS_ICP_BLOCK)
+					{
+						int r = fused_class(rp, ps, job, pd, g, Y, lds_raw, !(cls == 4 && has_ground), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
+											match, wd, tpos, nn_hint, mq, rows[cls], s_tf);
+						if (r == 2)
+						{
+							__syncthreads();
+							lds_search_class(rp, ps, job, d, g, Y, lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+						}
+						if (r)
+							pend |= 1u << cls;
+						continue;
+					}
+					if (!cert_class<MULLS_ICP_BLOCK>(rp, ps, job, d, g, Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+													 nn_hint, mq))
+					{
+						__syncthreads();
+						lds_search_class(rp, ps, job, d, g, Y, lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+					}
+					pend |= 1u << cls;
 				}
-			}
 			__threadfence_block();
 			__syncthreads();
+			if (threadIdx.x == 0 && i < 24)
+				O.t_search_it[i] = (uint32_t)(wall_clock64() - s_mark);
+			PHASE(0);
 			// --- counters rolled over (k_finish), count test, threshold update ------------------------------------------------------------
 			if (threadIdx.x < MULLS_NC)
 			{
@@ -160,37 +762,36 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 			__syncthreads();
 			if (!s_go)
 				break; // process code -2
+			PHASE(1);
 			// --- normal equations (cregistration.hpp:1869-1938) -------------------------------------------------------------------------------
 			int cnt[MULLS_NC];
 			for (int c = 0; c < MULLS_NC; c++)
 				cnt[c] = (int)s_nvalid[c];
-			if (threadIdx.x < MULLS_NC * MULLS_NTERM_PAD)
-				rows[threadIdx.x / MULLS_NTERM_PAD][threadIdx.x % MULLS_NTERM_PAD] = 0.0;
-			__syncthreads();
 			for (uint32_t j = j0; j < j1; j++)
 			{
-				const int cls = (int)rjobs[j].cls;
+				const int cls = (int)s_jobs[j - j0].cls;
+				if (!(pend >> cls & 1u))
+					continue; // the fused pass summed this row from its registers
 				const AccumCtx A = accum_ctx(rp, cls, i, false, class_weight(rp, cls, false, cnt));
 				class_row(A, ps.x, pd[cls], spos, mq, flag, wd, R, rows[cls]);
 			}
 			if (threadIdx.x < MULLS_NTERM)
 				combine_rows(rp, false, rows, comb, (int)threadIdx.x);
 			__syncthreads();
+			PHASE(2);
 			// --- solve, step and convergence tests (:1924-1964, :1333-1357) --------------------------------------------------------------------
+			if (threadIdx.x < 64)
+				solve_wave(h, K, comb, i, s_ws);
 			if (threadIdx.x == 0)
 			{
-				mulls::Mat6 N;
-				double b[6];
-				mulls::normal_from_row(comb, N, b);
-				mulls::step_solve(h, K, N, b, i);
 				if (trace && (uint32_t)O.trace_len < trace_cap)
 				{
 					mulls_iter_trace *tr = &trace[(size_t)pair * trace_cap + (uint32_t)O.trace_len];
 					for (int k = 0; k < 36; k++)
-						tr->atpa[k] = N.v[k];
+						tr->atpa[k] = s_ws.N[k];
 					for (int k = 0; k < 6; k++)
 					{
-						tr->atpb[k] = b[k];
+						tr->atpb[k] = s_ws.b[k];
 						tr->x[k] = h.x[k];
 					}
 					O.trace_len++;
@@ -209,6 +810,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 				}
 			}
 			__syncthreads();
+			PHASE(3);
 			if (s_go == 1)
 				continue;
 			if (s_go == 2)
@@ -219,7 +821,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 				__syncthreads();
 				for (uint32_t j = j0; j < j1; j++)
 				{
-					const int cls = (int)rjobs[j].cls;
+					const int cls = (int)s_jobs[j - j0].cls;
 					const AccumCtx A = accum_ctx(rp, cls, i, true, class_weight(rp, cls, true, cnt));
 					class_row(A, ps.x, pd[cls], spos, mq, flag, wd, R, rows[cls]);
 				}
@@ -229,6 +831,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 				if (threadIdx.x == 0)
 					mulls::step_residual(h, K, comb[0], comb[1]);
 				__syncthreads();
+				PHASE(4);
 			}
 			break;
 		}
@@ -247,6 +850,11 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 			O.src_pts = s_src_pts;
 			O.tgt_pts = s_tgt_pts;
 			O.corr_pts = s_corr_pts;
+			for (int k = 0; k < 5; k++)
+				O.t_phase[k] = s_t[k];
+			O.t_phase[5] = wall_clock64() - s_t[5];
+			for (int k = 0; k < 6; k++)
+				O.t_fused[k] = s_tf[k];
 		}
 	}
 }
@@ -264,7 +872,10 @@ int launch_icp(hipStream_t st, uint32_t npairs, uint32_t pair_base, const Job *r
 	static uint32_t n_cu = 256;
 	if (!attr_set)
 	{
-		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 6144) != hipSuccess)
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - MULLS_ICP_STATIC_LDS) != hipSuccess)
+			return -1;
+		hipFuncAttributes fa;
+		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_icp)) != hipSuccess || fa.sharedSizeBytes > (size_t)MULLS_ICP_STATIC_LDS)
 			return -1;
 		int dev = 0, cus = 0;
 		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -274,7 +885,7 @@ int launch_icp(hipStream_t st, uint32_t npairs, uint32_t pair_base, const Job *r
 	if (!npairs)
 		return 0;
 	size_t lds = nn_lds_bytes(cap, maxcells, true);
-	const size_t red = (size_t)MULLS_RED_TERMS * MULLS_ICP_BLOCK * sizeof(double);
+	const size_t red = MULLS_RED_BYTES;
 	if (lds < red)
 		lds = red;
 	hipLaunchKernelGGL(k_icp, dim3(npairs < n_cu ? npairs : n_cu), dim3(MULLS_ICP_BLOCK), lds, st, rjobs, pair_rjob, order, npairs, pair_base, queue, descs, setup, rp, K,

@@ -4,20 +4,18 @@
 #include "accum.h"
 
 // Normal-equation accumulation (active pairs) or posterior residual (pairs flagged want_residual), lock-step path.  The job
-// table is the one of the search (512 source slots per job); the job that starts a chunk of MULLS_ACC_CHUNK slots sums the whole
-// chunk in the library's summation order (accum.h) into its slot of `partial`, the other workgroups leave at once; k_finish
-// adds the chunk partials in order (run-to-run deterministic, unlike atomicAdd(double), and the same bits as k_icp).
-__global__ __launch_bounds__(MULLS_ACC_LANES) void k_accum(const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+// table is the one of the search (512 source slots per job); one workgroup per job that starts a trip of MULLS_ACC_LANES slots
+// (`leaders`) sums the whole trip in the library's summation order (accum.h) into that job's slot of `partial`; k_finish
+// adds the trip partials in order (run-to-run deterministic, unlike atomicAdd(double), and the same bits as k_icp).
+__global__ __launch_bounds__(MULLS_ACC_LANES) void k_accum(const uint32_t *__restrict__ leaders, const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
 															const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd,
-															double *__restrict__ partial, uint32_t job_base)
+															double *__restrict__ partial)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double part[MULLS_NTERM_PAD];
-	const uint32_t job_idx = xcd_job(blockIdx.x, gridDim.x);
+	const uint32_t job_idx = leaders[xcd_job(blockIdx.x, gridDim.x)]; // a job that starts a trip (index into the batch-wide job table)
 	const Job job = jobs[job_idx];
-	if (job.start % MULLS_ACC_CHUNK)
-		return;
 	const PairState &ps = states[job.pair];
 	if (!ps.active && !ps.want_residual)
 		return;
@@ -27,9 +25,9 @@ __global__ __launch_bounds__(MULLS_ACC_LANES) void k_accum(const Job *__restrict
 	for (int c = 0; c < MULLS_NC; c++)
 		cnt[c] = (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
 	const AccumCtx A = accum_ctx(rp, job.cls, ps.iter, residual_pass, class_weight(rp, job.cls, residual_pass, cnt));
-	chunk_sum(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, reinterpret_cast<double *>(lds_raw), part);
+	trip_sum(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, lds_raw, part);
 	if (threadIdx.x < MULLS_NTERM)
-		partial[(size_t)(job_base + job_idx) * MULLS_NTERM + threadIdx.x] = part[threadIdx.x]; // job_base: first job of this sub-batch in the batch-wide table
+		partial[(size_t)job_idx * MULLS_NTERM + threadIdx.x] = part[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -49,7 +47,7 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 		if (rp.used[c]) // unused classes contribute nothing: their slots are not even sent over PCIe
 		{
 			double sum = 0.0;
-			for (uint32_t j = pd[c].job_begin; j < pd[c].job_end; j += MULLS_ACC_CHUNK / MULLS_SRC_PER_BLOCK) // the jobs that start a chunk (k_accum)
+			for (uint32_t j = pd[c].job_begin; j < pd[c].job_end; j += MULLS_ACC_LANES / MULLS_SRC_PER_BLOCK) // the jobs that start a trip (k_accum)
 				sum += partial[(size_t)j * MULLS_NTERM + t];
 			o.sums[c][t] = sum;
 		}
@@ -215,8 +213,8 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
 
-void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, uint32_t job_base)
+void launch_accum(hipStream_t st, uint32_t nleaders, const uint32_t *leaders, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial)
 {
 	static bool attr_set = false;
 	if (!attr_set)
@@ -224,8 +222,8 @@ void launch_accum(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDe
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES);
 		attr_set = true;
 	}
-	if (njobs)
-		hipLaunchKernelGGL(k_accum, dim3(njobs), dim3(MULLS_ACC_LANES), MULLS_RED_BYTES, st, jobs, descs, states, rp, spos, mq, flag, wd, partial, job_base);
+	if (nleaders)
+		hipLaunchKernelGGL(k_accum, dim3(nleaders), dim3(MULLS_ACC_LANES), MULLS_RED_BYTES, st, leaders, jobs, descs, states, rp, spos, mq, flag, wd, partial);
 }
 
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
