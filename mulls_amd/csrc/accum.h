@@ -79,8 +79,8 @@ __device__ __forceinline__ AccumCtx accum_ctx(const RunParams &rp, int cls, int 
 // (point_wi; evaluated by the caller, once per point and away from the terms' registers — a double-precision exp).  TS = float where every term is a
 // float expression of the reference (point-to-plane and point-to-point normal equations) — it converts to double exactly when
 // the sum is taken, as the reference's `double += float expression` does — and double elsewhere.
-// MODE 1 (point-to-line classes with AccumCtx::li_diag): t[0..11] = the six diagonal terms (0, 6, 11, 15, 18, 20) and the six
-// right-hand-side terms (21..26)
+// MODE 1 (point-to-line classes with AccumCtx::li_diag): the six diagonal terms (0, 6, 11, 15, 18, 20) and the six right-hand-side
+// terms (21..26) are numbered 0..11, and T0 / NT select among those
 __device__ __forceinline__ constexpr int li_slot(int k) { return k == 0 ? 0 : (k == 6 ? 1 : (k == 11 ? 2 : (k == 15 ? 3 : (k == 18 ? 4 : (k == 20 ? 5 : (k >= 21 ? k - 15 : -1)))))); }
 __device__ __forceinline__ constexpr int li_term(int slot) { return slot == 0 ? 0 : (slot == 1 ? 6 : (slot == 2 ? 11 : (slot == 3 ? 15 : (slot == 4 ? 18 : (slot == 5 ? 20 : slot + 15))))); }
 #define ACC(k, v)                                              \
@@ -88,8 +88,8 @@ __device__ __forceinline__ constexpr int li_term(int slot) { return slot == 0 ? 
 	{                                                          \
 		if (MODE == 1)                                         \
 		{                                                      \
-			if (li_slot(k) >= 0)                               \
-				t[li_slot(k) >= 0 ? li_slot(k) : 0] = (TS)(v); \
+			if (li_slot(k) >= T0 && li_slot(k) < T0 + NT)      \
+				t[li_slot(k) >= T0 ? li_slot(k) - T0 : 0] = (TS)(v); \
 		}                                                      \
 		else if ((k) >= T0 && (k) < T0 + NT)                   \
 			t[(k)-T0] = (TS)(v);                               \
@@ -315,6 +315,7 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 //   (row0 + row1) + (row2 + row3)); the trip sums are added to 0.0 in trip order.
 #define MULLS_ACC_LANES 1024
 #define MULLS_RED_BYTES ((size_t)27 * MULLS_ACC_LANES * sizeof(float)) // the LDS term buffer: 27 float terms, or 13 double terms, of 1024 slots
+#define MULLS_RED_BYTES_HALF ((size_t)14 * MULLS_ACC_LANES * sizeof(float)) // ... in the two-halves mode: 14 float terms (or 7 double terms)
 
 namespace
 {
@@ -373,13 +374,14 @@ __device__ __forceinline__ void reduce_terms(const TS *R, double *part)
 			sum = dpp_add_f64<0x140>(sum); // row_mirror: every lane of a row holds the row's sum
 			const double r0 = readlane_f64(sum, 0), r1 = readlane_f64(sum, 16), r2 = readlane_f64(sum, 32), r3 = readlane_f64(sum, 48);
 			if (lane == 0)
-				part[MODE == 1 ? li_term(k) : T0 + k] = (r0 + r1) + (r2 + r3);
+				part[MODE == 1 ? li_term(T0 + k) : T0 + k] = (r0 + r1) + (r2 + r3);
 		}
 	}
 }
 
 // The 27 sums of one trip of 1024 slots whose data the lanes hold in registers (valid, P, Q, N, wdg as slot_terms) -> part[0..26]
 // (LDS; every entry written).  R: LDS, MULLS_RED_BYTES.  Every lane calls; ends with a barrier.
+template <bool HALF = false>
 __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x, bool valid, const float4 P, const float4 Q, const float4 N, float &wdg, void *R,
 											   double *part)
 {
@@ -397,11 +399,43 @@ __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x
 	{
 		// point-to-line, faithful: diagonal + right-hand side (the off-diagonal sums would be dropped by the mirror); the other entries are 0
 		__syncthreads();
-		slot_terms<double, 0, 12, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		if (threadIdx.x < 21 && li_slot((int)threadIdx.x) < 0)
 			part[threadIdx.x] = 0.0;
+		if (HALF)
+		{
+			slot_terms<double, 0, 6, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			__syncthreads();
+			reduce_terms<double, 0, 6, 1>(static_cast<const double *>(R), part);
+			__syncthreads();
+			slot_terms<double, 6, 6, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			__syncthreads();
+			reduce_terms<double, 6, 6, 1>(static_cast<const double *>(R), part);
+		}
+		else
+		{
+			slot_terms<double, 0, 12, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			__syncthreads();
+			reduce_terms<double, 0, 12, 1>(static_cast<const double *>(R), part);
+		}
+	}
+	else if (A.metric == 1 && HALF)
+	{
 		__syncthreads();
-		reduce_terms<double, 0, 12, 1>(static_cast<const double *>(R), part);
+		slot_terms<double, 0, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 0, 7>(static_cast<const double *>(R), part);
+		__syncthreads();
+		slot_terms<double, 7, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 7, 7>(static_cast<const double *>(R), part);
+		__syncthreads();
+		slot_terms<double, 14, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 14, 7>(static_cast<const double *>(R), part);
+		__syncthreads();
+		slot_terms<double, 21, 6>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		__syncthreads();
+		reduce_terms<double, 21, 6>(static_cast<const double *>(R), part);
 	}
 	else if (A.metric == 1)
 	{
@@ -419,6 +453,18 @@ __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x
 		__syncthreads();
 		reduce_terms<double, 26, 1>(static_cast<const double *>(R), part);
 	}
+	else if (HALF)
+	{
+		// two halves through a buffer of 14 float terms (56 KiB: two workgroups per CU, k_accum); same sums, term by term
+		__syncthreads();
+		slot_terms<float, 0, 14>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		__syncthreads();
+		reduce_terms<float, 0, 14>(static_cast<const float *>(R), part);
+		__syncthreads();
+		slot_terms<float, 14, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		__syncthreads();
+		reduce_terms<float, 14, 13>(static_cast<const float *>(R), part);
+	}
 	else
 	{
 		__syncthreads();
@@ -431,6 +477,7 @@ __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x
 
 // the 27 sums of one trip of a class cloud's source slots [trip0, trip0 + 1024), read from memory (all loads issued before the
 // validity test: one memory round trip) -> part[0..26]
+template <bool HALF = false>
 __device__ __forceinline__ void trip_sum(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t trip0, const float4 *__restrict__ spos,
 										  const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, void *R, double *part)
 {
@@ -447,7 +494,7 @@ __device__ __forceinline__ void trip_sum(const AccumCtx &A, const double *x, con
 		w = w0 = wd[g];
 		valid = (f & (MULLS_F_ALIVE | MULLS_F_VALID)) == (MULLS_F_ALIVE | MULLS_F_VALID);
 	}
-	trip_sum_regs(A, x, valid, P, Q, N, w, R, part);
+	trip_sum_regs<HALF>(A, x, valid, P, Q, N, w, R, part);
 	if (valid && __float_as_uint(w) != __float_as_uint(w0))
 		wd[g] = w; // pcl::Correspondence::weight
 }

@@ -7,7 +7,7 @@
 // table is the one of the search (512 source slots per job); one workgroup per job that starts a trip of MULLS_ACC_LANES slots
 // (`leaders`) sums the whole trip in the library's summation order (accum.h) into that job's slot of `partial`; k_finish
 // adds the trip partials in order (run-to-run deterministic, unlike atomicAdd(double), and the same bits as k_icp).
-__global__ __launch_bounds__(MULLS_ACC_LANES) void k_accum(const uint32_t *__restrict__ leaders, const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+__global__ __launch_bounds__(MULLS_ACC_LANES, 2) void k_accum(const uint32_t *__restrict__ leaders, const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
 															const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd,
 															double *__restrict__ partial)
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(MULLS_ACC_LANES) void k_accum(const uint32_t *__res
 	for (int c = 0; c < MULLS_NC; c++)
 		cnt[c] = (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
 	const AccumCtx A = accum_ctx(rp, job.cls, ps.iter, residual_pass, class_weight(rp, job.cls, residual_pass, cnt));
-	trip_sum(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, lds_raw, part);
+	trip_sum<true>(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, lds_raw, part); // 56 KiB term buffer: two workgroups per CU
 	if (threadIdx.x < MULLS_NTERM)
 		partial[(size_t)job_idx * MULLS_NTERM + threadIdx.x] = part[threadIdx.x];
 }
@@ -219,11 +219,11 @@ void launch_accum(hipStream_t st, uint32_t nleaders, const uint32_t *leaders, co
 	static bool attr_set = false;
 	if (!attr_set)
 	{
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
 		attr_set = true;
 	}
 	if (nleaders)
-		hipLaunchKernelGGL(k_accum, dim3(nleaders), dim3(MULLS_ACC_LANES), MULLS_RED_BYTES, st, leaders, jobs, descs, states, rp, spos, mq, flag, wd, partial);
+		hipLaunchKernelGGL(k_accum, dim3(nleaders), dim3(MULLS_ACC_LANES), MULLS_RED_BYTES_HALF, st, leaders, jobs, descs, states, rp, spos, mq, flag, wd, partial);
 }
 
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
