@@ -67,7 +67,8 @@ class Params(C.Structure):
         ("normal_bearing", C.c_float),
         ("keep_less_source_points", C.c_uint8),
         ("faithful", C.c_uint8),
-        ("reserved_", C.c_uint8 * 2),
+        ("rejector_strict", C.c_uint8),
+        ("reserved_", C.c_uint8),
         ("sigma_thre", C.c_float),
         ("min_neccessary_corr_ratio", C.c_float),
         ("max_bearable_rotation_d", C.c_float),

@@ -142,6 +142,7 @@ struct RunParams
 	uint8_t undistort;							 // apply_motion_undistortion_while_registration
 	uint8_t normal_shooting;					 // normal_shooting_on: ground / facade / roof use the 10-NN normal-shooting search
 	uint8_t faithful;
+	uint8_t rej_strict; // CorrespondenceRejectorDistance: 0 keep distance <= max^2 (NaN kept), 1 keep distance < max^2 (mulls_params.rejector_strict)
 	float z_xy_ratio;
 	float win_pt, win_pl, win_li;
 	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule

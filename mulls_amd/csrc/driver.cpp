@@ -1079,6 +1079,7 @@ extern "C"
 		rp.undistort = P->apply_motion_undistortion != 0;
 		rp.crop = P->apply_intersection_filter != 0 && !rp.undistort; // cregistration.hpp:1186
 		rp.faithful = P->faithful != 0;
+		rp.rej_strict = P->rejector_strict != 0;
 		rp.z_xy_ratio = P->z_xy_balanced_ratio;
 		rp.win_pt = P->pt2pt_residual_window;
 		rp.win_pl = P->pt2pl_residual_window;
@@ -1620,6 +1621,7 @@ extern "C"
 		rp.w_dist = P->weight_strategy[2] == '1';
 		rp.w_inten = P->weight_strategy[3] == '1';
 		rp.faithful = 1;
+		rp.rej_strict = P->rejector_strict != 0;
 		rp.win_pl = rp.win_li = rp.win_pt = 0.1f;			  // residual_window_size default of pt2pl_ground_3dof_lls_summation (:2323)
 		rp.cos_bearing = std::cos(40.0f / 180.0 * M_PI); // determine_corres' default angle_thre_degree (:1704)
 		rp.resid_from_iter = -1;							  // no iteration gate in ground_3dof_lls_tran_estimation (:2294)

@@ -248,7 +248,7 @@ __device__ __forceinline__ int fused_class(const RunParams &rp, const PairState 
 			}
 			if (valid)
 			{
-				valid = !(dist > max_sqr);
+				valid = rp.rej_strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
 				if (valid)
 				{
 					WD[k] = dist; // pcl::Correspondence::distance (shares storage with ::weight)

@@ -353,7 +353,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 		return;
 	const float thr = ps.thr[job.cls];
 	// vertex correspondences skip the direction check (cregistration.hpp:1292)
-	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u, thr * thr, rp.cos_bearing,
+	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u, rp.rej_strict != 0, thr * thr, rp.cos_bearing,
 						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32};
 	uint32_t n_alive = 0, n_valid = 0;
 #pragma unroll

@@ -9,7 +9,7 @@
 // `dedup_done`: the duplicate rule has been applied already (losers carry nn_idx = -1, k_nn_lds with rp.lds_dedup).
 struct FilterCtx
 {
-	bool gate, any_match, normal_check, dedup_done;
+	bool gate, any_match, normal_check, dedup_done, strict;
 	float max_sqr;	 // CorrespondenceRejectorDistance::setMaximumDistance (float)
 	double cos_thre; // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
 	unsigned long long key_hi;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc
 		if (valid)
 		{
 			const float dist = nn_d2[g];
-			valid = !(dist > F.max_sqr);
+			valid = F.strict ? dist < F.max_sqr : !(dist > F.max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
 			if (valid)
 			{
 				wd[g] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
@@ -426,7 +426,7 @@ __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState 
 		total_matched += red[w];
 	const float thr = ps.thr[job.cls];
 	// vertex correspondences skip the direction check (cregistration.hpp:1292)
-	const FilterCtx F = {C.gate, total_matched > 0u, job.cls != 5, true, thr * thr, rp.cos_bearing, C.key_hi};
+	const FilterCtx F = {C.gate, total_matched > 0u, job.cls != 5, true, rp.rej_strict != 0, thr * thr, rp.cos_bearing, C.key_hi};
 	uint32_t n_alive = 0, n_valid = 0;
 	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
 		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq, n_alive, n_valid);

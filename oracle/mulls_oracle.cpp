@@ -26,6 +26,7 @@
 // Build: see oracle/Makefile (g++ -O3 -ffp-contract=off -fopenmp).  FMA contraction must stay off: the reference
 // is built -O3 without -march (CMakeLists.txt:43), i.e. plain SSE2 mul/add.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -414,8 +415,18 @@ class KdTree
 	std::vector<Node> nodes_;
 };
 
+// Census of the third-party operators whose exact form cannot be checked against PCL / FLANN sources in this image
+// (tests/test_pcl_operators.py): how often a run lands on an input where two plausible readings of the upstream code differ.
+//   [0] radius tests evaluated (CorrespondenceEstimation::determineCorrespondences, `distance > max_dist_sqr` skips)   [1] ... with distance == max_dist_sqr exactly
+//   [2] rejector tests evaluated (CorrespondenceRejectorDistance::getRemainingCorrespondences)   [3] ... with distance == max^2 exactly (`<` and `<=` differ)
+//   [4] ... with a NaN distance (kept by `!(d > max)`, dropped by `d < max`)
+//   [5] brute-force nearest-neighbour queries   [6] ... whose minimum distance is shared by two or more targets (FLANN's tie order is implementation-defined)
+std::atomic<unsigned long long> g_census[8];
+bool g_rejector_strict = false; // mulls_params.rejector_strict of the registration being run (set on entry; the OpenMP sections read it)
+
 int brute_nearest(const Cloud &tgt, const Pt &q, float &d2)
 {
+	int ties = 0;
 	int best = -1;
 	float bd = FLT_MAX;
 	for (size_t t = 0; t < tgt.size(); t++)
@@ -425,8 +436,14 @@ int brute_nearest(const Cloud &tgt, const Pt &q, float &d2)
 		{
 			bd = d;
 			best = (int)t;
+			ties = 0;
 		}
+		else if (d == bd)
+			ties++;
 	}
+	g_census[5]++;
+	if (ties && best >= 0)
+		g_census[6]++;
 	d2 = bd;
 	return best;
 }
@@ -488,6 +505,12 @@ bool determine_corres(Cloud &src, std::vector<int> &orig, const Cloud &tgt, cons
 		{
 			float d2;
 			int t = brute ? brute_nearest(tgt, src[s], d2) : tree->nearest(src[s], d2);
+			if (t >= 0)
+			{
+				g_census[0]++;
+				if ((double)d2 == max_dist_sqr)
+					g_census[1]++;
+			}
 			if (t < 0 || (double)d2 > max_dist_sqr)
 				continue;
 			Corr c = {(int)s, t, d2};
@@ -528,8 +551,15 @@ bool determine_corres(Cloud &src, std::vector<int> &orig, const Cloud &tgt, cons
 		const float max_sqr = dis_thre * dis_thre;
 		corr_f.clear();
 		for (size_t i = 0; i < corr.size(); i++)
-			if (!(corr[i].dw > max_sqr))
+		{
+			g_census[2]++;
+			if (corr[i].dw == max_sqr)
+				g_census[3]++;
+			if (corr[i].dw != corr[i].dw)
+				g_census[4]++;
+			if (g_rejector_strict ? corr[i].dw < max_sqr : !(corr[i].dw > max_sqr)) // mulls_params.rejector_strict
 				corr_f.push_back(corr[i]);
+		}
 	}
 	else if (compacted)
 	{
@@ -1095,6 +1125,7 @@ inline int metric_of(int c) { return (c == MULLS_PILLAR || c == MULLS_BEAM) ? 1 
 
 int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int brute, int use_omp)
 {
+	g_rejector_strict = P->rejector_strict != 0;
 	auto tic = std::chrono::steady_clock::now();
 	int process_code = 0;
 	const int min_total_corr_num = 40, min_neccessary_corr_num = 20;
@@ -1420,6 +1451,7 @@ int icp_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int
 // keep_less_source_points, max_bearable_rotation_d).
 int icp_3dof_impl(const mulls_pair *pair, const mulls_params *P, mulls_result *R, int brute)
 {
+	g_rejector_strict = P->rejector_strict != 0;
 	int process_code = 0;
 	const int min_total_corr_num = 100, down_rate = 3;
 	M4 S2T = m4_identity(), TempTran = m4_identity();
@@ -1679,6 +1711,17 @@ namespace
 extern "C"
 {
 
+	// operator census (see g_census): copies the eight counters, optionally resetting them
+	void mulls_oracle_census(unsigned long long out[8], int reset)
+	{
+		for (int k = 0; k < 8; k++)
+		{
+			out[k] = g_census[k].load();
+			if (reset)
+				g_census[k] = 0;
+		}
+	}
+
 	// nn_mode: 0 = kd-tree (the PCL/FLANN cost model), 1 = brute force (cross-check).  use_omp: 1 = the reference's
 	// 3-wide OpenMP sections, 0 = serial.
 	int mulls_oracle_icp(const mulls_pair *pair, const mulls_params *params, mulls_result *result, int nn_mode, int use_omp)
@@ -1728,6 +1771,7 @@ extern "C"
 		}
 		Corrs cf;
 		size_t n0 = S.size();
+		g_rejector_strict = false; // the stage entry point has no parameter block: the default form
 		determine_corres(S, orig, T, &tree, dis_thre, cf, false, normal_check != 0, angle_thre_degree, nn_mode != 0);
 		(void)n0;
 		for (size_t k = 0; k < orig.size(); k++) // identity when no compaction happened

@@ -152,3 +152,11 @@ def map_update(map_clouds, map_pose, frame_down, frame_pose, params, fn=None):
     if rc != 0:
         raise RuntimeError("oracle map_update returned %d" % rc)
     return [out_m[c][: nm[c]].copy() for c in range(6)], [out_f[c][: nf[c]].copy() for c in range(6)], rep
+
+
+def census(reset=False):
+    """Operator census of the runs so far (see g_census in mulls_oracle.cpp): dict of counters."""
+    out = (C.c_ulonglong * 8)()
+    lib().mulls_oracle_census(out, int(reset))
+    names = ("radius_tests", "radius_equal", "rejector_tests", "rejector_equal", "rejector_nan", "brute_queries", "brute_ties")
+    return {n: int(out[i]) for i, n in enumerate(names)}

@@ -1,0 +1,103 @@
+"""Third-party operators the path relies on and that cannot be checked against PCL / FLANN / Eigen sources in this image
+(SURVEY.md Appendix C restates them from memory of PCL 1.8-1.10): where two plausible readings of the upstream code exist,
+count how often the bench workload lands on an input that tells them apart.
+
+  pcl/registration/impl/correspondence_estimation.hpp  CorrespondenceEstimation::determineCorrespondences(corrs, double max_distance)
+      `if (distance[0] > max_dist_sqr) continue;` with max_dist_sqr = max_distance * max_distance in double  — restated as is;
+      differs from `>=` only when (double)d2 == max_dist_sqr exactly                              -> census "radius_equal"
+  pcl/registration/correspondence_rejection_distance.{h,cpp}  CorrespondenceRejectorDistance::getRemainingCorrespondences
+      setMaximumDistance(float d) stores d * d; the kept test is remembered as `distance <= max` (kept when
+      !(distance > max), NaN kept) and as `distance < max` (NaN dropped)                           -> census "rejector_equal", "rejector_nan"
+      both forms exist in this library: mulls_params.rejector_strict (default 0 = the SURVEY's form)
+  flann/algorithms/kdtree_single_index.h  KDTreeSingleIndex::findNeighbors (exact, epsilon 0, L2_Simple<float>)
+      the order among targets at exactly the same distance is implementation-defined; here: lowest index     -> census "brute_ties"
+  Eigen/src/LU/PartialPivLU.h  inverse() of a fixed 6x6 — row-pivoted LU, columns solved against the identity; restated in
+      hostmath.h / the oracle; last-bit differences in the back substitution order would not change any integer output.
+
+The counts are reported, and bounded: should a workload ever hit these inputs at a rate that matters, the test fails and says so."""
+import numpy as np
+import pytest
+
+from mulls_amd import abi, synth
+from oracle import pyoracle
+
+
+def _bench_like_pairs(n):
+    import bench
+
+    scenes = bench.build_scenes(n, False, 4)
+    return [s[0] for s in scenes]
+
+
+@pytest.mark.timeout(600)
+def test_operator_census_on_the_bench_workload():
+    pairs = _bench_like_pairs(6)
+    P = abi.kitti_params(converge_translation=0.0, converge_rotation_d=0.0)
+    pyoracle.census(reset=True)
+    for p in pairs:
+        r = pyoracle.icp(p, P, nn_mode=1)[0]  # brute force: the tie counter sees every target of every query
+        assert r.code == 1 and r.iters == 20
+    c = pyoracle.census(reset=True)
+    print("operator census over %d registrations x 20 iterations: %s" % (len(pairs), c))
+    assert c["radius_tests"] > 200000 and c["rejector_tests"] > 100000 and c["brute_queries"] == c["radius_tests"]
+    # none of the boundary inputs occurs: the two readings of each operator give the same result on this workload
+    assert c["radius_equal"] == 0
+    assert c["rejector_equal"] == 0 and c["rejector_nan"] == 0
+    # exact ties of the nearest distance need two targets at the same float distance from a query: rare, reported
+    assert c["brute_ties"] <= c["brute_queries"] * 1e-4, c
+
+
+def test_strict_rejector_differs_only_on_the_boundary():
+    """rejector_strict = 1 (`distance < max^2`) and 0 (`distance <= max^2`): identical results unless a correspondence sits exactly
+    on the threshold — shown on the bench-like pairs (identical) and on a constructed boundary case (one correspondence apart)."""
+    pairs = _bench_like_pairs(2)
+    P0 = abi.kitti_params(max_iter_num=6)
+    P1 = abi.kitti_params(max_iter_num=6, rejector_strict=1)
+    for p in pairs:
+        a, b = pyoracle.icp(p, P0)[0], pyoracle.icp(p, P1)[0]
+        assert list(a.T) == list(b.T) and list(a.ncorr) == list(b.ncorr) and a.iters == b.iters
+    # boundary: a target grid, sources displaced by exactly thr along x (float-exact numbers): distance == thr^2
+    thr = 0.5
+    g = np.arange(-8, 9, dtype=np.float32) * 2.0
+    X, Y = np.meshgrid(g, g)
+    tgt = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32)], 1)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (len(tgt), 1))
+    src = tgt.copy()
+    src[:, 0] += thr
+    tp = abi.make_points(tgt, nrm, np.full(len(tgt), 10, np.float32), np.zeros(len(tgt), np.float32))
+    sp = abi.make_points(src, nrm, np.full(len(tgt), 10, np.float32), np.zeros(len(tgt), np.float32))
+    m0, d0, f0 = pyoracle.correspond(sp, tp, thr)
+    assert (d0 == np.float32(thr * thr)).all() and (f0 & 2).all()  # `<=`: every correspondence kept
+    pair = boundary_pair()
+    kw = dict(used_feature_type="100000", max_iter_num=1, dis_thre_unit=thr, apply_intersection_filter=0)
+    assert pyoracle.icp(pair, abi.default_params(**kw))[0].ncorr[0] == 289
+    assert pyoracle.icp(pair, abi.default_params(rejector_strict=1, **kw))[0].ncorr[0] == 0  # `<`: none
+
+
+def boundary_pair(thr=0.5):
+    """289 ground correspondences whose float distance equals the float threshold thr * thr exactly."""
+    g = np.arange(-8, 9, dtype=np.float32) * 2.0
+    X, Y = np.meshgrid(g, g)
+    tgt = np.stack([X.ravel(), Y.ravel(), np.zeros(X.size, np.float32)], 1)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (len(tgt), 1))
+    src = tgt.copy()
+    src[:, 0] += thr
+    mk = lambda xyz: abi.make_points(xyz, nrm, np.full(len(xyz), 10, np.float32), np.zeros(len(xyz), np.float32))
+    return abi.PairData([mk(tgt)] + [None] * 5, [mk(src)] + [None] * 5)
+
+
+@pytest.mark.gpu
+def test_strict_rejector_on_the_device(ctx):
+    """Both forms of the distance rejector on the device, against the oracle, on the constructed boundary case and on a scan pair."""
+    pair = boundary_pair()
+    kw = dict(used_feature_type="100000", max_iter_num=1, dis_thre_unit=0.5, apply_intersection_filter=0)
+    for strict in (0, 1):
+        P = abi.default_params(rejector_strict=strict, **kw)
+        rg, ro = ctx.icp(pair, P)[0], pyoracle.icp(pair, P)[0]
+        assert list(rg.ncorr) == list(ro.ncorr) and rg.code == ro.code and rg.ncorr[0] == (0 if strict else 289)
+    sp, _ = synth.make_pair(11, n_beams=32, n_az=900, src_counts={0: 600, 1: 300, 2: 700}, tgt_counts={0: 2500, 1: 900, 2: 3000}, vertex_count=0)
+    P = abi.kitti_params(dis_thre_unit=2.4, rejector_strict=1)
+    rg, ro = ctx.icp(sp, P)[0], pyoracle.icp(sp, P)[0]
+    assert rg.code == ro.code == 1 and rg.iters == ro.iters and list(rg.ncorr) == list(ro.ncorr)
+    dt, dr = synth.pose_error(np.array(rg.T[:]).reshape(4, 4).T, np.array(ro.T[:]).reshape(4, 4).T)
+    assert dt <= 1e-7 and dr <= 1e-7
