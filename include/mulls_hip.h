@@ -302,6 +302,47 @@ int mulls_io_write_pcd(const char *path, const void *pts, uint32_t n, uint32_t s
 /* DataIo::write_lo_pose_overwrite / _append (dataio.hpp:1896-1926): the top three rows of T (column-major), 8 significant digits */
 int mulls_io_write_pose(const char *path, const double T[16], int append);
 
+/* ---- feature extraction, first stage: CFilter::fast_ground_filter (include/common/cfilter.hpp:1658-2036),
+ * the two-threshold grid ground filter that splits a (voxel-down-sampled) scan into ground and non-ground points ---- */
+
+/* its positional parameters (cfilter.hpp:1663-1672; values of script/config/lo_gflag_list_kitti_urban.txt in brackets) */
+typedef struct mulls_ground_params
+{
+	int32_t min_grid_pt_num;			   /* gf_grid_min_pt_num [6] */
+	float grid_resolution;				   /* gf_grid_size [2.5] */
+	float max_height_difference;		   /* gf_in_grid_h_thre [0.25] */
+	float neighbor_height_diff;			   /* gf_neigh_grid_h_thre [1.5] */
+	float max_ground_height;			   /* gf_max_h [2.0] */
+	int32_t ground_random_down_rate;	   /* gf_ground_down_rate [12] */
+	int32_t ground_random_down_down_rate;  /* gf_down_down_rate [3] */
+	int32_t nonground_random_down_rate;	   /* gf_nonground_down_rate [3] */
+	int32_t reliable_neighbor_grid_num_thre; /* gf_reliable_neighbor_grid_thre [0] */
+	int32_t estimate_ground_normal_method; /* 0: (0,0,1) — the only one built: 1 / 2 are PCA normals, 3 [the shipped configs] a PCL RANSAC per grid
+											  cell (PCL is not in this image: its sample sequence cannot be restated and pinned) -> MULLS_E_UNSUPPORTED */
+	int32_t distance_weight_downsampling_method; /* dist_inverse_sampling_method: 0 off, 1 linear, 2 quadratic [2].  Upstream the per-cell rates of 1 / 2
+											  go through a variable shared by the threads of an OpenMP loop (cfilter.hpp:1829-1840: a data race); here
+											  every cell uses its own value, i.e. the loop's sequential semantics */
+	float standard_distance;			   /* [15.0] */
+	uint8_t fixed_num_downsampling;		   /* ground_down by a fixed number instead of every down_down_rate-th point */
+	uint8_t apply_grid_wise_outlier_filter; /* extract_semantic_pts passes apply_scanner_filter here (cfilter.hpp:2361) */
+	uint8_t reserved_[2];
+	int32_t down_ground_fixed_num;		   /* ground_down_fixed_num [800] */
+	float intensity_thre;				   /* intensity_thre_nonground [150]; FLT_MAX disables */
+	float outlier_std_scale;			   /* 3.0 */
+	uint64_t rng_seed;					   /* ABI-only: fixed_num_downsampling thins with the seeded order-preserving selection of mulls_params.rng_seed
+											  (upstream: pcl::RandomSample seeded with time(NULL)) */
+} mulls_ground_params;
+
+void mulls_ground_default_params(mulls_ground_params *p);
+
+/* fast_ground_filter on `n` points (48-byte records, `stride` bytes apart).  Outputs (48-byte records, host memory, capacities in
+ * points): ground = cloud_ground (normal (0,0,1)), ground_down = cloud_ground_down, unground = cloud_unground with data[3] (the
+ * float at byte offset 12) = height above ground as the reference stores it.  n_out[3] = the three sizes; a cloud larger than its
+ * capacity is truncated to it (its size is still reported).  The input is not modified (upstream writes normals and data[3] into
+ * cloud_in: the copies handed out carry them).  One workgroup per scan; grids of more than 65536 cells or scans of more than 500000 points -> MULLS_E_UNSUPPORTED. */
+int mulls_ground_filter(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *params, void *ground, uint32_t cap_ground,
+						void *ground_down, uint32_t cap_ground_down, void *unground, uint32_t cap_unground, uint32_t n_out[3]);
+
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 
 /* batch_transform_feature_points (cregistration.hpp:1685-1696): in place on a host cloud via the device kernel */

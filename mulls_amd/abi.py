@@ -172,6 +172,44 @@ def map_params(**kw):
 def colmajor16(M):
     return (C.c_double * 16)(*np.asarray(M, dtype=np.float64).T.reshape(-1))
 
+class GroundParams(C.Structure):
+    _fields_ = [
+        ("min_grid_pt_num", C.c_int32),
+        ("grid_resolution", C.c_float),
+        ("max_height_difference", C.c_float),
+        ("neighbor_height_diff", C.c_float),
+        ("max_ground_height", C.c_float),
+        ("ground_random_down_rate", C.c_int32),
+        ("ground_random_down_down_rate", C.c_int32),
+        ("nonground_random_down_rate", C.c_int32),
+        ("reliable_neighbor_grid_num_thre", C.c_int32),
+        ("estimate_ground_normal_method", C.c_int32),
+        ("distance_weight_downsampling_method", C.c_int32),
+        ("standard_distance", C.c_float),
+        ("fixed_num_downsampling", C.c_uint8),
+        ("apply_grid_wise_outlier_filter", C.c_uint8),
+        ("reserved_", C.c_uint8 * 2),
+        ("down_ground_fixed_num", C.c_int32),
+        ("intensity_thre", C.c_float),
+        ("outlier_std_scale", C.c_float),
+        ("rng_seed", C.c_uint64),
+    ]
+
+
+def ground_params(**overrides):
+    """fast_ground_filter's arguments as extract_semantic_pts passes them with script/config/lo_gflag_list_kitti_urban.txt, except
+    the ground normal method (0 instead of the RANSAC of method 3) and the distance-inverse sampling (0 instead of 2)."""
+    p = GroundParams()
+    kw = dict(min_grid_pt_num=6, grid_resolution=2.5, max_height_difference=0.25, neighbor_height_diff=1.5, max_ground_height=2.0,
+              ground_random_down_rate=12, ground_random_down_down_rate=3, nonground_random_down_rate=3, reliable_neighbor_grid_num_thre=0,
+              estimate_ground_normal_method=0, distance_weight_downsampling_method=0, standard_distance=15.0, fixed_num_downsampling=0,
+              apply_grid_wise_outlier_filter=0, down_ground_fixed_num=800, intensity_thre=150.0, outlier_std_scale=3.0, rng_seed=0)
+    kw.update(overrides)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("ms_setup", C.c_double),

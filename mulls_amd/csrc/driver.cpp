@@ -943,6 +943,8 @@ extern "C"
 
 	void mulls_destroy(mulls_ctx *ctx)
 	{
+		if (ctx && ctx->gf_buf)
+			(void)hipFree(ctx->gf_buf);
 		if (!ctx)
 			return;
 		(void)hipSetDevice(ctx->device);

@@ -67,6 +67,10 @@ def load():
     lib.mulls_map_pose.argtypes = [vp, vp, C.POINTER(C.c_double)]
     lib.mulls_map_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_map_frame_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_ground_default_params.argtypes = [C.POINTER(abi.GroundParams)]
+    lib.mulls_ground_default_params.restype = None
+    lib.mulls_ground_filter.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.GroundParams), vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32,
+                                        C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -81,7 +85,7 @@ EXPORTS = [
     "mulls_stage_transform", "mulls_stage_correspond", "mulls_stage_accumulate", "mulls_icp_3dof_ground", "mulls_icp_3dof_ground_batch",
     "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
     "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
-    "mulls_io_write_pcd", "mulls_io_write_pose",
+    "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
 ]
 
 
@@ -201,6 +205,17 @@ class Context:
                                                    converge_rotation_d, dis_thre_min, dis_thre_update_rate, max_bearable_rotation_d, res,
                                                    C.byref(ok), C.byref(best)), "mulls_icp_4dof_global")
         return res, bool(ok.value), float(best.value)
+
+    # --- feature extraction, first stage -------------------------------------------------------------------
+    def ground_filter(self, pts, params):
+        """CFilter::fast_ground_filter on the device.  Returns (ground, ground_down, unground) as (n, 48) uint8 record arrays."""
+        pts = abi.as_points(pts)
+        n = len(pts)
+        raw = [np.zeros(max(n, 1) * abi.POINT_BYTES, np.uint8) for _ in range(3)]
+        nout = (C.c_uint32 * 3)()
+        self._check(self.lib.mulls_ground_filter(self.h, pts.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), raw[0].ctypes.data_as(C.c_void_p), n,
+                                                 raw[1].ctypes.data_as(C.c_void_p), n, raw[2].ctypes.data_as(C.c_void_p), n, nout), "mulls_ground_filter")
+        return [raw[k][: nout[k] * abi.POINT_BYTES].reshape(nout[k], abi.POINT_BYTES).copy() for k in range(3)]
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

@@ -37,11 +37,14 @@ extract utility.hpp 92 157 "struct centerpoint_t" util_types.inc
 extract utility.hpp 233 558 "struct cloudblock_t" util_types.inc
 extract utility.hpp 561 590 "struct constraint_t" util_types.inc
 extract utility.hpp 795 886 "template <typename PointT>" util_cloudutility.inc
-# cfilter.hpp: motion compensation, random down-sampling, box filter, pair intersection
+# cfilter.hpp: grid_t, motion compensation, random down-sampling, box filter, the ground filter, pair intersection
+extract cfilter.hpp 45 69 "struct grid_t" cfilter_body.inc
 extract cfilter.hpp 470 549 "void apply_motion_compensation" cfilter_body.inc
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
+extract cfilter.hpp 685 712 "bool random_downsample_pcl(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
+extract cfilter.hpp 1658 2036 "bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 2613 2655 "bool get_cloud_pair_intersection" cfilter_body.inc
 # cregistration.hpp: the driver and every helper on the path
 extract cregistration.hpp 1114 1440 "int mm_lls_icp(constraint_t &registration_cons" creg_body.inc

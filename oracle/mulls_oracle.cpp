@@ -1028,6 +1028,199 @@ void random_downsample(Cloud &c, int keep_number, uint64_t seed, int cloud_id)
 	c.swap(out);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// CFilter::fast_ground_filter (cfilter.hpp:1658-2036), estimate_ground_normal_method = 0.  Statement by statement: the float /
+// double mix of every expression is the reference's (bounds_t holds doubles, the thresholds are floats).  The per-cell
+// down-sampling rates of distance_weight_downsampling_method 1 / 2 follow the loop's sequential semantics (upstream the loop
+// over cells is an OpenMP parallel-for writing a shared `distance_weight`, :1829-1840).  fixed_num_downsampling uses the ABI's
+// seeded selection (upstream: pcl::RandomSample seeded with time(NULL)).
+namespace
+{
+struct GfCell // grid_t (cfilter.hpp:45-69)
+{
+	std::vector<int> point_id;
+	float min_z = 0.f, min_z_outlier_thre = -FLT_MAX, neighbor_min_z = 0.f, dist2station = 0.001f;
+	int pts_count = 0, reliable_neighbor_grid_num = 0;
+};
+} // namespace
+int ground_filter_impl(Cloud &in, const mulls_ground_params &P, Cloud &ground, Cloud &ground_down, Cloud &unground)
+{
+	if (P.estimate_ground_normal_method != 0)
+		return MULLS_E_UNSUPPORTED;
+	const int min_grid_pt_num = P.min_grid_pt_num;
+	const float grid_resolution = P.grid_resolution, max_height_difference = P.max_height_difference, neighbor_height_diff = P.neighbor_height_diff,
+				max_ground_height = P.max_ground_height, standard_distance = P.standard_distance, intensity_thre = P.intensity_thre;
+	const int ground_random_down_rate = P.ground_random_down_rate, nonground_random_down_rate = P.nonground_random_down_rate;
+	const int dw_method = P.distance_weight_downsampling_method;
+	const int reliable_grid_pts_count_thre = min_grid_pt_num - 1;
+	int count_checkpoint = 0;
+	float sum_height = 0.001;
+	float appro_mean_height;
+	float underground_noise_thre = -FLT_MAX;
+	float non_ground_height_thre;
+	float distance_weight;
+	for (size_t j = 0; j < in.size(); j++) // :1689-1697
+		if (j % 100 == 0)
+		{
+			sum_height += in[j].z;
+			count_checkpoint++;
+		}
+	appro_mean_height = sum_height / count_checkpoint;
+	non_ground_height_thre = appro_mean_height + max_ground_height;
+	double b[6];
+	cloud_bbx(in, b); // get_cloud_bbx (utility.hpp:817-848)
+	const double min_x = b[0], min_y = b[1], max_x = b[3], max_y = b[4];
+	int row, col, num_grid;
+	row = ceil((max_y - min_y) / grid_resolution);
+	col = ceil((max_x - min_x) / grid_resolution);
+	num_grid = row * col;
+	if (num_grid < 0)
+		num_grid = 0;
+	std::vector<GfCell> grid((size_t)num_grid);
+	for (int i = 0; i < num_grid; i++)
+	{
+		grid[i].min_z = FLT_MAX;
+		grid[i].neighbor_min_z = FLT_MAX;
+	}
+	for (size_t j = 0; j < in.size(); j++) // :1727-1766
+	{
+		int temp_row, temp_col, temp_id;
+		temp_col = floor((in[j].x - min_x) / grid_resolution);
+		temp_row = floor((in[j].y - min_y) / grid_resolution);
+		temp_id = temp_row * col + temp_col;
+		if (temp_id >= 0 && temp_id < num_grid)
+		{
+			if (dw_method > 0 && !grid[temp_id].pts_count)
+				grid[temp_id].dist2station = std::sqrt(in[j].x * in[j].x + in[j].y * in[j].y + in[j].z * in[j].z);
+			if (in[j].z > non_ground_height_thre)
+			{
+				distance_weight = 1.0 * standard_distance / (grid[temp_id].dist2station + 0.0001);
+				int nonground_random_down_rate_temp = nonground_random_down_rate;
+				if (dw_method == 1)
+					nonground_random_down_rate_temp = (int)(distance_weight * nonground_random_down_rate + 1);
+				else if (dw_method == 2)
+					nonground_random_down_rate_temp = (int)(distance_weight * distance_weight * nonground_random_down_rate + 1);
+				if ((int)j % nonground_random_down_rate_temp == 0 || in[j].intensity > intensity_thre)
+				{
+					in[j].d3 = in[j].z - (appro_mean_height - 3.0);
+					unground.push_back(in[j]);
+				}
+			}
+			else if (in[j].z > underground_noise_thre)
+			{
+				grid[temp_id].pts_count++;
+				grid[temp_id].point_id.push_back((int)j);
+				if (in[j].z < grid[temp_id].min_z)
+				{
+					grid[temp_id].min_z = in[j].z;
+					grid[temp_id].neighbor_min_z = in[j].z;
+				}
+			}
+		}
+	}
+	if (P.apply_grid_wise_outlier_filter) // :1770-1790
+		for (int i = 0; i < num_grid; i++)
+			if (grid[i].pts_count >= min_grid_pt_num)
+			{
+				double sum_z = 0, sum_z2 = 0, std_z = 0, mean_z = 0;
+				for (size_t j = 0; j < grid[i].point_id.size(); j++)
+					sum_z += in[grid[i].point_id[j]].z;
+				mean_z = sum_z / grid[i].pts_count;
+				for (size_t j = 0; j < grid[i].point_id.size(); j++)
+					sum_z2 += (in[grid[i].point_id[j]].z - mean_z) * (in[grid[i].point_id[j]].z - mean_z);
+				std_z = std::sqrt(sum_z2 / grid[i].pts_count);
+				grid[i].min_z_outlier_thre = mean_z - P.outlier_std_scale * std_z;
+				grid[i].min_z = (grid[i].min_z > grid[i].min_z_outlier_thre) ? grid[i].min_z : grid[i].min_z_outlier_thre;
+				grid[i].neighbor_min_z = grid[i].min_z;
+			}
+	for (int m = 0; m < num_grid; m++) // :1795-1812
+	{
+		const int temp_row = m / col, temp_col = m % col;
+		if (temp_row >= 1 && temp_row <= row - 2 && temp_col >= 1 && temp_col <= col - 2)
+			for (int j = -1; j <= 1; j++)
+				for (int k = -1; k <= 1; k++)
+				{
+					grid[m].neighbor_min_z = (grid[m].neighbor_min_z < grid[m + j * col + k].min_z) ? grid[m].neighbor_min_z : grid[m + j * col + k].min_z;
+					if (grid[m + j * col + k].pts_count > reliable_grid_pts_count_thre)
+						grid[m].reliable_neighbor_grid_num++;
+				}
+	}
+	std::vector<Cloud> grid_ground_pcs((size_t)num_grid), grid_unground_pcs((size_t)num_grid);
+	for (int i = 0; i < num_grid; i++) // :1832-1935
+	{
+		if (grid[i].pts_count >= min_grid_pt_num && grid[i].reliable_neighbor_grid_num >= P.reliable_neighbor_grid_num_thre)
+		{
+			int ground_random_down_rate_temp = ground_random_down_rate;
+			int nonground_random_down_rate_temp = nonground_random_down_rate;
+			distance_weight = 1.0 * standard_distance / (grid[i].dist2station + 0.0001);
+			if (dw_method == 1)
+			{
+				ground_random_down_rate_temp = (int)(distance_weight * ground_random_down_rate + 1);
+				nonground_random_down_rate_temp = (int)(distance_weight * nonground_random_down_rate + 1);
+			}
+			else if (dw_method == 2)
+			{
+				ground_random_down_rate_temp = (int)(distance_weight * distance_weight * ground_random_down_rate + 1);
+				nonground_random_down_rate_temp = (int)(distance_weight * distance_weight * nonground_random_down_rate + 1);
+			}
+			if (grid[i].min_z - grid[i].neighbor_min_z < neighbor_height_diff)
+			{
+				for (int j = 0; j < (int)grid[i].point_id.size(); j++)
+				{
+					Pt &p = in[grid[i].point_id[j]];
+					if (p.z > grid[i].min_z_outlier_thre)
+					{
+						if (p.z - grid[i].min_z < max_height_difference)
+						{
+							if (j % ground_random_down_rate_temp == 0)
+							{
+								p.nx = 0.0;
+								p.ny = 0.0;
+								p.nz = 1.0;
+								grid_ground_pcs[i].push_back(p);
+							}
+						}
+						else if (j % nonground_random_down_rate_temp == 0 || p.intensity > intensity_thre)
+						{
+							p.d3 = p.z - grid[i].min_z;
+							grid_unground_pcs[i].push_back(p);
+						}
+					}
+				}
+			}
+			else
+			{
+				for (int j = 0; j < (int)grid[i].point_id.size(); j++)
+				{
+					Pt &p = in[grid[i].point_id[j]];
+					if (p.z > grid[i].min_z_outlier_thre && (j % nonground_random_down_rate_temp == 0 || p.intensity > intensity_thre))
+					{
+						p.d3 = p.z - grid[i].neighbor_min_z;
+						grid_unground_pcs[i].push_back(p);
+					}
+				}
+			}
+		}
+	}
+	for (int i = 0; i < num_grid; i++) // :1938-1942
+	{
+		ground.insert(ground.end(), grid_ground_pcs[i].begin(), grid_ground_pcs[i].end());
+		unground.insert(unground.end(), grid_unground_pcs[i].begin(), grid_unground_pcs[i].end());
+	}
+	if (!P.fixed_num_downsampling) // :1955-1968
+	{
+		for (int i = 0; i < (int)ground.size(); i++)
+			if (i % P.ground_random_down_down_rate == 0)
+				ground_down.push_back(ground[i]);
+	}
+	else
+	{
+		ground_down = ground; // random_downsample_pcl(cloud_ground, cloud_ground_down, down_ground_fixed_num)
+		random_downsample(ground_down, P.down_ground_fixed_num, P.rng_seed, 12);
+	}
+	return 0;
+}
+
 struct Quat
 {
 	double w, x, y, z;
@@ -1710,6 +1903,30 @@ namespace
 
 extern "C"
 {
+
+	// fast_ground_filter: same contract as mulls_ground_filter in include/mulls_hip.h
+	int mulls_oracle_ground_filter(const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *params, void *ground, uint32_t cap_ground,
+								   void *ground_down, uint32_t cap_ground_down, void *unground, uint32_t cap_unground, uint32_t n_out[3])
+	{
+		Cloud in(n), g, gd, u;
+		for (uint32_t i = 0; i < n; i++)
+			std::memcpy(&in[i], (const unsigned char *)pts + (size_t)i * stride, sizeof(Pt));
+		const int rc = ground_filter_impl(in, *params, g, gd, u);
+		if (rc != 0)
+			return rc;
+		auto put = [](const Cloud &c, void *dst, uint32_t cap) {
+			const size_t k = std::min<size_t>(c.size(), cap);
+			if (k)
+				std::memcpy(dst, c.data(), k * sizeof(Pt));
+		};
+		put(g, ground, cap_ground);
+		put(gd, ground_down, cap_ground_down);
+		put(u, unground, cap_unground);
+		n_out[0] = (uint32_t)g.size();
+		n_out[1] = (uint32_t)gd.size();
+		n_out[2] = (uint32_t)u.size();
+		return 0;
+	}
 
 	// operator census (see g_census): copies the eight counters, optionally resetting them
 	void mulls_oracle_census(unsigned long long out[8], int reset)

@@ -160,3 +160,22 @@ def census(reset=False):
     lib().mulls_oracle_census(out, int(reset))
     names = ("radius_tests", "radius_equal", "rejector_tests", "rejector_equal", "rejector_nan", "brute_queries", "brute_ties")
     return {n: int(out[i]) for i, n in enumerate(names)}
+
+
+def _ground_filter(fn, pts, params):
+    pts = abi.as_points(pts)
+    n = len(pts)
+    outs = [np.zeros(max(n, 1), abi.POINT_DTYPE) for _ in range(3)]
+    raw = [np.zeros(max(n, 1) * abi.POINT_BYTES, np.uint8) for _ in range(3)]
+    nout = (C.c_uint32 * 3)()
+    rc = fn(pts.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(abi.POINT_BYTES), C.byref(params), raw[0].ctypes.data_as(C.c_void_p), C.c_uint32(n),
+            raw[1].ctypes.data_as(C.c_void_p), C.c_uint32(n), raw[2].ctypes.data_as(C.c_void_p), C.c_uint32(n), nout)
+    if rc != 0:
+        raise RuntimeError("ground filter returned %d" % rc)
+    # raw 48-byte records (every byte: data[3] carries the height above ground)
+    return [raw[k][: nout[k] * abi.POINT_BYTES].reshape(nout[k], abi.POINT_BYTES).copy() for k in range(3)]
+
+
+def ground_filter(pts, params):
+    """CFilter::fast_ground_filter, oracle restatement.  Returns (ground, ground_down, unground) as (n, 48) uint8 record arrays."""
+    return _ground_filter(lib().mulls_oracle_ground_filter, pts, params)

@@ -60,3 +60,10 @@ def map_update(map_clouds, map_pose, frame_down, frame_pose, params):
     from oracle import pyoracle
 
     return pyoracle.map_update(map_clouds, map_pose, frame_down, frame_pose, params, fn=lib().mulls_ref_map_update)
+
+
+def ground_filter(pts, params):
+    """CFilter::fast_ground_filter, the reference's own lines (cfilter.hpp:1658-2036)."""
+    from oracle import pyoracle
+
+    return pyoracle._ground_filter(lib().mulls_ref_ground_filter, pts, params)

@@ -34,6 +34,8 @@ template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
+	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell, cfilter.hpp:2038-2076): not extracted, never reached by the pin
+	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
 #include "cfilter_body.inc"
 };
 
@@ -62,6 +64,35 @@ void fill_cloud(const mulls_cloud &c, pcTPtr &out)
 } // namespace
 
 static void fill_constraint(const mulls_pair *pair, lo::constraint_t &con);
+
+// CFilter::fast_ground_filter, the reference's own lines (cfilter.hpp:1658-2036), same contract as mulls_ground_filter.  The
+// fixed-number branch ends in pcl::RandomSample (time-seeded upstream): not comparable, refused here.
+extern "C" int mulls_ref_ground_filter(const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *P, void *ground, uint32_t cap_ground,
+										   void *ground_down, uint32_t cap_ground_down, void *unground, uint32_t cap_unground, uint32_t n_out[3])
+{
+	if (P->fixed_num_downsampling || P->estimate_ground_normal_method != 0)
+		return MULLS_E_UNSUPPORTED;
+	pcTPtr in(new pcT), g(new pcT), gd(new pcT), u(new pcT), curb(new pcT);
+	mulls_cloud c = {pts, n, stride};
+	fill_cloud(c, in);
+	lo::CFilter<Point_T> cf;
+	cf.fast_ground_filter(in, g, gd, u, curb, P->min_grid_pt_num, P->grid_resolution, P->max_height_difference, P->neighbor_height_diff, P->max_ground_height,
+						  P->ground_random_down_rate, P->ground_random_down_down_rate, P->nonground_random_down_rate, P->reliable_neighbor_grid_num_thre,
+						  P->estimate_ground_normal_method, 2.0f, P->distance_weight_downsampling_method, P->standard_distance, false, P->down_ground_fixed_num,
+						  false, P->intensity_thre, P->apply_grid_wise_outlier_filter != 0, P->outlier_std_scale);
+	auto put = [](const pcTPtr &cl, void *dst, uint32_t cap) {
+		const size_t k = std::min<size_t>(cl->points.size(), cap);
+		for (size_t i = 0; i < k; i++)
+			std::memcpy((unsigned char *)dst + i * sizeof(Point_T), &cl->points[i], sizeof(Point_T));
+	};
+	put(g, ground, cap_ground);
+	put(gd, ground_down, cap_ground_down);
+	put(u, unground, cap_unground);
+	n_out[0] = (uint32_t)g->points.size();
+	n_out[1] = (uint32_t)gd->points.size();
+	n_out[2] = (uint32_t)u->points.size();
+	return 0;
+}
 
 extern "C" int mulls_ref_icp_3dof_ground(const mulls_pair *pair, const mulls_params *P, mulls_result *R)
 {

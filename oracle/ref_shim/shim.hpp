@@ -416,6 +416,7 @@ struct PointCloud
 	std::vector<PointT> points;
 	size_t size() const { return points.size(); }
 	void push_back(const PointT &p) { points.push_back(p); }
+	void swap(PointCloud<PointT> &o) { points.swap(o.points); }
 };
 
 struct Correspondence
@@ -653,6 +654,22 @@ struct RandomSample
 	}
 };
 } // namespace pcl
+
+// what CFilter::fast_ground_filter names besides the point cloud types: the normal cloud of its PCA branches and the PCA estimator
+// (estimate_ground_normal_method 1 / 2, never taken by the pin: method 0) — declared so that the reference's lines compile, aborting if reached
+namespace pcl
+{
+struct Normal
+{
+	float normal_x = 0, normal_y = 0, normal_z = 0, curvature = 0;
+};
+} // namespace pcl
+template <typename PointT>
+struct PrincipleComponentAnalysis
+{
+	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+};
 
 // OpenMP calls made by CFilter::apply_motion_compensation
 inline void omp_set_num_threads(int) {}
