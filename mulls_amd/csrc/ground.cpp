@@ -13,16 +13,16 @@
 
 #include <hip/hip_vector_types.h>
 
-struct GfOut
+struct GfOut // head of the device-side state (k_ground.hip: GfState)
 {
 	uint32_t n_ground, n_unground, n_high, error;
 	uint32_t row, col;
 	float mean_height;
-	uint32_t pad_;
+	uint32_t n_cand;
 };
 int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mulls_ground_params &P, uint32_t *ids, uint16_t *cellof, uint8_t *code, float *d3v,
-						 float4 *ground, float4 *unground, uint32_t *tables, GfOut *out);
-size_t ground_filter_table_bytes();
+						 float4 *ground, float4 *unground, void *aux);
+size_t ground_filter_aux_bytes(uint32_t n);
 
 extern "C"
 {
@@ -81,11 +81,10 @@ extern "C"
 		}
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
-		// one arena: scan | ground | unground | ids | d3v | cellof | code | per-cell tables | out
+		// one arena: scan | ground | unground | ids | d3v | cellof | code | state, block / segment counters, per-cell tables
 		const size_t rec = (size_t)n * MULLS_POINT_BYTES;
 		const size_t o_ground = rec, o_unground = 2 * rec, o_ids = 3 * rec, o_d3 = o_ids + (size_t)n * 4, o_cell = o_d3 + (size_t)n * 4,
-					 o_code = o_cell + (size_t)n * 2, o_tab = (o_code + n + 15) & ~(size_t)15, o_out = o_tab + ground_filter_table_bytes(),
-					 total = o_out + sizeof(GfOut);
+					 o_code = o_cell + (size_t)n * 2, o_aux = (o_code + n + 255) & ~(size_t)255, total = o_aux + ground_filter_aux_bytes(n);
 		if (ctx->gf_cap < total)
 		{
 			if (ctx->gf_buf)
@@ -102,17 +101,17 @@ extern "C"
 			HIPCHK(ctx, hipMemcpy2DAsync(base, MULLS_POINT_BYTES, pts, stride, MULLS_POINT_BYTES, n, hipMemcpyHostToDevice, st));
 		if (launch_ground_filter(st, reinterpret_cast<const float4 *>(base), n, *P, reinterpret_cast<uint32_t *>(base + o_ids), reinterpret_cast<uint16_t *>(base + o_cell),
 								 base + o_code, reinterpret_cast<float *>(base + o_d3), reinterpret_cast<float4 *>(base + o_ground),
-								 reinterpret_cast<float4 *>(base + o_unground), reinterpret_cast<uint32_t *>(base + o_tab), reinterpret_cast<GfOut *>(base + o_out)) != 0)
+								 reinterpret_cast<float4 *>(base + o_unground), base + o_aux) != 0)
 		{
-			ctx->err = "could not raise the dynamic LDS limit of k_ground_filter";
+			ctx->err = "mulls_ground_filter: launch failed";
 			return MULLS_E_HIP;
 		}
 		GfOut out;
-		HIPCHK(ctx, hipMemcpyAsync(&out, base + o_out, sizeof(out), hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipMemcpyAsync(&out, base + o_aux, sizeof(out), hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		if (out.error)
 		{
-			ctx->err = "mulls_ground_filter: the grid has more than 65536 cells (grid_resolution too fine for this scan's extent)";
+			ctx->err = "mulls_ground_filter: the grid has too many cells (more than 65536, or more than 64 M table entries: grid_resolution too fine for this scan's extent)";
 			return MULLS_E_UNSUPPORTED;
 		}
 		std::vector<unsigned char> g((size_t)out.n_ground * MULLS_POINT_BYTES);

@@ -1,43 +1,50 @@
 // k_ground.hip — CFilter::fast_ground_filter (include/common/cfilter.hpp:1658-2036, estimate_ground_normal_method 0) on the device:
-// the first stage of MULLS's feature extraction.  ONE 512-lane workgroup per scan carries the scan through the
-// whole filter (scans are independent: a batch of scans is a batch of workgroups); everything the reference decides with its
-// sequential loops is reproduced bit for bit, outputs in the reference's order:
+// the first stage of MULLS's feature extraction.  Everything the reference decides with its sequential loops is
+// reproduced bit for bit, outputs in the reference's order; the order-sensitive steps are expressed as order-free ones:
 //
-//   A  approximate mean height: the sequential float sum of every 100th z (:1689-1698)                     one lane, values staged in LDS
-//   B  bounding box (utility.hpp:817-848), grid geometry (:1709-1713, double arithmetic)
-//   C  one walk over the points, each wave over its own contiguous range in steps of 64: cell of every point (:1730-1732), per-wave
-//      per-cell counts of the ground candidates (z <= mean + max_ground_height), per-cell minimum z and first candidate (LDS atomics)
-//   C2 per-cell totals, per-wave bases, prefix sum over the cells: where each cell's list starts in the cell-sorted order
-//   D  second walk: the candidates' indices scattered into that order — a STABLE counting sort, so every cell's list is in input
-//      order like the reference's point_id vectors; the kept high points (z above the threshold, :1742-1754) counted per wave
-//   E  per cell: optional outlier threshold (sequential double sums over the list, :1770-1790), then the 3x3 neighbourhood minimum
-//      and reliable-neighbour count (:1795-1812), the cell's verdict and down-sampling rates (:1834-1852)
-//   F  per sorted entry: ground / non-ground / dropped (:1853-1907) with its rank in the cell's list as the reference's `j`, then a
-//      stable compaction of both kinds into the output clouds; the kept high points first in the non-ground cloud, in input order
-//
-// The per-cell tables live in global memory (one workgroup = one CU: they stay in its caches; 64 B per cell), up to
-// MULLS_GF_MAXCELLS cells — a 64-beam scan's bounding box at the KITTI configuration's 2.5 m cells is 96 x 96.
+//   k_gf_bbox      bounding box (utility.hpp:817-848): ordered-key atomicMin / atomicMax
+//   k_gf_setup     approximate mean height = the SEQUENTIAL float sum of every 100th z (:1689-1698; one lane, values staged in LDS);
+//                  grid geometry (:1709-1713, double arithmetic); table initialisation
+//   k_gf_count     the scan in segments of 1024 points, one wave per segment, 64 points per step: cell of every point (:1730-1732),
+//                  per-segment per-cell counts of the ground candidates (z <= mean + max_ground_height), per-cell minimum z and
+//                  first candidate (atomicMin: order-free)
+//   k_gf_prefix    per cell: candidates in the segments before each segment; prefix sum over the cells = where each cell's list starts
+//   k_gf_scatter   the candidates' indices into the cell-sorted order — a STABLE counting sort (rank inside a 64-point step by a
+//                  readlane loop, running bases per segment: no atomic decides an order), so every cell's list is in input order like the
+//                  reference's point_id vectors; the kept high points (z above the threshold, :1742-1754) counted per segment
+//   k_gf_outlier   optional per-cell outlier threshold (:1770-1790): double sums over the cell's list in its order (one wave per cell)
+//   k_gf_cells1/2  per cell: the 3x3 neighbourhood minimum, reliable-neighbour count (:1795-1812) and the cell's verdict (:1834, :1853)
+//   k_gf_verdict   per sorted entry: ground / non-ground / dropped (:1853-1907), its rank in the cell's list being the reference's `j`;
+//                  per-block counts
+//   k_gf_scan      prefix sums over the blocks and the segments' high points
+//   k_gf_write     stable compaction into the output clouds; the kept high points first (input order) in the non-ground cloud
+#include <algorithm>
+
 #include "../../include/mulls_hip.h"
 #include "device_util.h"
 
-#define MULLS_GF_BLOCK 512
-#define MULLS_GF_WAVES (MULLS_GF_BLOCK / 64)
+#define MULLS_GF_BLOCK 256
+#define MULLS_GF_SEG 1024u // points per segment (one wave walks a segment in 16 steps of 64)
 #define MULLS_GF_MAXCELLS 65536u
-#define MULLS_GF_STAGE 4096u // z samples of phase A staged per round
+#define MULLS_GF_STAGE 4096u // z samples staged per round (k_gf_setup)
 
-struct GfOut // one per scan, read back by the host
+struct GfState // device-resident state of one call; the head (GfOut) is read back by the host
 {
 	uint32_t n_ground, n_unground, n_high, error; // error: 1 = grid too large
 	uint32_t row, col;
 	float mean_height;
-	uint32_t pad_;
+	uint32_t n_cand;
+	// ---- device only
+	uint32_t box[4]; // ordered keys: min x, min y, max x, max y
+	float thre;		 // non_ground_height_thre
+	int num_grid;
+	double min_x, min_y;
 };
 
 namespace
 {
 // (int)x as the reference's x86 build evaluates it: cvttss2si returns INT_MIN for NaN and for values outside the int range
 __device__ __forceinline__ int f2i_x86(float v) { return (v >= -2147483648.0f && v < 2147483648.0f) ? (int)v : (int)0x80000000; }
-
 // the reference's `j % rate == 0` with int operands (rate 0 would be a division by zero upstream: never produced, the rates are ... + 1)
 __device__ __forceinline__ bool every(int j, int rate) { return rate != 0 && j % rate == 0; }
 
@@ -64,476 +71,650 @@ __device__ __forceinline__ GfRates gf_rates(const mulls_ground_params &P, float 
 }
 __device__ __forceinline__ float gf_dist(const float4 p) { return std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z); }
 
-// exclusive prefix sum of one value per lane over the workgroup (512 lanes); total in *total (LDS scratch: MULLS_GF_WAVES + 1 words)
-__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t *scratch, uint32_t *total)
+// the cell of a point (:1730-1733): float coordinate minus double bound, divided by the float resolution, in double
+__device__ __forceinline__ int gf_cell(const GfState &S, const mulls_ground_params &P, const float4 p)
 {
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t incl = v;
-	for (int off = 1; off < 64; off <<= 1)
+	const int temp_col = (int)floor((p.x - S.min_x) / P.grid_resolution);
+	const int temp_row = (int)floor((p.y - S.min_y) / P.grid_resolution);
+	const int temp_id = temp_row * (int)S.col + temp_col;
+	return (temp_id >= 0 && temp_id < S.num_grid) ? temp_id : -1;
+}
+// is a high point kept (:1742-1754)?  The rates come from the cell's dist2station as it stands when point j is reached: the point's
+// own distance while the cell has no candidate yet (:1734-1737 overwrites it on every such point), the first candidate's afterwards.
+__device__ __forceinline__ bool gf_high_keep(const mulls_ground_params &P, const float4 *__restrict__ pts, const uint32_t *__restrict__ first, uint32_t j,
+											  const float4 p, float intensity, int cell)
+{
+	float d2s = 0.001f; // grid_t()
+	if (P.distance_weight_downsampling_method > 0)
 	{
-		const uint32_t o = __shfl_up(incl, off);
-		if (lane >= off)
-			incl += o;
+		const uint32_t jc = first[cell];
+		d2s = j <= jc ? gf_dist(p) : gf_dist(pts[(size_t)jc * 3]);
 	}
-	__syncthreads();
-	if (lane == 63)
-		scratch[wave] = incl;
-	__syncthreads();
-	uint32_t base = 0, tot = 0;
-	for (int w = 0; w < MULLS_GF_WAVES; w++)
-	{
-		if (w < wave)
-			base += scratch[w];
-		tot += scratch[w];
-	}
-	*total = tot;
-	return base + incl - v;
+	const GfRates r = gf_rates(P, d2s);
+	return every((int)j, r.nonground) || intensity > P.intensity_thre;
+}
+
+// per-cell tables inside one arena of uint32 words, `nc` cells, `ns` segments
+struct GfTables
+{
+	uint32_t *T;	  // [ns][nc] per-segment candidate counts -> candidates of the cell in the segments before
+	uint32_t *minz;	  // [nc] ordered key of the minimum candidate z
+	uint32_t *first;  // [nc] first candidate (input index)
+	uint32_t *cstart; // [nc + 1] start of the cell's list in the sorted order
+	float *c_minz;	  // [nc] min_z (after the outlier clamp)
+	float *c_nbr;	  // [nc] neighbor_min_z
+	float *c_out;	  // [nc] min_z_outlier_thre
+	uint32_t *c_flag; // [nc] bit0 eligible, bit1 ground cell
+};
+__device__ __forceinline__ GfTables gf_tables(uint32_t *arena, uint32_t nc, uint32_t ns)
+{
+	GfTables t;
+	t.minz = arena;
+	t.first = t.minz + nc;
+	t.cstart = t.first + nc;
+	t.c_minz = reinterpret_cast<float *>(t.cstart + nc + 1);
+	t.c_nbr = t.c_minz + nc;
+	t.c_out = t.c_nbr + nc;
+	t.c_flag = reinterpret_cast<uint32_t *>(t.c_out + nc);
+	t.T = t.c_flag + nc;
+	(void)ns;
+	return t;
 }
 } // namespace
 
-// pts: the scan as 48-byte records (3 float4 per point).  ids / cellof / code / d3v: scratch of n entries each.  ground / unground:
-// output records (capacity n points each).
-__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_ground_filter(const float4 *__restrict__ pts, uint32_t n, mulls_ground_params P, uint32_t *__restrict__ ids,
-																	uint16_t *__restrict__ cellof, uint8_t *__restrict__ code, float *__restrict__ d3v,
-																	float4 *__restrict__ ground, float4 *__restrict__ unground, uint32_t *tables, GfOut *__restrict__ out)
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_bbox(const float4 *__restrict__ pts, uint32_t n, GfState *S)
+{
+	float mnx = __builtin_inff(), mny = __builtin_inff(), mxx = -__builtin_inff(), mxy = -__builtin_inff();
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+	{
+		const float4 p = pts[(size_t)j * 3];
+		mnx = p.x < mnx ? p.x : mnx; // `if (min_x > x) min_x = x`: NaN never taken
+		mny = p.y < mny ? p.y : mny;
+		mxx = p.x > mxx ? p.x : mxx;
+		mxy = p.y > mxy ? p.y : mxy;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		const float a = __shfl_down(mnx, off), b = __shfl_down(mny, off), c = __shfl_down(mxx, off), d = __shfl_down(mxy, off);
+		mnx = a < mnx ? a : mnx;
+		mny = b < mny ? b : mny;
+		mxx = c > mxx ? c : mxx;
+		mxy = d > mxy ? d : mxy;
+	}
+	__shared__ float s_red[4 * (MULLS_GF_BLOCK / 64)];
+	if ((threadIdx.x & 63) == 0)
+	{
+		s_red[4 * (threadIdx.x >> 6) + 0] = mnx;
+		s_red[4 * (threadIdx.x >> 6) + 1] = mny;
+		s_red[4 * (threadIdx.x >> 6) + 2] = mxx;
+		s_red[4 * (threadIdx.x >> 6) + 3] = mxy;
+	}
+	__syncthreads();
+	if (threadIdx.x < 4)
+	{
+		float v = s_red[threadIdx.x];
+		for (int w = 1; w < MULLS_GF_BLOCK / 64; w++)
+		{
+			const float o = s_red[4 * w + threadIdx.x];
+			v = threadIdx.x < 2 ? (o < v ? o : v) : (o > v ? o : v);
+		}
+		if (threadIdx.x < 2)
+			atomicMin(&S->box[threadIdx.x], f2ord(v)); // one atomic per block and side
+		else
+			atomicMax(&S->box[threadIdx.x], f2ord(v));
+	}
+}
+
+__global__ __launch_bounds__(512) void k_gf_setup(const float4 *__restrict__ pts, uint32_t n, mulls_ground_params P, GfState *S, uint32_t max_cells)
 {
 	__shared__ float s_stage[MULLS_GF_STAGE];
-	__shared__ float s_red[6 * MULLS_GF_WAVES];
-	__shared__ uint32_t s_scan[MULLS_GF_WAVES + 1], s_high[MULLS_GF_WAVES + 1];
-	__shared__ float s_mean, s_thre;
-	__shared__ double s_minx, s_miny;
-	__shared__ int s_row, s_col, s_err;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-	// ---- A: approximate mean height ----------------------------------------------------------------------------------------------
+	__shared__ float s_sum;
 	const uint32_t n_samples = (n + 99u) / 100u;
 	if (threadIdx.x == 0)
-		s_mean = 0.001f; // float sum_height = 0.001
+		s_sum = 0.001f; // float sum_height = 0.001
 	__syncthreads();
 	for (uint32_t s0 = 0; s0 < n_samples; s0 += MULLS_GF_STAGE)
 	{
-		for (uint32_t s = s0 + threadIdx.x; s < min(n_samples, s0 + MULLS_GF_STAGE); s += MULLS_GF_BLOCK)
+		for (uint32_t s = s0 + threadIdx.x; s < min(n_samples, s0 + MULLS_GF_STAGE); s += blockDim.x)
 			s_stage[s - s0] = pts[(size_t)(s * 100u) * 3].z;
 		__syncthreads();
 		if (threadIdx.x == 0)
 		{
-			float sum = s_mean;
-			for (uint32_t s = s0; s < min(n_samples, s0 + MULLS_GF_STAGE); s++)
-				sum += s_stage[s - s0];
-			s_mean = sum;
-		}
-		__syncthreads();
-	}
-	// ---- B: bounding box, grid --------------------------------------------------------------------------------------------------
-	{
-		float mnx = __builtin_inff(), mny = __builtin_inff(), mxx = -__builtin_inff(), mxy = -__builtin_inff();
-		for (uint32_t j = threadIdx.x; j < n; j += MULLS_GF_BLOCK)
-		{
-			const float4 p = pts[(size_t)j * 3];
-			mnx = p.x < mnx ? p.x : mnx; // `if (min_x > x) min_x = x`: NaN never taken
-			mny = p.y < mny ? p.y : mny;
-			mxx = p.x > mxx ? p.x : mxx;
-			mxy = p.y > mxy ? p.y : mxy;
-		}
-		for (int off = 32; off > 0; off >>= 1)
-		{
-			const float a = __shfl_down(mnx, off), b = __shfl_down(mny, off), c = __shfl_down(mxx, off), d = __shfl_down(mxy, off);
-			mnx = a < mnx ? a : mnx;
-			mny = b < mny ? b : mny;
-			mxx = c > mxx ? c : mxx;
-			mxy = d > mxy ? d : mxy;
-		}
-		if (lane == 0)
-		{
-			s_red[wave * 4 + 0] = mnx;
-			s_red[wave * 4 + 1] = mny;
-			s_red[wave * 4 + 2] = mxx;
-			s_red[wave * 4 + 3] = mxy;
-		}
-		__syncthreads();
-		if (threadIdx.x == 0)
-		{
-			float a = s_red[0], b = s_red[1], c = s_red[2], d = s_red[3];
-			for (int w = 1; w < MULLS_GF_WAVES; w++)
+			float sum = s_sum;
+			const uint32_t cnt = min(n_samples, s0 + MULLS_GF_STAGE) - s0;
+			uint32_t s = 0;
+			for (; s + 16 <= cnt; s += 16) // 16 LDS loads in flight, then the chain of adds (the order of the additions is the reference's)
 			{
-				a = s_red[w * 4] < a ? s_red[w * 4] : a;
-				b = s_red[w * 4 + 1] < b ? s_red[w * 4 + 1] : b;
-				c = s_red[w * 4 + 2] > c ? s_red[w * 4 + 2] : c;
-				d = s_red[w * 4 + 3] > d ? s_red[w * 4 + 3] : d;
+				float v[16];
+#pragma unroll
+				for (int u = 0; u < 16; u++)
+					v[u] = s_stage[s + u];
+#pragma unroll
+				for (int u = 0; u < 16; u++)
+					sum += v[u];
 			}
-			// bounds_t holds doubles initialised to +-DBL_MAX: an empty side stays there (n >= 1 here)
-			const double min_x = a, min_y = b, max_x = c, max_y = d;
-			s_minx = min_x;
-			s_miny = min_y;
-			s_row = (int)ceil((max_y - min_y) / P.grid_resolution);
-			s_col = (int)ceil((max_x - min_x) / P.grid_resolution);
-			const float appro_mean_height = s_mean / (int)n_samples; // sum_height / count_checkpoint
-			s_mean = appro_mean_height;
-			s_thre = appro_mean_height + P.max_ground_height; // non_ground_height_thre
-			const long ng = (long)s_row * (long)s_col;
-			s_err = ng > (long)MULLS_GF_MAXCELLS ? 1 : 0;
+			for (; s < cnt; s++)
+				sum += s_stage[s];
+			s_sum = sum;
 		}
 		__syncthreads();
 	}
-	const int row = s_row, col = s_col;
-	const int num_grid = (row > 0 && col > 0) ? row * col : 0;
-	const float appro_mean_height = s_mean, non_ground_height_thre = s_thre;
-	const double min_x = s_minx, min_y = s_miny;
-	if (s_err)
+	if (threadIdx.x == 0)
 	{
-		if (threadIdx.x == 0)
-		{
-			out->error = 1u;
-			out->n_ground = out->n_unground = out->n_high = 0u;
-			out->row = (uint32_t)row;
-			out->col = (uint32_t)col;
-			out->mean_height = appro_mean_height;
-		}
+		// bounds_t holds doubles (n >= 1: every side is a point's coordinate)
+		const double min_x = ord2f(S->box[0]), min_y = ord2f(S->box[1]), max_x = ord2f(S->box[2]), max_y = ord2f(S->box[3]);
+		const int row = (int)ceil((max_y - min_y) / P.grid_resolution);
+		const int col = (int)ceil((max_x - min_x) / P.grid_resolution);
+		const float appro_mean_height = s_sum / (int)n_samples; // sum_height / count_checkpoint
+		const long ng = (row > 0 && col > 0) ? (long)row * (long)col : 0;
+		S->min_x = min_x;
+		S->min_y = min_y;
+		S->row = (uint32_t)row;
+		S->col = (uint32_t)col;
+		S->mean_height = appro_mean_height;
+		S->thre = appro_mean_height + P.max_ground_height; // non_ground_height_thre
+		S->error = ng > (long)max_cells ? 1u : 0u;
+		S->num_grid = S->error ? 0 : (int)ng;
+		S->n_ground = S->n_unground = S->n_high = S->n_cand = 0u;
+	}
+}
+
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_init(const GfState *S, uint32_t *arena, uint32_t ns)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const size_t total = (size_t)nc * ns;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+		t.T[i] = 0u;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += gridDim.x * blockDim.x)
+	{
+		t.minz[c] = f2ord(3.402823466e+38f); // FLT_MAX
+		t.first[c] = 0xffffffffu;
+	}
+}
+
+// one wave per segment; mode 0: counts (k_gf_count), mode 1: stable scatter + kept high points per segment (k_gf_scatter)
+template <int MODE>
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_walk(const float4 *__restrict__ pts, uint32_t n, mulls_ground_params P, const GfState *S, uint32_t *arena,
+															 uint32_t ns, uint32_t *__restrict__ ids, uint16_t *__restrict__ cellof, uint32_t *__restrict__ seg_high)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	if (!nc)
+	{
+		if (MODE == 1 && threadIdx.x == 0 && blockIdx.x == 0)
+			for (uint32_t s = 0; s < ns; s++)
+				seg_high[s] = 0u;
 		return;
 	}
-	// per-cell tables (global memory, 64 B per cell)
-	const uint32_t nc = (uint32_t)num_grid;
-	uint32_t *T = tables;								  // [MULLS_GF_WAVES][nc] per-wave counts -> running bases
-	uint32_t *minz = T + (size_t)MULLS_GF_WAVES * nc;	  // [nc] ordered key of the minimum candidate z (atomicMin)
-	uint32_t *first = minz + nc;						  // [nc] first candidate (input index, atomicMin)
-	uint32_t *cstart = first + nc;						  // [nc + 1] start of the cell's list in the sorted order
-	uint32_t *ccount = cstart + nc + 1;					  // [nc] candidates of the cell (pts_count)
-	float *c_minz = reinterpret_cast<float *>(ccount + nc); // [nc] min_z (after the outlier clamp)
-	float *c_nbr = c_minz + nc;							  // [nc] neighbor_min_z
-	float *c_out = c_nbr + nc;							  // [nc] min_z_outlier_thre
-	uint32_t *c_flag = reinterpret_cast<uint32_t *>(c_out + nc); // [nc] bit0 eligible, bit1 ground cell
-	for (uint32_t c = threadIdx.x; c < nc; c += MULLS_GF_BLOCK)
-	{
-		for (int w = 0; w < MULLS_GF_WAVES; w++)
-			T[w * nc + c] = 0;
-		minz[c] = f2ord(3.402823466e+38f); // FLT_MAX
-		first[c] = 0xffffffffu;
-	}
-	__threadfence();
-	__syncthreads();
-
-	// the cell of a point (:1730-1733): float coordinate minus double bound, divided by the float resolution, in double
-	auto cell_of = [&](const float4 p) -> int {
-		const int temp_col = (int)floor((p.x - min_x) / P.grid_resolution);
-		const int temp_row = (int)floor((p.y - min_y) / P.grid_resolution);
-		const int temp_id = temp_row * col + temp_col;
-		return (temp_id >= 0 && temp_id < num_grid) ? temp_id : -1;
-	};
-	// each wave walks its own contiguous range of the scan in steps of 64 points
-	const uint32_t per_wave = ((n + MULLS_GF_WAVES - 1) / MULLS_GF_WAVES + 63u) & ~63u;
-	const uint32_t w_begin = min(n, (uint32_t)wave * per_wave), w_end = min(n, w_begin + per_wave);
-
-	// ---- C: counts, minimum z and first candidate per cell -------------------------------------------------------------------------
-	for (uint32_t j0 = w_begin; j0 < w_end; j0 += 64)
-	{
-		const uint32_t j = j0 + lane;
-		int cell = -1;
-		bool cand = false;
-		if (j < w_end)
-		{
-			const float4 p = pts[(size_t)j * 3];
-			cell = cell_of(p);
-			cand = cell >= 0 && !(p.z > non_ground_height_thre) && p.z > -3.402823466e+38f; // else-branch of :1736, `z > underground_noise_thre`
-			if (cand)
-			{
-				atomicMin(&minz[cell], f2ord(p.z));
-				atomicMin(&first[cell], j);
-			}
-		}
-		// lanes of this step in the same cell: the last one adds the group's count to this wave's table (no atomics: one writer per cell)
-		uint32_t group = 0;
-		bool last = cand;
-#pragma unroll 8
-		for (int l = 0; l < 64; l++)
-		{
-			const int c = __builtin_amdgcn_readlane(cand ? cell : -2, l);
-			if (cand && c == cell)
-			{
-				group++;
-				if (l > lane)
-					last = false;
-			}
-		}
-		if (cand && last)
-			T[wave * nc + cell] += group;
-	}
-	__threadfence();
-	__syncthreads();
-	// ---- C2: totals, per-wave bases, cell starts ----------------------------------------------------------------------------------
-	{
-		// each lane owns the cells [c0, c1): their totals in a row, then the workgroup prefix
-		const uint32_t per_lane = (nc + MULLS_GF_BLOCK - 1) / MULLS_GF_BLOCK;
-		const uint32_t c0 = min(nc, threadIdx.x * per_lane), c1 = min(nc, c0 + per_lane);
-		uint32_t mine = 0;
-		for (uint32_t c = c0; c < c1; c++)
-		{
-			uint32_t run = 0;
-			for (int w = 0; w < MULLS_GF_WAVES; w++)
-			{
-				const uint32_t t = T[w * nc + c];
-				T[w * nc + c] = run; // candidates of this cell in the waves before w
-				run += t;
-			}
-			ccount[c] = run;
-			mine += run;
-		}
-		uint32_t total;
-		uint32_t base = block_exscan(mine, s_scan, &total);
-		for (uint32_t c = c0; c < c1; c++)
-		{
-			cstart[c] = base;
-			base += ccount[c];
-		}
-		if (threadIdx.x == 0)
-			cstart[nc] = total;
-		__threadfence();
-		__syncthreads();
-	}
-	const uint32_t n_cand = cstart[nc];
-	// ---- D: stable scatter of the candidates; kept high points counted per wave ---------------------------------------------------
+	const GfTables t = gf_tables(arena, nc, ns);
+	const int lane = threadIdx.x & 63;
+	const uint32_t seg = blockIdx.x * (MULLS_GF_BLOCK / 64) + (threadIdx.x >> 6);
+	if (seg >= ns)
+		return;
+	uint32_t *Tseg = t.T + (size_t)seg * nc;
+	const float thre = S->thre;
+	const uint32_t j_begin = seg * MULLS_GF_SEG, j_end = min(n, j_begin + MULLS_GF_SEG);
 	uint32_t high_kept = 0;
-	auto high_keep = [&](uint32_t j, const float4 p, const float4 q, int cell) -> bool {
-		// :1742-1754 — the rates come from the cell's dist2station as it stands when point j is reached: the point's own distance while
-		// the cell has no candidate yet (:1734-1737 overwrites it on every such point), the first candidate's afterwards
-		float d2s = 0.001f; // grid_t()
-		if (P.distance_weight_downsampling_method > 0)
-		{
-			const uint32_t jc = __hip_atomic_load(&first[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			d2s = j <= jc ? gf_dist(p) : gf_dist(pts[(size_t)jc * 3]);
-		}
-		const GfRates r = gf_rates(P, d2s);
-		return every((int)j, r.nonground) || q.x > P.intensity_thre;
-	};
-	for (uint32_t j0 = w_begin; j0 < w_end; j0 += 64)
+	for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64)
 	{
 		const uint32_t j = j0 + lane;
 		int cell = -1;
 		bool cand = false;
-		if (j < w_end)
+		float pz = 0.0f;
+		if (j < j_end)
 		{
 			const float4 p = pts[(size_t)j * 3];
-			cell = cell_of(p);
+			cell = gf_cell(*S, P, p);
 			if (cell >= 0)
 			{
-				if (p.z > non_ground_height_thre)
-					high_kept += high_keep(j, p, pts[(size_t)j * 3 + 2], cell) ? 1u : 0u;
+				if (p.z > thre)
+				{
+					if (MODE == 1)
+						high_kept += gf_high_keep(P, pts, t.first, j, p, pts[(size_t)j * 3 + 2].x, cell) ? 1u : 0u;
+				}
 				else
-					cand = p.z > -3.402823466e+38f;
+					cand = p.z > -3.402823466e+38f; // else-branch of :1736: `z > underground_noise_thre`
 			}
+			pz = p.z;
 		}
+		// lanes of this step in the same cell: rank by lane order; the last one advances this segment's entry (one writer per cell)
+		// and, in the counting pass, carries the group's minimum z and first point to the cell's tables (one atomic pair per group)
 		uint32_t group = 0, rank = 0;
 		bool last = cand;
+		float gmin = pz;
+		int gfirst = lane;
 #pragma unroll 8
 		for (int l = 0; l < 64; l++)
 		{
 			const int c = __builtin_amdgcn_readlane(cand ? cell : -2, l);
+			const float zl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), l));
 			if (cand && c == cell)
 			{
 				group++;
+				gmin = zl < gmin ? zl : gmin;
+				gfirst = l < gfirst ? l : gfirst;
 				if (l < lane)
 					rank++;
 				if (l > lane)
 					last = false;
 			}
 		}
-		if (cand)
+		if (MODE == 0 && cand && last)
 		{
-			const uint32_t pos = cstart[cell] + T[wave * nc + cell] + rank;
+			atomicMin(&t.minz[cell], f2ord(gmin));
+			atomicMin(&t.first[cell], j0 + (uint32_t)gfirst);
+		}
+		if (MODE == 1 && cand)
+		{
+			const uint32_t pos = t.cstart[cell] + Tseg[cell] + rank;
 			ids[pos] = j;
 			cellof[pos] = (uint16_t)cell;
 		}
-		// every lane of the group has read the running base: now the last one advances it (the step is one wave: in order)
-		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_wave_barrier(); // every lane of the group has read the running base before the last one advances it
 		if (cand && last)
-			T[wave * nc + cell] += group;
+			Tseg[cell] += group;
 		__builtin_amdgcn_wave_barrier();
 	}
-	for (int off = 32; off > 0; off >>= 1)
-		high_kept += __shfl_down(high_kept, off);
-	if (lane == 0)
-		s_high[wave] = high_kept;
-	__threadfence();
-	__syncthreads();
-	// ---- E: per cell — outlier threshold, neighbourhood, verdict ------------------------------------------------------------------
-	for (uint32_t c = threadIdx.x; c < nc; c += MULLS_GF_BLOCK)
+	if (MODE == 1)
 	{
-		float mz = ord2f(__hip_atomic_load(&minz[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); // FLT_MAX for a cell without candidates
-		float thre = -3.402823466e+38f;
-		const uint32_t cnt = ccount[c];
-		if (P.apply_grid_wise_outlier_filter && (int)cnt >= P.min_grid_pt_num)
+		for (int off = 32; off > 0; off >>= 1)
+			high_kept += __shfl_down(high_kept, off);
+		if (lane == 0)
+			seg_high[seg] = high_kept;
+	}
+}
+
+// per cell: counts of the segments -> candidates in the segments before; cell starts.  One workgroup of 1024 lanes.
+__global__ __launch_bounds__(1024) void k_gf_prefix(GfState *S, uint32_t *arena, uint32_t ns)
+{
+	__shared__ uint32_t s_scan[16];
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// lanes take cells round-robin for the column sums (coalesced rows of T), then contiguous runs for the prefix over the cells
+	for (uint32_t c = threadIdx.x; c < nc; c += 1024)
+	{
+		uint32_t run = 0;
+		for (uint32_t s = 0; s < ns; s++)
 		{
-			double sum_z = 0, sum_z2 = 0;
-			for (uint32_t k = 0; k < cnt; k++)
-				sum_z += pts[(size_t)ids[cstart[c] + k] * 3].z;
-			const double mean_z = sum_z / (int)cnt;
-			for (uint32_t k = 0; k < cnt; k++)
-			{
-				const float z = pts[(size_t)ids[cstart[c] + k] * 3].z;
-				sum_z2 += (z - mean_z) * (z - mean_z);
-			}
-			const double std_z = std::sqrt(sum_z2 / (int)cnt);
-			thre = (float)(mean_z - P.outlier_std_scale * std_z);
-			mz = (mz > thre) ? mz : thre; // max_(min_z, min_z_outlier_thre)
+			const uint32_t v = t.T[(size_t)s * nc + c];
+			t.T[(size_t)s * nc + c] = run;
+			run += v;
 		}
-		c_minz[c] = mz;
-		c_out[c] = thre;
+		t.cstart[c] = run; // the cell's total, for now
 	}
 	__threadfence();
 	__syncthreads();
-	for (uint32_t m = threadIdx.x; m < nc; m += MULLS_GF_BLOCK)
+	const uint32_t per_lane = (nc + 1023u) / 1024u;
+	const uint32_t c0 = min(nc, threadIdx.x * per_lane), c1 = min(nc, c0 + per_lane);
+	uint32_t mine = 0;
+	for (uint32_t c = c0; c < c1; c++)
+		mine += t.cstart[c];
+	uint32_t incl = mine;
+	for (int off = 1; off < 64; off <<= 1)
 	{
-		const int temp_row = (int)m / col, temp_col = (int)m % col;
-		float nbr = c_minz[m]; // neighbor_min_z starts as min_z (both FLT_MAX for an empty cell)
-		int reliable = 0;
-		if (temp_row >= 1 && temp_row <= row - 2 && temp_col >= 1 && temp_col <= col - 2)
-			for (int jj = -1; jj <= 1; jj++)
-				for (int kk = -1; kk <= 1; kk++)
-				{
-					const int o = (int)m + jj * col + kk;
-					nbr = (nbr < c_minz[o]) ? nbr : c_minz[o];
-					if ((int)ccount[o] > P.min_grid_pt_num - 1)
-						reliable++;
-				}
-		c_nbr[m] = nbr;
-		uint32_t f = 0;
-		if ((int)ccount[m] >= P.min_grid_pt_num && reliable >= P.reliable_neighbor_grid_num_thre)
-			f = 1u | ((c_minz[m] - nbr < P.neighbor_height_diff) ? 2u : 0u);
-		c_flag[m] = f;
+		const uint32_t o = __shfl_up(incl, off);
+		if (lane >= off)
+			incl += o;
 	}
-	__threadfence();
+	if (lane == 63)
+		s_scan[wave] = incl;
 	__syncthreads();
-	// ---- F: verdict per sorted entry, stable compaction into the outputs ------------------------------------------------------------
-	// every lane owns a contiguous range of the sorted order (and, for the high points, of the input order)
-	uint32_t n_g = 0, n_u = 0;
+	uint32_t base = 0, total = 0;
+	for (int w = 0; w < 16; w++)
 	{
-		const uint32_t per_lane = (n_cand + MULLS_GF_BLOCK - 1) / MULLS_GF_BLOCK;
-		const uint32_t k0 = min(n_cand, threadIdx.x * per_lane), k1 = min(n_cand, k0 + per_lane);
-		for (uint32_t k = k0; k < k1; k++)
+		if (w < wave)
+			base += s_scan[w];
+		total += s_scan[w];
+	}
+	base += incl - mine;
+	for (uint32_t c = c0; c < c1; c++)
+	{
+		const uint32_t cnt = t.cstart[c];
+		t.cstart[c] = base;
+		base += cnt;
+	}
+	if (threadIdx.x == 0)
+	{
+		t.cstart[nc] = total;
+		S->n_cand = total;
+	}
+}
+
+// per cell: min_z; no outlier threshold yet
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_cells1(const GfState *S, uint32_t *arena, uint32_t ns)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= nc)
+		return;
+	t.c_minz[c] = ord2f(t.minz[c]); // FLT_MAX for a cell without candidates
+	t.c_out[c] = -3.402823466e+38f;
+}
+
+// the optional grid-wise outlier threshold (:1770-1790): mean and standard deviation of the cell's z in double, summed in the list's
+// order.  One wave per cell: 64 values are gathered at once, lane 0 adds them one after the other (readlane) — the reference's order.
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_outlier(const float4 *__restrict__ pts, mulls_ground_params P, const GfState *S, uint32_t *arena, uint32_t ns,
+																 const uint32_t *__restrict__ ids)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const int lane = threadIdx.x & 63;
+	const uint32_t c = blockIdx.x * (MULLS_GF_BLOCK / 64) + (threadIdx.x >> 6);
+	if (c >= nc)
+		return;
+	const uint32_t c_begin = t.cstart[c], cnt = t.cstart[c + 1] - c_begin; // pts_count
+	if ((int)cnt < P.min_grid_pt_num)
+		return;
+	auto rl = [](double v, int l) {
+		const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+		return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+	};
+	double sum_z = 0, sum_z2 = 0;
+	for (uint32_t k0 = 0; k0 < cnt; k0 += 64)
+	{
+		const uint32_t k = k0 + lane;
+		const double z = k < cnt ? (double)pts[(size_t)ids[c_begin + k] * 3].z : 0.0;
+		const int m = (int)min(64u, cnt - k0);
+		for (int l = 0; l < m; l++)
+			sum_z += rl(z, l);
+	}
+	const double mean_z = sum_z / (int)cnt;
+	for (uint32_t k0 = 0; k0 < cnt; k0 += 64)
+	{
+		const uint32_t k = k0 + lane;
+		double term = 0.0;
+		if (k < cnt)
 		{
-			const uint32_t c = cellof[k];
-			uint8_t verdict = 0;
-			float d3 = 0.0f;
-			const uint32_t f = c_flag[c];
-			if (f & 1u)
+			const float z = pts[(size_t)ids[c_begin + k] * 3].z;
+			term = (z - mean_z) * (z - mean_z);
+		}
+		const int m = (int)min(64u, cnt - k0);
+		for (int l = 0; l < m; l++)
+			sum_z2 += rl(term, l);
+	}
+	if (lane == 0)
+	{
+		const double std_z = std::sqrt(sum_z2 / (int)cnt);
+		const float thre = (float)(mean_z - P.outlier_std_scale * std_z);
+		const float mz = t.c_minz[c];
+		t.c_minz[c] = (mz > thre) ? mz : thre; // max_(min_z, min_z_outlier_thre)
+		t.c_out[c] = thre;
+	}
+}
+
+// per cell: 3x3 neighbourhood minimum, reliable neighbours, verdict (:1795-1812, :1834, :1853)
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_cells2(mulls_ground_params P, const GfState *S, uint32_t *arena, uint32_t ns)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= nc)
+		return;
+	const int row = (int)S->row, col = (int)S->col;
+	const int temp_row = (int)m / col, temp_col = (int)m % col;
+	float nbr = t.c_minz[m]; // neighbor_min_z starts as min_z (both FLT_MAX for an empty cell)
+	int reliable = 0;
+	if (temp_row >= 1 && temp_row <= row - 2 && temp_col >= 1 && temp_col <= col - 2)
+		for (int jj = -1; jj <= 1; jj++)
+			for (int kk = -1; kk <= 1; kk++)
 			{
-				const uint32_t j = ids[k];
-				const float4 p = pts[(size_t)j * 3];
-				const float inten = pts[(size_t)j * 3 + 2].x;
-				const int jr = (int)(k - cstart[c]); // the reference's j: position in the cell's point_id list
-				float d2s = 0.001f;
-				if (P.distance_weight_downsampling_method > 0)
-					d2s = gf_dist(pts[(size_t)__hip_atomic_load(&first[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 3]); // the cell has candidates: dist2station is its first candidate's distance
-				const GfRates r = gf_rates(P, d2s);
-				if (f & 2u)
+				const int o = (int)m + jj * col + kk;
+				nbr = (nbr < t.c_minz[o]) ? nbr : t.c_minz[o];
+				if ((int)(t.cstart[o + 1] - t.cstart[o]) > P.min_grid_pt_num - 1)
+					reliable++;
+			}
+	t.c_nbr[m] = nbr;
+	uint32_t f = 0;
+	if ((int)(t.cstart[m + 1] - t.cstart[m]) >= P.min_grid_pt_num && reliable >= P.reliable_neighbor_grid_num_thre)
+		f = 1u | ((t.c_minz[m] - nbr < P.neighbor_height_diff) ? 2u : 0u);
+	t.c_flag[m] = f;
+}
+
+// per sorted entry: verdict (:1853-1907); per-block counts of ground / non-ground entries
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_verdict(const float4 *__restrict__ pts, mulls_ground_params P, const GfState *S, uint32_t *arena, uint32_t ns,
+																 const uint32_t *__restrict__ ids, const uint16_t *__restrict__ cellof, uint8_t *__restrict__ code,
+																 float *__restrict__ d3v, uint32_t *__restrict__ blk_cnt)
+{
+	__shared__ uint32_t s_cnt[2];
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (threadIdx.x < 2)
+		s_cnt[threadIdx.x] = 0u;
+	__syncthreads();
+	uint8_t verdict = 0;
+	if (k < S->n_cand)
+	{
+		const uint32_t c = cellof[k];
+		const uint32_t f = t.c_flag[c];
+		float d3 = 0.0f;
+		if (f & 1u)
+		{
+			const uint32_t j = ids[k];
+			const float4 p = pts[(size_t)j * 3];
+			const float inten = pts[(size_t)j * 3 + 2].x;
+			const int jr = (int)(k - t.cstart[c]); // the reference's j: position in the cell's point_id list
+			float d2s = 0.001f;
+			if (P.distance_weight_downsampling_method > 0)
+				d2s = gf_dist(pts[(size_t)t.first[c] * 3]); // the cell has candidates: dist2station is its first candidate's distance
+			const GfRates r = gf_rates(P, d2s);
+			const float mz = t.c_minz[c], othre = t.c_out[c];
+			if (f & 2u)
+			{
+				if (p.z > othre)
 				{
-					if (p.z > c_out[c])
+					if (p.z - mz < P.max_height_difference)
 					{
-						if (p.z - c_minz[c] < P.max_height_difference)
-						{
-							if (every(jr, r.ground))
-								verdict = 1;
-						}
-						else if (every(jr, r.nonground) || inten > P.intensity_thre)
-						{
-							verdict = 2;
-							d3 = p.z - c_minz[c];
-						}
+						if (every(jr, r.ground))
+							verdict = 1;
+					}
+					else if (every(jr, r.nonground) || inten > P.intensity_thre)
+					{
+						verdict = 2;
+						d3 = p.z - mz;
 					}
 				}
-				else if (p.z > c_out[c] && (every(jr, r.nonground) || inten > P.intensity_thre))
-				{
-					verdict = 2;
-					d3 = p.z - c_nbr[c];
-				}
 			}
-			code[k] = verdict;
-			d3v[k] = d3;
-			n_g += verdict == 1;
-			n_u += verdict == 2;
+			else if (p.z > othre && (every(jr, r.nonground) || inten > P.intensity_thre))
+			{
+				verdict = 2;
+				d3 = p.z - t.c_nbr[c];
+			}
 		}
-		uint32_t tot_g, tot_u;
-		uint32_t bg = block_exscan(n_g, s_scan, &tot_g);
-		uint32_t bu = block_exscan(n_u, s_scan, &tot_u);
-		uint32_t n_high = 0;
-		for (int w = 0; w < MULLS_GF_WAVES; w++)
-			n_high += s_high[w];
-		for (uint32_t k = k0; k < k1; k++)
+		code[k] = verdict;
+		d3v[k] = d3;
+	}
+	const unsigned long long mg = __ballot(verdict == 1), mu = __ballot(verdict == 2);
+	if ((threadIdx.x & 63) == 0)
+	{
+		atomicAdd(&s_cnt[0], (uint32_t)__popcll(mg));
+		atomicAdd(&s_cnt[1], (uint32_t)__popcll(mu));
+	}
+	__syncthreads();
+	if (threadIdx.x < 2)
+		blk_cnt[2 * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+// exclusive prefix sums: blk_cnt[nblk][2] and seg_high[ns] in place; totals into the state.  One workgroup of 1024 lanes.
+__global__ __launch_bounds__(1024) void k_gf_scan(GfState *S, uint32_t *__restrict__ blk_cnt, uint32_t nblk, uint32_t *__restrict__ seg_high, uint32_t ns)
+{
+	__shared__ uint32_t s_scan[16];
+	__shared__ uint32_t s_tot[3];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	for (int which = 0; which < 3; which++)
+	{
+		uint32_t *a = which < 2 ? blk_cnt + which : seg_high;
+		const uint32_t stride = which < 2 ? 2u : 1u, cnt = which < 2 ? nblk : ns;
+		const uint32_t per_lane = (cnt + 1023u) / 1024u;
+		const uint32_t i0 = min(cnt, threadIdx.x * per_lane), i1 = min(cnt, i0 + per_lane);
+		uint32_t mine = 0;
+		for (uint32_t i = i0; i < i1; i++)
+			mine += a[(size_t)i * stride];
+		uint32_t incl = mine;
+		for (int off = 1; off < 64; off <<= 1)
 		{
-			const uint8_t v = code[k];
-			if (!v)
-				continue;
-			const uint32_t j = ids[k];
-			float4 a = pts[(size_t)j * 3], b = pts[(size_t)j * 3 + 1];
-			const float4 cc = pts[(size_t)j * 3 + 2];
-			if (v == 1)
-			{
-				b.x = 0.0f, b.y = 0.0f, b.z = 1.0f; // estimate_ground_normal_method 0 (:1867-1871)
-				ground[(size_t)bg * 3] = a;
-				ground[(size_t)bg * 3 + 1] = b;
-				ground[(size_t)bg * 3 + 2] = cc;
-				bg++;
-			}
-			else
-			{
-				a.w = d3v[k]; // data[3]: height above ground
-				const size_t o = (size_t)(n_high + bu) * 3;
-				unground[o] = a;
-				unground[o + 1] = b;
-				unground[o + 2] = cc;
-				bu++;
-			}
+			const uint32_t o = __shfl_up(incl, off);
+			if (lane >= off)
+				incl += o;
+		}
+		__syncthreads();
+		if (lane == 63)
+			s_scan[wave] = incl;
+		__syncthreads();
+		uint32_t base = 0, total = 0;
+		for (int w = 0; w < 16; w++)
+		{
+			if (w < wave)
+				base += s_scan[w];
+			total += s_scan[w];
+		}
+		base += incl - mine;
+		for (uint32_t i = i0; i < i1; i++)
+		{
+			const uint32_t v = a[(size_t)i * stride];
+			a[(size_t)i * stride] = base;
+			base += v;
 		}
 		if (threadIdx.x == 0)
-		{
-			out->n_ground = tot_g;
-			out->n_unground = n_high + tot_u;
-			out->n_high = n_high;
-			out->error = 0u;
-			out->row = (uint32_t)row;
-			out->col = (uint32_t)col;
-			out->mean_height = appro_mean_height;
-		}
+			s_tot[which] = total;
 	}
-	// the kept high points, in input order, at the head of the non-ground cloud: each wave re-walks its range from its base
+	__syncthreads();
+	if (threadIdx.x == 0)
 	{
-		uint32_t base = 0;
-		for (int w = 0; w < wave; w++)
-			base += s_high[w];
-		for (uint32_t j0 = w_begin; j0 < w_end; j0 += 64)
+		S->n_ground = s_tot[0];
+		S->n_high = s_tot[2];
+		S->n_unground = s_tot[2] + s_tot[1];
+	}
+}
+
+// stable compaction of the sorted entries into the two output clouds (positions: block base + rank inside the block)
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_write(const float4 *__restrict__ pts, const GfState *S, const uint32_t *__restrict__ ids,
+															   const uint8_t *__restrict__ code, const float *__restrict__ d3v, const uint32_t *__restrict__ blk_base,
+															   float4 *__restrict__ ground, float4 *__restrict__ unground)
+{
+	__shared__ uint32_t s_w[2][MULLS_GF_BLOCK / 64];
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint8_t v = k < S->n_cand ? code[k] : 0;
+	const unsigned long long mg = __ballot(v == 1), mu = __ballot(v == 2);
+	if (lane == 0)
+	{
+		s_w[0][wave] = (uint32_t)__popcll(mg);
+		s_w[1][wave] = (uint32_t)__popcll(mu);
+	}
+	__syncthreads();
+	if (!v)
+		return;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	uint32_t pos = blk_base[2 * blockIdx.x + (v == 1 ? 0 : 1)] + (uint32_t)__popcll((v == 1 ? mg : mu) & below);
+	for (int w = 0; w < wave; w++)
+		pos += s_w[v == 1 ? 0 : 1][w];
+	const uint32_t j = ids[k];
+	float4 a = pts[(size_t)j * 3], b = pts[(size_t)j * 3 + 1];
+	const float4 c = pts[(size_t)j * 3 + 2];
+	if (v == 1)
+	{
+		b.x = 0.0f, b.y = 0.0f, b.z = 1.0f; // estimate_ground_normal_method 0 (:1867-1871)
+		ground[(size_t)pos * 3] = a;
+		ground[(size_t)pos * 3 + 1] = b;
+		ground[(size_t)pos * 3 + 2] = c;
+	}
+	else
+	{
+		a.w = d3v[k]; // data[3]: height above ground
+		const size_t o = (size_t)(S->n_high + pos) * 3;
+		unground[o] = a;
+		unground[o + 1] = b;
+		unground[o + 2] = c;
+	}
+}
+
+// the kept high points, in input order, at the head of the non-ground cloud: one wave per segment from its base
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_write_high(const float4 *__restrict__ pts, uint32_t n, mulls_ground_params P, const GfState *S, uint32_t *arena,
+																	uint32_t ns, const uint32_t *__restrict__ seg_base, float4 *__restrict__ unground)
+{
+	const uint32_t nc = (uint32_t)S->num_grid;
+	if (!nc)
+		return;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const int lane = threadIdx.x & 63;
+	const uint32_t seg = blockIdx.x * (MULLS_GF_BLOCK / 64) + (threadIdx.x >> 6);
+	if (seg >= ns)
+		return;
+	const float thre = S->thre, appro_mean_height = S->mean_height;
+	uint32_t base = seg_base[seg];
+	const uint32_t j_begin = seg * MULLS_GF_SEG, j_end = min(n, j_begin + MULLS_GF_SEG);
+	for (uint32_t j0 = j_begin; j0 < j_end; j0 += 64)
+	{
+		const uint32_t j = j0 + lane;
+		bool keep = false;
+		float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q = p;
+		if (j < j_end)
 		{
-			const uint32_t j = j0 + lane;
-			bool keep = false;
-			float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q = p;
-			if (j < w_end)
+			p = pts[(size_t)j * 3];
+			const int cell = gf_cell(*S, P, p);
+			if (cell >= 0 && p.z > thre)
 			{
-				p = pts[(size_t)j * 3];
-				const int cell = cell_of(p);
-				if (cell >= 0 && p.z > non_ground_height_thre)
-				{
-					q = pts[(size_t)j * 3 + 2];
-					keep = high_keep(j, p, q, cell);
-				}
+				q = pts[(size_t)j * 3 + 2];
+				keep = gf_high_keep(P, pts, t.first, j, p, q.x, cell);
 			}
-			const unsigned long long m = __ballot(keep);
-			if (keep)
-			{
-				const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-				p.w = (float)(p.z - (appro_mean_height - 3.0)); // data[3] = z - (appro_mean_height - 3.0), in double (:1751)
-				unground[(size_t)pos * 3] = p;
-				unground[(size_t)pos * 3 + 1] = pts[(size_t)j * 3 + 1];
-				unground[(size_t)pos * 3 + 2] = q;
-			}
-			base += (uint32_t)__popcll(m);
 		}
+		const unsigned long long m = __ballot(keep);
+		if (keep)
+		{
+			const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			p.w = (float)(p.z - (appro_mean_height - 3.0)); // data[3] = z - (appro_mean_height - 3.0), in double (:1751)
+			unground[(size_t)pos * 3] = p;
+			unground[(size_t)pos * 3 + 1] = pts[(size_t)j * 3 + 1];
+			unground[(size_t)pos * 3 + 2] = q;
+		}
+		base += (uint32_t)__popcll(m);
 	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-size_t ground_filter_table_bytes() { return ((size_t)(MULLS_GF_WAVES + 8) * MULLS_GF_MAXCELLS + 16) * sizeof(uint32_t); }
+// Arena of uint32 words behind the scan-sized arrays: state | seg_high[ns] | blk_cnt[2 * nblk] | tables (8 * MAXCELLS + 1 + ns * MAXCELLS ... bounded below)
+static size_t gf_cell_room(uint32_t n)
+{
+	// the per-segment tables take ns * nc words; nc is only known on the device: room for min(MAXCELLS, 64 M words / ns) cells
+	const size_t ns = (n + MULLS_GF_SEG - 1) / MULLS_GF_SEG;
+	return std::min<size_t>(MULLS_GF_MAXCELLS, ((size_t)64 << 20) / std::max<size_t>(ns, 1));
+}
+size_t ground_filter_aux_bytes(uint32_t n)
+{
+	const size_t ns = (n + MULLS_GF_SEG - 1) / MULLS_GF_SEG, nblk = (n + MULLS_GF_BLOCK - 1) / MULLS_GF_BLOCK;
+	const size_t nc_room = gf_cell_room(n);
+	return sizeof(GfState) + 64 + (ns + 2 * nblk + 16 + 8 * (size_t)MULLS_GF_MAXCELLS + ns * nc_room) * sizeof(uint32_t);
+}
 
 int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mulls_ground_params &P, uint32_t *ids, uint16_t *cellof, uint8_t *code, float *d3v,
-						 float4 *ground, float4 *unground, uint32_t *tables, GfOut *out)
+						 float4 *ground, float4 *unground, void *aux)
 {
-	hipLaunchKernelGGL(k_ground_filter, dim3(1), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, ids, cellof, code, d3v, ground, unground, tables, out);
+	const uint32_t ns = (n + MULLS_GF_SEG - 1) / MULLS_GF_SEG, nblk = (n + MULLS_GF_BLOCK - 1) / MULLS_GF_BLOCK;
+	GfState *S = static_cast<GfState *>(aux);
+	uint32_t *seg_high = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(aux) + ((sizeof(GfState) + 63) & ~(size_t)63));
+	uint32_t *blk_cnt = seg_high + ns;
+	uint32_t *arena = blk_cnt + 2 * nblk + 16;
+	static const uint32_t box0[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
+	if (hipMemcpyAsync(&S->box[0], box0, sizeof(box0), hipMemcpyHostToDevice, st) != hipSuccess)
+		return -1;
+	const uint32_t seg_blocks = (ns + MULLS_GF_BLOCK / 64 - 1) / (MULLS_GF_BLOCK / 64);
+	hipLaunchKernelGGL(k_gf_bbox, dim3(std::min<uint32_t>(nblk, 64u)), dim3(MULLS_GF_BLOCK), 0, st, pts, n, S);
+	hipLaunchKernelGGL(k_gf_setup, dim3(1), dim3(512), 0, st, pts, n, P, S, (uint32_t)gf_cell_room(n));
+	hipLaunchKernelGGL(k_gf_init, dim3(512), dim3(MULLS_GF_BLOCK), 0, st, S, arena, ns);
+	hipLaunchKernelGGL(k_gf_walk<0>, dim3(seg_blocks), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, S, arena, ns, ids, cellof, seg_high);
+	hipLaunchKernelGGL(k_gf_prefix, dim3(1), dim3(1024), 0, st, S, arena, ns);
+	hipLaunchKernelGGL(k_gf_walk<1>, dim3(seg_blocks), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, S, arena, ns, ids, cellof, seg_high);
+	hipLaunchKernelGGL(k_gf_cells1, dim3(MULLS_GF_MAXCELLS / MULLS_GF_BLOCK), dim3(MULLS_GF_BLOCK), 0, st, S, arena, ns);
+	if (P.apply_grid_wise_outlier_filter)
+		hipLaunchKernelGGL(k_gf_outlier, dim3(MULLS_GF_MAXCELLS / (MULLS_GF_BLOCK / 64)), dim3(MULLS_GF_BLOCK), 0, st, pts, P, S, arena, ns, ids);
+	hipLaunchKernelGGL(k_gf_cells2, dim3(MULLS_GF_MAXCELLS / MULLS_GF_BLOCK), dim3(MULLS_GF_BLOCK), 0, st, P, S, arena, ns);
+	hipLaunchKernelGGL(k_gf_verdict, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, pts, P, S, arena, ns, ids, cellof, code, d3v, blk_cnt);
+	hipLaunchKernelGGL(k_gf_scan, dim3(1), dim3(1024), 0, st, S, blk_cnt, nblk, seg_high, ns);
+	hipLaunchKernelGGL(k_gf_write, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, pts, S, ids, code, d3v, blk_cnt, ground, unground);
+	hipLaunchKernelGGL(k_gf_write_high, dim3(seg_blocks), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, S, arena, ns, seg_high, unground);
 	return 0;
 }
