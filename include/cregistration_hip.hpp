@@ -356,7 +356,7 @@ bool mm_lls_icp_4dof_global(constraint_t &registration_con, float heading_step_d
 										 dis_thre_min, dis_thre_update_rate, max_bearable_rotation_d, &R, &success, &best_heading);
 	if (rc != MULLS_OK)
 		throw std::runtime_error(std::string("mulls_icp_4dof_global failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
-	if (success) // the reference only touches registration_con when at least one trial succeeded (:1645-1657)
+	if (success == 1) // the reference only touches registration_con when a succeeded trial also took the best score (:1645-1657)
 	{
 		std::memcpy(registration_con.Trans1_2.data(), R.T, sizeof(R.T));
 		std::memcpy(registration_con.information_matrix.data(), R.info, sizeof(R.info));

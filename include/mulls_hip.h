@@ -224,7 +224,9 @@ int mulls_icp_3dof_ground_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, 
  * (block2->local_station) in steps of heading_step_d degrees; every trial is a full mm_lls_icp with classes "111110" and
  * weights "1001", all trials run as one lock-step batch; the trial maximising confidence / sigma wins.  pair->init_guess
  * is ignored.  converge_rotation_d and max_bearable_rotation_d are accepted for signature fidelity; the reference does
- * not use them (it passes converge_translation twice).  result->iters returns the number of trials. */
+ * not use them (it passes converge_translation twice).  result->iters returns the number of trials.  *success: 0 = no trial
+ * succeeded (the reference returns false), 1 = `result` is the best succeeded trial, 2 = trials succeeded but none scored above 0 (a NaN
+ * sigma): the reference returns true and leaves the constraint untouched — `result` is then a placeholder (identity, sigma FLT_MAX). */
 int mulls_icp_4dof_global(mulls_ctx *ctx, const mulls_pair *pair, float heading_step_d, const double station[3], int max_iter_num,
 						  float dis_thre_unit, float converge_translation, float converge_rotation_d, float dis_thre_min,
 						  float dis_thre_update_rate, float max_bearable_rotation_d, mulls_result *result, int *success,

@@ -1925,7 +1925,8 @@ extern "C"
 		result->trace_len = 0;
 		result->iters = (int)rs.size(); // number of heading trials
 		if (success)
-			*success = ok ? 1 : 0;
+			*success = ok ? (best >= 0 ? 1 : 2) : 0; // 2: trials succeeded but none scored above 0 (e.g. a NaN sigma) — the reference then returns true
+													 // and leaves registration_con untouched (:1645-1657)
 		if (best_heading_d)
 			*best_heading_d = best_heading;
 		return MULLS_OK;
