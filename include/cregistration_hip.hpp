@@ -371,8 +371,8 @@ bool mm_lls_icp_4dof_global(constraint_t &registration_con, float heading_step_d
 //     #ifdef MULLS_USE_HIP
 //         return lo::hip::update_local_map(local_map, last_target_cblock, local_map_radius, max_num_pts, ...);
 //     #endif
-// Differences: pcl::RandomSample is seeded with time(NULL) upstream, here with `map_rng_seed()`; recalculate_feature_on
-// (PCA refresh of pillar / beam points, pca.hpp) is not available on the device and throws.
+// Differences: pcl::RandomSample is seeded with time(NULL) upstream, here with `map_rng_seed()`; with recalculate_feature_on the
+// refreshed directions agree with pcl::PCA's up to Eigen's float eigen-solver accuracy and the direction's sign.
 inline uint64_t &map_rng_seed()
 {
 	static uint64_t seed = 0;

@@ -252,7 +252,8 @@ typedef struct mulls_map_params
 	float dynamic_dist_thre_min;	   /* 0.3 */
 	float dynamic_dist_thre_max;	   /* 3.0 */
 	float near_dist_thre;			   /* 0.03 */
-	int recalculate_feature_on;		   /* false; true = MULLS_E_UNSUPPORTED (PCA refresh belongs to feature extraction, 8f-3) */
+	int recalculate_feature_on;		   /* true: principal directions of the map's pillar / beam points recomputed from their own
+										  neighbourhoods, points that are not linear / steep / flat enough dropped (map_manager.cpp:98-118, :258-292) */
 	/* not in the reference's signature */
 	uint64_t rng_seed; /* random_downsample_pcl: the ABI's seeded selection sampling (see mulls_params.rng_seed) */
 	int tree_mode;	   /* what block1->tree_* held after the last mm_lls_icp against this map (cregistration.hpp:1209-1232):

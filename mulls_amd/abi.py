@@ -308,6 +308,12 @@ def make_points(xyz, normals=None, intensity=None, curvature=None):
     return pts
 
 
+def normal3(pts):
+    """normal[3] of every record (offset 28; not a named field: the registration never reads it, the map's PCA refresh writes it)."""
+    pts = np.ascontiguousarray(pts)
+    return pts.view(np.uint8).reshape(len(pts), POINT_BYTES)[:, 28:32].copy().view(np.float32).reshape(len(pts))
+
+
 def as_points(a):
     """Coerce any structured array carrying the eight point fields to a contiguous POINT_DTYPE array."""
     if a is None:

@@ -228,11 +228,6 @@ extern "C"
 			ctx->err = "used_feature_type and tree_used need 6 characters";
 			return MULLS_E_INVALID;
 		}
-		if (P->recalculate_feature_on)
-		{
-			ctx->err = "recalculate_feature_on (PCA refresh of the linear features) is not part of this build";
-			return MULLS_E_UNSUPPORTED;
-		}
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		const auto wall0 = std::chrono::steady_clock::now();
 		hipStream_t st = ctx->stream;
@@ -438,6 +433,60 @@ extern "C"
 		{
 			rep->local_bound[k] = key_to_double(keys[k], k < 3);
 			rep->bound[k] = key_to_double(keys[6 + k], k < 3);
+		}
+		// 9. recalculate_feature_on (:98-118): principal directions of the pillar and beam clouds from their own neighbourhoods
+		//    (pca_radius 1.8, pca_max_k 20, pca_min_k 6, min_linearity 0.65), pillars kept above sin 0.80, beams below sin 0.25
+		if (P->recalculate_feature_on)
+		{
+			static const int cls[2] = {MULLS_PILLAR, MULLS_BEAM};
+			static const float sin_low[2] = {0.0f, 0.25f}, sin_high[2] = {0.80f, 1.0f};
+			for (int k = 0; k < 2; k++)
+			{
+				const int c = cls[k];
+				const uint32_t nc = m->n[c];
+				if (P->used_feature_type[c] != '1' || nc == 0)
+					continue;
+				if (m->cap_best < nc)
+				{
+					if (m->best)
+						(void)hipFree(m->best);
+					if (m->keep)
+						(void)hipFree(m->keep);
+					m->best = nullptr, m->keep = nullptr;
+					m->cap_best = 0;
+					if (dmalloc(ctx, &m->best, (size_t)nc * 2) != MULLS_OK || dmalloc(ctx, &m->keep, (size_t)nc * 2) != MULLS_OK)
+						return MULLS_E_HIP;
+					m->cap_best = (size_t)nc * 2;
+				}
+				MapPcaArgs pa;
+				pa.recs = m->rec[c];
+				pa.n = nc;
+				pa.radius = 1.8f;
+				pa.max_k = 20;
+				pa.min_k = 6;
+				pa.sin_low = sin_low[k];
+				pa.sin_high = sin_high[k];
+				pa.min_linearity = 0.65f;
+				pa.keep = m->keep;
+				launch_map_pca(st, pa);
+				const int rc = reserve(ctx, &m->alt[c], &m->cap_alt[c], nc, 0);
+				if (rc != MULLS_OK)
+					return rc;
+				std::memset(&a, 0, sizeof(a));
+				a.cloud[0].in = m->rec[c];
+				a.cloud[0].out = m->alt[c];
+				a.cloud[0].mask = m->keep;
+				a.cloud[0].n = nc;
+				a.out_n = m->counts;
+				a.mode = 0;
+				if (compact(ctx, m, a) != MULLS_OK)
+					return MULLS_E_HIP;
+				HIPCHK(ctx, hipMemcpyAsync(cnt, m->counts, sizeof(cnt), hipMemcpyDeviceToHost, st));
+				HIPCHK(ctx, hipStreamSynchronize(st));
+				std::swap(m->rec[c], m->alt[c]);
+				std::swap(m->cap[c], m->cap_alt[c]);
+				m->n[c] = cnt[0];
+			}
 		}
 		for (int c = 0; c < MULLS_NC; c++)
 			rep->n[c] = m->n[c];

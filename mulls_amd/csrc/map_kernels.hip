@@ -260,6 +260,182 @@ __global__ void k_map_keep(const float4 *__restrict__ frame, uint32_t n_frame, c
 	keep[q] = k ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MapManager::update_cloud_vectors (src/map_manager.cpp:258-292): every point of a linear-feature cloud gets the principal direction
+// of its radius-limited k-neighbourhood (pca.hpp:209-290, :392-437) and survives only if the neighbourhood is linear enough and its
+// direction steep (pillars) or flat (beams) enough.  One lane per point; the cloud streams through LDS in 256-point tiles and every
+// lane keeps its `max_k` nearest neighbours as a sorted list in LDS (slot-major, so that neighbouring lanes touch neighbouring banks).
+// A cloud of a few thousand points is all this ever sees (the map's pillar / beam share of max_num_pts): n^2 distances is microseconds.
+//   neighbourhood   squared L2_Simple distance (((dx*dx)+dy*dy)+dz*dz, float) < radius^2, the max_k nearest in (distance, index) order,
+//                   the point itself included — pcl::KdTreeFLANN::radiusSearch with max_nn
+//   pcl::PCA        float centroid and float demeaned covariance summed in the neighbours' order, scaled by 1/(n-1); the
+//                   eigen-decomposition of that float matrix in double (cyclic Jacobi), eigenvalues rounded to float
+#define MAP_PCA_K 24 // list slots per lane (max_k <= 24: 48 KB of lists per workgroup)
+namespace
+{
+struct Sym3
+{
+	double xx, xy, xz, yy, yz, zz;
+};
+// one Jacobi rotation annihilating a(p,q); the matrix is carried as named scalars so that nothing is indexed dynamically
+#define MAP_ROT(app, aqq, apq, apr, aqr, vxp, vxq, vyp, vyq, vzp, vzq)                                  \
+	if (apq != 0.0)                                                                                      \
+	{                                                                                                    \
+		const double theta = (aqq - app) / (2.0 * apq);                                                  \
+		const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));          \
+		const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;                                          \
+		/* A <- A J : columns p and q */                                                                 \
+		const double c_pp = cs * app - sn * apq, c_pq = sn * app + cs * apq;                             \
+		const double c_qp = cs * apq - sn * aqq, c_qq = sn * apq + cs * aqq;                             \
+		const double c_rp = cs * apr - sn * aqr, c_rq = sn * apr + cs * aqr;                             \
+		/* A <- J^T A : rows p and q (the third row's entries are c_rp, c_rq by symmetry) */             \
+		app = cs * c_pp - sn * c_qp;                                                                     \
+		aqq = sn * c_pq + cs * c_qq;                                                                     \
+		apq = cs * c_pq - sn * c_qq;                                                                     \
+		apr = c_rp;                                                                                      \
+		aqr = c_rq;                                                                                      \
+		double u = vxp, w = vxq;                                                                         \
+		vxp = cs * u - sn * w, vxq = sn * u + cs * w;                                                    \
+		u = vyp, w = vyq;                                                                                \
+		vyp = cs * u - sn * w, vyq = sn * u + cs * w;                                                    \
+		u = vzp, w = vzq;                                                                                \
+		vzp = cs * u - sn * w, vzq = sn * u + cs * w;                                                    \
+	}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_map_pca(MapPcaArgs a)
+{
+	__shared__ float tx[256], ty[256], tz[256];
+	__shared__ float ld[MAP_PCA_K * 256];
+	__shared__ uint32_t li[MAP_PCA_K * 256];
+	const uint32_t t = threadIdx.x, i = blockIdx.x * 256u + t;
+	const bool live = i < a.n;
+	float qx = 0, qy = 0, qz = 0;
+	if (live)
+	{
+		const float4 r0 = a.recs[(size_t)i * 3];
+		qx = r0.x, qy = r0.y, qz = r0.z;
+	}
+	const float r2 = a.radius * a.radius;
+	const uint32_t K = (uint32_t)a.max_k;
+	uint32_t m = 0;	   // list length
+	float worst = r2; // a candidate enters while its distance is below this
+	for (uint32_t base = 0; base < a.n; base += 256u)
+	{
+		__syncthreads();
+		if (base + t < a.n)
+		{
+			const float4 r0 = a.recs[(size_t)(base + t) * 3];
+			tx[t] = r0.x, ty[t] = r0.y, tz[t] = r0.z;
+		}
+		__syncthreads();
+		const uint32_t cnt = min(256u, a.n - base);
+		if (!live)
+			continue;
+		for (uint32_t j = 0; j < cnt; j++)
+		{
+			const float dx = qx - tx[j], dy = qy - ty[j], dz = qz - tz[j];
+			const float d = dx * dx + dy * dy + dz * dz;
+			if (!(d < worst))
+				continue;
+			// behind every entry with distance <= d: candidates arrive in index order, so ties stay in index order
+			uint32_t pos = m < K ? m : K - 1u;
+			while (pos > 0 && ld[(pos - 1u) * 256u + t] > d)
+			{
+				ld[pos * 256u + t] = ld[(pos - 1u) * 256u + t];
+				li[pos * 256u + t] = li[(pos - 1u) * 256u + t];
+				pos--;
+			}
+			ld[pos * 256u + t] = d;
+			li[pos * 256u + t] = base + j;
+			if (m < K)
+				m++;
+			if (m == K)
+				worst = ld[(K - 1u) * 256u + t];
+		}
+	}
+	if (!live)
+		return;
+	uint8_t keep = 0;
+	if (m > 3u && (int)m >= a.min_k)
+	{
+		float mx = 0, my = 0, mz = 0;
+		for (uint32_t k = 0; k < m; k++)
+		{
+			const float4 r0 = a.recs[(size_t)li[k * 256u + t] * 3];
+			mx += r0.x, my += r0.y, mz += r0.z;
+		}
+		mx /= (float)m, my /= (float)m, mz /= (float)m;
+		float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+		for (uint32_t k = 0; k < m; k++)
+		{
+			const float4 r0 = a.recs[(size_t)li[k * 256u + t] * 3];
+			const float dx = r0.x - mx, dy = r0.y - my, dz = r0.z - mz;
+			s0 += dx * dx, s1 += dx * dy, s2 += dx * dz, s3 += dy * dy, s4 += dy * dz, s5 += dz * dz;
+		}
+		const float alpha = 1.f / ((float)m - 1.f);
+		double a00 = (double)(alpha * s0), a01 = (double)(alpha * s1), a02 = (double)(alpha * s2), a11 = (double)(alpha * s3), a12 = (double)(alpha * s4),
+			   a22 = (double)(alpha * s5);
+		double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+		for (int sweep = 0; sweep < 60; sweep++)
+		{
+			const double off = a01 * a01 + a02 * a02 + a12 * a12;
+			if (off < 1e-300)
+				break;
+			MAP_ROT(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21) // (0,1)
+			MAP_ROT(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22) // (0,2)
+			MAP_ROT(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22) // (1,2)
+		}
+		// the largest and the second eigenvalue (descending selection, the lower index first among equals) and the first one's vector
+		double e0 = a00, e1d = a11, e2d = a22, px = v00, py = v10, pz = v20, qx2 = v01, qy2 = v11, qz2 = v21;
+		if (e1d > e0)
+		{
+			double w = e0;
+			e0 = e1d, e1d = w;
+			w = px, px = qx2, qx2 = w;
+			w = py, py = qy2, qy2 = w;
+			w = pz, pz = qz2, qz2 = w;
+		}
+		if (e2d > e0)
+		{
+			const double w = e0;
+			e0 = e2d, e2d = w;
+			px = v02, py = v12, pz = v22;
+		}
+		if (e2d > e1d)
+			e1d = e2d;
+		const double l1 = e0, l2 = e1d;
+		const double nrm = sqrt(px * px + py * py + pz * pz);
+		int big = 0;
+		double bigv = fabs(px);
+		if (fabs(py) > bigv)
+			big = 1, bigv = fabs(py);
+		if (fabs(pz) > bigv)
+			big = 2;
+		const double lead = big == 0 ? px : (big == 1 ? py : pz);
+		const double sgn = lead < 0 ? -1.0 : 1.0;
+		const float e1 = (float)l1, e2 = (float)l2;
+		float dx = (float)(sgn * px / nrm), dy = (float)(sgn * py / nrm), dz = (float)(sgn * pz / nrm);
+		const float dn = sqrtf(dx * dx + dy * dy + dz * dz); // Vector3f::normalize()
+		dx /= dn, dy /= dn, dz /= dn;
+		const float linear_2 = (e1 - e2) / e1;
+		if (linear_2 > a.min_linearity && (fabsf(dz) > a.sin_high || fabsf(dz) < a.sin_low))
+		{
+			keep = 1;
+			a.recs[(size_t)i * 3 + 1] = make_float4(dx, dy, dz, linear_2); // assign_normal(pt, feature, false)
+			float4 r2v = a.recs[(size_t)i * 3 + 2];
+			r2v.y = linear_2; // curvature <- linearity (:280)
+			a.recs[(size_t)i * 3 + 2] = r2v;
+		}
+	}
+	a.keep[i] = keep;
+}
+void launch_map_pca(hipStream_t st, const MapPcaArgs &a)
+{
+	if (a.n)
+		hipLaunchKernelGGL(k_map_pca, dim3((a.n + 255u) / 256u), dim3(256), 0, st, a);
+}
+
 uint32_t map_compact_segments(const MapCompactArgs &a)
 {
 	uint32_t ns = 0;

@@ -38,3 +38,16 @@ void launch_map_nn(hipStream_t st, const float4 *frame, uint32_t n_frame, const 
 				   uint32_t *best);
 void launch_map_keep(hipStream_t st, const float4 *frame, uint32_t n_frame, const uint32_t *best, float center_radius, float dmin, float dmax,
 					 float near, uint8_t *keep);
+
+// PCA refresh of a linear-feature cloud (MapManager::update_cloud_vectors): writes direction / linearity into the records of
+// the points it keeps and keep[i] = 0/1 for every point; max_k <= 24
+struct MapPcaArgs
+{
+	float4 *recs;
+	uint32_t n;
+	float radius;
+	int max_k, min_k;
+	float sin_low, sin_high, min_linearity;
+	uint8_t *keep;
+};
+void launch_map_pca(hipStream_t st, const MapPcaArgs &a);

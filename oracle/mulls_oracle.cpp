@@ -2121,6 +2121,192 @@ void distance_removal(Cloud &pts, const Cloud &tree_pts, float center_radius, fl
 	}
 	pts.swap(out);
 }
+// ---------------------------------------------------------------------------------------------------------
+// MapManager::update_cloud_vectors (src/map_manager.cpp:258-292), the PCA refresh of the local map's linear features
+// (recalculate_feature_on, :98-118) with what it calls: PrincipleComponentAnalysis::get_pc_pca_feature (pca.hpp:209-290),
+// get_pca_feature (:392-437), assign_normal (:440-456).  The third-party pieces, restated (PCL 1.8-1.10 as remembered; neither PCL nor
+// Eigen is in this image — "parity unpinned" for them):
+//   pcl::KdTreeFLANN::radiusSearch(index, radius, k_indices, k_sqr_distances, max_nn)   the max_nn nearest points with
+//       squared L2_Simple<float> distance < radius^2 (FLANN's KNNRadiusResultSet: a candidate is taken while dist < worst, worst starting
+//       at the squared radius), ascending by distance; ties by index here (FLANN: implementation-defined).  The query point is a member.
+//   pcl::PCA<PointT> (pcl/common/impl/pca.hpp)   mean_ by compute3DCentroid (float accumulators), the demeaned float coordinates,
+//       covariance = 1/(n-1) * D D^T in float, Eigen::SelfAdjointEigenSolver<Eigen::Matrix3f>; eigenvalues descending, eigenvectors
+//       as columns.  Here: the float sums in the neighbours' order, the eigen-decomposition by cyclic Jacobi rotations in double on the
+//       float covariance, rounded to float; an eigenvector's sign (arbitrary in Eigen) is fixed by making its largest component
+//       positive.  Eigen's float solver is accurate to ~1e-6 of the largest eigenvalue: the comparisons with the thresholds below can
+//       differ from it for points that close to a threshold.
+struct PcaFeature
+{
+	float lamada1 = 0, lamada2 = 0, lamada3 = 0, curvature = 0, linear_2 = 0, planar_2 = 0, spherical_2 = 0;
+	float principal[3] = {0, 0, 0}, normal[3] = {0, 0, 0};
+	int pt_num = 0;
+};
+void radius_knn(const Cloud &c, size_t q, float radius, int max_nn, std::vector<int> &idx, std::vector<float> &d2)
+{
+	const float r2 = radius * radius;
+	std::vector<std::pair<float, int>> all;
+	for (size_t t = 0; t < c.size(); t++)
+	{
+		const float d = l2_simple(c[q], c[t]);
+		if (d < r2)
+			all.push_back(std::make_pair(d, (int)t));
+	}
+	std::sort(all.begin(), all.end()); // (distance, index)
+	if (max_nn > 0 && (int)all.size() > max_nn)
+		all.resize(max_nn);
+	idx.clear();
+	d2.clear();
+	for (size_t k = 0; k < all.size(); k++)
+	{
+		d2.push_back(all[k].first);
+		idx.push_back(all[k].second);
+	}
+}
+// eigen-decomposition of a symmetric 3x3 (a = xx xy xz yy yz zz): cyclic Jacobi, eigenvalues descending, unit eigenvectors (columns of v)
+void jacobi3(const double a6[6], double lam[3], double v[3][3])
+{
+	double A[3][3] = {{a6[0], a6[1], a6[2]}, {a6[1], a6[3], a6[4]}, {a6[2], a6[4], a6[5]}};
+	for (int r = 0; r < 3; r++)
+		for (int c = 0; c < 3; c++)
+			v[r][c] = r == c ? 1.0 : 0.0;
+	for (int sweep = 0; sweep < 60; sweep++)
+	{
+		const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+		if (off < 1e-300)
+			break;
+		for (int p = 0; p < 2; p++)
+			for (int q = p + 1; q < 3; q++)
+			{
+				if (A[p][q] == 0.0)
+					continue;
+				const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+				const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+				const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+				for (int k = 0; k < 3; k++) // A <- A J
+				{
+					const double akp = A[k][p], akq = A[k][q];
+					A[k][p] = cs * akp - sn * akq;
+					A[k][q] = sn * akp + cs * akq;
+				}
+				for (int k = 0; k < 3; k++) // A <- J^T A
+				{
+					const double apk = A[p][k], aqk = A[q][k];
+					A[p][k] = cs * apk - sn * aqk;
+					A[q][k] = sn * apk + cs * aqk;
+				}
+				for (int r = 0; r < 3; r++) // the upper triangle is the matrix
+					for (int c2 = r + 1; c2 < 3; c2++)
+						A[c2][r] = A[r][c2];
+				for (int k = 0; k < 3; k++)
+				{
+					const double vkp = v[k][p], vkq = v[k][q];
+					v[k][p] = cs * vkp - sn * vkq;
+					v[k][q] = sn * vkp + cs * vkq;
+				}
+			}
+	}
+	int ord[3] = {0, 1, 2};
+	for (int i = 0; i < 3; i++)
+		for (int j = i + 1; j < 3; j++)
+			if (A[ord[j]][ord[j]] > A[ord[i]][ord[i]])
+				std::swap(ord[i], ord[j]);
+	double vv[3][3];
+	for (int i = 0; i < 3; i++)
+	{
+		lam[i] = A[ord[i]][ord[i]];
+		double nrm = 0;
+		for (int k = 0; k < 3; k++)
+			nrm += v[k][ord[i]] * v[k][ord[i]];
+		nrm = std::sqrt(nrm);
+		int big = 0;
+		for (int k = 1; k < 3; k++)
+			if (std::fabs(v[k][ord[i]]) > std::fabs(v[big][ord[i]]))
+				big = k;
+		const double sgn = v[big][ord[i]] < 0 ? -1.0 : 1.0;
+		for (int k = 0; k < 3; k++)
+			vv[k][i] = sgn * v[k][ord[i]] / nrm;
+	}
+	std::memcpy(v, vv, sizeof(vv));
+}
+bool pca_feature(const Cloud &c, const std::vector<int> &idx, PcaFeature &f) // get_pca_feature (pca.hpp:392-437)
+{
+	const int pt_num = (int)idx.size();
+	if (pt_num <= 3)
+		return false;
+	float mx = 0, my = 0, mz = 0; // compute3DCentroid: float accumulators, then divided by the count
+	for (int i = 0; i < pt_num; i++)
+	{
+		mx += c[idx[i]].x;
+		my += c[idx[i]].y;
+		mz += c[idx[i]].z;
+	}
+	mx /= (float)pt_num;
+	my /= (float)pt_num;
+	mz /= (float)pt_num;
+	float s[6] = {0, 0, 0, 0, 0, 0};
+	for (int i = 0; i < pt_num; i++)
+	{
+		const float dx = c[idx[i]].x - mx, dy = c[idx[i]].y - my, dz = c[idx[i]].z - mz;
+		s[0] += dx * dx;
+		s[1] += dx * dy;
+		s[2] += dx * dz;
+		s[3] += dy * dy;
+		s[4] += dy * dz;
+		s[5] += dz * dz;
+	}
+	const float alpha = 1.f / ((float)pt_num - 1.f);
+	double a6[6], lam[3], v[3][3];
+	for (int k = 0; k < 6; k++)
+		a6[k] = (double)(alpha * s[k]);
+	jacobi3(a6, lam, v);
+	f.lamada1 = (float)lam[0];
+	f.lamada2 = (float)lam[1];
+	f.lamada3 = (float)lam[2];
+	float pd[3] = {(float)v[0][0], (float)v[1][0], (float)v[2][0]}, nd[3] = {(float)v[0][2], (float)v[1][2], (float)v[2][2]};
+	const float pn = std::sqrt(pd[0] * pd[0] + pd[1] * pd[1] + pd[2] * pd[2]), nn = std::sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+	for (int k = 0; k < 3; k++) // Vector3f::normalize()
+	{
+		f.principal[k] = pd[k] / pn;
+		f.normal[k] = nd[k] / nn;
+	}
+	if ((f.lamada1 + f.lamada2 + f.lamada3) == 0)
+		f.curvature = 0;
+	else
+		f.curvature = f.lamada3 / (f.lamada1 + f.lamada2 + f.lamada3);
+	f.linear_2 = ((f.lamada1) - (f.lamada2)) / (f.lamada1);
+	f.planar_2 = ((f.lamada2) - (f.lamada3)) / (f.lamada1);
+	f.spherical_2 = (f.lamada3) / (f.lamada1);
+	return true;
+}
+// update_cloud_vectors(feature_pts, tree, pca_radius, pca_k, k_min, sin_low, sin_high, min_linearity)
+void update_cloud_vectors(Cloud &pts, float pca_radius, int pca_k, int k_min, float sin_low, float sin_high, float min_linearity)
+{
+	Cloud temp;
+	std::vector<int> idx;
+	std::vector<float> d2;
+	const Cloud positions = pts; // the neighbourhoods only read x, y, z (get_pc_pca_feature overwrites normals while it runs: never read)
+	for (size_t i = 0; i < pts.size(); i++)
+	{
+		radius_knn(positions, i, pca_radius, pca_k, idx, d2);
+		PcaFeature f;
+		f.pt_num = (int)idx.size();
+		pca_feature(positions, idx, f);
+		if (f.pt_num >= k_min && f.linear_2 > min_linearity)
+		{
+			Pt p = pts[i];
+			p.nx = f.principal[0]; // assign_normal(pt, feature, false): primary direction, linearity in normal[3]
+			p.ny = f.principal[1];
+			p.nz = f.principal[2];
+			p.n3 = f.linear_2;
+			if (std::abs(f.principal[2]) > sin_high || std::abs(f.principal[2]) < sin_low)
+			{
+				p.curvature = f.linear_2;
+				temp.push_back(p);
+			}
+		}
+	}
+	pts.swap(temp);
+}
 } // namespace
 
 extern "C"
@@ -2147,8 +2333,6 @@ extern "C"
 	{
 		if (!map_in || !map_pose || !frame_down || !frame_pose || !P || !rep)
 			return MULLS_E_INVALID;
-		if (P->recalculate_feature_on)
-			return MULLS_E_UNSUPPORTED;
 		Cloud M[6], F[6];
 		for (int c = 0; c < 6; c++)
 		{
@@ -2222,6 +2406,13 @@ extern "C"
 		transform_positions(raw, frame_T); // local_map->pose_lo = last_target_cblock->pose_lo (:58), then :92
 		cloud_bbx(raw, rep->bound);
 
+		if (P->recalculate_feature_on) // :98-118: pca_radius 1.8, pca_max_k 20, pca_min_k 6, pillars steeper than 55 deg, beams flatter than 15 deg
+		{
+			if (P->used_feature_type[1] == '1')
+				update_cloud_vectors(M[MULLS_PILLAR], 1.8f, 20, 6, 0.0f, 0.80f, 0.65f);
+			if (P->used_feature_type[3] == '1')
+				update_cloud_vectors(M[MULLS_BEAM], 1.8f, 20, 6, 0.25f, 1.0f, 0.65f);
+		}
 		rep->feature_point_num = (int)(M[MULLS_GROUND].size() + M[MULLS_FACADE].size() + M[MULLS_ROOF].size() + M[MULLS_PILLAR].size() +
 									   M[MULLS_BEAM].size());
 		for (int c = 0; c < 6; c++)

@@ -151,7 +151,8 @@ def map_update(map_clouds, map_pose, frame_down, frame_pose, params, fn=None):
     rc = fn(m_arr, abi.colmajor16(map_pose), f_arr, abi.colmajor16(frame_pose), C.byref(params), pm, nm, pf, nf, C.byref(rep))
     if rc != 0:
         raise RuntimeError("oracle map_update returned %d" % rc)
-    return [out_m[c][: nm[c]].copy() for c in range(6)], [out_f[c][: nf[c]].copy() for c in range(6)], rep
+    raw = lambda a, n: a[:n].view(np.uint8).copy().view(abi.POINT_DTYPE)  # .copy() of a record array drops the bytes between fields (normal[3])
+    return [raw(out_m[c], nm[c]) for c in range(6)], [raw(out_f[c], nf[c]) for c in range(6)], rep
 
 
 def census(reset=False):

@@ -5,7 +5,7 @@ import pytest
 
 from mulls_amd import abi, synth
 from oracle import pyoracle
-from test_map import same_cloud, small_frames
+from test_map import linear_frames, same_cloud, small_frames
 
 pytestmark = pytest.mark.gpu
 
@@ -26,6 +26,8 @@ def drive(ctx_auto, frames, params_of):
         for c in range(6):
             same_cloud(dev.download(c), clouds[c])
             same_cloud(dev.frame_download(c), appended[c])
+            if P.recalculate_feature_on and c in (abi.PILLAR, abi.BEAM):  # linearity in normal[3]
+                assert np.array_equal(abi.normal3(dev.download(c)), abi.normal3(clouds[c]))
         assert np.array_equal(dev.pose(), fp)
         reps.append(rg)
     return dev, clouds, reps
@@ -88,12 +90,26 @@ def test_scan_to_map_registration_with_resident_target(ctx_auto):
     dev.close()
 
 
+@pytest.mark.parametrize("thin", [False, True])
+def test_pca_refresh_matches_oracle(ctx_auto, thin):
+    """recalculate_feature_on: the device's neighbourhood PCA is the oracle's arithmetic operation by operation (float sums in
+    neighbour order, the same Jacobi rotations in double), so kept sets, directions and linearities are bit-identical; the
+    refreshed directions then feed the next frame's update."""
+    frames = linear_frames(310, n_frames=4)
+    kw = dict(max_num_pts=2500, kept_vertex_num=60, rng_seed=77) if thin else dict(max_num_pts=10**7, kept_vertex_num=10**6)
+    dev, clouds, reps = drive(ctx_auto, frames, lambda k: abi.map_params(recalculate_feature_on=1, local_map_radius=60.0,
+                                                                        used_feature_type="111110" if k != 2 else "110010", **kw))
+    assert 0 < reps[-1].n[abi.PILLAR] and 0 < reps[0].n[abi.BEAM]
+    assert np.all(np.abs(dev.download(abi.PILLAR)["nz"]) > 0.80) and np.all(np.abs(dev.download(abi.BEAM)["nz"]) < 0.25)
+    dev.close()
+
+
 def test_map_argument_errors(ctx_auto):
     m = ctx_auto.local_map()
     assert all(len(m.download(c)) == 0 for c in range(6))
     frames = small_frames(90, n_frames=2)
     with pytest.raises(Exception):
-        m.update(frames[1][0], frames[1][1], abi.map_params(recalculate_feature_on=1))
+        m.update(frames[1][0], frames[1][1], abi.map_params(used_feature_type="111"))
     rep = m.update(frames[1][0], frames[1][1], abi.map_params())  # empty map + first frame
     assert rep.n[0] == len(frames[1][0][0])
     m.close()

@@ -181,3 +181,77 @@ def test_random_update_sequences_oracle_equals_reference_lines(block):
             same_cloud(mo[c], mr[c])
         compared += 1
     assert compared == len(frames) - 1
+
+
+def _pca_expectation(cloud, radius=1.8, max_k=20):
+    """Independent numpy statement of the refresh for the property test: float64 throughout, eigh instead of Jacobi."""
+    xyz = np.stack([cloud[k] for k in "xyz"], 1).astype(np.float32)
+    out = []
+    for i in range(len(xyz)):
+        d = ((xyz[i] - xyz) ** 2).astype(np.float32)
+        d2 = (d[:, 0] + d[:, 1]) + d[:, 2]
+        idx = np.nonzero(d2 < np.float32(radius) ** 2)[0]
+        idx = idx[np.lexsort((idx, d2[idx]))][:max_k]
+        if len(idx) <= 3:
+            out.append((len(idx), 0.0, np.zeros(3)))
+            continue
+        nb = xyz[idx].astype(np.float64)
+        w, v = np.linalg.eigh(np.cov(nb.T))
+        out.append((len(idx), (w[2] - w[1]) / w[2] if w[2] > 0 else np.nan, v[:, 2]))
+    return out
+
+
+def linear_frames(seed, n_frames=3):
+    """small_frames with denser pillars / beams, so that the 1.8 m neighbourhoods of the PCA refresh are populated."""
+    frames = []
+    pose = np.eye(4)
+    for k in range(n_frames):
+        src = {abi.GROUND: 300, abi.PILLAR: 900, abi.FACADE: 300, abi.BEAM: 500, abi.ROOF: 40}
+        pair, T_gt = synth.make_pair(seed + k, n_beams=48, n_az=900, src_counts=src, tgt_counts=src, vertex_count=50)
+        frames.append(([pair.src[c] for c in range(6)], pose.copy()))
+        pose = pose @ np.linalg.inv(T_gt)
+    return frames
+
+
+def test_pca_refresh_of_linear_features():
+    """recalculate_feature_on (map_manager.cpp:98-118, :258-292): against the same update without it and against a float64 numpy
+    statement of the neighbourhood PCA.  Points whose linearity or direction lies within 1e-4 of a threshold may go either way."""
+    frames = linear_frames(300)
+    kw = dict(max_num_pts=10**7, kept_vertex_num=10**6, local_map_radius=60.0)
+    m_off, _, r_off = pyoracle.map_update(frames[0][0], frames[0][1], frames[1][0], frames[1][1], abi.map_params(**kw))
+    m_on, _, r_on = pyoracle.map_update(frames[0][0], frames[0][1], frames[1][0], frames[1][1], abi.map_params(recalculate_feature_on=1, **kw))
+    for c in (abi.GROUND, abi.FACADE, abi.ROOF, abi.VERTEX):
+        same_cloud(m_on[c], m_off[c])
+    assert list(r_on.local_bound) == list(r_off.local_bound)  # the boxes are taken before the refresh (:88-94)
+    assert r_on.feature_point_num == sum(len(m_on[c]) for c in range(5))
+    kept_total = 0
+    for c, lo, hi in ((abi.PILLAR, 0.0, 0.80), (abi.BEAM, 0.25, 1.0)):
+        before, after = m_off[c], m_on[c]
+        key = lambda a: list(zip(a["x"].tolist(), a["y"].tolist(), a["z"].tolist(), a["intensity"].tolist()))
+        kb, ka = key(before), key(after)
+        pos = {k: i for i, k in enumerate(kb)}
+        assert len(pos) == len(kb)
+        where = [pos[k] for k in ka]
+        assert where == sorted(where)  # a sub-sequence, order kept
+        expect = _pca_expectation(before)
+        kept = set(where)
+        for i, (n, lin, d) in enumerate(expect):
+            want = n >= 6 and lin > 0.65 and (abs(d[2]) > hi or abs(d[2]) < lo)
+            near = n >= 6 and (abs(lin - 0.65) < 1e-4 or abs(abs(d[2]) - hi) < 1e-4 or abs(abs(d[2]) - lo) < 1e-4)
+            assert near or (i in kept) == want, (c, i, n, lin, d)
+        for j, i in enumerate(where):
+            n, lin, d = expect[i]
+            got = np.array([after["nx"][j], after["ny"][j], after["nz"][j]], np.float64)
+            assert abs(np.linalg.norm(got) - 1) < 1e-6 and abs(abs(got @ d) - 1) < 1e-5
+            assert got[np.argmax(np.abs(got))] > 0  # the sign convention of the restatement
+            n3 = abi.normal3(after)[j]
+            assert n3 == after["curvature"][j] and abs(n3 - lin) < 1e-4
+        kept_total += len(where)
+        assert 0 < len(where) < len(before)
+    assert kept_total > 200
+    # class switched off: its cloud is not refreshed
+    off = dict(used_feature_type="101110", **kw)
+    m_p, _, _ = pyoracle.map_update(frames[0][0], frames[0][1], frames[1][0], frames[1][1], abi.map_params(recalculate_feature_on=1, **off))
+    m_q, _, _ = pyoracle.map_update(frames[0][0], frames[0][1], frames[1][0], frames[1][1], abi.map_params(**off))
+    same_cloud(m_p[abi.PILLAR], m_q[abi.PILLAR])
+    assert len(m_p[abi.BEAM]) < len(m_q[abi.BEAM])
