@@ -346,6 +346,59 @@ void mulls_ground_default_params(mulls_ground_params *p);
 int mulls_ground_filter(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *params, void *ground, uint32_t cap_ground,
 						void *ground_down, uint32_t cap_ground_down, void *unground, uint32_t cap_unground, uint32_t n_out[3]);
 
+/* ---- feature extraction, second stage: CFilter::classify_nground_pts (include/common/cfilter.hpp:2058-2290) ---- */
+
+/* its positional parameters (cfilter.hpp:2068-2082); defaults = what extract_semantic_pts (:2301-2318) passes when test/mulls_reg.cpp
+ * calls it with script/run_mulls_reg.sh's flags */
+typedef struct mulls_classify_params
+{
+	float neighbor_searching_radius; /* pca_neighbor_radius [1.0] */
+	int32_t neighbor_k;				 /* pca_neighbor_count [50]; at most 64 */
+	int32_t neigh_k_min;			 /* pca_neighbor_k_min [8] */
+	int32_t pca_down_rate;			 /* [1]: every pca_down_rate-th point is a query, all are neighbours */
+	float edge_thre, planar_thre;	 /* linearity_thre, planarity_thre [0.65, 0.65] */
+	float edge_thre_down, planar_thre_down; /* [0.75, 0.75]; only read when sharpen_with_nms = 0 */
+	int32_t extract_vertex_points_method;	/* [2]; 0 = no promotion of high-curvature points to pillar / beam */
+	float curvature_thre;					/* [0.10] */
+	float vertex_curvature_non_max_radius;	/* unused upstream too (1.5 * radius) */
+	float linear_vertical_sin_high_thre, linear_vertical_sin_low_thre; /* [0.94, 0.17]: pillar above, beam below */
+	float planar_vertical_sin_high_thre, planar_vertical_sin_low_thre; /* [0.98, 0.34]: roof above, facade below */
+	uint8_t fixed_num_downsampling;			/* [0] */
+	uint8_t sharpen_with_nms;				/* [1] */
+	uint8_t use_distance_adaptive_pca;		/* [0] */
+	uint8_t reserved_;
+	int32_t pillar_down_fixed_num, facade_down_fixed_num, beam_down_fixed_num, roof_down_fixed_num, unground_down_fixed_num; /* [200, 800, 200, 200, 20000] */
+	float beam_height_max, roof_height_min; /* [FLT_MAX, 0.0] */
+	float feature_pts_ratio_guess;			/* [0.3] */
+	uint64_t rng_seed;						/* ABI-only: the fixed-number down-samplings use the seeded order-preserving selection of mulls_params.rng_seed */
+} mulls_classify_params;
+
+void mulls_classify_default_params(mulls_classify_params *p);
+
+enum mulls_classify_cloud
+{
+	MULLS_CL_PILLAR = 0,
+	MULLS_CL_BEAM = 1,
+	MULLS_CL_FACADE = 2,
+	MULLS_CL_ROOF = 3,
+	MULLS_CL_PILLAR_DOWN = 4,
+	MULLS_CL_BEAM_DOWN = 5,
+	MULLS_CL_FACADE_DOWN = 6,
+	MULLS_CL_ROOF_DOWN = 7,
+	MULLS_CL_VERTEX = 8, /* the key points this call appends to cloud_vertex */
+	MULLS_CL_COUNT = 9
+};
+
+/* classify_nground_pts on the `n` non-ground points of a scan (48-byte records, `stride` bytes apart; normally mulls_ground_filter's
+ * `unground`).  out[k] / cap[k] / n_out[k], k = enum mulls_classify_cloud: host buffers of 48-byte records, capacities in points, sizes; a
+ * cloud larger than its capacity is truncated to it (its size is still reported); out[k] may be NULL with cap[k] = 0.
+ * Neighbourhoods are exact (the neighbor_k nearest within the radius, by (distance, index)); what pcl::PCA / Eigen compute is restated (float
+ * covariance in neighbour order, Jacobi in double; a direction's largest component is positive) — see DESIGN.md section 11 for what that means
+ * for points within ~1e-6 of a threshold.  non_max_suppress's visiting order (and the order the class clouds are left in) is std::sort's by
+ * normal[3] descending, ties included: the keys are sorted by the host's std::sort, the one order upstream's own build would produce. */
+int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_classify_params *params, void *const out[MULLS_CL_COUNT],
+						   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT]);
+
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 
 /* batch_transform_feature_points (cregistration.hpp:1685-1696): in place on a host cloud via the device kernel */

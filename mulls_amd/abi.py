@@ -210,6 +210,73 @@ def ground_params(**overrides):
     return p
 
 
+class ClassifyParams(C.Structure):
+    _fields_ = [
+        ("neighbor_searching_radius", C.c_float),
+        ("neighbor_k", C.c_int32),
+        ("neigh_k_min", C.c_int32),
+        ("pca_down_rate", C.c_int32),
+        ("edge_thre", C.c_float),
+        ("planar_thre", C.c_float),
+        ("edge_thre_down", C.c_float),
+        ("planar_thre_down", C.c_float),
+        ("extract_vertex_points_method", C.c_int32),
+        ("curvature_thre", C.c_float),
+        ("vertex_curvature_non_max_radius", C.c_float),
+        ("linear_vertical_sin_high_thre", C.c_float),
+        ("linear_vertical_sin_low_thre", C.c_float),
+        ("planar_vertical_sin_high_thre", C.c_float),
+        ("planar_vertical_sin_low_thre", C.c_float),
+        ("fixed_num_downsampling", C.c_uint8),
+        ("sharpen_with_nms", C.c_uint8),
+        ("use_distance_adaptive_pca", C.c_uint8),
+        ("reserved_", C.c_uint8),
+        ("pillar_down_fixed_num", C.c_int32),
+        ("facade_down_fixed_num", C.c_int32),
+        ("beam_down_fixed_num", C.c_int32),
+        ("roof_down_fixed_num", C.c_int32),
+        ("unground_down_fixed_num", C.c_int32),
+        ("beam_height_max", C.c_float),
+        ("roof_height_min", C.c_float),
+        ("feature_pts_ratio_guess", C.c_float),
+        ("rng_seed", C.c_uint64),
+    ]
+
+
+CL_PILLAR, CL_BEAM, CL_FACADE, CL_ROOF, CL_PILLAR_DOWN, CL_BEAM_DOWN, CL_FACADE_DOWN, CL_ROOF_DOWN, CL_VERTEX, CL_COUNT = range(10)
+CL_NAMES = ("pillar", "beam", "facade", "roof", "pillar_down", "beam_down", "facade_down", "roof_down", "vertex")
+
+
+def classify_params(**overrides):
+    """classify_nground_pts's arguments as extract_semantic_pts passes them for script/run_mulls_reg.sh (mulls_classify_default_params)."""
+    p = ClassifyParams()
+    kw = dict(neighbor_searching_radius=1.0, neighbor_k=50, neigh_k_min=8, pca_down_rate=1, edge_thre=0.65, planar_thre=0.65, edge_thre_down=0.75,
+              planar_thre_down=0.75, extract_vertex_points_method=2, curvature_thre=0.10, vertex_curvature_non_max_radius=1.5,
+              linear_vertical_sin_high_thre=0.94, linear_vertical_sin_low_thre=0.17, planar_vertical_sin_high_thre=0.98,
+              planar_vertical_sin_low_thre=0.34, fixed_num_downsampling=0, sharpen_with_nms=1, use_distance_adaptive_pca=0, pillar_down_fixed_num=200,
+              facade_down_fixed_num=800, beam_down_fixed_num=200, roof_down_fixed_num=200, unground_down_fixed_num=20000,
+              beam_height_max=3.4028234663852886e38, roof_height_min=0.0, feature_pts_ratio_guess=0.3, rng_seed=0)
+    kw.update(overrides)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def records(a):
+    """Any point array (POINT_DTYPE records or raw (n, 48) bytes) as contiguous raw (n, 48) uint8 records, every byte kept."""
+    a = np.asarray(a)
+    if a.dtype == np.uint8 and a.ndim == 2 and a.shape[1] == POINT_BYTES:
+        return np.ascontiguousarray(a)
+    pts = as_points(a)
+    return pts.view(np.uint8).reshape(len(pts), POINT_BYTES)
+
+
+def points_of(raw):
+    """Raw (n, 48) records viewed as POINT_DTYPE (no copy)."""
+    raw = np.ascontiguousarray(raw)
+    return raw.reshape(-1).view(POINT_DTYPE)
+
+
 class Profile(C.Structure):
     _fields_ = [
         ("ms_setup", C.c_double),

@@ -29,6 +29,8 @@ struct mulls_ctx
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	std::vector<mulls_map *> maps; // live local maps: their buffers are the device clouds mulls_pair may point to
 	void *gf_buf = nullptr; // mulls_ground_filter's device arena (grow-only)
+	void *cl_buf = nullptr; // mulls_classify_nground's device arena (grow-only)
+	size_t cl_cap = 0;
 	size_t gf_cap = 0;
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };

@@ -945,6 +945,8 @@ extern "C"
 	{
 		if (ctx && ctx->gf_buf)
 			(void)hipFree(ctx->gf_buf);
+		if (ctx && ctx->cl_buf)
+			(void)hipFree(ctx->cl_buf);
 		if (!ctx)
 			return;
 		(void)hipSetDevice(ctx->device);

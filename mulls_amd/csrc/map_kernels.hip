@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "map_launch.h"
+#include "pca_device.h"
 
 namespace
 {
@@ -271,38 +272,6 @@ __global__ void k_map_keep(const float4 *__restrict__ frame, uint32_t n_frame, c
 //   pcl::PCA        float centroid and float demeaned covariance summed in the neighbours' order, scaled by 1/(n-1); the
 //                   eigen-decomposition of that float matrix in double (cyclic Jacobi), eigenvalues rounded to float
 #define MAP_PCA_K 24 // list slots per lane (max_k <= 24: 48 KB of lists per workgroup)
-namespace
-{
-struct Sym3
-{
-	double xx, xy, xz, yy, yz, zz;
-};
-// one Jacobi rotation annihilating a(p,q); the matrix is carried as named scalars so that nothing is indexed dynamically
-#define MAP_ROT(app, aqq, apq, apr, aqr, vxp, vxq, vyp, vyq, vzp, vzq)                                  \
-	if (apq != 0.0)                                                                                      \
-	{                                                                                                    \
-		const double theta = (aqq - app) / (2.0 * apq);                                                  \
-		const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));          \
-		const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;                                          \
-		/* A <- A J : columns p and q */                                                                 \
-		const double c_pp = cs * app - sn * apq, c_pq = sn * app + cs * apq;                             \
-		const double c_qp = cs * apq - sn * aqq, c_qq = sn * apq + cs * aqq;                             \
-		const double c_rp = cs * apr - sn * aqr, c_rq = sn * apr + cs * aqr;                             \
-		/* A <- J^T A : rows p and q (the third row's entries are c_rp, c_rq by symmetry) */             \
-		app = cs * c_pp - sn * c_qp;                                                                     \
-		aqq = sn * c_pq + cs * c_qq;                                                                     \
-		apq = cs * c_pq - sn * c_qq;                                                                     \
-		apr = c_rp;                                                                                      \
-		aqr = c_rq;                                                                                      \
-		double u = vxp, w = vxq;                                                                         \
-		vxp = cs * u - sn * w, vxq = sn * u + cs * w;                                                    \
-		u = vyp, w = vyq;                                                                                \
-		vyp = cs * u - sn * w, vyq = sn * u + cs * w;                                                    \
-		u = vzp, w = vzq;                                                                                \
-		vzp = cs * u - sn * w, vzq = sn * u + cs * w;                                                    \
-	}
-} // namespace
-
 __global__ __launch_bounds__(256) void k_map_pca(MapPcaArgs a)
 {
 	__shared__ float tx[256], ty[256], tz[256];
@@ -374,57 +343,17 @@ __global__ __launch_bounds__(256) void k_map_pca(MapPcaArgs a)
 			s0 += dx * dx, s1 += dx * dy, s2 += dx * dz, s3 += dy * dy, s4 += dy * dz, s5 += dz * dz;
 		}
 		const float alpha = 1.f / ((float)m - 1.f);
-		double a00 = (double)(alpha * s0), a01 = (double)(alpha * s1), a02 = (double)(alpha * s2), a11 = (double)(alpha * s3), a12 = (double)(alpha * s4),
-			   a22 = (double)(alpha * s5);
-		double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
-		for (int sweep = 0; sweep < 60; sweep++)
-		{
-			const double off = a01 * a01 + a02 * a02 + a12 * a12;
-			if (off < 1e-300)
-				break;
-			MAP_ROT(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21) // (0,1)
-			MAP_ROT(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22) // (0,2)
-			MAP_ROT(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22) // (1,2)
-		}
-		// the largest and the second eigenvalue (descending selection, the lower index first among equals) and the first one's vector
-		double e0 = a00, e1d = a11, e2d = a22, px = v00, py = v10, pz = v20, qx2 = v01, qy2 = v11, qz2 = v21;
-		if (e1d > e0)
-		{
-			double w = e0;
-			e0 = e1d, e1d = w;
-			w = px, px = qx2, qx2 = w;
-			w = py, py = qy2, qy2 = w;
-			w = pz, pz = qz2, qz2 = w;
-		}
-		if (e2d > e0)
-		{
-			const double w = e0;
-			e0 = e2d, e2d = w;
-			px = v02, py = v12, pz = v22;
-		}
-		if (e2d > e1d)
-			e1d = e2d;
-		const double l1 = e0, l2 = e1d;
-		const double nrm = sqrt(px * px + py * py + pz * pz);
-		int big = 0;
-		double bigv = fabs(px);
-		if (fabs(py) > bigv)
-			big = 1, bigv = fabs(py);
-		if (fabs(pz) > bigv)
-			big = 2;
-		const double lead = big == 0 ? px : (big == 1 ? py : pz);
-		const double sgn = lead < 0 ? -1.0 : 1.0;
-		const float e1 = (float)l1, e2 = (float)l2;
-		float dx = (float)(sgn * px / nrm), dy = (float)(sgn * py / nrm), dz = (float)(sgn * pz / nrm);
-		const float dn = sqrtf(dx * dx + dy * dy + dz * dz); // Vector3f::normalize()
-		dx /= dn, dy /= dn, dz /= dn;
-		const float linear_2 = (e1 - e2) / e1;
-		if (linear_2 > a.min_linearity && (fabsf(dz) > a.sin_high || fabsf(dz) < a.sin_low))
+		const mulls_pca::Eig E = mulls_pca::eigen3(alpha * s0, alpha * s1, alpha * s2, alpha * s3, alpha * s4, alpha * s5);
+		const float e1 = E.e1, e2 = E.e2;
+		float dx = E.px, dy = E.py, dz = E.pz;
+		mulls_pca::normalize3(dx, dy, dz); // Vector3f::normalize()
+		const double linear_2 = ((double)e1 - (double)e2) / (double)e1; // pca_feature_t keeps eigenvalues and ratios as doubles (pca.hpp:18-40)
+		if (linear_2 > (double)a.min_linearity && (fabsf(dz) > a.sin_high || fabsf(dz) < a.sin_low))
 		{
 			keep = 1;
-			a.recs[(size_t)i * 3 + 1] = make_float4(dx, dy, dz, linear_2); // assign_normal(pt, feature, false)
+			a.recs[(size_t)i * 3 + 1] = make_float4(dx, dy, dz, (float)linear_2); // assign_normal(pt, feature, false)
 			float4 r2v = a.recs[(size_t)i * 3 + 2];
-			r2v.y = linear_2; // curvature <- linearity (:280)
+			r2v.y = (float)linear_2; // curvature <- linearity (:280)
 			a.recs[(size_t)i * 3 + 2] = r2v;
 		}
 	}

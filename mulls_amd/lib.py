@@ -71,6 +71,10 @@ def load():
     lib.mulls_ground_default_params.restype = None
     lib.mulls_ground_filter.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.GroundParams), vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32,
                                         C.POINTER(C.c_uint32)]
+    lib.mulls_classify_default_params.argtypes = [C.POINTER(abi.ClassifyParams)]
+    lib.mulls_classify_default_params.restype = None
+    lib.mulls_classify_nground.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ClassifyParams), C.POINTER(vp), C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -86,6 +90,7 @@ EXPORTS = [
     "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
     "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
     "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
+    "mulls_classify_default_params", "mulls_classify_nground",
 ]
 
 
@@ -216,6 +221,19 @@ class Context:
         self._check(self.lib.mulls_ground_filter(self.h, pts.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), raw[0].ctypes.data_as(C.c_void_p), n,
                                                  raw[1].ctypes.data_as(C.c_void_p), n, raw[2].ctypes.data_as(C.c_void_p), n, nout), "mulls_ground_filter")
         return [raw[k][: nout[k] * abi.POINT_BYTES].reshape(nout[k], abi.POINT_BYTES).copy() for k in range(3)]
+
+    # --- feature extraction, second stage -----------------------------------------------------------------------------------
+    def classify_nground(self, pts, params):
+        """CFilter::classify_nground_pts on the device.  Returns the nine clouds of enum mulls_classify_cloud as (n, 48) uint8 record arrays."""
+        raw_in = abi.records(pts)
+        n = len(raw_in)
+        outs = [np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8) for _ in range(abi.CL_COUNT)]
+        out_p = (C.c_void_p * abi.CL_COUNT)(*[o.ctypes.data for o in outs])
+        cap = (C.c_uint32 * abi.CL_COUNT)(*([n] * abi.CL_COUNT))
+        nout = (C.c_uint32 * abi.CL_COUNT)()
+        self._check(self.lib.mulls_classify_nground(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), out_p, cap, nout),
+                    "mulls_classify_nground")
+        return [outs[k][: nout[k]].copy() for k in range(abi.CL_COUNT)]
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

@@ -32,6 +32,18 @@ namespace lo
 #include "util_types.inc"
 #include "util_cloudutility.inc"
 };
+// pca.hpp: pca_feature_t and the member functions of PrincipleComponentAnalysis that do the neighbourhood PCA (its other members wrap
+// pcl::NormalEstimationOMP: the ground filter's normal methods 1 / 2, never reached)
+#include "pca_types.inc"
+template <typename PointT>
+class PrincipleComponentAnalysis
+{
+  public:
+	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+#include "pca_body.inc"
+};
+
 template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
@@ -46,7 +58,6 @@ class CRegistration : public CloudUtility<PointT>
 };
 #include "map_decl.inc"
 #include "map_body.inc"
-bool MapManager::update_cloud_vectors(pcTPtr, const pcTreePtr, float, int, int, float, float, float) { std::abort(); }
 } // namespace lo
 
 #include "cregistration_hip.hpp" // the adapter under test: sees exactly the types a MULLS translation unit has at this point

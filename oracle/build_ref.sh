@@ -40,11 +40,18 @@ extract utility.hpp 795 886 "template <typename PointT>" util_cloudutility.inc
 # cfilter.hpp: grid_t, motion compensation, random down-sampling, box filter, the ground filter, pair intersection
 extract cfilter.hpp 45 69 "struct grid_t" cfilter_body.inc
 extract cfilter.hpp 470 549 "void apply_motion_compensation" cfilter_body.inc
+extract cfilter.hpp 551 602 "bool xy_normal_balanced_downsample" cfilter_body.inc
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
 extract cfilter.hpp 685 712 "bool random_downsample_pcl(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
+extract cfilter.hpp 1071 1181 "bool encode_stable_points" cfilter_body.inc
+extract cfilter.hpp 1243 1312 "bool non_max_suppress(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 1658 2036 "bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
+extract cfilter.hpp 2058 2290 "bool classify_nground_pts" cfilter_body.inc
+# pca.hpp: pca_feature_t and the neighbourhood PCA (get_pc_pca_feature x2, calculate_normal_inconsistency, get_pca_feature, assign_normal)
+extract pca.hpp 23 54 "struct eigenvalue_t" pca_types.inc
+extract pca.hpp 207 454 "// R - K neighborhood (without already built-kd tree)" pca_body.inc
 extract cfilter.hpp 2613 2655 "bool get_cloud_pair_intersection" cfilter_body.inc
 # cregistration.hpp: the driver and every helper on the path
 extract cregistration.hpp 1114 1440 "int mm_lls_icp(constraint_t &registration_cons" creg_body.inc
@@ -56,11 +63,12 @@ extract cregistration.hpp 2518 2722 "bool get_multi_metrics_lls_residual" creg_b
 extract cregistration.hpp 2740 2764 "bool construct_trans_a" creg_body.inc
 extract cregistration.hpp 2795 2836 "bool get_quat_euler_jacobi" creg_body.inc
 extract cregistration.hpp 2866 2922 "bool keep_less_source_pts" creg_body.inc
-# local map manager: class declaration, update_local_map, dynamic removal (update_cloud_vectors = PCA, not extracted)
+# local map manager: class declaration, update_local_map, dynamic removal, PCA refresh of the linear features
 extract "$REF/include/pgo/map_manager.h" 19 52 "class MapManager" map_decl.inc
 extract "$REF/src/map_manager.cpp" 18 140 "bool MapManager::update_local_map" map_body.inc
 extract "$REF/src/map_manager.cpp" 149 218 "bool MapManager::map_based_dynamic_close_removal" map_body.inc
 extract "$REF/src/map_manager.cpp" 222 256 "bool MapManager::map_scan_feature_pts_distance_removal" map_body.inc
+extract "$REF/src/map_manager.cpp" 258 292 "bool MapManager::update_cloud_vectors" map_body.inc
 
 mkdir -p "$HERE/_ref"
 # same flags as the reference's Release build (CMakeLists.txt:43: -O3, no -march); no OpenMP: the only pragmas on the path

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../include/mulls_hip.h"
+#include "pcl_restated.h"
 
 namespace
 {
@@ -2122,153 +2123,33 @@ void distance_removal(Cloud &pts, const Cloud &tree_pts, float center_radius, fl
 	pts.swap(out);
 }
 // ---------------------------------------------------------------------------------------------------------
-// MapManager::update_cloud_vectors (src/map_manager.cpp:258-292), the PCA refresh of the local map's linear features
-// (recalculate_feature_on, :98-118) with what it calls: PrincipleComponentAnalysis::get_pc_pca_feature (pca.hpp:209-290),
-// get_pca_feature (:392-437), assign_normal (:440-456).  The third-party pieces, restated (PCL 1.8-1.10 as remembered; neither PCL nor
-// Eigen is in this image — "parity unpinned" for them):
-//   pcl::KdTreeFLANN::radiusSearch(index, radius, k_indices, k_sqr_distances, max_nn)   the max_nn nearest points with
-//       squared L2_Simple<float> distance < radius^2 (FLANN's KNNRadiusResultSet: a candidate is taken while dist < worst, worst starting
-//       at the squared radius), ascending by distance; ties by index here (FLANN: implementation-defined).  The query point is a member.
-//   pcl::PCA<PointT> (pcl/common/impl/pca.hpp)   mean_ by compute3DCentroid (float accumulators), the demeaned float coordinates,
-//       covariance = 1/(n-1) * D D^T in float, Eigen::SelfAdjointEigenSolver<Eigen::Matrix3f>; eigenvalues descending, eigenvectors
-//       as columns.  Here: the float sums in the neighbours' order, the eigen-decomposition by cyclic Jacobi rotations in double on the
-//       float covariance, rounded to float; an eigenvector's sign (arbitrary in Eigen) is fixed by making its largest component
-//       positive.  Eigen's float solver is accurate to ~1e-6 of the largest eigenvalue: the comparisons with the thresholds below can
-//       differ from it for points that close to a threshold.
-struct PcaFeature
+// PrincipleComponentAnalysis (pca.hpp): get_pc_pca_feature in its two overloads (:209-290 without, :292-352 with a kd-tree
+// argument), get_pca_feature (:392-437), assign_normal (:440-456).  What they call of PCL / FLANN / Eigen is in pcl_restated.h.
+struct PcaFeature // pca_feature_t (pca.hpp:18-47): eigenvalues and the ratios derived from them are doubles, the directions floats
 {
-	float lamada1 = 0, lamada2 = 0, lamada3 = 0, curvature = 0, linear_2 = 0, planar_2 = 0, spherical_2 = 0;
+	double lamada1 = 0, lamada2 = 0, lamada3 = 0, curvature = 0, linear_2 = 0, planar_2 = 0, spherical_2 = 0;
 	float principal[3] = {0, 0, 0}, normal[3] = {0, 0, 0};
 	int pt_num = 0;
+	std::vector<int> neighbor_indices;
+	std::vector<char> close_to_query_point;
 };
-void radius_knn(const Cloud &c, size_t q, float radius, int max_nn, std::vector<int> &idx, std::vector<float> &d2)
-{
-	const float r2 = radius * radius;
-	std::vector<std::pair<float, int>> all;
-	for (size_t t = 0; t < c.size(); t++)
-	{
-		const float d = l2_simple(c[q], c[t]);
-		if (d < r2)
-			all.push_back(std::make_pair(d, (int)t));
-	}
-	std::sort(all.begin(), all.end()); // (distance, index)
-	if (max_nn > 0 && (int)all.size() > max_nn)
-		all.resize(max_nn);
-	idx.clear();
-	d2.clear();
-	for (size_t k = 0; k < all.size(); k++)
-	{
-		d2.push_back(all[k].first);
-		idx.push_back(all[k].second);
-	}
-}
-// eigen-decomposition of a symmetric 3x3 (a = xx xy xz yy yz zz): cyclic Jacobi, eigenvalues descending, unit eigenvectors (columns of v)
-void jacobi3(const double a6[6], double lam[3], double v[3][3])
-{
-	double A[3][3] = {{a6[0], a6[1], a6[2]}, {a6[1], a6[3], a6[4]}, {a6[2], a6[4], a6[5]}};
-	for (int r = 0; r < 3; r++)
-		for (int c = 0; c < 3; c++)
-			v[r][c] = r == c ? 1.0 : 0.0;
-	for (int sweep = 0; sweep < 60; sweep++)
-	{
-		const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-		if (off < 1e-300)
-			break;
-		for (int p = 0; p < 2; p++)
-			for (int q = p + 1; q < 3; q++)
-			{
-				if (A[p][q] == 0.0)
-					continue;
-				const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-				const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-				const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-				for (int k = 0; k < 3; k++) // A <- A J
-				{
-					const double akp = A[k][p], akq = A[k][q];
-					A[k][p] = cs * akp - sn * akq;
-					A[k][q] = sn * akp + cs * akq;
-				}
-				for (int k = 0; k < 3; k++) // A <- J^T A
-				{
-					const double apk = A[p][k], aqk = A[q][k];
-					A[p][k] = cs * apk - sn * aqk;
-					A[q][k] = sn * apk + cs * aqk;
-				}
-				for (int r = 0; r < 3; r++) // the upper triangle is the matrix
-					for (int c2 = r + 1; c2 < 3; c2++)
-						A[c2][r] = A[r][c2];
-				for (int k = 0; k < 3; k++)
-				{
-					const double vkp = v[k][p], vkq = v[k][q];
-					v[k][p] = cs * vkp - sn * vkq;
-					v[k][q] = sn * vkp + cs * vkq;
-				}
-			}
-	}
-	int ord[3] = {0, 1, 2};
-	for (int i = 0; i < 3; i++)
-		for (int j = i + 1; j < 3; j++)
-			if (A[ord[j]][ord[j]] > A[ord[i]][ord[i]])
-				std::swap(ord[i], ord[j]);
-	double vv[3][3];
-	for (int i = 0; i < 3; i++)
-	{
-		lam[i] = A[ord[i]][ord[i]];
-		double nrm = 0;
-		for (int k = 0; k < 3; k++)
-			nrm += v[k][ord[i]] * v[k][ord[i]];
-		nrm = std::sqrt(nrm);
-		int big = 0;
-		for (int k = 1; k < 3; k++)
-			if (std::fabs(v[k][ord[i]]) > std::fabs(v[big][ord[i]]))
-				big = k;
-		const double sgn = v[big][ord[i]] < 0 ? -1.0 : 1.0;
-		for (int k = 0; k < 3; k++)
-			vv[k][i] = sgn * v[k][ord[i]] / nrm;
-	}
-	std::memcpy(v, vv, sizeof(vv));
-}
-bool pca_feature(const Cloud &c, const std::vector<int> &idx, PcaFeature &f) // get_pca_feature (pca.hpp:392-437)
+bool pca_feature(const Cloud &c, std::vector<int> &idx, PcaFeature &f) // get_pca_feature (:392-437)
 {
 	const int pt_num = (int)idx.size();
 	if (pt_num <= 3)
 		return false;
-	float mx = 0, my = 0, mz = 0; // compute3DCentroid: float accumulators, then divided by the count
-	for (int i = 0; i < pt_num; i++)
+	float eval[3], evec[3][3];
+	restated::pca(c, idx, eval, evec);
+	for (int k = 0; k < 3; k++)
 	{
-		mx += c[idx[i]].x;
-		my += c[idx[i]].y;
-		mz += c[idx[i]].z;
+		f.principal[k] = evec[k][0];
+		f.normal[k] = evec[k][2];
 	}
-	mx /= (float)pt_num;
-	my /= (float)pt_num;
-	mz /= (float)pt_num;
-	float s[6] = {0, 0, 0, 0, 0, 0};
-	for (int i = 0; i < pt_num; i++)
-	{
-		const float dx = c[idx[i]].x - mx, dy = c[idx[i]].y - my, dz = c[idx[i]].z - mz;
-		s[0] += dx * dx;
-		s[1] += dx * dy;
-		s[2] += dx * dz;
-		s[3] += dy * dy;
-		s[4] += dy * dz;
-		s[5] += dz * dz;
-	}
-	const float alpha = 1.f / ((float)pt_num - 1.f);
-	double a6[6], lam[3], v[3][3];
-	for (int k = 0; k < 6; k++)
-		a6[k] = (double)(alpha * s[k]);
-	jacobi3(a6, lam, v);
-	f.lamada1 = (float)lam[0];
-	f.lamada2 = (float)lam[1];
-	f.lamada3 = (float)lam[2];
-	float pd[3] = {(float)v[0][0], (float)v[1][0], (float)v[2][0]}, nd[3] = {(float)v[0][2], (float)v[1][2], (float)v[2][2]};
-	const float pn = std::sqrt(pd[0] * pd[0] + pd[1] * pd[1] + pd[2] * pd[2]), nn = std::sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
-	for (int k = 0; k < 3; k++) // Vector3f::normalize()
-	{
-		f.principal[k] = pd[k] / pn;
-		f.normal[k] = nd[k] / nn;
-	}
+	restated::normalize3(f.principal);
+	restated::normalize3(f.normal);
+	f.lamada1 = eval[0];
+	f.lamada2 = eval[1];
+	f.lamada3 = eval[2];
 	if ((f.lamada1 + f.lamada2 + f.lamada3) == 0)
 		f.curvature = 0;
 	else
@@ -2276,32 +2157,324 @@ bool pca_feature(const Cloud &c, const std::vector<int> &idx, PcaFeature &f) // 
 	f.linear_2 = ((f.lamada1) - (f.lamada2)) / (f.lamada1);
 	f.planar_2 = ((f.lamada2) - (f.lamada3)) / (f.lamada1);
 	f.spherical_2 = (f.lamada3) / (f.lamada1);
+	idx.swap(f.neighbor_indices);
 	return true;
 }
-// update_cloud_vectors(feature_pts, tree, pca_radius, pca_k, k_min, sin_low, sin_high, min_linearity)
+void assign_normal(Pt &pt, const PcaFeature &f, bool is_plane_feature = true) // :440-456
+{
+	const float *d = is_plane_feature ? f.normal : f.principal;
+	pt.nx = d[0];
+	pt.ny = d[1];
+	pt.nz = d[2];
+	pt.n3 = (float)(is_plane_feature ? f.planar_2 : f.linear_2);
+}
+// with_tree: the overload taking the kd-tree (:292-352; distance-adaptive radius from the 3-D range, square-root law) — the other one
+// (:209-290) adapts linearly to the planar range and is "deprecated" there
+void get_pc_pca_feature(Cloud &cloud, std::vector<PcaFeature> &features, bool with_tree, float radius, int nearest_k, int min_k, int pca_down_rate,
+						bool distance_adaptive_on, float unit_dist)
+{
+	features.assign(cloud.size(), PcaFeature());
+	const Cloud positions = cloud; // the loop writes normals into the cloud it searches: only x, y, z are ever read back
+	restated::RadiusIndex<Pt> tree;
+	tree.build(positions, radius);
+	if (pca_down_rate < 1)
+		pca_down_rate = 1; // upstream: i += 0 never ends
+	std::vector<int> search_indices;
+	std::vector<float> squared_distances;
+	for (size_t i = 0; i < cloud.size(); i += (size_t)pca_down_rate)
+	{
+		float neighborhood_r = radius;
+		if (distance_adaptive_on)
+		{
+			if (with_tree)
+			{
+				double dist = std::sqrt(cloud[i].x * cloud[i].x + cloud[i].y * cloud[i].y + cloud[i].z * cloud[i].z);
+				if (dist > unit_dist)
+					neighborhood_r = std::sqrt(dist / unit_dist) * radius;
+			}
+			else
+			{
+				double dist = std::sqrt(cloud[i].x * cloud[i].x + cloud[i].y * cloud[i].y);
+				const double scaled = dist / unit_dist * radius;
+				neighborhood_r = (radius > scaled) ? radius : scaled; // max_(radius, dist / unit_dist * radius)
+			}
+		}
+		tree.search(positions[i], neighborhood_r, (unsigned)nearest_k, search_indices, squared_distances);
+		PcaFeature &f = features[i];
+		f.pt_num = (int)search_indices.size();
+		f.close_to_query_point.resize(search_indices.size());
+		for (size_t j = 0; j < search_indices.size(); j++)
+			f.close_to_query_point[j] = squared_distances[j] < 0.64 * radius * radius;
+		pca_feature(positions, search_indices, f);
+		if (f.pt_num > min_k)
+			assign_normal(cloud[i], f);
+	}
+}
+// ---------------------------------------------------------------------------------------------------------
+// CFilter::classify_nground_pts (cfilter.hpp:2058-2290) and what it calls: encode_stable_points (:1071-1181), non_max_suppress
+// (:1243-1311), xy_normal_balanced_downsample (:551-602), random_downsample_pcl (:606-628).
+std::atomic<unsigned long long> g_nms_ties{0}; // pairs of neighbours in non_max_suppress's visiting order with equal normal[3]
+
+// non_max_suppress(cloud_in, cloud_out, nms_radius).  The visiting order is std::sort's by normal[3] descending: among equal keys — a few
+// hundred per scan, points of one small cluster share their neighbourhood — it is whatever this toolchain's introsort leaves, upstream as
+// here (the permutation depends on the keys and the element count only, not on what is attached to a key)
+bool non_max_suppress(Cloud &cloud_in, Cloud &cloud_out, float nms_radius)
+{
+	const int pt_count_before = (int)cloud_in.size();
+	if (pt_count_before < 10)
+		return false;
+	std::sort(cloud_in.begin(), cloud_in.end(), [](const Pt &a, const Pt &b) { return a.n3 > b.n3; });
+	for (int i = 1; i < pt_count_before; i++)
+		if (cloud_in[i].n3 == cloud_in[i - 1].n3)
+			g_nms_ties++;
+	std::vector<char> visited(pt_count_before, 0);
+	restated::RadiusIndex<Pt> tree;
+	tree.build(cloud_in, nms_radius);
+	std::vector<int> search_indices;
+	std::vector<float> distances;
+	for (int id = 0; id < pt_count_before; id++) // *unVisitedPtId.begin(): the lowest id not yet erased
+	{
+		if (visited[id])
+			continue;
+		cloud_out.push_back(cloud_in[id]);
+		visited[id] = 1;
+		tree.search(cloud_in[id], nms_radius, 0, search_indices, distances);
+		for (size_t i = 0; i < search_indices.size(); i++)
+			visited[search_indices[i]] = 1;
+	}
+	return true;
+}
+// xy_normal_balanced_downsample(cloud_in_out, keep_number_per_sector, sector_num)
+bool xy_normal_balanced_downsample(Cloud &cloud, int keep_number_per_sector, int sector_num, uint64_t seed, int cloud_id)
+{
+	if ((long)cloud.size() <= (long)keep_number_per_sector)
+		return false;
+	std::vector<Cloud> sectors(sector_num);
+	const double angle_per_sector = 360.0 / sector_num;
+	for (size_t i = 0; i < cloud.size(); i++)
+	{
+		double ang = std::atan2(cloud[i].ny, cloud[i].nx); // the float overload
+		if (ang < 0)
+			ang += 2 * M_PI;
+		ang *= (180.0 / M_PI);
+		int sector_id = (int)(ang / angle_per_sector);
+		if (sector_id >= sector_num) // -tiny + 2 pi rounds to 2 pi: upstream writes past the last sector; the ABI puts the point into the last one
+			sector_id = sector_num - 1;
+		if (sector_id < 0) // NaN normals: (int)NaN is INT_MIN on x86
+			sector_id = 0;
+		sectors[sector_id].push_back(cloud[i]);
+	}
+	Cloud temp;
+	for (int j = 0; j < sector_num; j++)
+	{
+		random_downsample(sectors[j], keep_number_per_sector, seed, cloud_id + j);
+		temp.insert(temp.end(), sectors[j].begin(), sectors[j].end());
+	}
+	temp.swap(cloud);
+	return true;
+}
+// encode_stable_points(cloud_in, cloud_out, features, index_with_feature, min_curvature, min_feature_point_num_neighborhood, min_point_num_neighborhood)
+void encode_stable_points(const Cloud &cloud_in, Cloud &cloud_out, const std::vector<PcaFeature> &features, const std::vector<int> &index_with_feature,
+						  float min_curvature, int min_feature_point_num_neighborhood, int min_point_num_neighborhood)
+{
+	for (size_t i = 0; i < features.size(); ++i)
+	{
+		if (features[i].pt_num > min_point_num_neighborhood && features[i].curvature > min_curvature)
+		{
+			float accu_intensity = 0.0;
+			Pt pt = cloud_in[i];
+			pt.n3 = features[i].curvature;
+			int cnt[5] = {0, 0, 0, 0, 0}, close_cnt[5] = {0, 0, 0, 0, 0}, far_cnt[5] = {0, 0, 0, 0, 0};
+			const int neighbor_total_count = (int)features[i].neighbor_indices.size();
+			for (int j = 0; j < neighbor_total_count; j++)
+			{
+				const int nb = features[i].neighbor_indices[j];
+				const int lab = index_with_feature[nb];
+				if (lab >= 1 && lab <= 4)
+				{
+					cnt[lab]++;
+					if (features[i].close_to_query_point[j])
+						close_cnt[lab]++;
+					else
+						far_cnt[lab]++;
+				}
+				accu_intensity += cloud_in[nb].intensity;
+			}
+			if (cnt[1] + cnt[2] + cnt[3] + cnt[4] < min_feature_point_num_neighborhood)
+				continue;
+			if (neighbor_total_count == 0) // only with neigh_k_min < 3 and a non-positive minimum: upstream divides by zero below
+				continue;
+			for (int l = 1; l <= 4; l++)
+			{
+				cnt[l] = 100 * cnt[l] / neighbor_total_count;
+				close_cnt[l] = 100 * close_cnt[l] / neighbor_total_count;
+				far_cnt[l] = 100 * far_cnt[l] / neighbor_total_count;
+			}
+			const int descriptor = cnt[1] * 1000000 + cnt[2] * 10000 + cnt[3] * 100 + cnt[4];
+			const int descriptor_1 = close_cnt[1] * 1000000 + close_cnt[2] * 10000 + close_cnt[3] * 100 + close_cnt[4];
+			const int descriptor_2 = far_cnt[1] * 1000000 + far_cnt[2] * 10000 + far_cnt[3] * 100 + far_cnt[4];
+			pt.curvature = descriptor;
+			pt.nx = descriptor_1;
+			pt.ny = descriptor_2;
+			pt.intensity = accu_intensity / neighbor_total_count;
+			cloud_out.push_back(pt);
+		}
+	}
+}
+// clouds: enum mulls_classify_cloud; cloud_in is modified as upstream modifies it (normals of the queried points)
+int classify_nground_impl(Cloud &cloud_in, const mulls_classify_params &P, Cloud out[MULLS_CL_COUNT])
+{
+	Cloud &cloud_pillar = out[MULLS_CL_PILLAR], &cloud_beam = out[MULLS_CL_BEAM], &cloud_facade = out[MULLS_CL_FACADE], &cloud_roof = out[MULLS_CL_ROOF];
+	Cloud &cloud_pillar_down = out[MULLS_CL_PILLAR_DOWN], &cloud_beam_down = out[MULLS_CL_BEAM_DOWN], &cloud_facade_down = out[MULLS_CL_FACADE_DOWN],
+		  &cloud_roof_down = out[MULLS_CL_ROOF_DOWN], &cloud_vertex = out[MULLS_CL_VERTEX];
+	const float neighbor_searching_radius = P.neighbor_searching_radius;
+	const int neighbor_k = P.neighbor_k, neigh_k_min = P.neigh_k_min, pca_down_rate = P.pca_down_rate;
+	if (pca_down_rate < 1 || neighbor_k < 1 || neighbor_k > 64 || !(neighbor_searching_radius > 0))
+		return MULLS_E_INVALID;
+	const float edge_thre = P.edge_thre, planar_thre = P.planar_thre, edge_thre_down = P.edge_thre_down, planar_thre_down = P.planar_thre_down;
+	int extract_vertex_points_method = P.extract_vertex_points_method;
+	const float curvature_thre = P.curvature_thre;
+	const float linear_vertical_sin_high_thre = P.linear_vertical_sin_high_thre, linear_vertical_sin_low_thre = P.linear_vertical_sin_low_thre;
+	const float planar_vertical_sin_high_thre = P.planar_vertical_sin_high_thre, planar_vertical_sin_low_thre = P.planar_vertical_sin_low_thre;
+	const bool fixed_num_downsampling = P.fixed_num_downsampling, sharpen_with_nms = P.sharpen_with_nms;
+	const float beam_height_max = P.beam_height_max, roof_height_min = P.roof_height_min, feature_pts_ratio_guess = P.feature_pts_ratio_guess;
+
+	if (fixed_num_downsampling)
+		random_downsample(cloud_in, P.unground_down_fixed_num, P.rng_seed, 30);
+
+	std::vector<PcaFeature> cloud_features;
+	const float unit_distance = 30.0;
+	get_pc_pca_feature(cloud_in, cloud_features, true, neighbor_searching_radius, neighbor_k, 1, pca_down_rate, P.use_distance_adaptive_pca, unit_distance);
+
+	std::vector<int> index_with_feature(cloud_in.size(), 0); // 0 - not special points, 1 - pillar, 2 - beam, 3 - facade, 4 - roof
+	for (size_t i = 0; i < cloud_in.size(); i++)
+	{
+		const PcaFeature &f = cloud_features[i];
+		if (f.pt_num > neigh_k_min)
+		{
+			if (f.linear_2 > edge_thre)
+			{
+				if (std::abs(f.principal[2]) > linear_vertical_sin_high_thre)
+				{
+					assign_normal(cloud_in[i], f, false);
+					cloud_pillar.push_back(cloud_in[i]);
+					index_with_feature[i] = 1;
+				}
+				else if (std::abs(f.principal[2]) < linear_vertical_sin_low_thre && cloud_in[i].z < beam_height_max)
+				{
+					assign_normal(cloud_in[i], f, false);
+					cloud_beam.push_back(cloud_in[i]);
+					index_with_feature[i] = 2;
+				}
+				if (!sharpen_with_nms && f.linear_2 > edge_thre_down)
+				{
+					if (std::abs(f.principal[2]) > linear_vertical_sin_high_thre)
+						cloud_pillar_down.push_back(cloud_in[i]);
+					else if (std::abs(f.principal[2]) < linear_vertical_sin_low_thre && cloud_in[i].z < beam_height_max)
+						cloud_beam_down.push_back(cloud_in[i]);
+				}
+			}
+			else if (f.planar_2 > planar_thre)
+			{
+				if (std::abs(f.normal[2]) > planar_vertical_sin_high_thre && cloud_in[i].z > roof_height_min)
+				{
+					assign_normal(cloud_in[i], f, true);
+					cloud_roof.push_back(cloud_in[i]);
+					index_with_feature[i] = 4;
+				}
+				else if (std::abs(f.normal[2]) < planar_vertical_sin_low_thre)
+				{
+					assign_normal(cloud_in[i], f, true);
+					cloud_facade.push_back(cloud_in[i]);
+					index_with_feature[i] = 3;
+				}
+				if (!sharpen_with_nms && f.planar_2 > planar_thre_down)
+				{
+					if (std::abs(f.normal[2]) > planar_vertical_sin_high_thre && cloud_in[i].z > roof_height_min)
+						cloud_roof_down.push_back(cloud_in[i]);
+					else if (std::abs(f.normal[2]) < planar_vertical_sin_low_thre)
+						cloud_facade_down.push_back(cloud_in[i]);
+				}
+			}
+		}
+	}
+
+	if (curvature_thre < 1e-8)
+		extract_vertex_points_method = 0;
+	if (extract_vertex_points_method == 2) // high-curvature points among the neighbourhood of geometric feature points; the labels grow while the loop runs
+	{
+		const float vertex_feature_ratio_thre = feature_pts_ratio_guess / pca_down_rate;
+		for (size_t i = 0; i < cloud_in.size(); i++)
+		{
+			const PcaFeature &f = cloud_features[i];
+			if (index_with_feature[i] == 0 && f.pt_num > neigh_k_min && f.curvature > curvature_thre)
+			{
+				int geo_feature_point_count = 0;
+				for (size_t j = 0; j < f.neighbor_indices.size(); j++)
+					if (index_with_feature[f.neighbor_indices[j]])
+						geo_feature_point_count++;
+				if (1.0 * geo_feature_point_count / f.pt_num > vertex_feature_ratio_thre)
+				{
+					assign_normal(cloud_in[i], f, false);
+					cloud_in[i].n3 = 5.0 * f.curvature;
+					if (std::abs(f.principal[2]) > linear_vertical_sin_high_thre)
+					{
+						cloud_pillar.push_back(cloud_in[i]);
+						index_with_feature[i] = 1;
+					}
+					else if (std::abs(f.principal[2]) < linear_vertical_sin_low_thre && cloud_in[i].z < beam_height_max)
+					{
+						cloud_beam.push_back(cloud_in[i]);
+						index_with_feature[i] = 2;
+					}
+				}
+			}
+		}
+	}
+	const int min_neighbor_feature_pts = (int)(feature_pts_ratio_guess / pca_down_rate * neighbor_k) - 1;
+	encode_stable_points(cloud_in, cloud_vertex, cloud_features, index_with_feature, 0.3 * curvature_thre, min_neighbor_feature_pts, neigh_k_min);
+
+	if (sharpen_with_nms)
+	{
+		const float nms_radius = 0.25 * neighbor_searching_radius;
+		if (P.pillar_down_fixed_num > 0)
+			non_max_suppress(cloud_pillar, cloud_pillar_down, nms_radius);
+		if (P.facade_down_fixed_num > 0)
+			non_max_suppress(cloud_facade, cloud_facade_down, nms_radius);
+		if (P.beam_down_fixed_num > 0)
+			non_max_suppress(cloud_beam, cloud_beam_down, nms_radius);
+		if (P.roof_down_fixed_num > 0)
+			non_max_suppress(cloud_roof, cloud_roof_down, nms_radius);
+	}
+	if (fixed_num_downsampling)
+	{
+		random_downsample(cloud_pillar_down, P.pillar_down_fixed_num, P.rng_seed, 31);
+		const int sector_num = 4;
+		xy_normal_balanced_downsample(cloud_facade_down, (int)(P.facade_down_fixed_num / sector_num), sector_num, P.rng_seed, 32);
+		xy_normal_balanced_downsample(cloud_beam_down, (int)(P.beam_down_fixed_num / sector_num), sector_num, P.rng_seed, 36);
+		random_downsample(cloud_roof_down, P.roof_down_fixed_num, P.rng_seed, 40);
+	}
+	return MULLS_OK;
+}
+
+// MapManager::update_cloud_vectors (src/map_manager.cpp:258-292), the PCA refresh of the local map's linear features
+// (recalculate_feature_on, :98-118)
 void update_cloud_vectors(Cloud &pts, float pca_radius, int pca_k, int k_min, float sin_low, float sin_high, float min_linearity)
 {
+	if (pts.size() == 0)
+		return;
+	std::vector<PcaFeature> pca_features;
 	Cloud temp;
-	std::vector<int> idx;
-	std::vector<float> d2;
-	const Cloud positions = pts; // the neighbourhoods only read x, y, z (get_pc_pca_feature overwrites normals while it runs: never read)
+	get_pc_pca_feature(pts, pca_features, false, pca_radius, pca_k, k_min, 1, false, 35.0f);
 	for (size_t i = 0; i < pts.size(); i++)
 	{
-		radius_knn(positions, i, pca_radius, pca_k, idx, d2);
-		PcaFeature f;
-		f.pt_num = (int)idx.size();
-		pca_feature(positions, idx, f);
-		if (f.pt_num >= k_min && f.linear_2 > min_linearity)
+		if (pca_features[i].pt_num >= k_min && pca_features[i].linear_2 > min_linearity)
 		{
-			Pt p = pts[i];
-			p.nx = f.principal[0]; // assign_normal(pt, feature, false): primary direction, linearity in normal[3]
-			p.ny = f.principal[1];
-			p.nz = f.principal[2];
-			p.n3 = f.linear_2;
-			if (std::abs(f.principal[2]) > sin_high || std::abs(f.principal[2]) < sin_low)
+			assign_normal(pts[i], pca_features[i], false);
+			if (std::abs(pca_features[i].principal[2]) > sin_high || std::abs(pca_features[i].principal[2]) < sin_low)
 			{
-				p.curvature = f.linear_2;
-				temp.push_back(p);
+				pts[i].curvature = pca_features[i].linear_2;
+				temp.push_back(pts[i]);
 			}
 		}
 	}
@@ -2311,6 +2484,65 @@ void update_cloud_vectors(Cloud &pts, float pca_radius, int pca_k, int k_min, fl
 
 extern "C"
 {
+	void mulls_oracle_classify_default_params(mulls_classify_params *p)
+	{
+		std::memset(p, 0, sizeof(*p));
+		p->neighbor_searching_radius = 1.0f;
+		p->neighbor_k = 50;
+		p->neigh_k_min = 8;
+		p->pca_down_rate = 1;
+		p->edge_thre = 0.65f;
+		p->planar_thre = 0.65f;
+		p->edge_thre_down = 0.75f;
+		p->planar_thre_down = 0.75f;
+		p->extract_vertex_points_method = 2;
+		p->curvature_thre = 0.10f;
+		p->vertex_curvature_non_max_radius = 1.5f;
+		p->linear_vertical_sin_high_thre = 0.94f;
+		p->linear_vertical_sin_low_thre = 0.17f;
+		p->planar_vertical_sin_high_thre = 0.98f;
+		p->planar_vertical_sin_low_thre = 0.34f;
+		p->sharpen_with_nms = 1;
+		p->pillar_down_fixed_num = 200;
+		p->facade_down_fixed_num = 800;
+		p->beam_down_fixed_num = 200;
+		p->roof_down_fixed_num = 200;
+		p->unground_down_fixed_num = 20000;
+		p->beam_height_max = FLT_MAX;
+		p->roof_height_min = 0.0f;
+		p->feature_pts_ratio_guess = 0.3f;
+	}
+	// same contract as mulls_classify_nground; additionally `in_after` (n records or NULL): cloud_in as the function leaves it
+	int mulls_oracle_classify_nground(const void *pts, uint32_t n, uint32_t stride, const mulls_classify_params *P, void *const out[MULLS_CL_COUNT],
+									  const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *in_after, uint32_t *n_in_after)
+	{
+		Cloud in(n);
+		for (uint32_t i = 0; i < n; i++)
+			std::memcpy(&in[i], (const unsigned char *)pts + (size_t)i * stride, sizeof(Pt));
+		Cloud o[MULLS_CL_COUNT];
+		const int rc = classify_nground_impl(in, *P, o);
+		if (rc != MULLS_OK)
+			return rc;
+		for (int k = 0; k < MULLS_CL_COUNT; k++)
+		{
+			n_out[k] = (uint32_t)o[k].size();
+			const size_t m = std::min<size_t>(o[k].size(), cap[k]);
+			if (m && out[k])
+				std::memcpy(out[k], o[k].data(), m * sizeof(Pt));
+		}
+		if (n_in_after)
+			*n_in_after = (uint32_t)in.size();
+		if (in_after && in.size())
+			std::memcpy(in_after, in.data(), in.size() * sizeof(Pt));
+		return MULLS_OK;
+	}
+	unsigned long long mulls_oracle_nms_ties(int reset)
+	{
+		const unsigned long long v = g_nms_ties;
+		if (reset)
+			g_nms_ties = 0;
+		return v;
+	}
 	void mulls_oracle_map_default_params(mulls_map_params *p)
 	{
 		std::memset(p, 0, sizeof(*p));

@@ -180,3 +180,33 @@ def _ground_filter(fn, pts, params):
 def ground_filter(pts, params):
     """CFilter::fast_ground_filter, oracle restatement.  Returns (ground, ground_down, unground) as (n, 48) uint8 record arrays."""
     return _ground_filter(lib().mulls_oracle_ground_filter, pts, params)
+
+
+def _classify(fn, pts, params):
+    raw_in = abi.records(pts)
+    n = len(raw_in)
+    outs = [np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8) for _ in range(abi.CL_COUNT)]
+    after = np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8)
+    out_p = (C.c_void_p * abi.CL_COUNT)(*[o.ctypes.data for o in outs])
+    cap = (C.c_uint32 * abi.CL_COUNT)(*([n] * abi.CL_COUNT))
+    nout = (C.c_uint32 * abi.CL_COUNT)()
+    n_after = C.c_uint32(0)
+    fn.restype = C.c_int
+    rc = fn(raw_in.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(abi.POINT_BYTES), C.byref(params), out_p, cap, nout,
+            after.ctypes.data_as(C.c_void_p), C.byref(n_after))
+    if rc != 0:
+        raise RuntimeError("classify_nground returned %d" % rc)
+    return [outs[k][: nout[k]].copy() for k in range(abi.CL_COUNT)], after[: n_after.value].copy()
+
+
+def classify_nground(pts, params):
+    """CFilter::classify_nground_pts, oracle restatement.  Returns ([9 clouds in enum mulls_classify_cloud order], cloud_in afterwards), all as
+    raw (n, 48) uint8 records (normal[3] and the other unnamed bytes matter here)."""
+    return _classify(lib().mulls_oracle_classify_nground, pts, params)
+
+
+def nms_ties(reset=False):
+    """How many neighbours in non_max_suppress's visiting order had equal normal[3] so far (the order upstream leaves to std::sort)."""
+    f = lib().mulls_oracle_nms_ties
+    f.restype = C.c_ulonglong
+    return int(f(int(reset)))

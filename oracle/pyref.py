@@ -67,3 +67,10 @@ def ground_filter(pts, params):
     from oracle import pyoracle
 
     return pyoracle._ground_filter(lib().mulls_ref_ground_filter, pts, params)
+
+
+def classify_nground(pts, params):
+    """CFilter::classify_nground_pts, the reference's own lines (cfilter.hpp:2058-2290, with pca.hpp:207-454) over oracle/pcl_restated.h."""
+    from oracle import pyoracle
+
+    return pyoracle._classify(lib().mulls_ref_classify_nground, pts, params)

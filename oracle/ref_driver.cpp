@@ -30,6 +30,18 @@ namespace lo
 #include "util_cloudutility.inc" // template <typename PointT> class CloudUtility { public: ... bbox helpers
 };
 
+// pca.hpp: pca_feature_t and the member functions of PrincipleComponentAnalysis that do the neighbourhood PCA (its other members wrap
+// pcl::NormalEstimationOMP: the ground filter's normal methods 1 / 2, never reached)
+#include "pca_types.inc"
+template <typename PointT>
+class PrincipleComponentAnalysis
+{
+  public:
+	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+#include "pca_body.inc"
+};
+
 template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
@@ -47,9 +59,7 @@ class CRegistration : public CloudUtility<PointT>
 };
 
 #include "map_decl.inc" // class MapManager { ... };
-#include "map_body.inc" // MapManager::update_local_map, ::map_based_dynamic_close_removal, ::map_scan_feature_pts_distance_removal
-// the PCA refresh of the linear features belongs to feature extraction (pca.hpp); never reached: recalculate_feature_on = false
-bool MapManager::update_cloud_vectors(pcTPtr, const pcTreePtr, float, int, int, float, float, float) { std::abort(); }
+#include "map_body.inc" // MapManager::update_local_map, ::map_based_dynamic_close_removal, ::map_scan_feature_pts_distance_removal, ::update_cloud_vectors
 } // namespace lo
 
 namespace
@@ -239,7 +249,7 @@ extern "C" int mulls_ref_map_update(const mulls_cloud map_in[6], const double ma
 	rep->dynamic_removal_ran = (removal && map->feature_point_num > P->max_num_pts / 5) ? 1 : 0;
 	mm.update_local_map(map, frame, P->local_map_radius, P->max_num_pts, P->kept_vertex_num, P->last_frame_reliable_radius, removal,
 						std::string(P->used_feature_type, 6), P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, P->dynamic_dist_thre_max,
-						P->near_dist_thre, false);
+						P->near_dist_thre, P->recalculate_feature_on != 0);
 	for (int c = 0; c < 6; c++)
 	{
 		map_out_n[c] = (uint32_t)(*mc[c])->points.size();
@@ -256,5 +266,38 @@ extern "C" int mulls_ref_map_update(const mulls_cloud map_in[6], const double ma
 	rep->local_bound[3] = map->local_bound.max_x, rep->local_bound[4] = map->local_bound.max_y, rep->local_bound[5] = map->local_bound.max_z;
 	rep->bound[0] = map->bound.min_x, rep->bound[1] = map->bound.min_y, rep->bound[2] = map->bound.min_z;
 	rep->bound[3] = map->bound.max_x, rep->bound[4] = map->bound.max_y, rep->bound[5] = map->bound.max_z;
+	return 0;
+}
+
+// CFilter::classify_nground_pts, the reference's own lines (cfilter.hpp:2058-2290), same contract as mulls_oracle_classify_nground.
+// The fixed-number down-samplings go through pcl::RandomSample (time-seeded upstream, a fixed seed in the shim): only sizes compare.
+extern "C" int mulls_ref_classify_nground(const void *pts, uint32_t n, uint32_t stride, const mulls_classify_params *P, void *const out[MULLS_CL_COUNT],
+										  const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *in_after, uint32_t *n_in_after)
+{
+	mulls_cloud c;
+	c.pts = pts, c.n = n, c.stride = stride;
+	pcTPtr in(new pcT()), o[MULLS_CL_COUNT];
+	fill_cloud(c, in);
+	for (int k = 0; k < MULLS_CL_COUNT; k++)
+		o[k].reset(new pcT());
+	lo::CFilter<Point_T> cf;
+	cf.classify_nground_pts(in, o[MULLS_CL_PILLAR], o[MULLS_CL_BEAM], o[MULLS_CL_FACADE], o[MULLS_CL_ROOF], o[MULLS_CL_PILLAR_DOWN], o[MULLS_CL_BEAM_DOWN],
+							o[MULLS_CL_FACADE_DOWN], o[MULLS_CL_ROOF_DOWN], o[MULLS_CL_VERTEX], P->neighbor_searching_radius, P->neighbor_k, P->neigh_k_min,
+							P->pca_down_rate, P->edge_thre, P->planar_thre, P->edge_thre_down, P->planar_thre_down, P->extract_vertex_points_method,
+							P->curvature_thre, P->vertex_curvature_non_max_radius, P->linear_vertical_sin_high_thre, P->linear_vertical_sin_low_thre,
+							P->planar_vertical_sin_high_thre, P->planar_vertical_sin_low_thre, P->fixed_num_downsampling != 0, P->pillar_down_fixed_num,
+							P->facade_down_fixed_num, P->beam_down_fixed_num, P->roof_down_fixed_num, P->unground_down_fixed_num, P->beam_height_max,
+							P->roof_height_min, P->feature_pts_ratio_guess, P->sharpen_with_nms != 0, P->use_distance_adaptive_pca != 0);
+	for (int k = 0; k < MULLS_CL_COUNT; k++)
+	{
+		n_out[k] = (uint32_t)o[k]->points.size();
+		const size_t m = std::min<size_t>(o[k]->points.size(), cap[k]);
+		if (m && out[k])
+			std::memcpy(out[k], o[k]->points.data(), m * sizeof(Point_T));
+	}
+	if (n_in_after)
+		*n_in_after = (uint32_t)in->points.size();
+	if (in_after && in->points.size())
+		std::memcpy(in_after, in->points.data(), in->points.size() * sizeof(Point_T));
 	return 0;
 }

@@ -16,7 +16,10 @@
 #include <iostream>
 #include <memory>
 #include <string>
+#include <set>
 #include <vector>
+
+#include "pcl_restated.h" // oracle/: the PCL / FLANN / Eigen behaviours of the feature-extraction lines, restated once
 
 // ------------------------------------------------------------------------------------------------------------------
 // glog
@@ -125,6 +128,22 @@ struct Matrix
 		static_assert(R == 1 && C == 1, "only 1x1 converts to scalar");
 		return v[0];
 	}
+	const T &x() const { return v[0]; }
+	const T &y() const { return v[1]; }
+	const T &z() const { return v[2]; }
+	void normalize() // Eigen 3.3: if (squaredNorm() > 0) *this /= sqrt(squaredNorm())
+	{
+		T z2 = 0;
+		for (int i = 0; i < R * C; i++)
+			z2 += v[i] * v[i];
+		if (z2 > T(0))
+		{
+			const T n = std::sqrt(z2);
+			for (int i = 0; i < R * C; i++)
+				v[i] /= n;
+		}
+	}
+	BlockRef<T, R, C, R, 1> col(int c) { return BlockRef<T, R, C, R, 1>(this, 0, c); }
 	template <int BR, int BC>
 	BlockRef<T, R, C, BR, BC> block(int r0, int c0)
 	{
@@ -306,6 +325,7 @@ typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<float, 4, 4> Matrix4f;
+typedef Matrix<float, 3, 3> Matrix3f;
 typedef Matrix<float, 3, 1> Vector3f;
 
 // unit quaternion, as far as the path uses it (rotation matrix -> quaternion, slerp from identity, rotate a vector)
@@ -451,7 +471,11 @@ struct KdTree
 {
 	typedef boost::shared_ptr<KdTree<PointT>> Ptr;
 	typename PointCloud<PointT>::Ptr cloud;
-	void setInputCloud(const typename PointCloud<PointT>::Ptr &c) { cloud = c; }
+	void setInputCloud(const typename PointCloud<PointT>::Ptr &c)
+	{
+		cloud = c;
+		index_built = false;
+	}
 	int nearestKSearch(const PointT &q, int k, std::vector<int> &idx, std::vector<float> &d2) const
 	{
 		std::vector<std::pair<float, int>> all;
@@ -469,8 +493,86 @@ struct KdTree
 		}
 		return kk;
 	}
+	// FLANN radius search (oracle/pcl_restated.h): squared distance < (float)(radius * radius), ascending, cut to max_nn if > 0
+	int radiusSearch(const PointT &q, double radius, std::vector<int> &idx, std::vector<float> &d2, unsigned max_nn = 0) const
+	{
+		if (!index_built)
+		{
+			index.build(cloud->points, (float)radius);
+			index_built = true;
+		}
+		index.search(q, radius, max_nn, idx, d2);
+		return (int)idx.size();
+	}
+	int radiusSearch(int i, double radius, std::vector<int> &idx, std::vector<float> &d2, unsigned max_nn = 0) const
+	{
+		return radiusSearch(cloud->points[i], radius, idx, d2, max_nn);
+	}
+	mutable restated::RadiusIndex<PointT> index;
+	mutable bool index_built = false;
 };
 } // namespace search
+
+// pcl::KdTreeFLANN: the same index under its other name (the searches copy the positions at setInputCloud time: later writes to the
+// cloud's normals, as get_pc_pca_feature does, are not seen — positions never change)
+template <typename PointT>
+struct KdTreeFLANN
+{
+	typedef boost::shared_ptr<KdTreeFLANN<PointT>> Ptr;
+	std::vector<PointT> pts;
+	mutable restated::RadiusIndex<PointT> index;
+	mutable bool index_built = false;
+	void setInputCloud(const typename PointCloud<PointT>::Ptr &c)
+	{
+		pts = c->points;
+		index_built = false;
+	}
+	int radiusSearch(const PointT &q, double radius, std::vector<int> &idx, std::vector<float> &d2, unsigned max_nn = 0) const
+	{
+		if (!index_built)
+		{
+			index.build(pts, (float)radius);
+			index_built = true;
+		}
+		index.search(q, radius, max_nn, idx, d2);
+		return (int)idx.size();
+	}
+	int radiusSearch(int i, double radius, std::vector<int> &idx, std::vector<float> &d2, unsigned max_nn = 0) const
+	{
+		return radiusSearch(pts[i], radius, idx, d2, max_nn);
+	}
+};
+
+// pcl::PCA (oracle/pcl_restated.h)
+template <typename PointT>
+struct PCA
+{
+	Eigen::Matrix<float, 3, 3> vectors;
+	Eigen::Matrix<float, 3, 1> values;
+	void setInputCloud(const typename PointCloud<PointT>::Ptr &c)
+	{
+		std::vector<int> all(c->points.size());
+		for (size_t i = 0; i < all.size(); i++)
+			all[i] = (int)i;
+		float eval[3], evec[3][3];
+		restated::pca(c->points, all, eval, evec);
+		for (int r = 0; r < 3; r++)
+		{
+			values(r) = eval[r];
+			for (int k = 0; k < 3; k++)
+				vectors(r, k) = evec[r][k];
+		}
+	}
+	Eigen::Matrix<float, 3, 3> &getEigenVectors() { return vectors; }
+	Eigen::Matrix<float, 3, 1> &getEigenValues() { return values; }
+};
+
+struct PointNormal
+{
+	float x = 0, y = 0, z = 0, d3 = 0;
+	float normal_x = 0, normal_y = 0, normal_z = 0, n3 = 0;
+	float curvature = 0, pad_[3] = {0, 0, 0};
+};
 
 namespace registration
 {
@@ -656,7 +758,7 @@ struct RandomSample
 } // namespace pcl
 
 // what CFilter::fast_ground_filter names besides the point cloud types: the normal cloud of its PCA branches and the PCA estimator
-// (estimate_ground_normal_method 1 / 2, never taken by the pin: method 0) — declared so that the reference's lines compile, aborting if reached
+// (estimate_ground_normal_method 1 / 2, never taken by the pin: method 0); the estimator's class shell is in ref_driver.cpp / adapter_check.cpp
 namespace pcl
 {
 struct Normal
@@ -664,13 +766,6 @@ struct Normal
 	float normal_x = 0, normal_y = 0, normal_z = 0, curvature = 0;
 };
 } // namespace pcl
-template <typename PointT>
-struct PrincipleComponentAnalysis
-{
-	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
-	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
-};
-
 // OpenMP calls made by CFilter::apply_motion_compensation
 inline void omp_set_num_threads(int) {}
 inline int omp_get_max_threads() { return 1; }
