@@ -42,7 +42,8 @@ struct Layout
 	float4 *cls_a[6];	  // pillar, pillar (promoted), beam, beam (promoted), facade, roof: compaction targets, pillar / beam become the class clouds
 	float4 *cls_sorted[4]; // class clouds in visiting order
 	float4 *down[4], *vertex;
-	float4 *kept_pos[4];
+	uint32_t *nms_list[4], *nms_cnt[4], *nms_off[4], *nms_wcur[4], *nms_pool, *nms_pool_used;
+	uint32_t nms_pool_cap;
 	uint8_t *keep[4];
 	float *keys;	// [4][n]
 	uint32_t *perm; // [4][n]
@@ -66,6 +67,7 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K)
 	A.nbr = b.take<uint32_t>((size_t)n * K);
 	A.closebits = b.take<unsigned long long>(n);
 	A.f_cnt = b.take<int32_t>(n);
+	A.cov = b.take<float>((size_t)n * 6);
 	A.f_curv = b.take<double>(n);
 	A.f_lin = b.take<double>(n);
 	A.f_pla = b.take<double>(n);
@@ -86,10 +88,16 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K)
 	{
 		L.cls_sorted[k] = b.take<float4>((size_t)n * 3);
 		L.down[k] = b.take<float4>((size_t)n * 3);
-		L.kept_pos[k] = b.take<float4>(n);
+		L.nms_list[k] = b.take<uint32_t>((size_t)n * MULLS_CL_NMS_CAP);
+		L.nms_cnt[k] = b.take<uint32_t>(n);
+		L.nms_off[k] = b.take<uint32_t>(n);
+		L.nms_wcur[k] = b.take<uint32_t>(n);
 		L.keep[k] = b.take<uint8_t>(n);
 	}
 	L.vertex = b.take<float4>((size_t)n * 3);
+	L.nms_pool_cap = (uint32_t)std::min<size_t>((size_t)n * 64u, 0x7fffffffu);
+	L.nms_pool = b.take<uint32_t>(L.nms_pool_cap);
+	L.nms_pool_used = b.take<uint32_t>(1);
 	L.keys = b.take<float>((size_t)n * 4);
 	L.perm = b.take<uint32_t>((size_t)n * 4);
 	L.counts = b.take<uint32_t>(16);
@@ -249,13 +257,8 @@ extern "C"
 		const ClArrays &A = L.A;
 		HIPCHK(ctx, hipMemcpyAsync(A.recs, src, (size_t)n * REC, hipMemcpyHostToDevice, st));
 		// features of points that are not queried (pca_down_rate > 1) are pca_feature_t's zeros
-		HIPCHK(ctx, hipMemsetAsync(A.closebits, 0, (size_t)n * 8, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_cnt, 0, (size_t)n * 4, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_curv, 0, (size_t)n * 8, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_lin, 0, (size_t)n * 8, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_pla, 0, (size_t)n * 8, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_pd, 0, (size_t)n * 16, st));
-		HIPCHK(ctx, hipMemsetAsync(A.f_nd, 0, (size_t)n * 16, st));
+		// (closebits .. f_nd are carved back to back: one fill)
+		HIPCHK(ctx, hipMemsetAsync(A.closebits, 0, (size_t)(reinterpret_cast<unsigned char *>(A.f_nd + n) - reinterpret_cast<unsigned char *>(A.closebits)), st));
 		HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
 
 		ClParams Q;
@@ -283,7 +286,7 @@ extern "C"
 		{
 			for (uint32_t round = 0;;)
 			{
-				for (int r = 0; r < 8; r++, round++)
+				for (int r = 0; r < 4; r++, round++)
 					launch_cl_promote_round(st, A, Q, round & 63u);
 				uint32_t left = 0;
 				HIPCHK(ctx, hipMemcpyAsync(&left, A.round_cnt + ((round - 1u) & 63u), 4, hipMemcpyDeviceToHost, st));
@@ -392,9 +395,32 @@ extern "C"
 					na.recs[c] = L.cls_sorted[c];
 					na.n[c] = ncls[c];
 					na.keep[c] = L.keep[c];
-					na.kept_pos[c] = L.kept_pos[c];
+					na.list[c] = L.nms_list[c];
+					na.cnt[c] = L.nms_cnt[c];
+					na.off[c] = L.nms_off[c];
+					na.wcur[c] = L.nms_wcur[c];
 				}
-				launch_cl_nms(st, na);
+				na.pool = L.nms_pool, na.pool_used = L.nms_pool_used, na.pool_cap = L.nms_pool_cap;
+				HIPCHK(ctx, hipMemsetAsync(L.nms_pool_used, 0, 4, st));
+				launch_cl_nms_lists(st, na);
+				HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
+				for (uint32_t round = 0;;)
+				{
+					for (int r = 0; r < 8; r++, round++)
+						launch_cl_nms_round(st, na, A.round_cnt + (round & 63u));
+					uint32_t left = 0;
+					HIPCHK(ctx, hipMemcpyAsync(&left, A.round_cnt + ((round - 1u) & 63u), 4, hipMemcpyDeviceToHost, st));
+					HIPCHK(ctx, hipStreamSynchronize(st));
+					if (left == 0)
+						break;
+					if ((round & 63u) == 0)
+						HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
+					if (round > (1u << 22))
+					{
+						ctx->err = "mulls_classify_nground: the suppression rounds did not settle";
+						return MULLS_E_HIP;
+					}
+				}
 				std::memset(&ca, 0, sizeof(ca));
 				for (int c = 0; c < 4; c++)
 				{

@@ -31,6 +31,7 @@ struct ClArrays
 	uint32_t *nbr;					  // [K][n] neighbour indices, nearest first
 	unsigned long long *closebits;	  // [n] bit k: neighbour k is closer than sqrt(0.64) * radius
 	int32_t *f_cnt;					  // [n] pt_num
+	float *cov;						  // [6][n] xx xy xz yy yz zz of the neighbourhood's covariance
 	double *f_curv, *f_lin, *f_pla;	  // [n] curvature, linear_2, planar_2
 	float4 *f_pd, *f_nd;			  // [n] principal / normal direction
 	uint8_t *lab, *plab, *cstate, *cand, *down; // [n] each
@@ -61,15 +62,22 @@ void launch_cl_label(hipStream_t st, const ClArrays &A, const ClParams &P);
 void launch_cl_promote_round(hipStream_t st, const ClArrays &A, const ClParams &P, uint32_t round);
 void launch_cl_encode_and_masks(hipStream_t st, const ClArrays &A, const ClParams &P);
 
+#define MULLS_CL_NMS_CAP 32u
 struct ClNmsArgs
 {
 	const float4 *recs[4]; // class clouds in visiting order
 	uint32_t n[4];		   // 0 = skip
-	uint8_t *keep[4];
-	float4 *kept_pos[4]; // scratch, n[c] entries
+	uint8_t *keep[4];	   // state while the rounds run, keep mask once they have settled
+	uint32_t *list[4];	   // [MULLS_CL_NMS_CAP][n[c]] earlier neighbours within the radius
+	uint32_t *cnt[4];	   // [n[c]] how many there are (may exceed the list)
+	uint32_t *off[4];	   // [n[c]] where a longer list starts in the pool, ~0 if it did not fit
+	uint32_t *wcur[4];	   // [n[c]] fill cursor of a pool list
+	uint32_t *pool, *pool_used; // pool of pool_cap entries shared by the four classes; *pool_used = 0 before launch_cl_nms_lists
+	uint32_t pool_cap;
 	float r2;
 };
-void launch_cl_nms(hipStream_t st, const ClNmsArgs &a);
+void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a);
+void launch_cl_nms_round(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt); // *round_cnt += points still undecided
 // keys[i] = normal[3] of record i
 void launch_cl_keys(hipStream_t st, const float4 *recs, uint32_t n, float *keys);
 // out[i] = in[perm[i]]

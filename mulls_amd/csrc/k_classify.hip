@@ -3,14 +3,15 @@
 // descriptors (encode_stable_points, :1071-1181) and non-maximum suppression (:1243-1312).  Host side: classify.cpp.
 //
 // A scan's non-ground cloud is 20-60 k points: the whole working set (48-B records, a [K][n] neighbour table, per-point features) is a few
-// tens of MB and stays in HBM / L2 between the passes; every pass is one lane per point except the suppression, which is sequential by
-// nature and runs as one 1024-lane workgroup per class cloud.
+// tens of MB and stays in HBM / L2 between the passes.  The two loops upstream that are sequential by nature (promotion, suppression) run
+// as fixed-point rounds that settle every point whose predecessors are settled.
 //   k_cl_bbox / _setup / _count / scan / _scatter   uniform search grid (cell = radius, coarsened to fit 4 M cells), points cell-sorted
-//   k_cl_pca        one lane per query point: the neighbor_k nearest within the radius as a sorted list in LDS (slot-major), then the PCA
+//   k_cl_knn        a wavefront per query point: the in-radius candidates buffered in LDS, the neighbor_k nearest by rank counting, the sums
+//   k_cl_eig        a lane per query point: eigen-decomposition, pca_feature_t
 //   k_cl_label      class decision per point, normals written as the reference writes them
 //   k_cl_promote    fixed-point rounds of the one loop upstream that reads labels it has just written (:2166-2197)
 //   k_cl_encode     key points and their neighbourhood descriptors; masks for the stable compactions (map_kernels.hip)
-//   k_cl_nms        greedy suppression in visiting order, block by block: against the kept points so far, then inside the block
+//   k_cl_nms_*      greedy suppression in visiting order as earlier-neighbour lists + fixed-point rounds
 #include <hip/hip_runtime.h>
 
 #include "classify_launch.h"
@@ -218,16 +219,71 @@ __global__ __launch_bounds__(256) void k_cl_scatter(const float4 *__restrict__ r
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// get_pc_pca_feature with the kd-tree argument (pca.hpp:292-352) + get_pca_feature (:392-437).  One lane per query point.
-__global__ __launch_bounds__(64) void k_cl_pca(ClArrays A, ClParams P)
+// get_pc_pca_feature with the kd-tree argument (pca.hpp:292-352) + get_pca_feature (:392-437), in two kernels.
+// k_cl_knn: one wavefront per query point (a scan's non-ground cloud is only 20-60 k queries: a lane per query leaves the chip to one
+// latency-bound wavefront per CU, and sub-groups of a wavefront diverge at every prune).  The 64 lanes stream the candidates of the 3 x 3
+// cell columns around the query (coalesced), append those within the radius to the query's buffer in LDS (ballot prefix), and pick the
+// neighbor_k smallest (distance, index) pairs by rank counting — every lane ranks its share of the buffer against all of it, four
+// candidates per LDS read.  A full buffer is pruned to its neighbor_k best, whose last entry becomes the admission threshold.  The sums of
+// the PCA are sequential in the neighbours' order (that order is part of the result's rounding): one lane per sum.
+// k_cl_eig: one lane per query, the 3 x 3 eigen-decomposition and what pca_feature_t derives from it.
+#define CL_CAND 256u // candidate buffer entries per query
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+namespace
 {
-	extern __shared__ unsigned char cl_lds[];
-	float *ld = reinterpret_cast<float *>(cl_lds);			// [K][64] squared distances, ascending
-	uint32_t *li = reinterpret_cast<uint32_t *>(ld + P.K * 64u); // [K][64] indices
-	const uint32_t t = threadIdx.x, q = blockIdx.x * 64u + t;
-	const uint64_t i64 = (uint64_t)q * (uint64_t)P.down_rate;
+struct KnnLds
+{
+	float4 cand_d[CL_CAND / 4u]; // squared distances
+	uint4 cand_i[CL_CAND / 4u];	 // indices
+	float sel_d[MULLS_CL_MAX_K];
+	uint32_t sel_i[MULLS_CL_MAX_K];
+	float sel_x[MULLS_CL_MAX_K], sel_y[MULLS_CL_MAX_K], sel_z[MULLS_CL_MAX_K];
+};
+// the K smallest (distance, index) of the c buffered candidates, ascending, into sel_*; returns min(c, K)
+__device__ __forceinline__ uint32_t knn_select(KnnLds &L, uint32_t lane, uint32_t c, uint32_t K)
+{
+	float *cd = reinterpret_cast<float *>(L.cand_d);
+	uint32_t *ci = reinterpret_cast<uint32_t *>(L.cand_i);
+	const uint32_t c4 = (c + 3u) & ~3u;
+	if (lane < c4 - c) // pad to a multiple of four with entries that rank behind everything
+	{
+		cd[c + lane] = __builtin_inff();
+		ci[c + lane] = 0xffffffffu;
+	}
+	WSYNC();
+	for (uint32_t j = lane; j < c; j += 64u)
+	{
+		const float dj = cd[j];
+		const uint32_t ij = ci[j];
+		uint32_t rank = 0;
+		for (uint32_t u = 0; u < c4 / 4u; u++)
+		{
+			const float4 d4 = L.cand_d[u];
+			const uint4 i4 = L.cand_i[u];
+			rank += (d4.x < dj || (d4.x == dj && i4.x < ij)) ? 1u : 0u;
+			rank += (d4.y < dj || (d4.y == dj && i4.y < ij)) ? 1u : 0u;
+			rank += (d4.z < dj || (d4.z == dj && i4.z < ij)) ? 1u : 0u;
+			rank += (d4.w < dj || (d4.w == dj && i4.w < ij)) ? 1u : 0u;
+		}
+		if (rank < K)
+		{
+			L.sel_d[rank] = dj;
+			L.sel_i[rank] = ij;
+		}
+	}
+	WSYNC();
+	return c < K ? c : K;
+}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_cl_knn(ClArrays A, ClParams P)
+{
+	__shared__ KnnLds Lw[4];
+	const uint32_t t = threadIdx.x, w = t >> 6, lane = t & 63u;
+	KnnLds &L = Lw[w];
+	const uint64_t i64 = ((uint64_t)blockIdx.x * 4u + w) * (uint64_t)P.down_rate;
 	if (i64 >= P.n)
-		return;
+		return; // the whole wavefront leaves
 	const uint32_t i = (uint32_t)i64, n = P.n, K = P.K;
 	const float4 q0 = A.recs[(size_t)i * 3];
 	const float qx = q0.x, qy = q0.y, qz = q0.z;
@@ -245,75 +301,123 @@ __global__ __launch_bounds__(64) void k_cl_pca(ClArrays A, ClParams P)
 	const int x0 = cell_axis((double)qx - reach, (double)g->lo[0], cell, g->dim[0]), x1 = cell_axis((double)qx + reach, (double)g->lo[0], cell, g->dim[0]);
 	const int y0 = cell_axis((double)qy - reach, (double)g->lo[1], cell, d1), y1 = cell_axis((double)qy + reach, (double)g->lo[1], cell, d1);
 	const int z0 = cell_axis((double)qz - reach, (double)g->lo[2], cell, d2n), z1 = cell_axis((double)qz + reach, (double)g->lo[2], cell, d2n);
-	uint32_t m = 0;
-	float worst_d = r2; // while the list is not full a candidate enters below the squared radius; afterwards below its last entry
-	uint32_t worst_i = 0;
+	float *cd = reinterpret_cast<float *>(L.cand_d);
+	uint32_t *ci = reinterpret_cast<uint32_t *>(L.cand_i);
+	uint32_t c = 0;		  // buffered candidates (wave-uniform)
+	bool pruned = false; // after a prune a candidate has to beat the kept list's last entry
+	float thr_d = r2;
+	uint32_t thr_i = 0;
 	for (int cx = x0; cx <= x1; cx++)
 		for (int cy = y0; cy <= y1; cy++)
 		{
 			const uint32_t row = ((uint32_t)cx * d1 + (uint32_t)cy) * d2n;
 			const uint32_t s0 = A.cell_start[row + (uint32_t)z0], s1 = A.cell_start[row + (uint32_t)z1 + 1u]; // the z cells of one column are contiguous
-			for (uint32_t s = s0; s < s1; s++)
+			for (uint32_t base = s0; base < s1; base += 64u)
 			{
-				const float4 c = A.sorted[s];
-				const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-				const float d = dx * dx + dy * dy + dz * dz;
-				const uint32_t ci = __float_as_uint(c.w);
-				if (m < K ? !(d < r2) : !(d < worst_d || (d == worst_d && ci < worst_i)))
-					continue;
-				uint32_t pos = m < K ? m : K - 1u;
-				while (pos > 0)
+				const uint32_t s = base + lane;
+				bool accept = false;
+				float d = 0.f;
+				uint32_t idx = 0;
+				if (s < s1)
 				{
-					const float pd = ld[(pos - 1u) * 64u + t];
-					const uint32_t pi = li[(pos - 1u) * 64u + t];
-					if (!(pd > d || (pd == d && pi > ci)))
-						break;
-					ld[pos * 64u + t] = pd;
-					li[pos * 64u + t] = pi;
-					pos--;
+					const float4 cpt = A.sorted[s];
+					const float dx = qx - cpt.x, dy = qy - cpt.y, dz = qz - cpt.z;
+					d = dx * dx + dy * dy + dz * dz;
+					idx = __float_as_uint(cpt.w);
+					accept = pruned ? (d < thr_d || (d == thr_d && idx < thr_i)) : (d < r2);
 				}
-				ld[pos * 64u + t] = d;
-				li[pos * 64u + t] = ci;
-				if (m < K)
-					m++;
-				if (m == K)
+				const unsigned long long bal = __ballot(accept);
+				const uint32_t add = (uint32_t)__popcll(bal);
+				if (c + add > CL_CAND) // make room first: the buffer's neighbor_k best stay
 				{
-					worst_d = ld[(K - 1u) * 64u + t];
-					worst_i = li[(K - 1u) * 64u + t];
+					const uint32_t m = knn_select(L, lane, c, K);
+					if (lane < m)
+					{
+						cd[lane] = L.sel_d[lane];
+						ci[lane] = L.sel_i[lane];
+					}
+					c = m;
+					if (m == K)
+					{
+						pruned = true;
+						thr_d = L.sel_d[K - 1u];
+						thr_i = L.sel_i[K - 1u];
+					}
+					WSYNC();
+					// the pending candidates face the new threshold as well (admitting them anyway would still be correct: the selection decides)
 				}
+				if (accept)
+				{
+					const uint32_t pos = c + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+					cd[pos] = d;
+					ci[pos] = idx;
+				}
+				c += add;
 			}
 		}
+	const uint32_t m = knn_select(L, lane, c, K);
 	// features[i].pt_num, neighbor_indices, close_to_query_point (squared_distances[j] < 0.64 * radius * radius, in double)
 	const double close_thr = 0.64 * (double)P.radius * (double)P.radius;
-	unsigned long long bits = 0;
-	for (uint32_t k = 0; k < m; k++)
+	bool close = false;
+	if (lane < m)
 	{
-		A.nbr[(size_t)k * n + i] = li[k * 64u + t];
-		if ((double)ld[k * 64u + t] < close_thr)
-			bits |= 1ull << k;
+		const uint32_t j = L.sel_i[lane];
+		A.nbr[(size_t)lane * n + i] = j;
+		close = (double)L.sel_d[lane] < close_thr;
+		const float4 r0 = A.recs[(size_t)j * 3];
+		L.sel_x[lane] = r0.x, L.sel_y[lane] = r0.y, L.sel_z[lane] = r0.z;
 	}
-	A.closebits[i] = bits;
-	A.f_cnt[i] = (int32_t)m;
-	double curvature = 0, linear_2 = 0, planar_2 = 0;
-	float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
+	const unsigned long long bits = __ballot(close);
+	WSYNC();
+	float out = 0.f; // lanes 0..5: xx xy xz yy yz zz of the scaled covariance
 	if (m > 3u)
 	{
-		float mx = 0, my = 0, mz = 0;
-		for (uint32_t k = 0; k < m; k++)
+		// lane 0 / 1 / 2: the centroid's x / y / z; lanes 0..5: one covariance sum each — every sum sequential in the neighbours' order
+		float mean = 0;
+		if (lane < 3u)
 		{
-			const float4 r0 = A.recs[(size_t)li[k * 64u + t] * 3];
-			mx += r0.x, my += r0.y, mz += r0.z;
+			const float *v = lane == 0 ? L.sel_x : (lane == 1 ? L.sel_y : L.sel_z);
+			for (uint32_t k = 0; k < m; k++)
+				mean += v[k];
+			mean /= (float)m;
 		}
-		mx /= (float)m, my /= (float)m, mz /= (float)m;
-		float s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
-		for (uint32_t k = 0; k < m; k++)
+		const float mx = __shfl(mean, 0), my = __shfl(mean, 1), mz = __shfl(mean, 2);
+		if (lane < 6u)
 		{
-			const float4 r0 = A.recs[(size_t)li[k * 64u + t] * 3];
-			const float dx = r0.x - mx, dy = r0.y - my, dz = r0.z - mz;
-			s0 += dx * dx, s1 += dx * dy, s2 += dx * dz, s3 += dy * dy, s4 += dy * dz, s5 += dz * dz;
+			const float *va = lane < 3u ? L.sel_x : (lane < 5u ? L.sel_y : L.sel_z);
+			const float *vb = (lane == 0) ? L.sel_x : ((lane == 1 || lane == 3) ? L.sel_y : L.sel_z);
+			const float ma = lane < 3u ? mx : (lane < 5u ? my : mz);
+			const float mb = (lane == 0) ? mx : ((lane == 1 || lane == 3) ? my : mz);
+			float sum = 0;
+			for (uint32_t k = 0; k < m; k++)
+				sum += (va[k] - ma) * (vb[k] - mb);
+			const float alpha = 1.f / ((float)m - 1.f);
+			out = alpha * sum;
 		}
-		const float alpha = 1.f / ((float)m - 1.f);
-		const mulls_pca::Eig E = mulls_pca::eigen3(alpha * s0, alpha * s1, alpha * s2, alpha * s3, alpha * s4, alpha * s5);
+	}
+	if (lane < 6u)
+		A.cov[(size_t)lane * n + i] = out;
+	if (lane == 0)
+	{
+		A.closebits[i] = bits;
+		A.f_cnt[i] = (int32_t)m;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_cl_eig(ClArrays A, ClParams P)
+{
+	const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+	const uint64_t i64 = (uint64_t)q * (uint64_t)P.down_rate;
+	if (i64 >= P.n)
+		return;
+	const uint32_t i = (uint32_t)i64, n = P.n;
+	const int m = A.f_cnt[i];
+	double curvature = 0, linear_2 = 0, planar_2 = 0;
+	float px = 0, py = 0, pz = 0, nx = 0, ny = 0, nz = 0;
+	if (m > 3)
+	{
+		const mulls_pca::Eig E = mulls_pca::eigen3(A.cov[i], A.cov[(size_t)n + i], A.cov[(size_t)2 * n + i], A.cov[(size_t)3 * n + i], A.cov[(size_t)4 * n + i],
+												  A.cov[(size_t)5 * n + i]);
 		px = E.px, py = E.py, pz = E.pz;
 		nx = E.py * E.mz - E.pz * E.my; // col(2) = col(0).cross(col(1))
 		ny = E.pz * E.mx - E.px * E.mz;
@@ -330,7 +434,7 @@ __global__ __launch_bounds__(64) void k_cl_pca(ClArrays A, ClParams P)
 	A.f_pla[i] = planar_2;
 	A.f_pd[i] = make_float4(px, py, pz, 0.f);
 	A.f_nd[i] = make_float4(nx, ny, nz, 0.f);
-	if (m > 1u) // features[i].pt_num > min_k (= 1): assign_normal(in_cloud->points[i], features[i]) — the plane's normal and planarity
+	if (m > 1) // features[i].pt_num > min_k (= 1): assign_normal(in_cloud->points[i], features[i]) — the plane's normal and planarity
 		A.recs[(size_t)i * 3 + 1] = make_float4(nx, ny, nz, (float)planar_2);
 }
 
@@ -394,37 +498,44 @@ __global__ __launch_bounds__(256) void k_cl_promote(ClArrays A, ClParams P, uint
 		return;
 	const int pt_num = A.f_cnt[i];
 	const int listed = pt_num > 3 ? pt_num : 0; // neighbor_indices is only filled when the PCA ran (pca.hpp:396-397)
-	uint32_t lo = 0, hi = 0;
-	const volatile uint8_t *cstate = A.cstate;
-	for (int k = 0; k < listed; k++)
-	{
-		const uint32_t j = A.nbr[(size_t)k * P.n + i];
-		if (A.lab[j])
-			lo++, hi++;
-		else if (j < i && (A.cand[j] & 6u))
-		{
-			const uint8_t s = cstate[j];
-			if (s == 3)
-				lo++, hi++;
-			else if (s == 1)
-				hi++;
-		}
-	}
+	const uint8_t *cstate = A.cstate;
 	const double thr = (double)P.vertex_ratio_thre;
-	const bool pass = 1.0 * (double)lo / (double)pt_num > thr, may = 1.0 * (double)hi / (double)pt_num > thr;
-	if (pass)
+	for (int look = 0; look < 1; look++) // (more looks per launch only pay with cheap coherent loads: they go to memory here)
 	{
-		const float4 pd = A.f_pd[i];
-		A.recs[(size_t)i * 3 + 1] = make_float4(pd.x, pd.y, pd.z, (float)(5.0 * A.f_curv[i])); // assign_normal(.., false); normal[3] = 5.0 * curvature
-		const uint8_t c = A.cand[i];
-		A.plab[i] = (c & 2u) ? 1 : ((c & 4u) ? 2 : 0);
+		uint32_t lo = 0, hi = 0;
+		for (int k = 0; k < listed; k++)
+		{
+			const uint32_t j = A.nbr[(size_t)k * P.n + i];
+			if (A.lab[j])
+				lo++, hi++;
+			else if (j < i && (A.cand[j] & 6u))
+			{
+				const uint8_t s = cstate[j];
+				if (s == 3)
+					lo++, hi++;
+				else if (s == 1)
+					hi++;
+			}
+		}
+		const bool pass = 1.0 * (double)lo / (double)pt_num > thr, may = 1.0 * (double)hi / (double)pt_num > thr;
+		if (pass)
+		{
+			const float4 pd = A.f_pd[i];
+			A.recs[(size_t)i * 3 + 1] = make_float4(pd.x, pd.y, pd.z, (float)(5.0 * A.f_curv[i])); // assign_normal(.., false); normal[3] = 5.0 * curvature
+			const uint8_t c = A.cand[i];
+			A.plab[i] = (c & 2u) ? 1 : ((c & 4u) ? 2 : 0);
+			__threadfence();
+			A.cstate[i] = 3;
+			return;
+		}
+		if (!may)
+		{
+			A.cstate[i] = 2;
+			return;
+		}
 		__threadfence();
-		A.cstate[i] = 3;
 	}
-	else if (!may)
-		A.cstate[i] = 2;
-	else
-		atomicAdd(&A.round_cnt[round], 1u);
+	atomicAdd(&A.round_cnt[round], 1u);
 }
 
 // encode_stable_points (:1071-1181) into vtx[i] + the eleven masks of the stable compactions:
@@ -489,126 +600,172 @@ __global__ __launch_bounds__(256) void k_cl_encode(ClArrays A, ClParams P)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// non_max_suppress (:1243-1312) on a class cloud already in visiting order: a point is kept unless a kept point of higher priority lies
-// within the radius.  One workgroup per class; 1024 points at a time: first against everything kept so far, then among themselves.
-__global__ __launch_bounds__(1024) void k_cl_nms(ClNmsArgs a)
+// non_max_suppress (:1243-1312) on class clouds already in visiting order: a point is kept unless a kept point of higher priority (earlier
+// in the order) lies within the radius.  Two steps over the whole chip instead of upstream's walk:
+//   k_cl_nms_lists   every point's earlier neighbours within the radius (all pairs once, LDS-tiled; a class cloud is <= a few 10 k points)
+//   k_cl_nms_round   fixed-point rounds: an undecided point with a kept earlier neighbour is suppressed, one whose earlier neighbours are
+//                    all suppressed is kept, the others wait — the first undecided point of the order never waits, so every round decides
+// state: 0 suppressed, 1 kept, 2 undecided (so that the settled array is the compaction's keep mask)
+#define CL_NMS_CAP MULLS_CL_NMS_CAP // list slots; a point with more earlier neighbours scans its predecessors directly in every round
+__global__ __launch_bounds__(256) void k_cl_nms_lists(ClNmsArgs a)
 {
-	__shared__ float sx[1024], sy[1024], sz[1024];
-	__shared__ uint8_t st[1024];
-	__shared__ uint32_t s_nk, s_pending, wave_cnt[16];
-	const uint32_t c = blockIdx.x, n = a.n[c], t = threadIdx.x;
-	if (n == 0)
+	// one workgroup per pair of 256-point tiles (bi >= bj) of one class: lane t's point p of tile bi against the points q < p of tile bj
+	__shared__ float sx[256], sy[256], sz[256];
+	const uint32_t c = blockIdx.y, n = a.n[c], t = threadIdx.x, nb = (n + 255u) / 256u;
+	const uint32_t pair = blockIdx.x;
+	if (pair >= nb * (nb + 1u) / 2u)
 		return;
+	uint32_t bi = (uint32_t)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+	while (bi * (bi + 1u) / 2u > pair)
+		bi--;
+	while ((bi + 1u) * (bi + 2u) / 2u <= pair)
+		bi++;
+	const uint32_t bj = pair - bi * (bi + 1u) / 2u;
 	const float4 *recs = a.recs[c];
-	float4 *kept = a.kept_pos[c];
-	uint8_t *keep = a.keep[c];
-	const float r2 = a.r2;
-	if (t == 0)
-		s_nk = 0;
-	__syncthreads();
-	for (uint32_t base = 0; base < n; base += 1024u)
+	const uint32_t p = bi * 256u + t, q0 = bj * 256u;
+	if (q0 + t < n)
 	{
-		const uint32_t p = base + t;
-		const bool live = p < n;
-		float x = 0, y = 0, z = 0;
-		if (live)
-		{
-			const float4 r0 = recs[(size_t)p * 3];
-			x = r0.x, y = r0.y, z = r0.z;
-		}
-		bool sup = false;
-		const uint32_t nk = s_nk;
-		for (uint32_t kb = 0; kb < nk; kb += 1024u)
-		{
-			__syncthreads();
-			if (kb + t < nk)
-			{
-				const float4 k4 = kept[kb + t];
-				sx[t] = k4.x, sy[t] = k4.y, sz[t] = k4.z;
-			}
-			__syncthreads();
-			const uint32_t cnt = min(1024u, nk - kb);
-			if (live && !sup)
-				for (uint32_t j = 0; j < cnt; j++)
-				{
-					const float dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
-					if (dx * dx + dy * dy + dz * dz < r2)
-					{
-						sup = true;
-						break;
-					}
-				}
-		}
-		__syncthreads();
-		// among the block's own points: 0 suppressed, 1 undecided, 2 kept
-		sx[t] = x, sy[t] = y, sz[t] = z;
-		uint8_t my = (live && !sup) ? 1 : 0;
-		st[t] = my;
-		__syncthreads();
-		uint32_t resume = 0;
-		for (;;)
-		{
-			if (t == 0)
-				s_pending = 0;
-			__syncthreads();
-			if (my == 1)
-			{
-				uint32_t u = resume;
-				const volatile uint8_t *vst = st;
-				for (; u < t; u++)
-				{
-					const float dx = x - sx[u], dy = y - sy[u], dz = z - sz[u];
-					if (dx * dx + dy * dy + dz * dz < r2)
-					{
-						const uint8_t s = vst[u];
-						if (s == 2)
-						{
-							my = 0;
-							break;
-						}
-						if (s == 1)
-							break; // wait for it
-					}
-				}
-				resume = u;
-				if (my == 1 && u == t)
-					my = 2;
-				if (my == 1)
-					s_pending = 1;
-				else
-					st[t] = my;
-			}
-			__syncthreads();
-			const uint32_t pending = s_pending;
-			__syncthreads();
-			if (!pending)
-				break;
-		}
-		// the block's kept points join the list in order
-		const bool k = my == 2;
-		const unsigned long long bal = __ballot(k);
-		const uint32_t lane = t & 63u, w = t >> 6;
-		if (lane == 0)
-			wave_cnt[w] = (uint32_t)__popcll(bal);
-		__syncthreads();
-		uint32_t off = s_nk;
-		for (uint32_t ww = 0; ww < w; ww++)
-			off += wave_cnt[ww];
-		if (k)
-			kept[off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_float4(x, y, z, 0.f);
-		if (live)
-			keep[p] = k ? 1 : 0;
-		__syncthreads();
-		if (t == 0)
-		{
-			uint32_t tot = 0;
-			for (uint32_t ww = 0; ww < 16u; ww++)
-				tot += wave_cnt[ww];
-			s_nk += tot;
-		}
-		__threadfence_block();
-		__syncthreads();
+		const float4 r0 = recs[(size_t)(q0 + t) * 3];
+		sx[t] = r0.x, sy[t] = r0.y, sz[t] = r0.z;
 	}
+	__syncthreads();
+	if (p >= n)
+		return;
+	const float4 r0 = recs[(size_t)p * 3];
+	const float x = r0.x, y = r0.y, z = r0.z;
+	const uint32_t lim = bi == bj ? t : 256u; // q = q0 + j < p
+	uint32_t *lst = a.list[c];
+	for (uint32_t j = 0; j < lim; j++)
+	{
+		const float dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+		if (dx * dx + dy * dy + dz * dz < a.r2)
+		{
+			const uint32_t slot = atomicAdd(&a.cnt[c][p], 1u);
+			if (slot < CL_NMS_CAP)
+				lst[(size_t)slot * n + p] = q0 + j;
+		}
+	}
+}
+// the points whose earlier neighbours did not fit the fixed list (dozens of points within a quarter of the PCA radius) take cnt entries of a
+// shared pool and the tile pairs are walked once more for them; only a cloud that exhausts the pool (pathological: everything within the
+// radius of everything) leaves points to the direct scan of k_cl_nms_round
+__global__ __launch_bounds__(256) void k_cl_nms_reserve(ClNmsArgs a)
+{
+	const uint32_t c = blockIdx.y, n = a.n[c], p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= n)
+		return;
+	const uint32_t cnt = a.cnt[c][p];
+	uint32_t off = 0xffffffffu;
+	if (cnt > CL_NMS_CAP)
+	{
+		const uint32_t o = atomicAdd(a.pool_used, cnt);
+		if (o <= a.pool_cap && cnt <= a.pool_cap - o)
+			off = o;
+	}
+	a.off[c][p] = off;
+	a.wcur[c][p] = 0;
+}
+__global__ __launch_bounds__(256) void k_cl_nms_lists_long(ClNmsArgs a)
+{
+	__shared__ float sx[256], sy[256], sz[256];
+	const uint32_t c = blockIdx.y, n = a.n[c], t = threadIdx.x, nb = (n + 255u) / 256u;
+	const uint32_t pair = blockIdx.x;
+	if (pair >= nb * (nb + 1u) / 2u)
+		return;
+	uint32_t bi = (uint32_t)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);
+	while (bi * (bi + 1u) / 2u > pair)
+		bi--;
+	while ((bi + 1u) * (bi + 2u) / 2u <= pair)
+		bi++;
+	const uint32_t bj = pair - bi * (bi + 1u) / 2u;
+	const uint32_t p = bi * 256u + t, q0 = bj * 256u;
+	const uint32_t off = p < n ? a.off[c][p] : 0xffffffffu;
+	if (!__syncthreads_or(off != 0xffffffffu))
+		return; // nobody in this tile has a long list
+	const float4 *recs = a.recs[c];
+	if (q0 + t < n)
+	{
+		const float4 r0 = recs[(size_t)(q0 + t) * 3];
+		sx[t] = r0.x, sy[t] = r0.y, sz[t] = r0.z;
+	}
+	__syncthreads();
+	if (off == 0xffffffffu)
+		return;
+	const float4 r0 = recs[(size_t)p * 3];
+	const float x = r0.x, y = r0.y, z = r0.z;
+	const uint32_t lim = bi == bj ? t : 256u;
+	for (uint32_t j = 0; j < lim; j++)
+	{
+		const float dx = x - sx[j], dy = y - sy[j], dz = z - sz[j];
+		if (dx * dx + dy * dy + dz * dz < a.r2)
+			a.pool[off + atomicAdd(&a.wcur[c][p], 1u)] = q0 + j;
+	}
+}
+__global__ __launch_bounds__(256) void k_cl_nms_round(ClNmsArgs a, uint32_t *round_cnt)
+{
+	const uint32_t c = blockIdx.y, n = a.n[c], p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= n)
+		return;
+	uint8_t *state = a.keep[c];
+	if (state[p] != 2)
+		return;
+	const uint32_t cnt = a.cnt[c][p];
+	const uint32_t off = cnt > CL_NMS_CAP ? a.off[c][p] : 0u;
+	// one look per launch: what the other wavefronts settle meanwhile would have to be read past the L2 (one per XCD), at memory latency
+	for (int look = 0; look < 1; look++)
+	{
+		bool kept_near = false, wait = false;
+		if (cnt <= CL_NMS_CAP)
+		{
+			const uint32_t *lst = a.list[c];
+			for (uint32_t k = 0; k < cnt; k++)
+			{
+				const uint8_t s = state[lst[(size_t)k * n + p]];
+				kept_near |= s == 1;
+				wait |= s == 2;
+			}
+		}
+		else if (off != 0xffffffffu)
+		{
+			const uint32_t *lst = a.pool + off;
+			for (uint32_t k = 0; k < cnt && !kept_near; k++)
+			{
+				const uint8_t s = state[lst[k]];
+				kept_near |= s == 1;
+				wait |= s == 2;
+			}
+		}
+		else
+		{
+			const float4 *recs = a.recs[c];
+			const float4 r0 = recs[(size_t)p * 3];
+			for (uint32_t q = 0; q < p && !kept_near; q++)
+			{
+				const uint8_t s = state[q];
+				if (s == 0)
+					continue;
+				const float4 rq = recs[(size_t)q * 3];
+				const float dx = r0.x - rq.x, dy = r0.y - rq.y, dz = r0.z - rq.z;
+				if (dx * dx + dy * dy + dz * dz < a.r2)
+				{
+					kept_near |= s == 1;
+					wait |= s == 2;
+				}
+			}
+		}
+		if (kept_near)
+		{
+			state[p] = 0;
+			return;
+		}
+		if (!wait)
+		{
+			state[p] = 1;
+			return;
+		}
+		__threadfence();
+	}
+	atomicAdd(round_cnt, 1u);
 }
 
 __global__ __launch_bounds__(256) void k_cl_keys(const float4 *__restrict__ recs, uint32_t n, float *__restrict__ keys)
@@ -647,7 +804,8 @@ void launch_cl_grid(hipStream_t st, const ClArrays &A, const ClParams &P)
 void launch_cl_pca(hipStream_t st, const ClArrays &A, const ClParams &P)
 {
 	const uint32_t nq = (P.n + (uint32_t)P.down_rate - 1u) / (uint32_t)P.down_rate;
-	hipLaunchKernelGGL(k_cl_pca, dim3((nq + 63u) / 64u), dim3(64), (size_t)P.K * 64u * 8u, st, A, P);
+	hipLaunchKernelGGL(k_cl_knn, dim3((nq + 3u) / 4u), dim3(256), 0, st, A, P);
+	hipLaunchKernelGGL(k_cl_eig, dim3((nq + 255u) / 256u), dim3(256), 0, st, A, P);
 }
 void launch_cl_label(hipStream_t st, const ClArrays &A, const ClParams &P)
 {
@@ -661,7 +819,34 @@ void launch_cl_encode_and_masks(hipStream_t st, const ClArrays &A, const ClParam
 {
 	hipLaunchKernelGGL(k_cl_encode, dim3((P.n + 255u) / 256u), dim3(256), 0, st, A, P);
 }
-void launch_cl_nms(hipStream_t st, const ClNmsArgs &a) { hipLaunchKernelGGL(k_cl_nms, dim3(4), dim3(1024), 0, st, a); }
+void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a)
+{
+	uint32_t nmax = 0;
+	for (int c = 0; c < 4; c++)
+	{
+		nmax = max(nmax, a.n[c]);
+		if (a.n[c])
+		{
+			(void)hipMemsetAsync(a.cnt[c], 0, (size_t)a.n[c] * 4, st);
+			(void)hipMemsetAsync(a.keep[c], 2, a.n[c], st); // every point undecided
+		}
+	}
+	if (nmax)
+	{
+		const uint32_t nb = (nmax + 255u) / 256u;
+		hipLaunchKernelGGL(k_cl_nms_lists, dim3(nb * (nb + 1u) / 2u, 4), dim3(256), 0, st, a);
+		hipLaunchKernelGGL(k_cl_nms_reserve, dim3(nb, 4), dim3(256), 0, st, a);
+		hipLaunchKernelGGL(k_cl_nms_lists_long, dim3(nb * (nb + 1u) / 2u, 4), dim3(256), 0, st, a);
+	}
+}
+void launch_cl_nms_round(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt)
+{
+	uint32_t nmax = 0;
+	for (int c = 0; c < 4; c++)
+		nmax = max(nmax, a.n[c]);
+	if (nmax)
+		hipLaunchKernelGGL(k_cl_nms_round, dim3((nmax + 255u) / 256u, 4), dim3(256), 0, st, a, round_cnt);
+}
 void launch_cl_keys(hipStream_t st, const float4 *recs, uint32_t n, float *keys)
 {
 	if (n)
