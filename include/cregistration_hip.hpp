@@ -444,6 +444,131 @@ inline bool update_local_map(cloudblock_Ptr local_map, cloudblock_Ptr last_targe
 	return true;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Feature extraction: CFilter<PointT>::fast_ground_filter (include/common/cfilter.hpp:1658-2036) and
+// CFilter<PointT>::classify_nground_pts (:2058-2290), verbatim signatures.  The binding a maintainer adds is one early return at the top of
+// each member function:
+//     #ifdef MULLS_USE_HIP
+//         return lo::hip::fast_ground_filter<PointT>(cloud_in, cloud_ground, cloud_ground_down, cloud_unground, cloud_curb, min_grid_pt_num, ...);
+//     #endif
+// Differences: estimate_ground_normal_method must be 0 (1 / 2 / 3 throw: PCA / PCL-RANSAC normals are not built), fast_ground_filter's cloud_in
+// keeps its contents (upstream writes normals and data[3] into it; the clouds handed out carry them), the fixed-number selections are seeded with
+// `feature_rng_seed()` (upstream: pcl::RandomSample seeded with time(NULL)), and what pcl::PCA / Eigen compute inside classify_nground_pts is
+// the library's restatement.
+inline uint64_t &feature_rng_seed()
+{
+	static uint64_t seed = 0;
+	return seed;
+}
+template <typename PointT, typename CloudPtr>
+inline void take_cloud(CloudPtr &dst, const std::vector<unsigned char> &raw, uint32_t n, bool append)
+{
+	static_assert(sizeof(PointT) == MULLS_POINT_BYTES, "48-byte point records expected");
+	const size_t before = append ? dst->points.size() : 0;
+	dst->points.resize(before + n);
+	if (n)
+		std::memcpy(static_cast<void *>(&dst->points[before]), raw.data(), (size_t)n * MULLS_POINT_BYTES);
+}
+template <typename PointT>
+inline bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &cloud_in, typename pcl::PointCloud<PointT>::Ptr &cloud_ground,
+							   typename pcl::PointCloud<PointT>::Ptr &cloud_ground_down, typename pcl::PointCloud<PointT>::Ptr &cloud_unground,
+							   typename pcl::PointCloud<PointT>::Ptr &cloud_curb, int min_grid_pt_num, float grid_resolution, float max_height_difference,
+							   float neighbor_height_diff, float max_ground_height, int ground_random_down_rate, int ground_random_down_down_rate,
+							   int nonground_random_down_rate, int reliable_neighbor_grid_num_thre, int estimate_ground_normal_method,
+							   float normal_estimation_radius, int distance_weight_downsampling_method, float standard_distance,
+							   bool fixed_num_downsampling = false, int down_ground_fixed_num = 1000, bool detect_curb_or_not = false,
+							   float intensity_thre = FLT_MAX, bool apply_grid_wise_outlier_filter = false, float outlier_std_scale = 3.0)
+{
+	(void)cloud_curb, (void)normal_estimation_radius, (void)detect_curb_or_not; // curb detection is commented out upstream (:1990-2010)
+	mulls_ctx *ctx = thread_context();
+	mulls_ground_params P;
+	mulls_ground_default_params(&P);
+	P.min_grid_pt_num = min_grid_pt_num;
+	P.grid_resolution = grid_resolution;
+	P.max_height_difference = max_height_difference;
+	P.neighbor_height_diff = neighbor_height_diff;
+	P.max_ground_height = max_ground_height;
+	P.ground_random_down_rate = ground_random_down_rate;
+	P.ground_random_down_down_rate = ground_random_down_down_rate;
+	P.nonground_random_down_rate = nonground_random_down_rate;
+	P.reliable_neighbor_grid_num_thre = reliable_neighbor_grid_num_thre;
+	P.estimate_ground_normal_method = estimate_ground_normal_method;
+	P.distance_weight_downsampling_method = distance_weight_downsampling_method;
+	P.standard_distance = standard_distance;
+	P.fixed_num_downsampling = fixed_num_downsampling;
+	P.down_ground_fixed_num = down_ground_fixed_num;
+	P.intensity_thre = intensity_thre;
+	P.apply_grid_wise_outlier_filter = apply_grid_wise_outlier_filter;
+	P.outlier_std_scale = outlier_std_scale;
+	P.rng_seed = feature_rng_seed()++;
+	const mulls_cloud in = borrow(cloud_in);
+	std::vector<unsigned char> g((size_t)in.n * MULLS_POINT_BYTES), gd((size_t)in.n * MULLS_POINT_BYTES), u((size_t)in.n * MULLS_POINT_BYTES);
+	uint32_t n_out[3] = {0, 0, 0};
+	const int rc = mulls_ground_filter(ctx, in.pts, in.n, in.stride, &P, g.data(), in.n, gd.data(), in.n, u.data(), in.n, n_out);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_ground_filter failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	take_cloud<PointT>(cloud_ground, g, n_out[0], true); // upstream pushes back into the clouds it is given
+	take_cloud<PointT>(cloud_ground_down, gd, n_out[1], true);
+	take_cloud<PointT>(cloud_unground, u, n_out[2], true);
+	return 1;
+}
+template <typename PointT>
+inline bool classify_nground_pts(typename pcl::PointCloud<PointT>::Ptr &cloud_in, typename pcl::PointCloud<PointT>::Ptr &cloud_pillar,
+								 typename pcl::PointCloud<PointT>::Ptr &cloud_beam, typename pcl::PointCloud<PointT>::Ptr &cloud_facade,
+								 typename pcl::PointCloud<PointT>::Ptr &cloud_roof, typename pcl::PointCloud<PointT>::Ptr &cloud_pillar_down,
+								 typename pcl::PointCloud<PointT>::Ptr &cloud_beam_down, typename pcl::PointCloud<PointT>::Ptr &cloud_facade_down,
+								 typename pcl::PointCloud<PointT>::Ptr &cloud_roof_down, typename pcl::PointCloud<PointT>::Ptr &cloud_vertex,
+								 float neighbor_searching_radius, int neighbor_k, int neigh_k_min, int pca_down_rate, float edge_thre, float planar_thre,
+								 float edge_thre_down, float planar_thre_down, int extract_vertex_points_method, float curvature_thre,
+								 float vertex_curvature_non_max_radius, float linear_vertical_sin_high_thre, float linear_vertical_sin_low_thre,
+								 float planar_vertical_sin_high_thre, float planar_vertical_sin_low_thre, bool fixed_num_downsampling = false,
+								 int pillar_down_fixed_num = 200, int facade_down_fixed_num = 800, int beam_down_fixed_num = 200, int roof_down_fixed_num = 100,
+								 int unground_down_fixed_num = 20000, float beam_height_max = FLT_MAX, float roof_height_min = -FLT_MAX,
+								 float feature_pts_ratio_guess = 0.3, bool sharpen_with_nms = true, bool use_distance_adaptive_pca = false)
+{
+	mulls_ctx *ctx = thread_context();
+	mulls_classify_params P;
+	mulls_classify_default_params(&P);
+	P.neighbor_searching_radius = neighbor_searching_radius;
+	P.neighbor_k = neighbor_k;
+	P.neigh_k_min = neigh_k_min;
+	P.pca_down_rate = pca_down_rate;
+	P.edge_thre = edge_thre, P.planar_thre = planar_thre, P.edge_thre_down = edge_thre_down, P.planar_thre_down = planar_thre_down;
+	P.extract_vertex_points_method = extract_vertex_points_method;
+	P.curvature_thre = curvature_thre;
+	P.vertex_curvature_non_max_radius = vertex_curvature_non_max_radius;
+	P.linear_vertical_sin_high_thre = linear_vertical_sin_high_thre, P.linear_vertical_sin_low_thre = linear_vertical_sin_low_thre;
+	P.planar_vertical_sin_high_thre = planar_vertical_sin_high_thre, P.planar_vertical_sin_low_thre = planar_vertical_sin_low_thre;
+	P.fixed_num_downsampling = fixed_num_downsampling;
+	P.sharpen_with_nms = sharpen_with_nms;
+	P.use_distance_adaptive_pca = use_distance_adaptive_pca;
+	P.pillar_down_fixed_num = pillar_down_fixed_num, P.facade_down_fixed_num = facade_down_fixed_num, P.beam_down_fixed_num = beam_down_fixed_num;
+	P.roof_down_fixed_num = roof_down_fixed_num, P.unground_down_fixed_num = unground_down_fixed_num;
+	P.beam_height_max = beam_height_max, P.roof_height_min = roof_height_min, P.feature_pts_ratio_guess = feature_pts_ratio_guess;
+	P.rng_seed = feature_rng_seed()++;
+	const mulls_cloud in = borrow(cloud_in);
+	std::vector<unsigned char> raw[MULLS_CL_COUNT];
+	void *out[MULLS_CL_COUNT];
+	uint32_t cap[MULLS_CL_COUNT], n_out[MULLS_CL_COUNT];
+	for (int k = 0; k < MULLS_CL_COUNT; k++)
+	{
+		raw[k].resize((size_t)in.n * MULLS_POINT_BYTES);
+		out[k] = raw[k].data();
+		cap[k] = in.n;
+	}
+	std::vector<unsigned char> after((size_t)in.n * MULLS_POINT_BYTES);
+	uint32_t n_after = 0;
+	const int rc = mulls_classify_nground(ctx, in.pts, in.n, in.stride, &P, out, cap, n_out, after.data(), &n_after);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_classify_nground failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	take_cloud<PointT>(cloud_in, after, n_after, false); // upstream works on cloud_in itself: thinned first (fixed numbers), normals written into it
+	typename pcl::PointCloud<PointT>::Ptr *dst[MULLS_CL_COUNT] = {&cloud_pillar,	  &cloud_beam,		  &cloud_facade,	  &cloud_roof,	&cloud_pillar_down,
+																	  &cloud_beam_down, &cloud_facade_down, &cloud_roof_down, &cloud_vertex};
+	for (int k = 0; k < MULLS_CL_COUNT; k++)
+		take_cloud<PointT>(*dst[k], raw[k], n_out[k], true);
+	return 1;
+}
+
 } // namespace hip
 } // namespace lo
 

@@ -392,12 +392,14 @@ enum mulls_classify_cloud
 /* classify_nground_pts on the `n` non-ground points of a scan (48-byte records, `stride` bytes apart; normally mulls_ground_filter's
  * `unground`).  out[k] / cap[k] / n_out[k], k = enum mulls_classify_cloud: host buffers of 48-byte records, capacities in points, sizes; a
  * cloud larger than its capacity is truncated to it (its size is still reported); out[k] may be NULL with cap[k] = 0.
+ * cloud_in_after (NULL, or room for n records) / n_cloud_in_after (NULL or a count): cloud_in as upstream leaves it — the function writes the
+ * estimated normals into the cloud it is given, and thins it first when fixed_num_downsampling is on.  `pts` itself is not modified.
  * Neighbourhoods are exact (the neighbor_k nearest within the radius, by (distance, index)); what pcl::PCA / Eigen compute is restated (float
  * covariance in neighbour order, Jacobi in double; a direction's largest component is positive) — see DESIGN.md section 11 for what that means
  * for points within ~1e-6 of a threshold.  non_max_suppress's visiting order (and the order the class clouds are left in) is std::sort's by
  * normal[3] descending, ties included: the keys are sorted by the host's std::sort, the one order upstream's own build would produce. */
 int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_classify_params *params, void *const out[MULLS_CL_COUNT],
-						   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT]);
+						   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after);
 
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 

@@ -198,7 +198,7 @@ extern "C"
 	}
 
 	int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n_in, uint32_t stride, const mulls_classify_params *P, void *const out[MULLS_CL_COUNT],
-							   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT])
+							   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after)
 	try
 	{
 		if (!ctx || !P || !out || !cap || !n_out || (n_in && !pts) || stride < MULLS_POINT_BYTES)
@@ -227,6 +227,8 @@ extern "C"
 			in_mask.resize(n_in);
 			n = thin_mask(in_mask.data(), n_in, P->unground_down_fixed_num, P->rng_seed, 30);
 		}
+		if (n_cloud_in_after)
+			*n_cloud_in_after = n;
 		if (n == 0)
 			return MULLS_OK;
 		Bytes packed;
@@ -458,6 +460,8 @@ extern "C"
 			else
 				HIPCHK(ctx, hipMemcpyAsync(out[k], dev[k], (size_t)want * REC, hipMemcpyDeviceToHost, st));
 		}
+		if (cloud_in_after)
+			HIPCHK(ctx, hipMemcpyAsync(cloud_in_after, A.recs, (size_t)n * REC, hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		if (P->fixed_num_downsampling) // :2247-2257
 		{

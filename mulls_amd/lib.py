@@ -74,7 +74,7 @@ def load():
     lib.mulls_classify_default_params.argtypes = [C.POINTER(abi.ClassifyParams)]
     lib.mulls_classify_default_params.restype = None
     lib.mulls_classify_nground.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ClassifyParams), C.POINTER(vp), C.POINTER(C.c_uint32),
-                                           C.POINTER(C.c_uint32)]
+                                           C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -223,17 +223,21 @@ class Context:
         return [raw[k][: nout[k] * abi.POINT_BYTES].reshape(nout[k], abi.POINT_BYTES).copy() for k in range(3)]
 
     # --- feature extraction, second stage -----------------------------------------------------------------------------------
-    def classify_nground(self, pts, params):
-        """CFilter::classify_nground_pts on the device.  Returns the nine clouds of enum mulls_classify_cloud as (n, 48) uint8 record arrays."""
+    def classify_nground(self, pts, params, with_cloud_in=False):
+        """CFilter::classify_nground_pts on the device.  Returns the nine clouds of enum mulls_classify_cloud as (n, 48) uint8 record arrays
+        (and, with_cloud_in, the input cloud as the function leaves it)."""
         raw_in = abi.records(pts)
         n = len(raw_in)
         outs = [np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8) for _ in range(abi.CL_COUNT)]
         out_p = (C.c_void_p * abi.CL_COUNT)(*[o.ctypes.data for o in outs])
         cap = (C.c_uint32 * abi.CL_COUNT)(*([n] * abi.CL_COUNT))
         nout = (C.c_uint32 * abi.CL_COUNT)()
-        self._check(self.lib.mulls_classify_nground(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), out_p, cap, nout),
-                    "mulls_classify_nground")
-        return [outs[k][: nout[k]].copy() for k in range(abi.CL_COUNT)]
+        after = np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8)
+        n_after = C.c_uint32(0)
+        self._check(self.lib.mulls_classify_nground(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), out_p, cap, nout,
+                                                    after.ctypes.data_as(C.c_void_p) if with_cloud_in else None, C.byref(n_after)), "mulls_classify_nground")
+        res = [outs[k][: nout[k]].copy() for k in range(abi.CL_COUNT)]
+        return (res, after[: n_after.value].copy()) if with_cloud_in else res
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

@@ -48,6 +48,8 @@ template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
+	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell): not extracted, never reached (method 0)
+	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
 #include "cfilter_body.inc"
 };
 template <typename PointT>
@@ -121,6 +123,49 @@ int main(int argc, char **argv)
 	Eigen::Matrix4d initial_guess_tran;
 	std::memcpy(initial_guess_tran.data(), guess_raw, sizeof(guess_raw));
 
+	if (std::string(argv[2]) == "features")
+	{
+		// extract_semantic_pts' two stages on a raw scan (handed over in block1's ground slot): the reference's CFilter members vs the
+		// bridge functions of the same names, same arguments (run_mulls_reg.sh's flags, ground normal method 0)
+		pcTPtr scan = con_ref.block1->pc_ground;
+		for (int w = 0; w < 2; w++)
+		{
+			pcTPtr in(new pcT());
+			*in = *scan;
+			pcTPtr g(new pcT()), gd(new pcT()), u(new pcT()), curb(new pcT()), o[9];
+			for (int k = 0; k < 9; k++)
+				o[k].reset(new pcT());
+			if (w == 0)
+			{
+				lo::CFilter<Point_T> cf;
+				cf.fast_ground_filter(in, g, gd, u, curb, 8, 2.0f, 0.25f, 1.2f, 2.0f, 10, 2, 3, 0, 0, 2.0f, 0, 15.0f, false, 500, false, FLT_MAX, false);
+				cf.classify_nground_pts(u, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], 1.0f, 50, 8, 1, 0.65f, 0.65f, 0.75f, 0.75f, 2, 0.10f, 1.5f, 0.94f,
+										0.17f, 0.98f, 0.34f, false, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 0.3f, true, false);
+			}
+			else
+			{
+				lo::hip::fast_ground_filter<Point_T>(in, g, gd, u, curb, 8, 2.0f, 0.25f, 1.2f, 2.0f, 10, 2, 3, 0, 0, 2.0f, 0, 15.0f, false, 500, false, FLT_MAX, false);
+				lo::hip::classify_nground_pts<Point_T>(u, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], 1.0f, 50, 8, 1, 0.65f, 0.65f, 0.75f, 0.75f, 2, 0.10f,
+													   1.5f, 0.94f, 0.17f, 0.98f, 0.34f, false, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 0.3f, true, false);
+			}
+			pcTPtr all[12] = {g, gd, u, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8]};
+			printf("{\"who\": \"%s\", \"sizes\": [", w == 0 ? "reference" : "hip");
+			for (int k = 0; k < 12; k++)
+				printf("%s%zu", k ? ", " : "", all[k]->points.size());
+			printf("], \"sums\": [");
+			for (int k = 0; k < 12; k++)
+			{
+				// the classes' 40 meaningful bytes per record (the bridge copies whole records, the reference's push_back too: all 48 compare)
+				unsigned long long h = 1469598103934665603ull;
+				const unsigned char *b = reinterpret_cast<const unsigned char *>(all[k]->points.data());
+				for (size_t i = 0; i < all[k]->points.size() * sizeof(Point_T); i++)
+					h = (h ^ b[i]) * 1099511628211ull;
+				printf("%s\"%016llx\"", k ? ", " : "", h);
+			}
+			printf("]}\n");
+		}
+		return 0;
+	}
 	if (std::string(argv[2]) == "map")
 	{
 		// scan-to-map step of test/mulls_slam.cpp: mm_lls_icp against the local map (block1), then update_local_map with the

@@ -140,9 +140,10 @@ def test_degenerate_inputs():
 def test_device_equals_oracle(ctx_auto):
     n = 0
     for name, ung, P in cases():
-        a, _ = pyoracle.classify_nground(ung, P)
-        b = ctx_auto.classify_nground(ung, P)
+        a, a_in = pyoracle.classify_nground(ung, P)
+        b, b_in = ctx_auto.classify_nground(ung, P, with_cloud_in=True)
         same_outputs(a, b, name)
+        assert np.array_equal(a_in, b_in), name  # cloud_in as the function leaves it
         assert sum(len(x) for x in a) > 0
         n += 1
     assert n >= 6
@@ -155,9 +156,10 @@ def test_device_fixed_number_downsampling(ctx_auto):
     for seed in (11, 12):
         P = abi.classify_params(fixed_num_downsampling=1, unground_down_fixed_num=15000, pillar_down_fixed_num=60, facade_down_fixed_num=400,
                                 beam_down_fixed_num=100, roof_down_fixed_num=5, rng_seed=seed)
-        a, _ = pyoracle.classify_nground(ung, P)
-        b = ctx_auto.classify_nground(ung, P)
+        a, a_in = pyoracle.classify_nground(ung, P)
+        b, b_in = ctx_auto.classify_nground(ung, P, with_cloud_in=True)
         same_outputs(a, b, "fixed-number, seed %d" % seed)
+        assert len(a_in) == 15000 and np.array_equal(a_in, b_in)
         assert len(a[abi.CL_FACADE_DOWN]) == 400
 
 

@@ -83,3 +83,20 @@ def test_adapter_local_map_matches_reference_map_manager(pairs_small):
         for key in ("n", "frame_n", "hash", "frame_hash", "feature_point_num", "local_bound", "bound"):
             assert ref[key] == hip[key], key
         assert sum(ref["frame_n"]) < sum(len(pair.src[c]) for c in range(5))  # the removal filtered something
+
+
+def test_adapter_feature_extraction_matches_reference_members():
+    """lo::hip::fast_ground_filter / classify_nground_pts vs the reference's CFilter members on one raw scan: every output cloud the same bytes."""
+    from test_ground_filter import raw_scan
+
+    scan = raw_scan(14, n_beams=48, n_az=1400)
+    empty = np.zeros(0, abi.POINT_DTYPE)
+    pair = abi.PairData([scan] + [empty] * 5, [empty] * 6)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "scan.bin")
+        dump(pair, path)
+        out = subprocess.check_output([BIN, path, "features"], timeout=300).decode().strip().split("\n")
+    ref, hip = json.loads(out[0]), json.loads(out[1])
+    assert ref["who"] == "reference" and hip["who"] == "hip"
+    assert ref["sizes"] == hip["sizes"] and ref["sums"] == hip["sums"]
+    assert ref["sizes"][0] > 1000 and ref["sizes"][5] > 1000 and sum(ref["sizes"][7:11]) > 100
