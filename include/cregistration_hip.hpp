@@ -175,6 +175,12 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 		if (it != mm.end())
 		{
 			mirror = &it->second; // block1 is a device-resident local map: its clouds are already in HBM
+			// keep_less_source_points thins the target's ground / facade clouds before their kd-trees are built (cregistration.hpp:1190-1193,
+			// time-seeded): the trees the next update_local_map's dynamic removal searches would hold that random subset, which the mirror's
+			// tree state (crop box only) cannot describe — refused rather than silently searching a different point set
+			if (keep_less_source_points)
+				throw std::runtime_error("lo::hip::mm_lls_icp: keep_less_source_points with a device-resident block1 (local map mirror) is not supported; "
+										 "call lo::hip::invalidate_map_mirror(block1) first or pass keep_less_source_points = false");
 			for (int c = 0; c < 6; c++)
 				if (mulls_map_cloud(ctx, mirror->map, c, &pair.tgt[c]) != MULLS_OK)
 					throw std::runtime_error(std::string("mulls_map_cloud: ") + mulls_last_error(ctx));
