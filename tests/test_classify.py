@@ -120,6 +120,43 @@ def test_oracle_properties():
     assert checked > 300
 
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_case():
+    sys_path_golden = os.path.join(GOLD, "make_classify_golden.py")
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_classify_golden", sys_path_golden)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    scan = np.load(os.path.join(GOLD, "ground_filter_demo.npz"))["scan"].view(abi.POINT_DTYPE).reshape(-1)
+    return mod, scan, np.load(os.path.join(GOLD, "classify_demo.npz"))
+
+
+def check_golden(mod, z, ung, out, after):
+    assert len(ung) == int(z["unground_size"]) and mod.checksum(ung) == int(z["unground_checksum"])
+    assert [len(x) for x in out] + [len(after)] == list(z["sizes"])
+    assert [mod.checksum(x) for x in out] + [mod.checksum(after)] == list(z["checksums"])
+
+
+def test_golden_fixture():
+    """The committed fixture (a quarter of the reference's demo scan; written where the reference's lines could be run beside the oracle)."""
+    mod, scan, z = golden_case()
+    ung = pyoracle.ground_filter(scan, mod.GROUND)[2]
+    out, after = pyoracle.classify_nground(ung, mod.CLASSIFY)
+    check_golden(mod, z, ung, out, after)
+    assert sum(int(v) for v in z["sizes"][:4]) > 2000
+
+
+@pytest.mark.gpu
+def test_device_on_the_golden_scan(ctx_auto):
+    mod, scan, z = golden_case()
+    ung = ctx_auto.ground_filter(scan, mod.GROUND)[2]
+    out, after = ctx_auto.classify_nground(ung, mod.CLASSIFY, with_cloud_in=True)
+    check_golden(mod, z, ung, out, after)
+
+
 def test_degenerate_inputs():
     P = abi.classify_params()
     for pts in (np.zeros(0, abi.POINT_DTYPE), abi.make_points(np.zeros((1, 3)), None, [1.0], [0.0]),
@@ -220,3 +257,35 @@ def test_scan_to_registration_end_to_end(ctx_auto):
     dt, dr = _s.pose_error(rg.T_matrix(), ro.T_matrix())
     assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)
     assert rg.code == 1
+
+
+@pytest.mark.gpu
+def test_mulls_reg_tool_on_pcd_files(tmp_path):
+    """Config #1's command line (script/run_mulls_reg.sh -> test/mulls_reg.cpp) through tools/mulls_reg.py: two PCD files in, the transform
+    and the registered source cloud out."""
+    import importlib.util
+
+    from mulls_amd import synth
+
+    spec = importlib.util.spec_from_file_location("mulls_reg_tool", os.path.join(os.path.dirname(GOLD), "..", "tools", "mulls_reg.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    scene = synth.Scene(31)
+    T_12 = synth.se3(0.8, -0.2, 0.0, 0.0, 0.0, 0.03)  # scan 2's sensor in scan 1's frame
+    paths = []
+    for k, pose in enumerate((synth.se3(0, 0, scene.sensor_height), synth.se3(0, 0, scene.sensor_height) @ T_12)):
+        s = synth.raycast(scene, pose, 64, 1500, seed=31 + k)
+        path = str(tmp_path / ("scan%d.pcd" % k))
+        lib.write_pcd(path, abi.make_points(s["xyz"], np.zeros_like(s["xyz"]), s["intensity"], s["t"]))
+        paths.append(path)
+    out = str(tmp_path / "registered.pcd")
+    res, source = tool.main(["--point_cloud_1_path", paths[0], "--point_cloud_2_path", paths[1], "--output_point_cloud_path", out, "--is_global_reg=false",
+                             "--pca_neighbor_count=50", "--gf_in_grid_h_thre=0.25", "--gf_neigh_grid_h_thre=1.2", "--linearity_thre=0.65",
+                             "--planarity_thre=0.65", "--corr_dis_thre=3.0", "--reg_max_iter_num=10", "--colorlogtostderr=true"])
+    assert res.code == 1
+    T = res.T_matrix()  # source -> target
+    want = T_12 if source == 2 else np.linalg.inv(T_12)
+    dt, dr = synth.pose_error(T, want)
+    assert dt < 0.05 and dr < 3e-3, (dt, dr)
+    moved = lib.read_pcd(out)
+    assert len(moved) == len(lib.read_pcd(paths[source - 1]))
