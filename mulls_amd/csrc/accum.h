@@ -337,10 +337,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 } // namespace
 
 // Terms T0 .. T0 + NT - 1 of one slot (lane) into the LDS term buffer R (NT x 1024 values of TS): zeros unless `valid`.
-template <typename TS, int T0, int NT, int MODE = 0>
+// LANES: the slots the trip can have (1024; k_accum's workgroups for short trips use 512 / 256 — the slots beyond are +0.0 in the sum anyway)
+template <typename TS, int T0, int NT, int MODE = 0, int LANES = MULLS_ACC_LANES>
 __device__ __forceinline__ void slot_terms(const AccumCtx &A, const double *x, bool valid, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS *R)
 {
-	static_assert(sizeof(TS) * NT * MULLS_ACC_LANES <= MULLS_RED_BYTES, "the term buffer holds NT terms of 1024 slots");
+	static_assert(sizeof(TS) * NT * LANES <= MULLS_RED_BYTES, "the term buffer holds NT terms of LANES slots");
 	TS t[NT];
 #pragma unroll
 	for (int k = 0; k < NT; k++)
@@ -349,24 +350,25 @@ __device__ __forceinline__ void slot_terms(const AccumCtx &A, const double *x, b
 		point_terms<TS, T0, NT, MODE>(A, x, P, Q, N, wi, wdg, t);
 #pragma unroll
 	for (int k = 0; k < NT; k++)
-		R[k * MULLS_ACC_LANES + threadIdx.x] = t[k];
+		R[k * LANES + threadIdx.x] = t[k];
 }
 // ... and their sums over the 1024 slots -> part[T0 ..] (LDS).  The caller puts a barrier between slot_terms and reduce_terms,
 // and another one before the buffer is written again.
-template <typename TS, int T0, int NT, int MODE = 0>
+template <typename TS, int T0, int NT, int MODE = 0, int LANES = MULLS_ACC_LANES>
 __device__ __forceinline__ void reduce_terms(const TS *R, double *part)
 {
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-	for (int k0 = 0; k0 < NT; k0 += MULLS_ACC_LANES / 64)
+	for (int k0 = 0; k0 < NT; k0 += LANES / 64)
 	{
 		const int k = k0 + wave;
 		if (k < NT)
 		{
-			const TS *r = R + k * MULLS_ACC_LANES;
+			const TS *r = R + k * LANES;
 			double sum = (double)r[lane];
 #pragma unroll
-			for (int i = 1; i < MULLS_ACC_LANES / 64; i++) // all 16 loads in flight, then the chain of adds (values beyond the cloud are +0.0)
+			for (int i = 1; i < LANES / 64; i++) // all loads in flight, then the chain of adds (values beyond the cloud are +0.0: with fewer LANES they are not
+												 // added at all — the same sum, and a -0.0 that survives only that way is added to +0.0 by k_finish)
 				sum += (double)r[lane + 64 * i];
 			sum = dpp_add_f64<0xB1>(sum);	// quad_perm [1,0,3,2]
 			sum = dpp_add_f64<0x4E>(sum);	// quad_perm [2,3,0,1]
@@ -381,7 +383,7 @@ __device__ __forceinline__ void reduce_terms(const TS *R, double *part)
 
 // The 27 sums of one trip of 1024 slots whose data the lanes hold in registers (valid, P, Q, N, wdg as slot_terms) -> part[0..26]
 // (LDS; every entry written).  R: LDS, MULLS_RED_BYTES.  Every lane calls; ends with a barrier.
-template <bool HALF = false>
+template <bool HALF = false, int LANES = MULLS_ACC_LANES>
 __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x, bool valid, const float4 P, const float4 Q, const float4 N, float &wdg, void *R,
 											   double *part)
 {
@@ -389,9 +391,9 @@ __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x
 	if (A.residual_pass)
 	{
 		__syncthreads(); // the buffer is free
-		slot_terms<double, 0, 2>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R)); // sum of w * r^2, number of observations
+		slot_terms<double, 0, 2, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R)); // sum of w * r^2, number of observations
 		__syncthreads();
-		reduce_terms<double, 0, 2>(static_cast<const double *>(R), part);
+		reduce_terms<double, 0, 2, 0, LANES>(static_cast<const double *>(R), part);
 		if (threadIdx.x >= 2 && threadIdx.x < MULLS_NTERM)
 			part[threadIdx.x] = 0.0;
 	}
@@ -403,81 +405,81 @@ __device__ __forceinline__ void trip_sum_regs(const AccumCtx &A, const double *x
 			part[threadIdx.x] = 0.0;
 		if (HALF)
 		{
-			slot_terms<double, 0, 6, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			slot_terms<double, 0, 6, 1, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 			__syncthreads();
-			reduce_terms<double, 0, 6, 1>(static_cast<const double *>(R), part);
+			reduce_terms<double, 0, 6, 1, LANES>(static_cast<const double *>(R), part);
 			__syncthreads();
-			slot_terms<double, 6, 6, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			slot_terms<double, 6, 6, 1, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 			__syncthreads();
-			reduce_terms<double, 6, 6, 1>(static_cast<const double *>(R), part);
+			reduce_terms<double, 6, 6, 1, LANES>(static_cast<const double *>(R), part);
 		}
 		else
 		{
-			slot_terms<double, 0, 12, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+			slot_terms<double, 0, 12, 1, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 			__syncthreads();
-			reduce_terms<double, 0, 12, 1>(static_cast<const double *>(R), part);
+			reduce_terms<double, 0, 12, 1, LANES>(static_cast<const double *>(R), part);
 		}
 	}
 	else if (A.metric == 1 && HALF)
 	{
 		__syncthreads();
-		slot_terms<double, 0, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 0, 7, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 0, 7>(static_cast<const double *>(R), part);
+		reduce_terms<double, 0, 7, 0, LANES>(static_cast<const double *>(R), part);
 		__syncthreads();
-		slot_terms<double, 7, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 7, 7, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 7, 7>(static_cast<const double *>(R), part);
+		reduce_terms<double, 7, 7, 0, LANES>(static_cast<const double *>(R), part);
 		__syncthreads();
-		slot_terms<double, 14, 7>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 14, 7, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 14, 7>(static_cast<const double *>(R), part);
+		reduce_terms<double, 14, 7, 0, LANES>(static_cast<const double *>(R), part);
 		__syncthreads();
-		slot_terms<double, 21, 6>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 21, 6, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 21, 6>(static_cast<const double *>(R), part);
+		reduce_terms<double, 21, 6, 0, LANES>(static_cast<const double *>(R), part);
 	}
 	else if (A.metric == 1)
 	{
 		// point-to-line: the terms are products of doubles
 		__syncthreads();
-		slot_terms<double, 0, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 0, 13, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 0, 13>(static_cast<const double *>(R), part);
+		reduce_terms<double, 0, 13, 0, LANES>(static_cast<const double *>(R), part);
 		__syncthreads();
-		slot_terms<double, 13, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 13, 13, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 13, 13>(static_cast<const double *>(R), part);
+		reduce_terms<double, 13, 13, 0, LANES>(static_cast<const double *>(R), part);
 		__syncthreads();
-		slot_terms<double, 26, 1>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
+		slot_terms<double, 26, 1, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<double *>(R));
 		__syncthreads();
-		reduce_terms<double, 26, 1>(static_cast<const double *>(R), part);
+		reduce_terms<double, 26, 1, 0, LANES>(static_cast<const double *>(R), part);
 	}
 	else if (HALF)
 	{
 		// two halves through a buffer of 14 float terms (56 KiB: two workgroups per CU, k_accum); same sums, term by term
 		__syncthreads();
-		slot_terms<float, 0, 14>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		slot_terms<float, 0, 14, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
 		__syncthreads();
-		reduce_terms<float, 0, 14>(static_cast<const float *>(R), part);
+		reduce_terms<float, 0, 14, 0, LANES>(static_cast<const float *>(R), part);
 		__syncthreads();
-		slot_terms<float, 14, 13>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		slot_terms<float, 14, 13, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
 		__syncthreads();
-		reduce_terms<float, 14, 13>(static_cast<const float *>(R), part);
+		reduce_terms<float, 14, 13, 0, LANES>(static_cast<const float *>(R), part);
 	}
 	else
 	{
 		__syncthreads();
-		slot_terms<float, 0, 27>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
+		slot_terms<float, 0, 27, 0, LANES>(A, x, valid, P, Q, N, wi, wdg, static_cast<float *>(R));
 		__syncthreads();
-		reduce_terms<float, 0, 27>(static_cast<const float *>(R), part);
+		reduce_terms<float, 0, 27, 0, LANES>(static_cast<const float *>(R), part);
 	}
 	__syncthreads();
 }
 
 // the 27 sums of one trip of a class cloud's source slots [trip0, trip0 + 1024), read from memory (all loads issued before the
 // validity test: one memory round trip) -> part[0..26]
-template <bool HALF = false>
+template <bool HALF = false, int LANES = MULLS_ACC_LANES>
 __device__ __forceinline__ void trip_sum(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t trip0, const float4 *__restrict__ spos,
 										  const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd, void *R, double *part)
 {
@@ -494,7 +496,7 @@ __device__ __forceinline__ void trip_sum(const AccumCtx &A, const double *x, con
 		w = w0 = wd[g];
 		valid = (f & (MULLS_F_ALIVE | MULLS_F_VALID)) == (MULLS_F_ALIVE | MULLS_F_VALID);
 	}
-	trip_sum_regs<HALF>(A, x, valid, P, Q, N, w, R, part);
+	trip_sum_regs<HALF, LANES>(A, x, valid, P, Q, N, w, R, part);
 	if (valid && __float_as_uint(w) != __float_as_uint(w0))
 		wd[g] = w; // pcl::Correspondence::weight
 }

@@ -45,7 +45,9 @@ struct mulls_batch
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> cjobs_dev_h; // the same entries as uploaded: inside each sub-batch's slice the most expensive class clouds come first
 	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
-	std::vector<uint32_t> ajobs_h; // jobs that start a trip of 1024 source slots: k_accum's workgroups (indices into jobs_h, ascending)
+	std::vector<uint32_t> ajobs_h; // jobs that start a trip of 1024 source slots: k_accum's workgroups (indices into jobs_h) — per sub-batch slice,
+								   // and inside a slice grouped by trip length (ajob_split)
+	uint32_t ajob_split[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [sub-batch][0..3]: the slice's trips of > 512, 257..512, <= 256 slots
 	// device-resident loop (k_icp): class-level jobs in pair order, each pair's range in them, the pairs most expensive first
 	std::vector<Job> rjobs_h;
 	std::vector<uint32_t> pair_rjob_h, order_h;
@@ -306,9 +308,30 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 					B->tjobs_h.push_back(j);
 				}
 	B->ajobs_h.clear();
-	for (uint32_t j = 0; j < (uint32_t)B->jobs_h.size(); j++)
-		if (B->jobs_h[j].start % 1024u == 0u)
-			B->ajobs_h.push_back(j);
+	{
+		const int nsub = subbatch_count(B->n);
+		for (int k = 0; k < 2; k++)
+			for (int b = 0; b < 4; b++)
+				B->ajob_split[k][b] = 0;
+		for (int k = 0; k < nsub; k++)
+		{
+			const uint32_t lo = (uint32_t)((long)B->n * k / nsub), hi = (uint32_t)((long)B->n * (k + 1) / nsub);
+			for (int bucket = 0; bucket < 3; bucket++)
+			{
+				B->ajob_split[k][bucket] = (uint32_t)B->ajobs_h.size();
+				for (uint32_t j = 0; j < (uint32_t)B->jobs_h.size(); j++)
+				{
+					const Job &jb = B->jobs_h[j];
+					if (jb.start % 1024u != 0u || jb.pair < lo || jb.pair >= hi)
+						continue;
+					const uint32_t slots = std::min(1024u, B->descs_h[jb.pair * MULLS_NC + jb.cls].src_cap - jb.start);
+					if ((slots > 512u ? 0 : (slots > 256u ? 1 : 2)) == bucket)
+						B->ajobs_h.push_back(j);
+				}
+			}
+			B->ajob_split[k][3] = (uint32_t)B->ajobs_h.size();
+		}
+	}
 	B->njobs = (uint32_t)B->jobs_h.size();
 	B->jobs_key = key;
 }
@@ -1272,7 +1295,8 @@ extern "C"
 		struct Sub
 		{
 			int lo = 0, hi = 0;
-			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0, ajob_lo = 0, ajob_n = 0;
+			uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
+			const uint32_t *ajob_split = nullptr;
 			int iter = 0;
 			bool inflight = false;
 			uint32_t nn_launches = 0; // parity of the LDS tier's queue counters
@@ -1297,8 +1321,7 @@ extern "C"
 			S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
 			S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
 			S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
-			S.ajob_lo = (uint32_t)(std::lower_bound(B->ajobs_h.begin(), B->ajobs_h.end(), S.job_lo) - B->ajobs_h.begin());
-			S.ajob_n = (uint32_t)(std::lower_bound(B->ajobs_h.begin(), B->ajobs_h.end(), S.job_lo + S.job_n) - B->ajobs_h.begin()) - S.ajob_lo;
+			S.ajob_split = B->ajob_split[k];
 			S.epoch_ctr = k == 0 ? &B->epoch : &B->epoch1;
 			S.word = B->epoch_h + 16 * k;
 			S.word_dev = B->epoch_dev + 16 * k;
@@ -1388,7 +1411,7 @@ extern "C"
 					ctx->prof.iterations++;
 			}
 			ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-			launch_accum(st, S.ajob_n, B->ajobs + S.ajob_lo, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+			launch_accum(st, B->ajobs, S.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 			launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 						  (uint32_t)S.lo);
 			ev.end();
@@ -1730,7 +1753,8 @@ extern "C"
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-			launch_accum(st, (uint32_t)B->ajobs_h.size(), B->ajobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+			for (int k = 0; k < subbatch_count(B->n); k++)
+				launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
 				return MULLS_E_HIP;
@@ -2139,7 +2163,8 @@ extern "C"
 				// clear every flag to "alive, not a correspondence", then switch the requested ones on
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd, B->descs_h[cls].tgt_off, B->tpos, B->tnrm, B->mq);
-				launch_accum(st, (uint32_t)B->ajobs_h.size(), B->ajobs, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+				for (int k = 0; k < subbatch_count(B->n); k++)
+				launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}
 			std::vector<float> wall(src->n);

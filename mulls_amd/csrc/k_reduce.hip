@@ -7,10 +7,14 @@
 // table is the one of the search (512 source slots per job); one workgroup per job that starts a trip of MULLS_ACC_LANES slots
 // (`leaders`) sums the whole trip in the library's summation order (accum.h) into that job's slot of `partial`; k_finish
 // adds the trip partials in order (run-to-run deterministic, unlike atomicAdd(double), and the same bits as k_icp).
-__global__ __launch_bounds__(MULLS_ACC_LANES, 2) void k_accum(const uint32_t *__restrict__ leaders, const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
-															const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
-															const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd,
-															double *__restrict__ partial)
+// LANES: the workgroup size and the most slots the trip can have.  A trip of 100-400 slots (the roof, beam and pillar clouds of a scan, the tail of
+// a facade cloud) in a 1024-lane workgroup occupies a 56-KiB buffer and sixteen waves for the latency of its four barriers; as a 256- or
+// 512-lane workgroup it shares the CU with seven or three others.  The sums are the same (accum.h: reduce_terms).
+template <int LANES, int MIN_WG>
+__global__ __launch_bounds__(LANES, MIN_WG) void k_accum(const uint32_t *__restrict__ leaders, const Job *__restrict__ jobs, const CloudDesc *__restrict__ descs,
+														 const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
+														 const float4 *__restrict__ mq, const uint8_t *__restrict__ flag, float *__restrict__ wd,
+														 double *__restrict__ partial)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	__shared__ double part[MULLS_NTERM_PAD];
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(MULLS_ACC_LANES, 2) void k_accum(const uint32_t *__
 	for (int c = 0; c < MULLS_NC; c++)
 		cnt[c] = (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
 	const AccumCtx A = accum_ctx(rp, job.cls, ps.iter, residual_pass, class_weight(rp, job.cls, residual_pass, cnt));
-	trip_sum<true>(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, lds_raw, part); // 56 KiB term buffer: two workgroups per CU
+	trip_sum<true, LANES>(A, ps.x, pd[job.cls], job.start, spos, mq, flag, wd, lds_raw, part); // two halves of 14 terms: 56 / 28 / 14 KiB of LDS
 	if (threadIdx.x < MULLS_NTERM)
 		partial[(size_t)job_idx * MULLS_NTERM + threadIdx.x] = part[threadIdx.x];
 }
@@ -213,17 +217,25 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
 
-void launch_accum(hipStream_t st, uint32_t nleaders, const uint32_t *leaders, const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
+void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
 				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial)
 {
 	static bool attr_set = false;
 	if (!attr_set)
 	{
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
 		attr_set = true;
 	}
-	if (nleaders)
-		hipLaunchKernelGGL(k_accum, dim3(nleaders), dim3(MULLS_ACC_LANES), MULLS_RED_BYTES_HALF, st, leaders, jobs, descs, states, rp, spos, mq, flag, wd, partial);
+	// leaders[split[0] .. split[1]): trips of more than 512 slots; [split[1] .. split[2]): 257..512; [split[2] .. split[3]): up to 256
+	if (split[1] > split[0])
+		hipLaunchKernelGGL((k_accum<1024, 2>), dim3(split[1] - split[0]), dim3(1024), MULLS_RED_BYTES_HALF, st, leaders + split[0], jobs, descs, states, rp, spos, mq, flag,
+						   wd, partial);
+	if (split[2] > split[1])
+		hipLaunchKernelGGL((k_accum<512, 4>), dim3(split[2] - split[1]), dim3(512), MULLS_RED_BYTES_HALF / 2, st, leaders + split[1], jobs, descs, states, rp, spos, mq, flag,
+						   wd, partial);
+	if (split[3] > split[2])
+		hipLaunchKernelGGL((k_accum<256, 8>), dim3(split[3] - split[2]), dim3(256), MULLS_RED_BYTES_HALF / 4, st, leaders + split[2], jobs, descs, states, rp, spos, mq, flag,
+						   wd, partial);
 }
 
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
