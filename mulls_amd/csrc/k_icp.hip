@@ -341,6 +341,330 @@ __device__ __forceinline__ int fused_class(const RunParams &rp, const PairState 
 #undef FST
 }
 
+// The duplicate table of a class that fused_all hands to lds_search_class, rebuilt at Y.W from what stage 1 left in memory (its own copy
+// lies where the target cloud is about to be staged): the certified, matched points are the ones with nn_idx >= 0.  Every lane calls.
+__device__ __forceinline__ void rebuild_dup_table(uint32_t *W, const CloudDesc &d, const uint8_t *flag, const int32_t *__restrict__ nn_idx)
+{
+	for (uint32_t t = threadIdx.x; t < d.tgt_n; t += MULLS_ICP_BLOCK)
+		W[t] = 0xffffffffu;
+	__syncthreads();
+	for (uint32_t s = threadIdx.x; s < d.src_n; s += MULLS_ICP_BLOCK)
+	{
+		const uint32_t gi = d.src_off + s;
+		if (!(flag[gi] & MULLS_F_ALIVE))
+			continue;
+		const int32_t m = nn_idx[gi];
+		if (m >= 0)
+			atomicMin(&W[m], s);
+	}
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused pass over ALL class clouds of the pair at once (stages 1-3 of fused_class, the same arithmetic point by point): the source
+// points of the participating classes are numbered through, a lane takes the points f = lane, lane + 1024, ... of that numbering, and
+// every stage runs once per iteration instead of once per class — a class cloud of a few hundred points no longer costs a full round of
+// barriers and memory latencies of its own.  Per class: its own duplicate table (all tables side by side in the LDS the staged cloud
+// would use), its own leftover count; the leftovers of all classes share one queue.  A class with more than MULLS_FA_SMALL leftovers
+// drops out after stage 1 (its nn_idx / nn_d2 in memory as cert_class leaves them): the caller rebuilds its duplicate table at Y.W and
+// runs lds_search_class.  Returns the mask of those classes.  Rows: summed afterwards from memory (class_row).
+#define MULLS_FA_TRIPS 3
+#define MULLS_FA_SMALL 256u // leftovers per class that fused_all searches itself (against the grids in global memory)
+#define MULLS_FA_QCAP (MULLS_NC * MULLS_FA_SMALL)
+struct FaClass
+{
+	ClassCtx C;
+	uint32_t base, src_n, src_off, tgt_n, tgt_off, w_off, cls;
+	float thr;
+	uint32_t ucount, matched, alive, valid;
+};
+__device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairState &ps, const Job *jobs, uint32_t njobs, uint32_t part_mask, CloudDesc *pd,
+											   const GridDesc *grids, float4 *uq, uint32_t *us, uint32_t *Wall, FaClass *FC, uint32_t *s_q, float4 *__restrict__ spos,
+											   float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
+											   int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner,
+											   const float4 *__restrict__ tnrm, int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos,
+											   int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+{
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
+	// uq [MULLS_FA_QCAP]: leftover queries; us: their source index | class slot << 24
+	const bool have_prev = ps.iter > 0;
+	// class table (lane 0), duplicate tables, counters
+	if (threadIdx.x == 0)
+	{
+		uint32_t base = 0, w_off = 0, k = 0;
+		for (uint32_t j = 0; j < njobs; j++)
+		{
+			const int cls = (int)jobs[j].cls;
+			if (!(part_mask >> cls & 1u))
+				continue;
+			FaClass &F = FC[k++];
+			const CloudDesc &d = pd[cls];
+			F.C = class_ctx(rp, ps, grids[cls], cls, d.alive_cur, true);
+			F.base = base, F.src_n = d.src_n, F.src_off = d.src_off, F.tgt_n = d.tgt_n, F.tgt_off = d.tgt_off, F.cls = (uint32_t)cls;
+			F.w_off = w_off;
+			F.thr = ps.thr[cls];
+			F.ucount = F.matched = F.alive = F.valid = 0u;
+			base += d.src_n;
+			if (F.C.dedup)
+				w_off += d.tgt_n;
+		}
+		s_q[0] = 0u; // queue length
+		s_q[1] = k;	 // classes
+		s_q[2] = base;
+		s_q[3] = w_off;
+	}
+	__syncthreads();
+	const uint32_t ncls = s_q[1], total = s_q[2], wtot = s_q[3];
+	for (uint32_t t = threadIdx.x; t < wtot; t += MULLS_ICP_BLOCK)
+		Wall[t] = 0xffffffffu;
+	__syncthreads();
+
+	// ---- stage 1: rigid step + certificate ---------------------------------------------------------------------------------------------
+	uint32_t F[MULLS_FA_TRIPS], K[MULLS_FA_TRIPS]; // flag byte as loaded (0: no point); class slot of the point
+	float4 Nn[MULLS_FA_TRIPS], Q1[MULLS_FA_TRIPS];
+	int32_t M[MULLS_FA_TRIPS], PM[MULLS_FA_TRIPS];
+	float D0[MULLS_FA_TRIPS];
+	uint32_t S[MULLS_FA_TRIPS];
+#pragma unroll
+	for (int k = 0; k < MULLS_FA_TRIPS; k++)
+	{
+		const uint32_t f = threadIdx.x + (uint32_t)k * MULLS_ICP_BLOCK;
+		F[k] = 0u, K[k] = 0u, M[k] = -1, PM[k] = -1, D0[k] = 0.0f, S[k] = 0u;
+		Nn[k] = Q1[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		bool matched = false;
+		uint32_t kc = 0;
+		if (f < total)
+		{
+			while (kc + 1u < ncls && f >= FC[kc + 1u].base)
+				kc++;
+			const FaClass &A = FC[kc];
+			const uint32_t s = f - A.base, gi = A.src_off + s, tgt_n = A.tgt_n;
+			K[k] = kc, S[k] = s;
+			F[k] = flag[gi];
+			if (F[k] & MULLS_F_ALIVE)
+			{
+				const float4 p = spos[gi], n = snrm[gi];
+				const int2 h = hint2[gi];
+				PM[k] = match[gi];
+				const float4 q0 = mq[2u * gi];
+				Q1[k] = mq[2u * gi + 1u];
+				const uint32_t hv = have_prev ? (uint32_t)h.x : 0xffffu;
+				const float lb = have_prev ? __int_as_float(h.y) : 0.0f;
+				const int32_t pm = have_prev ? PM[k] : -1;
+				const uint32_t hj = hv & 0xffffu;
+				float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (hj < tgt_n)
+					tj = (int32_t)hj == pm ? q0 : tpos[A.tgt_off + hj];
+				// rigid step (cregistration.hpp:1690-1695): double math, float store, in place
+				const double *T = ps.T;
+				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+				float4 out;
+				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+				Nn[k] = make_float4(onx, ony, onz, n.w);
+				spos[gi] = make_float4(out.x, out.y, out.z, p.w);
+				snrm[gi] = Nn[k];
+				const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
+				const float moved = sqrtf((mx * mx + my * my) + mz * mz);
+				const float lb_next = lb - moved * 1.00001f;
+				out.w = __builtin_inff(); // sweep radius of a search: +inf = no hint
+				bool certified = false;
+				if (hj < tgt_n)
+				{
+					const float dx = out.x - tj.x, dy = out.y - tj.y, dz = out.z - tj.z;
+					const float d0 = (dx * dx + dy * dy) + dz * dz; // the very expression a search evaluates for this candidate
+					if (d0 >= 0.0f)
+					{
+						const float dh = sqrtf(d0);
+						certified = rp.cert != 0u && (dh * 1.00001f + moved * 1.00001f < lb * 0.99999f); // NaN anywhere fails the test
+						out.w = dh + fminf(fmaxf(rp.cert_slack_rate * moved, rp.cert_slack_min), rp.cert_slack_max);
+						if (certified)
+						{
+							matched = !((double)d0 > A.C.max_dist_sqr);
+							M[k] = matched ? (int32_t)hj : -1;
+							D0[k] = d0;
+							hint2[gi] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
+							if (matched)
+							{
+								if (A.C.dedup)
+									atomicMin(&Wall[A.w_off + hj], s);
+								else if (A.C.gate)
+									atomicMin(&winner[A.tgt_off + hj], A.C.key_hi | (unsigned long long)s);
+							}
+						}
+					}
+				}
+				if (!certified)
+				{
+					M[k] = MULLS_NEEDS_SEARCH;
+					D0[k] = out.w;
+					const uint32_t qc = atomicAdd(&FC[kc].ucount, 1u);
+					if (qc < MULLS_FA_SMALL)
+					{
+						const uint32_t q = atomicAdd(&s_q[0], 1u);
+						uq[q] = out;
+						us[q] = s | (kc << 24);
+					}
+				}
+			}
+		}
+		// matches certified here, per class (a wave's lanes belong to at most a few classes)
+		for (uint32_t c = 0; c < ncls; c++)
+		{
+			const unsigned long long b = __ballot(matched && kc == c);
+			if ((threadIdx.x & 63u) == 0u && b)
+				atomicAdd(&FC[c].matched, (uint32_t)__popcll(b));
+		}
+	}
+	__syncthreads();
+	// classes with too many leftovers drop out: their nn_idx / nn_d2 as cert_class leaves them
+	uint32_t over = 0u;
+	for (uint32_t c = 0; c < ncls; c++)
+		if (FC[c].ucount > MULLS_FA_SMALL)
+			over |= 1u << c;
+	if (over)
+	{
+#pragma unroll
+		for (int k = 0; k < MULLS_FA_TRIPS; k++)
+			if ((F[k] & MULLS_F_ALIVE) && (over >> K[k] & 1u))
+			{
+				const uint32_t gi = FC[K[k]].src_off + S[k];
+				nn_idx[gi] = M[k];
+				nn_d2[gi] = D0[k];
+			}
+	}
+	// ---- stage 2: the leftovers against the grids in global memory ----------------------------------------------------------------------
+	{
+		const uint32_t U = s_q[0];
+		const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+		for (uint32_t i = grp; i < U; i += MULLS_ICP_BLOCK / MULLS_LDS_GROUP)
+		{
+			const uint32_t kc = us[i] >> 24, s = us[i] & 0xffffffu;
+			if (over >> kc & 1u)
+				continue;
+			const FaClass &A = FC[kc];
+			const GridDesc &g = grids[A.cls];
+			const GlobGrid L = {tsorted + A.tgt_off, reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off};
+			nnkey bk;
+			float sec, Rfin;
+			uint32_t trips;
+			search_query(g, L, uq[i], A.C.r, A.C.m, sub, bk, sec, Rfin, trips);
+			if (sub == 0 && commit_search(A.C, pd[A.cls], s, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, Wall + A.w_off, winner))
+				atomicAdd(&FC[kc].matched, 1u);
+		}
+	}
+	__threadfence_block(); // the leftovers' nn_idx / nn_d2, read back below by the lanes that own the points
+	__syncthreads();
+	// ---- stage 3: duplicate rule (cregistration.hpp:1762-1789) and rejection chain (:1794-1830) ---------------------------------------
+#pragma unroll
+	for (int k = 0; k < MULLS_FA_TRIPS; k++)
+	{
+		const uint32_t kc = K[k];
+		bool alive = false, valid = false;
+		const bool mine = (F[k] & MULLS_F_ALIVE) && !(over >> kc & 1u);
+		if (mine)
+		{
+			const FaClass &A = FC[kc];
+			const uint32_t s = S[k], gi = A.src_off + s;
+			const float max_sqr = A.thr * A.thr; // CorrespondenceRejectorDistance::setMaximumDistance (float)
+			const bool any_match = A.matched > 0u, normal_check = A.cls != 5u; // vertex correspondences skip the direction check (:1292)
+			int32_t m = M[k];
+			float dist = D0[k];
+			if (m == MULLS_NEEDS_SEARCH)
+			{
+				m = nn_idx[gi];
+				dist = nn_d2[gi];
+			}
+			if (A.C.dedup && m >= 0 && Wall[A.w_off + m] != s)
+				m = -1; // first source (lowest index) matched to a target keeps it; the others become unmatched
+			bool fresh = false;
+			alive = true;
+			float4 n2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			float wdist = 0.0f;
+			if (any_match)
+			{
+				valid = m >= 0;
+				if (A.C.gate && m < 0)
+				{
+					alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+					valid = false;
+				}
+				if (valid)
+				{
+					valid = rp.rej_strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
+					if (valid)
+					{
+						wdist = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+						if (PM[k] == m)
+							n2 = Q1[k];
+						else
+						{
+							match[gi] = m;
+							n2 = tnrm[A.tgt_off + m];
+							mq[2u * gi] = tpos[A.tgt_off + m];
+							mq[2u * gi + 1u] = n2;
+						}
+						fresh = true;
+					}
+				}
+			}
+			else if (A.C.gate)
+			{
+				alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+				valid = false;
+			}
+			else
+				valid = (F[k] & MULLS_F_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
+			if (valid && normal_check)
+			{
+				if (!fresh)
+					n2 = Q1[k]; // the standing correspondence's target direction
+				const float4 n1 = Nn[k];
+				const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+				const float c = (float)fabs(dot);
+				if ((double)c < rp.cos_bearing)
+					valid = false;
+			}
+			const uint32_t nf = (alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u);
+			if (nf != F[k])
+				flag[gi] = (uint8_t)nf;
+			if (fresh)
+				wd[gi] = wdist;
+		}
+		for (uint32_t c = 0; c < ncls; c++)
+		{
+			const unsigned long long ba = __ballot(mine && alive && kc == c), bv = __ballot(mine && valid && kc == c);
+			if ((threadIdx.x & 63u) == 0u)
+			{
+				if (ba)
+					atomicAdd(&FC[c].alive, (uint32_t)__popcll(ba));
+				if (bv)
+					atomicAdd(&FC[c].valid, (uint32_t)__popcll(bv));
+			}
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < ncls && !(over >> threadIdx.x & 1u))
+	{
+		const FaClass &A = FC[threadIdx.x];
+		CloudDesc &d = pd[A.cls];
+		d.n_matched = A.matched;
+		d.alive_next = A.alive;
+		d.valid_next = A.valid;
+		d.n_search = A.ucount;
+	}
+	// class slots -> classes
+	uint32_t over_cls = 0u;
+	for (uint32_t c = 0; c < ncls; c++)
+		if (over >> c & 1u)
+			over_cls |= 1u << FC[c].cls;
+	return over_cls;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // icp_step.h's step_solve, by the 64 lanes of ONE wave (the other waves of the workgroup wait at the next barrier): the same
 // operations on the same operands in the same order as the host functions it mirrors (hostmath.h: invert6, solve_step,
@@ -575,7 +899,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 														   unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
 														   float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq,
 														   const uint32_t *__restrict__ bbox, uint32_t cap, IcpOut *__restrict__ outs, mulls_iter_trace *__restrict__ trace,
-														   uint32_t trace_cap)
+														   uint32_t trace_cap, uint32_t lds_bytes)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const LdsLayout Y = lds_layout(lds_raw, cap, rp.grid_maxcells);
@@ -592,6 +916,13 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 	__shared__ SolveWs s_ws;  // counters are read and rolled over many times per iteration (a scalar load from memory each time otherwise)
 	__shared__ int s_go;
 	__shared__ unsigned long long s_src_pts, s_tgt_pts, s_corr_pts, s_t[6], s_mark;
+	__shared__ uint32_t s_q[4], s_dup[MULLS_NC]; // s_dup: fused_all kept a duplicate table for the class
+	// fused_all's scratch, in the LDS the staged target cloud uses otherwise: leftover queue, class table, then the duplicate tables
+	float4 *fa_uq = reinterpret_cast<float4 *>(Y.P);
+	uint32_t *fa_us = reinterpret_cast<uint32_t *>(fa_uq + MULLS_FA_QCAP);
+	FaClass *s_fc = reinterpret_cast<FaClass *>(fa_us + MULLS_FA_QCAP);
+	uint32_t *Wall = reinterpret_cast<uint32_t *>(s_fc + MULLS_NC);
+	const uint32_t wall_cap = lds_bytes > (uint32_t)(reinterpret_cast<unsigned char *>(Wall) - lds_raw) ? (lds_bytes - (uint32_t)(reinterpret_cast<unsigned char *>(Wall) - lds_raw)) / 4u : 0u;
 // phase clock: lane 0 charges the time since the last mark to phase k
 #define PHASE(k)                                    \
 	do                                              \
@@ -672,12 +1003,59 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 					}
 			if (threadIdx.x < MULLS_NC * MULLS_NTERM_PAD)
 				rows[threadIdx.x / MULLS_NTERM_PAD][threadIdx.x % MULLS_NTERM_PAD] = 0.0;
-			// Class order: the classes whose weight is 1 first, then roof and ground (their weight needs the other classes' counts,
-			// cregistration.hpp:1886-1894).  `pend`: classes whose row is summed from memory after the count test (uniform).
+			// Flattened pass (fused_all) when every called class cloud fits: at most MULLS_FA_TRIPS x 1024 source points in all, the
+			// duplicate tables side by side in the LDS of the staged cloud.  Otherwise class by class as before.
+			uint32_t part = 0u, fa_src = 0u, fa_w = 0u;
+			for (uint32_t j = j0; j < j1; j++)
+			{
+				const int cls = (int)s_jobs[j - j0].cls;
+				const CloudDesc &d = pd[cls];
+				if (class_called(rp, d, cls))
+				{
+					part |= 1u << cls;
+					fa_src += d.src_n;
+					if (rp.lds_dedup != 0u && d.alive_cur >= 500u)
+						fa_w += d.tgt_n;
+				}
+			}
+			const bool flat = fuse && rp.debug_stop != 8u && i > 0 && part != 0u && fa_src <= MULLS_FA_TRIPS * MULLS_ICP_BLOCK && fa_w <= wall_cap;
 			uint32_t pend = 0u;
 			bool has_ground = false;
 			for (uint32_t j = j0; j < j1; j++)
 				has_ground |= s_jobs[j - j0].cls == 0u;
+			if (flat)
+			{
+				__syncthreads(); // the previous iteration's LDS contents have been consumed
+				const uint32_t over = fused_all(rp, ps, s_jobs, j1 - j0, part, pd, s_grid, fa_uq, fa_us, Wall, s_fc, s_q, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner,
+												tnrm, match, wd, tpos, nn_hint, mq);
+				if (threadIdx.x < s_q[1]) // (the class table lies where lds_search_class stages the target cloud)
+					s_dup[s_fc[threadIdx.x].cls] = s_fc[threadIdx.x].C.dedup ? 1u : 0u;
+				for (uint32_t j = j0; j < j1; j++)
+				{
+					const Job job = s_jobs[j - j0];
+					const int cls = (int)job.cls;
+					pend |= 1u << cls;
+					if (part >> cls & 1u)
+					{
+						if (!(over >> cls & 1u))
+							continue;
+						// too many leftovers: the class's duplicate table moves to where lds_search_class expects it, the target cloud is staged
+						__syncthreads();
+						if (s_dup[cls])
+							rebuild_dup_table(Y.W, pd[cls], flag, nn_idx);
+						lds_search_class(rp, ps, job, pd[cls], s_grid[cls], Y, lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+						continue;
+					}
+					// a class that sits this iteration out: its points still move (cert_class)
+					__syncthreads();
+					(void)cert_class<MULLS_ICP_BLOCK>(rp, ps, job, pd[cls], s_grid[cls], Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+													  nn_hint, mq);
+				}
+			}
+			else
+			{
+			// Class order: the classes whose weight is 1 first, then roof and ground (their weight needs the other classes' counts,
+			// cregistration.hpp:1886-1894).  `pend`: classes whose row is summed from memory after the count test (uniform).
 			for (int pass = 0; pass < 3; pass++)
 				for (uint32_t j = j0; j < j1; j++)
 				{
@@ -709,6 +1087,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 					}
 					pend |= 1u << cls;
 				}
+			}
 			__threadfence_block();
 			__syncthreads();
 			if (threadIdx.x == 0 && i < 24)
@@ -890,6 +1269,6 @@ int launch_icp(hipStream_t st, uint32_t npairs, uint32_t pair_base, const Job *r
 		lds = red;
 	hipLaunchKernelGGL(k_icp, dim3(npairs < n_cu ? npairs : n_cu), dim3(MULLS_ICP_BLOCK), lds, st, rjobs, pair_rjob, order, npairs, pair_base, queue, descs, setup, rp, K,
 					   spos, snrm, grids, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, bbox, cap, outs,
-					   trace, trace_cap);
+					   trace, trace_cap, (uint32_t)lds);
 	return 0;
 }
