@@ -27,7 +27,7 @@
 #include "ctx.h"
 
 // auto mode (nn_mode 0): batch sizes the device-resident loop takes (prepare_run)
-#define MULLS_RESIDENT_MIN_PAIRS 40
+#define MULLS_RESIDENT_MIN_PAIRS 4
 #define MULLS_RESIDENT_MAX_PAIRS 1024
 
 using mulls::Mat4;

@@ -383,8 +383,20 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 											   float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
 											   int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner,
 											   const float4 *__restrict__ tnrm, int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos,
-											   int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+											   int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, unsigned long long *tf)
 {
+#define FST(k)                                       \
+	do                                               \
+	{                                                \
+		if (threadIdx.x == 0)                        \
+		{                                            \
+			const unsigned long long now_ = wall_clock64(); \
+			tf[k] += now_ - tf[6];                   \
+			tf[6] = now_;                            \
+		}                                            \
+	} while (0)
+	if (threadIdx.x == 0)
+		tf[6] = wall_clock64();
 	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
 	// uq [MULLS_FA_QCAP]: leftover queries; us: their source index | class slot << 24
 	const bool have_prev = ps.iter > 0;
@@ -418,6 +430,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 	for (uint32_t t = threadIdx.x; t < wtot; t += MULLS_ICP_BLOCK)
 		Wall[t] = 0xffffffffu;
 	__syncthreads();
+	FST(0);
 
 	// ---- stage 1: rigid step + certificate ---------------------------------------------------------------------------------------------
 	uint32_t F[MULLS_FA_TRIPS], K[MULLS_FA_TRIPS]; // flag byte as loaded (0: no point); class slot of the point
@@ -440,14 +453,16 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 			const FaClass &A = FC[kc];
 			const uint32_t s = f - A.base, gi = A.src_off + s, tgt_n = A.tgt_n;
 			K[k] = kc, S[k] = s;
+			// every record of the point is requested before the flag is looked at: one memory round trip, not two
 			F[k] = flag[gi];
+			const float4 p = spos[gi], n = snrm[gi];
+			const int2 h = hint2[gi];
+			const int32_t pm0 = match[gi];
+			const float4 q0 = mq[2u * gi], q1 = mq[2u * gi + 1u];
 			if (F[k] & MULLS_F_ALIVE)
 			{
-				const float4 p = spos[gi], n = snrm[gi];
-				const int2 h = hint2[gi];
-				PM[k] = match[gi];
-				const float4 q0 = mq[2u * gi];
-				Q1[k] = mq[2u * gi + 1u];
+				PM[k] = pm0;
+				Q1[k] = q1;
 				const uint32_t hv = have_prev ? (uint32_t)h.x : 0xffffu;
 				const float lb = have_prev ? __int_as_float(h.y) : 0.0f;
 				const int32_t pm = have_prev ? PM[k] : -1;
@@ -521,6 +536,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 		}
 	}
 	__syncthreads();
+	FST(1);
 	// classes with too many leftovers drop out: their nn_idx / nn_d2 as cert_class leaves them
 	uint32_t over = 0u;
 	for (uint32_t c = 0; c < ncls; c++)
@@ -559,6 +575,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 	}
 	__threadfence_block(); // the leftovers' nn_idx / nn_d2, read back below by the lanes that own the points
 	__syncthreads();
+	FST(2);
 	// ---- stage 3: duplicate rule (cregistration.hpp:1762-1789) and rejection chain (:1794-1830) ---------------------------------------
 #pragma unroll
 	for (int k = 0; k < MULLS_FA_TRIPS; k++)
@@ -648,6 +665,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 		}
 	}
 	__syncthreads();
+	FST(3);
 	if (threadIdx.x < ncls && !(over >> threadIdx.x & 1u))
 	{
 		const FaClass &A = FC[threadIdx.x];
@@ -663,6 +681,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 		if (over >> c & 1u)
 			over_cls |= 1u << FC[c].cls;
 	return over_cls;
+#undef FST
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1027,7 +1046,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 			{
 				__syncthreads(); // the previous iteration's LDS contents have been consumed
 				const uint32_t over = fused_all(rp, ps, s_jobs, j1 - j0, part, pd, s_grid, fa_uq, fa_us, Wall, s_fc, s_q, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner,
-												tnrm, match, wd, tpos, nn_hint, mq);
+												tnrm, match, wd, tpos, nn_hint, mq, s_tf);
 				if (threadIdx.x < s_q[1]) // (the class table lies where lds_search_class stages the target cloud)
 					s_dup[s_fc[threadIdx.x].cls] = s_fc[threadIdx.x].C.dedup ? 1u : 0u;
 				for (uint32_t j = j0; j < j1; j++)
