@@ -153,7 +153,9 @@ typedef struct mulls_result
 } mulls_result;
 
 /* Per-kernel device time of the last mulls_batch_run, measured with hipEvents on the library's stream
- * when mulls_set_profiling(ctx, 1) is on (adds one event pair per launch; keep off for throughput runs). */
+ * when mulls_set_profiling(ctx, 1) is on (adds one event pair per launch group and waits on events; keep off for throughput runs).
+ * mulls_set_profiling(ctx, 2): only the correspondence search is bracketed (ms_nn, launches_nn and the counters; the other ms_* stay 0) —
+ * two events per iteration, the iteration hand-over as without profiling. */
 typedef struct mulls_profile
 {
 	double ms_setup;	  /* clone + initial guess + intersection filter kernels */

@@ -23,7 +23,7 @@ struct mulls_ctx
 								   // kernels overlap the issue-bound search of the other sub-batch
 	hipEvent_t ev_setup = nullptr; // setup done on `stream` -> stream2 may start
 	std::string err;
-	bool profiling = false;
+	int profiling = 0; // 0 off, 1 hipEvent pairs around every launch group, 2 around the correspondence search only
 	mulls_profile prof{};
 	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)

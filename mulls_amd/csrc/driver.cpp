@@ -358,8 +358,8 @@ int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipE
 		if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
 			break;
 	}
-	if (seen && !ctx->profiling)
-		return MULLS_OK;
+	if (seen && ctx->profiling != 1)
+		return MULLS_OK; // (level 2: the search's events lie before the kernel that published the epoch — complete)
 	if (seen && last)
 	{
 		// profiling: the timing event recorded behind the publishing kernel completes right after it — poll, do not sleep
@@ -844,28 +844,35 @@ struct EvTimer
 	hipStream_t stream = nullptr; // where its events are recorded (default: ctx->stream)
 	int base = 0; // first event of this timer's set in ctx->ev
 	int used = 0;
+	bool open = false;
 	double *slot[5];
 	void begin(double *acc)
 	{
-		if (!ctx->profiling)
+		open = ctx->profiling == 1 || (ctx->profiling == 2 && acc == &ctx->prof.ms_nn);
+		if (!open)
 			return;
 		slot[used / 2] = acc;
 		(void)hipEventRecord(ctx->ev[base + used], stream ? stream : ctx->stream);
 	}
 	void end()
 	{
-		if (!ctx->profiling)
+		if (!open)
 			return;
+		open = false;
 		(void)hipEventRecord(ctx->ev[base + used + 1], stream ? stream : ctx->stream);
 		used += 2;
 	}
-	hipEvent_t last() const { return (ctx->profiling && used) ? ctx->ev[base + used - 1] : nullptr; }
+	hipEvent_t last() const { return (ctx->profiling == 1 && used) ? ctx->ev[base + used - 1] : nullptr; }
 	void collect() // after the last recorded event completed
 	{
 		for (int i = 0; i < used; i += 2)
 		{
 			float ms = 0;
-			(void)hipEventElapsedTime(&ms, ctx->ev[base + i], ctx->ev[base + i + 1]);
+			if (hipEventElapsedTime(&ms, ctx->ev[base + i], ctx->ev[base + i + 1]) != hipSuccess)
+			{
+				(void)hipEventSynchronize(ctx->ev[base + i + 1]);
+				(void)hipEventElapsedTime(&ms, ctx->ev[base + i], ctx->ev[base + i + 1]);
+			}
 			*slot[i / 2] += ms;
 		}
 		used = 0;
@@ -996,7 +1003,7 @@ extern "C"
 	{
 		if (!ctx)
 			return MULLS_E_INVALID;
-		ctx->profiling = on != 0;
+		ctx->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
 		return MULLS_OK;
 	}
 	catch (...)
