@@ -132,6 +132,25 @@ def test_resident_batch_is_repeatable(ctx, pairs_small):
     b.close()
 
 
+def test_profiling_levels_do_not_change_results(ctx, pairs_small):
+    """mulls_set_profiling: 0 off, 1 events around every launch group, 2 around the correspondence search only — same results, and the
+    profile says what was bracketed."""
+    P = abi.kitti_params(dis_thre_unit=2.4)
+    b = ctx.batch([p for p, _ in pairs_small])
+    out = {}
+    for level in (0, 2, 1):
+        ctx.set_profiling(level)
+        out[level] = [(r.code, r.iters, tuple(r.T), tuple(r.info), r.sigma) for r in b.run(P)]
+        pf = ctx.profile()
+        if level:
+            assert pf.ms_nn > 0 and pf.launches_nn > 0
+        if level == 2:
+            assert pf.ms_accum == 0 and pf.ms_setup == 0
+    ctx.set_profiling(0)
+    assert out[0] == out[1] == out[2]
+    b.close()
+
+
 def test_resident_loop_equals_lock_step(ctx_auto, pairs_small):
     """The device-resident loop (one launch, 6x6 solve on the device) and the lock-step path (host-stepped launches) run the same
     arithmetic in the same order: every output bit-identical, trace included."""
