@@ -403,6 +403,42 @@ enum mulls_classify_cloud
 int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_classify_params *params, void *const out[MULLS_CL_COUNT],
 						   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after);
 
+/* ---- feature extraction, the whole chain: CFilter::extract_semantic_pts (include/common/cfilter.hpp:2294-2413) ---- */
+
+/* scanner filter (:2338-2346, :914-929) -> fast_ground_filter -> classify_nground_pts in one call: the scan goes up once, the non-ground cloud
+ * never leaves the device between the two stages.  Not part of it: voxel down-sampling (off in every shipped configuration: cloud_down_res 0),
+ * the semantic-mask filters (semantic_assisted), the adaptive parameter update. */
+typedef struct mulls_extract_params
+{
+	mulls_ground_params ground;
+	mulls_classify_params classify;
+	uint8_t apply_scanner_filter; /* extract_semantic_pts passes the same flag to fast_ground_filter as apply_grid_wise_outlier_filter: set ground.* yourself */
+	uint8_t reserved_[3];
+	float self_ring_radius; /* [1.75] */
+	float ghost_radius;		/* [20.0] */
+	float z_min;			/* -approx_scanner_height - 4.0: ghost points below it within ghost_radius go */
+	float z_min_min;		/* -approx_scanner_height + underground_thre: everything below it goes */
+} mulls_extract_params;
+
+void mulls_extract_default_params(mulls_extract_params *p);
+
+enum mulls_extract_cloud
+{
+	MULLS_EX_RAW = 0,		  /* pc_raw after the scanner filter (= pc_down: no voxel down-sampling) */
+	MULLS_EX_GROUND = 1,	  /* pc_ground */
+	MULLS_EX_GROUND_DOWN = 2, /* pc_ground_down */
+	MULLS_EX_UNGROUND = 3,	  /* pc_unground as classify_nground_pts leaves it (written only if its capacity holds the whole cloud) */
+	MULLS_EX_PILLAR = 4,	  /* ... followed by the nine clouds of enum mulls_classify_cloud in that order */
+	MULLS_EX_VERTEX = 12,
+	MULLS_EX_COUNT = 13
+};
+
+/* out[k] / cap[k] / n_out[k], k = enum mulls_extract_cloud: host buffers of 48-byte records, capacities in points, sizes (a cloud larger than its
+ * capacity is truncated, its size still reported; out[k] may be NULL with cap[k] = 0).  Results are those of mulls_ground_filter followed by
+ * mulls_classify_nground on its `unground`. */
+int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *params, void *const out[MULLS_EX_COUNT],
+						   const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT]);
+
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 
 /* batch_transform_feature_points (cregistration.hpp:1685-1696): in place on a host cloud via the device kernel */

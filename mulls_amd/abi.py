@@ -262,6 +262,34 @@ def classify_params(**overrides):
     return p
 
 
+class ExtractParams(C.Structure):
+    _fields_ = [
+        ("ground", GroundParams),
+        ("classify", ClassifyParams),
+        ("apply_scanner_filter", C.c_uint8),
+        ("reserved_", C.c_uint8 * 3),
+        ("self_ring_radius", C.c_float),
+        ("ghost_radius", C.c_float),
+        ("z_min", C.c_float),
+        ("z_min_min", C.c_float),
+    ]
+
+
+EX_RAW, EX_GROUND, EX_GROUND_DOWN, EX_UNGROUND, EX_PILLAR, EX_VERTEX, EX_COUNT = 0, 1, 2, 3, 4, 12, 13
+
+
+def extract_params(ground=None, classify=None, apply_scanner_filter=0, approx_scanner_height=2.0, underground_thre=-7.0):
+    """extract_semantic_pts' chain: scanner filter (cfilter.hpp:2338-2346) -> fast_ground_filter -> classify_nground_pts."""
+    p = ExtractParams()
+    p.ground = ground if ground is not None else ground_params()
+    p.classify = classify if classify is not None else classify_params()
+    p.apply_scanner_filter = apply_scanner_filter
+    p.self_ring_radius, p.ghost_radius = 1.75, 20.0
+    p.z_min = np.float32(-np.float32(approx_scanner_height) - 4.0)
+    p.z_min_min = np.float32(-np.float32(approx_scanner_height) + np.float32(underground_thre))
+    return p
+
+
 def records(a):
     """Any point array (POINT_DTYPE records or raw (n, 48) bytes) as contiguous raw (n, 48) uint8 records, every byte kept."""
     a = np.asarray(a)

@@ -53,7 +53,8 @@ struct Layout
 	size_t total;
 };
 
-Layout carve(unsigned char *base, uint32_t n, uint32_t K)
+// n: points the passes work on; n_in >= n: points of the cloud as handed in (the device-side thinning needs a mask and compaction scratch of that size)
+Layout carve(unsigned char *base, uint32_t n, uint32_t K, uint32_t n_in)
 {
 	Layout L;
 	Bump b{base, 0};
@@ -78,7 +79,7 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K)
 	A.cstate = b.take<uint8_t>(n);
 	A.cand = b.take<uint8_t>(n);
 	A.down = b.take<uint8_t>(n);
-	A.mask = b.take<uint8_t>((size_t)n * 11);
+	A.mask = b.take<uint8_t>(std::max<size_t>((size_t)n * 11, n_in));
 	A.vtx = b.take<float4>((size_t)n * 3);
 	A.round_cnt = b.take<uint32_t>(64);
 	A.grid = b.take<ClGrid>(1);
@@ -101,7 +102,7 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K)
 	L.keys = b.take<float>((size_t)n * 4);
 	L.perm = b.take<uint32_t>((size_t)n * 4);
 	L.counts = b.take<uint32_t>(16);
-	L.seg_cap = (size_t)6 * ((n + 4095u) / 4096u + 1u) + 16;
+	L.seg_cap = (size_t)6 * ((std::max(n, n_in) + 4095u) / 4096u + 1u) + 16;
 	L.seg = b.take<uint32_t>(L.seg_cap);
 	L.total = b.off + 256;
 	return L;
@@ -197,11 +198,12 @@ extern "C"
 		p->feature_pts_ratio_guess = 0.3f;
 	}
 
-	int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n_in, uint32_t stride, const mulls_classify_params *P, void *const out[MULLS_CL_COUNT],
-							   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after)
-	try
+	// pts_on_device: `pts` is device memory of this context's device holding packed 48-byte records (mulls_extract_features)
+	__attribute__((visibility("hidden"))) int mulls_classify_impl(mulls_ctx *ctx, const void *pts, bool pts_on_device, uint32_t n_in, uint32_t stride, const mulls_classify_params *P,
+							void *const out[MULLS_CL_COUNT], const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after,
+							uint32_t *n_cloud_in_after)
 	{
-		if (!ctx || !P || !out || !cap || !n_out || (n_in && !pts) || stride < MULLS_POINT_BYTES)
+		if (!ctx || !P || !out || !cap || !n_out || (n_in && !pts) || stride < MULLS_POINT_BYTES || (pts_on_device && stride != MULLS_POINT_BYTES))
 			return MULLS_E_INVALID;
 		for (int k = 0; k < MULLS_CL_COUNT; k++)
 		{
@@ -233,7 +235,7 @@ extern "C"
 			return MULLS_OK;
 		Bytes packed;
 		const unsigned char *src = static_cast<const unsigned char *>(pts);
-		if (stride != REC || !in_mask.empty())
+		if (!pts_on_device && (stride != REC || !in_mask.empty()))
 		{
 			packed.resize((size_t)n * REC);
 			size_t w = 0;
@@ -245,7 +247,7 @@ extern "C"
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
 		const uint32_t K = (uint32_t)P->neighbor_k;
-		const size_t total = carve(nullptr, n, K).total;
+		const size_t total = carve(nullptr, n, K, n_in).total;
 		if (ctx->cl_cap < total)
 		{
 			if (ctx->cl_buf)
@@ -255,9 +257,27 @@ extern "C"
 			HIPCHK(ctx, hipMalloc(&ctx->cl_buf, total + total / 4));
 			ctx->cl_cap = total + total / 4;
 		}
-		Layout L = carve(static_cast<unsigned char *>(ctx->cl_buf), n, K);
+		Layout L = carve(static_cast<unsigned char *>(ctx->cl_buf), n, K, n_in);
 		const ClArrays &A = L.A;
-		HIPCHK(ctx, hipMemcpyAsync(A.recs, src, (size_t)n * REC, hipMemcpyHostToDevice, st));
+		if (!pts_on_device)
+			HIPCHK(ctx, hipMemcpyAsync(A.recs, src, (size_t)n * REC, hipMemcpyHostToDevice, st));
+		else if (in_mask.empty())
+			HIPCHK(ctx, hipMemcpyAsync(A.recs, src, (size_t)n * REC, hipMemcpyDeviceToDevice, st));
+		else
+		{
+			// the fixed-number thinning of a cloud that is already on the device: the selection mask goes up, a stable compaction applies it
+			HIPCHK(ctx, hipMemcpyAsync(A.mask, in_mask.data(), n_in, hipMemcpyHostToDevice, st));
+			MapCompactArgs ta;
+			std::memset(&ta, 0, sizeof(ta));
+			ta.cloud[0].in = reinterpret_cast<const float4 *>(src);
+			ta.cloud[0].out = A.recs;
+			ta.cloud[0].mask = A.mask;
+			ta.cloud[0].n = n_in;
+			ta.out_n = L.counts;
+			ta.mode = 0;
+			launch_map_compact(st, ta, L.seg);
+			HIPCHK(ctx, hipStreamSynchronize(st)); // in_mask is a host vector
+		}
 		// features of points that are not queried (pca_down_rate > 1) are pca_feature_t's zeros
 		// (closebits .. f_nd are carved back to back: one fill)
 		HIPCHK(ctx, hipMemsetAsync(A.closebits, 0, (size_t)(reinterpret_cast<unsigned char *>(A.f_nd + n) - reinterpret_cast<unsigned char *>(A.closebits)), st));
@@ -479,6 +499,13 @@ extern "C"
 			}
 		}
 		return MULLS_OK;
+	}
+
+	int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n_in, uint32_t stride, const mulls_classify_params *P, void *const out[MULLS_CL_COUNT],
+							   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after)
+	try
+	{
+		return mulls_classify_impl(ctx, pts, false, n_in, stride, P, out, cap, n_out, cloud_in_after, n_cloud_in_after);
 	}
 	catch (...)
 	{

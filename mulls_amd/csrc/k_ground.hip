@@ -718,3 +718,24 @@ int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mu
 	hipLaunchKernelGGL(k_gf_write_high, dim3(seg_blocks), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, S, arena, ns, seg_high, unground);
 	return 0;
 }
+
+// CFilter::scanner_filter (cfilter.hpp:914-929): the points of the ego vehicle's ring and the underground ghost points near the scanner go.
+// mask[i] = 1 keeps point i; the stable compaction is map_kernels.hip's.
+__global__ __launch_bounds__(256) void k_scanner_mask(const float4 *__restrict__ pts, uint32_t n, float self_radius, float ghost_radius, float z_min_ghost,
+													   float z_min_global, uint8_t *__restrict__ mask)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n)
+		return;
+	const float4 p = pts[(size_t)i * 3];
+	const float dis_square = p.x * p.x + p.y * p.y;
+	bool keep = false;
+	if (dis_square > self_radius * self_radius && p.z > z_min_global)
+		keep = dis_square > ghost_radius * ghost_radius || p.z > z_min_ghost;
+	mask[i] = keep ? 1 : 0;
+}
+void launch_scanner_mask(hipStream_t st, const float4 *pts, uint32_t n, float self_radius, float ghost_radius, float z_min_ghost, float z_min_global, uint8_t *mask)
+{
+	if (n)
+		hipLaunchKernelGGL(k_scanner_mask, dim3((n + 255u) / 256u), dim3(256), 0, st, pts, n, self_radius, ghost_radius, z_min_ghost, z_min_global, mask);
+}

@@ -75,6 +75,9 @@ def load():
     lib.mulls_classify_default_params.restype = None
     lib.mulls_classify_nground.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ClassifyParams), C.POINTER(vp), C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]
+    lib.mulls_extract_default_params.argtypes = [C.POINTER(abi.ExtractParams)]
+    lib.mulls_extract_default_params.restype = None
+    lib.mulls_extract_features.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ExtractParams), C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -90,7 +93,7 @@ EXPORTS = [
     "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
     "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
     "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
-    "mulls_classify_default_params", "mulls_classify_nground",
+    "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features",
 ]
 
 
@@ -238,6 +241,26 @@ class Context:
                                                     after.ctypes.data_as(C.c_void_p) if with_cloud_in else None, C.byref(n_after)), "mulls_classify_nground")
         res = [outs[k][: nout[k]].copy() for k in range(abi.CL_COUNT)]
         return (res, after[: n_after.value].copy()) if with_cloud_in else res
+
+    def extract_features(self, scan, params):
+        """CFilter::extract_semantic_pts' chain on the device in one call.  Returns the thirteen clouds of enum mulls_extract_cloud as (n, 48) uint8 arrays."""
+        raw_in = abi.records(scan)
+        n = len(raw_in)
+        if getattr(self, "_ex_cap", 0) < n:  # receive buffers kept between calls (fresh pages cost more than the transfers)
+            self._ex_out = [np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8) for _ in range(abi.EX_COUNT)]
+            self._ex_cap = n
+        outs = self._ex_out
+        out_p = (C.c_void_p * abi.EX_COUNT)(*[o.ctypes.data for o in outs])
+        cap = (C.c_uint32 * abi.EX_COUNT)(*([n] * abi.EX_COUNT))
+        if not params.apply_scanner_filter:
+            cap[abi.EX_RAW] = 0  # pc_raw is the scan itself: not sent back
+        nout = (C.c_uint32 * abi.EX_COUNT)()
+        self._check(self.lib.mulls_extract_features(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), out_p, cap, nout),
+                    "mulls_extract_features")
+        res = [outs[k][: nout[k]].copy() for k in range(abi.EX_COUNT)]
+        if not params.apply_scanner_filter:
+            res[abi.EX_RAW] = raw_in
+        return res
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

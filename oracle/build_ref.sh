@@ -44,6 +44,7 @@ extract cfilter.hpp 551 602 "bool xy_normal_balanced_downsample" cfilter_body.in
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
 extract cfilter.hpp 685 712 "bool random_downsample_pcl(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
+extract cfilter.hpp 914 929 "bool scanner_filter" cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
 extract cfilter.hpp 1071 1181 "bool encode_stable_points" cfilter_body.inc
 extract cfilter.hpp 1243 1312 "bool non_max_suppress(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc

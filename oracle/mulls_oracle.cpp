@@ -2484,6 +2484,29 @@ void update_cloud_vectors(Cloud &pts, float pca_radius, int pca_k, int k_min, fl
 
 extern "C"
 {
+	// CFilter::scanner_filter (cfilter.hpp:914-929): points on the ego vehicle and underground ghost points near the scanner are dropped
+	int mulls_oracle_scanner_filter(const void *pts, uint32_t n, uint32_t stride, float self_radius, float ghost_radius, float z_min_thre_ghost,
+									float z_min_thre_global, void *out, uint32_t cap, uint32_t *n_out)
+	{
+		uint32_t w = 0;
+		for (uint32_t i = 0; i < n; i++)
+		{
+			Pt p;
+			std::memcpy(&p, (const unsigned char *)pts + (size_t)i * stride, sizeof(Pt));
+			float dis_square = p.x * p.x + p.y * p.y;
+			if (dis_square > self_radius * self_radius && p.z > z_min_thre_global)
+			{
+				if (dis_square > ghost_radius * ghost_radius || p.z > z_min_thre_ghost)
+				{
+					if (w < cap)
+						std::memcpy((unsigned char *)out + (size_t)w * sizeof(Pt), &p, sizeof(Pt));
+					w++;
+				}
+			}
+		}
+		*n_out = w;
+		return MULLS_OK;
+	}
 	void mulls_oracle_classify_default_params(mulls_classify_params *p)
 	{
 		std::memset(p, 0, sizeof(*p));

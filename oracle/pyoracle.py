@@ -210,3 +210,28 @@ def nms_ties(reset=False):
     f = lib().mulls_oracle_nms_ties
     f.restype = C.c_ulonglong
     return int(f(int(reset)))
+
+
+def scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global, fn=None):
+    """CFilter::scanner_filter (cfilter.hpp:914-929).  Returns the kept points as (n, 48) uint8 records."""
+    raw_in = abi.records(pts)
+    n = len(raw_in)
+    out = np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8)
+    n_out = C.c_uint32(0)
+    f = fn if fn is not None else lib().mulls_oracle_scanner_filter
+    f.restype = C.c_int
+    rc = f(raw_in.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(abi.POINT_BYTES), C.c_float(self_radius), C.c_float(ghost_radius), C.c_float(z_min_ghost),
+           C.c_float(z_min_global), out.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError("scanner_filter returned %d" % rc)
+    return out[: n_out.value].copy()
+
+
+def extract_features(scan, X):
+    """The chain mulls_extract_features runs, stage by stage in the oracle: the thirteen clouds of enum mulls_extract_cloud."""
+    raw = abi.records(scan)
+    if X.apply_scanner_filter:
+        raw = scanner_filter(raw, X.self_ring_radius, X.ghost_radius, X.z_min, X.z_min_min)
+    g, gd, ung = ground_filter(abi.points_of(raw), X.ground) if len(raw) else (raw[:0], raw[:0], raw[:0])
+    c, after = classify_nground(ung, X.classify)
+    return [raw, g, gd, after] + c

@@ -74,3 +74,10 @@ def classify_nground(pts, params):
     from oracle import pyoracle
 
     return pyoracle._classify(lib().mulls_ref_classify_nground, pts, params)
+
+
+def scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global):
+    """CFilter::scanner_filter, the reference's own lines (cfilter.hpp:914-929)."""
+    from oracle import pyoracle
+
+    return pyoracle.scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global, fn=lib().mulls_ref_scanner_filter)

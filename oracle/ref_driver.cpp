@@ -301,3 +301,20 @@ extern "C" int mulls_ref_classify_nground(const void *pts, uint32_t n, uint32_t 
 		std::memcpy(in_after, in->points.data(), in->points.size() * sizeof(Point_T));
 	return 0;
 }
+
+// CFilter::scanner_filter, the reference's own lines (cfilter.hpp:914-929)
+extern "C" int mulls_ref_scanner_filter(const void *pts, uint32_t n, uint32_t stride, float self_radius, float ghost_radius, float z_min_thre_ghost,
+										float z_min_thre_global, void *out, uint32_t cap, uint32_t *n_out)
+{
+	mulls_cloud c;
+	c.pts = pts, c.n = n, c.stride = stride;
+	pcTPtr in(new pcT());
+	fill_cloud(c, in);
+	lo::CFilter<Point_T> cf;
+	cf.scanner_filter(in, self_radius, ghost_radius, z_min_thre_ghost, z_min_thre_global);
+	*n_out = (uint32_t)in->points.size();
+	const size_t m = std::min<size_t>(in->points.size(), cap);
+	if (m && out)
+		std::memcpy(out, in->points.data(), m * sizeof(Point_T));
+	return 0;
+}

@@ -289,3 +289,51 @@ def test_mulls_reg_tool_on_pcd_files(tmp_path):
     assert dt < 0.05 and dr < 3e-3, (dt, dr)
     moved = lib.read_pcd(out)
     assert len(moved) == len(lib.read_pcd(paths[source - 1]))
+
+
+def with_ego_and_ghost_points(scan, seed=0):
+    """A scan with what scanner_filter is there to remove: returns from the ego vehicle (inside the 1.75 m ring) and underground ghost points
+    (near the scanner between the two height thresholds, far away below the lower one), interleaved with the scan's points."""
+    rng = np.random.default_rng(seed)
+    n_extra = 1500
+    r = np.concatenate([rng.uniform(0.2, 1.74, 500), rng.uniform(2.0, 19.0, 400), rng.uniform(21.0, 60.0, 300), rng.uniform(2.0, 60.0, 300)])
+    az = rng.uniform(0, 2 * np.pi, n_extra)
+    z = np.concatenate([rng.uniform(-1.5, 0.5, 500), rng.uniform(-8.9, -6.1, 400), rng.uniform(-8.9, -6.1, 300), rng.uniform(-15.0, -9.1, 300)])
+    extra = abi.make_points(np.stack([r * np.cos(az), r * np.sin(az), z], 1), None, rng.uniform(0, 255, n_extra), np.zeros(n_extra))
+    allp = np.concatenate([abi.as_points(scan), extra])
+    return allp[rng.permutation(len(allp))]
+
+
+def extract_cases():
+    yield "plain", raw_scan(15, n_beams=48, n_az=1500), abi.extract_params(classify=abi.classify_params(neighbor_k=30))
+    yield "kitti-like", with_ego_and_ghost_points(raw_scan(16)), abi.extract_params(
+        ground=abi.ground_params(apply_grid_wise_outlier_filter=1, fixed_num_downsampling=1, down_ground_fixed_num=500, rng_seed=3),
+        classify=abi.classify_params(neighbor_searching_radius=0.7, neighbor_k=25, neigh_k_min=7, curvature_thre=0.08, fixed_num_downsampling=1,
+                                     unground_down_fixed_num=15000, pillar_down_fixed_num=200, facade_down_fixed_num=600, beam_down_fixed_num=100, roof_down_fixed_num=50,
+                                     beam_height_max=0.5, rng_seed=3),
+        apply_scanner_filter=1)
+
+
+def test_scanner_filter_oracle_equals_reference_lines():
+    scan = with_ego_and_ghost_points(raw_scan(16))
+    X = abi.extract_params(apply_scanner_filter=1)
+    a = pyoracle.scanner_filter(scan, X.self_ring_radius, X.ghost_radius, X.z_min, X.z_min_min)
+    assert len(a) == len(scan) - 500 - 400 - 300  # ego ring, near ghosts, everything below the lower threshold; far "ghosts" stay
+    if pyref.available():
+        b = pyref.scanner_filter(scan, X.self_ring_radius, X.ghost_radius, X.z_min, X.z_min_min)
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_extract_features_equals_the_stages(ctx_auto):
+    """mulls_extract_features (scanner filter -> ground filter -> classes, the clouds staying on the device, the fixed-number thinning of the
+    non-ground cloud applied there) against the same chain stage by stage in the oracle: thirteen clouds, byte for byte."""
+    for name, scan, X in extract_cases():
+        a = pyoracle.extract_features(scan, X)
+        b = ctx_auto.extract_features(scan, X)
+        for k in range(abi.EX_COUNT):
+            assert a[k].shape == b[k].shape, (name, k, a[k].shape, b[k].shape)
+            assert np.array_equal(a[k], b[k]), (name, k)
+        assert len(a[abi.EX_GROUND]) > 1000 and len(a[abi.EX_PILLAR + abi.CL_FACADE]) > 1000
+        if X.apply_scanner_filter:
+            assert len(a[abi.EX_RAW]) < len(scan) and len(a[abi.EX_UNGROUND]) == 15000

@@ -28,3 +28,15 @@ for name, CP, rate in (("run_mulls_reg.sh (r 1.0, k 50)", abi.classify_params(),
     ok = all(np.array_equal(x, y) for x, y in zip(a, b))
     print("%-32s %d unground points -> %s: device %.2f ms (upload + kernels + host sort + download), scan -> features %.2f ms, oracle %.1f ms (one core), identical %s"
           % (name, len(ung), [len(x) for x in a], dt * 1e3, dboth * 1e3, do * 1e3, ok))
+X = abi.extract_params(ground=abi.ground_params(), classify=abi.classify_params())
+a = ctx.extract_features(pts, X)
+t = time.time()
+for _ in range(10):
+    a = ctx.extract_features(pts, X)
+dx = (time.time() - t) / 10
+t = time.time()
+for _ in range(10):
+    g = ctx.ground_filter(pts, abi.ground_params())
+    c = ctx.classify_nground(g[2], abi.classify_params())
+d2 = (time.time() - t) / 10
+print("mulls_extract_features (one call, clouds stay on the device): %.2f ms; the two calls: %.2f ms; %d points -> %s" % (dx * 1e3, d2 * 1e3, len(pts), [len(x) for x in a]))
