@@ -337,3 +337,17 @@ def test_extract_features_equals_the_stages(ctx_auto):
         assert len(a[abi.EX_GROUND]) > 1000 and len(a[abi.EX_PILLAR + abi.CL_FACADE]) > 1000
         if X.apply_scanner_filter:
             assert len(a[abi.EX_RAW]) < len(scan) and len(a[abi.EX_UNGROUND]) == 15000
+
+
+@pytest.mark.gpu
+def test_odometry_front_end_from_raw_scans():
+    """test/mulls_slam.cpp's per-frame chain on the device (tools/gpu_odometry.py): raw scan -> extract_semantic_pts -> scan-to-map mm_lls_icp
+    against the device-resident local map -> update_local_map; the first frames through the oracle's chain as well — features, registration
+    and map identical —, every frame converged, drift bounded."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gpu_odometry_tool", os.path.join(os.path.dirname(GOLD), "..", "tools", "gpu_odometry.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    et, er = tool.main(["6", "--check", "2"])
+    assert et < 0.05 and er < 0.005
