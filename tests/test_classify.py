@@ -351,3 +351,34 @@ def test_odometry_front_end_from_raw_scans():
     spec.loader.exec_module(tool)
     et, er = tool.main(["6", "--check", "2"])
     assert et < 0.05 and er < 0.005
+
+
+@pytest.mark.gpu
+def test_classify_abi_stride_and_truncation(ctx_auto):
+    """Straight through the C ABI: records 64 bytes apart, capacities smaller than the clouds (prefix kept, full size reported), NULL outputs."""
+    import ctypes as C
+
+    ung = unground_of(raw_scan(13, n_beams=32, n_az=900), 1)
+    P = abi.classify_params(neighbor_k=20)
+    want, want_in = pyoracle.classify_nground(ung, P)
+    n = len(ung)
+    wide = np.zeros((n, 64), np.uint8)
+    wide[:, :48] = ung
+    wide[:, 48:] = 0xAB
+    lib_ = ctx_auto.lib
+    caps = [0, 5, n, n, 3, n, 7, n, 100]
+    outs = [np.zeros((max(c, 1), 48), np.uint8) for c in caps]
+    out_p = (C.c_void_p * abi.CL_COUNT)(*[(o.ctypes.data if c else None) for o, c in zip(outs, caps)])
+    cap = (C.c_uint32 * abi.CL_COUNT)(*caps)
+    nout = (C.c_uint32 * abi.CL_COUNT)()
+    n_after = C.c_uint32(0)
+    rc = lib_.mulls_classify_nground(ctx_auto.h, wide.ctypes.data_as(C.c_void_p), n, 64, C.byref(P), out_p, cap, nout, None, C.byref(n_after))
+    assert rc == 0 and n_after.value == len(want_in)
+    for k in range(abi.CL_COUNT):
+        assert nout[k] == len(want[k])
+        m = min(caps[k], len(want[k]))
+        assert np.array_equal(outs[k][:m], want[k][:m]), abi.CL_NAMES[k]
+    assert np.array_equal(wide[:, :48], ung) and np.all(wide[:, 48:] == 0xAB)  # the input is not written to
+    bad = (C.c_uint32 * abi.CL_COUNT)(*([1] * abi.CL_COUNT))
+    null_p = (C.c_void_p * abi.CL_COUNT)()
+    assert lib_.mulls_classify_nground(ctx_auto.h, wide.ctypes.data_as(C.c_void_p), n, 64, C.byref(P), null_p, bad, nout, None, None) == abi.MULLS_E_INVALID
