@@ -494,18 +494,22 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 		const uint32_t gi = d.src_off + s;
 		if (!(flag[gi] & MULLS_F_ALIVE))
 			continue;
+		// every record of the point is requested at once (position, direction, hint, standing match and its target position): one memory
+		// round trip instead of a chain of three
 		const float4 p = spos[gi], n = snrm[gi];
+		const int2 h = hint2[gi];
+		const int32_t pm0 = match[gi];
+		const float4 q0 = mq[2u * gi];
 		uint32_t hv = 0xffffu;
 		float lb = 0.0f;
 		int32_t pm = -1;
 		if (have_prev)
 		{
-			const int2 h = hint2[gi];
 			lb = __int_as_float(h.y);
 			if (use_hint)
 			{
 				hv = (uint32_t)h.x;
-				pm = match[gi];
+				pm = pm0;
 			}
 		}
 		// the hinted target's position: for a point whose hint is its standing correspondence it sits in the point's own
@@ -513,7 +517,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 		const uint32_t hj = hv & 0xffffu;
 		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (hj < tgt_n)
-			tj = (int32_t)hj == pm ? mq[2u * gi] : tpos[d.tgt_off + hj];
+			tj = (int32_t)hj == pm ? q0 : tpos[d.tgt_off + hj];
 		// fused rigid step (cregistration.hpp:1690-1695): double math, float store, in place
 		const double *T = ps.T;
 		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
