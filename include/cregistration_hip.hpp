@@ -575,6 +575,120 @@ inline bool classify_nground_pts(typename pcl::PointCloud<PointT>::Ptr &cloud_in
 	return 1;
 }
 
+// CFilter<PointT>::extract_semantic_pts (include/common/cfilter.hpp:2295-2413), verbatim signature: the whole chain in one device call
+// (mulls_extract_features).  The binding is one early return at the top of the member function:
+//     #ifdef MULLS_USE_HIP
+//         return lo::hip::extract_semantic_pts<PointT>(in_block, vf_downsample_resolution, gf_grid_resolution, ...);
+//     #endif
+// Not available and refused: voxel down-sampling (vf_downsample_resolution >= 0.001; every shipped configuration passes 0), semantic_assisted,
+// use_adpative_parameters, estimate_ground_normal_method != 0.  apply_roi_filtering is dead code upstream ("#if 0") and ignored here too.
+// One side effect is not reproduced: upstream's ground filter writes (0,0,1) normals and data[3] heights into the points of pc_down (= pc_raw)
+// it classifies; here pc_raw / pc_down / pc_sketch keep the scan's records (the clouds handed out carry those values).
+template <typename PointT>
+inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_resolution, float gf_grid_resolution, float gf_max_grid_height_diff,
+								 float gf_neighbor_height_diff, float gf_max_ground_height, int &gf_down_rate_ground, int &gf_downsample_rate_nonground,
+								 float pca_neighbor_radius, int pca_neighbor_k, float edge_thre, float planar_thre, float curvature_thre, float edge_thre_down,
+								 float planar_thre_down, bool use_distance_adaptive_pca = false, int distance_inverse_sampling_method = 0,
+								 float standard_distance = 15.0, int estimate_ground_normal_method = 3, float normal_estimation_radius = 2.0,
+								 bool use_adpative_parameters = false, bool apply_scanner_filter = false, bool extract_curb_or_not = false,
+								 int extract_vertex_points_method = 2, int gf_grid_pt_num_thre = 8, int gf_reliable_neighbor_grid_thre = 0,
+								 int gf_down_down_rate_ground = 2, int pca_neighbor_k_min = 8, int pca_down_rate = 1, float intensity_thre = FLT_MAX,
+								 float linear_vertical_sin_high_thre = 0.94, float linear_vertical_sin_low_thre = 0.17, float planar_vertical_sin_high_thre = 0.98,
+								 float planar_vertical_sin_low_thre = 0.34, bool sharpen_with_nms_on = true, bool fixed_num_downsampling = false,
+								 int ground_down_fixed_num = 500, int pillar_down_fixed_num = 200, int facade_down_fixed_num = 800, int beam_down_fixed_num = 200,
+								 int roof_down_fixed_num = 200, int unground_down_fixed_num = 20000, float beam_height_max = FLT_MAX, float roof_height_min = 0.0,
+								 float approx_scanner_height = 2.0, float underground_thre = -7.0, float feature_pts_ratio_guess = 0.3, bool semantic_assisted = false,
+								 bool apply_roi_filtering = false, float roi_min_y = 0.0, float roi_max_y = 0.0)
+{
+	(void)normal_estimation_radius, (void)extract_curb_or_not, (void)apply_roi_filtering, (void)roi_min_y, (void)roi_max_y;
+	if (semantic_assisted || use_adpative_parameters || vf_downsample_resolution >= 0.001f)
+		throw std::runtime_error("lo::hip::extract_semantic_pts: semantic masks, adaptive parameters and voxel down-sampling are not part of this build");
+	mulls_ctx *ctx = thread_context();
+	mulls_extract_params X;
+	mulls_extract_default_params(&X);
+	mulls_ground_params &G = X.ground;
+	G.min_grid_pt_num = gf_grid_pt_num_thre;
+	G.grid_resolution = gf_grid_resolution;
+	G.max_height_difference = gf_max_grid_height_diff;
+	G.neighbor_height_diff = gf_neighbor_height_diff;
+	G.max_ground_height = gf_max_ground_height;
+	G.ground_random_down_rate = gf_down_rate_ground;
+	G.ground_random_down_down_rate = gf_down_down_rate_ground;
+	G.nonground_random_down_rate = gf_downsample_rate_nonground;
+	G.reliable_neighbor_grid_num_thre = gf_reliable_neighbor_grid_thre;
+	G.estimate_ground_normal_method = estimate_ground_normal_method;
+	G.distance_weight_downsampling_method = distance_inverse_sampling_method;
+	G.standard_distance = standard_distance;
+	G.fixed_num_downsampling = fixed_num_downsampling;
+	G.down_ground_fixed_num = ground_down_fixed_num;
+	G.intensity_thre = intensity_thre;
+	G.apply_grid_wise_outlier_filter = apply_scanner_filter; // :2361
+	G.outlier_std_scale = 3.0f;
+	G.rng_seed = feature_rng_seed()++;
+	mulls_classify_params &K = X.classify;
+	K.neighbor_searching_radius = pca_neighbor_radius;
+	K.neighbor_k = pca_neighbor_k;
+	K.neigh_k_min = pca_neighbor_k_min;
+	K.pca_down_rate = pca_down_rate;
+	K.edge_thre = edge_thre, K.planar_thre = planar_thre, K.edge_thre_down = edge_thre_down, K.planar_thre_down = planar_thre_down;
+	K.extract_vertex_points_method = extract_vertex_points_method;
+	K.curvature_thre = curvature_thre;
+	K.vertex_curvature_non_max_radius = 1.5 * pca_neighbor_radius; // :2365
+	K.linear_vertical_sin_high_thre = linear_vertical_sin_high_thre, K.linear_vertical_sin_low_thre = linear_vertical_sin_low_thre;
+	K.planar_vertical_sin_high_thre = planar_vertical_sin_high_thre, K.planar_vertical_sin_low_thre = planar_vertical_sin_low_thre;
+	K.fixed_num_downsampling = fixed_num_downsampling;
+	K.sharpen_with_nms = sharpen_with_nms_on;
+	K.use_distance_adaptive_pca = use_distance_adaptive_pca;
+	K.pillar_down_fixed_num = pillar_down_fixed_num, K.facade_down_fixed_num = facade_down_fixed_num, K.beam_down_fixed_num = beam_down_fixed_num;
+	K.roof_down_fixed_num = roof_down_fixed_num, K.unground_down_fixed_num = unground_down_fixed_num;
+	K.beam_height_max = beam_height_max, K.roof_height_min = roof_height_min, K.feature_pts_ratio_guess = feature_pts_ratio_guess;
+	K.rng_seed = feature_rng_seed()++;
+	X.apply_scanner_filter = apply_scanner_filter;
+	X.self_ring_radius = 1.75f; // :2340-2343
+	X.ghost_radius = 20.0f;
+	X.z_min = -approx_scanner_height - 4.0;
+	X.z_min_min = -approx_scanner_height + underground_thre;
+
+	cloudblock_t &b = *in_block;
+	const mulls_cloud in = borrow(b.pc_raw);
+	std::vector<unsigned char> raw[MULLS_EX_COUNT];
+	void *out[MULLS_EX_COUNT];
+	uint32_t cap[MULLS_EX_COUNT], n_out[MULLS_EX_COUNT];
+	for (int k = 0; k < MULLS_EX_COUNT; k++)
+	{
+		const bool want = k != MULLS_EX_RAW || apply_scanner_filter; // without the scanner filter pc_raw stays what it is
+		raw[k].resize(want ? (size_t)in.n * MULLS_POINT_BYTES : 0);
+		out[k] = want ? raw[k].data() : nullptr;
+		cap[k] = want ? in.n : 0;
+	}
+	const int rc = mulls_extract_features(ctx, in.pts, in.n, in.stride, &X, out, cap, n_out);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_extract_features failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	if (apply_scanner_filter)
+		take_cloud<PointT>(b.pc_raw, raw[MULLS_EX_RAW], n_out[MULLS_EX_RAW], false); // scanner_filter works on pc_raw itself
+	b.pc_down = b.pc_raw; // voxel_downsample below 0.001 m: `cloud_out = cloud_in` (:92)
+	{
+		// random_downsample(pc_down, pc_sketch, size / 1024 + 1) (:2351, :713-728)
+		const int ratio = (int)(b.pc_down->points.size() / 1024 + 1);
+		if (ratio > 1)
+		{
+			b.pc_sketch->points.clear();
+			for (size_t i = 0; i < b.pc_down->points.size(); i++)
+				if ((int)i % ratio == 0)
+					b.pc_sketch->points.push_back(b.pc_down->points[i]);
+		}
+	}
+	take_cloud<PointT>(b.pc_ground, raw[MULLS_EX_GROUND], n_out[MULLS_EX_GROUND], true);
+	take_cloud<PointT>(b.pc_ground_down, raw[MULLS_EX_GROUND_DOWN], n_out[MULLS_EX_GROUND_DOWN], true);
+	take_cloud<PointT>(b.pc_unground, raw[MULLS_EX_UNGROUND], n_out[MULLS_EX_UNGROUND], false); // the filter appends to an empty cloud, the classification works on it in place
+	typename pcl::PointCloud<PointT>::Ptr *dst[9] = {&b.pc_pillar, &b.pc_beam, &b.pc_facade, &b.pc_roof, &b.pc_pillar_down, &b.pc_beam_down, &b.pc_facade_down, &b.pc_roof_down, &b.pc_vertex};
+	for (int k = 0; k < 9; k++)
+		take_cloud<PointT>(*dst[k], raw[MULLS_EX_PILLAR + k], n_out[MULLS_EX_PILLAR + k], true);
+	b.down_feature_point_num = b.pc_ground_down->points.size() + b.pc_pillar_down->points.size() + b.pc_beam_down->points.size() + b.pc_facade_down->points.size() +
+							   b.pc_roof_down->points.size() + b.pc_vertex->points.size(); // :2397-2398
+	return true;
+}
+
 } // namespace hip
 } // namespace lo
 

@@ -50,6 +50,9 @@ class CFilter : public CloudUtility<PointT>
   public:
 	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell): not extracted, never reached (method 0)
 	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
+	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
+	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
+	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }
 #include "cfilter_body.inc"
 };
 template <typename PointT>
@@ -160,6 +163,41 @@ int main(int argc, char **argv)
 				const unsigned char *b = reinterpret_cast<const unsigned char *>(all[k]->points.data());
 				for (size_t i = 0; i < all[k]->points.size() * sizeof(Point_T); i++)
 					h = (h ^ b[i]) * 1099511628211ull;
+				printf("%s\"%016llx\"", k ? ", " : "", h);
+			}
+			printf("]}\n");
+		}
+		// the same chain through its one entry point, extract_semantic_pts, with the scanner filter on: the reference member vs the bridge, on cloudblocks
+		for (int w = 0; w < 2; w++)
+		{
+			lo::cloudblock_Ptr blk(new lo::cloudblock_t());
+			*blk->pc_raw = *scan;
+			int gdr = 10, ndr = 3;
+			if (w == 0)
+			{
+				lo::CFilter<Point_T> cf;
+				cf.extract_semantic_pts(blk, 0.0f, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, 0.75f, 0.75f, false, 0, 15.0f, 0, 2.0f, false, true, false, 2, 8, 0, 2,
+										8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f, false, false, 0.0f, 0.0f);
+			}
+			else
+				lo::hip::extract_semantic_pts<Point_T>(blk, 0.0f, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, 0.75f, 0.75f, false, 0, 15.0f, 0, 2.0f, false, true, false, 2,
+													   8, 0, 2, 8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f,
+													   false, false, 0.0f, 0.0f);
+			pcTPtr all[15] = {blk->pc_raw,	  blk->pc_down,	 blk->pc_sketch, blk->pc_ground,	  blk->pc_ground_down, blk->pc_unground,	blk->pc_pillar,	   blk->pc_beam,
+							  blk->pc_facade, blk->pc_roof, blk->pc_pillar_down, blk->pc_beam_down, blk->pc_facade_down, blk->pc_roof_down, blk->pc_vertex};
+			printf("{\"who\": \"%s\", \"down_feature_point_num\": %d, \"sizes\": [", w == 0 ? "reference_block" : "hip_block", blk->down_feature_point_num);
+			for (int k = 0; k < 15; k++)
+				printf("%s%zu", k ? ", " : "", all[k]->points.size());
+			printf("], \"sums\": [");
+			for (int k = 0; k < 15; k++)
+			{
+				// pc_raw / pc_down / pc_sketch (k < 3): position, intensity, curvature only — upstream's ground filter writes (0,0,1) normals and
+				// data[3] heights into the cloud it is given (pc_down = pc_raw), the bridge leaves the scan's points as they are
+				unsigned long long h = 1469598103934665603ull;
+				const unsigned char *b = reinterpret_cast<const unsigned char *>(all[k]->points.data());
+				for (size_t i = 0; i < all[k]->points.size() * sizeof(Point_T); i++)
+					if (k >= 3 || i % sizeof(Point_T) < 12 || (i % sizeof(Point_T) >= 32 && i % sizeof(Point_T) < 40))
+						h = (h ^ b[i]) * 1099511628211ull;
 				printf("%s\"%016llx\"", k ? ", " : "", h);
 			}
 			printf("]}\n");

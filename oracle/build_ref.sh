@@ -38,11 +38,14 @@ extract utility.hpp 233 558 "struct cloudblock_t" util_types.inc
 extract utility.hpp 561 590 "struct constraint_t" util_types.inc
 extract utility.hpp 795 886 "template <typename PointT>" util_cloudutility.inc
 # cfilter.hpp: grid_t, motion compensation, random down-sampling, box filter, the ground filter, pair intersection
+extract cfilter.hpp 35 43 "struct idpair_t" cfilter_body.inc
 extract cfilter.hpp 45 69 "struct grid_t" cfilter_body.inc
+extract cfilter.hpp 83 165 "bool voxel_downsample" cfilter_body.inc
 extract cfilter.hpp 470 549 "void apply_motion_compensation" cfilter_body.inc
 extract cfilter.hpp 551 602 "bool xy_normal_balanced_downsample" cfilter_body.inc
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
 extract cfilter.hpp 685 712 "bool random_downsample_pcl(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
+extract cfilter.hpp 713 728 "bool random_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 914 929 "bool scanner_filter" cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
@@ -50,6 +53,8 @@ extract cfilter.hpp 1071 1181 "bool encode_stable_points" cfilter_body.inc
 extract cfilter.hpp 1243 1312 "bool non_max_suppress(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 1658 2036 "bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 2058 2290 "bool classify_nground_pts" cfilter_body.inc
+extract cfilter.hpp 2295 2413 "bool extract_semantic_pts" cfilter_body.inc
+extract cfilter.hpp 2416 2482 "void update_parameters_self_adaptive" cfilter_body.inc
 # pca.hpp: pca_feature_t and the neighbourhood PCA (get_pc_pca_feature x2, calculate_normal_inconsistency, get_pca_feature, assign_normal)
 extract pca.hpp 23 54 "struct eigenvalue_t" pca_types.inc
 extract pca.hpp 207 454 "// R - K neighborhood (without already built-kd tree)" pca_body.inc

@@ -48,6 +48,9 @@ class CFilter : public CloudUtility<PointT>
   public:
 	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell, cfilter.hpp:2038-2076): not extracted, never reached by the pin
 	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
+	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
+	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
+	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }
 #include "cfilter_body.inc"
 };
 

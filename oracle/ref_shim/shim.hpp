@@ -128,6 +128,7 @@ struct Matrix
 		static_assert(R == 1 && C == 1, "only 1x1 converts to scalar");
 		return v[0];
 	}
+	const T &coeff(int i) const { return v[i]; }
 	const T &x() const { return v[0]; }
 	const T &y() const { return v[1]; }
 	const T &z() const { return v[2]; }
@@ -326,6 +327,7 @@ typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<float, 4, 4> Matrix4f;
 typedef Matrix<float, 3, 3> Matrix3f;
+typedef Matrix<float, 4, 1> Vector4f;
 typedef Matrix<float, 3, 1> Vector3f;
 
 // unit quaternion, as far as the path uses it (rotation matrix -> quaternion, slerp from identity, rotate a vector)
@@ -512,6 +514,29 @@ struct KdTree
 	mutable bool index_built = false;
 };
 } // namespace search
+
+// pcl::getMinMax3D (pcl/common/impl/common.hpp): component-wise bounds of the finite points
+template <typename PointT>
+inline void getMinMax3D(const PointCloud<PointT> &cloud, Eigen::Matrix<float, 4, 1> &min_pt, Eigen::Matrix<float, 4, 1> &max_pt)
+{
+	for (int k = 0; k < 4; k++)
+	{
+		min_pt(k) = FLT_MAX;
+		max_pt(k) = -FLT_MAX;
+	}
+	for (size_t i = 0; i < cloud.points.size(); i++)
+	{
+		const PointT &p = cloud.points[i];
+		if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z))
+			continue;
+		const float v[3] = {p.x, p.y, p.z};
+		for (int k = 0; k < 3; k++)
+		{
+			min_pt(k) = std::min(min_pt(k), v[k]);
+			max_pt(k) = std::max(max_pt(k), v[k]);
+		}
+	}
+}
 
 // pcl::KdTreeFLANN: the same index under its other name (the searches copy the positions at setInputCloud time: later writes to the
 // cloud's normals, as get_pc_pca_feature does, are not seen — positions never change)

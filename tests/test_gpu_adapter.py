@@ -89,7 +89,9 @@ def test_adapter_feature_extraction_matches_reference_members():
     """lo::hip::fast_ground_filter / classify_nground_pts vs the reference's CFilter members on one raw scan: every output cloud the same bytes."""
     from test_ground_filter import raw_scan
 
-    scan = raw_scan(14, n_beams=48, n_az=1400)
+    from test_classify import with_ego_and_ghost_points
+
+    scan = with_ego_and_ghost_points(raw_scan(14, n_beams=48, n_az=1400))
     empty = np.zeros(0, abi.POINT_DTYPE)
     pair = abi.PairData([scan] + [empty] * 5, [empty] * 6)
     with tempfile.TemporaryDirectory() as d:
@@ -99,4 +101,10 @@ def test_adapter_feature_extraction_matches_reference_members():
     ref, hip = json.loads(out[0]), json.loads(out[1])
     assert ref["who"] == "reference" and hip["who"] == "hip"
     assert ref["sizes"] == hip["sizes"] and ref["sums"] == hip["sums"]
-    assert ref["sizes"][0] > 1000 and ref["sizes"][5] > 1000 and sum(ref["sizes"][7:11]) > 100
+    assert ref["sizes"][2] > 1000  # (the scan carries underground ghost points: without the scanner filter the ground filter finds little ground)
+    # ... and through the chain's one entry point, CFilter::extract_semantic_pts vs lo::hip::extract_semantic_pts, scanner filter on, on cloudblocks
+    refb, hipb = json.loads(out[2]), json.loads(out[3])
+    assert refb["who"] == "reference_block" and hipb["who"] == "hip_block"
+    assert refb["sizes"] == hipb["sizes"] and refb["sums"] == hipb["sums"] and refb["down_feature_point_num"] == hipb["down_feature_point_num"] > 0
+    assert refb["sizes"][0] == len(scan) - 1200 and refb["sizes"][1] == refb["sizes"][0] and 0 < refb["sizes"][2] <= 1024  # pc_raw filtered, pc_down = pc_raw, pc_sketch
+    assert refb["sizes"][3] > 1000 and refb["sizes"][8] > 1000 and sum(refb["sizes"][10:14]) > 100  # ground, facade, the *_down clouds
