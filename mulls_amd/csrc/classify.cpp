@@ -42,7 +42,8 @@ struct Layout
 	float4 *cls_a[6];	  // pillar, pillar (promoted), beam, beam (promoted), facade, roof: compaction targets, pillar / beam become the class clouds
 	float4 *cls_sorted[4]; // class clouds in visiting order
 	float4 *down[4], *vertex;
-	uint32_t *nms_list[4], *nms_cnt[4], *nms_off[4], *nms_wcur[4], *nms_pool, *nms_pool_used;
+	uint32_t *nms_list[4], *nms_cnt[4], *nms_off[4], *nms_wcur[4], *nms_pool;
+	unsigned long long *nms_pool_used;
 	uint32_t nms_pool_cap;
 	uint8_t *keep[4];
 	float *keys;	// [4][n]
@@ -98,7 +99,7 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K, uint32_t n_in)
 	L.vertex = b.take<float4>((size_t)n * 3);
 	L.nms_pool_cap = (uint32_t)std::min<size_t>((size_t)n * 64u, 0x7fffffffu);
 	L.nms_pool = b.take<uint32_t>(L.nms_pool_cap);
-	L.nms_pool_used = b.take<uint32_t>(1);
+	L.nms_pool_used = b.take<unsigned long long>(1);
 	L.keys = b.take<float>((size_t)n * 4);
 	L.perm = b.take<uint32_t>((size_t)n * 4);
 	L.counts = b.take<uint32_t>(16);
@@ -423,7 +424,7 @@ extern "C"
 					na.wcur[c] = L.nms_wcur[c];
 				}
 				na.pool = L.nms_pool, na.pool_used = L.nms_pool_used, na.pool_cap = L.nms_pool_cap;
-				HIPCHK(ctx, hipMemsetAsync(L.nms_pool_used, 0, 4, st));
+				HIPCHK(ctx, hipMemsetAsync(L.nms_pool_used, 0, 8, st));
 				launch_cl_nms_lists(st, na);
 				HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
 				for (uint32_t round = 0;;)

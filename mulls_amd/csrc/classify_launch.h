@@ -72,7 +72,8 @@ struct ClNmsArgs
 	uint32_t *cnt[4];	   // [n[c]] how many there are (may exceed the list)
 	uint32_t *off[4];	   // [n[c]] where a longer list starts in the pool, ~0 if it did not fit
 	uint32_t *wcur[4];	   // [n[c]] fill cursor of a pool list
-	uint32_t *pool, *pool_used; // pool of pool_cap entries shared by the four classes; *pool_used = 0 before launch_cl_nms_lists
+	uint32_t *pool;				// pool of pool_cap entries shared by the four classes
+	unsigned long long *pool_used; // entries requested so far; 0 before launch_cl_nms_lists
 	uint32_t pool_cap;
 	float r2;
 };

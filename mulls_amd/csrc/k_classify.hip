@@ -658,9 +658,9 @@ __global__ __launch_bounds__(256) void k_cl_nms_reserve(ClNmsArgs a)
 	uint32_t off = 0xffffffffu;
 	if (cnt > CL_NMS_CAP)
 	{
-		const uint32_t o = atomicAdd(a.pool_used, cnt);
-		if (o <= a.pool_cap && cnt <= a.pool_cap - o)
-			off = o;
+		const unsigned long long o = atomicAdd(a.pool_used, (unsigned long long)cnt); // 64-bit: the requests of a pathological cloud must not wrap back into the pool
+		if (o <= (unsigned long long)a.pool_cap && (unsigned long long)cnt <= (unsigned long long)a.pool_cap - o)
+			off = (uint32_t)o;
 	}
 	a.off[c][p] = off;
 	a.wcur[c][p] = 0;
