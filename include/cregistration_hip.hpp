@@ -575,13 +575,34 @@ inline bool classify_nground_pts(typename pcl::PointCloud<PointT>::Ptr &cloud_in
 	return 1;
 }
 
+// CFilter<PointT>::voxel_downsample (include/common/cfilter.hpp:83-160), verbatim signature
+template <typename PointT>
+inline bool voxel_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_in, typename pcl::PointCloud<PointT>::Ptr &cloud_out, float voxel_size)
+{
+	if (voxel_size < 0.001)
+	{
+		cloud_out = cloud_in; // :90-97
+		return false;
+	}
+	mulls_ctx *ctx = thread_context();
+	const mulls_cloud in = borrow(cloud_in);
+	std::vector<unsigned char> raw((size_t)in.n * MULLS_POINT_BYTES);
+	uint32_t n_out = 0;
+	const int rc = mulls_voxel_downsample(ctx, in.pts, in.n, in.stride, voxel_size, raw.data(), in.n, &n_out);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_voxel_downsample failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+	take_cloud<PointT>(cloud_out, raw, n_out, true); // `cloud_out->push_back(...)`: appended (:147)
+	return 1;
+}
+
 // CFilter<PointT>::extract_semantic_pts (include/common/cfilter.hpp:2295-2413), verbatim signature: the whole chain in one device call
 // (mulls_extract_features).  The binding is one early return at the top of the member function:
 //     #ifdef MULLS_USE_HIP
 //         return lo::hip::extract_semantic_pts<PointT>(in_block, vf_downsample_resolution, gf_grid_resolution, ...);
 //     #endif
-// Not available and refused: voxel down-sampling (vf_downsample_resolution >= 0.001; every shipped configuration passes 0), semantic_assisted,
-// use_adpative_parameters, estimate_ground_normal_method != 0.  apply_roi_filtering is dead code upstream ("#if 0") and ignored here too.
+// Not available and refused: semantic_assisted, estimate_ground_normal_method != 0.  apply_roi_filtering is dead code upstream ("#if 0") and
+// ignored here too.  use_adpative_parameters runs upstream's update (:2416-2444) on the host; where upstream would divide by zero (no facade and
+// no pillar point left) this throws instead.
 // One side effect is not reproduced: upstream's ground filter writes (0,0,1) normals and data[3] heights into the points of pc_down (= pc_raw)
 // it classifies; here pc_raw / pc_down / pc_sketch keep the scan's records (the clouds handed out carry those values).
 template <typename PointT>
@@ -601,8 +622,8 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 								 bool apply_roi_filtering = false, float roi_min_y = 0.0, float roi_max_y = 0.0)
 {
 	(void)normal_estimation_radius, (void)extract_curb_or_not, (void)apply_roi_filtering, (void)roi_min_y, (void)roi_max_y;
-	if (semantic_assisted || use_adpative_parameters || vf_downsample_resolution >= 0.001f)
-		throw std::runtime_error("lo::hip::extract_semantic_pts: semantic masks, adaptive parameters and voxel down-sampling are not part of this build");
+	if (semantic_assisted)
+		throw std::runtime_error("lo::hip::extract_semantic_pts: semantic masks are not part of this build");
 	mulls_ctx *ctx = thread_context();
 	mulls_extract_params X;
 	mulls_extract_default_params(&X);
@@ -648,6 +669,8 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	X.ghost_radius = 20.0f;
 	X.z_min = -approx_scanner_height - 4.0;
 	X.z_min_min = -approx_scanner_height + underground_thre;
+	X.vf_downsample_resolution = vf_downsample_resolution;
+	const bool voxels = !(vf_downsample_resolution < 0.001);
 
 	cloudblock_t &b = *in_block;
 	const mulls_cloud in = borrow(b.pc_raw);
@@ -656,7 +679,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	uint32_t cap[MULLS_EX_COUNT], n_out[MULLS_EX_COUNT];
 	for (int k = 0; k < MULLS_EX_COUNT; k++)
 	{
-		const bool want = k != MULLS_EX_RAW || apply_scanner_filter; // without the scanner filter pc_raw stays what it is
+		const bool want = k == MULLS_EX_RAW ? apply_scanner_filter : k == MULLS_EX_DOWN ? voxels : true; // without the scanner filter pc_raw stays what it is, without voxels pc_down is pc_raw
 		raw[k].resize(want ? (size_t)in.n * MULLS_POINT_BYTES : 0);
 		out[k] = want ? raw[k].data() : nullptr;
 		cap[k] = want ? in.n : 0;
@@ -666,7 +689,10 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 		throw std::runtime_error(std::string("mulls_extract_features failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
 	if (apply_scanner_filter)
 		take_cloud<PointT>(b.pc_raw, raw[MULLS_EX_RAW], n_out[MULLS_EX_RAW], false); // scanner_filter works on pc_raw itself
-	b.pc_down = b.pc_raw; // voxel_downsample below 0.001 m: `cloud_out = cloud_in` (:92)
+	if (voxels)
+		take_cloud<PointT>(b.pc_down, raw[MULLS_EX_DOWN], n_out[MULLS_EX_DOWN], true); // `cloud_out->push_back(...)` (:147)
+	else
+		b.pc_down = b.pc_raw; // voxel_downsample below 0.001 m: `cloud_out = cloud_in` (:92)
 	{
 		// random_downsample(pc_down, pc_sketch, size / 1024 + 1) (:2351, :713-728)
 		const int ratio = (int)(b.pc_down->points.size() / 1024 + 1);
@@ -686,6 +712,18 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 		take_cloud<PointT>(*dst[k], raw[MULLS_EX_PILLAR + k], n_out[MULLS_EX_PILLAR + k], true);
 	b.down_feature_point_num = b.pc_ground_down->points.size() + b.pc_pillar_down->points.size() + b.pc_beam_down->points.size() + b.pc_facade_down->points.size() +
 							   b.pc_roof_down->points.size() + b.pc_vertex->points.size(); // :2397-2398
+	if (use_adpative_parameters)
+	{
+		// update_parameters_self_adaptive (:2416-2444): the one live rule lowers the non-ground down-sampling rate when few facade / pillar points came out
+		const int non_ground_num_min_expected = 200;
+		const int non_ground_feature_num = (int)b.pc_facade_down->points.size() + (int)b.pc_pillar_down->points.size();
+		if (non_ground_feature_num < non_ground_num_min_expected)
+		{
+			if (non_ground_feature_num == 0)
+				throw std::runtime_error("lo::hip::extract_semantic_pts: adaptive parameters with no facade / pillar point (upstream divides by zero here)");
+			gf_downsample_rate_nonground = std::max(1, gf_downsample_rate_nonground - non_ground_num_min_expected / non_ground_feature_num);
+		}
+	}
 	return true;
 }
 

@@ -405,32 +405,38 @@ int mulls_classify_nground(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t
 
 /* ---- feature extraction, the whole chain: CFilter::extract_semantic_pts (include/common/cfilter.hpp:2294-2413) ---- */
 
-/* scanner filter (:2338-2346, :914-929) -> fast_ground_filter -> classify_nground_pts in one call: the scan goes up once, the non-ground cloud
- * never leaves the device between the two stages.  Not part of it: voxel down-sampling (off in every shipped configuration: cloud_down_res 0),
- * the semantic-mask filters (semantic_assisted), the adaptive parameter update. */
+/* The per-frame front end of test/mulls_slam.cpp:359-365 / :404-421 in one call: dist_filter (:806-832, --apply_dist_filter) -> scanner filter
+ * (:2338-2346, :914-929) -> voxel_downsample (:83-160, off below 0.001 m as in every shipped configuration: cloud_down_res 0) ->
+ * fast_ground_filter -> classify_nground_pts.  The scan goes up once and the clouds stay on the device between the stages.  Not part of it: the
+ * semantic-mask filters (semantic_assisted), the adaptive parameter update (host arithmetic on the cloud sizes, :2416-2444). */
 typedef struct mulls_extract_params
 {
 	mulls_ground_params ground;
 	mulls_classify_params classify;
 	uint8_t apply_scanner_filter; /* extract_semantic_pts passes the same flag to fast_ground_filter as apply_grid_wise_outlier_filter: set ground.* yourself */
-	uint8_t reserved_[3];
-	float self_ring_radius; /* [1.75] */
-	float ghost_radius;		/* [20.0] */
-	float z_min;			/* -approx_scanner_height - 4.0: ghost points below it within ghost_radius go */
-	float z_min_min;		/* -approx_scanner_height + underground_thre: everything below it goes */
+	uint8_t apply_dist_filter;	  /* keep min_dist_used^2 < x^2 + y^2 < max_dist_used^2 (float range, double limits), ahead of everything else */
+	uint8_t reserved_[2];
+	float self_ring_radius;			/* [1.75] */
+	float ghost_radius;				/* [20.0] */
+	float z_min;					/* -approx_scanner_height - 4.0: ghost points below it within ghost_radius go */
+	float z_min_min;				/* -approx_scanner_height + underground_thre: everything below it goes */
+	float vf_downsample_resolution; /* [0.0] voxel edge in metres; < 0.001: pc_down = pc_raw */
+	double min_dist_used;			/* [1.0]  */
+	double max_dist_used;			/* [120.0] */
 } mulls_extract_params;
 
 void mulls_extract_default_params(mulls_extract_params *p);
 
 enum mulls_extract_cloud
 {
-	MULLS_EX_RAW = 0,		  /* pc_raw after the scanner filter (= pc_down: no voxel down-sampling) */
+	MULLS_EX_RAW = 0,		  /* pc_raw after the distance and scanner filters */
 	MULLS_EX_GROUND = 1,	  /* pc_ground */
 	MULLS_EX_GROUND_DOWN = 2, /* pc_ground_down */
 	MULLS_EX_UNGROUND = 3,	  /* pc_unground as classify_nground_pts leaves it (written only if its capacity holds the whole cloud) */
 	MULLS_EX_PILLAR = 4,	  /* ... followed by the nine clouds of enum mulls_classify_cloud in that order */
 	MULLS_EX_VERTEX = 12,
-	MULLS_EX_COUNT = 13
+	MULLS_EX_DOWN = 13, /* pc_down: pc_raw after voxel_downsample (the same cloud when that is off; ask for it with a capacity only when it is on) */
+	MULLS_EX_COUNT = 14
 };
 
 /* out[k] / cap[k] / n_out[k], k = enum mulls_extract_cloud: host buffers of 48-byte records, capacities in points, sizes (a cloud larger than its
@@ -438,6 +444,13 @@ enum mulls_extract_cloud
  * mulls_classify_nground on its `unground`. */
 int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *params, void *const out[MULLS_EX_COUNT],
 						   const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT]);
+
+/* CFilter::voxel_downsample (cfilter.hpp:83-160): one point per occupied voxel of edge voxel_size, voxels in increasing index
+ * ((vx * ny + vy) * nz + vz from the cloud's minimum corner), the point of a voxel being the one std::sort leaves first among that voxel's
+ * (voxel, index) pairs, exactly as upstream (bounding box and voxel indices on the device, that one sort on the host).  voxel_size < 0.001
+ * copies the cloud.  MULLS_E_INVALID for a non-finite coordinate, MULLS_E_UNSUPPORTED beyond 2^21 voxels along an axis or 500000 points.
+ * out: host buffer of cap 48-byte records; *n_out = size of pc_down (truncated to cap when larger). */
+int mulls_voxel_downsample(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, float voxel_size, void *out, uint32_t cap, uint32_t *n_out);
 
 /* ---- stage-level entry points (used by the parity tests; same kernels the driver launches) ---- */
 

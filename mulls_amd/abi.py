@@ -267,19 +267,25 @@ class ExtractParams(C.Structure):
         ("ground", GroundParams),
         ("classify", ClassifyParams),
         ("apply_scanner_filter", C.c_uint8),
-        ("reserved_", C.c_uint8 * 3),
+        ("apply_dist_filter", C.c_uint8),
+        ("reserved_", C.c_uint8 * 2),
         ("self_ring_radius", C.c_float),
         ("ghost_radius", C.c_float),
         ("z_min", C.c_float),
         ("z_min_min", C.c_float),
+        ("vf_downsample_resolution", C.c_float),
+        ("min_dist_used", C.c_double),
+        ("max_dist_used", C.c_double),
     ]
 
 
-EX_RAW, EX_GROUND, EX_GROUND_DOWN, EX_UNGROUND, EX_PILLAR, EX_VERTEX, EX_COUNT = 0, 1, 2, 3, 4, 12, 13
+EX_RAW, EX_GROUND, EX_GROUND_DOWN, EX_UNGROUND, EX_PILLAR, EX_VERTEX, EX_DOWN, EX_COUNT = 0, 1, 2, 3, 4, 12, 13, 14
 
 
-def extract_params(ground=None, classify=None, apply_scanner_filter=0, approx_scanner_height=2.0, underground_thre=-7.0):
-    """extract_semantic_pts' chain: scanner filter (cfilter.hpp:2338-2346) -> fast_ground_filter -> classify_nground_pts."""
+def extract_params(ground=None, classify=None, apply_scanner_filter=0, approx_scanner_height=2.0, underground_thre=-7.0, apply_dist_filter=0,
+                   min_dist_used=1.0, max_dist_used=120.0, vf_downsample_resolution=0.0):
+    """The frame front end: dist_filter (test/mulls_slam.cpp:359-360) -> scanner filter (cfilter.hpp:2338-2346) -> voxel_downsample ->
+    fast_ground_filter -> classify_nground_pts."""
     p = ExtractParams()
     p.ground = ground if ground is not None else ground_params()
     p.classify = classify if classify is not None else classify_params()
@@ -287,6 +293,9 @@ def extract_params(ground=None, classify=None, apply_scanner_filter=0, approx_sc
     p.self_ring_radius, p.ghost_radius = 1.75, 20.0
     p.z_min = np.float32(-np.float32(approx_scanner_height) - 4.0)
     p.z_min_min = np.float32(-np.float32(approx_scanner_height) + np.float32(underground_thre))
+    p.apply_dist_filter = apply_dist_filter
+    p.min_dist_used, p.max_dist_used = min_dist_used, max_dist_used
+    p.vf_downsample_resolution = vf_downsample_resolution
     return p
 
 

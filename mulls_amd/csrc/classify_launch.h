@@ -81,5 +81,5 @@ void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a);
 void launch_cl_nms_round(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt); // *round_cnt += points still undecided
 // keys[i] = normal[3] of record i
 void launch_cl_keys(hipStream_t st, const float4 *recs, uint32_t n, float *keys);
-// out[i] = in[perm[i]]
+// out[i] = in[perm[i]], whole 48-byte records
 void launch_cl_gather(hipStream_t st, const float4 *in, const uint32_t *perm, float4 *out, uint32_t n);

@@ -4,6 +4,8 @@
 // ground_random_down_down_rate-th point, or the ABI's seeded fixed-number selection: cfilter.hpp:1955-1968) and is taken on the way out.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -13,19 +15,9 @@
 #include "device_types.h"
 #include "map_launch.h"
 
-#include <hip/hip_vector_types.h>
+#include "classify_launch.h"
+#include "ground_launch.h"
 
-struct GfOut // head of the device-side state (k_ground.hip: GfState)
-{
-	uint32_t n_ground, n_unground, n_high, error;
-	uint32_t row, col;
-	float mean_height;
-	uint32_t n_cand;
-};
-int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mulls_ground_params &P, uint32_t *ids, uint16_t *cellof, uint8_t *code, float *d3v,
-						 float4 *ground, float4 *unground, void *aux);
-size_t ground_filter_aux_bytes(uint32_t n);
-void launch_scanner_mask(hipStream_t st, const float4 *pts, uint32_t n, float self_radius, float ghost_radius, float z_min_ghost, float z_min_global, uint8_t *mask);
 extern "C" __attribute__((visibility("hidden"))) int mulls_classify_impl(mulls_ctx *ctx, const void *pts, bool pts_on_device, uint32_t n_in, uint32_t stride, const mulls_classify_params *P,
 								   void *const out[MULLS_CL_COUNT], const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after,
 								   uint32_t *n_cloud_in_after);
@@ -60,11 +52,12 @@ extern "C"
 	}
 
 	// ---- shared by mulls_ground_filter and mulls_extract_features -------------------------------------------------------------------
-	struct GfArena // one device arena: scan | ground | unground | ids | d3v | cellof | code | state, counters, per-cell tables | (scanner filter:) scan copy, mask, scratch
+	struct GfArena // one device arena: scan | ground | unground | ids | d3v | cellof | code | state, counters, per-cell tables | (filters / voxels ahead:) scan copy, mask, scratch, voxel keys, order
 	{
-		size_t o_ground, o_unground, o_ids, o_d3, o_cell, o_code, o_aux, o_alt, o_mask, o_seg, total;
+		size_t o_ground, o_unground, o_ids, o_d3, o_cell, o_code, o_aux, o_alt, o_mask, o_seg, o_keys, o_perm, total;
 	};
-	static GfArena gf_layout(uint32_t n, bool scanner)
+	// prefilter: dist_filter / scanner_filter ahead of the ground filter; voxels: voxel_downsample ahead of it (either needs a second scan-sized buffer)
+	static GfArena gf_layout(uint32_t n, bool prefilter, bool voxels)
 	{
 		GfArena a;
 		const size_t rec = (size_t)n * MULLS_POINT_BYTES;
@@ -72,9 +65,11 @@ extern "C"
 		a.o_code = a.o_cell + (size_t)n * 2;
 		a.o_aux = (a.o_code + n + 255) & ~(size_t)255;
 		a.o_alt = (a.o_aux + ground_filter_aux_bytes(n) + 255) & ~(size_t)255;
-		a.o_mask = a.o_alt + (scanner ? rec : 0);
-		a.o_seg = (a.o_mask + (scanner ? n : 0) + 255) & ~(size_t)255;
-		a.total = a.o_seg + (scanner ? ((size_t)n / 4096 + 32) * 4 * 8 : 0);
+		a.o_mask = a.o_alt + (prefilter || voxels ? rec : 0);
+		a.o_seg = (a.o_mask + (prefilter ? n : 0) + 255) & ~(size_t)255;
+		a.o_keys = (a.o_seg + (prefilter ? ((size_t)n / 4096 + 32) * 4 * 8 : 0) + 255) & ~(size_t)255;
+		a.o_perm = a.o_keys + (voxels ? (size_t)n * 8 + 256 : 0);
+		a.total = a.o_perm + (voxels ? (size_t)n * 4 : 0);
 		return a;
 	}
 	static int gf_check(mulls_ctx *ctx, const mulls_ground_params *P, uint32_t n)
@@ -131,6 +126,81 @@ extern "C"
 		}
 		return MULLS_OK;
 	}
+	// CFilter::voxel_downsample (cfilter.hpp:83-160) on the n records at `in` (device): pc_down is gathered to `down` (device, room for n records),
+	// *n_down = its size.  Bounding box and voxel indices come from the device; the order of the (voxel, index) pairs is std::sort's on the host,
+	// as upstream's is: which point of a voxel comes first is decided by that sort (the comparison sees the voxel only, :42), and it depends on
+	// nothing but the indices' values and their count, so the same sort over the same indices picks the same points.  The stream is idle afterwards.
+	static int vox_run(mulls_ctx *ctx, const GfArena &a, const float4 *in, uint32_t n, float voxel_size, float4 *down, uint32_t *n_down)
+	{
+		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
+		hipStream_t st = ctx->stream;
+		unsigned long long *keys = reinterpret_cast<unsigned long long *>(base + a.o_keys);
+		uint32_t *box = reinterpret_cast<uint32_t *>(base + a.o_keys + (size_t)n * 8);
+		uint32_t *perm = reinterpret_cast<uint32_t *>(base + a.o_perm);
+		*n_down = 0;
+		if (n == 0)
+			return MULLS_OK;
+		uint32_t hb[7];
+		if (launch_vox_bbox(st, in, n, box) != 0)
+		{
+			ctx->err = "mulls_voxel_downsample: launch failed";
+			return MULLS_E_HIP;
+		}
+		HIPCHK(ctx, hipMemcpyAsync(hb, box, sizeof(hb), hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (hb[6])
+		{
+			ctx->err = "mulls_voxel_downsample: non-finite coordinate";
+			return MULLS_E_INVALID;
+		}
+		float min_p[3], max_p[3];
+		for (int k = 0; k < 3; k++)
+		{
+			const uint32_t lo = hb[k], hi = hb[3 + k]; // ordered keys back to floats
+			const uint32_t ul = (lo & 0x80000000u) ? (lo & 0x7fffffffu) : ~lo, uh = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
+			std::memcpy(&min_p[k], &ul, 4);
+			std::memcpy(&max_p[k], &uh, 4);
+		}
+		const float inverse_voxel_size = 1.0f / voxel_size;
+		const float gap_p[3] = {max_p[0] - min_p[0], max_p[1] - min_p[1], max_p[2] - min_p[2]};
+		for (int k = 0; k < 3; k++)
+			if (!(std::ceil((double)(gap_p[k] * inverse_voxel_size)) + 1 < 2097152.0))
+			{
+				ctx->err = "mulls_voxel_downsample: more than 2^21 voxels along an axis";
+				return MULLS_E_UNSUPPORTED;
+			}
+		const unsigned long long max_vy = (unsigned long long)(std::ceil(gap_p[1] * inverse_voxel_size) + 1);
+		const unsigned long long max_vz = (unsigned long long)(std::ceil(gap_p[2] * inverse_voxel_size) + 1);
+		launch_vox_keys(st, in, n, min_p, inverse_voxel_size, max_vy * max_vz, max_vz, keys);
+		std::vector<unsigned long long> hk(n);
+		HIPCHK(ctx, hipMemcpyAsync(hk.data(), keys, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		struct IdPair
+		{
+			unsigned long long voxel_idx;
+			int idx;
+			bool operator<(const IdPair &o) const { return voxel_idx < o.voxel_idx; }
+		};
+		std::vector<IdPair> id_pairs(n);
+		for (uint32_t i = 0; i < n; i++)
+			id_pairs[i].voxel_idx = hk[i], id_pairs[i].idx = (int)i;
+		std::sort(id_pairs.begin(), id_pairs.end());
+		std::vector<uint32_t> first;
+		first.reserve(n);
+		for (size_t b = 0; b < id_pairs.size();)
+		{
+			first.push_back((uint32_t)id_pairs[b].idx);
+			size_t c = b + 1;
+			while (c < id_pairs.size() && id_pairs[c].voxel_idx == id_pairs[b].voxel_idx)
+				c++;
+			b = c;
+		}
+		HIPCHK(ctx, hipMemcpyAsync(perm, first.data(), first.size() * 4, hipMemcpyHostToDevice, st));
+		launch_cl_gather(st, in, perm, down, (uint32_t)first.size()); // whole 48-byte records
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		*n_down = (uint32_t)first.size();
+		return MULLS_OK;
+	}
 	// cloud_ground (n_ground records at g) -> cloud_ground_down (cfilter.hpp:1955-1968), taken on the host from the downloaded cloud
 	static uint32_t gf_ground_down(const mulls_ground_params *P, const unsigned char *g, uint32_t n_ground, void *ground_down, uint32_t cap_ground_down)
 	{
@@ -173,7 +243,7 @@ extern "C"
 			return MULLS_OK; // (the reference divides by a zero sample count here)
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
-		const GfArena a = gf_layout(n, false);
+		const GfArena a = gf_layout(n, false, false);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
 		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
@@ -219,6 +289,58 @@ extern "C"
 		p->ghost_radius = 20.0f;
 		p->z_min = -2.0f - 4.0f;
 		p->z_min_min = -2.0f + -7.0f;
+		// test/mulls_slam.cpp:51-53 (apply_dist_filter false, min_dist_used 1.0, max_dist_used 120.0), :40 (cloud_down_res 0.0)
+		p->apply_dist_filter = 0;
+		p->min_dist_used = 1.0;
+		p->max_dist_used = 120.0;
+		p->vf_downsample_resolution = 0.0f;
+	}
+
+	int mulls_voxel_downsample(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, float voxel_size, void *out, uint32_t cap, uint32_t *n_out)
+	try
+	{
+		if (!ctx || !n_out || (n && !pts) || (cap && !out) || stride < MULLS_POINT_BYTES)
+			return MULLS_E_INVALID;
+		*n_out = 0;
+		if (voxel_size < 0.001) // `cloud_out = cloud_in` (:90-97)
+		{
+			*n_out = n;
+			for (uint32_t i = 0; i < std::min(n, cap); i++)
+				std::memcpy(static_cast<unsigned char *>(out) + (size_t)i * MULLS_POINT_BYTES, static_cast<const unsigned char *>(pts) + (size_t)i * stride, MULLS_POINT_BYTES);
+			return MULLS_OK;
+		}
+		if (n == 0)
+			return MULLS_OK;
+		if (n > 500000u)
+		{
+			ctx->err = "mulls_voxel_downsample: more than 500000 points in one scan";
+			return MULLS_E_UNSUPPORTED;
+		}
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		hipStream_t st = ctx->stream;
+		const GfArena a = gf_layout(n, false, true);
+		if (gf_reserve(ctx, a) != MULLS_OK)
+			return MULLS_E_HIP;
+		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
+		if (stride == MULLS_POINT_BYTES)
+			HIPCHK(ctx, hipMemcpyAsync(base + a.o_alt, pts, (size_t)n * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st));
+		else
+			HIPCHK(ctx, hipMemcpy2DAsync(base + a.o_alt, MULLS_POINT_BYTES, pts, stride, MULLS_POINT_BYTES, n, hipMemcpyHostToDevice, st));
+		uint32_t nd = 0;
+		const int rc = vox_run(ctx, a, reinterpret_cast<const float4 *>(base + a.o_alt), n, voxel_size, reinterpret_cast<float4 *>(base), &nd);
+		if (rc != MULLS_OK)
+			return rc;
+		*n_out = nd;
+		if (std::min(nd, cap))
+		{
+			HIPCHK(ctx, hipMemcpyAsync(out, base, (size_t)std::min(nd, cap) * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipStreamSynchronize(st));
+		}
+		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(ctx); // nothing is thrown across the ABI
 	}
 
 	int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n_in, uint32_t stride, const mulls_extract_params *X, void *const out[MULLS_EX_COUNT],
@@ -241,27 +363,34 @@ extern "C"
 			return MULLS_OK;
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
-		const bool scanner = X->apply_scanner_filter != 0;
-		const GfArena a = gf_layout(n_in, scanner);
+		const bool scanner = X->apply_scanner_filter != 0, dist = X->apply_dist_filter != 0, prefilter = scanner || dist;
+		const bool voxels = !(X->vf_downsample_resolution < 0.001); // voxel_downsample hands the cloud on below 0.001 m (:90-97)
+		const GfArena a = gf_layout(n_in, prefilter, voxels);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
 		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
 		const size_t rec_in = (size_t)n_in * MULLS_POINT_BYTES;
-		unsigned char *up = scanner ? base + a.o_alt : base; // the scanner filter compacts from the copy into the scan's place
+		// two scan-sized buffers (base, alt): every stage ahead of the ground filter reads one and writes the other
+		unsigned char *cur = (prefilter != voxels) ? base + a.o_alt : base, *other = (prefilter != voxels) ? base : base + a.o_alt;
 		if (stride == MULLS_POINT_BYTES)
-			HIPCHK(ctx, hipMemcpyAsync(up, scan, rec_in, hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemcpyAsync(cur, scan, rec_in, hipMemcpyHostToDevice, st));
 		else
-			HIPCHK(ctx, hipMemcpy2DAsync(up, MULLS_POINT_BYTES, scan, stride, MULLS_POINT_BYTES, n_in, hipMemcpyHostToDevice, st));
+			HIPCHK(ctx, hipMemcpy2DAsync(cur, MULLS_POINT_BYTES, scan, stride, MULLS_POINT_BYTES, n_in, hipMemcpyHostToDevice, st));
 		uint32_t n = n_in;
-		if (scanner)
+		if (prefilter)
 		{
-			// scanner_filter (cfilter.hpp:914-929): ego-vehicle ring and underground ghost points
+			// dist_filter (test/mulls_slam.cpp:359-360 -> cfilter.hpp:806-832), then scanner_filter (cfilter.hpp:2338-2346 -> :914-929)
 			uint32_t *counts = reinterpret_cast<uint32_t *>(base + a.o_seg);
-			launch_scanner_mask(st, reinterpret_cast<const float4 *>(up), n_in, X->self_ring_radius, X->ghost_radius, X->z_min, X->z_min_min, base + a.o_mask);
+			RawMaskArgs ma;
+			std::memset(&ma, 0, sizeof(ma));
+			ma.dist_on = dist, ma.scanner_on = scanner;
+			ma.dist_min_sq = X->min_dist_used * X->min_dist_used, ma.dist_max_sq = X->max_dist_used * X->max_dist_used;
+			ma.self_radius = X->self_ring_radius, ma.ghost_radius = X->ghost_radius, ma.z_min_ghost = X->z_min, ma.z_min_global = X->z_min_min;
+			launch_raw_mask(st, reinterpret_cast<const float4 *>(cur), n_in, ma, base + a.o_mask);
 			MapCompactArgs ca;
 			std::memset(&ca, 0, sizeof(ca));
-			ca.cloud[0].in = reinterpret_cast<const float4 *>(up);
-			ca.cloud[0].out = reinterpret_cast<float4 *>(base);
+			ca.cloud[0].in = reinterpret_cast<const float4 *>(cur);
+			ca.cloud[0].out = reinterpret_cast<float4 *>(other);
 			ca.cloud[0].mask = base + a.o_mask;
 			ca.cloud[0].n = n_in;
 			ca.out_n = counts;
@@ -271,15 +400,31 @@ extern "C"
 			HIPCHK(ctx, hipMemcpyAsync(c6, counts, sizeof(c6), hipMemcpyDeviceToHost, st));
 			HIPCHK(ctx, hipStreamSynchronize(st));
 			n = c6[0];
+			std::swap(cur, other);
 		}
 		n_out[MULLS_EX_RAW] = n;
+		n_out[MULLS_EX_DOWN] = n;
 		if (n == 0)
 			return MULLS_OK;
 		const uint32_t kr = std::min(n, cap[MULLS_EX_RAW]);
 		if (kr)
-			HIPCHK(ctx, hipMemcpyAsync(out[MULLS_EX_RAW], base, (size_t)kr * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipMemcpyAsync(out[MULLS_EX_RAW], cur, (size_t)kr * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, st));
+		if (voxels)
+		{
+			uint32_t nd = 0;
+			const int rcv = vox_run(ctx, a, reinterpret_cast<const float4 *>(cur), n, X->vf_downsample_resolution, reinterpret_cast<float4 *>(other), &nd);
+			if (rcv != MULLS_OK)
+				return rcv;
+			std::swap(cur, other);
+			n = nd;
+			n_out[MULLS_EX_DOWN] = n;
+		}
+		// cur == base here: one stage (or none) when exactly one of the two ran from alt, two stages from base
+		const uint32_t kd = std::min(n, cap[MULLS_EX_DOWN]);
+		if (kd)
+			HIPCHK(ctx, hipMemcpyAsync(out[MULLS_EX_DOWN], cur, (size_t)kd * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, st));
 		GfOut go;
-		const int rc = gf_run(ctx, a, reinterpret_cast<const float4 *>(base), n, P, go);
+		const int rc = gf_run(ctx, a, reinterpret_cast<const float4 *>(cur), n, P, go);
 		if (rc != MULLS_OK)
 			return rc;
 		std::vector<unsigned char> g((size_t)go.n_ground * MULLS_POINT_BYTES);

@@ -22,6 +22,7 @@
 
 #include "../../include/mulls_hip.h"
 #include "device_util.h"
+#include "ground_launch.h"
 
 #define MULLS_GF_BLOCK 256
 #define MULLS_GF_SEG 1024u // points per segment (one wave walks a segment in 16 steps of 64)
@@ -719,23 +720,97 @@ int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mu
 	return 0;
 }
 
-// CFilter::scanner_filter (cfilter.hpp:914-929): the points of the ego vehicle's ring and the underground ghost points near the scanner go.
+// The per-point filters ahead of the ground filter as one keep mask (both keep the order, so their sequence is the AND of their tests):
+// CFilter::dist_filter(cloud, xy_dist_min, xy_dist_max) (cfilter.hpp:806-832: float range expression widened to double, double limits) and
+// CFilter::scanner_filter (cfilter.hpp:914-929: the ego vehicle's ring and the underground ghost points near the scanner).
 // mask[i] = 1 keeps point i; the stable compaction is map_kernels.hip's.
-__global__ __launch_bounds__(256) void k_scanner_mask(const float4 *__restrict__ pts, uint32_t n, float self_radius, float ghost_radius, float z_min_ghost,
-													   float z_min_global, uint8_t *__restrict__ mask)
+__global__ __launch_bounds__(256) void k_raw_mask(const float4 *__restrict__ pts, uint32_t n, RawMaskArgs a, uint8_t *__restrict__ mask)
 {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n)
 		return;
 	const float4 p = pts[(size_t)i * 3];
 	const float dis_square = p.x * p.x + p.y * p.y;
-	bool keep = false;
-	if (dis_square > self_radius * self_radius && p.z > z_min_global)
-		keep = dis_square > ghost_radius * ghost_radius || p.z > z_min_ghost;
+	bool keep = true;
+	if (a.dist_on)
+		keep = (double)dis_square < a.dist_max_sq && (double)dis_square > a.dist_min_sq;
+	if (a.scanner_on)
+	{
+		bool k2 = false;
+		if (dis_square > a.self_radius * a.self_radius && p.z > a.z_min_global)
+			k2 = dis_square > a.ghost_radius * a.ghost_radius || p.z > a.z_min_ghost;
+		keep = keep && k2;
+	}
 	mask[i] = keep ? 1 : 0;
 }
-void launch_scanner_mask(hipStream_t st, const float4 *pts, uint32_t n, float self_radius, float ghost_radius, float z_min_ghost, float z_min_global, uint8_t *mask)
+void launch_raw_mask(hipStream_t st, const float4 *pts, uint32_t n, const RawMaskArgs &a, uint8_t *mask)
 {
 	if (n)
-		hipLaunchKernelGGL(k_scanner_mask, dim3((n + 255u) / 256u), dim3(256), 0, st, pts, n, self_radius, ghost_radius, z_min_ghost, z_min_global, mask);
+		hipLaunchKernelGGL(k_raw_mask, dim3((n + 255u) / 256u), dim3(256), 0, st, pts, n, a, mask);
+}
+
+// CFilter::voxel_downsample (cfilter.hpp:83-160), device part: pcl::getMinMax3D as ordered keys (box[0..2] min, box[3..5] max, box[6] != 0: a
+// non-finite coordinate) and the voxel index of every point (:128-139: float difference times the float inverse size, floor, 64-bit index).
+__global__ __launch_bounds__(256) void k_vox_bbox(const float4 *__restrict__ pts, uint32_t n, uint32_t *__restrict__ box)
+{
+	float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+	uint32_t bad = 0;
+	for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u)
+	{
+		const float4 p = pts[(size_t)j * 3];
+		const float v[3] = {p.x, p.y, p.z};
+		for (int k = 0; k < 3; k++)
+		{
+			bad |= !(fabsf(v[k]) <= 3.402823466e+38f);
+			mn[k] = v[k] < mn[k] ? v[k] : mn[k];
+			mx[k] = v[k] > mx[k] ? v[k] : mx[k];
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		for (int k = 0; k < 3; k++)
+		{
+			const float a = __shfl_down(mn[k], off), b = __shfl_down(mx[k], off);
+			mn[k] = a < mn[k] ? a : mn[k];
+			mx[k] = b > mx[k] ? b : mx[k];
+		}
+		bad |= __shfl_down(bad, off);
+	}
+	if ((threadIdx.x & 63u) == 0)
+	{
+		for (int k = 0; k < 3; k++)
+		{
+			atomicMin(&box[k], f2ord(mn[k]));
+			atomicMax(&box[3 + k], f2ord(mx[k]));
+		}
+		if (bad)
+			atomicOr(&box[6], 1u);
+	}
+}
+__global__ __launch_bounds__(256) void k_vox_keys(const float4 *__restrict__ pts, uint32_t n, float min_x, float min_y, float min_z, float inverse_voxel_size,
+												   unsigned long long mul_vx, unsigned long long mul_vy, unsigned long long *__restrict__ keys)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n)
+		return;
+	const float4 p = pts[(size_t)i * 3];
+	const unsigned long long vx = (unsigned long long)floorf((p.x - min_x) * inverse_voxel_size);
+	const unsigned long long vy = (unsigned long long)floorf((p.y - min_y) * inverse_voxel_size);
+	const unsigned long long vz = (unsigned long long)floorf((p.z - min_z) * inverse_voxel_size);
+	keys[i] = vx * mul_vx + vy * mul_vy + vz;
+}
+int launch_vox_bbox(hipStream_t st, const float4 *pts, uint32_t n, uint32_t *box)
+{
+	static const uint32_t box0[7] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u};
+	if (hipMemcpyAsync(box, box0, sizeof(box0), hipMemcpyHostToDevice, st) != hipSuccess)
+		return -1;
+	if (n)
+		hipLaunchKernelGGL(k_vox_bbox, dim3(std::min<uint32_t>((n + 255u) / 256u, 128u)), dim3(256), 0, st, pts, n, box);
+	return 0;
+}
+void launch_vox_keys(hipStream_t st, const float4 *pts, uint32_t n, const float min_p[3], float inverse_voxel_size, unsigned long long mul_vx,
+					 unsigned long long mul_vy, unsigned long long *keys)
+{
+	if (n)
+		hipLaunchKernelGGL(k_vox_keys, dim3((n + 255u) / 256u), dim3(256), 0, st, pts, n, min_p[0], min_p[1], min_p[2], inverse_voxel_size, mul_vx, mul_vy, keys);
 }

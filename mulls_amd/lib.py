@@ -93,7 +93,7 @@ EXPORTS = [
     "mulls_icp_4dof_global", "mulls_map_default_params", "mulls_map_create", "mulls_map_destroy", "mulls_map_set", "mulls_map_update",
     "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
     "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
-    "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features",
+    "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features", "mulls_voxel_downsample",
 ]
 
 
@@ -243,7 +243,7 @@ class Context:
         return (res, after[: n_after.value].copy()) if with_cloud_in else res
 
     def extract_features(self, scan, params):
-        """CFilter::extract_semantic_pts' chain on the device in one call.  Returns the thirteen clouds of enum mulls_extract_cloud as (n, 48) uint8 arrays."""
+        """CFilter::extract_semantic_pts' chain on the device in one call.  Returns the clouds of enum mulls_extract_cloud as (n, 48) uint8 arrays."""
         raw_in = abi.records(scan)
         n = len(raw_in)
         if getattr(self, "_ex_cap", 0) < n:  # receive buffers kept between calls (fresh pages cost more than the transfers)
@@ -252,15 +252,31 @@ class Context:
         outs = self._ex_out
         out_p = (C.c_void_p * abi.EX_COUNT)(*[o.ctypes.data for o in outs])
         cap = (C.c_uint32 * abi.EX_COUNT)(*([n] * abi.EX_COUNT))
-        if not params.apply_scanner_filter:
+        filtered = bool(params.apply_scanner_filter or params.apply_dist_filter)
+        voxels = not (params.vf_downsample_resolution < 0.001)
+        if not filtered:
             cap[abi.EX_RAW] = 0  # pc_raw is the scan itself: not sent back
+        if not voxels:
+            cap[abi.EX_DOWN] = 0  # pc_down is pc_raw
         nout = (C.c_uint32 * abi.EX_COUNT)()
         self._check(self.lib.mulls_extract_features(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.byref(params), out_p, cap, nout),
                     "mulls_extract_features")
         res = [outs[k][: nout[k]].copy() for k in range(abi.EX_COUNT)]
-        if not params.apply_scanner_filter:
+        if not filtered:
             res[abi.EX_RAW] = raw_in
+        if not voxels:
+            res[abi.EX_DOWN] = res[abi.EX_RAW]
         return res
+
+    def voxel_downsample(self, pts, voxel_size):
+        """CFilter::voxel_downsample (cfilter.hpp:83-160).  Returns pc_down as (n, 48) uint8 records."""
+        raw_in = abi.records(pts)
+        n = len(raw_in)
+        out = np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8)
+        n_out = C.c_uint32(0)
+        self._check(self.lib.mulls_voxel_downsample(self.h, raw_in.ctypes.data_as(C.c_void_p), n, abi.POINT_BYTES, C.c_float(voxel_size),
+                                                    out.ctypes.data_as(C.c_void_p), n, C.byref(n_out)), "mulls_voxel_downsample")
+        return out[: n_out.value].copy()
 
     # --- stage-level entry points --------------------------------------------------------------------------------
     def transform(self, pts, T):

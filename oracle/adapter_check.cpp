@@ -167,25 +167,30 @@ int main(int argc, char **argv)
 			}
 			printf("]}\n");
 		}
-		// the same chain through its one entry point, extract_semantic_pts, with the scanner filter on: the reference member vs the bridge, on cloudblocks
-		for (int w = 0; w < 2; w++)
+		// the same chain through its one entry point, extract_semantic_pts, with the scanner filter on: the reference member vs the bridge, on
+		// cloudblocks; a second time with a voxel grid ahead of the ground filter, a high non-ground down-sampling rate and the adaptive parameter
+		// update (which then lowers that rate: fewer than 200 facade + pillar points come out)
+		for (int w = 0; w < 4; w++)
 		{
 			lo::cloudblock_Ptr blk(new lo::cloudblock_t());
 			*blk->pc_raw = *scan;
-			int gdr = 10, ndr = 3;
-			if (w == 0)
+			const bool second = w >= 2;
+			int gdr = 10, ndr = second ? 20 : 3;
+			const float vox = second ? 0.08f : 0.0f, thre_down = 0.75f;
+			if (w % 2 == 0)
 			{
 				lo::CFilter<Point_T> cf;
-				cf.extract_semantic_pts(blk, 0.0f, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, 0.75f, 0.75f, false, 0, 15.0f, 0, 2.0f, false, true, false, 2, 8, 0, 2,
+				cf.extract_semantic_pts(blk, vox, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, thre_down, thre_down, false, 0, 15.0f, 0, 2.0f, second, true, false, 2, 8, 0, 2,
 										8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f, false, false, 0.0f, 0.0f);
 			}
 			else
-				lo::hip::extract_semantic_pts<Point_T>(blk, 0.0f, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, 0.75f, 0.75f, false, 0, 15.0f, 0, 2.0f, false, true, false, 2,
+				lo::hip::extract_semantic_pts<Point_T>(blk, vox, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, thre_down, thre_down, false, 0, 15.0f, 0, 2.0f, second, true, false, 2,
 													   8, 0, 2, 8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f,
 													   false, false, 0.0f, 0.0f);
 			pcTPtr all[15] = {blk->pc_raw,	  blk->pc_down,	 blk->pc_sketch, blk->pc_ground,	  blk->pc_ground_down, blk->pc_unground,	blk->pc_pillar,	   blk->pc_beam,
 							  blk->pc_facade, blk->pc_roof, blk->pc_pillar_down, blk->pc_beam_down, blk->pc_facade_down, blk->pc_roof_down, blk->pc_vertex};
-			printf("{\"who\": \"%s\", \"down_feature_point_num\": %d, \"sizes\": [", w == 0 ? "reference_block" : "hip_block", blk->down_feature_point_num);
+			static const char *who[4] = {"reference_block", "hip_block", "reference_block_voxels", "hip_block_voxels"};
+			printf("{\"who\": \"%s\", \"down_feature_point_num\": %d, \"rates\": [%d, %d], \"sizes\": [", who[w], blk->down_feature_point_num, gdr, ndr);
 			for (int k = 0; k < 15; k++)
 				printf("%s%zu", k ? ", " : "", all[k]->points.size());
 			printf("], \"sums\": [");

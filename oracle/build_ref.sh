@@ -46,6 +46,7 @@ extract cfilter.hpp 551 602 "bool xy_normal_balanced_downsample" cfilter_body.in
 extract cfilter.hpp 606 628 "bool random_downsample_pcl" cfilter_body.inc
 extract cfilter.hpp 685 712 "bool random_downsample_pcl(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 713 728 "bool random_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
+extract cfilter.hpp 806 832 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 834 872 "bool dist_filter(typename pcl::PointCloud<PointT>::Ptr &cloud_in_out," cfilter_body.inc
 extract cfilter.hpp 914 929 "bool scanner_filter" cfilter_body.inc
 extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc

@@ -2507,6 +2507,95 @@ extern "C"
 		*n_out = w;
 		return MULLS_OK;
 	}
+	// CFilter::dist_filter(cloud, xy_dist_min, xy_dist_max) (cfilter.hpp:806-832), the pass test/mulls_slam.cpp:359-360 / :404-405 runs on pc_raw
+	// under --apply_dist_filter: the squared horizontal range is a float expression widened to double, the limits are doubles
+	int mulls_oracle_dist_filter(const void *pts, uint32_t n, uint32_t stride, double xy_dist_min, double xy_dist_max, void *out, uint32_t cap, uint32_t *n_out)
+	{
+		uint32_t w = 0;
+		for (uint32_t i = 0; i < n; i++)
+		{
+			Pt p;
+			std::memcpy(&p, (const unsigned char *)pts + (size_t)i * stride, sizeof(Pt));
+			double dis_square = p.x * p.x + p.y * p.y;
+			if (dis_square < xy_dist_max * xy_dist_max && dis_square > xy_dist_min * xy_dist_min)
+			{
+				if (w < cap)
+					std::memcpy((unsigned char *)out + (size_t)w * sizeof(Pt), &p, sizeof(Pt));
+				w++;
+			}
+		}
+		*n_out = w;
+		return MULLS_OK;
+	}
+	// CFilter::voxel_downsample (cfilter.hpp:83-160): one point per occupied voxel, the first of its voxel in the order std::sort leaves the
+	// (voxel, index) pairs in (the comparison looks at the voxel only, :42), voxels in increasing index.  Below 0.001 m the cloud is handed on as
+	// it is (:90-97).  Beyond 2^21 voxels along an axis the call is refused (the reference's index arithmetic would start to depend on whether
+	// ceil / floor resolve to the float or the double overload, and the 64-bit index could wrap).
+	int mulls_oracle_voxel_downsample(const void *pts, uint32_t n, uint32_t stride, float voxel_size, void *out, uint32_t cap, uint32_t *n_out)
+	{
+		std::vector<Pt> in(n);
+		for (uint32_t i = 0; i < n; i++)
+			std::memcpy(&in[i], (const unsigned char *)pts + (size_t)i * stride, sizeof(Pt));
+		*n_out = 0;
+		if (voxel_size < 0.001)
+		{
+			*n_out = n;
+			if (std::min(n, cap))
+				std::memcpy(out, in.data(), (size_t)std::min(n, cap) * sizeof(Pt));
+			return MULLS_OK;
+		}
+		if (n == 0)
+			return MULLS_OK;
+		float inverse_voxel_size = 1.0f / voxel_size;
+		float min_p[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, max_p[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}; // pcl::getMinMax3D
+		for (uint32_t i = 0; i < n; i++)
+		{
+			const float v[3] = {in[i].x, in[i].y, in[i].z};
+			if (!std::isfinite(v[0]) || !std::isfinite(v[1]) || !std::isfinite(v[2]))
+				return MULLS_E_INVALID;
+			for (int k = 0; k < 3; k++)
+				min_p[k] = std::min(min_p[k], v[k]), max_p[k] = std::max(max_p[k], v[k]);
+		}
+		float gap_p[3] = {max_p[0] - min_p[0], max_p[1] - min_p[1], max_p[2] - min_p[2]};
+		for (int k = 0; k < 3; k++)
+			if (!(std::ceil((double)(gap_p[k] * inverse_voxel_size)) + 1 < 2097152.0))
+				return MULLS_E_UNSUPPORTED;
+		unsigned long long max_vy = ceil(gap_p[1] * inverse_voxel_size) + 1;
+		unsigned long long max_vz = ceil(gap_p[2] * inverse_voxel_size) + 1;
+		unsigned long long mul_vx = max_vy * max_vz;
+		unsigned long long mul_vy = max_vz;
+		unsigned long long mul_vz = 1;
+		struct IdPair
+		{
+			unsigned long long voxel_idx;
+			int idx;
+			bool operator<(const IdPair &o) const { return voxel_idx < o.voxel_idx; }
+		};
+		std::vector<IdPair> id_pairs(n);
+		for (uint32_t i = 0; i < n; i++)
+		{
+			unsigned long long vx = floor((in[i].x - min_p[0]) * inverse_voxel_size);
+			unsigned long long vy = floor((in[i].y - min_p[1]) * inverse_voxel_size);
+			unsigned long long vz = floor((in[i].z - min_p[2]) * inverse_voxel_size);
+			id_pairs[i].idx = (int)i;
+			id_pairs[i].voxel_idx = vx * mul_vx + vy * mul_vy + vz * mul_vz;
+		}
+		std::sort(id_pairs.begin(), id_pairs.end());
+		uint32_t w = 0;
+		size_t begin_id = 0;
+		while (begin_id < id_pairs.size())
+		{
+			if (w < cap)
+				std::memcpy((unsigned char *)out + (size_t)w * sizeof(Pt), &in[id_pairs[begin_id].idx], sizeof(Pt));
+			w++;
+			size_t compare_id = begin_id + 1;
+			while (compare_id < id_pairs.size() && id_pairs[begin_id].voxel_idx == id_pairs[compare_id].voxel_idx)
+				compare_id++;
+			begin_id = compare_id;
+		}
+		*n_out = w;
+		return MULLS_OK;
+	}
 	void mulls_oracle_classify_default_params(mulls_classify_params *p)
 	{
 		std::memset(p, 0, sizeof(*p));

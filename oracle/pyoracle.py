@@ -227,11 +227,36 @@ def scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global, fn
     return out[: n_out.value].copy()
 
 
+def _filter_call(f, pts, *args):
+    raw_in = abi.records(pts)
+    n = len(raw_in)
+    out = np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8)
+    n_out = C.c_uint32(0)
+    f.restype = C.c_int
+    rc = f(raw_in.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(abi.POINT_BYTES), *args, out.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError("%s returned %d" % (getattr(f, "__name__", "filter"), rc))
+    return out[: n_out.value].copy()
+
+
+def dist_filter(pts, xy_dist_min, xy_dist_max, fn=None):
+    """CFilter::dist_filter(cloud, xy_dist_min, xy_dist_max) (cfilter.hpp:806-832).  Returns the kept points as (n, 48) uint8 records."""
+    return _filter_call(fn if fn is not None else lib().mulls_oracle_dist_filter, pts, C.c_double(xy_dist_min), C.c_double(xy_dist_max))
+
+
+def voxel_downsample(pts, voxel_size, fn=None):
+    """CFilter::voxel_downsample (cfilter.hpp:83-160).  Returns pc_down as (n, 48) uint8 records."""
+    return _filter_call(fn if fn is not None else lib().mulls_oracle_voxel_downsample, pts, C.c_float(voxel_size))
+
+
 def extract_features(scan, X):
-    """The chain mulls_extract_features runs, stage by stage in the oracle: the thirteen clouds of enum mulls_extract_cloud."""
+    """The chain mulls_extract_features runs, stage by stage in the oracle: the clouds of enum mulls_extract_cloud."""
     raw = abi.records(scan)
+    if X.apply_dist_filter:
+        raw = dist_filter(raw, X.min_dist_used, X.max_dist_used)
     if X.apply_scanner_filter:
         raw = scanner_filter(raw, X.self_ring_radius, X.ghost_radius, X.z_min, X.z_min_min)
-    g, gd, ung = ground_filter(abi.points_of(raw), X.ground) if len(raw) else (raw[:0], raw[:0], raw[:0])
+    down = voxel_downsample(raw, X.vf_downsample_resolution)
+    g, gd, ung = ground_filter(abi.points_of(down), X.ground) if len(down) else (down[:0], down[:0], down[:0])
     c, after = classify_nground(ung, X.classify)
-    return [raw, g, gd, after] + c
+    return [raw, g, gd, after] + c + [down]

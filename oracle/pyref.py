@@ -81,3 +81,17 @@ def scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global):
     from oracle import pyoracle
 
     return pyoracle.scanner_filter(pts, self_radius, ghost_radius, z_min_ghost, z_min_global, fn=lib().mulls_ref_scanner_filter)
+
+
+def dist_filter(pts, xy_dist_min, xy_dist_max):
+    """CFilter::dist_filter(cloud, xy_dist_min, xy_dist_max), the reference's own lines (cfilter.hpp:806-832)."""
+    from oracle import pyoracle
+
+    return pyoracle.dist_filter(pts, xy_dist_min, xy_dist_max, fn=lib().mulls_ref_dist_filter)
+
+
+def voxel_downsample(pts, voxel_size):
+    """CFilter::voxel_downsample, the reference's own lines (cfilter.hpp:83-160)."""
+    from oracle import pyoracle
+
+    return pyoracle.voxel_downsample(pts, voxel_size, fn=lib().mulls_ref_voxel_downsample)

@@ -321,3 +321,35 @@ extern "C" int mulls_ref_scanner_filter(const void *pts, uint32_t n, uint32_t st
 		std::memcpy(out, in->points.data(), m * sizeof(Point_T));
 	return 0;
 }
+
+// CFilter::dist_filter(cloud, xy_dist_min, xy_dist_max), the reference's own lines (cfilter.hpp:806-832)
+extern "C" int mulls_ref_dist_filter(const void *pts, uint32_t n, uint32_t stride, double xy_dist_min, double xy_dist_max, void *out, uint32_t cap, uint32_t *n_out)
+{
+	mulls_cloud c;
+	c.pts = pts, c.n = n, c.stride = stride;
+	pcTPtr in(new pcT());
+	fill_cloud(c, in);
+	lo::CFilter<Point_T> cf;
+	cf.dist_filter(in, xy_dist_min, xy_dist_max);
+	*n_out = (uint32_t)in->points.size();
+	const size_t m = std::min<size_t>(in->points.size(), cap);
+	if (m && out)
+		std::memcpy(out, in->points.data(), m * sizeof(Point_T));
+	return 0;
+}
+
+// CFilter::voxel_downsample, the reference's own lines (cfilter.hpp:83-160)
+extern "C" int mulls_ref_voxel_downsample(const void *pts, uint32_t n, uint32_t stride, float voxel_size, void *out, uint32_t cap, uint32_t *n_out)
+{
+	mulls_cloud c;
+	c.pts = pts, c.n = n, c.stride = stride;
+	pcTPtr in(new pcT()), down(new pcT());
+	fill_cloud(c, in);
+	lo::CFilter<Point_T> cf;
+	cf.voxel_downsample(in, down, voxel_size);
+	*n_out = (uint32_t)down->points.size();
+	const size_t m = std::min<size_t>(down->points.size(), cap);
+	if (m && out)
+		std::memcpy(out, down->points.data(), m * sizeof(Point_T));
+	return 0;
+}

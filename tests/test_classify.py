@@ -289,6 +289,14 @@ def test_mulls_reg_tool_on_pcd_files(tmp_path):
     assert dt < 0.05 and dr < 3e-3, (dt, dr)
     moved = lib.read_pcd(out)
     assert len(moved) == len(lib.read_pcd(paths[source - 1]))
+    # the same pair through 10 cm voxels (cloud_1_down_res / cloud_2_down_res): the written cloud is the source's pc_down
+    res_v, source_v = tool.main(["--point_cloud_1_path", paths[0], "--point_cloud_2_path", paths[1], "--output_point_cloud_path", out, "--is_global_reg=false",
+                                 "--pca_neighbor_count=50", "--gf_in_grid_h_thre=0.25", "--gf_neigh_grid_h_thre=1.2", "--linearity_thre=0.65",
+                                 "--planarity_thre=0.65", "--corr_dis_thre=3.0", "--reg_max_iter_num=10", "--cloud_1_down_res=0.1", "--cloud_2_down_res=0.1"])
+    assert res_v.code == 1
+    dt, dr = synth.pose_error(res_v.T_matrix(), T_12 if source_v == 2 else np.linalg.inv(T_12))
+    assert dt < 0.08 and dr < 5e-3, (dt, dr)
+    assert 1000 < len(lib.read_pcd(out)) < len(lib.read_pcd(paths[source_v - 1]))
 
 
 def with_ego_and_ghost_points(scan, seed=0):
@@ -312,6 +320,56 @@ def extract_cases():
                                      unground_down_fixed_num=15000, pillar_down_fixed_num=200, facade_down_fixed_num=600, beam_down_fixed_num=100, roof_down_fixed_num=50,
                                      beam_height_max=0.5, rng_seed=3),
         apply_scanner_filter=1)
+    # lo_gflag_list_64.txt:12-14 (apply_dist_filter, min_dist_used 1.5) with a shorter range so that both limits bite on the synthetic scene
+    yield "dist-filter", with_ego_and_ghost_points(raw_scan(17, n_beams=48, n_az=1500)), abi.extract_params(
+        classify=abi.classify_params(neighbor_k=30), apply_scanner_filter=1, apply_dist_filter=1, min_dist_used=1.5, max_dist_used=28.0)
+    yield "dist-filter-only", raw_scan(18, n_beams=32, n_az=1200), abi.extract_params(
+        classify=abi.classify_params(neighbor_k=30), apply_dist_filter=1, min_dist_used=3.0, max_dist_used=25.0)
+    yield "voxels", raw_scan(19, n_beams=64, n_az=1500), abi.extract_params(classify=abi.classify_params(neighbor_k=30), vf_downsample_resolution=0.1)
+    yield "all-three", with_ego_and_ghost_points(raw_scan(20)), abi.extract_params(
+        classify=abi.classify_params(neighbor_k=30), apply_scanner_filter=1, apply_dist_filter=1, min_dist_used=1.5, max_dist_used=30.0,
+        vf_downsample_resolution=0.06)
+
+
+def test_dist_filter_and_voxel_downsample_oracle_equals_reference_lines():
+    """CFilter::dist_filter (cfilter.hpp:806-832) and CFilter::voxel_downsample (:83-160) of the oracle against the reference's own lines; the
+    voxel grid's properties hold whatever std::sort does with equal voxels."""
+    scan = with_ego_and_ghost_points(raw_scan(16))
+    recs = abi.records(scan)
+    xyz = abi.points_of(recs)
+    r2 = xyz["x"].astype(np.float32) * xyz["x"].astype(np.float32) + xyz["y"].astype(np.float32) * xyz["y"].astype(np.float32)
+    for lo, hi in ((1.5, 120.0), (2.0, 25.0), (0.0, 10.0)):
+        a = pyoracle.dist_filter(scan, lo, hi)
+        keep = (r2.astype(np.float64) < hi * hi) & (r2.astype(np.float64) > lo * lo)
+        assert np.array_equal(a, recs[keep])
+        if pyref.available():
+            assert np.array_equal(a, pyref.dist_filter(scan, lo, hi))
+    for v in (0.0005, 0.05, 0.3, 2.5):
+        a = pyoracle.voxel_downsample(scan, v)
+        if pyref.available():
+            assert np.array_equal(a, pyref.voxel_downsample(scan, v))
+        if v < 0.001:
+            assert np.array_equal(a, recs)
+            continue
+        # one point per occupied voxel, every one a record of the scan, voxels in increasing index
+        p = abi.points_of(a)
+        mn = np.array([xyz[c].min() for c in "xyz"], np.float32)
+        inv = np.float32(1.0) / np.float32(v)
+        def vox(q):
+            return np.stack([np.floor((q[c].astype(np.float32) - mn[i]) * inv).astype(np.int64) for i, c in enumerate("xyz")], 1)
+        gap = np.array([xyz[c].max() for c in "xyz"], np.float32) - mn
+        dims = np.ceil(gap * inv).astype(np.int64) + 1
+        def key(vv):
+            return (vv[:, 0] * dims[1] + vv[:, 1]) * dims[2] + vv[:, 2]
+        ka, ks = key(vox(p)), key(vox(xyz))
+        assert np.all(np.diff(ka) > 0) and np.array_equal(ka, np.unique(ks))
+        have = set(map(bytes, recs))
+        assert all(bytes(r) in have for r in a[:: max(1, len(a) // 500)])
+    with pytest.raises(RuntimeError):
+        bad = abi.as_points(scan).copy()
+        bad["x"][5] = np.nan
+        pyoracle.voxel_downsample(bad, 0.2)
+    assert len(pyoracle.voxel_downsample(recs[:0], 0.2)) == 0 and len(pyoracle.voxel_downsample(recs[:1], 0.2)) == 1
 
 
 def test_scanner_filter_oracle_equals_reference_lines():
@@ -327,7 +385,8 @@ def test_scanner_filter_oracle_equals_reference_lines():
 @pytest.mark.gpu
 def test_extract_features_equals_the_stages(ctx_auto):
     """mulls_extract_features (scanner filter -> ground filter -> classes, the clouds staying on the device, the fixed-number thinning of the
-    non-ground cloud applied there) against the same chain stage by stage in the oracle: thirteen clouds, byte for byte."""
+    non-ground cloud applied there; with the distance filter and the voxel grid ahead of it in some cases) against the same chain stage by
+    stage in the oracle: every cloud of enum mulls_extract_cloud, byte for byte."""
     for name, scan, X in extract_cases():
         a = pyoracle.extract_features(scan, X)
         b = ctx_auto.extract_features(scan, X)
@@ -335,8 +394,48 @@ def test_extract_features_equals_the_stages(ctx_auto):
             assert a[k].shape == b[k].shape, (name, k, a[k].shape, b[k].shape)
             assert np.array_equal(a[k], b[k]), (name, k)
         assert len(a[abi.EX_GROUND]) > 1000 and len(a[abi.EX_PILLAR + abi.CL_FACADE]) > 1000
-        if X.apply_scanner_filter:
+        if name == "kitti-like":
             assert len(a[abi.EX_RAW]) < len(scan) and len(a[abi.EX_UNGROUND]) == 15000
+        if X.apply_dist_filter or X.apply_scanner_filter:
+            assert len(a[abi.EX_RAW]) < len(scan)
+        if X.vf_downsample_resolution >= 0.001:
+            assert 1000 < len(a[abi.EX_DOWN]) < len(a[abi.EX_RAW])
+        else:
+            assert np.array_equal(a[abi.EX_DOWN], a[abi.EX_RAW])
+
+
+@pytest.mark.gpu
+def test_device_voxel_downsample(ctx_auto):
+    """mulls_voxel_downsample against the oracle byte for byte: voxel sizes from "nearly every point its own voxel" to a handful of voxels (long
+    runs of equal indices in the sort), a cloud with one point, an empty one, a stride with padding, truncation, and the refusals."""
+    import ctypes as C
+
+    scan = raw_scan(21)
+    for v in (0.0005, 0.02, 0.1, 0.4, 3.0, 40.0):
+        a = pyoracle.voxel_downsample(scan, v)
+        b = ctx_auto.voxel_downsample(scan, v)
+        assert np.array_equal(a, b), v
+    small = raw_scan(22, n_beams=4, n_az=50)
+    for m in (0, 1, 2, 17, len(small)):
+        assert np.array_equal(pyoracle.voxel_downsample(small[:m], 0.5), ctx_auto.voxel_downsample(small[:m], 0.5)), m
+    recs = abi.records(small)
+    wide = np.zeros((len(recs), 64), np.uint8)
+    wide[:, :48] = recs
+    ref = pyoracle.voxel_downsample(small, 0.5)
+    out = np.zeros((len(recs), 48), np.uint8)
+    n_out = C.c_uint32(0)
+    rc = ctx_auto.lib.mulls_voxel_downsample(ctx_auto.h, wide.ctypes.data_as(C.c_void_p), len(recs), 64, C.c_float(0.5), out.ctypes.data_as(C.c_void_p), 5, C.byref(n_out))
+    assert rc == 0 and n_out.value == len(ref) and np.array_equal(out[:5], ref[:5]) and not out[5:].any()
+    bad = abi.as_points(small).copy()
+    bad["z"][3] = np.inf
+    with pytest.raises(RuntimeError):
+        ctx_auto.voxel_downsample(bad, 0.5)
+    far = abi.as_points(small).copy()
+    far["x"][0] = 3.0e6
+    with pytest.raises(RuntimeError):
+        ctx_auto.voxel_downsample(far, 0.5)
+    with pytest.raises(RuntimeError):
+        pyoracle.voxel_downsample(far, 0.5)
 
 
 @pytest.mark.gpu

@@ -108,3 +108,10 @@ def test_adapter_feature_extraction_matches_reference_members():
     assert refb["sizes"] == hipb["sizes"] and refb["sums"] == hipb["sums"] and refb["down_feature_point_num"] == hipb["down_feature_point_num"] > 0
     assert refb["sizes"][0] == len(scan) - 1200 and refb["sizes"][1] == refb["sizes"][0] and 0 < refb["sizes"][2] <= 1024  # pc_raw filtered, pc_down = pc_raw, pc_sketch
     assert refb["sizes"][3] > 1000 and refb["sizes"][8] > 1000 and sum(refb["sizes"][10:14]) > 100  # ground, facade, the *_down clouds
+    # ... and with voxel_downsample ahead of the ground filter and the adaptive parameter update after it
+    refv, hipv = json.loads(out[4]), json.loads(out[5])
+    assert refv["who"] == "reference_block_voxels" and hipv["who"] == "hip_block_voxels"
+    assert refv["sizes"] == hipv["sizes"] and refv["sums"] == hipv["sums"] and refv["down_feature_point_num"] == hipv["down_feature_point_num"] > 0
+    assert refv["sizes"][0] == refb["sizes"][0] and 1000 < refv["sizes"][1] < refv["sizes"][0]  # pc_raw as before, pc_down one point per voxel
+    assert refv["rates"] == hipv["rates"] and refv["rates"][0] == 10 and 1 <= refv["rates"][1] < 20  # 20 - 200 / (facade_down + pillar_down)
+    assert refb["rates"] == hipb["rates"] == [10, 3]

@@ -23,7 +23,7 @@ def raw_drive(seed, n_frames, n_beams=64, n_az=1900, step=0.9):
 
 
 def block_of(ex):
-    """(full clouds, down clouds) in class order ground, pillar, facade, beam, roof, vertex from the thirteen clouds of mulls_extract_features"""
+    """(full clouds, down clouds) in class order ground, pillar, facade, beam, roof, vertex from the clouds of mulls_extract_features"""
     c = ex[abi.EX_PILLAR:]
     full = [ex[abi.EX_GROUND], c[abi.CL_PILLAR], c[abi.CL_FACADE], c[abi.CL_BEAM], c[abi.CL_ROOF], c[abi.CL_VERTEX]]
     down = [ex[abi.EX_GROUND_DOWN], c[abi.CL_PILLAR_DOWN], c[abi.CL_FACADE_DOWN], c[abi.CL_BEAM_DOWN], c[abi.CL_ROOF_DOWN], c[abi.CL_VERTEX]]
@@ -39,7 +39,8 @@ def main(argv=None):
     X = abi.extract_params(ground=abi.ground_params(fixed_num_downsampling=1, down_ground_fixed_num=800, rng_seed=1),
                            classify=abi.classify_params(neighbor_searching_radius=0.7, neighbor_k=25, neigh_k_min=7, curvature_thre=0.08, fixed_num_downsampling=1,
                                                         unground_down_fixed_num=20000, pillar_down_fixed_num=400, facade_down_fixed_num=1200, beam_down_fixed_num=200,
-                                                        roof_down_fixed_num=200, rng_seed=1))
+                                                        roof_down_fixed_num=200, rng_seed=1),
+                           apply_dist_filter=1, min_dist_used=1.5, max_dist_used=120.0)  # lo_gflag_list_kitti_urban.txt: --apply_dist_filter=true, 1.5 m .. 120 m
     P = abi.kitti_params(dis_thre_unit=1.5, used_feature_type="111110")
     ctx = lib.Context(0)
     t_feat = t_reg = t_map = 0.0

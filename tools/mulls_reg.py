@@ -1,8 +1,8 @@
 """Pairwise registration of two point clouds with the library, stage for stage what test/mulls_reg.cpp does (script/run_mulls_reg.sh):
-read -> fast_ground_filter -> classify_nground_pts per cloud -> the cloud with more down-sampled feature points is the target ->
-mm_lls_icp -> the source cloud, transformed, written out.  Flags carry the reference's names and defaults (test/mulls_reg.cpp:24-60).
-Not here: voxel down-sampling (cloud_*_down_res must be 0, as in run_mulls_reg.sh), the global coarse registration (TEASER / RANSAC on
-key-point correspondences: --is_global_reg must be false, the initial guess is the identity), the viewers.
+read -> voxel_downsample (cloud_*_down_res, 0 = off as in run_mulls_reg.sh) -> fast_ground_filter -> classify_nground_pts per cloud -> the
+cloud with more down-sampled feature points is the target -> mm_lls_icp -> the source's pc_down, transformed, written out.  Flags carry the
+reference's names and defaults (test/mulls_reg.cpp:24-60).  Not here: the global coarse registration (TEASER / RANSAC on key-point
+correspondences: --is_global_reg must be false, the initial guess is the identity), the viewers.
 
     python tools/mulls_reg.py --point_cloud_1_path a.pcd --point_cloud_2_path b.pcd --output_point_cloud_path b_reg.pcd --is_global_reg=false
 """
@@ -54,8 +54,9 @@ def read_cloud(path):
     return lib.read_kitti_bin(path) if path.endswith(".bin") else lib.read_pcd(path)
 
 
-def extract_semantic_pts(ctx, scan, F):
-    """CFilter::extract_semantic_pts (cfilter.hpp:2294-2413) as test/mulls_reg.cpp:134-143 calls it; estimate_ground_normal_method 0."""
+def extract_semantic_pts(ctx, scan, F, vf_downsample_resolution):
+    """CFilter::extract_semantic_pts (cfilter.hpp:2294-2413) as test/mulls_reg.cpp:134-143 calls it; estimate_ground_normal_method 0.
+    Returns (class clouds, their *_down clouds, pc_down)."""
     GP = abi.ground_params(min_grid_pt_num=8, grid_resolution=F.gf_grid_size, max_height_difference=F.gf_in_grid_h_thre,
                            neighbor_height_diff=F.gf_neigh_grid_h_thre, max_ground_height=F.gf_max_h, ground_random_down_rate=F.gf_ground_down_rate,
                            ground_random_down_down_rate=2, nonground_random_down_rate=F.gf_nonground_down_rate, reliable_neighbor_grid_num_thre=0,
@@ -66,17 +67,19 @@ def extract_semantic_pts(ctx, scan, F):
                              edge_thre=F.linearity_thre, planar_thre=F.planarity_thre, edge_thre_down=F.linearity_thre + 0.1,
                              planar_thre_down=F.planarity_thre + 0.1, curvature_thre=F.curvature_thre,
                              vertex_curvature_non_max_radius=1.5 * F.pca_neighbor_radius, use_distance_adaptive_pca=int(F.pca_distance_adpative_on))
-    ground, ground_down, unground = ctx.ground_filter(scan, GP)
+    pc_down = ctx.voxel_downsample(scan, vf_downsample_resolution) if vf_downsample_resolution >= 0.001 else abi.records(scan)
+    ground, ground_down, unground = ctx.ground_filter(abi.points_of(pc_down), GP)
     c = ctx.classify_nground(unground, CP)
     full = [ground, c[abi.CL_PILLAR], c[abi.CL_FACADE], c[abi.CL_BEAM], c[abi.CL_ROOF], c[abi.CL_VERTEX]]
     down = [ground_down, c[abi.CL_PILLAR_DOWN], c[abi.CL_FACADE_DOWN], c[abi.CL_BEAM_DOWN], c[abi.CL_ROOF_DOWN], c[abi.CL_VERTEX]]
-    return full, down
+    return full, down, pc_down
 
 
 def register(ctx, scan1, scan2, F):
-    """Returns (abi.Result, which scan is the source: 1 or 2)."""
-    f1, d1 = extract_semantic_pts(ctx, scan1, F)
-    f2, d2 = extract_semantic_pts(ctx, scan2, F)
+    """Returns (abi.Result, which scan is the source: 1 or 2, that scan's pc_down)."""
+    # test/mulls_reg.cpp:80-81, :134-143: block 1 is down-sampled with cloud_2_down_res, block 2 with cloud_1_down_res
+    f1, d1, p1 = extract_semantic_pts(ctx, scan1, F, F.cloud_2_down_res)
+    f2, d2, p2 = extract_semantic_pts(ctx, scan2, F, F.cloud_1_down_res)
     n1, n2 = sum(len(x) for x in d1), sum(len(x) for x in d2)
     # determine_source_target_cloud (cregistration.hpp:857-870): block1 (target) = the one with more down-sampled feature points
     (tgt_full, src_down, source) = (f1, d2, 2) if n1 > n2 else (f2, d1, 1)
@@ -86,23 +89,21 @@ def register(ctx, scan1, scan2, F):
                            converge_rotation_d=F.converge_rot_d, dis_thre_min=0.25 * F.corr_dis_thre, dis_thre_update_rate=1.1,
                            used_feature_type="111110", weight_strategy="1101", z_xy_balanced_ratio=1.0, pt2pt_residual_window=0.1,
                            pt2pl_residual_window=0.1, pt2li_residual_window=0.1)
-    return ctx.icp(pair, P)[0], source
+    return ctx.icp(pair, P)[0], source, (p1, p2)[source - 1]
 
 
 def main(argv=None):
     F = flags(argv)
-    if F.cloud_1_down_res >= 0.001 or F.cloud_2_down_res >= 0.001:
-        sys.exit("voxel down-sampling is not part of this build: cloud_*_down_res must be 0 (as in script/run_mulls_reg.sh)")
     if F.is_global_reg:
         sys.exit("the global coarse registration is out of scope: pass --is_global_reg=false (the initial guess is the identity)")
     ctx = lib.Context(F.device)
     scans = [read_cloud(F.point_cloud_1_path), read_cloud(F.point_cloud_2_path)]
-    res, source = register(ctx, scans[0], scans[1], F)
+    res, source, source_down = register(ctx, scans[0], scans[1], F)
     T = res.T_matrix()
     print("process code %d after %d iterations; source = point cloud %d; Trans1_2 =" % (res.code, res.iters, source))
     print(np.array2string(T, precision=6, suppress_small=True))
     if F.output_point_cloud_path:
-        moved = ctx.transform(scans[source - 1], T)  # pcl::transformPointCloud(*block2->pc_down, *pc_s_tran, Trans1_2)
+        moved = ctx.transform(abi.points_of(source_down), T)  # pcl::transformPointCloud(*block2->pc_down, *pc_s_tran, Trans1_2)
         lib.write_pcd(F.output_point_cloud_path, moved)
     return res, source
 
