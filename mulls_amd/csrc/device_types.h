@@ -122,6 +122,7 @@ struct IcpOut
 	unsigned long long t_fused[6]; // ... of the fused class pass by stage: set-up, stage 1, leftovers, stage 3, stage 4, (unused)
 	uint32_t t_search_it[24]; // ... and of the search phase of the first 24 iterations
 	unsigned long long t_phase[6]; // time of this pair in the loop's phases, 10-ns ticks (wall_clock64): search, counters + count test, normal equations, solve, residual pass, total
+	unsigned long long tgt_job_pts, pair_evals; // lock-step loop with the device step only: target points times the workgroups that read them; brute-force pair evaluations
 };
 
 // One workgroup's worth of the correspondence search / filter / accumulation.

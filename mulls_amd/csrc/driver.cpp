@@ -88,6 +88,10 @@ struct mulls_batch
 	IcpOut *icp_outs = nullptr;
 	mulls_iter_trace *trace_dev = nullptr;
 	size_t cap_icp[5] = {};
+	mulls::StepState *steps = nullptr; // lock-step loop with the device step: per-pair loop state
+	size_t cap_steps = 0;
+	uint32_t epoch2 = 0; // ... and the last epoch issued on its 8-byte word (words 32-33 of epoch_h)
+	int nsub = 1;		 // sub-batches the job tables are laid out for (build_jobs)
 	uint32_t *wl = nullptr;		// LDS tier: class clouds k_cert queued for k_nn_lds (one slot per class-level job)
 	uint32_t *wl_ctr = nullptr; // ... and the queue counters: per sub-batch 8 words = (queued, taken) x launch parity
 	size_t cap_wl = 0;
@@ -218,11 +222,13 @@ int subbatch_count(int n)
 	return n < 2 ? 1 : nsub;
 }
 
-void build_jobs(mulls_batch *B, const mulls_params *P)
+void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 {
 	std::string key(P->used_feature_type, 6);
+	key += (char)('0' + nsub);
 	if (key == B->jobs_key)
 		return;
+	B->nsub = nsub;
 	B->jobs_h.clear();
 	for (int p = 0; p < B->n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
@@ -262,7 +268,6 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 	// of a launch is made of the cheap class clouds (cost ~ queries x log(targets); ties keep the pair order)
 	B->cjobs_dev_h = B->cjobs_h;
 	{
-		const int nsub = subbatch_count(B->n);
 		auto first_of = [&](uint32_t pair) {
 			return std::lower_bound(B->cjobs_dev_h.begin(), B->cjobs_dev_h.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; });
 		};
@@ -309,7 +314,6 @@ void build_jobs(mulls_batch *B, const mulls_params *P)
 				}
 	B->ajobs_h.clear();
 	{
-		const int nsub = subbatch_count(B->n);
 		for (int k = 0; k < 2; k++)
 			for (int b = 0; b < 4; b++)
 				B->ajob_split[k][b] = 0;
@@ -687,12 +691,13 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 // Per-run device tables.  Job tables and the pristine descriptor block only change with the batch layout or the set of
 // used classes, so they are uploaded once (pinned copies would not help: they are simply not re-sent) and every run
 // restores the mutable descriptors / box keys with device-to-device copies — no pageable H2D traffic per run.
-int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr)
+// nsub: sub-batches the lock-step job tables are laid out for (0 = subbatch_count)
+int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr, int nsub = 0)
 {
 	hipStream_t st = ctx->stream;
 	const int n = B->n;
 	const std::string old_key = B->jobs_key;
-	build_jobs(B, P_jobs);
+	build_jobs(B, P_jobs, nsub > 0 ? nsub : subbatch_count(n));
 	uint32_t lds_cap = 0;
 	const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 	if (tier < 0)
@@ -1047,7 +1052,8 @@ extern "C"
 			(void)hipSetDevice(ctx->device);
 		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->mq, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
-					   B->tjobs, B->cjobs, B->wl, B->wl_ctr, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init};
+					   B->tjobs, B->cjobs, B->wl, B->wl_ctr, B->grids, B->tsorted, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init,
+					   B->rjobs, B->ajobs, B->pair_rjob, B->order, B->icp_queue, B->icp_outs, B->trace_dev, B->steps};
 		for (void *p : dev)
 			if (p)
 				(void)hipFree(p);
@@ -1126,10 +1132,18 @@ extern "C"
 		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
 			rp.debug_stop = (uint32_t)std::atoi(dbg);
 
+		// Lock-step tiers: the O(1) half of every iteration (count test, 6x6 solve, convergence tests, residual) runs on the device behind the
+		// accumulation (k_finish_step) unless the caller wants per-iteration traces, which the host half collects (MULLS_HOST_STEP=1: diagnostics).
+		// Nothing but one 8-byte word crosses PCIe per iteration then, and there is no host work to hide behind a second sub-batch.
+		bool dstep = P->max_iter_num > 0;
+		for (int p = 0; p < n && dstep; p++)
+			dstep = !(results[p].trace && results[p].trace_cap > 0);
+		if (const char *e = std::getenv("MULLS_HOST_STEP"))
+			dstep = dstep && std::atoi(e) == 0;
 		uint32_t lds_cap = 0;
 		int tier = 0;
 		bool resident = false;
-		rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident);
+		rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident, dstep ? 1 : 0);
 		if (rc != MULLS_OK)
 			return rc;
 		const bool use_grid = tier != 0;
@@ -1187,28 +1201,8 @@ extern "C"
 		evt.end();
 
 		const mulls::IcpConst K = icp_const(P);
-		if (resident)
-		{
-			// ---- device-resident loop: ONE launch iterates every pair to the end (k_icp.hip) ------------------------------------------
-			uint32_t trace_cap = 0;
-			for (int p = 0; p < n; p++)
-				if (results[p].trace && results[p].trace_cap > 0)
-					trace_cap = std::max(trace_cap, (uint32_t)results[p].trace_cap);
-			if (trace_cap)
-			{
-				trace_cap = std::min(trace_cap, (uint32_t)std::max(P->max_iter_num, 1));
-				if (grow(ctx, &B->trace_dev, &B->cap_icp[4], (size_t)n * trace_cap) != MULLS_OK)
-					return MULLS_E_HIP;
-			}
-			evt.begin(&ctx->prof.ms_nn);
-			if (launch_icp(st, (uint32_t)n, 0u, B->rjobs, B->pair_rjob, B->order, B->icp_queue, B->descs, B->setup, rp, K, B->spos, B->snrm, B->grids, B->cell_start,
-						   B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, B->bbox, lds_cap, rp.grid_maxcells,
-						   B->icp_outs, trace_cap ? B->trace_dev : nullptr, trace_cap) != 0)
-			{
-				ctx->err = "could not raise the dynamic LDS limit of k_icp";
-				return MULLS_E_HIP;
-			}
-			evt.end();
+		// results of the loops that end on the device (k_icp; k_finish_step): IcpOut records -> mulls_result, profile counters
+		auto results_from_device = [&](uint32_t trace_cap, bool from_icp) -> int {
 			B->icp_outs_h.resize(n);
 			HIPCHK(ctx, hipMemcpyAsync(B->icp_outs_h.data(), B->icp_outs, sizeof(IcpOut) * (size_t)n, hipMemcpyDeviceToHost, st));
 			if (trace_cap)
@@ -1219,7 +1213,6 @@ extern "C"
 			HIPCHK(ctx, hipStreamSynchronize(st));
 			evt.collect();
 			const double wall_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() * 1e3;
-			ctx->prof.launches_nn = 1;
 			int max_it = 0;
 			for (int p = 0; p < n; p++)
 			{
@@ -1243,25 +1236,165 @@ extern "C"
 				std::memset(R.crop_box, 0, sizeof(R.crop_box));
 				fill_crop_box(rp, B->setup_h[p].tgt_bound, o.bbox, R);
 				R.trace_len = 0;
-				if (R.trace && R.trace_cap > 0)
+				if (trace_cap && R.trace && R.trace_cap > 0)
 				{
 					R.trace_len = std::min(o.trace_len, R.trace_cap);
 					std::memcpy(R.trace, &B->trace_h[(size_t)p * trace_cap], sizeof(mulls_iter_trace) * (size_t)R.trace_len);
 				}
 				ctx->prof.nn_src_pts += o.src_pts;
 				ctx->prof.nn_tgt_unique += o.tgt_pts;
-				ctx->prof.nn_tgt_pts += o.tgt_pts;
+				ctx->prof.nn_tgt_pts += from_icp ? o.tgt_pts : o.tgt_job_pts;
 				ctx->prof.nn_corr_pts += o.corr_pts;
-				for (int k = 0; k < 6; k++)
-					ctx->prof.icp_phase_ms[k] += (double)o.t_phase[k] * 1e-5; // 10-ns ticks -> ms (summed over the pairs)
-				for (int k = 0; k < 6; k++)
-					ctx->prof.icp_fused_ms[k] += (double)o.t_fused[k] * 1e-5;
-				for (int k = 0; k < 24 && k < o.iters; k++)
-					ctx->prof.icp_search_ms[k] += (double)o.t_search_it[k] * 1e-5;
+				if (!from_icp)
+					ctx->prof.nn_pair_evals += o.pair_evals;
+				if (from_icp)
+				{
+					for (int k = 0; k < 6; k++)
+						ctx->prof.icp_phase_ms[k] += (double)o.t_phase[k] * 1e-5; // 10-ns ticks -> ms (summed over the pairs)
+					for (int k = 0; k < 6; k++)
+						ctx->prof.icp_fused_ms[k] += (double)o.t_fused[k] * 1e-5;
+					for (int k = 0; k < 24 && k < o.iters; k++)
+						ctx->prof.icp_search_ms[k] += (double)o.t_search_it[k] * 1e-5;
+				}
 				max_it = std::max(max_it, o.iters);
 			}
 			ctx->prof.iterations = max_it;
 			return MULLS_OK;
+		};
+		if (resident)
+		{
+			// ---- device-resident loop: ONE launch iterates every pair to the end (k_icp.hip) ------------------------------------------
+			uint32_t trace_cap = 0;
+			for (int p = 0; p < n; p++)
+				if (results[p].trace && results[p].trace_cap > 0)
+					trace_cap = std::max(trace_cap, (uint32_t)results[p].trace_cap);
+			if (trace_cap)
+			{
+				trace_cap = std::min(trace_cap, (uint32_t)std::max(P->max_iter_num, 1));
+				if (grow(ctx, &B->trace_dev, &B->cap_icp[4], (size_t)n * trace_cap) != MULLS_OK)
+					return MULLS_E_HIP;
+			}
+			evt.begin(&ctx->prof.ms_nn);
+			if (launch_icp(st, (uint32_t)n, 0u, B->rjobs, B->pair_rjob, B->order, B->icp_queue, B->descs, B->setup, rp, K, B->spos, B->snrm, B->grids, B->cell_start,
+						   B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, B->bbox, lds_cap, rp.grid_maxcells,
+						   B->icp_outs, trace_cap ? B->trace_dev : nullptr, trace_cap) != 0)
+			{
+				ctx->err = "could not raise the dynamic LDS limit of k_icp";
+				return MULLS_E_HIP;
+			}
+			evt.end();
+			const int rcr = results_from_device(trace_cap, true);
+			if (rcr != MULLS_OK)
+				return rcr;
+			ctx->prof.launches_nn = 1;
+			return MULLS_OK;
+		}
+		if (dstep)
+		{
+			// ---- lock-step loop with the O(1) half of the iteration on the device (k_reduce.hip: k_finish_step) ----------------------------
+			// One launch set per iteration for the whole batch: search (+ filter), accumulation, finish + step.  The host keeps two sets queued
+			// and reads one 8-byte word per set — (epoch << 32 | pairs still iterating) — to know when to stop queueing; a set queued behind the
+			// last useful one finds no active pair and falls through.
+			if (grow(ctx, &B->steps, &B->cap_steps, (size_t)n) != MULLS_OK || grow(ctx, &B->icp_outs, &B->cap_icp[3], (size_t)n) != MULLS_OK)
+				return MULLS_E_HIP;
+			volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(B->epoch_h + 32);
+			unsigned long long *word_dev = reinterpret_cast<unsigned long long *>(B->epoch_dev + 32);
+			HIPCHK(ctx, hipMemsetAsync(B->icp_outs, 0, sizeof(IcpOut) * (size_t)n, st));
+			launch_step_init(st, (uint32_t)n, B->setup, K, B->steps, B->states);
+			EvTimer ev2[2] = {EvTimer{ctx}, EvTimer{ctx}};
+			ev2[1].base = 10;
+			ev2[0].used = evt.used; // the setup events were recorded on the first set
+			for (int k = 0; k < 5; k++)
+				ev2[0].slot[k] = evt.slot[k];
+			evt.used = 0;
+			struct DrainOnError // an error from here on leaves kernels in flight that still write the pinned word
+			{
+				mulls_ctx *ctx;
+				bool armed = true;
+				~DrainOnError()
+				{
+					if (armed)
+						(void)hipStreamSynchronize(ctx->stream);
+				}
+			} drain{ctx};
+			const uint32_t epoch0 = B->epoch2;
+			uint32_t left = (uint32_t)n, nn_launches = 0;
+			// wait until launch set `set` has published; left = pairs still iterating after the newest published set
+			auto wait_set = [&](int set) -> int {
+				const uint32_t want = epoch0 + (uint32_t)set + 1u;
+				const auto t0 = std::chrono::steady_clock::now();
+				bool synced = false;
+				for (uint64_t spins = 0;; spins++)
+				{
+					const unsigned long long w = *word;
+					if ((int32_t)((uint32_t)(w >> 32) - want) >= 0)
+					{
+						std::atomic_thread_fence(std::memory_order_acquire);
+						left = (uint32_t)w;
+						return MULLS_OK;
+					}
+					if (synced)
+						break;
+					if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+					{
+						HIPCHK(ctx, hipStreamSynchronize(st)); // a stalled device, or an asynchronous error: surfaces here
+						synced = true;
+					}
+				}
+				ctx->err = "device did not publish the iteration epoch";
+				return MULLS_E_HIP;
+			};
+			const auto t_loop0 = std::chrono::steady_clock::now();
+			for (int s = 0; s <= P->max_iter_num; s++) // max_iter_num iterations and the residual pass of the last pairs to finish
+			{
+				if (s >= 2)
+				{
+					const auto t_wait0 = std::chrono::steady_clock::now();
+					if ((rc = wait_set(s - 2)) != MULLS_OK)
+						return rc;
+					ctx->prof.ms_host_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() * 1e3;
+					ev2[s & 1].collect();
+					if (left == 0)
+						break;
+				}
+				EvTimer &ev = ev2[s & 1];
+				ev.begin(&ctx->prof.ms_nn);
+				if (tier == 2)
+				{
+					if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+									  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr,
+									  nn_launches++) != 0)
+					{
+						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
+						return MULLS_E_HIP;
+					}
+				}
+				else if (tier == 1)
+					launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
+								   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
+				else
+					launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				if (rp.normal_shooting)
+					launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				ev.end();
+				ev.begin(&ctx->prof.ms_filter);
+				if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
+					launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
+				ev.end();
+				ctx->prof.launches_nn++;
+				ev.begin(&ctx->prof.ms_accum);
+				for (int k = 0; k < B->nsub; k++)
+					launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+				launch_finish_step(st, (uint32_t)n, B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, word_dev, ++B->epoch2,
+								   use_grid ? 0 : 1);
+				ev.end();
+			}
+			ctx->prof.ms_host_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() * 1e3 - ctx->prof.ms_host_wait;
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			drain.armed = false;
+			ev2[0].collect();
+			ev2[1].collect();
+			return results_from_device(0, false);
 		}
 		std::vector<PairHost> H(n);
 		for (int p = 0; p < n; p++)
@@ -1760,7 +1893,7 @@ extern "C"
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)
 				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-			for (int k = 0; k < subbatch_count(B->n); k++)
+			for (int k = 0; k < B->nsub; k++)
 				launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 			launch_finish(st, (uint32_t)n, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			if (wait_epoch(ctx, B) != MULLS_OK)
@@ -2170,7 +2303,7 @@ extern "C"
 				// clear every flag to "alive, not a correspondence", then switch the requested ones on
 				e = hipMemsetAsync(B->flag + off, MULLS_F_ALIVE, src->n, st);
 				launch_set_corr(st, off, dcs, dct, corr_d2 ? dcd : nullptr, ncorr, B->flag, B->match, B->wd, B->descs_h[cls].tgt_off, B->tpos, B->tnrm, B->mq);
-				for (int k = 0; k < subbatch_count(B->n); k++)
+				for (int k = 0; k < B->nsub; k++)
 				launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 				launch_finish(st, 1, B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, B->ticket, B->epoch_dev, ++B->epoch, 0);
 			}

@@ -35,6 +35,18 @@ struct PairIter
 	int32_t active, want_residual, done;
 };
 
+// Lock-step loop with this half of the iteration on the device (k_reduce.hip: k_finish_step): what the host otherwise keeps per pair between
+// the launches, resident in HBM instead
+struct StepState
+{
+	PairIter h;
+	uint32_t alive_prev[6];						  // live source points per class before the iteration's search
+	uint32_t ncorr[6], nsrc0[6], ntgt0[6], bbox[6]; // what the result record reports: last |Corr_f|, post-filter cloud sizes, crop box keys
+	uint32_t first;									  // the first iteration's bookkeeping (cloud sizes, crop box, source_feature_points_count) is still to do
+	uint32_t pad_;
+	unsigned long long src_pts, tgt_pts, tgt_job_pts, pair_evals, corr_pts; // profile counters, summed over the iterations
+};
+
 MULLS_HD inline void pair_iter_init(PairIter &h, const double guess_rows[12], const IcpConst &K)
 {
 	for (int r = 0; r < 3; r++)

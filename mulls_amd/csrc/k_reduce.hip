@@ -2,6 +2,7 @@
 // (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
 #include "device_util.h"
 #include "accum.h"
+#include "solve_wave.h"
 
 // Normal-equation accumulation (active pairs) or posterior residual (pairs flagged want_residual), lock-step path.  The job
 // table is the one of the search (512 source slots per job); one workgroup per job that starts a trip of MULLS_ACC_LANES slots
@@ -168,6 +169,211 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_pull_outs(const uint4 *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Lock-step loop with the O(1) half of the iteration on the device.  k_step_init prepares what the host path keeps in PairHost (pair_iter_init,
+// the first PairState, an empty result); k_step, launched behind k_finish, does what driver.cpp's host_step does with the record k_pull_outs
+// would have shipped: first-iteration bookkeeping, the correspondence-count test and threshold update (step_counts), the 6x6 solve with its
+// step and convergence tests (solve_wave = step_solve), the posterior residual (step_residual), the next PairState — the very functions the
+// host calls (icp_step.h), so the two paths produce the same bits — and, once the pair is done, its result record.  One wave per pair (every
+// pair of the batch is resident at once: the solve is a latency chain), the pair's state staged in LDS.  Nothing crosses PCIe per iteration
+// except one 8-byte word: (epoch << 32 | pairs still iterating), published by k_step_publish.
+__global__ __launch_bounds__(64) void k_step_init(uint32_t npairs, const PairSetup *__restrict__ setup, mulls::IcpConst K, mulls::StepState *__restrict__ steps,
+												  PairState *__restrict__ states)
+{
+	const uint32_t pair = blockIdx.x * 64u + threadIdx.x;
+	if (pair >= npairs)
+		return;
+	mulls::StepState &S = steps[pair];
+	static_assert(sizeof(mulls::StepState) % 8 == 0, "StepState is cleared / moved in 8-byte words");
+	unsigned long long *w = reinterpret_cast<unsigned long long *>(&S);
+	for (uint32_t k = 0; k < sizeof(mulls::StepState) / 8; k++)
+		w[k] = 0ull;
+	mulls::pair_iter_init(S.h, setup[pair].guess, K);
+	S.first = 1u;
+	PairState &ps = states[pair];
+	for (int k = 0; k < 12; k++)
+		ps.T[k] = (k % 5 == 0) ? 1.0 : 0.0; // TempTran = identity at i = 0
+	for (int k = 0; k < 6; k++)
+		ps.x[k] = 0.0;
+	for (int c = 0; c < MULLS_NC; c++)
+		ps.thr[c] = K.dis_thre_unit;
+	ps.iter = 0;
+	ps.active = S.h.active;
+	ps.want_residual = 0;
+	ps.pad_[0] = ps.pad_[1] = ps.pad_[2] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
+											 const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute)
+{
+	const uint32_t pair = blockIdx.x;
+	const int l = (int)threadIdx.x;
+	__shared__ mulls::StepState S;
+	__shared__ SolveWs ws;
+	__shared__ double s_comb[MULLS_NTERM_PAD];
+	__shared__ uint32_t s_cnt[32]; // the record's counter block: n_valid, n_alive, src_n, tgt_n, bbox (6 each)
+	__shared__ uint32_t s_jobs[MULLS_NC], s_n0[MULLS_NC];
+	__shared__ int s_go, s_iter, s_active, s_resid, s_done;
+	if (l == 0)
+	{
+		s_active = states[pair].active;
+		s_resid = states[pair].want_residual;
+		s_iter = states[pair].iter;
+	}
+	__syncthreads();
+	if (s_active || s_resid) // uniform
+	{
+		const PairOut &o = out[pair];
+		{
+			const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&steps[pair]);
+			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&S);
+			for (uint32_t w = (uint32_t)l; w < sizeof(mulls::StepState) / 8; w += 64u)
+				dst[w] = src[w];
+		}
+		if (l < MULLS_NTERM_PAD)
+			s_comb[l] = o.comb[l];
+		if (l < 30)
+			s_cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
+		if (l < MULLS_NC)
+		{
+			const CloudDesc &d = descs[pair * MULLS_NC + l];
+			s_jobs[l] = d.job_end - d.job_begin;
+			s_n0[l] = d.src_n0;
+		}
+		__syncthreads();
+		const uint32_t *n_valid = s_cnt, *n_alive = s_cnt + 6, *src_n = s_cnt + 12, *tgt_n = s_cnt + 18, *obox = s_cnt + 24;
+		mulls::PairIter &h = S.h;
+		if (l == 0)
+		{
+			s_go = 0;
+			if (s_resid)
+				mulls::step_residual(h, K, s_comb[0], s_comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
+			else
+			{
+				const int i = s_iter;
+				h.iters = i + 1;
+				if (S.first)
+				{
+					// the sizes the reference counts at :1195-1201 (while undistorting: those of the cloned clouds) and the crop box's keys
+					int sfc = 0;
+					for (int c = 0; c < MULLS_NC; c++)
+					{
+						const uint32_t n0 = rp.undistort ? s_n0[c] : src_n[c];
+						S.nsrc0[c] = n0;
+						S.ntgt0[c] = tgt_n[c];
+						S.alive_prev[c] = src_n[c];
+						if ((c == 1 || c == 2 || c == 3) && rp.used[c])
+							sfc += (int)n0;
+					}
+					h.src_feature_count = sfc;
+					for (int k = 0; k < 6; k++)
+						S.bbox[k] = obox[k];
+					S.first = 0u;
+				}
+				for (int c = 0; c < MULLS_NC; c++)
+				{
+					if (rp.used[c] && S.alive_prev[c] >= 3u && tgt_n[c] >= 3u)
+					{
+						if (brute)
+							S.pair_evals += (unsigned long long)S.alive_prev[c] * tgt_n[c];
+						S.src_pts += S.alive_prev[c];
+						S.tgt_pts += tgt_n[c];
+						S.tgt_job_pts += (unsigned long long)tgt_n[c] * s_jobs[c];
+					}
+					S.alive_prev[c] = n_alive[c];
+					S.ncorr[c] = n_valid[c];
+					S.corr_pts += n_valid[c];
+				}
+				s_go = mulls::step_counts(h, K, n_valid) ? 1 : 0; // :1305-1311, then update_corr_dist_thre :1855-1866
+			}
+		}
+		__syncthreads();
+		if (s_go)
+			solve_wave(h, K, s_comb, s_iter, ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
+		__syncthreads();
+		if (l == 0)
+		{
+			s_done = (!h.active && !h.want_residual) ? 1 : 0;
+			if (s_done)
+				h.guess = h.temp * h.guess; // :1403 (TempTran is the identity after a failure)
+		}
+		__syncthreads();
+		// the next iteration's PairState
+		PairState &ps = states[pair];
+		if (l < 12)
+			ps.T[l] = h.temp.at(l / 4, l % 4);
+		else if (l < 18)
+			ps.x[l - 12] = h.x[l - 12];
+		else if (l < 24)
+			ps.thr[l - 18] = h.thr[l - 18];
+		else if (l == 24)
+		{
+			ps.iter = h.want_residual ? h.iters - 1 : s_iter + 1;
+			ps.active = h.active ? 1 : 0;
+			ps.want_residual = h.want_residual ? 1 : 0;
+		}
+		{
+			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&steps[pair]);
+			const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&S);
+			for (uint32_t w = (uint32_t)l; w < sizeof(mulls::StepState) / 8; w += 64u)
+				dst[w] = src[w];
+		}
+		if (s_done) // the result record (the fields k_icp's timers fill stay zero)
+		{
+			IcpOut &O = results[pair];
+			if (l < 16)
+				O.T[l] = h.guess.v[l];
+			if (l < 36)
+				O.info[l] = h.info.v[l];
+			if (l >= 40 && l < 46)
+			{
+				const int c = l - 40;
+				O.ncorr[c] = S.ncorr[c];
+				O.nsrc0[c] = S.nsrc0[c];
+				O.ntgt0[c] = S.ntgt0[c];
+				O.bbox[c] = S.bbox[c];
+			}
+			if (l == 63)
+			{
+				O.sigma2 = h.sigma2;
+				O.ratio = h.ratio;
+				O.code = h.code;
+				O.iters = h.iters;
+				O.singular = h.singular;
+				O.trace_len = 0;
+				O.src_pts = S.src_pts;
+				O.tgt_pts = S.tgt_pts;
+				O.corr_pts = S.corr_pts;
+				O.tgt_job_pts = S.tgt_job_pts;
+				O.pair_evals = S.pair_evals;
+			}
+		}
+	}
+}
+
+// ... and the word the host reads: pairs still iterating after this launch set.  Its own small launch: thousands of single-wave workgroups
+// taking a ticket on one address cost more than the whole step (the atomics serialise in the L2).
+__global__ __launch_bounds__(1024) void k_step_publish(const PairState *__restrict__ states, uint32_t npairs, volatile unsigned long long *host_word, uint32_t epoch)
+{
+	int mine = 0;
+	for (uint32_t p = threadIdx.x; p < npairs; p += 1024u)
+		mine += (states[p].active || states[p].want_residual) ? 1 : 0;
+	__shared__ uint32_t s_left;
+	if (threadIdx.x == 0)
+		s_left = 0u;
+	__syncthreads();
+	for (int off = 32; off > 0; off >>= 1)
+		mine += __shfl_down(mine, off);
+	if ((threadIdx.x & 63u) == 0u && mine)
+		atomicAdd(&s_left, (uint32_t)mine);
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		__threadfence_system();
+		*host_word = (unsigned long long)epoch << 32 | s_left;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Per-iteration input: the host writes the PairState records into pinned memory; this kernel pulls them into HBM with
 // coalesced 16-B reads over PCIe (one read of the block instead of one per workgroup of every later kernel).
 static_assert(sizeof(PairState) % 16 == 0, "PairState must be a whole number of uint4 words");
@@ -255,6 +461,23 @@ void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const Pair
 	const uint32_t nwords = npairs * (8u + (MULLS_NTERM_PAD / 2u) * (rp.pull_comb ? 1u : n_used));
 	hipLaunchKernelGGL(k_pull_outs, dim3((nwords + MULLS_BLOCK - 1) / MULLS_BLOCK), dim3(MULLS_BLOCK), 0, st, reinterpret_cast<const uint4 *>(out),
 					   reinterpret_cast<uint4 *>(out_host), rp, pair_base, npairs, ticket, host_epoch, epoch);
+}
+
+void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, const mulls::IcpConst &K, mulls::StepState *steps, PairState *states)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_step_init, dim3((npairs + 63u) / 64u), dim3(64), 0, st, npairs, setup, K, steps, states);
+}
+
+void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
+						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute)
+{
+	if (!npairs)
+		return;
+	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, 0u, static_cast<uint4 *>(nullptr),
+					   static_cast<uint32_t *>(nullptr), static_cast<volatile uint32_t *>(nullptr), 0u);
+	hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute);
+	hipLaunchKernelGGL(k_step_publish, dim3(1), dim3(1024), 0, st, states, npairs, host_word, epoch);
 }
 
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)

@@ -40,6 +40,15 @@ void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const Pair
 				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
 				   uint32_t pair_base);
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs);
+namespace mulls
+{
+struct IcpConst;
+struct StepState;
+} // namespace mulls
+// lock-step loop with the O(1) half of the iteration on the device: initial per-pair state and first PairState; k_finish followed by the step (k_step)
+void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, const mulls::IcpConst &K, mulls::StepState *steps, PairState *states);
+void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
+						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute);
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
 					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq);

@@ -97,9 +97,10 @@ def test_batch_equals_single(ctx, pairs_small):
         assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma  # bit-identical
 
 
-def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
-    """n >= 2048 runs as two sub-batches pipelined on the stream (driver.cpp): per-pair results stay bit-identical to the
-    single-pair call, whichever half a pair lands in and whenever its neighbours converge or fail."""
+def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small, monkeypatch):
+    """n >= 2048: one launch set per iteration for the whole batch (device step), or two sub-batches pipelined on the stream when the host
+    steps (driver.cpp): per-pair results stay bit-identical to the single-pair call, wherever a pair lands and whenever its neighbours
+    converge or fail."""
     rng = np.random.default_rng(3)
     tgt = planes_scene(rng)
     far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
@@ -109,11 +110,49 @@ def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
     assert len({r.iters for r in single}) > 1  # sub-batches do not finish together
     order = [int(k) for k in rng.integers(0, len(base), 2100)]
     order[0], order[1049], order[1050], order[2099] = 3, 3, 3, 3
-    rb = ctx.icp_batch([base[k] for k in order], P)
-    for i, k in enumerate(order):
-        r1 = single[k]
-        assert (r1.code, r1.iters, list(r1.ncorr)) == (rb[i].code, rb[i].iters, list(rb[i].ncorr)), i
-        assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma, i
+    for host_step in ("0", "1"):  # one launch set per iteration with the step on the device; two sub-batches with the host stepping them
+        monkeypatch.setenv("MULLS_HOST_STEP", host_step)
+        rb = ctx.icp_batch([base[k] for k in order], P)
+        for i, k in enumerate(order):
+            r1 = single[k]
+            assert (r1.code, r1.iters, list(r1.ncorr)) == (rb[i].code, rb[i].iters, list(rb[i].ncorr)), i
+            assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma, i
+
+
+def test_device_step_equals_host_step(ctx, pairs_small, monkeypatch):
+    """The lock-step loop steps on the device (k_finish_step: count test, 6x6 solve, convergence tests, residual — icp_step.h's functions) unless
+    traces are asked for, which the host half of the loop collects (or MULLS_HOST_STEP=1): every output bit-identical between the two, for
+    healthy pairs, failing ones (-1, -2, -3), loops of one to three iterations, and so are the profile's point counters."""
+    rng = np.random.default_rng(11)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    empty = abi.PairData(tgt, [None] * 6)
+    turned = abi.PairData(tgt, transformed_copy(tgt, np.linalg.inv(synth.se3(0.05, 0, 0, 0, 0, 0.03))))
+    plist = [p for p, _ in pairs_small] + [far, empty, turned] + [p for p, _ in pairs_small]
+    sets = [abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111000", max_bearable_rotation_d=0.1),
+            abi.default_params(used_feature_type="111000", sigma_thre=1e-9), abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1),
+            abi.kitti_params(dis_thre_unit=2.4, max_iter_num=2), abi.kitti_params(dis_thre_unit=2.4, max_iter_num=3),
+            abi.kitti_params(dis_thre_unit=2.4, apply_motion_undistortion=1), abi.kitti_params(dis_thre_unit=2.4, apply_intersection_filter=0)]
+    b = ctx.batch(plist)
+    codes = set()
+    for P in sets:
+        out, prof = {}, {}
+        for host in (0, 1, 0):
+            monkeypatch.setenv("MULLS_HOST_STEP", str(host))
+            r = b.run(P)
+            got = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), tuple(x.ntgt0), x.cropped, tuple(x.crop_box), np.array(x.T[:]).tobytes(),
+                    np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes(), np.float32(x.confidence).tobytes(), x.singular) for x in r]  # (NaN-safe: bytes)
+            pf = ctx.profile()
+            cnt = (pf.nn_src_pts, pf.nn_tgt_pts, pf.nn_tgt_unique, pf.nn_pair_evals, pf.iterations)
+            if host in out:
+                assert out[host] == got and prof[host] == cnt  # and run after run
+            out[host], prof[host] = got, cnt
+        assert out[0] == out[1]
+        assert prof[0] == prof[1]
+        codes |= {x[0] for x in out[0]}
+    monkeypatch.delenv("MULLS_HOST_STEP")
+    assert codes >= {1, -1, -2, -3}
+    b.close()
 
 
 def test_resident_batch_is_repeatable(ctx, pairs_small):
