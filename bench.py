@@ -401,14 +401,17 @@ def main(argv=None, engine_factory=None):
                 pmc = None
         except Exception:
             pmc = None
+        # pairs one launch of the search covers (the lock-step loop queues one launch per iteration for the whole batch, or one per sub-batch)
+        pairs_per_launch = len(pairs) * float(np.mean(iters)) * args.steps / launches
+        pmc_scale = pairs_per_launch / pmc["config"]["pairs_per_launch"] if pmc and pmc["config"].get("pairs_per_launch") else 1.0
         valu_view = None
         if brute:
             valu_view = {"achieved": valu, "peak": VALU_PEAK_TLOPS, "unit": "Tlane-op/s", "frac": valu / VALU_PEAK_TLOPS,
                          "distance_evals_per_launch": acc["nn_pair_evals"] / launches}
         elif pmc and pmc.get("valu_wave_insts_per_launch") and avg_ms > 0:
             # a wave64 VALU instruction holds its SIMD for 4 cycles: issue time = instructions x 4 / (SIMDs x clock)
-            issue_ms = pmc["valu_wave_insts_per_launch"] * 4.0 / (1024 * 2.4e9) * 1e3
-            valu_view = {"valu_wave_insts_per_launch": pmc["valu_wave_insts_per_launch"], "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
+            issue_ms = pmc["valu_wave_insts_per_launch"] * pmc_scale * 4.0 / (1024 * 2.4e9) * 1e3
+            valu_view = {"valu_wave_insts_per_launch": pmc["valu_wave_insts_per_launch"] * pmc_scale, "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
                          "source": pmc.get("source_sq"), "note": "SQ_INSTS_VALU of the committed pass x 4 cycles / (1024 SIMDs x 2.4 GHz) against the live launch duration"}
         sizes = sorted(sum(len(s[0].tgt[c]) for c in (abi.GROUND, abi.PILLAR, abi.FACADE)) for s in scenes)
         out = {
@@ -452,9 +455,12 @@ def main(argv=None, engine_factory=None):
                           "correspondence search of one ICP iteration, LDS tier: k_cert (rigid step, certificates, rejection chain) + k_nn_lds (exact "
                           "fixed-radius 1-NN of the uncertified queries on a uniform grid staged in LDS)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic": pmc["traffic_bytes_per_launch"] * pmc_scale if pmc else None,
                 "traffic_note": "bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (%s; 2 x FETCH + WRITE "
-                                "per the gfx950 guide); null when the run differs from it" % (pmc.get("source") if pmc else "profiles/pmc_traffic.json"),
+                                "per the gfx950 guide)%s; null when the run differs from it" % (
+                                    pmc.get("source") if pmc else "profiles/pmc_traffic.json",
+                                    "" if abs(pmc_scale - 1.0) < 0.01 else ", measured on launches of %d pairs and scaled by %.2f to this run's %.0f pairs per launch" % (
+                                        pmc["config"]["pairs_per_launch"], pmc_scale, pairs_per_launch)),
                 "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "the search is an irregular exact query, bound by VALU issue (instruction count) and dependent memory access, not by HBM "
                         "bandwidth (DESIGN.md section 4); the HBM fraction is reported as the contract asks",

@@ -1358,30 +1358,34 @@ extern "C"
 						break;
 				}
 				EvTimer &ev = ev2[s & 1];
-				ev.begin(&ctx->prof.ms_nn);
-				if (tier == 2)
+				const bool search = s < P->max_iter_num; // the last set can only hold residual passes
+				if (search)
 				{
-					if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-									  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr,
-									  nn_launches++) != 0)
+					ev.begin(&ctx->prof.ms_nn);
+					if (tier == 2)
 					{
-						ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
-						return MULLS_E_HIP;
+						if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
+										  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr,
+										  nn_launches++) != 0)
+						{
+							ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
+							return MULLS_E_HIP;
+						}
 					}
+					else if (tier == 1)
+						launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
+									   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
+					else
+						launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+					if (rp.normal_shooting)
+						launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+					ev.end();
+					ev.begin(&ctx->prof.ms_filter);
+					if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
+						launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
+					ev.end();
+					ctx->prof.launches_nn++;
 				}
-				else if (tier == 1)
-					launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
-								   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
-				else
-					launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-				if (rp.normal_shooting)
-					launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-				ev.end();
-				ev.begin(&ctx->prof.ms_filter);
-				if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
-					launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-				ev.end();
-				ctx->prof.launches_nn++;
 				ev.begin(&ctx->prof.ms_accum);
 				for (int k = 0; k < B->nsub; k++)
 					launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
