@@ -168,7 +168,8 @@ typedef struct mulls_profile
 	uint64_t nn_pair_evals; /* source-target distance evaluations issued by those launches */
 	uint64_t nn_src_pts;	/* live source points searched, summed over launches */
 	uint64_t nn_tgt_pts;	/* target points streamed into LDS (once per 512-source job), summed over launches */
-	double ms_host_step;	/* host time spent in the per-iteration algebra (6x6 solves, tests, next states), summed over iterations */
+	double ms_host_step;	/* host time spent in the per-iteration algebra (6x6 solves, tests, next states), summed over iterations; 0 when the
+							   loop steps on the device (every run without per-iteration traces) */
 	double ms_host_wait;	/* host time spent waiting for the device epoch, summed over iterations */
 	double ms_host_launch;	/* host time spent enqueueing the launch set, summed over iterations */
 	uint64_t nn_tgt_unique; /* target points of the searched class clouds (once per cloud), summed over launches */

@@ -1,12 +1,13 @@
 // driver.cpp — host side of libmulls_hip.so: the C ABI of include/mulls_hip.h, device-resident batches and the
 // lock-step ICP iteration loop (reference: CRegistration::mm_lls_icp, include/common/cregistration.hpp:1114-1440).
 //
-// Division of labour (BASELINE.json north_star): correspondences, rejection and the normal-equation reduction run in
-// the HIP kernels of k_setup / k_grid / k_search / k_reduce .hip; per iteration and per pair the host receives 6 x 27 doubles + a few counters, mirrors
-// and solves the 6x6 system, builds the rigid step, applies the convergence / health tests and writes the next
-// PairState.  One H2D copy, three to four launches, one D2H copy and one stream sync advance the whole batch by one
-// ICP iteration.  There is no CPU fallback anywhere in this file: without a usable HIP device every entry point
-// fails with MULLS_E_NO_DEVICE / MULLS_E_HIP.
+// Division of labour (BASELINE.json north_star): correspondences, rejection, the normal-equation reduction AND the per-iteration 6x6 solve with
+// its step / convergence / health tests run in the HIP kernels of k_setup / k_grid / k_search / k_reduce / k_icp .hip; the host queues launch
+// sets, reads one 8-byte word per set to learn how many pairs still iterate, and downloads the result records at the end (batches of up to
+// 1024 pairs: one launch, k_icp).  Only when the caller asks for per-iteration traces does the host step the loop itself: per iteration and
+// pair it then receives the combined 27-double system + a few counters, solves it with the same icp_step.h functions and writes the next
+// PairState.  There is no CPU fallback anywhere in this file: without a usable HIP device every entry point fails with
+// MULLS_E_NO_DEVICE / MULLS_E_HIP.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
