@@ -29,7 +29,7 @@
 
 // auto mode (nn_mode 0): batch sizes the device-resident loop takes (prepare_run)
 #define MULLS_RESIDENT_MIN_PAIRS 4
-#define MULLS_RESIDENT_MAX_PAIRS 1024
+#define MULLS_RESIDENT_MAX_PAIRS 256
 
 using mulls::Mat4;
 using mulls::Mat6;
@@ -729,10 +729,10 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		// applies with its on-chip duplicate table, the loop is the plain mm_lls_icp one (resident_out) and no source class cloud is
 		// so large that one workgroup per pair would be the wrong shape (those pairs are spread over many workgroups by the
 		// lock-step path).  In auto mode it runs batches of MULLS_RESIDENT_MIN_PAIRS .. MAX_PAIRS pairs, where it is the faster of the two
-		// (measured, tools/gpu_modes.py: 60 k vs 45 k registrations/s at 128 pairs, 119 k vs 101 k at 512; the lock-step path wins from 2048
-		// pairs on — its light kernels run several workgroups per CU — and below ~40, where one pair spread over many workgroups beats one
-		// workgroup per pair).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the resident loop (and gets the lock-step LDS
-		// tier where the loop does not apply).
+		// (measured, tools/gpu_modes.py, profiles/r02_zzz_modes.txt: 73 k vs 67 k registrations/s at 128 pairs; the lock-step path, whose
+		// light kernels run several workgroups per CU and whose per-iteration step runs on the device too, wins from 512 pairs on — 151 k vs
+		// 142 k, 174 k vs 146 k at 1024 — and the two tie below ~40).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the
+		// resident loop (and gets the lock-step LDS tier where the loop does not apply).
 		uint32_t max_src = 0;
 		for (const Job &j : B->rjobs_h)
 			max_src = std::max(max_src, j.count);

@@ -1,11 +1,11 @@
-"""Resident loop vs lock-step path by batch size on the bench workload: usage gpu_modes.py"""
+"""Resident loop vs lock-step path by batch size on the bench workload: usage gpu_modes.py [sizes ...]"""
 import sys, warnings, time, os
 sys.path.insert(0, "."); warnings.filterwarnings("ignore")
 import bench
 from mulls_amd import abi, lib
 scenes = bench.build_scenes(64, False, 16)
 P = bench.bench_params()
-for nb in (1, 8, 32, 128, 512, 2048, 4096):
+for nb in ([int(a) for a in sys.argv[1:]] or [1, 8, 32, 128, 512, 1024, 2048, 4096]):
     pairs = [bench.global_pair(scenes, g) for g in range(nb)]
     row = []
     for mode in (4, 3, 0):
