@@ -157,6 +157,32 @@ def test_device_on_the_golden_scan(ctx_auto):
     check_golden(mod, z, ung, out, after)
 
 
+def front_end_golden(dist_filter, voxel_downsample):
+    """tests/golden/front_end_demo.npz: dist_filter and voxel_downsample of the golden scan as the reference's own lines return them
+    (tests/golden/make_front_end_golden.py, written where /root/reference exists)."""
+    mod, scan, _ = golden_case()
+    z = np.load(os.path.join(GOLD, "front_end_demo.npz"))
+    got = [dist_filter(scan, float(lo), float(hi)) for lo, hi in z["dist"]] + [voxel_downsample(scan, float(v)) for v in z["voxels"]]
+    assert [len(x) for x in got] == list(z["sizes"])
+    assert [mod.checksum(x) for x in got] == list(z["checksums"])
+    assert 1000 < int(z["sizes"][-1]) < int(z["sizes"][2]) < len(scan)
+
+
+def test_front_end_golden_fixture():
+    front_end_golden(pyoracle.dist_filter, pyoracle.voxel_downsample)
+
+
+@pytest.mark.gpu
+def test_device_front_end_on_the_golden_scan(ctx_auto):
+    """The device against the reference's own output on the real scan: the voxel grid (mulls_voxel_downsample) and, through
+    mulls_extract_features' pc_raw, the distance filter."""
+    def dist(scan, lo, hi):
+        X = abi.extract_params(classify=abi.classify_params(neighbor_searching_radius=1.5, neighbor_k=30), apply_dist_filter=1, min_dist_used=lo, max_dist_used=hi)
+        return ctx_auto.extract_features(scan, X)[abi.EX_RAW]
+
+    front_end_golden(dist, ctx_auto.voxel_downsample)
+
+
 def test_degenerate_inputs():
     P = abi.classify_params()
     for pts in (np.zeros(0, abi.POINT_DTYPE), abi.make_points(np.zeros((1, 3)), None, [1.0], [0.0]),
