@@ -9,17 +9,18 @@
 //   k_filter      duplicate rule, permanent source compaction, distance + direction rejectors    cregistration.hpp:1755-1830
 //   k_accum       pt2pl / pt2li / pt2pt normal-equation terms, and the posterior residual pass   cregistration.hpp:1976-2275, :2546-2677
 //   k_finish      fixed-order reduction of per-workgroup partials, per-iteration bookkeeping
+//   k_step        correspondence-count test, 6x6 solve, step / convergence tests, posterior residual (icp_step.h)  cregistration.hpp:1296-1401
 //
 // Numerics policy: every float/double operation order follows the reference's C++ expressions; the translation unit
 // is compiled with -ffp-contract=off (the reference build has no FMA: CMakeLists.txt:43, no -march), float sqrt and
 // division are IEEE-correct (hipcc default), accumulators are double.  No MFMA: this is a search plus a reduction.
 //
 // Launch geometry: 256-thread workgroups (4 wave64) unless a kernel says otherwise (k_nn_lds: 1024 lanes per class cloud,
-// k_accum: 128).  The search / filter / accumulate kernels share one static job table (one job = 512 consecutive source
+// k_accum: 1024 / 512 / 256 by trip length, k_step: one wave per pair).  The search / filter / accumulate kernels share one static job table (one job = 512 consecutive source
 // points of one feature class of one pair; the LDS tier's class-level jobs are whole class clouds); dead source points keep
 // their slot and are masked by a flag byte instead of being physically compacted, which makes the job tables iteration-
-// invariant and the whole batch advance with a handful of launches per ICP iteration (push states, search (+ rejection
-// chain), accumulate, finish (+ pull)).
+// invariant and the whole batch advance with a handful of launches per ICP iteration (search (+ rejection chain), accumulate,
+// finish, step, publish; host-stepped loop: push states, ..., finish (+ pull)).
 
 #pragma once
 #include <hip/hip_runtime.h>

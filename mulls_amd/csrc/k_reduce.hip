@@ -1,4 +1,5 @@
-// k_reduce.hip — normal-equation accumulation, per-pair finish, host exchange of states / results, stage helpers
+// k_reduce.hip — normal-equation accumulation, per-pair finish, the loop's per-iteration step on the device (k_step), host exchange of
+// states / results (host-stepped loop), stage helpers
 // (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
 #include "device_util.h"
 #include "accum.h"
