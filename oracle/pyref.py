@@ -95,3 +95,28 @@ def voxel_downsample(pts, voxel_size):
     from oracle import pyoracle
 
     return pyoracle.voxel_downsample(pts, voxel_size, fn=lib().mulls_ref_voxel_downsample)
+
+
+def extract_semantic_pts(scan, X):
+    """dist_filter + the member CFilter::extract_semantic_pts on a cloudblock_t, the reference's own lines (test/mulls_slam.cpp:359-365,
+    cfilter.hpp:2295-2413).  Returns (the clouds of enum mulls_extract_cloud as (n, 48) uint8 records, (gf_down_rate_ground,
+    gf_downsample_rate_nonground) after the call)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from mulls_amd import abi
+
+    raw_in = abi.records(scan)
+    n = len(raw_in)
+    outs = [np.zeros((max(n, 1), abi.POINT_BYTES), np.uint8) for _ in range(abi.EX_COUNT)]
+    out_p = (C.c_void_p * abi.EX_COUNT)(*[o.ctypes.data for o in outs])
+    cap = (C.c_uint32 * abi.EX_COUNT)(*([n] * abi.EX_COUNT))
+    nout = (C.c_uint32 * abi.EX_COUNT)()
+    rates = (C.c_int32 * 2)()
+    f = lib().mulls_ref_extract_semantic_pts
+    f.restype = C.c_int
+    rc = f(raw_in.ctypes.data_as(C.c_void_p), C.c_uint32(n), C.c_uint32(abi.POINT_BYTES), C.byref(X), out_p, cap, nout, rates)
+    if rc != 0:
+        raise RuntimeError("mulls_ref_extract_semantic_pts returned %d" % rc)
+    return [outs[k][: nout[k]].copy() for k in range(abi.EX_COUNT)], (rates[0], rates[1])

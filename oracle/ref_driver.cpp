@@ -353,3 +353,43 @@ extern "C" int mulls_ref_voxel_downsample(const void *pts, uint32_t n, uint32_t 
 		std::memcpy(out, down->points.data(), m * sizeof(Point_T));
 	return 0;
 }
+
+// The frame front end as test/mulls_slam.cpp:359-365 runs it, the reference's own lines: CFilter::dist_filter on pc_raw (when asked for), then
+// the member CFilter::extract_semantic_pts (cfilter.hpp:2295-2413) on a cloudblock_t — the composition the stage-by-stage oracle chain
+// (pyoracle.extract_features) and mulls_extract_features restate.  approx_scanner_height / underground_thre are recovered from the two
+// heights the ABI carries (z_min = -h - 4, z_min_min = -h + u).  out[] in enum mulls_extract_cloud's order.
+extern "C" int mulls_ref_extract_semantic_pts(const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *X, void *const out[MULLS_EX_COUNT],
+											  const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT], int32_t rates_after[2])
+{
+	mulls_cloud c;
+	c.pts = scan, c.n = n, c.stride = stride;
+	lo::cloudblock_Ptr blk(new lo::cloudblock_t());
+	fill_cloud(c, blk->pc_raw);
+	lo::CFilter<Point_T> cf;
+	if (X->apply_dist_filter)
+		cf.dist_filter(blk->pc_raw, X->min_dist_used, X->max_dist_used);
+	const mulls_ground_params &G = X->ground;
+	const mulls_classify_params &K = X->classify;
+	int gdr = G.ground_random_down_rate, ndr = G.nonground_random_down_rate;
+	const float approx_scanner_height = -(X->z_min + 4.0f), underground_thre = X->z_min_min + approx_scanner_height;
+	cf.extract_semantic_pts(blk, X->vf_downsample_resolution, G.grid_resolution, G.max_height_difference, G.neighbor_height_diff, G.max_ground_height, gdr, ndr,
+							K.neighbor_searching_radius, K.neighbor_k, K.edge_thre, K.planar_thre, K.curvature_thre, K.edge_thre_down, K.planar_thre_down,
+							K.use_distance_adaptive_pca != 0, G.distance_weight_downsampling_method, G.standard_distance, G.estimate_ground_normal_method, 2.0f, false,
+							X->apply_scanner_filter != 0, false, K.extract_vertex_points_method, G.min_grid_pt_num, G.reliable_neighbor_grid_num_thre,
+							G.ground_random_down_down_rate, K.neigh_k_min, K.pca_down_rate, G.intensity_thre, K.linear_vertical_sin_high_thre,
+							K.linear_vertical_sin_low_thre, K.planar_vertical_sin_high_thre, K.planar_vertical_sin_low_thre, K.sharpen_with_nms != 0,
+							G.fixed_num_downsampling != 0, G.down_ground_fixed_num, K.pillar_down_fixed_num, K.facade_down_fixed_num, K.beam_down_fixed_num,
+							K.roof_down_fixed_num, K.unground_down_fixed_num, K.beam_height_max, K.roof_height_min, approx_scanner_height, underground_thre,
+							K.feature_pts_ratio_guess, false, false, 0.0f, 0.0f);
+	rates_after[0] = gdr, rates_after[1] = ndr;
+	pcTPtr all[MULLS_EX_COUNT] = {blk->pc_raw,	blk->pc_ground, blk->pc_ground_down, blk->pc_unground,	  blk->pc_pillar,	  blk->pc_beam,	  blk->pc_facade,
+								  blk->pc_roof, blk->pc_pillar_down, blk->pc_beam_down,	blk->pc_facade_down, blk->pc_roof_down, blk->pc_vertex, blk->pc_down};
+	for (int k = 0; k < MULLS_EX_COUNT; k++)
+	{
+		n_out[k] = (uint32_t)all[k]->points.size();
+		const size_t m = std::min<size_t>(all[k]->points.size(), cap[k]);
+		if (m && out[k])
+			std::memcpy(out[k], all[k]->points.data(), m * sizeof(Point_T));
+	}
+	return 0;
+}

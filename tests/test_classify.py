@@ -398,6 +398,33 @@ def test_dist_filter_and_voxel_downsample_oracle_equals_reference_lines():
     assert len(pyoracle.voxel_downsample(recs[:0], 0.2)) == 0 and len(pyoracle.voxel_downsample(recs[:1], 0.2)) == 1
 
 
+@pytest.mark.skipif(not pyref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_chain_equals_the_reference_member():
+    """The composition: dist_filter + the reference's member CFilter::extract_semantic_pts on a cloudblock_t (its own lines: which stage feeds
+    which, the scanner filter's heights, 1.5 x radius for the key points' suppression, pc_down) against the oracle's chain stage by stage —
+    what mulls_extract_features is held to on the GPU box — every cloud byte for byte (pc_raw / pc_down on position, intensity, curvature:
+    upstream's ground filter writes normals and heights into the cloud it is given)."""
+    scan = with_ego_and_ghost_points(raw_scan(14, n_beams=48, n_az=1400))
+    G = abi.ground_params(apply_grid_wise_outlier_filter=1)
+    cases = [abi.extract_params(ground=G, classify=abi.classify_params(neighbor_k=30, vertex_curvature_non_max_radius=np.float32(1.5 * 1.0)), apply_scanner_filter=1),
+             abi.extract_params(ground=G, classify=abi.classify_params(neighbor_searching_radius=0.8, neighbor_k=30,
+                                                                       vertex_curvature_non_max_radius=np.float32(1.5 * np.float32(0.8))),
+                                apply_scanner_filter=1, apply_dist_filter=1, min_dist_used=1.5, max_dist_used=30.0, vf_downsample_resolution=0.07)]
+    for X in cases:
+        a = pyoracle.extract_features(scan, X)
+        b, rates = pyref.extract_semantic_pts(scan, X)
+        assert rates == (X.ground.ground_random_down_rate, X.ground.nonground_random_down_rate)
+        for k in range(abi.EX_COUNT):
+            if k in (abi.EX_RAW, abi.EX_DOWN):
+                pa, pb = abi.points_of(a[k]), abi.points_of(b[k])
+                assert len(pa) == len(pb) and all(np.array_equal(pa[f], pb[f]) for f in ("x", "y", "z", "intensity", "curvature")), k
+            else:
+                assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        assert len(a[abi.EX_GROUND]) > 1000 and len(a[abi.EX_PILLAR + abi.CL_FACADE]) > 1000 and len(a[abi.EX_VERTEX]) > 100
+        if X.vf_downsample_resolution >= 0.001:
+            assert len(a[abi.EX_DOWN]) < len(a[abi.EX_RAW]) < len(scan)
+
+
 def test_scanner_filter_oracle_equals_reference_lines():
     scan = with_ego_and_ghost_points(raw_scan(16))
     X = abi.extract_params(apply_scanner_filter=1)
