@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=4096, help="weak scaling: scan pairs per GPU per step (>= 2048: two sub-batches in flight)")
+    ap.add_argument("--pairs", type=int, default=4096, help="weak scaling: scan pairs per GPU per step (one lock-step batch: one launch set per ICP iteration)")
     ap.add_argument("--total-pairs", type=int, default=0, help="strong scaling (configs[3]): this many pairs of the global list, block-partitioned over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
