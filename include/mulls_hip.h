@@ -106,10 +106,11 @@ typedef struct mulls_params
 	uint8_t keep_less_source_points; /* false */
 	uint8_t faithful;				 /* ABI-only. 1 = reproduce reference quirks (pt2li off-diagonals dropped,
 										vertex residual weighted by d^2); 0 = mathematically intended version */
-	uint8_t rejector_strict;		 /* ABI-only. pcl::registration::CorrespondenceRejectorDistance keeps a correspondence when distance <= max^2
-										(0, the default: as SURVEY.md A.4-3 restates it, NaN distances kept) or when distance < max^2 (1: strict,
-										NaN dropped) — PCL is not in this image and releases are remembered both ways; the two differ only on
-										correspondences whose float distance equals the float threshold exactly (tests/test_pcl_operators.py counts them) */
+	uint8_t rejector_strict;		 /* ABI-only. 1 (default): pcl::registration::CorrespondenceRejectorDistance::getRemainingCorrespondences as PCL 1.7-1.12 ship it
+										(registration/src/correspondence_rejection_distance.cpp: `original_correspondences[i].distance < max_distance_`,
+										max_distance_ = the float square set by setMaximumDistance; a NaN distance is dropped).  0: `distance <= max^2` (NaN kept),
+										the reading SURVEY.md A.4-3 wrote down.  The two differ only on correspondences whose float distance equals the float
+										threshold exactly (tests/test_pcl_operators.py counts them: none on the bench workload) */
 	uint8_t reserved_;
 	float sigma_thre;				 /* 0.5 */
 	float min_neccessary_corr_ratio; /* 0.03 */

@@ -359,6 +359,7 @@ def default_params(**overrides):
     p.normal_bearing = 45.0
     p.keep_less_source_points = 0
     p.faithful = 1
+    p.rejector_strict = 1
     p.sigma_thre = 0.5
     p.min_neccessary_corr_ratio = 0.03
     p.max_bearable_rotation_d = 45.0

@@ -113,7 +113,7 @@ Layout carve(unsigned char *base, uint32_t n, uint32_t K, uint32_t n_in)
 void random_downsample(Bytes &c, int keep_number, uint64_t seed, int cloud_id)
 {
 	const uint32_t n = (uint32_t)(c.size() / REC);
-	if ((long)n <= (long)keep_number)
+	if (keep_number < 0 || (long)n <= (long)keep_number) // size_t comparison upstream (:608): a negative count keeps every point
 		return;
 	std::vector<uint8_t> mask(n);
 	thin_mask(mask.data(), n, keep_number, seed, cloud_id);
@@ -131,7 +131,7 @@ void random_downsample(Bytes &c, int keep_number, uint64_t seed, int cloud_id)
 void xy_normal_balanced_downsample(Bytes &c, int keep_number_per_sector, int sector_num, uint64_t seed, int cloud_id)
 {
 	const uint32_t n = (uint32_t)(c.size() / REC);
-	if ((long)n <= (long)keep_number_per_sector)
+	if (keep_number_per_sector < 0 || (long)n <= (long)keep_number_per_sector) // size_t comparison upstream (:555)
 		return;
 	std::vector<Bytes> sectors(sector_num);
 	const double angle_per_sector = 360.0 / sector_num;

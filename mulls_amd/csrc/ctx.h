@@ -69,6 +69,13 @@ inline int abi_caught(mulls_ctx *ctx) noexcept
 		}
 	return rc;
 }
+// Scope guard of an entry point that queues asynchronous copies into caller buffers or into host vectors of its own: whichever way
+// the function is left — an error return included — the stream is idle before those buffers go back to their owners.
+struct StreamDrain
+{
+	hipStream_t st;
+	~StreamDrain() { (void)hipStreamSynchronize(st); }
+};
 } // namespace mulls
 
 namespace
@@ -105,7 +112,7 @@ inline uint64_t splitmix64(uint64_t &x)
 // CFilter::random_downsample_pcl semantics (cfilter.hpp:606-628) expressed as a keep mask; returns the new size
 uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, int cloud_id)
 {
-	if ((long)n <= (long)keep_number)
+	if (keep_number < 0 || (long)n <= (long)keep_number) // upstream compares `points.size() <= keep_number` as size_t: a negative count keeps every point
 	{
 		std::memset(mask, 1, n);
 		return n;

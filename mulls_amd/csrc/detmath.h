@@ -3,7 +3,11 @@
 // (the library is built -ffp-contract=off; the only fused operation is the explicit fma of the exact product), no libm.
 //
 // Evaluation is in double-double (~104 bits) and the result is the rounding of that value to double, i.e. the correctly
-// rounded function value except when the true value lies within ~2^-100 of a rounding boundary.  The reference calls glibc's
+// rounded function value except when the true value lies within ~2^-100 of a rounding boundary.  In front of it sits a quick
+// phase in Ziv's manner for the arguments an ICP step produces (|angle| <= 0.5 rad, tan <= 1/8): the leading correction term in
+// double-double, the tail of the series in double, an explicit bound on what that leaves out — the value is returned only when
+// rounding it gives the same double with the bound added and subtracted, i.e. when it IS the correctly rounded result; otherwise
+// (a few calls in a million at ICP angles) the full evaluation runs.  Same bits either way, a tenth of the operations.  The reference calls glibc's
 // sin / cos / atan2 (construct_trans_a cregistration.hpp:2740-2764, get_quat_euler_jacobi :2795-2819, Eigen::AngleAxisd :1345);
 // glibc 2.35 documents an error below 1 ulp for them, not 0.5: its results equal the values computed here except at the rare
 // arguments where glibc itself misrounds (tests/test_detmath.py counts them over the ICP range of angles).
@@ -165,9 +169,44 @@ MULLS_HD inline double trig(double x, int which)
 		return x - x + (x - x) / (x - x); // as NaN (an Euler angle of 1e12 rad is a diverged solve; its translation fails the step test first)
 	if (x == 0.0)
 		return which ? 1.0 : x; // sin keeps the sign of zero
+	const double ax = std::fabs(x);
+#ifndef MULLS_DETMATH_NO_QUICK // (tests/test_detmath.py builds the header both ways and demands equal bits)
+	if (ax <= 0.5 && ax >= 0x1p-300)
+	{
+		// quick phase: x^2 exactly (s), the series' first correction in double-double (c1), the rest in double (c2)
+		const dd s = two_prod(x, x);
+		const double s1 = s.hi;
+		double hi, lo, err;
+		if (which == 0)
+		{
+			dd t = two_prod(x, s.hi); // x^3
+			t.lo += x * s.lo;
+			dd c1 = two_prod(t.hi, -0x1.5555555555555p-3); // -x^3 / 6
+			c1.lo += t.hi * -0x1.5555555555555p-57 + t.lo * -0x1.5555555555555p-3;
+			const double p = 0x1.1111111111111p-7 + s1 * (-0x1.a01a01a01a01ap-13 + s1 * (0x1.71de3a556c734p-19 + s1 * (-0x1.ae64567f544e4p-26 + s1 * (0x1.6124613a86d09p-33 + s1 * (-0x1.ae7f3e733b81fp-41 + s1 * 0x1.952c77030ad4ap-49)))));
+			const double c2 = (t.hi * s1) * p; // x^5 / 5! - x^7 / 7! + ... + x^17 / 17!
+			const dd y = fast_two_sum(x, c1.hi);
+			hi = y.hi;
+			lo = y.lo + (c1.lo + c2);
+			err = std::fabs(c2) * 0x1p-48 + ax * 0x1p-100;
+		}
+		else
+		{
+			const double q = 0x1.5555555555555p-5 + s1 * (-0x1.6c16c16c16c17p-10 + s1 * (0x1.a01a01a01a01ap-16 + s1 * (-0x1.27e4fb7789f5cp-22 + s1 * (0x1.1eed8eff8d898p-29 + s1 * (-0x1.93974a8c07c9dp-37 + s1 * (0x1.ae7f3e733b81fp-45 + s1 * -0x1.6827863b97d97p-53))))));
+			const double c2 = (s1 * s1) * q; // x^4 / 4! - x^6 / 6! + ... - x^18 / 18!
+			const dd y = fast_two_sum(1.0, -0.5 * s.hi); // -x^2 / 2 is exact in (s.hi, s.lo)
+			hi = y.hi;
+			lo = y.lo + (-0.5 * s.lo + c2);
+			err = c2 * 0x1p-48 + 0x1p-100;
+		}
+		const double out = hi + lo;
+		if (out == hi + (lo + err) && out == hi + (lo - err))
+			return out;
+	}
+#endif
 	dd r = {x, 0.0};
 	int quad = 0;
-	if (std::fabs(x) > 0.78539816339744828) // beyond pi/4: r = x - k * pi/2 with pi/2 = P1 + P2 + P3 (159 bits)
+	if (ax > 0.78539816339744828) // beyond pi/4: r = x - k * pi/2 with pi/2 = P1 + P2 + P3 (159 bits)
 	{
 		const double k = std::nearbyint(x * 0x1.45f306dc9c883p-1); // round to nearest even, like the default rounding mode everywhere else
 		const dd t1 = two_prod(k, 0x1.921fb54442d18p+0);
@@ -226,6 +265,32 @@ MULLS_HD inline double atan2_cr(double y, double x)
 		res = (ax == inf && ay == inf) ? (xneg ? 3.0 * PIO4_HI : PIO4_HI) : (ay == inf ? PIO2_HI : (xneg ? PI_HI : 0.0));
 	else
 	{
+#ifndef MULLS_DETMATH_NO_QUICK
+		if (!xneg && ay <= 0.125 * ax && ay >= 0x1p-300 && ax >= 0x1p-300 && ax <= 0x1p300)
+		{
+			// quick phase (see trig): z = ay / ax as quotient + remainder, z^3 / 3 in double-double, the rest of the series in double
+			const double q = ay / ax;
+			if (q >= 0x1p-200)
+			{
+				const double ql = __builtin_fma(-q, ax, ay) / ax; // z = q + ql
+				dd s = two_prod(q, q);						   // z^2
+				s.lo += 2.0 * q * ql;
+				dd t = two_prod(q, s.hi); // z^3
+				t.lo += q * s.lo + ql * s.hi;
+				dd c1 = two_prod(t.hi, -0x1.5555555555555p-2); // -z^3 / 3
+				c1.lo += t.hi * -0x1.5555555555555p-56 + t.lo * -0x1.5555555555555p-2;
+				const double s1 = s.hi;
+				const double p = 0x1.999999999999ap-3 + s1 * (-0x1.2492492492492p-3 + s1 * (0x1.c71c71c71c71cp-4 + s1 * (-0x1.745d1745d1746p-4 + s1 * (0x1.3b13b13b13b14p-4 + s1 * (-0x1.1111111111111p-4 + s1 * (0x1.e1e1e1e1e1e1ep-5 + s1 * (-0x1.af286bca1af28p-5 + s1 * (0x1.8618618618618p-5 + s1 * (-0x1.642c8590b2164p-5 + s1 * (0x1.47ae147ae147bp-5 + s1 * -0x1.2f684bda12f68p-5))))))))));
+				const double c2 = (t.hi * s1) * p; // z^5 / 5 - z^7 / 7 + ... - z^27 / 27
+				const dd yv = fast_two_sum(q, c1.hi);
+				const double lo = yv.lo + ((ql + c1.lo) + c2);
+				const double err = c2 * 0x1p-48 + q * 0x1p-100;
+				const double out = yv.hi + lo;
+				if (out == yv.hi + (lo + err) && out == yv.hi + (lo - err))
+					return std::signbit(y) ? -out : out;
+			}
+		}
+#endif
 		const bool swap = ay > ax;
 		dd z = div(dd{swap ? ax : ay, 0.0}, dd{swap ? ay : ax, 0.0}); // in [0, 1]
 		// halve the angle until tan is small: atan z = 2 atan(z / (1 + sqrt(1 + z^2)))

@@ -944,6 +944,7 @@ extern "C"
 		p->apply_intersection_filter = 1;
 		p->normal_bearing = 45.0f;
 		p->faithful = 1;
+		p->rejector_strict = 1; // pcl::registration::CorrespondenceRejectorDistance: `distance < max_distance_` (correspondence_rejection_distance.cpp)
 		p->sigma_thre = 0.5f;
 		p->min_neccessary_corr_ratio = 0.03f;
 		p->max_bearable_rotation_d = 45.0f;
@@ -979,13 +980,13 @@ extern "C"
 
 	void mulls_destroy(mulls_ctx *ctx)
 	{
-		if (ctx && ctx->gf_buf)
-			(void)hipFree(ctx->gf_buf);
-		if (ctx && ctx->cl_buf)
-			(void)hipFree(ctx->cl_buf);
 		if (!ctx)
 			return;
 		(void)hipSetDevice(ctx->device);
+		if (ctx->gf_buf)
+			(void)hipFree(ctx->gf_buf);
+		if (ctx->cl_buf)
+			(void)hipFree(ctx->cl_buf);
 		if (ctx->scratch)
 			mulls_batch_destroy(ctx, ctx->scratch);
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
@@ -2168,6 +2169,7 @@ extern "C"
 		std::memset(rp, 0, sizeof(*rp));
 		rp->used[cls] = 1;
 		rp->faithful = 1;
+		rp->rej_strict = P.rejector_strict != 0;
 		rp->resid_from_iter = 2;
 		if ((rc = take_epochs(ctx, B, 4u, &rp->tick_base)) != MULLS_OK)
 			return rc;

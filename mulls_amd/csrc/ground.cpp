@@ -243,6 +243,7 @@ extern "C"
 			return MULLS_OK; // (the reference divides by a zero sample count here)
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
+		const mulls::StreamDrain drain{st}; // error returns below leave copies into `unground` / `g` queued
 		const GfArena a = gf_layout(n, false, false);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
@@ -318,6 +319,7 @@ extern "C"
 		}
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
+		const mulls::StreamDrain drain{st};
 		const GfArena a = gf_layout(n, false, true);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
@@ -363,6 +365,7 @@ extern "C"
 			return MULLS_OK;
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
+		const mulls::StreamDrain drain{st}; // error returns below leave copies into out[] / `g` queued
 		const bool scanner = X->apply_scanner_filter != 0, dist = X->apply_dist_filter != 0, prefilter = scanner || dist;
 		const bool voxels = !(X->vf_downsample_resolution < 0.001); // voxel_downsample hands the cloud on below 0.001 m (:90-97)
 		const GfArena a = gf_layout(n_in, prefilter, voxels);

@@ -16,6 +16,9 @@ struct SolveWs
 	int row_of[6], p, regular;
 };
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+#ifndef MULLS_SOLVE_MARK // tools/gpu_solve_bench.hip defines it to time the sections; nothing in the library
+#define MULLS_SOLVE_MARK(k)
+#endif
 __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpConst &K, const double *comb, int i, SolveWs &w)
 {
 	const int l = (int)threadIdx.x; // 0..63
@@ -35,6 +38,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 	if (l == 0)
 		w.regular = 1;
 	WSYNC();
+	MULLS_SOLVE_MARK(0);
 	// invert6: row-pivoted LU ...
 	for (int col = 0; col < 6; col++)
 	{
@@ -82,6 +86,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 		}
 		WSYNC();
 	}
+	MULLS_SOLVE_MARK(1);
 	// ... solved against the identity column by column (one lane per column, the factors in registers)
 	if (l < 6)
 	{
@@ -110,6 +115,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 			w.inv[r + 6 * l] = y[r];
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(2);
 	// solve_step: x = N^-1 b
 	if (l < 6)
 	{
@@ -119,6 +125,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 		h.x[l] = acc;
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(3);
 	// quat_euler_jacobian's half-angle sines / cosines (float locals in the reference, :2797-2804) and euler_step_to_matrix's
 	if (l < 12)
 	{
@@ -130,6 +137,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 			w.sc[q] = v; // sa ca sb cb sg cg
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(4);
 	if (l == 0)
 	{
 		const float sr = w.scf[0], cr = w.scf[1], sp = w.scf[2], cp = w.scf[3], sy = w.scf[4], cy = w.scf[5];
@@ -164,6 +172,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 		m.at(3, 3) = 1.0;
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(5);
 	// cofactor = N^-1 with its rotational blocks propagated to quaternion space
 	if (l < 36)
 		h.cofactor.v[l] = w.inv[l];
@@ -184,6 +193,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 			h.cofactor.v[(3 + r) + 6 * c] = w.J[r * 3 + 0] * w.inv[(3 + 0) + 6 * c] + w.J[r * 3 + 1] * w.inv[(3 + 1) + 6 * c] + w.J[r * 3 + 2] * w.inv[(3 + 2) + 6 * c];
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(6);
 	// step-size and convergence tests (icp_step.h: step_solve)
 	if (l == 0)
 	{
@@ -211,6 +221,7 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 			w.p = 1;
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(7);
 	if (w.p == 1) // initial_guess = TempTran * initial_guess (:1400)
 	{
 		if (l < 16)
@@ -226,4 +237,5 @@ __device__ __forceinline__ void solve_wave(mulls::PairIter &h, const mulls::IcpC
 			h.guess.v[l] = w.newg[l];
 	}
 	WSYNC();
+	MULLS_SOLVE_MARK(8);
 }

@@ -78,6 +78,7 @@ def load():
     lib.mulls_extract_default_params.argtypes = [C.POINTER(abi.ExtractParams)]
     lib.mulls_extract_default_params.restype = None
     lib.mulls_extract_features.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ExtractParams), C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mulls_voxel_downsample.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_float, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_write_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]

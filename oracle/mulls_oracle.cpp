@@ -423,7 +423,7 @@ class KdTree
 //   [4] ... with a NaN distance (kept by `!(d > max)`, dropped by `d < max`)
 //   [5] brute-force nearest-neighbour queries   [6] ... whose minimum distance is shared by two or more targets (FLANN's tie order is implementation-defined)
 std::atomic<unsigned long long> g_census[8];
-bool g_rejector_strict = false; // mulls_params.rejector_strict of the registration being run (set on entry; the OpenMP sections read it)
+bool g_rejector_strict = true; // mulls_params.rejector_strict of the registration being run (set on entry; the OpenMP sections read it)
 
 int brute_nearest(const Cloud &tgt, const Pt &q, float &d2)
 {
@@ -1006,7 +1006,7 @@ inline uint64_t splitmix64(uint64_t &x)
 }
 void random_downsample(Cloud &c, int keep_number, uint64_t seed, int cloud_id)
 {
-	if ((long)c.size() <= (long)keep_number)
+	if (keep_number < 0 || (long)c.size() <= (long)keep_number) // `points.size() <= keep_number` compares as size_t upstream: a negative count keeps all
 		return;
 	if (keep_number == 0)
 	{
@@ -1896,6 +1896,7 @@ namespace
 		p->apply_intersection_filter = 1;
 		p->normal_bearing = 45.0f;
 		p->faithful = 1;
+		p->rejector_strict = 1;
 		p->sigma_thre = 0.5f;
 		p->min_neccessary_corr_ratio = 0.03f;
 		p->max_bearable_rotation_d = 45.0f;
@@ -1989,7 +1990,7 @@ extern "C"
 		}
 		Corrs cf;
 		size_t n0 = S.size();
-		g_rejector_strict = false; // the stage entry point has no parameter block: the default form
+		g_rejector_strict = true; // the stage entry point has no parameter block: the default form (PCL's `<`)
 		determine_corres(S, orig, T, &tree, dis_thre, cf, false, normal_check != 0, angle_thre_degree, nn_mode != 0);
 		(void)n0;
 		for (size_t k = 0; k < orig.size(); k++) // identity when no compaction happened
@@ -2247,7 +2248,7 @@ bool non_max_suppress(Cloud &cloud_in, Cloud &cloud_out, float nms_radius)
 // xy_normal_balanced_downsample(cloud_in_out, keep_number_per_sector, sector_num)
 bool xy_normal_balanced_downsample(Cloud &cloud, int keep_number_per_sector, int sector_num, uint64_t seed, int cloud_id)
 {
-	if ((long)cloud.size() <= (long)keep_number_per_sector)
+	if (keep_number_per_sector < 0 || (long)cloud.size() <= (long)keep_number_per_sector) // size_t comparison upstream (:554)
 		return false;
 	std::vector<Cloud> sectors(sector_num);
 	const double angle_per_sector = 360.0 / sector_num;

@@ -113,6 +113,7 @@ extern "C" int mulls_ref_icp_3dof_ground(const mulls_pair *pair, const mulls_par
 	fill_constraint(pair, con);
 	Eigen::Matrix4d guess;
 	std::memcpy(guess.data(), pair->init_guess, sizeof(double) * 16);
+	pcl::registration::rejector_strict_flag() = P->rejector_strict != 0;
 	lo::CRegistration<Point_T> creg;
 	const bool ok = creg.lls_icp_3dof_ground(con, P->max_iter_num, P->dis_thre_unit, P->converge_translation, P->converge_rotation_d, P->dis_thre_min,
 												P->dis_thre_update_rate, std::string(P->weight_strategy), guess, P->keep_less_source_points != 0,
@@ -135,6 +136,7 @@ extern "C" int mulls_ref_icp_4dof_global(const mulls_pair *pair, float heading_s
 	con.block2->local_station.x = station[0];
 	con.block2->local_station.y = station[1];
 	con.block2->local_station.z = station[2];
+	pcl::registration::rejector_strict_flag() = true; // the trials run with mulls_default_params
 	lo::CRegistration<Point_T> creg;
 	const bool ok = creg.mm_lls_icp_4dof_global(con, heading_step_d, max_iter_num, dis_thre_unit, converge_translation, converge_translation,
 												   dis_thre_min, dis_thre_update_rate);
@@ -185,6 +187,7 @@ extern "C" int mulls_ref_icp(const mulls_pair *pair, const mulls_params *P, mull
 	Eigen::Matrix4d guess;
 	std::memcpy(guess.data(), pair->init_guess, sizeof(double) * 16);
 
+	pcl::registration::rejector_strict_flag() = P->rejector_strict != 0;
 	lo::CRegistration<Point_T> creg;
 	const int code = creg.mm_lls_icp(con, P->max_iter_num, P->dis_thre_unit, P->converge_translation, P->converge_rotation_d, P->dis_thre_min,
 									 P->dis_thre_update_rate, std::string(P->used_feature_type), std::string(P->weight_strategy),

@@ -480,10 +480,18 @@ struct KdTree
 	}
 	int nearestKSearch(const PointT &q, int k, std::vector<int> &idx, std::vector<float> &d2) const
 	{
+		// FLANN's KNN result sets admit a candidate only while `dist < worst_dist`: a NaN distance (a query with a NaN coordinate — the
+		// clouds after a singular solve) never is, so such a query finds nothing.  (pcl::KdTreeFLANN::nearestKSearch then still returns k
+		// with its output vectors as the previous query left them — undefined contents upstream; defined here, in the oracle and on the
+		// device as "no neighbour", SURVEY B-11.)
 		std::vector<std::pair<float, int>> all;
 		if (cloud)
 			for (size_t i = 0; i < cloud->points.size(); i++)
-				all.push_back(std::make_pair(shim_l2(q, cloud->points[i]), (int)i));
+			{
+				const float d = shim_l2(q, cloud->points[i]);
+				if (d == d)
+					all.push_back(std::make_pair(d, (int)i));
+			}
 		int kk = std::min<int>(k, (int)all.size());
 		std::partial_sort(all.begin(), all.begin() + kk, all.end());
 		idx.resize(kk);
@@ -682,7 +690,13 @@ struct CorrespondenceEstimationNormalShooting
 	}
 };
 
-// CorrespondenceRejectorDistance without a data container
+// CorrespondenceRejectorDistance without a data container (registration/src/correspondence_rejection_distance.cpp: `distance < max_distance_`;
+// ref_driver.cpp switches to the `<=` reading when mulls_params.rejector_strict is 0, so both forms stay pinned against the reference lines)
+inline bool &rejector_strict_flag()
+{
+	static bool strict = true;
+	return strict;
+}
 struct CorrespondenceRejectorDistance
 {
 	boost::shared_ptr<Correspondences> input;
@@ -695,7 +709,7 @@ struct CorrespondenceRejectorDistance
 			return; // PCL returns without touching the output
 		Correspondences kept;
 		for (size_t i = 0; i < input->size(); i++)
-			if (!((*input)[i].distance > max_distance_))
+			if (rejector_strict_flag() ? (*input)[i].distance < max_distance_ : !((*input)[i].distance > max_distance_))
 				kept.push_back((*input)[i]);
 		out.swap(kept);
 	}

@@ -20,6 +20,15 @@ def dm(tmp_path_factory):
     return C.CDLL(so)
 
 
+@pytest.fixture(scope="module")
+def dm_full(tmp_path_factory):
+    """the same header with the quick phase compiled out: every call takes the full double-double evaluation"""
+    so = str(tmp_path_factory.mktemp("dmf") / "libdmf.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-DMULLS_DETMATH_NO_QUICK", "-shared", "-fPIC",
+                           os.path.join(ROOT, "tests", "detmath_harness.cpp"), "-o", so])
+    return C.CDLL(so)
+
+
 def call(fn, *arrs):
     n = len(arrs[0])
     out = np.empty(n)
@@ -79,3 +88,30 @@ def test_glibc_agrees_over_the_icp_range(dm):
     da = np.abs(call(dm.dm_atan2, y, w) - libm("atan2", y, w)) / np.spacing(np.arctan2(y, w))
     assert da.max() <= 1.0 and (da > 0).mean() < 5e-3
     print("glibc != correctly rounded: sin %.2e cos %.2e atan2 %.2e of the calls" % ((ds > 0).mean(), (dc > 0).mean(), (da > 0).mean()))
+
+
+def test_quick_phase_returns_the_bits_of_the_full_evaluation(dm, dm_full):
+    """Ziv's quick phase (detmath.h) in front of the double-double evaluation: the same double on every argument — two million angles
+    over the ICP range and beyond it, quaternion pairs for atan2 — and it is the path taken (the timing ratio says so)."""
+    import time
+
+    rng = np.random.default_rng(6)
+    n = 1000000
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-16), np.log(0.5), n)) * rng.choice([-1, 1], n), rng.uniform(-0.6, 0.6, n // 4),
+                        [0.5, -0.5, 0.4999999999999999, 2.0 ** -300, 2.0 ** -301, 2.0 ** -27, 2.0 ** -26 * 1.5, 1e-8, 3e-5]])
+    t0 = time.perf_counter()
+    sq, cq = call(dm.dm_sin, x), call(dm.dm_cos, x)
+    t1 = time.perf_counter()
+    sf, cf = call(dm_full.dm_sin, x), call(dm_full.dm_cos, x)
+    t2 = time.perf_counter()
+    assert (sq.view(np.uint64) == sf.view(np.uint64)).all() and (cq.view(np.uint64) == cf.view(np.uint64)).all()
+    y = np.concatenate([np.exp(rng.uniform(np.log(1e-16), np.log(0.2), n)) * rng.choice([-1, 1], n), rng.uniform(-1, 1, n // 4)])
+    w = np.concatenate([np.sqrt(1 - y[:n] ** 2), rng.uniform(-1, 1, n // 4)])
+    aq, af = call(dm.dm_atan2, y, w), call(dm_full.dm_atan2, y, w)
+    assert (aq.view(np.uint64) == af.view(np.uint64)).all()
+    # scaled operands: towards the ends of the exponent range the quick phase steps aside
+    for k in (2.0 ** -250, 2.0 ** 250, 3.7e-120, 2.0 ** -290, 2.0 ** 295):
+        ys, ws = y[:20000] * k, w[:20000] * k
+        assert (call(dm.dm_atan2, ys, ws).view(np.uint64) == call(dm_full.dm_atan2, ys, ws).view(np.uint64)).all()
+    print("sin+cos of %d angles: quick %.2f s, full %.2f s" % (len(x), t1 - t0, t2 - t1))
+    assert (t1 - t0) < 0.6 * (t2 - t1)

@@ -6,9 +6,9 @@ count how often the bench workload lands on an input that tells them apart.
       `if (distance[0] > max_dist_sqr) continue;` with max_dist_sqr = max_distance * max_distance in double  — restated as is;
       differs from `>=` only when (double)d2 == max_dist_sqr exactly                              -> census "radius_equal"
   pcl/registration/correspondence_rejection_distance.{h,cpp}  CorrespondenceRejectorDistance::getRemainingCorrespondences
-      setMaximumDistance(float d) stores d * d; the kept test is remembered as `distance <= max` (kept when
-      !(distance > max), NaN kept) and as `distance < max` (NaN dropped)                           -> census "rejector_equal", "rejector_nan"
-      both forms exist in this library: mulls_params.rejector_strict (default 0 = the SURVEY's form)
+      setMaximumDistance(float d) stores d * d; PCL 1.7-1.12 keep a correspondence when `distance < max_distance_` (NaN dropped) —
+      the library's default, mulls_params.rejector_strict = 1 —; SURVEY A.4-3 had written `!(distance > max)` (NaN kept), still
+      selectable as rejector_strict = 0                                                           -> census "rejector_equal", "rejector_nan"
   flann/algorithms/kdtree_single_index.h  KDTreeSingleIndex::findNeighbors (exact, epsilon 0, L2_Simple<float>)
       the order among targets at exactly the same distance is implementation-defined; here: lowest index     -> census "brute_ties"
   Eigen/src/LU/PartialPivLU.h  inverse() of a fixed 6x6 — row-pivoted LU, columns solved against the identity; restated in
@@ -51,8 +51,9 @@ def test_strict_rejector_differs_only_on_the_boundary():
     """rejector_strict = 1 (`distance < max^2`) and 0 (`distance <= max^2`): identical results unless a correspondence sits exactly
     on the threshold — shown on the bench-like pairs (identical) and on a constructed boundary case (one correspondence apart)."""
     pairs = _bench_like_pairs(2)
-    P0 = abi.kitti_params(max_iter_num=6)
-    P1 = abi.kitti_params(max_iter_num=6, rejector_strict=1)
+    P0 = abi.kitti_params(max_iter_num=6, rejector_strict=0)
+    P1 = abi.kitti_params(max_iter_num=6)
+    assert P1.rejector_strict == 1  # the default is PCL's operator
     for p in pairs:
         a, b = pyoracle.icp(p, P0)[0], pyoracle.icp(p, P1)[0]
         assert list(a.T) == list(b.T) and list(a.ncorr) == list(b.ncorr) and a.iters == b.iters
@@ -67,11 +68,11 @@ def test_strict_rejector_differs_only_on_the_boundary():
     tp = abi.make_points(tgt, nrm, np.full(len(tgt), 10, np.float32), np.zeros(len(tgt), np.float32))
     sp = abi.make_points(src, nrm, np.full(len(tgt), 10, np.float32), np.zeros(len(tgt), np.float32))
     m0, d0, f0 = pyoracle.correspond(sp, tp, thr)
-    assert (d0 == np.float32(thr * thr)).all() and (f0 & 2).all()  # `<=`: every correspondence kept
+    assert (d0 == np.float32(thr * thr)).all() and not (f0 & 2).any()  # the stage entry point runs the default `<`: none kept
     pair = boundary_pair()
     kw = dict(used_feature_type="100000", max_iter_num=1, dis_thre_unit=thr, apply_intersection_filter=0)
-    assert pyoracle.icp(pair, abi.default_params(**kw))[0].ncorr[0] == 289
-    assert pyoracle.icp(pair, abi.default_params(rejector_strict=1, **kw))[0].ncorr[0] == 0  # `<`: none
+    assert pyoracle.icp(pair, abi.default_params(rejector_strict=0, **kw))[0].ncorr[0] == 289  # `<=`: every correspondence kept
+    assert pyoracle.icp(pair, abi.default_params(**kw))[0].ncorr[0] == 0  # `<` (default): none
 
 
 def boundary_pair(thr=0.5):
