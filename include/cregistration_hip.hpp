@@ -457,7 +457,8 @@ inline bool update_local_map(cloudblock_Ptr local_map, cloudblock_Ptr last_targe
 //     #ifdef MULLS_USE_HIP
 //         return lo::hip::fast_ground_filter<PointT>(cloud_in, cloud_ground, cloud_ground_down, cloud_unground, cloud_curb, min_grid_pt_num, ...);
 //     #endif
-// Differences: estimate_ground_normal_method must be 0 (1 / 2 / 3 throw: PCA / PCL-RANSAC normals are not built), fast_ground_filter's cloud_in
+// Differences: what PCL computes inside estimate_ground_normal_method 1 - 3 (NormalEstimationOMP, SACSegmentation) is the library's restatement of
+// it (include/mulls_hip.h: mulls_ground_params), fast_ground_filter's cloud_in
 // keeps its contents (upstream writes normals and data[3] into it; the clouds handed out carry them), the fixed-number selections are seeded with
 // `feature_rng_seed()` (upstream: pcl::RandomSample seeded with time(NULL)), and what pcl::PCA / Eigen compute inside classify_nground_pts is
 // the library's restatement.
@@ -485,7 +486,7 @@ inline bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &clou
 							   bool fixed_num_downsampling = false, int down_ground_fixed_num = 1000, bool detect_curb_or_not = false,
 							   float intensity_thre = FLT_MAX, bool apply_grid_wise_outlier_filter = false, float outlier_std_scale = 3.0)
 {
-	(void)cloud_curb, (void)normal_estimation_radius, (void)detect_curb_or_not; // curb detection is commented out upstream (:1990-2010)
+	(void)cloud_curb, (void)detect_curb_or_not; // curb detection is commented out upstream (:1990-2010)
 	mulls_ctx *ctx = thread_context();
 	mulls_ground_params P;
 	mulls_ground_default_params(&P);
@@ -499,6 +500,7 @@ inline bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &clou
 	P.nonground_random_down_rate = nonground_random_down_rate;
 	P.reliable_neighbor_grid_num_thre = reliable_neighbor_grid_num_thre;
 	P.estimate_ground_normal_method = estimate_ground_normal_method;
+	P.normal_estimation_radius = normal_estimation_radius;
 	P.distance_weight_downsampling_method = distance_weight_downsampling_method;
 	P.standard_distance = standard_distance;
 	P.fixed_num_downsampling = fixed_num_downsampling;
@@ -600,7 +602,7 @@ inline bool voxel_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_
 //     #ifdef MULLS_USE_HIP
 //         return lo::hip::extract_semantic_pts<PointT>(in_block, vf_downsample_resolution, gf_grid_resolution, ...);
 //     #endif
-// Not available and refused: semantic_assisted, estimate_ground_normal_method != 0.  apply_roi_filtering is dead code upstream ("#if 0") and
+// Not available and refused: semantic_assisted.  apply_roi_filtering is dead code upstream ("#if 0") and
 // ignored here too.  use_adpative_parameters runs upstream's update (:2416-2444) on the host; where upstream would divide by zero (no facade and
 // no pillar point left) this throws instead.
 // One side effect is not reproduced: upstream's ground filter writes (0,0,1) normals and data[3] heights into the points of pc_down (= pc_raw)
@@ -621,7 +623,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 								 float approx_scanner_height = 2.0, float underground_thre = -7.0, float feature_pts_ratio_guess = 0.3, bool semantic_assisted = false,
 								 bool apply_roi_filtering = false, float roi_min_y = 0.0, float roi_max_y = 0.0)
 {
-	(void)normal_estimation_radius, (void)extract_curb_or_not, (void)apply_roi_filtering, (void)roi_min_y, (void)roi_max_y;
+	(void)extract_curb_or_not, (void)apply_roi_filtering, (void)roi_min_y, (void)roi_max_y;
 	if (semantic_assisted)
 		throw std::runtime_error("lo::hip::extract_semantic_pts: semantic masks are not part of this build");
 	mulls_ctx *ctx = thread_context();
@@ -638,6 +640,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	G.nonground_random_down_rate = gf_downsample_rate_nonground;
 	G.reliable_neighbor_grid_num_thre = gf_reliable_neighbor_grid_thre;
 	G.estimate_ground_normal_method = estimate_ground_normal_method;
+	G.normal_estimation_radius = normal_estimation_radius;
 	G.distance_weight_downsampling_method = distance_inverse_sampling_method;
 	G.standard_distance = standard_distance;
 	G.fixed_num_downsampling = fixed_num_downsampling;

@@ -324,8 +324,17 @@ typedef struct mulls_ground_params
 	int32_t ground_random_down_down_rate;  /* gf_down_down_rate [3] */
 	int32_t nonground_random_down_rate;	   /* gf_nonground_down_rate [3] */
 	int32_t reliable_neighbor_grid_num_thre; /* gf_reliable_neighbor_grid_thre [0] */
-	int32_t estimate_ground_normal_method; /* 0: (0,0,1) — the only one built: 1 / 2 are PCA normals, 3 [the shipped configs] a PCL RANSAC per grid
-											  cell (PCL is not in this image: its sample sequence cannot be restated and pinned) -> MULLS_E_UNSUPPORTED */
+	int32_t estimate_ground_normal_method; /* 0: (0,0,1).  1 / 2: pcl::NormalEstimationOMP over cloud_ground with every neighbour within normal_estimation_radius /
+											  with the 2 * min_grid_pt_num nearest (pca.hpp:66-119), non-finite normals replaced by 0.577 (check_normal, :462-475).
+											  3 [the shipped configs and extract_semantic_pts' default]: one PCL plane RANSAC per grid cell (cfilter.hpp:1909,
+											  :2038-2056 -> cprocessing.hpp:67-106: SACSegmentation, 20 iterations, threshold 0.3 * max_height_difference, refit to the
+											  inliers); the cell's ground points are the refined plane's inliers, every ground_random_down_rate-th of them kept with the
+											  plane's normal if abs(normal_z) > 0.8.  PCL is not in this image: what it computes inside these calls is restated —
+											  PCL's own deterministic sample sequence (boost::mt19937 seeded 12345, draw = output / 2, partial shuffles carried from
+											  draw to draw), its float expressions, the neighbours of methods 1 / 2 ascending by (distance, index); the plane through
+											  the inliers / neighbours is the smallest eigenvector of PCL's float covariance by Jacobi rotations in double instead of
+											  pcl::eigen33's closed form (its largest component positive for method 3; turned towards the sensor for 1 / 2, as PCL
+											  does) — "parity unpinned" for that part, everything MULLS wrote around the calls is pinned */
 	int32_t distance_weight_downsampling_method; /* dist_inverse_sampling_method: 0 off, 1 linear, 2 quadratic [2].  Upstream the per-cell rates of 1 / 2
 											  go through a variable shared by the threads of an OpenMP loop (cfilter.hpp:1829-1840: a data race); here
 											  every cell uses its own value, i.e. the loop's sequential semantics */
@@ -336,6 +345,8 @@ typedef struct mulls_ground_params
 	int32_t down_ground_fixed_num;		   /* ground_down_fixed_num [800] */
 	float intensity_thre;				   /* intensity_thre_nonground [150]; FLT_MAX disables */
 	float outlier_std_scale;			   /* 3.0 */
+	float normal_estimation_radius;		   /* [2.0] estimate_ground_normal_method 1 only (cfilter.hpp:1669) */
+	uint32_t reserved2_;
 	uint64_t rng_seed;					   /* ABI-only: fixed_num_downsampling thins with the seeded order-preserving selection of mulls_params.rng_seed
 											  (upstream: pcl::RandomSample seeded with time(NULL)) */
 } mulls_ground_params;

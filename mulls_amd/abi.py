@@ -192,6 +192,8 @@ class GroundParams(C.Structure):
         ("down_ground_fixed_num", C.c_int32),
         ("intensity_thre", C.c_float),
         ("outlier_std_scale", C.c_float),
+        ("normal_estimation_radius", C.c_float),
+        ("reserved2_", C.c_uint32),
         ("rng_seed", C.c_uint64),
     ]
 
@@ -203,7 +205,8 @@ def ground_params(**overrides):
     kw = dict(min_grid_pt_num=6, grid_resolution=2.5, max_height_difference=0.25, neighbor_height_diff=1.5, max_ground_height=2.0,
               ground_random_down_rate=12, ground_random_down_down_rate=3, nonground_random_down_rate=3, reliable_neighbor_grid_num_thre=0,
               estimate_ground_normal_method=0, distance_weight_downsampling_method=0, standard_distance=15.0, fixed_num_downsampling=0,
-              apply_grid_wise_outlier_filter=0, down_ground_fixed_num=800, intensity_thre=150.0, outlier_std_scale=3.0, rng_seed=0)
+              apply_grid_wise_outlier_filter=0, down_ground_fixed_num=800, intensity_thre=150.0, outlier_std_scale=3.0, normal_estimation_radius=2.0,
+              rng_seed=0)
     kw.update(overrides)
     for k, v in kw.items():
         setattr(p, k, v)

@@ -29,6 +29,7 @@ struct mulls_ctx
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	std::vector<mulls_map *> maps; // live local maps: their buffers are the device clouds mulls_pair may point to
 	void *gf_buf = nullptr; // mulls_ground_filter's device arena (grow-only)
+	void *gf_rnd = nullptr; // ... and PCL's RANSAC sample sequence (normal method 3), made on first use
 	void *cl_buf = nullptr; // mulls_classify_nground's device arena (grow-only)
 	size_t cl_cap = 0;
 	size_t gf_cap = 0;

@@ -985,6 +985,8 @@ extern "C"
 		(void)hipSetDevice(ctx->device);
 		if (ctx->gf_buf)
 			(void)hipFree(ctx->gf_buf);
+		if (ctx->gf_rnd)
+			(void)hipFree(ctx->gf_rnd);
 		if (ctx->cl_buf)
 			(void)hipFree(ctx->cl_buf);
 		if (ctx->scratch)
@@ -1388,7 +1390,9 @@ extern "C"
 					ev.end();
 					ctx->prof.launches_nn++;
 				}
-				ev.begin(&ctx->prof.ms_accum);
+				// a set without a search holds only posterior-residual passes (every pair ran its last iteration in the set before): that is the
+				// residual kernel time; a set of a converging batch mixes both kinds of pairs and is charged to the accumulation
+				ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 				for (int k = 0; k < B->nsub; k++)
 					launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 				launch_finish_step(st, (uint32_t)n, B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, word_dev, ++B->epoch2,

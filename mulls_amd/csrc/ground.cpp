@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <random>
 #include <vector>
 
 #include "../../include/mulls_hip.h"
@@ -48,16 +49,17 @@ extern "C"
 		p->down_ground_fixed_num = 500;
 		p->intensity_thre = 3.402823466e+38f;
 		p->outlier_std_scale = 3.0f;
+		p->normal_estimation_radius = 2.0f;
 		p->rng_seed = 0;
 	}
 
 	// ---- shared by mulls_ground_filter and mulls_extract_features -------------------------------------------------------------------
 	struct GfArena // one device arena: scan | ground | unground | ids | d3v | cellof | code | state, counters, per-cell tables | (filters / voxels ahead:) scan copy, mask, scratch, voxel keys, order
 	{
-		size_t o_ground, o_unground, o_ids, o_d3, o_cell, o_code, o_aux, o_alt, o_mask, o_seg, o_keys, o_perm, total;
+		size_t o_ground, o_unground, o_ids, o_d3, o_cell, o_code, o_aux, o_alt, o_mask, o_seg, o_keys, o_perm, o_ransac, o_normals, total;
 	};
 	// prefilter: dist_filter / scanner_filter ahead of the ground filter; voxels: voxel_downsample ahead of it (either needs a second scan-sized buffer)
-	static GfArena gf_layout(uint32_t n, bool prefilter, bool voxels)
+	static GfArena gf_layout(uint32_t n, bool prefilter, bool voxels, int normal_method = 0)
 	{
 		GfArena a;
 		const size_t rec = (size_t)n * MULLS_POINT_BYTES;
@@ -69,14 +71,27 @@ extern "C"
 		a.o_seg = (a.o_mask + (prefilter ? n : 0) + 255) & ~(size_t)255;
 		a.o_keys = (a.o_seg + (prefilter ? ((size_t)n / 4096 + 32) * 4 * 8 : 0) + 255) & ~(size_t)255;
 		a.o_perm = a.o_keys + (voxels ? (size_t)n * 8 + 256 : 0);
-		a.total = a.o_perm + (voxels ? (size_t)n * 4 : 0);
+		// normal method 3: gg | perm | inl (uint32 each) | gxyz (float4) | cell_nrm (float4 per cell); methods 1 / 2: the neighbour grid of the ground cloud
+		a.o_ransac = (a.o_perm + (voxels ? (size_t)n * 4 : 0) + 255) & ~(size_t)255;
+		a.o_normals = a.o_ransac + (normal_method == 3 ? (size_t)n * 28 + (size_t)MULLS_GF_MAXCELLS * 16 + 256 : 0);
+		a.total = a.o_normals + ((normal_method == 1 || normal_method == 2) ? ground_normals_bytes(n) : 0);
 		return a;
 	}
 	static int gf_check(mulls_ctx *ctx, const mulls_ground_params *P, uint32_t n)
 	{
-		if (P->estimate_ground_normal_method != 0)
+		if (P->estimate_ground_normal_method < 0 || P->estimate_ground_normal_method > 3)
 		{
-			ctx->err = "mulls_ground_filter: only estimate_ground_normal_method 0 is built (1 / 2: PCA normals, 3: PCL RANSAC per cell)";
+			ctx->err = "mulls_ground_filter: estimate_ground_normal_method must be 0 .. 3";
+			return MULLS_E_INVALID;
+		}
+		if (P->estimate_ground_normal_method == 1 && !(P->normal_estimation_radius > 0.0f))
+		{
+			ctx->err = "mulls_ground_filter: normal method 1 needs a positive normal_estimation_radius";
+			return MULLS_E_INVALID;
+		}
+		if (P->estimate_ground_normal_method == 2 && 2 * (long)P->min_grid_pt_num > 64)
+		{
+			ctx->err = "mulls_ground_filter: normal method 2 searches 2 * min_grid_pt_num neighbours, at most 64";
 			return MULLS_E_UNSUPPORTED;
 		}
 		if (P->min_grid_pt_num < 1 || !(P->grid_resolution > 0.0f) || P->ground_random_down_rate < 1 || P->ground_random_down_down_rate < 1 ||
@@ -105,14 +120,41 @@ extern "C"
 		}
 		return MULLS_OK;
 	}
+	// PCL's sample sequence for the plane RANSAC of normal method 3: SACSegmentation(random = false) seeds boost::mt19937 with 12345u for every
+	// model and draws through boost::uniform_int<>(0, INT_MAX), i.e. output / 2 — the same draws for every grid cell, so one table serves all
+	static int gf_rnd_table(mulls_ctx *ctx)
+	{
+		if (ctx->gf_rnd)
+			return MULLS_OK;
+		std::vector<uint32_t> t(MULLS_GF_RND);
+		std::mt19937 eng(12345u);
+		for (uint32_t &v : t)
+			v = (uint32_t)(eng() >> 1);
+		HIPCHK(ctx, hipMalloc(&ctx->gf_rnd, t.size() * sizeof(uint32_t)));
+		HIPCHK(ctx, hipMemcpy(ctx->gf_rnd, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+		return MULLS_OK;
+	}
 	// the filter on the n records at `scan` (device, inside the arena); the stream is idle afterwards
 	static int gf_run(mulls_ctx *ctx, const GfArena &a, const float4 *scan, uint32_t n, const mulls_ground_params *P, GfOut &out)
 	{
 		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
 		hipStream_t st = ctx->stream;
+		GfRansac R = {};
+		if (P->estimate_ground_normal_method == 3)
+		{
+			if (gf_rnd_table(ctx) != MULLS_OK)
+				return MULLS_E_HIP;
+			unsigned char *r = base + a.o_ransac;
+			R.gg = reinterpret_cast<uint32_t *>(r);
+			R.perm = R.gg + n;
+			R.inl = R.perm + n;
+			R.gxyz = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(R.inl + n) + 15) & ~(uintptr_t)15);
+			R.cell_nrm = R.gxyz + n;
+			R.rnd = static_cast<const uint32_t *>(ctx->gf_rnd);
+		}
 		if (launch_ground_filter(st, scan, n, *P, reinterpret_cast<uint32_t *>(base + a.o_ids), reinterpret_cast<uint16_t *>(base + a.o_cell), base + a.o_code,
 								 reinterpret_cast<float *>(base + a.o_d3), reinterpret_cast<float4 *>(base + a.o_ground), reinterpret_cast<float4 *>(base + a.o_unground),
-								 base + a.o_aux) != 0)
+								 base + a.o_aux, R) != 0)
 		{
 			ctx->err = "mulls_ground_filter: launch failed";
 			return MULLS_E_HIP;
@@ -123,6 +165,21 @@ extern "C"
 		{
 			ctx->err = "mulls_ground_filter: the grid has too many cells (more than 65536, or more than 64 M table entries: grid_resolution too fine for this scan's extent)";
 			return MULLS_E_UNSUPPORTED;
+		}
+		if ((P->estimate_ground_normal_method == 1 || P->estimate_ground_normal_method == 2) && out.n_ground)
+		{
+			// normals of cloud_ground from its own neighbourhoods (:1943-1954); the error word of the state reports a neighbourhood beyond the buffer
+			uint32_t *err_word = reinterpret_cast<uint32_t *>(base + a.o_aux) + 3;
+			launch_ground_normals(st, reinterpret_cast<float4 *>(base + a.o_ground), out.n_ground, P->estimate_ground_normal_method == 1 ? P->normal_estimation_radius : 0.0f,
+								  2 * P->min_grid_pt_num, base + a.o_normals, err_word);
+			uint32_t e = 0;
+			HIPCHK(ctx, hipMemcpyAsync(&e, err_word, sizeof(e), hipMemcpyDeviceToHost, st));
+			HIPCHK(ctx, hipStreamSynchronize(st));
+			if (e)
+			{
+				ctx->err = "mulls_ground_filter: more than 1024 ground points within normal_estimation_radius of one point";
+				return MULLS_E_UNSUPPORTED;
+			}
 		}
 		return MULLS_OK;
 	}
@@ -244,7 +301,7 @@ extern "C"
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		hipStream_t st = ctx->stream;
 		const mulls::StreamDrain drain{st}; // error returns below leave copies into `unground` / `g` queued
-		const GfArena a = gf_layout(n, false, false);
+		const GfArena a = gf_layout(n, false, false, P->estimate_ground_normal_method);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
 		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);
@@ -368,7 +425,7 @@ extern "C"
 		const mulls::StreamDrain drain{st}; // error returns below leave copies into out[] / `g` queued
 		const bool scanner = X->apply_scanner_filter != 0, dist = X->apply_dist_filter != 0, prefilter = scanner || dist;
 		const bool voxels = !(X->vf_downsample_resolution < 0.001); // voxel_downsample hands the cloud on below 0.001 m (:90-97)
-		const GfArena a = gf_layout(n_in, prefilter, voxels);
+		const GfArena a = gf_layout(n_in, prefilter, voxels, P->estimate_ground_normal_method);
 		if (gf_reserve(ctx, a) != MULLS_OK)
 			return MULLS_E_HIP;
 		unsigned char *base = static_cast<unsigned char *>(ctx->gf_buf);

@@ -1,4 +1,4 @@
-// k_ground.hip — CFilter::fast_ground_filter (include/common/cfilter.hpp:1658-2036, estimate_ground_normal_method 0) on the device:
+// k_ground.hip — CFilter::fast_ground_filter (include/common/cfilter.hpp:1658-2036) on the device, every estimate_ground_normal_method:
 // the first stage of MULLS's feature extraction.  Everything the reference decides with its sequential loops is
 // reproduced bit for bit, outputs in the reference's order; the order-sensitive steps are expressed as order-free ones:
 //
@@ -15,7 +15,11 @@
 //   k_gf_outlier   optional per-cell outlier threshold (:1770-1790): double sums over the cell's list in its order (one wave per cell)
 //   k_gf_cells1/2  per cell: the 3x3 neighbourhood minimum, reliable-neighbour count (:1795-1812) and the cell's verdict (:1834, :1853)
 //   k_gf_verdict   per sorted entry: ground / non-ground / dropped (:1853-1907), its rank in the cell's list being the reference's `j`;
-//                  per-block counts
+//                  per-block counts.  Normal method 3: every ground candidate of a ground cell becomes a member of the cell's grid_ground cloud
+//   k_gf_ransac    normal method 3 (:1909-1932 -> :2038-2056 -> cprocessing.hpp:67-106): one wave per ground cell runs pcl::SACSegmentation's plane
+//                  RANSAC as include/mulls_hip.h defines it (PCL's own sample sequence from a table, its float expressions, the least-squares
+//                  refit through Jacobi rotations), keeps every rate-th inlier of the refined plane if abs(normal_z) > 0.8; k_gf_recount
+//   k_gf_normals   normal methods 1 / 2 (:1943-1954 -> pca.hpp:66-119, :462-475), k_ground_normals.hip
 //   k_gf_scan      prefix sums over the blocks and the segments' high points
 //   k_gf_write     stable compaction into the output clouds; the kept high points first (input order) in the non-ground cloud
 #include <algorithm>
@@ -23,10 +27,10 @@
 #include "../../include/mulls_hip.h"
 #include "device_util.h"
 #include "ground_launch.h"
+#include "pca_device.h"
 
 #define MULLS_GF_BLOCK 256
 #define MULLS_GF_SEG 1024u // points per segment (one wave walks a segment in 16 steps of 64)
-#define MULLS_GF_MAXCELLS 65536u
 #define MULLS_GF_STAGE 4096u // z samples staged per round (k_gf_setup)
 
 struct GfState // device-resident state of one call; the head (GfOut) is read back by the host
@@ -509,7 +513,9 @@ __global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_verdict(const float4 *__r
 				{
 					if (p.z - mz < P.max_height_difference)
 					{
-						if (every(jr, r.ground))
+						if (P.estimate_ground_normal_method == 3)
+							verdict = 3; // member of the cell's grid_ground cloud (:1860-1861): k_gf_ransac decides
+						else if (every(jr, r.ground))
 							verdict = 1;
 					}
 					else if (every(jr, r.nonground) || inten > P.intensity_thre)
@@ -537,6 +543,224 @@ __global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_verdict(const float4 *__r
 	__syncthreads();
 	if (threadIdx.x < 2)
 		blk_cnt[2 * blockIdx.x + threadIdx.x] = s_cnt[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// estimate_ground_normal_method 3: pcl::SACSegmentation (SACMODEL_PLANE, SAC_RANSAC, 20 iterations, optimised coefficients) on every ground
+// cell's grid_ground cloud, as include/mulls_hip.h defines it and oracle/pcl_restated.h::plane_ransac states it — the same float / double
+// operations in the same order, so the same inliers and the same normal bits.  One wave per cell; the cell's members, its shuffled index
+// array and its inlier list live in global scratch (a cell of a 64-beam scan holds up to a few thousand candidates).
+namespace
+{
+// dot of a plane with (x, y, z, w) in the order Eigen's 4-float packet reduction adds it up
+__device__ __forceinline__ float plane_dot(float c0, float c1, float c2, float c3, float x, float y, float z, float w) { return (c0 * x + c2 * z) + (c1 * y + c3 * w); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+} // namespace
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_ransac(const float4 *__restrict__ pts, mulls_ground_params P, const GfState *S, uint32_t *arena, uint32_t ns,
+															   const uint32_t *__restrict__ ids, uint8_t *__restrict__ code, GfRansac X)
+{
+	__shared__ uint32_t s_sel[MULLS_GF_BLOCK / 64][8];
+	const uint32_t nc = (uint32_t)S->num_grid;
+	const GfTables t = gf_tables(arena, nc, ns);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t c = blockIdx.x * (MULLS_GF_BLOCK / 64) + wv;
+	if (c >= nc || (t.c_flag[c] & 3u) != 3u)
+		return; // not a ground cell
+	const uint32_t c_begin = t.cstart[c], cnt = t.cstart[c + 1] - c_begin;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	// grid_ground: the members in the list's order
+	uint32_t G = 0;
+	for (uint32_t k0 = 0; k0 < cnt; k0 += 64)
+	{
+		const uint32_t k = k0 + lane;
+		const bool member = k < cnt && code[c_begin + k] == 3;
+		const unsigned long long bal = __ballot(member);
+		if (member)
+		{
+			const uint32_t pos = G + (uint32_t)__popcll(bal & below);
+			X.gg[c_begin + pos] = c_begin + k;
+			X.gxyz[c_begin + pos] = pts[(size_t)ids[c_begin + k] * 3];
+			X.perm[c_begin + pos] = pos;
+			code[c_begin + k] = 0; // dropped unless the plane keeps it
+		}
+		G += (uint32_t)__popcll(bal);
+	}
+	if ((int)G < P.min_grid_pt_num || G < 3u) // (:1909; the members of a cell below the count vanish, as upstream; fewer than three points: no model)
+		return;
+	__threadfence_block();
+	const float4 *gx = X.gxyz + c_begin;
+	uint32_t *perm = X.perm + c_begin, *inl = X.inl + c_begin;
+	const float dist_thre = (float)(0.3 * P.max_height_difference);
+	const double threshold = (double)dist_thre;
+	int iterations = 0, n_best = -2147483647;
+	float b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+	bool have = false;
+	double p_no_outliers = 0.0;
+	const double one_over_indices = 1.0 / (double)G, log_arg = 1.0 - 0.99;
+	uint32_t rpos = 0;
+	for (;;)
+	{
+		if (have)
+		{
+			double pw = 1.0;
+			for (int i = 0; i < iterations; i++)
+				pw *= p_no_outliers;
+			if (!(pw > log_arg))
+				break;
+		}
+		else if (iterations > 0)
+			break;
+		// getSamples: lane 0 shuffles until isSampleGood (at most 1000 draws)
+		if (lane == 0)
+		{
+			uint32_t good = 0, a0 = 0, a1 = 0, a2 = 0;
+			for (int check = 0; check < 1000 && !good; check++)
+			{
+				for (uint32_t i = 0; i < 3; i++)
+				{
+					const uint32_t j = i + X.rnd[rpos++] % (G - i);
+					const uint32_t ti = perm[i], tj = perm[j];
+					perm[i] = tj, perm[j] = ti;
+				}
+				a0 = perm[0], a1 = perm[1], a2 = perm[2];
+				const float4 p0 = gx[a0], p1 = gx[a1], p2 = gx[a2];
+				const float d0 = (p1.x - p0.x) / (p2.x - p0.x), d1 = (p1.y - p0.y) / (p2.y - p0.y), d2 = (p1.z - p0.z) / (p2.z - p0.z);
+				good = ((d0 != d1) || (d2 != d1)) ? 1u : 0u;
+			}
+			s_sel[wv][0] = a0, s_sel[wv][1] = a1, s_sel[wv][2] = a2, s_sel[wv][3] = good, s_sel[wv][4] = rpos;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		if (!s_sel[wv][3])
+			break; // "No samples could be selected!"
+		rpos = s_sel[wv][4];
+		const float4 p0 = gx[s_sel[wv][0]], p1 = gx[s_sel[wv][1]], p2 = gx[s_sel[wv][2]];
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // lane 0 rewrites s_sel in the next round
+		const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z, bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+		float c0 = ay * bz - az * by, c1 = az * bx - ax * bz, c2 = ax * by - ay * bx, c3 = 0.0f;
+		const float zz = (c0 * c0 + c2 * c2) + (c1 * c1 + c3 * c3);
+		if (zz > 0.0f)
+		{
+			const float nrm = sqrtf(zz);
+			c0 /= nrm, c1 /= nrm, c2 /= nrm, c3 /= nrm;
+		}
+		c3 = -1 * plane_dot(c0, c1, c2, c3, p0.x, p0.y, p0.z, p0.w);
+		int count = 0;
+		for (uint32_t k0 = 0; k0 < G; k0 += 64)
+		{
+			const uint32_t k = k0 + lane;
+			bool in = false;
+			if (k < G)
+			{
+				const float4 q = gx[k];
+				in = (double)fabsf(plane_dot(c0, c1, c2, c3, q.x, q.y, q.z, 1.0f)) < threshold;
+			}
+			count += (int)__popcll(__ballot(in));
+		}
+		if (count > n_best)
+		{
+			n_best = count;
+			b0 = c0, b1 = c1, b2 = c2, b3 = c3;
+			have = true;
+			const double w = (double)n_best * one_over_indices;
+			p_no_outliers = 1.0 - w * w * w;
+			p_no_outliers = p_no_outliers > 2.220446049250313e-16 ? p_no_outliers : 2.220446049250313e-16;
+			p_no_outliers = p_no_outliers < 1.0 - 2.220446049250313e-16 ? p_no_outliers : 1.0 - 2.220446049250313e-16;
+		}
+		++iterations;
+		if (iterations > 20)
+			break;
+	}
+	if (!have)
+		return; // no model: no ground points from this cell
+	// the best model's inliers, in order
+	uint32_t I = 0;
+	for (uint32_t k0 = 0; k0 < G; k0 += 64)
+	{
+		const uint32_t k = k0 + lane;
+		bool in = false;
+		if (k < G)
+		{
+			const float4 q = gx[k];
+			in = (double)fabsf(plane_dot(b0, b1, b2, b3, q.x, q.y, q.z, 1.0f)) < threshold;
+		}
+		const unsigned long long bal = __ballot(in);
+		if (in)
+			inl[I + (uint32_t)__popcll(bal & below)] = k;
+		I += (uint32_t)__popcll(bal);
+	}
+	float r0 = b0, r1 = b1, r2 = b2, r3 = b3;
+	if (I >= 4u)
+	{
+		// optimizeModelCoefficients: pcl::computeMeanAndCovarianceMatrix — nine float sums in the inliers' order (64 points gathered at a time,
+		// every lane adds them one after the other), then the smallest eigenvector
+		__threadfence_block();
+		float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0, a8 = 0;
+		for (uint32_t k0 = 0; k0 < I; k0 += 64)
+		{
+			const uint32_t k = k0 + lane;
+			float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (k < I)
+				q = gx[inl[k]];
+			const int m = (int)min(64u, I - k0);
+			for (int l = 0; l < m; l++)
+			{
+				const float x = rl_f(q.x, l), y = rl_f(q.y, l), z = rl_f(q.z, l);
+				a0 += x * x;
+				a1 += x * y;
+				a2 += x * z;
+				a3 += y * y;
+				a4 += y * z;
+				a5 += z * z;
+				a6 += x;
+				a7 += y;
+				a8 += z;
+			}
+		}
+		const float nI = (float)I;
+		a0 /= nI, a1 /= nI, a2 /= nI, a3 /= nI, a4 /= nI, a5 /= nI, a6 /= nI, a7 /= nI, a8 /= nI;
+		const float v0 = a0 - a6 * a6, v1 = a1 - a6 * a7, v2 = a2 - a6 * a8, v3 = a3 - a7 * a7, v4 = a4 - a7 * a8, v5 = a5 - a8 * a8;
+		mulls_pca::smallest_eigenvector(v0, v1, v2, v3, v4, v5, r0, r1, r2);
+		r3 = 0.0f;
+		r3 = -1 * plane_dot(r0, r1, r2, r3, a6, a7, a8, 1.0f);
+	}
+	// the refined plane's inliers are the cell's ground points: every rate-th of them, if the plane is flat enough (:1916-1926)
+	float d2s = 0.001f;
+	if (P.distance_weight_downsampling_method > 0)
+		d2s = gf_dist(pts[(size_t)t.first[c] * 3]);
+	const int rate = gf_rates(P, d2s).ground;
+	const bool flat = (double)fabsf(r2) > 0.8;
+	uint32_t J = 0;
+	for (uint32_t k0 = 0; k0 < G; k0 += 64)
+	{
+		const uint32_t k = k0 + lane;
+		bool in = false;
+		if (k < G)
+		{
+			const float4 q = gx[k];
+			in = (double)fabsf(plane_dot(r0, r1, r2, r3, q.x, q.y, q.z, 1.0f)) < threshold;
+		}
+		const unsigned long long bal = __ballot(in);
+		if (in && flat && every((int)(J + (uint32_t)__popcll(bal & below)), rate))
+			code[X.gg[c_begin + k]] = 1;
+		J += (uint32_t)__popcll(bal);
+	}
+	if (lane == 0)
+		X.cell_nrm[c] = make_float4(r0, r1, r2, 0.0f);
+}
+// ... and the per-block count of ground entries once more (k_gf_verdict counted none of them)
+__global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_recount(const GfState *S, const uint8_t *__restrict__ code, uint32_t *__restrict__ blk_cnt)
+{
+	__shared__ uint32_t s_cnt;
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (threadIdx.x == 0)
+		s_cnt = 0u;
+	__syncthreads();
+	const unsigned long long mg = __ballot(k < S->n_cand && code[k] == 1);
+	if ((threadIdx.x & 63) == 0)
+		atomicAdd(&s_cnt, (uint32_t)__popcll(mg));
+	__syncthreads();
+	if (threadIdx.x == 0)
+		blk_cnt[2 * blockIdx.x] = s_cnt;
 }
 
 // exclusive prefix sums: blk_cnt[nblk][2] and seg_high[ns] in place; totals into the state.  One workgroup of 1024 lanes.
@@ -594,7 +818,8 @@ __global__ __launch_bounds__(1024) void k_gf_scan(GfState *S, uint32_t *__restri
 // stable compaction of the sorted entries into the two output clouds (positions: block base + rank inside the block)
 __global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_write(const float4 *__restrict__ pts, const GfState *S, const uint32_t *__restrict__ ids,
 															   const uint8_t *__restrict__ code, const float *__restrict__ d3v, const uint32_t *__restrict__ blk_base,
-															   float4 *__restrict__ ground, float4 *__restrict__ unground)
+															   float4 *__restrict__ ground, float4 *__restrict__ unground, int normal_method,
+															   const uint16_t *__restrict__ cellof, const float4 *__restrict__ cell_nrm)
 {
 	__shared__ uint32_t s_w[2][MULLS_GF_BLOCK / 64];
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -618,7 +843,13 @@ __global__ __launch_bounds__(MULLS_GF_BLOCK) void k_gf_write(const float4 *__res
 	const float4 c = pts[(size_t)j * 3 + 2];
 	if (v == 1)
 	{
-		b.x = 0.0f, b.y = 0.0f, b.z = 1.0f; // estimate_ground_normal_method 0 (:1867-1871)
+		if (normal_method == 0)
+			b.x = 0.0f, b.y = 0.0f, b.z = 1.0f; // (:1867-1871)
+		else if (normal_method == 3)
+		{
+			const float4 nn = cell_nrm[cellof[k]]; // the cell's refined plane (:1922-1924)
+			b.x = nn.x, b.y = nn.y, b.z = nn.z;
+		} // 1 / 2: the input's normal for now; k_gf_normals overwrites it (:1947-1952)
 		ground[(size_t)pos * 3] = a;
 		ground[(size_t)pos * 3 + 1] = b;
 		ground[(size_t)pos * 3 + 2] = c;
@@ -692,7 +923,7 @@ size_t ground_filter_aux_bytes(uint32_t n)
 }
 
 int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mulls_ground_params &P, uint32_t *ids, uint16_t *cellof, uint8_t *code, float *d3v,
-						 float4 *ground, float4 *unground, void *aux)
+						 float4 *ground, float4 *unground, void *aux, const GfRansac &R)
 {
 	const uint32_t ns = (n + MULLS_GF_SEG - 1) / MULLS_GF_SEG, nblk = (n + MULLS_GF_BLOCK - 1) / MULLS_GF_BLOCK;
 	GfState *S = static_cast<GfState *>(aux);
@@ -714,8 +945,14 @@ int launch_ground_filter(hipStream_t st, const float4 *pts, uint32_t n, const mu
 		hipLaunchKernelGGL(k_gf_outlier, dim3(MULLS_GF_MAXCELLS / (MULLS_GF_BLOCK / 64)), dim3(MULLS_GF_BLOCK), 0, st, pts, P, S, arena, ns, ids);
 	hipLaunchKernelGGL(k_gf_cells2, dim3(MULLS_GF_MAXCELLS / MULLS_GF_BLOCK), dim3(MULLS_GF_BLOCK), 0, st, P, S, arena, ns);
 	hipLaunchKernelGGL(k_gf_verdict, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, pts, P, S, arena, ns, ids, cellof, code, d3v, blk_cnt);
+	if (P.estimate_ground_normal_method == 3)
+	{
+		hipLaunchKernelGGL(k_gf_ransac, dim3(MULLS_GF_MAXCELLS / (MULLS_GF_BLOCK / 64)), dim3(MULLS_GF_BLOCK), 0, st, pts, P, S, arena, ns, ids, code, R);
+		hipLaunchKernelGGL(k_gf_recount, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, S, code, blk_cnt);
+	}
 	hipLaunchKernelGGL(k_gf_scan, dim3(1), dim3(1024), 0, st, S, blk_cnt, nblk, seg_high, ns);
-	hipLaunchKernelGGL(k_gf_write, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, pts, S, ids, code, d3v, blk_cnt, ground, unground);
+	hipLaunchKernelGGL(k_gf_write, dim3(nblk), dim3(MULLS_GF_BLOCK), 0, st, pts, S, ids, code, d3v, blk_cnt, ground, unground, (int)P.estimate_ground_normal_method,
+					   cellof, R.cell_nrm);
 	hipLaunchKernelGGL(k_gf_write_high, dim3(seg_blocks), dim3(MULLS_GF_BLOCK), 0, st, pts, n, P, S, arena, ns, seg_high, unground);
 	return 0;
 }

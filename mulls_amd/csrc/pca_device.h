@@ -56,8 +56,13 @@ __device__ __forceinline__ void signed_unit(double x, double y, double z, float 
 	fx = (float)(sgn * x / nrm), fy = (float)(sgn * y / nrm), fz = (float)(sgn * z / nrm);
 }
 
-// s0..s5 = xx xy xz yy yz zz of the float covariance (already scaled)
-__device__ __forceinline__ Eig eigen3(float s0, float s1, float s2, float s3, float s4, float s5)
+// s0..s5 = xx xy xz yy yz zz of a float covariance: eigenvalues descending (the lower index first among equals) and their eigenvectors, raw (double)
+struct EigD
+{
+	double e0, e1, e2;
+	double x0, y0, z0, x1, y1, z1, x2, y2, z2;
+};
+__device__ __forceinline__ EigD eigen3_d(float s0, float s1, float s2, float s3, float s4, float s5)
 {
 	double a00 = (double)s0, a01 = (double)s1, a02 = (double)s2, a11 = (double)s3, a12 = (double)s4, a22 = (double)s5;
 	double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
@@ -71,8 +76,9 @@ __device__ __forceinline__ Eig eigen3(float s0, float s1, float s2, float s3, fl
 		MULLS_PCA_ROT(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22) // (1,2)
 	}
 	// descending selection, the lower index first among equals (three compare-and-swaps on value + column)
-	double e0 = a00, e1 = a11, e2 = a22;
-	double x0 = v00, y0 = v10, z0 = v20, x1 = v01, y1 = v11, z1 = v21, x2 = v02, y2 = v12, z2 = v22;
+	EigD d;
+	d.e0 = a00, d.e1 = a11, d.e2 = a22;
+	d.x0 = v00, d.y0 = v10, d.z0 = v20, d.x1 = v01, d.y1 = v11, d.z1 = v21, d.x2 = v02, d.y2 = v12, d.z2 = v22;
 #define MULLS_PCA_SWAP(ea, eb, xa, ya, za, xb, yb, zb) \
 	if (eb > ea)                                       \
 	{                                                  \
@@ -82,15 +88,27 @@ __device__ __forceinline__ Eig eigen3(float s0, float s1, float s2, float s3, fl
 		w = ya, ya = yb, yb = w;                       \
 		w = za, za = zb, zb = w;                       \
 	}
-	MULLS_PCA_SWAP(e0, e1, x0, y0, z0, x1, y1, z1)
-	MULLS_PCA_SWAP(e0, e2, x0, y0, z0, x2, y2, z2)
-	MULLS_PCA_SWAP(e1, e2, x1, y1, z1, x2, y2, z2)
+	MULLS_PCA_SWAP(d.e0, d.e1, d.x0, d.y0, d.z0, d.x1, d.y1, d.z1)
+	MULLS_PCA_SWAP(d.e0, d.e2, d.x0, d.y0, d.z0, d.x2, d.y2, d.z2)
+	MULLS_PCA_SWAP(d.e1, d.e2, d.x1, d.y1, d.z1, d.x2, d.y2, d.z2)
 #undef MULLS_PCA_SWAP
+	return d;
+}
+// ... the two leading directions as pcl::PCA's callers use them
+__device__ __forceinline__ Eig eigen3(float s0, float s1, float s2, float s3, float s4, float s5)
+{
+	const EigD d = eigen3_d(s0, s1, s2, s3, s4, s5);
 	Eig r;
-	r.e1 = (float)e0, r.e2 = (float)e1, r.e3 = (float)e2;
-	signed_unit(x0, y0, z0, r.px, r.py, r.pz);
-	signed_unit(x1, y1, z1, r.mx, r.my, r.mz);
+	r.e1 = (float)d.e0, r.e2 = (float)d.e1, r.e3 = (float)d.e2;
+	signed_unit(d.x0, d.y0, d.z0, r.px, r.py, r.pz);
+	signed_unit(d.x1, d.y1, d.z1, r.mx, r.my, r.mz);
 	return r;
+}
+// ... the direction of the smallest eigenvalue: the normal of the least-squares plane (ground normals, k_ground.hip)
+__device__ __forceinline__ void smallest_eigenvector(float s0, float s1, float s2, float s3, float s4, float s5, float &nx, float &ny, float &nz)
+{
+	const EigD d = eigen3_d(s0, s1, s2, s3, s4, s5);
+	signed_unit(d.x2, d.y2, d.z2, nx, ny, nz);
 }
 
 // Eigen::Vector3f::normalize()

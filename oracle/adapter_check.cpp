@@ -32,24 +32,26 @@ namespace lo
 #include "util_types.inc"
 #include "util_cloudutility.inc"
 };
-// pca.hpp: pca_feature_t and the member functions of PrincipleComponentAnalysis that do the neighbourhood PCA (its other members wrap
-// pcl::NormalEstimationOMP: the ground filter's normal methods 1 / 2, never reached)
+// pca.hpp / cprocessing.hpp / cfilter.hpp: the same class shells as oracle/ref_driver.cpp
 #include "pca_types.inc"
 template <typename PointT>
 class PrincipleComponentAnalysis
 {
   public:
-	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
-	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+#include "pca_normals.inc"
 #include "pca_body.inc"
+};
+template <typename PointT>
+class CProceesing : public CloudUtility<PointT>
+{
+  public:
+#include "cproc_body.inc"
 };
 
 template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
-	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell): not extracted, never reached (method 0)
-	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
 	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
 	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
 	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }

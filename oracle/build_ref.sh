@@ -53,12 +53,18 @@ extract cfilter.hpp 950 981 "bool bbx_filter" cfilter_body.inc
 extract cfilter.hpp 1071 1181 "bool encode_stable_points" cfilter_body.inc
 extract cfilter.hpp 1243 1312 "bool non_max_suppress(typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
 extract cfilter.hpp 1658 2036 "bool fast_ground_filter(const typename pcl::PointCloud<PointT>::Ptr &cloud_in," cfilter_body.inc
+extract cfilter.hpp 2038 2056 "bool estimate_ground_normal_by_ransac" cfilter_body.inc
 extract cfilter.hpp 2058 2290 "bool classify_nground_pts" cfilter_body.inc
 extract cfilter.hpp 2295 2413 "bool extract_semantic_pts" cfilter_body.inc
 extract cfilter.hpp 2416 2482 "void update_parameters_self_adaptive" cfilter_body.inc
 # pca.hpp: pca_feature_t and the neighbourhood PCA (get_pc_pca_feature x2, calculate_normal_inconsistency, get_pca_feature, assign_normal)
 extract pca.hpp 23 54 "struct eigenvalue_t" pca_types.inc
 extract pca.hpp 207 454 "// R - K neighborhood (without already built-kd tree)" pca_body.inc
+# the ground filter's normal methods: pcl::NormalEstimationOMP wrappers + check_normal (1 / 2), the per-cell plane RANSAC (3)
+extract pca.hpp 66 84 "bool get_normal_pcar" pca_normals.inc
+extract pca.hpp 102 119 "bool get_normal_pcak" pca_normals.inc
+extract pca.hpp 462 475 "void check_normal" pca_normals.inc
+extract cprocessing.hpp 67 106 "bool plane_seg_ransac" cproc_body.inc
 extract cfilter.hpp 2613 2655 "bool get_cloud_pair_intersection" cfilter_body.inc
 # cregistration.hpp: the driver and every helper on the path
 extract cregistration.hpp 1114 1440 "int mm_lls_icp(constraint_t &registration_cons" creg_body.inc

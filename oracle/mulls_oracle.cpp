@@ -1030,7 +1030,7 @@ void random_downsample(Cloud &c, int keep_number, uint64_t seed, int cloud_id)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// CFilter::fast_ground_filter (cfilter.hpp:1658-2036), estimate_ground_normal_method = 0.  Statement by statement: the float /
+// CFilter::fast_ground_filter (cfilter.hpp:1658-2036), every estimate_ground_normal_method (the PCL calls of 1 - 3: pcl_restated.h).  Statement by statement: the float /
 // double mix of every expression is the reference's (bounds_t holds doubles, the thresholds are floats).  The per-cell
 // down-sampling rates of distance_weight_downsampling_method 1 / 2 follow the loop's sequential semantics (upstream the loop
 // over cells is an OpenMP parallel-for writing a shared `distance_weight`, :1829-1840).  fixed_num_downsampling uses the ABI's
@@ -1046,8 +1046,9 @@ struct GfCell // grid_t (cfilter.hpp:45-69)
 } // namespace
 int ground_filter_impl(Cloud &in, const mulls_ground_params &P, Cloud &ground, Cloud &ground_down, Cloud &unground)
 {
-	if (P.estimate_ground_normal_method != 0)
-		return MULLS_E_UNSUPPORTED;
+	const int estimate_ground_normal_method = P.estimate_ground_normal_method;
+	if (estimate_ground_normal_method < 0 || estimate_ground_normal_method > 3)
+		return MULLS_E_INVALID;
 	const int min_grid_pt_num = P.min_grid_pt_num;
 	const float grid_resolution = P.grid_resolution, max_height_difference = P.max_height_difference, neighbor_height_diff = P.neighbor_height_diff,
 				max_ground_height = P.max_ground_height, standard_distance = P.standard_distance, intensity_thre = P.intensity_thre;
@@ -1147,6 +1148,7 @@ int ground_filter_impl(Cloud &in, const mulls_ground_params &P, Cloud &ground, C
 				}
 	}
 	std::vector<Cloud> grid_ground_pcs((size_t)num_grid), grid_unground_pcs((size_t)num_grid);
+	Cloud grid_ground; // method 3: the cell's ground candidates, every one of them (:1860-1861)
 	for (int i = 0; i < num_grid; i++) // :1832-1935
 	{
 		if (grid[i].pts_count >= min_grid_pt_num && grid[i].reliable_neighbor_grid_num >= P.reliable_neighbor_grid_num_thre)
@@ -1173,11 +1175,16 @@ int ground_filter_impl(Cloud &in, const mulls_ground_params &P, Cloud &ground, C
 					{
 						if (p.z - grid[i].min_z < max_height_difference)
 						{
-							if (j % ground_random_down_rate_temp == 0)
+							if (estimate_ground_normal_method == 3)
+								grid_ground.push_back(p);
+							else if (j % ground_random_down_rate_temp == 0)
 							{
-								p.nx = 0.0;
-								p.ny = 0.0;
-								p.nz = 1.0;
+								if (estimate_ground_normal_method == 0)
+								{
+									p.nx = 0.0;
+									p.ny = 0.0;
+									p.nz = 1.0;
+								}
 								grid_ground_pcs[i].push_back(p);
 							}
 						}
@@ -1201,12 +1208,49 @@ int ground_filter_impl(Cloud &in, const mulls_ground_params &P, Cloud &ground, C
 					}
 				}
 			}
+			if (estimate_ground_normal_method == 3 && (int)grid_ground.size() >= min_grid_pt_num) // :1909-1932
+			{
+				// estimate_ground_normal_by_ransac(grid_ground, 0.3 * max_height_difference, 20, ...) (:2038-2056) -> CProceesing::plane_seg_ransac
+				// (cprocessing.hpp:67-106): grid_ground becomes the plane's inliers, the normal the plane's first three coefficients
+				const float dist_thre = 0.3 * max_height_difference;
+				std::vector<restated::P4> pts(grid_ground.size());
+				for (size_t k = 0; k < grid_ground.size(); k++)
+					pts[k] = restated::P4{grid_ground[k].x, grid_ground[k].y, grid_ground[k].z, grid_ground[k].d3};
+				std::vector<int> inliers;
+				float coeff[4];
+				if (restated::plane_ransac(pts, dist_thre, 20, inliers, coeff)) // (no model: upstream reads an empty coefficient vector — undefined; here: no ground points)
+				{
+					const float normal_x = coeff[0], normal_y = coeff[1], normal_z = coeff[2];
+					for (int j = 0; j < (int)inliers.size(); j++)
+						if (j % ground_random_down_rate_temp == 0 && std::abs(normal_z) > 0.8)
+						{
+							Pt q = grid_ground[inliers[j]];
+							q.nx = normal_x;
+							q.ny = normal_y;
+							q.nz = normal_z;
+							grid_ground_pcs[i].push_back(q);
+						}
+				}
+			}
+			grid_ground.clear();
 		}
 	}
 	for (int i = 0; i < num_grid; i++) // :1938-1942
 	{
 		ground.insert(ground.end(), grid_ground_pcs[i].begin(), grid_ground_pcs[i].end());
 		unground.insert(unground.end(), grid_unground_pcs[i].begin(), grid_unground_pcs[i].end());
+	}
+	if (estimate_ground_normal_method == 1 || estimate_ground_normal_method == 2) // :1943-1954: pca_estimator.get_normal_pcar / _pcak + check_normal (pca.hpp:66-119, :462-475)
+	{
+		std::vector<float> nrm;
+		restated::normal_estimation(ground, estimate_ground_normal_method == 1 ? (double)P.normal_estimation_radius : 0.0, 2 * min_grid_pt_num, nrm);
+		for (size_t i = 0; i < ground.size(); i++)
+		{
+			const bool finite = std::isfinite(nrm[3 * i]) && std::isfinite(nrm[3 * i + 1]) && std::isfinite(nrm[3 * i + 2]);
+			ground[i].nx = finite ? nrm[3 * i] : (float)0.577;
+			ground[i].ny = finite ? nrm[3 * i + 1] : (float)0.577;
+			ground[i].nz = finite ? nrm[3 * i + 2] : (float)0.577;
+		}
 	}
 	if (!P.fixed_num_downsampling) // :1955-1968
 	{
@@ -1859,6 +1903,13 @@ extern "C"
 {
 
 	void mulls_oracle_default_params(mulls_params *p) { mulls_oracle_default_params_impl(p); }
+	// the first n draws of the sample sequence of the ground filter's plane RANSAC (pcl_restated.h: plane_ransac)
+	void mulls_oracle_sac_draws(uint32_t *out, int n)
+	{
+		std::mt19937 eng(12345u);
+		for (int i = 0; i < n; i++)
+			out[i] = (uint32_t)(eng() >> 1);
+	}
 	int mulls_oracle_icp_3dof_ground(const mulls_pair *pair, const mulls_params *params, mulls_result *result, int nn_mode)
 	{
 		if (!pair || !params || !result)

@@ -15,8 +15,26 @@
 //       in double on the float matrix, results rounded to float; Eigen leaves an eigenvector's sign open, here its largest component is
 //       positive.  Eigen's float solver is accurate to ~1e-6 of the largest eigenvalue: threshold comparisons downstream can differ from
 //       upstream for points that close to a threshold.
+//   pcl::SACSegmentation<PointT> with SACMODEL_PLANE, SAC_RANSAC, setOptimizeCoefficients(true)   (cprocessing.hpp:67-106: the ground filter's
+//       normal method 3, one call per grid cell) — plane_ransac below: segmentation/impl/sac_segmentation.hpp (segment), sample_consensus/
+//       impl/ransac.hpp (computeModel), sac_model.h (getSamples, drawIndexSample: a partial Fisher-Yates shuffle carried from draw to draw,
+//       rnd() = boost::mt19937 seeded 12345u — SACSegmentation(random = false) — through boost::uniform_int<>(0, INT_MAX), which for Boost >=
+//       1.47 is eng() / 2), impl/sac_model_plane.hpp (isSampleGood, computeModelCoefficients, countWithinDistance, selectWithinDistance,
+//       optimizeModelCoefficients), common/impl/centroid.hpp (computeMeanAndCovarianceMatrix: one-pass float moments).  Float expressions in
+//       Eigen's SSE evaluation order for 4-vectors ((a0 + a2) + (a1 + a3)).  Two things are NOT PCL's: the loop test `iterations < log(1 - 0.99) /
+//       log(1 - w^3)` is evaluated as `(1 - w^3)^iterations > 1 - 0.99` by repeated multiplication (no libm: the same bits on the device; the two
+//       differ only if the power lands within rounding of 0.01), and pcl::eigen33's closed-form float roots are replaced by the smallest
+//       eigenvector of the same float covariance from cyclic Jacobi in double (jacobi3), its largest component positive (eigen33 leaves the
+//       sign to a cross product; fast_ground_filter tests abs(normal_z) and the point-to-plane metric is even in the normal).
+//   pcl::NormalEstimationOMP<PointT, pcl::Normal> with setRadiusSearch / setKSearch   (pca.hpp:66-119: normal methods 1 / 2) — normal_estimation
+//       below: features/impl/normal_3d_omp.hpp, features/normal_3d.h (computePointNormal, flipNormalTowardsViewpoint with the view point
+//       (0, 0, 0)): neighbours ascending by (distance, index), the query included; fewer than 3 -> NaN (which pca.hpp's check_normal turns
+//       into 0.577); one-pass float moments in that order; the normal = the smallest eigenvector as above, turned towards the origin.
 #pragma once
 #include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <random>
 #include <cmath>
 #include <cstring>
 #include <utility>
@@ -292,6 +310,204 @@ inline void normalize3(float v[3])
 		v[0] /= n;
 		v[1] /= n;
 		v[2] /= n;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct P4 // Eigen::Array4f map of a point: x, y, z, data[3]
+{
+	float x, y, z, w;
+};
+// pcl::computeMeanAndCovarianceMatrix (dense cloud, float): raw moments summed in the indices' order, divided by the count, then
+// covariance = E[xx^T] - c c^T.  cov6 = xx xy xz yy yz zz.  Returns the count.
+inline int mean_and_covariance(const std::vector<P4> &pts, const std::vector<int> &idx, float cov6[6], float centroid[3])
+{
+	float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	for (size_t k = 0; k < idx.size(); k++)
+	{
+		const P4 &p = pts[idx[k]];
+		accu[0] += p.x * p.x;
+		accu[1] += p.x * p.y;
+		accu[2] += p.x * p.z;
+		accu[3] += p.y * p.y;
+		accu[4] += p.y * p.z;
+		accu[5] += p.z * p.z;
+		accu[6] += p.x;
+		accu[7] += p.y;
+		accu[8] += p.z;
+	}
+	const float n = static_cast<float>(idx.size());
+	for (int k = 0; k < 9; k++)
+		accu[k] /= n;
+	centroid[0] = accu[6], centroid[1] = accu[7], centroid[2] = accu[8];
+	cov6[0] = accu[0] - accu[6] * accu[6];
+	cov6[1] = accu[1] - accu[6] * accu[7];
+	cov6[2] = accu[2] - accu[6] * accu[8];
+	cov6[3] = accu[3] - accu[7] * accu[7];
+	cov6[4] = accu[4] - accu[7] * accu[8];
+	cov6[5] = accu[5] - accu[8] * accu[8];
+	return (int)idx.size();
+}
+// the unit eigenvector of the smallest eigenvalue of a float covariance, rounded to float (largest component positive)
+inline void smallest_eigenvector(const float cov6[6], float n[3])
+{
+	double a6[6], lam[3], v[3][3];
+	for (int k = 0; k < 6; k++)
+		a6[k] = (double)cov6[k];
+	jacobi3(a6, lam, v);
+	volatile float r[3] = {(float)v[0][2], (float)v[1][2], (float)v[2][2]}; // (see pca(): the rounding must not be forwarded away)
+	n[0] = r[0], n[1] = r[1], n[2] = r[2];
+}
+// dot of a plane (4 coefficients) with (x, y, z, w) as Eigen's 4-float packet reduction adds it up
+inline float plane_dot(const float c[4], float x, float y, float z, float w) { return (c[0] * x + c[2] * z) + (c[1] * y + c[3] * w); }
+
+// pcl::SACSegmentation<PointT>::segment as CProceesing::plane_seg_ransac sets it up.  Out: the inliers (ascending indices) and the four
+// plane coefficients; false when no model could be found (upstream then leaves both outputs empty).
+inline bool plane_ransac(const std::vector<P4> &pts, double threshold, int max_iterations, std::vector<int> &inliers, float coeff[4])
+{
+	const int n = (int)pts.size();
+	inliers.clear();
+	if (n < 3)
+		return false; // getSamples: "Can not select 3 unique points out of n"
+	std::mt19937 eng(12345u);
+	std::vector<int> shuffled(n);
+	for (int i = 0; i < n; i++)
+		shuffled[i] = i;
+	int iterations = 0, n_best = -INT_MAX;
+	float best[4] = {0, 0, 0, 0};
+	bool have = false;
+	double p_no_outliers = 0.0;
+	const double one_over_indices = 1.0 / static_cast<double>(n), log_arg = 1.0 - 0.99; // probability_ = 0.99
+	for (;;)
+	{
+		if (have) // while (iterations_ < k), k = log(1 - probability) / log(p_no_outliers)
+		{
+			double pw = 1.0;
+			for (int i = 0; i < iterations; i++)
+				pw *= p_no_outliers;
+			if (!(pw > log_arg))
+				break;
+		}
+		else if (iterations > 0)
+			break; // (unreachable: the first good sample always installs a model)
+		// getSamples: up to max_sample_checks_ = 1000 draws until isSampleGood
+		int sel[3] = {0, 0, 0};
+		bool good = false;
+		for (int check = 0; check < 1000 && !good; check++)
+		{
+			for (int i = 0; i < 3; i++)
+				std::swap(shuffled[i], shuffled[i + (int)((eng() >> 1) % (uint32_t)(n - i))]);
+			sel[0] = shuffled[0], sel[1] = shuffled[1], sel[2] = shuffled[2];
+			const P4 &p0 = pts[sel[0]], &p1 = pts[sel[1]], &p2 = pts[sel[2]];
+			const float d0 = (p1.x - p0.x) / (p2.x - p0.x), d1 = (p1.y - p0.y) / (p2.y - p0.y), d2 = (p1.z - p0.z) / (p2.z - p0.z);
+			good = (d0 != d1) || (d2 != d1);
+		}
+		if (!good)
+			break; // "No samples could be selected!"
+		// computeModelCoefficients (the collinearity test it repeats cannot fail after isSampleGood)
+		const P4 &p0 = pts[sel[0]], &p1 = pts[sel[1]], &p2 = pts[sel[2]];
+		const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z, bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+		float c[4];
+		c[0] = ay * bz - az * by;
+		c[1] = az * bx - ax * bz;
+		c[2] = ax * by - ay * bx;
+		c[3] = 0;
+		const float z = (c[0] * c[0] + c[2] * c[2]) + (c[1] * c[1] + c[3] * c[3]);
+		if (z > 0.0f)
+		{
+			const float nrm = std::sqrt(z);
+			c[0] /= nrm, c[1] /= nrm, c[2] /= nrm, c[3] /= nrm;
+		}
+		c[3] = -1 * plane_dot(c, p0.x, p0.y, p0.z, p0.w);
+		// countWithinDistance
+		int count = 0;
+		for (int i = 0; i < n; i++)
+			if ((double)std::fabs(plane_dot(c, pts[i].x, pts[i].y, pts[i].z, 1.0f)) < threshold)
+				count++;
+		if (count > n_best)
+		{
+			n_best = count;
+			for (int k = 0; k < 4; k++)
+				best[k] = c[k];
+			have = true;
+			const double w = static_cast<double>(n_best) * one_over_indices;
+			p_no_outliers = 1.0 - w * w * w; // pow(w, 3.0)
+			p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
+			p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+		}
+		++iterations;
+		if (iterations > max_iterations)
+			break;
+	}
+	if (!have)
+		return false;
+	auto select = [&](const float c[4]) {
+		inliers.clear();
+		for (int i = 0; i < n; i++)
+			if ((double)std::fabs(plane_dot(c, pts[i].x, pts[i].y, pts[i].z, 1.0f)) < threshold)
+				inliers.push_back(i);
+	};
+	select(best);
+	// optimizeModelCoefficients: least squares through the inliers (needs more than 3), then the inliers of the refined plane
+	for (int k = 0; k < 4; k++)
+		coeff[k] = best[k];
+	if (inliers.size() >= 4)
+	{
+		float cov6[6], cen[3], nv[3];
+		mean_and_covariance(pts, inliers, cov6, cen);
+		smallest_eigenvector(cov6, nv);
+		coeff[0] = nv[0], coeff[1] = nv[1], coeff[2] = nv[2], coeff[3] = 0;
+		coeff[3] = -1 * plane_dot(coeff, cen[0], cen[1], cen[2], 1.0f);
+	}
+	select(coeff);
+	return true;
+}
+
+// pcl::NormalEstimationOMP on a cloud against itself: out[i] = (nx, ny, nz) of point i, NaN where fewer than 3 neighbours were found.
+// radius > 0: every point within the radius (setRadiusSearch); else the k nearest (setKSearch).
+template <typename P>
+inline void normal_estimation(const std::vector<P> &cloud, double radius, int k, std::vector<float> &out)
+{
+	const size_t n = cloud.size();
+	out.assign(3 * n, std::numeric_limits<float>::quiet_NaN());
+	if (!n)
+		return;
+	std::vector<P4> pts(n);
+	for (size_t i = 0; i < n; i++)
+		pts[i] = P4{cloud[i].x, cloud[i].y, cloud[i].z, 1.0f};
+	RadiusIndex<P4> index;
+	index.build(pts, radius > 0 ? (float)radius : 1.0f);
+	std::vector<int> idx;
+	std::vector<float> d2;
+	for (size_t i = 0; i < n; i++)
+	{
+		if (radius > 0)
+			index.search(pts[i], radius, 0, idx, d2);
+		else
+		{
+			// the k nearest: every point within R for a growing R — once k are inside, the k nearest are among them
+			double R = 1.0;
+			for (;;)
+			{
+				index.search(pts[i], R, 0, idx, d2);
+				if ((int)idx.size() >= k || idx.size() == n || R > 1e7)
+					break;
+				R *= 2.0;
+			}
+			if ((int)idx.size() > k)
+				idx.resize(k);
+		}
+		if (idx.size() < 3)
+			continue;
+		float cov6[6], cen[3], nv[3];
+		mean_and_covariance(pts, idx, cov6, cen);
+		smallest_eigenvector(cov6, nv);
+		// flipNormalTowardsViewpoint(point, 0, 0, 0, nx, ny, nz)
+		const float vx = 0.0f - pts[i].x, vy = 0.0f - pts[i].y, vz = 0.0f - pts[i].z;
+		const float cos_theta = (vx * nv[0] + vy * nv[1] + vz * nv[2]);
+		if (cos_theta < 0)
+			nv[0] *= -1, nv[1] *= -1, nv[2] *= -1;
+		out[3 * i] = nv[0], out[3 * i + 1] = nv[1], out[3 * i + 2] = nv[2];
 	}
 }
 } // namespace restated

@@ -30,28 +30,33 @@ namespace lo
 #include "util_cloudutility.inc" // template <typename PointT> class CloudUtility { public: ... bbox helpers
 };
 
-// pca.hpp: pca_feature_t and the member functions of PrincipleComponentAnalysis that do the neighbourhood PCA (its other members wrap
-// pcl::NormalEstimationOMP: the ground filter's normal methods 1 / 2, never reached)
+// pca.hpp: pca_feature_t, the member functions of PrincipleComponentAnalysis that do the neighbourhood PCA, and the two wrappers of
+// pcl::NormalEstimationOMP with check_normal behind them (the ground filter's normal methods 1 / 2)
 #include "pca_types.inc"
 template <typename PointT>
 class PrincipleComponentAnalysis
 {
   public:
-	bool get_normal_pcar(typename pcl::PointCloud<PointT>::Ptr, float, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
-	bool get_normal_pcak(typename pcl::PointCloud<PointT>::Ptr, int, pcl::PointCloud<pcl::Normal>::Ptr &) { std::abort(); }
+#include "pca_normals.inc" // get_normal_pcar (pca.hpp:66-84), get_normal_pcak (:102-119), check_normal (:462-475)
 #include "pca_body.inc"
+};
+
+// cprocessing.hpp: the class shell around plane_seg_ransac (:67-106), the ground filter's normal method 3
+template <typename PointT>
+class CProceesing : public CloudUtility<PointT>
+{
+  public:
+#include "cproc_body.inc"
 };
 
 template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
-	// estimate_ground_normal_method 3 (a PCL SACSegmentation per grid cell, cfilter.hpp:2038-2076): not extracted, never reached by the pin
-	bool estimate_ground_normal_by_ransac(typename pcl::PointCloud<PointT>::Ptr &, float, int, float &, float &, float &) { std::abort(); }
 	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
 	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
 	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }
-#include "cfilter_body.inc"
+#include "cfilter_body.inc" // (with estimate_ground_normal_by_ransac, cfilter.hpp:2038-2056)
 };
 
 template <typename PointT>
@@ -83,7 +88,7 @@ static void fill_constraint(const mulls_pair *pair, lo::constraint_t &con);
 extern "C" int mulls_ref_ground_filter(const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *P, void *ground, uint32_t cap_ground,
 										   void *ground_down, uint32_t cap_ground_down, void *unground, uint32_t cap_unground, uint32_t n_out[3])
 {
-	if (P->fixed_num_downsampling || P->estimate_ground_normal_method != 0)
+	if (P->fixed_num_downsampling)
 		return MULLS_E_UNSUPPORTED;
 	pcTPtr in(new pcT), g(new pcT), gd(new pcT), u(new pcT), curb(new pcT);
 	mulls_cloud c = {pts, n, stride};
@@ -91,8 +96,8 @@ extern "C" int mulls_ref_ground_filter(const void *pts, uint32_t n, uint32_t str
 	lo::CFilter<Point_T> cf;
 	cf.fast_ground_filter(in, g, gd, u, curb, P->min_grid_pt_num, P->grid_resolution, P->max_height_difference, P->neighbor_height_diff, P->max_ground_height,
 						  P->ground_random_down_rate, P->ground_random_down_down_rate, P->nonground_random_down_rate, P->reliable_neighbor_grid_num_thre,
-						  P->estimate_ground_normal_method, 2.0f, P->distance_weight_downsampling_method, P->standard_distance, false, P->down_ground_fixed_num,
-						  false, P->intensity_thre, P->apply_grid_wise_outlier_filter != 0, P->outlier_std_scale);
+						  P->estimate_ground_normal_method, P->normal_estimation_radius, P->distance_weight_downsampling_method, P->standard_distance, false,
+						  P->down_ground_fixed_num, false, P->intensity_thre, P->apply_grid_wise_outlier_filter != 0, P->outlier_std_scale);
 	auto put = [](const pcTPtr &cl, void *dst, uint32_t cap) {
 		const size_t k = std::min<size_t>(cl->points.size(), cap);
 		for (size_t i = 0; i < k; i++)
@@ -377,7 +382,7 @@ extern "C" int mulls_ref_extract_semantic_pts(const void *scan, uint32_t n, uint
 	const float approx_scanner_height = -(X->z_min + 4.0f), underground_thre = X->z_min_min + approx_scanner_height;
 	cf.extract_semantic_pts(blk, X->vf_downsample_resolution, G.grid_resolution, G.max_height_difference, G.neighbor_height_diff, G.max_ground_height, gdr, ndr,
 							K.neighbor_searching_radius, K.neighbor_k, K.edge_thre, K.planar_thre, K.curvature_thre, K.edge_thre_down, K.planar_thre_down,
-							K.use_distance_adaptive_pca != 0, G.distance_weight_downsampling_method, G.standard_distance, G.estimate_ground_normal_method, 2.0f, false,
+							K.use_distance_adaptive_pca != 0, G.distance_weight_downsampling_method, G.standard_distance, G.estimate_ground_normal_method, G.normal_estimation_radius, false,
 							X->apply_scanner_filter != 0, false, K.extract_vertex_points_method, G.min_grid_pt_num, G.reliable_neighbor_grid_num_thre,
 							G.ground_random_down_down_rate, K.neigh_k_min, K.pca_down_rate, G.intensity_thre, K.linear_vertical_sin_high_thre,
 							K.linear_vertical_sin_low_thre, K.planar_vertical_sin_high_thre, K.planar_vertical_sin_low_thre, K.sharpen_with_nms != 0,

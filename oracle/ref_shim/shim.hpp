@@ -796,15 +796,91 @@ struct RandomSample
 };
 } // namespace pcl
 
-// what CFilter::fast_ground_filter names besides the point cloud types: the normal cloud of its PCA branches and the PCA estimator
-// (estimate_ground_normal_method 1 / 2, never taken by the pin: method 0); the estimator's class shell is in ref_driver.cpp / adapter_check.cpp
+// what CFilter::fast_ground_filter calls for its ground normals besides the point cloud types (estimate_ground_normal_method 1 - 3): the
+// stand-ins hand the work to oracle/pcl_restated.h, the one restatement of these PCL classes the oracle uses too — a comparison "oracle ==
+// reference lines" therefore pins what MULLS wrote around the calls (which points go in, which come out, the j % rate rule, the abs(normal_z)
+// gate, check_normal) and nothing inside them
 namespace pcl
 {
 struct Normal
 {
 	float normal_x = 0, normal_y = 0, normal_z = 0, curvature = 0;
 };
+template <typename T>
+inline bool isFinite(const T &p);
+template <>
+inline bool isFinite<Normal>(const Normal &n)
+{
+	return std::isfinite(n.normal_x) && std::isfinite(n.normal_y) && std::isfinite(n.normal_z);
+}
+struct ModelCoefficients
+{
+	typedef boost::shared_ptr<ModelCoefficients> Ptr;
+	std::vector<float> values;
+};
+struct PointIndices
+{
+	typedef boost::shared_ptr<PointIndices> Ptr;
+	std::vector<int> indices;
+};
+enum
+{
+	SACMODEL_PLANE = 0
+};
+enum
+{
+	SAC_RANSAC = 0
+};
+template <typename PointT>
+struct SACSegmentation
+{
+	typename PointCloud<PointT>::Ptr cloud;
+	double threshold = 0;
+	int max_iter = 50;
+	void setOptimizeCoefficients(bool) {}
+	void setModelType(int) {}
+	void setMethodType(int) {}
+	void setDistanceThreshold(double t) { threshold = t; }
+	void setMaxIterations(int m) { max_iter = m; }
+	void setInputCloud(const typename PointCloud<PointT>::Ptr &c) { cloud = c; }
+	void segment(PointIndices &inliers, ModelCoefficients &coefficients)
+	{
+		std::vector<restated::P4> pts(cloud->points.size());
+		for (size_t i = 0; i < pts.size(); i++)
+			pts[i] = restated::P4{cloud->points[i].x, cloud->points[i].y, cloud->points[i].z, cloud->points[i].data[3]};
+		float c[4];
+		inliers.indices.clear();
+		coefficients.values.clear();
+		if (restated::plane_ransac(pts, threshold, max_iter, inliers.indices, c))
+			coefficients.values.assign(c, c + 4);
+	}
+};
+template <typename PointT, typename NormalT>
+struct NormalEstimationOMP
+{
+	typename PointCloud<PointT>::Ptr cloud;
+	double radius = 0;
+	int k = 0;
+	void setNumberOfThreads(int) {}
+	void setInputCloud(const typename PointCloud<PointT>::Ptr &c) { cloud = c; }
+	void setSearchMethod(const typename search::KdTree<PointT>::Ptr &) {}
+	void setRadiusSearch(double r) { radius = r; }
+	void setKSearch(int kk) { k = kk; }
+	void compute(PointCloud<NormalT> &out)
+	{
+		std::vector<float> n;
+		restated::normal_estimation(cloud->points, radius, k, n);
+		out.points.resize(cloud->points.size());
+		for (size_t i = 0; i < out.points.size(); i++)
+		{
+			out.points[i].normal_x = n[3 * i];
+			out.points[i].normal_y = n[3 * i + 1];
+			out.points[i].normal_z = n[3 * i + 2];
+		}
+	}
+};
 } // namespace pcl
+#define PCL_ERROR(...) ((void)0)
 // OpenMP calls made by CFilter::apply_motion_compensation
 inline void omp_set_num_threads(int) {}
 inline int omp_get_max_threads() { return 1; }

@@ -56,6 +56,53 @@ def test_oracle_equals_reference_lines():
     assert n_cases >= 24
 
 
+def normal_param_sets():
+    """estimate_ground_normal_method 1 - 3 (cfilter.hpp:1860-1932, :1943-1954): 3 is what every shipped configuration and extract_semantic_pts'
+    default use; each with the distance-inverse rates and the outlier filter switched on as the KITTI configurations have them."""
+    for method in (3, 1, 2):
+        yield "m%d" % method, abi.ground_params(estimate_ground_normal_method=method)
+        yield "m%d_dist2" % method, abi.ground_params(estimate_ground_normal_method=method, distance_weight_downsampling_method=2)
+        yield "m%d_outlier" % method, abi.ground_params(estimate_ground_normal_method=method, apply_grid_wise_outlier_filter=1, grid_resolution=2.0, min_grid_pt_num=8,
+                                                         normal_estimation_radius=1.5)
+    yield "m3_reg", abi.ground_params(estimate_ground_normal_method=3, grid_resolution=2.0, max_height_difference=0.25, neighbor_height_diff=1.2, min_grid_pt_num=8,
+                                      ground_random_down_rate=10, ground_random_down_down_rate=2, distance_weight_downsampling_method=2, intensity_thre=3.0e38)  # run_mulls_reg.sh
+
+
+@pytest.mark.skipif(not pyref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_normal_methods_oracle_equals_reference_lines():
+    """Everything MULLS wrote around the PCL calls of the three normal methods — which points enter the per-cell plane fit, that its inliers
+    replace the cell's cloud, the j % rate rule on the inliers, the abs(normal_z) > 0.8 gate, which normal a point receives, check_normal's
+    0.577 — byte for byte against the reference's own lines (fast_ground_filter, estimate_ground_normal_by_ransac, plane_seg_ransac,
+    get_normal_pcar / _pcak, check_normal), with the PCL classes inside them stood in by the one restatement both sides share
+    (oracle/pcl_restated.h: parity unpinned for that part)."""
+    n_cases = 0
+    for cname, pts in clouds():
+        for pname, P in normal_param_sets():
+            a, b = pyoracle.ground_filter(pts, P), pyref.ground_filter(pts, P)
+            for k, what in enumerate(("ground", "ground_down", "unground")):
+                assert a[k].shape == b[k].shape, (cname, pname, what, a[k].shape, b[k].shape)
+                assert np.array_equal(a[k], b[k]), (cname, pname, what)
+            g = abi.points_of(a[0])
+            assert len(g) > 0
+            if P.estimate_ground_normal_method == 3:
+                assert (np.abs(g["nz"]) > 0.8).all() and np.allclose(g["nx"] ** 2 + g["ny"] ** 2 + g["nz"] ** 2, 1.0, atol=1e-5)
+            n_cases += 1
+    assert n_cases >= 40
+
+
+def test_plane_ransac_sample_sequence():
+    """The sample sequence the ABI defines for normal method 3 is PCL's own: boost::mt19937 seeded 12345, a draw = output / 2 (what
+    boost::uniform_int<>(0, INT_MAX) returns for Boost >= 1.47).  Checked against an independent MT19937 (numpy's legacy generator, same
+    init_genrand seeding) so that a change of generator or seed cannot go unnoticed."""
+    import ctypes as C
+
+    raw = np.random.RandomState(12345).randint(0, 2**32, size=64, dtype=np.uint64)
+    out = (C.c_uint32 * 64)()
+    pyoracle.lib().mulls_oracle_sac_draws(out, 64)
+    assert list(out) == [int(v) >> 1 for v in raw]
+    assert out[0] == 3992670690 >> 1  # mt19937(12345)'s first output
+
+
 def test_degenerate_inputs():
     P = abi.ground_params()
     empty = np.zeros(0, abi.POINT_DTYPE)
@@ -67,8 +114,14 @@ def test_degenerate_inputs():
         if pyref.available():
             b = pyref.ground_filter(pts, P)
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    for method in (1, 2, 3):  # one point, a line of points: no cell is a ground cell, no normal is estimated — and nothing breaks
+        Pm = abi.ground_params(estimate_ground_normal_method=method)
+        for pts in (one, flat):
+            a = pyoracle.ground_filter(pts, Pm)
+            if pyref.available():
+                assert all(np.array_equal(x, y) for x, y in zip(a, pyref.ground_filter(pts, Pm)))
     with pytest.raises(RuntimeError):
-        pyoracle.ground_filter(one, abi.ground_params(estimate_ground_normal_method=3))
+        pyoracle.ground_filter(one, abi.ground_params(estimate_ground_normal_method=4))
     del empty  # an empty cloud divides by a zero sample count upstream: not fed (the device entry point returns three empty clouds)
 
 
@@ -102,6 +155,23 @@ def test_device_on_the_golden_scan(ctx_auto):
     a = ctx_auto.ground_filter(z["scan"].view(abi.POINT_DTYPE).reshape(-1), abi.ground_params())
     assert [len(x) for x in a] == list(z["sizes"])
     assert [int(np.frombuffer(x.tobytes(), np.uint32).astype(np.uint64).sum() & 0xffffffff) for x in a] == list(z["checksums"])
+
+
+@pytest.mark.gpu
+def test_device_normal_methods_equal_oracle(ctx_auto):
+    """estimate_ground_normal_method 1 - 3 on the device against the oracle, every output record byte for byte: the per-cell plane RANSAC
+    (k_gf_ransac) and the neighbourhood normals (k_gf_normals) take the same samples, the same inliers / neighbours and the same float sums."""
+    for cname, pts in clouds():
+        for pname, P in normal_param_sets():
+            a = pyoracle.ground_filter(pts, P)
+            b = ctx_auto.ground_filter(pts, P)
+            for k, what in enumerate(("ground", "ground_down", "unground")):
+                assert a[k].shape == b[k].shape, (cname, pname, what, a[k].shape, b[k].shape)
+                assert np.array_equal(a[k], b[k]), (cname, pname, what)
+    for method in (1, 2, 3):  # degenerate inputs: no ground cell at all
+        Pm = abi.ground_params(estimate_ground_normal_method=method)
+        one = abi.make_points(np.array([[1.0, 2.0, -1.7]], np.float32), np.zeros((1, 3), np.float32), np.array([5.0], np.float32), np.zeros(1, np.float32))
+        assert all(np.array_equal(x, y) for x, y in zip(pyoracle.ground_filter(one, Pm), ctx_auto.ground_filter(one, Pm)))
 
 
 @pytest.mark.gpu

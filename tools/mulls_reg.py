@@ -34,6 +34,7 @@ def flags(argv=None):
     p.add_argument("--gf_nonground_down_rate", type=int, default=3)
     p.add_argument("--dist_inverse_sampling_method", type=int, default=0)
     p.add_argument("--unit_dist", type=float, default=15.0)
+    p.add_argument("--ground_normal_method", type=int, default=3, help="extract_semantic_pts' default (cfilter.hpp:2304): 3 = plane RANSAC per grid cell")
     p.add_argument("--pca_distance_adpative_on", type=boolean, default=False)
     p.add_argument("--pca_neighbor_radius", type=float, default=1.0)
     p.add_argument("--pca_neighbor_count", type=int, default=30)
@@ -55,12 +56,12 @@ def read_cloud(path):
 
 
 def extract_semantic_pts(ctx, scan, F, vf_downsample_resolution):
-    """CFilter::extract_semantic_pts (cfilter.hpp:2294-2413) as test/mulls_reg.cpp:134-143 calls it; estimate_ground_normal_method 0.
+    """CFilter::extract_semantic_pts (cfilter.hpp:2294-2413) as test/mulls_reg.cpp:134-143 calls it (its default ground normal method 3: the per-cell plane RANSAC).
     Returns (class clouds, their *_down clouds, pc_down)."""
     GP = abi.ground_params(min_grid_pt_num=8, grid_resolution=F.gf_grid_size, max_height_difference=F.gf_in_grid_h_thre,
                            neighbor_height_diff=F.gf_neigh_grid_h_thre, max_ground_height=F.gf_max_h, ground_random_down_rate=F.gf_ground_down_rate,
                            ground_random_down_down_rate=2, nonground_random_down_rate=F.gf_nonground_down_rate, reliable_neighbor_grid_num_thre=0,
-                           estimate_ground_normal_method=0, distance_weight_downsampling_method=F.dist_inverse_sampling_method,
+                           estimate_ground_normal_method=F.ground_normal_method, distance_weight_downsampling_method=F.dist_inverse_sampling_method,
                            standard_distance=F.unit_dist, fixed_num_downsampling=0, down_ground_fixed_num=500, intensity_thre=3.0e38,
                            apply_grid_wise_outlier_filter=0)
     CP = abi.classify_params(neighbor_searching_radius=F.pca_neighbor_radius, neighbor_k=F.pca_neighbor_count, neigh_k_min=8, pca_down_rate=1,
