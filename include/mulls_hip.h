@@ -192,13 +192,41 @@ void mulls_destroy(mulls_ctx *ctx);
 const char *mulls_last_error(const mulls_ctx *ctx);
 int mulls_set_profiling(mulls_ctx *ctx, int on);
 int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
-/* correspondence-search tier: 0 = auto (target class clouds of <= 9728 points: uniform grid staged in LDS, run by the
- * device-resident loop — one launch iterates every pair of the batch to the end — for batches of more than 8 pairs;
- * otherwise the uniform grid in global memory with lock-step launches), 1 = LDS-tiled brute force, 2 = uniform grid in
- * global memory, 3 = uniform grid staged in LDS with lock-step launches (MULLS_E_INVALID when a cloud is too large),
- * 4 = device-resident loop (the lock-step LDS tier where the loop does not apply: normal shooting, source class clouds
- * above 16384 points).  All tiers are exact and return bit-identical results (tests/test_gpu_stages.py, test_gpu_icp.py). */
+/* correspondence-search tier: 0 = auto, 1 = LDS-tiled brute force, 2 = uniform grid in global memory, 3 = uniform grid staged in LDS with lock-step
+ * launches (MULLS_E_INVALID when a searched target class cloud exceeds 9728 points), 4 = device-resident loop (k_icp: one launch iterates every pair
+ * of the batch to the end; the lock-step LDS tier where the loop does not apply: normal shooting, source class clouds above 16384 points).
+ * Auto: searched target class clouds of <= 9728 points -> the grid staged in LDS, stepped by lock-step launch sets (the O(1) half of the iteration
+ * on the device too) or, inside the window MULLS_OPT_RESIDENT_MIN_PAIRS .. _MAX_PAIRS, by the device-resident loop; larger targets -> the grid in
+ * global memory.  All tiers are exact and return bit-identical results (tests/test_gpu_stages.py, test_gpu_icp.py). */
 int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
+/* Execution options of a context (none of them changes a result: every path returns the same bits).  mulls_create presets each from the environment
+ * variable named after it (MULLS_OPT_HOST_STEP <- MULLS_HOST_STEP=1, ...: diagnostics and the A/B scripts under tools/); nothing reads the
+ * environment after that. */
+enum mulls_option
+{
+	MULLS_OPT_HOST_STEP = 0,			  /* [0] 1: the lock-step loop is stepped by the host (what per-iteration traces switch on anyway) */
+	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [4]   auto mode runs the device-resident loop for batches of MIN .. MAX pairs; */
+	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [256] MAX < MIN: never (MULLS_NO_RESIDENT=1 presets that) */
+	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 4 launches per iteration instead of 7 (one accumulation launch;
+											 finish + step + publication as one kernel) — small batches are bound by the launch count */
+	MULLS_OPT_SUBBATCHES = 4,			  /* [0 = by batch size] host-stepped loop: sub-batches in flight (1 or 2) */
+	MULLS_OPT_TWO_STREAMS = 5,			  /* [0] host-stepped loop: the second sub-batch on a second stream */
+	MULLS_OPT_CERTIFICATES = 6,			  /* [1] LDS tier: certified correspondences (0: every point is searched every iteration; MULLS_NO_CERT=1) */
+	MULLS_OPT_CERT_SLACK_MIN = 7,		  /* [0.02 m] how much farther than the hinted target a searched query sweeps: */
+	MULLS_OPT_CERT_SLACK_MAX = 8,		  /* [0.10 m]   clamp(rate * distance moved, min, max)                          */
+	MULLS_OPT_CERT_SLACK_RATE = 9,		  /* [1.0] */
+	MULLS_OPT_LDS_DEDUP = 10,			  /* [1] LDS tier: duplicate rule and rejection chain inside the search kernels (0: k_filter; MULLS_NO_LDS_DEDUP=1) */
+	MULLS_OPT_GRID_H0 = 11,				  /* [0 = 1.0 m] LDS tier: preferred cell edge */
+	MULLS_OPT_BM_H0 = 12,				  /* [0 = from the point spacing] global-memory tier: one fixed cell edge for every cloud */
+	MULLS_OPT_LEAN_STAGING = 13,		  /* [0] mulls_icp / mulls_icp_batch stage only what the registration reads: the classes of used_feature_type (plus the
+											 source ground / pillar / facade clouds the intersection box is taken from).  mulls_result.nsrc0 / ntgt0 of the
+											 classes left out report 0; every output of the reference's interface is unchanged.  The C++ bridge switches it on. */
+	MULLS_OPT_DEBUG_STOP = 14,			  /* [0] kernel bring-up switches (tools/gpu_time_nn.py) */
+	MULLS_OPT_DEBUG_TICK = 15,			  /* [0] tests: start a fresh batch's duplicate-table epoch counter here */
+	MULLS_OPT_COUNT = 16
+};
+int mulls_set_option(mulls_ctx *ctx, int option, double value);
+int mulls_get_option(const mulls_ctx *ctx, int option, double *value);
 /* raw hipStream_t the library launches on (so callers can bracket it with their own events) */
 void *mulls_stream(mulls_ctx *ctx);
 

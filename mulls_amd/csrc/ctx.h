@@ -33,6 +33,7 @@ struct mulls_ctx
 	void *cl_buf = nullptr; // mulls_classify_nground's device arena (grow-only)
 	size_t cl_cap = 0;
 	size_t gf_cap = 0;
+	double opt[MULLS_OPT_COUNT] = {}; // enum mulls_option (mulls_set_option; preset from the environment by mulls_create)
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 

@@ -27,9 +27,6 @@
 #include "launch.h"
 #include "ctx.h"
 
-// auto mode (nn_mode 0): batch sizes the device-resident loop takes (prepare_run)
-#define MULLS_RESIDENT_MIN_PAIRS 4
-#define MULLS_RESIDENT_MAX_PAIRS 256
 
 using mulls::Mat4;
 using mulls::Mat6;
@@ -194,33 +191,56 @@ int check_params(mulls_ctx *ctx, const mulls_params *P)
 	return MULLS_OK;
 }
 
-// certified correspondences of the LDS tier (k_nn_lds): on unless MULLS_NO_CERT is set; MULLS_CERT_SLACK="min,max,rate" (metres,
-// metres, factor on the distance a point moved) tunes how much farther than the hinted target a searched query sweeps
-void init_cert(RunParams &rp)
+// certified correspondences of the LDS tier (k_cert / k_nn_lds): MULLS_OPT_CERTIFICATES, and how much farther than the hinted target a searched
+// query sweeps (MULLS_OPT_CERT_SLACK_*: metres, metres, factor on the distance a point moved)
+void init_cert(const mulls_ctx *ctx, RunParams &rp)
 {
-	rp.cert = std::getenv("MULLS_NO_CERT") ? 0u : 1u;
-	rp.cert_slack_min = 0.02f;
-	rp.cert_slack_max = 0.10f;
-	rp.cert_slack_rate = 1.0f;
-	if (const char *e = std::getenv("MULLS_CERT_SLACK"))
+	rp.cert = ctx->opt[MULLS_OPT_CERTIFICATES] != 0.0 ? 1u : 0u;
+	rp.cert_slack_min = (float)ctx->opt[MULLS_OPT_CERT_SLACK_MIN];
+	rp.cert_slack_max = (float)ctx->opt[MULLS_OPT_CERT_SLACK_MAX];
+	rp.cert_slack_rate = (float)ctx->opt[MULLS_OPT_CERT_SLACK_RATE];
+}
+
+// sub-batches in flight of a host-stepped lock-step batch of n pairs
+int subbatch_count(const mulls_ctx *ctx, int n)
+{
+	int nsub = n >= 2048 ? 2 : 1; // below that the half-size launches cost more (k_nn_lds tail) than the overlap returns
+	if (ctx->opt[MULLS_OPT_SUBBATCHES] >= 1.0)
+		nsub = std::max(1, std::min(2, (int)ctx->opt[MULLS_OPT_SUBBATCHES]));
+	return n < 2 ? 1 : nsub;
+}
+
+// defaults of enum mulls_option, then the presets from the environment (read here and nowhere else)
+void options_init(mulls_ctx *ctx)
+{
+	double *o = ctx->opt;
+	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 4, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 256, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 384;
+	o[MULLS_OPT_SUBBATCHES] = 0, o[MULLS_OPT_TWO_STREAMS] = 0, o[MULLS_OPT_CERTIFICATES] = 1;
+	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
+	o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0;
+	static const struct
+	{
+		const char *name;
+		int opt;
+	} env[] = {{"MULLS_HOST_STEP", MULLS_OPT_HOST_STEP}, {"MULLS_RESIDENT_MIN_PAIRS", MULLS_OPT_RESIDENT_MIN_PAIRS}, {"MULLS_RESIDENT_MAX_PAIRS", MULLS_OPT_RESIDENT_MAX_PAIRS},
+			   {"MULLS_FEW_LAUNCHES_MAX_PAIRS", MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS}, {"MULLS_SUBBATCHES", MULLS_OPT_SUBBATCHES}, {"MULLS_TWO_STREAMS", MULLS_OPT_TWO_STREAMS},
+			   {"MULLS_CERTIFICATES", MULLS_OPT_CERTIFICATES}, {"MULLS_LDS_DEDUP", MULLS_OPT_LDS_DEDUP}, {"MULLS_GRID_H0", MULLS_OPT_GRID_H0}, {"MULLS_BM_H0", MULLS_OPT_BM_H0},
+			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}};
+	for (const auto &e : env)
+		if (const char *v = std::getenv(e.name))
+			o[e.opt] = std::strtod(v, nullptr);
+	if (std::getenv("MULLS_NO_CERT"))
+		o[MULLS_OPT_CERTIFICATES] = 0;
+	if (std::getenv("MULLS_NO_LDS_DEDUP"))
+		o[MULLS_OPT_LDS_DEDUP] = 0;
+	if (std::getenv("MULLS_NO_RESIDENT"))
+		o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0;
+	if (const char *e = std::getenv("MULLS_CERT_SLACK")) // "min,max,rate"
 	{
 		float a = 0, b = 0, c = 0;
 		if (std::sscanf(e, "%f,%f,%f", &a, &b, &c) == 3 && a >= 0.0f && b >= a && c >= 0.0f)
-		{
-			rp.cert_slack_min = a;
-			rp.cert_slack_max = b;
-			rp.cert_slack_rate = c;
-		}
+			o[MULLS_OPT_CERT_SLACK_MIN] = a, o[MULLS_OPT_CERT_SLACK_MAX] = b, o[MULLS_OPT_CERT_SLACK_RATE] = c;
 	}
-}
-
-// sub-batches in flight of a lock-step batch of n pairs (mulls_icp_batch / mulls_batch_run)
-int subbatch_count(int n)
-{
-	int nsub = n >= 2048 ? 2 : 1; // below that the half-size launches cost more (k_nn_lds tail) than the overlap returns
-	if (const char *e = std::getenv("MULLS_SUBBATCHES"))
-		nsub = std::max(1, std::min(2, std::atoi(e)));
-	return n < 2 ? 1 : nsub;
 }
 
 void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
@@ -252,9 +272,14 @@ void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 				Job j = {(uint32_t)p, (uint32_t)c, 0u, B->descs_h[p * MULLS_NC + c].src_cap};
 				B->cjobs_h.push_back(j);
 			}
-	if (B->cjobs_h.size() < 512)
+	uint32_t max_src_cap = 0;
+	for (const Job &j : B->cjobs_h)
+		max_src_cap = std::max(max_src_cap, j.count);
+	if (B->cjobs_h.size() < 512 && max_src_cap > 4096u)
 	{
-		// too few class clouds to fill 256 CUs: split them into 512-query jobs (each stages its target cloud itself)
+		// few AND large class clouds (a pair of dense scans): split them into 512-query jobs (each stages its target cloud itself) so that more than a
+		// handful of workgroups walk them.  Down-sampled class clouds stay whole whatever the batch size: a class-level job resolves the duplicate
+		// rule and the rejection chain itself (no k_filter launch), and a small batch is bound by the number of launches, not by their width
 		B->cjobs_h.clear();
 		for (int p = 0; p < B->n; p++)
 			for (int c = 0; c < MULLS_NC; c++)
@@ -698,7 +723,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	hipStream_t st = ctx->stream;
 	const int n = B->n;
 	const std::string old_key = B->jobs_key;
-	build_jobs(B, P_jobs, nsub > 0 ? nsub : subbatch_count(n));
+	build_jobs(B, P_jobs, nsub > 0 ? nsub : subbatch_count(ctx, n));
 	uint32_t lds_cap = 0;
 	const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
 	if (tier < 0)
@@ -712,9 +737,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += rp.used[c];
 	rp.bm_h0 = 0.0f;
-	rp.grid_h0 = MULLS_GRID_H0;
-	if (const char *e = std::getenv("MULLS_GRID_H0")) // diagnostics
-		rp.grid_h0 = std::max(0.05f, (float)std::atof(e));
+	rp.grid_h0 = ctx->opt[MULLS_OPT_GRID_H0] > 0.0 ? std::max(0.05f, (float)ctx->opt[MULLS_OPT_GRID_H0]) : MULLS_GRID_H0;
 	rp.lds_dedup = 0;
 	bool resident = false;
 	if (tier == 2)
@@ -724,7 +747,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		// still leave a useful cell budget next to the staged cloud (MULLS_ICP_STATIC_LDS bytes stay free for the static LDS of k_icp)
 		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
 		const long left = 160L * 1024L - 64L - (long)MULLS_ICP_STATIC_LDS - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
-		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 4096 && !std::getenv("MULLS_NO_LDS_DEDUP"); // k_nn_shoot uses the global table
+		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 4096 && ctx->opt[MULLS_OPT_LDS_DEDUP] != 0.0; // k_nn_shoot uses the global table
 		// Device-resident loop (k_icp: one workgroup carries a pair through all its iterations): the default whenever the LDS tier
 		// applies with its on-chip duplicate table, the loop is the plain mm_lls_icp one (resident_out) and no source class cloud is
 		// so large that one workgroup per pair would be the wrong shape (those pairs are spread over many workgroups by the
@@ -736,7 +759,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		uint32_t max_src = 0;
 		for (const Job &j : B->rjobs_h)
 			max_src = std::max(max_src, j.count);
-		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && n >= MULLS_RESIDENT_MIN_PAIRS && n <= MULLS_RESIDENT_MAX_PAIRS && !std::getenv("MULLS_NO_RESIDENT")));
+		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && n >= (int)ctx->opt[MULLS_OPT_RESIDENT_MIN_PAIRS] && n <= (int)ctx->opt[MULLS_OPT_RESIDENT_MAX_PAIRS]));
 		if ((class_level || resident) && dedup_fits)
 		{
 			rp.lds_dedup = 1;
@@ -749,9 +772,9 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		// occupancy-bitmap grids: grid_maxcells / cell_stride count 64-cell words per cloud
 		rp.bm_h0 = MULLS_BM_H0;
 		rp.bm_auto = 1;
-		if (const char *e = std::getenv("MULLS_BM_H0")) // diagnostics: one fixed cell edge for every cloud
+		if (ctx->opt[MULLS_OPT_BM_H0] > 0.0) // diagnostics: one fixed cell edge for every cloud
 		{
-			rp.bm_h0 = std::max(0.05f, (float)std::atof(e));
+			rp.bm_h0 = std::max(0.05f, (float)ctx->opt[MULLS_OPT_BM_H0]);
 			rp.bm_auto = 0;
 		}
 		const size_t clouds = std::max<size_t>((size_t)n * std::max(n_used, 1), 1);
@@ -909,9 +932,8 @@ static mulls::IcpConst icp_const(const mulls_params *P)
 // with 0xff and the count restarts (stream order puts the fill before this run's kernels).
 static int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, uint32_t *base)
 {
-	if (const char *e = std::getenv("MULLS_DEBUG_TICK")) // tests only: put a fresh batch's counter next to the wrap
-		if (B->tick == 1)
-			B->tick = (uint32_t)std::strtoul(e, nullptr, 0);
+	if (ctx->opt[MULLS_OPT_DEBUG_TICK] > 0.0 && B->tick == 1) // tests only: put a fresh batch's counter next to the wrap
+		B->tick = (uint32_t)ctx->opt[MULLS_OPT_DEBUG_TICK];
 	if (B->tick > 0xfffffff0u - n)
 	{
 		if (B->winner)
@@ -961,6 +983,7 @@ extern "C"
 			return MULLS_E_NO_DEVICE;
 		mulls_ctx *ctx = new mulls_ctx();
 		ctx->device = device;
+		options_init(ctx);
 		if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
 			hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
 			hipEventCreateWithFlags(&ctx->ev_setup, hipEventDisableTiming) != hipSuccess)
@@ -1034,6 +1057,21 @@ extern "C"
 	}
 
 	void *mulls_stream(mulls_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+	int mulls_set_option(mulls_ctx *ctx, int option, double value)
+	{
+		if (!ctx || option < 0 || option >= MULLS_OPT_COUNT || !(value == value))
+			return MULLS_E_INVALID;
+		ctx->opt[option] = value;
+		return MULLS_OK;
+	}
+	int mulls_get_option(const mulls_ctx *ctx, int option, double *value)
+	{
+		if (!ctx || !value || option < 0 || option >= MULLS_OPT_COUNT)
+			return MULLS_E_INVALID;
+		*value = ctx->opt[option];
+		return MULLS_OK;
+	}
 
 	int mulls_set_nn_mode(mulls_ctx *ctx, int mode)
 	try
@@ -1130,11 +1168,10 @@ extern "C"
 		rp.win_li = P->pt2li_residual_window;
 		rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
 		rp.resid_from_iter = 2;
-		init_cert(rp);
+		init_cert(ctx, rp);
 		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
 			return rc;
-		if (const char *dbg = std::getenv("MULLS_DEBUG_STOP"))
-			rp.debug_stop = (uint32_t)std::atoi(dbg);
+		rp.debug_stop = (uint32_t)ctx->opt[MULLS_OPT_DEBUG_STOP];
 
 		// Lock-step tiers: the O(1) half of every iteration (count test, 6x6 solve, convergence tests, residual) runs on the device behind the
 		// accumulation (k_finish_step) unless the caller wants per-iteration traces, which the host half collects (MULLS_HOST_STEP=1: diagnostics).
@@ -1142,8 +1179,7 @@ extern "C"
 		bool dstep = P->max_iter_num > 0;
 		for (int p = 0; p < n && dstep; p++)
 			dstep = !(results[p].trace && results[p].trace_cap > 0);
-		if (const char *e = std::getenv("MULLS_HOST_STEP"))
-			dstep = dstep && std::atoi(e) == 0;
+		dstep = dstep && ctx->opt[MULLS_OPT_HOST_STEP] == 0.0;
 		uint32_t lds_cap = 0;
 		int tier = 0;
 		bool resident = false;
@@ -1323,6 +1359,9 @@ extern "C"
 			} drain{ctx};
 			const uint32_t epoch0 = B->epoch2;
 			uint32_t left = (uint32_t)n, nn_launches = 0;
+			// Small batches are bound by the NUMBER of launches (a kernel of a few hundred workgroups takes ~5 us whatever it does; one pair is bound by
+			// the host's ~4 us per launch): the three accumulation launches become one, finish + step + publication one (k_finish_step)
+			const bool few_launches = n <= (int)ctx->opt[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS];
 			// wait until launch set `set` has published; left = pairs still iterating after the newest published set
 			auto wait_set = [&](int set) -> int {
 				const uint32_t want = epoch0 + (uint32_t)set + 1u;
@@ -1394,9 +1433,9 @@ extern "C"
 				// residual kernel time; a set of a converging batch mixes both kinds of pairs and is charged to the accumulation
 				ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 				for (int k = 0; k < B->nsub; k++)
-					launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+					launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
 				launch_finish_step(st, (uint32_t)n, B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, word_dev, ++B->epoch2,
-								   use_grid ? 0 : 1);
+								   use_grid ? 0 : 1, few_launches ? B->ticket + 2 : nullptr);
 				ev.end();
 			}
 			ctx->prof.ms_host_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() * 1e3 - ctx->prof.ms_host_wait;
@@ -1457,7 +1496,7 @@ extern "C"
 			hipStream_t st = nullptr;
 			EvTimer evt{nullptr};
 		};
-		const int nsub = subbatch_count(n);
+		const int nsub = subbatch_count(ctx, n);
 		Sub subs[2];
 		for (int k = 0; k < nsub; k++)
 		{
@@ -1484,9 +1523,7 @@ extern "C"
 		// run under the first one's search (issue-bound, one workgroup per CU) and vice versa
 		// Opt-in (MULLS_TWO_STREAMS=1): measured +4 % registrations/s at 4096 pairs, but the two searches then share the CUs and
 		// every kernel's own duration doubles, which would blur the per-kernel accounting bench.py and the profiles report.
-		bool two_streams = false;
-		if (const char *e = std::getenv("MULLS_TWO_STREAMS"))
-			two_streams = nsub == 2 && std::atoi(e) != 0;
+		const bool two_streams = nsub == 2 && ctx->opt[MULLS_OPT_TWO_STREAMS] != 0.0;
 		if (two_streams)
 		{
 			subs[1].st = ctx->stream2;
@@ -1802,7 +1839,7 @@ extern "C"
 		rp.win_pl = rp.win_li = rp.win_pt = 0.1f;			  // residual_window_size default of pt2pl_ground_3dof_lls_summation (:2323)
 		rp.cos_bearing = std::cos(40.0f / 180.0 * M_PI); // determine_corres' default angle_thre_degree (:1704)
 		rp.resid_from_iter = -1;							  // no iteration gate in ground_3dof_lls_tran_estimation (:2294)
-		init_cert(rp);
+		init_cert(ctx, rp);
 		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
 			return rc;
 		mulls_params Pj = *P;
@@ -2179,7 +2216,11 @@ extern "C"
 			return rc;
 		uint32_t lds_cap = 0;
 		int tier = 0;
+		// the stage entry points hand out the raw nearest neighbours (nn_idx before the duplicate rule): k_filter applies the chain, not the search kernels
+		const double dedup_opt = ctx->opt[MULLS_OPT_LDS_DEDUP];
+		ctx->opt[MULLS_OPT_LDS_DEDUP] = 0.0;
 		rc = prepare_run(ctx, B, &P, *rp, &lds_cap, &tier);
+		ctx->opt[MULLS_OPT_LDS_DEDUP] = dedup_opt;
 		if (rc != MULLS_OK)
 			return rc;
 		launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, *rp);

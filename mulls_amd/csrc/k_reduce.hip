@@ -203,27 +203,34 @@ __global__ __launch_bounds__(64) void k_step_init(uint32_t npairs, const PairSet
 	ps.pad_[0] = ps.pad_[1] = ps.pad_[2] = 0;
 }
 
-__global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
-											 const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute)
+// the step of one pair by the first wave of the workgroup (k_step: a 64-lane workgroup; k_finish_step: the first wave of the 256 lanes that summed
+// the pair's partials — every lane reaches the barriers).  Returns (to every lane) whether the pair still iterates or waits for its residual pass.
+struct StepLds
 {
-	const uint32_t pair = blockIdx.x;
+	mulls::StepState S;
+	SolveWs ws;
+	double comb[MULLS_NTERM_PAD];
+	uint32_t cnt[32]; // the record's counter block: n_valid, n_alive, src_n, tgt_n, bbox (6 each)
+	uint32_t jobs[MULLS_NC], n0[MULLS_NC];
+	int go, iter, active, resid, done, left;
+};
+__device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__restrict__ descs, PairState *__restrict__ states, const RunParams &rp, const mulls::IcpConst &K,
+										   const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, StepLds &L)
+{
 	const int l = (int)threadIdx.x;
-	__shared__ mulls::StepState S;
-	__shared__ SolveWs ws;
-	__shared__ double s_comb[MULLS_NTERM_PAD];
-	__shared__ uint32_t s_cnt[32]; // the record's counter block: n_valid, n_alive, src_n, tgt_n, bbox (6 each)
-	__shared__ uint32_t s_jobs[MULLS_NC], s_n0[MULLS_NC];
-	__shared__ int s_go, s_iter, s_active, s_resid, s_done;
+	mulls::StepState &S = L.S;
 	if (l == 0)
 	{
-		s_active = states[pair].active;
-		s_resid = states[pair].want_residual;
-		s_iter = states[pair].iter;
+		L.active = states[pair].active;
+		L.resid = states[pair].want_residual;
+		L.iter = states[pair].iter;
+		L.left = 0;
 	}
 	__syncthreads();
-	if (s_active || s_resid) // uniform
+	if (L.active || L.resid) // uniform
 	{
 		const PairOut &o = out[pair];
+		if (l < 64)
 		{
 			const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&steps[pair]);
 			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&S);
@@ -231,26 +238,26 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 				dst[w] = src[w];
 		}
 		if (l < MULLS_NTERM_PAD)
-			s_comb[l] = o.comb[l];
+			L.comb[l] = o.comb[l];
 		if (l < 30)
-			s_cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
+			L.cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
 		if (l < MULLS_NC)
 		{
 			const CloudDesc &d = descs[pair * MULLS_NC + l];
-			s_jobs[l] = d.job_end - d.job_begin;
-			s_n0[l] = d.src_n0;
+			L.jobs[l] = d.job_end - d.job_begin;
+			L.n0[l] = d.src_n0;
 		}
 		__syncthreads();
-		const uint32_t *n_valid = s_cnt, *n_alive = s_cnt + 6, *src_n = s_cnt + 12, *tgt_n = s_cnt + 18, *obox = s_cnt + 24;
+		const uint32_t *n_valid = L.cnt, *n_alive = L.cnt + 6, *src_n = L.cnt + 12, *tgt_n = L.cnt + 18, *obox = L.cnt + 24;
 		mulls::PairIter &h = S.h;
 		if (l == 0)
 		{
-			s_go = 0;
-			if (s_resid)
-				mulls::step_residual(h, K, s_comb[0], s_comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
+			L.go = 0;
+			if (L.resid)
+				mulls::step_residual(h, K, L.comb[0], L.comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
 			else
 			{
-				const int i = s_iter;
+				const int i = L.iter;
 				h.iters = i + 1;
 				if (S.first)
 				{
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 					int sfc = 0;
 					for (int c = 0; c < MULLS_NC; c++)
 					{
-						const uint32_t n0 = rp.undistort ? s_n0[c] : src_n[c];
+						const uint32_t n0 = rp.undistort ? L.n0[c] : src_n[c];
 						S.nsrc0[c] = n0;
 						S.ntgt0[c] = tgt_n[c];
 						S.alive_prev[c] = src_n[c];
@@ -278,23 +285,24 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 							S.pair_evals += (unsigned long long)S.alive_prev[c] * tgt_n[c];
 						S.src_pts += S.alive_prev[c];
 						S.tgt_pts += tgt_n[c];
-						S.tgt_job_pts += (unsigned long long)tgt_n[c] * s_jobs[c];
+						S.tgt_job_pts += (unsigned long long)tgt_n[c] * L.jobs[c];
 					}
 					S.alive_prev[c] = n_alive[c];
 					S.ncorr[c] = n_valid[c];
 					S.corr_pts += n_valid[c];
 				}
-				s_go = mulls::step_counts(h, K, n_valid) ? 1 : 0; // :1305-1311, then update_corr_dist_thre :1855-1866
+				L.go = mulls::step_counts(h, K, n_valid) ? 1 : 0; // :1305-1311, then update_corr_dist_thre :1855-1866
 			}
 		}
 		__syncthreads();
-		if (s_go)
-			solve_wave(h, K, s_comb, s_iter, ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
+		if (L.go && l < 64)
+			solve_wave(h, K, L.comb, L.iter, L.ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
 		__syncthreads();
 		if (l == 0)
 		{
-			s_done = (!h.active && !h.want_residual) ? 1 : 0;
-			if (s_done)
+			L.done = (!h.active && !h.want_residual) ? 1 : 0;
+			L.left = L.done ? 0 : 1;
+			if (L.done)
 				h.guess = h.temp * h.guess; // :1403 (TempTran is the identity after a failure)
 		}
 		__syncthreads();
@@ -308,17 +316,18 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 			ps.thr[l - 18] = h.thr[l - 18];
 		else if (l == 24)
 		{
-			ps.iter = h.want_residual ? h.iters - 1 : s_iter + 1;
+			ps.iter = h.want_residual ? h.iters - 1 : L.iter + 1;
 			ps.active = h.active ? 1 : 0;
 			ps.want_residual = h.want_residual ? 1 : 0;
 		}
+		if (l < 64)
 		{
 			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&steps[pair]);
 			const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&S);
 			for (uint32_t w = (uint32_t)l; w < sizeof(mulls::StepState) / 8; w += 64u)
 				dst[w] = src[w];
 		}
-		if (s_done) // the result record (the fields k_icp's timers fill stay zero)
+		if (L.done) // the result record (the fields k_icp's timers fill stay zero)
 		{
 			IcpOut &O = results[pair];
 			if (l < 16)
@@ -347,6 +356,46 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 				O.tgt_job_pts = S.tgt_job_pts;
 				O.pair_evals = S.pair_evals;
 			}
+		}
+	}
+	return L.left != 0;
+}
+
+__global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
+											 const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute)
+{
+	__shared__ StepLds L;
+	(void)step_pair(blockIdx.x, descs, states, rp, K, out, steps, results, brute, L);
+}
+
+// Small batches (launch_finish_step decides): k_finish, k_step and k_step_publish as ONE launch — a workgroup sums its pair's partials, its
+// first wave steps the pair, and the last workgroup to arrive publishes the word the host reads.  With a few hundred workgroups the arrival
+// ticket (one device-scope fence and two atomics per workgroup) costs less than the two launches it saves; with thousands it does not
+// (110 us at 4096 pairs), so large batches keep the three kernels.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_finish_step(CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
+															  const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
+															  mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, uint32_t *__restrict__ ticket,
+															  volatile unsigned long long *host_word, uint32_t epoch)
+{
+	__shared__ StepLds L;
+	const uint32_t pair = blockIdx.x;
+	if (states[pair].active || states[pair].want_residual) // uniform per workgroup
+		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
+	__threadfence_block();
+	__syncthreads(); // the record is read back by the step below
+	const bool left = step_pair(pair, descs, states, rp, K, out, steps, results, brute, L);
+	if (threadIdx.x == 0)
+	{
+		if (left)
+			atomicAdd(&ticket[1], 1u);
+		__threadfence();
+		const uint32_t t = atomicAdd(&ticket[0], 1u);
+		if (t == gridDim.x - 1u)
+		{
+			const uint32_t n_left = atomicExch(&ticket[1], 0u);
+			ticket[0] = 0u; // re-armed for the next launch (stream order: nobody else touches it before)
+			__threadfence_system();
+			*host_word = (unsigned long long)epoch << 32 | n_left;
 		}
 	}
 }
@@ -425,13 +474,22 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 #include "launch.h"
 
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial)
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single)
 {
 	static bool attr_set = false;
 	if (!attr_set)
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
 		attr_set = true;
+	}
+	if (single)
+	{
+		// small batches: one launch for every trip length (a kernel of a few hundred workgroups takes ~5 us whatever it does: two launches saved
+		// are worth more than the short trips' better occupancy)
+		if (split[3] > split[0])
+			hipLaunchKernelGGL((k_accum<1024, 2>), dim3(split[3] - split[0]), dim3(1024), MULLS_RED_BYTES_HALF, st, leaders + split[0], jobs, descs, states, rp, spos, mq,
+							   flag, wd, partial);
+		return;
 	}
 	// leaders[split[0] .. split[1]): trips of more than 512 slots; [split[1] .. split[2]): 257..512; [split[2] .. split[3]): up to 256
 	if (split[1] > split[0])
@@ -471,10 +529,16 @@ void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, c
 }
 
 void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
-						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute)
+						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
+						uint32_t *ticket)
 {
 	if (!npairs)
 		return;
+	if (ticket) // small batch: one launch
+	{
+		hipLaunchKernelGGL(k_finish_step, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, K, partial, out, bbox, steps, results, brute, ticket, host_word, epoch);
+		return;
+	}
 	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, 0u, static_cast<uint4 *>(nullptr),
 					   static_cast<uint32_t *>(nullptr), static_cast<volatile uint32_t *>(nullptr), 0u);
 	hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute);

@@ -35,7 +35,7 @@ void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *d
 				   const unsigned long long *winner, const float4 *tpos, float4 *mq);
 // leaders: job indices of the trip starts, grouped by trip length (split[0..3]: see k_reduce.hip)
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial);
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single = false);
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
 				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
 				   uint32_t pair_base);
@@ -48,7 +48,8 @@ struct StepState;
 // lock-step loop with the O(1) half of the iteration on the device: initial per-pair state and first PairState; k_finish followed by the step (k_step)
 void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, const mulls::IcpConst &K, mulls::StepState *steps, PairState *states);
 void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
-						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute);
+						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
+						uint32_t *ticket = nullptr); // ticket: two zeroed device words -> finish, step and publication in one launch (small batches)
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
 					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq);

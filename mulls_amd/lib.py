@@ -40,6 +40,8 @@ def load():
     lib.mulls_set_profiling.argtypes = [vp, C.c_int]
     lib.mulls_get_profile.argtypes = [vp, C.POINTER(abi.Profile)]
     lib.mulls_set_nn_mode.argtypes = [vp, C.c_int]
+    lib.mulls_set_option.argtypes = [vp, C.c_int, C.c_double]
+    lib.mulls_get_option.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.mulls_stream.argtypes = [vp]
     lib.mulls_stream.restype = vp
     lib.mulls_icp.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
@@ -165,6 +167,15 @@ class Context:
     def set_nn_mode(self, mode):
         """0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS (lock-step), 4 device-resident loop."""
         self._check(self.lib.mulls_set_nn_mode(self.h, int(mode)), "mulls_set_nn_mode")
+
+    def set_option(self, option, value):
+        """enum mulls_option (abi.OPT_*): execution options of the context; none of them changes a result."""
+        self._check(self.lib.mulls_set_option(self.h, int(option), float(value)), "mulls_set_option")
+
+    def get_option(self, option):
+        v = C.c_double(0)
+        self._check(self.lib.mulls_get_option(self.h, int(option), C.byref(v)), "mulls_get_option")
+        return v.value
 
     def profile(self):
         p = abi.Profile()

@@ -97,7 +97,7 @@ def test_batch_equals_single(ctx, pairs_small):
         assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma  # bit-identical
 
 
-def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small, monkeypatch):
+def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small):
     """n >= 2048: one launch set per iteration for the whole batch (device step), or two sub-batches pipelined on the stream when the host
     steps (driver.cpp): per-pair results stay bit-identical to the single-pair call, wherever a pair lands and whenever its neighbours
     converge or fail."""
@@ -110,18 +110,19 @@ def test_large_batch_two_sub_batches_in_flight(ctx, pairs_small, monkeypatch):
     assert len({r.iters for r in single}) > 1  # sub-batches do not finish together
     order = [int(k) for k in rng.integers(0, len(base), 2100)]
     order[0], order[1049], order[1050], order[2099] = 3, 3, 3, 3
-    for host_step in ("0", "1"):  # one launch set per iteration with the step on the device; two sub-batches with the host stepping them
-        monkeypatch.setenv("MULLS_HOST_STEP", host_step)
+    for host_step in (0, 1):  # one launch set per iteration with the step on the device; two sub-batches with the host stepping them
+        ctx.set_option(abi.OPT_HOST_STEP, host_step)
         rb = ctx.icp_batch([base[k] for k in order], P)
+        ctx.set_option(abi.OPT_HOST_STEP, 0)
         for i, k in enumerate(order):
             r1 = single[k]
             assert (r1.code, r1.iters, list(r1.ncorr)) == (rb[i].code, rb[i].iters, list(rb[i].ncorr)), i
             assert r1.T[:] == rb[i].T[:] and r1.info[:] == rb[i].info[:] and r1.sigma == rb[i].sigma, i
 
 
-def test_device_step_equals_host_step(ctx, pairs_small, monkeypatch):
+def test_device_step_equals_host_step(ctx, pairs_small):
     """The lock-step loop steps on the device (k_finish_step: count test, 6x6 solve, convergence tests, residual — icp_step.h's functions) unless
-    traces are asked for, which the host half of the loop collects (or MULLS_HOST_STEP=1): every output bit-identical between the two, for
+    traces are asked for, which the host half of the loop collects (or MULLS_OPT_HOST_STEP): every output bit-identical between the two, for
     healthy pairs, failing ones (-1, -2, -3), loops of one to three iterations, and so are the profile's point counters."""
     rng = np.random.default_rng(11)
     tgt = planes_scene(rng)
@@ -138,7 +139,7 @@ def test_device_step_equals_host_step(ctx, pairs_small, monkeypatch):
     for P in sets:
         out, prof = {}, {}
         for host in (0, 1, 0):
-            monkeypatch.setenv("MULLS_HOST_STEP", str(host))
+            ctx.set_option(abi.OPT_HOST_STEP, host)
             r = b.run(P)
             got = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), tuple(x.ntgt0), x.cropped, tuple(x.crop_box), np.array(x.T[:]).tobytes(),
                     np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes(), np.float32(x.confidence).tobytes(), x.singular) for x in r]  # (NaN-safe: bytes)
@@ -150,8 +151,29 @@ def test_device_step_equals_host_step(ctx, pairs_small, monkeypatch):
         assert out[0] == out[1]
         assert prof[0] == prof[1]
         codes |= {x[0] for x in out[0]}
-    monkeypatch.delenv("MULLS_HOST_STEP")
+    ctx.set_option(abi.OPT_HOST_STEP, 0)
     assert codes >= {1, -1, -2, -3}
+    b.close()
+
+
+def test_few_launches_path_equals_separate_launches(ctx, pairs_small):
+    """Small lock-step batches run four launches per iteration (one accumulation launch for every trip length; k_finish_step = finish + step +
+    publication behind an arrival ticket) instead of seven: the same bits as the separate launches, healthy and failing pairs, run after run."""
+    rng = np.random.default_rng(5)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    empty = abi.PairData(tgt, [None] * 6)
+    plist = ([p for p, _ in pairs_small] + [far, empty]) * 7
+    b = ctx.batch(plist)
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
+        got = {}
+        for limit in (0, 512, 0, 512):
+            ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, limit)
+            r = b.run(P)
+            rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
+            assert got.setdefault(limit, rows) == rows
+        assert got[0] == got[512]
+    ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
     b.close()
 
 
@@ -210,7 +232,7 @@ def test_resident_loop_equals_lock_step(ctx_auto, pairs_small):
         assert any(x[0] == 1 for x in out[4])
 
 
-def test_duplicate_table_epoch_wrap(ctx, pairs_small, monkeypatch):
+def test_duplicate_table_epoch_wrap(ctx, pairs_small):
     """The duplicate table's 32-bit epoch counter: runs on either side of the wrap give the results of a fresh batch
     (stale winner entries of older epochs must not beat the keys of the restarted count)."""
     P = abi.kitti_params(dis_thre_unit=2.4)
@@ -218,11 +240,12 @@ def test_duplicate_table_epoch_wrap(ctx, pairs_small, monkeypatch):
     b0 = ctx.batch(plist)
     want = [(r.code, r.iters, tuple(r.ncorr), tuple(r.T)) for r in b0.run(P)]
     b0.close()
-    monkeypatch.setenv("MULLS_DEBUG_TICK", str(0xfffffff0 - 3 * 22 - 5))  # the fourth run of 22 epochs crosses the limit
+    ctx.set_option(abi.OPT_DEBUG_TICK, 0xfffffff0 - 3 * 22 - 5)  # the fourth run of 22 epochs crosses the limit
     b = ctx.batch(plist)
     for _ in range(6):
         assert [(r.code, r.iters, tuple(r.ncorr), tuple(r.T)) for r in b.run(P)] == want
     b.close()
+    ctx.set_option(abi.OPT_DEBUG_TICK, 0)
 
 
 def test_mixed_outcomes_in_one_batch(ctx):

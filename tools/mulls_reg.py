@@ -52,7 +52,21 @@ def flags(argv=None):
 
 
 def read_cloud(path):
-    return lib.read_kitti_bin(path) if path.endswith(".bin") else lib.read_pcd(path)
+    """DataIo::read_pc_cloud_block(block, normalize_intensity_or_not = true) (dataio.hpp:1732-1756, test/mulls_reg.cpp:130-131): the intensity
+    rescaled to 0 - 255 with the reference's float expressions"""
+    p = lib.read_kitti_bin(path) if path.endswith(".bin") else lib.read_pcd(path)
+    p = p.copy()
+    inten = p["intensity"].astype(np.float32)
+    if len(inten):
+        lo, hi = np.float32(inten.min()), np.float32(inten.max())
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p["intensity"] = (inten - lo) * np.float32(255.0 / float(hi - lo))
+    return p
+
+
+def scan_bound(p):
+    """block->local_bound = the bounding box of pc_raw (get_cloud_bbx_cpt, dataio.hpp:1736)"""
+    return [float(p[k].min()) for k in ("x", "y", "z")] + [float(p[k].max()) for k in ("x", "y", "z")]
 
 
 def extract_semantic_pts(ctx, scan, F, vf_downsample_resolution):
@@ -84,7 +98,8 @@ def register(ctx, scan1, scan2, F):
     n1, n2 = sum(len(x) for x in d1), sum(len(x) for x in d2)
     # determine_source_target_cloud (cregistration.hpp:857-870): block1 (target) = the one with more down-sampled feature points
     (tgt_full, src_down, source) = (f1, d2, 2) if n1 > n2 else (f2, d1, 1)
-    pair = abi.PairData([abi.points_of(t) for t in tgt_full], [abi.points_of(s) for s in src_down])
+    pair = abi.PairData([abi.points_of(t) for t in tgt_full], [abi.points_of(s) for s in src_down],
+                        tgt_bound=scan_bound(abi.as_points(scan1 if source == 2 else scan2)) if len(scan1) and len(scan2) else None)
     # mm_lls_icp(reg_con, max_iter, thre, converge_tran, converge_rot_d, 0.25 * thre, 1.1, "111110", "1101", 1.0, 0.1, 0.1, 0.1, init_mat)
     P = abi.default_params(max_iter_num=F.reg_max_iter_num, dis_thre_unit=F.corr_dis_thre, converge_translation=F.converge_tran,
                            converge_rotation_d=F.converge_rot_d, dis_thre_min=0.25 * F.corr_dis_thre, dis_thre_update_rate=1.1,
