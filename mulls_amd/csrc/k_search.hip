@@ -375,7 +375,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 }
 
 
-__global__ __launch_bounds__(MULLS_CERT_BLOCK) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
+// BLK lanes per class cloud: 512 when there are enough class clouds to give every CU several workgroups, 1024 for small batches (a class cloud of
+// 1200 points is then two trips instead of three, and the launch is as long as its longest workgroup)
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
 															const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(MULLS_CERT_BLOCK) void k_cert(const Job *__restrict
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	if (!cert_class<MULLS_CERT_BLOCK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
+	if (!cert_class<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }
@@ -595,8 +598,12 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	if (!njobs)
 		return 0;
 	const bool dedup = rp.lds_dedup != 0u;
-	hipLaunchKernelGGL(k_cert, dim3(njobs), dim3(MULLS_CERT_BLOCK), dedup ? (size_t)cap * 4u : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
-					   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
+	if (njobs <= 2u * n_cu)
+		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? (size_t)cap * 4u : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
+						   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
+	else
+		hipLaunchKernelGGL(k_cert<MULLS_CERT_BLOCK>, dim3(njobs), dim3(MULLS_CERT_BLOCK), dedup ? (size_t)cap * 4u : 0u, st, jobs, descs, states, rp, spos, snrm, grids,
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	// one workgroup per CU is all the LDS allows: they take the queued class clouds by ticket
 	hipLaunchKernelGGL(k_nn_lds, dim3(njobs < n_cu ? njobs : n_cu), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm,
 					   grids, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, wl, wl_ctr, parity & 1u);

@@ -156,23 +156,26 @@ def test_device_step_equals_host_step(ctx, pairs_small):
     b.close()
 
 
-def test_few_launches_path_equals_separate_launches(ctx, pairs_small):
-    """Small lock-step batches run four launches per iteration (one accumulation launch for every trip length; k_finish_step = finish + step +
-    publication behind an arrival ticket) instead of seven: the same bits as the separate launches, healthy and failing pairs, run after run."""
+def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
+    """The lock-step iteration exists in two launch forms, picked by batch size: four launches (one accumulation launch for every trip length;
+    k_finish_step = finish + step + publication behind an arrival ticket) for small batches, seven for large ones.  Same bits from both, healthy
+    and failing pairs, all six classes (every metric's term set), the residual pass, run after run."""
     rng = np.random.default_rng(5)
     tgt = planes_scene(rng)
     far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
     empty = abi.PairData(tgt, [None] * 6)
     plist = ([p for p, _ in pairs_small] + [far, empty]) * 7
     b = ctx.batch(plist)
-    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
+    forms = {"few": 384, "separate": 0}
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0),
+              abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
         got = {}
-        for limit in (0, 512, 0, 512):
-            ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, limit)
+        for name in ("few", "separate", "few", "separate"):
+            ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, forms[name])
             r = b.run(P)
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
-            assert got.setdefault(limit, rows) == rows
-        assert got[0] == got[512]
+            assert got.setdefault(name, rows) == rows
+        assert got["few"] == got["separate"]
     ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
     b.close()
 
