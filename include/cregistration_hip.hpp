@@ -53,6 +53,8 @@ inline mulls_ctx *thread_context(int device = 0)
 		const int rc = mulls_create(device, &holder.ctx);
 		if (rc != MULLS_OK)
 			throw std::runtime_error("mulls_create failed (" + std::to_string(rc) + "): no usable gfx950 device; there is no CPU fallback");
+		// constraint_t carries no per-class cloud sizes: stage only the clouds the registration reads (mulls_result.nsrc0 / ntgt0 of the others read 0)
+		(void)mulls_set_option(holder.ctx, MULLS_OPT_LEAN_STAGING, 1.0);
 	}
 	return holder.ctx;
 }

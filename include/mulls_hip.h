@@ -180,6 +180,9 @@ typedef struct mulls_profile
 	double icp_search_ms[24]; /* device-resident loop: the search phase by iteration (summed over the pairs) */
 	double icp_phase_ms[6]; /* device-resident loop: workgroup time summed over the pairs, by phase: search, counters + count test, normal
 							   equations, solve + step tests, residual pass, whole loop (one workgroup per CU: divide by the CUs for wall time) */
+	double ms_stage;		/* mulls_icp / mulls_icp_batch: wall time of staging the caller's clouds (host gather into pinned memory + upload), */
+	double ms_stage_pack;	/* ... of which the host gather, */
+	uint64_t stage_bytes;	/* ... and the bytes that crossed PCIe */
 } mulls_profile;
 
 typedef struct mulls_ctx mulls_ctx;		/* one per host thread / HIP stream */

@@ -341,6 +341,9 @@ class Profile(C.Structure):
         ("icp_fused_ms", C.c_double * 6),
         ("icp_search_ms", C.c_double * 24),
         ("icp_phase_ms", C.c_double * 6),
+        ("ms_stage", C.c_double),
+        ("ms_stage_pack", C.c_double),
+        ("stage_bytes", C.c_uint64),
     ]
 
 

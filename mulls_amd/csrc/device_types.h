@@ -38,7 +38,7 @@
 // nrm = (nx,ny,nz,curvature).  Offsets index the batch-wide arenas.
 struct CloudDesc
 {
-	uint32_t src_stage; // first record of this cloud in the staged AoS upload (48-B records)
+	uint32_t src_stage; // where this cloud starts in the staged upload, in float4 units; layout per cloud: stage_fmt
 	uint32_t tgt_stage;
 	uint32_t src_n0; // staged point count
 	uint32_t tgt_n0;
@@ -58,7 +58,12 @@ struct CloudDesc
 	uint32_t src_cap; // slots reserved for this source cloud in the working arenas = max(src_n0, sd_n0)
 	uint32_t big_slot; // target clouds beyond MULLS_BIG_CLOUD points are cropped by many workgroups: 1-based slot, 0 = small
 	uint32_t n_search; // LDS tier: queries of this class cloud that went through the grid search in the last iteration (the others were certified)
+	uint32_t stage_fmt; // staged layout of the source (bits 0-1), target (2-3) and src_down (4-5) clouds: MULLS_STAGE_*
 };
+// staged layouts of one cloud of n points (load_staged, device_util.h)
+#define MULLS_STAGE_AOS48 0u  // n x 3 float4: the caller's 48-byte PointXYZINormal records (device-resident map clouds, copied device to device)
+#define MULLS_STAGE_PACK32 1u // n float4 (x y z intensity), then n float4 (nx ny nz curvature): what the host gathers out of the caller's records
+#define MULLS_STAGE_PACK28 2u // n float4 (x y z intensity), then 3n floats (nx ny nz): no curvature (only motion undistortion reads it)
 
 // Uniform grid over one cropped target-class cloud (exact fixed-radius search tier).  cell id = (cz*ny + cy)*nx + cx,
 // x fastest, so the cells cx0..cx1 of one (cy,cz) row are one contiguous range of the cell-sorted target array.

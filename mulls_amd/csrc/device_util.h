@@ -55,6 +55,33 @@ __device__ __forceinline__ float ord2f(uint32_t k)
 	return __uint_as_float(u);
 }
 
+// point i of a staged cloud of n points starting at float4 `off` (CloudDesc::stage_fmt): pos = x y z intensity, nrm = nx ny nz curvature
+__device__ __forceinline__ void load_staged(const float4 *__restrict__ stage, uint32_t off, uint32_t fmt, uint32_t n, uint32_t i, float4 &pos, float4 &nrm)
+{
+	if (fmt == MULLS_STAGE_PACK32)
+	{
+		pos = stage[(size_t)off + i];
+		nrm = stage[(size_t)off + n + i];
+	}
+	else if (fmt == MULLS_STAGE_PACK28)
+	{
+		pos = stage[(size_t)off + i];
+		const float *f = reinterpret_cast<const float *>(stage + (size_t)off + n) + 3u * (size_t)i;
+		nrm = make_float4(f[0], f[1], f[2], 0.0f);
+	}
+	else
+	{
+		const float4 *rec = stage + (size_t)off + (size_t)i * 3;
+		const float4 a = rec[0], b = rec[1], c = rec[2]; // (x y z _) (nx ny nz _) (intensity curvature _ _)
+		pos = make_float4(a.x, a.y, a.z, c.x);
+		nrm = make_float4(b.x, b.y, b.z, c.y);
+	}
+}
+__device__ __forceinline__ float4 load_staged_pos(const float4 *__restrict__ stage, uint32_t off, uint32_t fmt, uint32_t i)
+{
+	return fmt == MULLS_STAGE_AOS48 ? stage[(size_t)off + (size_t)i * 3] : stage[(size_t)off + i]; // (.w: data[3] or the intensity — callers read x y z)
+}
+
 __device__ __forceinline__ bool class_called(const RunParams &rp, const CloudDesc &d, int cls)
 {
 	// `if (used[c] && src.size() > 0) determine_corres(...)` (cregistration.hpp:1272-1292) combined with the

@@ -90,6 +90,8 @@ struct mulls_batch
 	size_t cap_steps = 0;
 	uint32_t epoch2 = 0; // ... and the last epoch issued on its 8-byte word (words 32-33 of epoch_h)
 	int nsub = 1;		 // sub-batches the job tables are laid out for (build_jobs)
+	double fill_ms = 0.0, fill_pack_ms = 0.0; // the last batch_fill: wall time, host packing time ...
+	uint64_t fill_bytes = 0;				   // ... and bytes staged
 	uint32_t *wl = nullptr;		// LDS tier: class clouds k_cert queued for k_nn_lds (one slot per class-level job)
 	uint32_t *wl_ctr = nullptr; // ... and the queue counters: per sub-batch 8 words = (queued, taken) x launch parity
 	size_t cap_wl = 0;
@@ -473,9 +475,21 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	}
 }
 
-// lay the pairs out in the batch arenas, (re)allocate what is too small and stage the caller's clouds in HBM
-int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
+// float4 units a staged cloud of n points takes (device_types.h: MULLS_STAGE_*)
+inline size_t stage_quads(uint32_t n, uint32_t fmt) { return fmt == MULLS_STAGE_AOS48 ? (size_t)n * 3 : (fmt == MULLS_STAGE_PACK32 ? (size_t)n * 2 : (size_t)n + ((size_t)n * 3 + 3) / 4); }
+
+// lay the pairs out in the batch arenas, (re)allocate what is too small and stage the caller's clouds in HBM.  Host clouds are gathered out of the
+// caller's records into the packed layouts (32 of the 48 bytes are live; 28 when the run is known not to undistort: P given); class clouds of a
+// device-resident local map keep their 48-byte records and are copied device to device.  P + MULLS_OPT_LEAN_STAGING: the clouds the run never
+// reads are staged as empty.
+int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, const mulls_params *P = nullptr)
 {
+	const auto t_fill0 = std::chrono::steady_clock::now();
+	const uint32_t host_fmt = (P && !P->apply_motion_undistortion) ? MULLS_STAGE_PACK28 : MULLS_STAGE_PACK32;
+	const bool lean = P && ctx->opt[MULLS_OPT_LEAN_STAGING] != 0.0;
+	const bool crop_on = P && P->apply_intersection_filter != 0 && !P->apply_motion_undistortion;
+	// is class c's cloud read by the run?  (source ground / pillar / facade feed the intersection box whatever the used classes are, :2912-2915)
+	auto wanted = [&](int c, bool source) { return !lean || P->used_feature_type[c] == '1' || (source && crop_on && c <= 2); };
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	B->n = n;
 	B->descs_h.assign((size_t)n * MULLS_NC, CloudDesc());
@@ -485,37 +499,42 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	B->big_clouds_h.clear();
 	B->jobs_key.clear(); // the job table depends on the layout
 	B->dev_key.clear();
-	size_t stage_rec = 0, so = 0, to = 0;
+	size_t stage_rec = 0, so = 0, to = 0; // stage_rec: float4 units
+	static const mulls_cloud no_cloud = {nullptr, 0u, MULLS_POINT_BYTES};
+	auto fmt_of = [&](const mulls_cloud &c) { return (c.n && mulls_is_map_memory(ctx, c.pts, (size_t)c.n * MULLS_POINT_BYTES)) ? MULLS_STAGE_AOS48 : host_fmt; };
 	for (int p = 0; p < n; p++)
 	{
 		for (int c = 0; c < MULLS_NC; c++)
 		{
 			CloudDesc &d = B->descs_h[p * MULLS_NC + c];
 			std::memset(&d, 0, sizeof(d));
-			const mulls_cloud &s = pairs[p].src[c], &t = pairs[p].tgt[c];
+			const mulls_cloud &s = wanted(c, true) ? pairs[p].src[c] : no_cloud, &t = wanted(c, false) ? pairs[p].tgt[c] : no_cloud;
 			if ((s.n && (!s.pts || s.stride < MULLS_POINT_BYTES)) || (t.n && (!t.pts || t.stride < MULLS_POINT_BYTES)))
 			{
 				ctx->err = "cloud with points but null pointer or stride < 48";
 				return MULLS_E_INVALID;
 			}
+			const uint32_t sf = fmt_of(s), tf = fmt_of(t);
 			d.src_stage = (uint32_t)stage_rec;
 			d.src_n0 = s.n;
-			stage_rec += s.n;
+			stage_rec += stage_quads(s.n, sf);
 			d.tgt_stage = (uint32_t)stage_rec;
 			d.tgt_n0 = t.n;
-			stage_rec += t.n;
-			// block2->pc_*_down for the undistortion branch: staged separately only when it is a different cloud
-			const mulls_cloud &sd = pairs[p].src_down[c];
+			stage_rec += stage_quads(t.n, tf);
+			// block2->pc_*_down for the undistortion branch: staged separately only when it is a different cloud (and the run can undistort)
+			const mulls_cloud &sd = (wanted(c, true) && !(P && !P->apply_motion_undistortion)) ? pairs[p].src_down[c] : no_cloud;
 			const bool own_down = c != MULLS_VERTEX && sd.pts && sd.n && !(sd.pts == s.pts && sd.n == s.n && sd.stride == s.stride);
 			if (own_down && sd.stride < MULLS_POINT_BYTES)
 			{
 				ctx->err = "src_down cloud with stride < 48";
 				return MULLS_E_INVALID;
 			}
+			const uint32_t df = own_down ? fmt_of(sd) : sf;
+			d.stage_fmt = sf | (tf << 2) | (df << 4);
 			d.sd_stage = own_down ? (uint32_t)stage_rec : d.src_stage;
 			d.sd_n0 = own_down ? sd.n : s.n;
 			if (own_down)
-				stage_rec += sd.n;
+				stage_rec += stage_quads(sd.n, df);
 			d.src_cap = std::max(d.src_n0, d.sd_n0);
 			d.src_off = (uint32_t)so;
 			d.tgt_off = (uint32_t)to;
@@ -549,7 +568,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 			B->setup_h[p].inv_t[3] = 0.0;
 		}
 	}
-	if (stage_rec >= (1ull << 31))
+	if (stage_rec >= (1ull << 32) || so >= (1ull << 31) || to >= (1ull << 31))
 	{
 		ctx->err = "batch too large (>= 2^31 points)";
 		return MULLS_E_INVALID;
@@ -560,7 +579,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	int rc = MULLS_OK;
 	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
 	bool winner_grew = false;
-	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec * 3));
+	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec));
 	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so));
 	A(grow(ctx, &B->tmp_nrm, &B->cap_src[1], so));
 	A(grow(ctx, &B->spos, &B->cap_src[2], so));
@@ -596,7 +615,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	A(grow_pinned(ctx, &B->states_h, &B->cap_pin[0], (size_t)n, hipHostMallocMapped));
 	A(grow_pinned(ctx, &B->outs_h, &B->cap_pin[1], (size_t)n, hipHostMallocMapped));
 	A(grow_pinned(ctx, &B->bbox_h, &B->cap_pin[2], (size_t)n * 6, hipHostMallocDefault));
-	A(grow_pinned(ctx, &B->upload_h, &B->cap_pin[3], std::max<size_t>(stage_rec, 1) * MULLS_POINT_BYTES, hipHostMallocDefault));
+	A(grow_pinned(ctx, &B->upload_h, &B->cap_pin[3], std::max<size_t>(stage_rec, 1) * 16, hipHostMallocDefault));
 	if (rc == MULLS_OK && !B->epoch_h)
 	{
 		if (hipHostMalloc((void **)&B->epoch_h, 256, hipHostMallocMapped) != hipSuccess)
@@ -618,7 +637,8 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 		for (int k = 0; k < 6; k++)
 			B->bbox_h[p * 6 + k] = k < 3 ? 0xffffffffu : 0u;
 
-	// stage the caller's AoS records (48-B PointXYZINormal) contiguously in pinned memory, then one H2D copy
+	// gather the live fields of the caller's 48-byte records into pinned memory (packed layouts), blocks of pairs at a time: the host threads pack
+	// block k while the copy engine moves block k - 1
 	struct DevCopy
 	{
 		size_t dst;
@@ -630,7 +650,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 	{
 		uint8_t *dst;
 		const uint8_t *src;
-		uint32_t n, stride;
+		uint32_t n, stride, fmt;
 	};
 	std::vector<HostCopy> host_copies;
 	std::vector<size_t> first_copy_of_pair(n + 1, 0);
@@ -641,14 +661,14 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 		{
 			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
 			const mulls_cloud *cl[3] = {&pairs[p].src[c], &pairs[p].tgt[c], &pairs[p].src_down[c]};
-			const uint32_t off[3] = {d.src_stage, d.tgt_stage, d.sd_stage};
+			const uint32_t off[3] = {d.src_stage, d.tgt_stage, d.sd_stage}, cnt[3] = {d.src_n0, d.tgt_n0, d.sd_n0};
+			const uint32_t fmt[3] = {d.stage_fmt & 3u, (d.stage_fmt >> 2) & 3u, (d.stage_fmt >> 4) & 3u};
 			for (int k = 0; k < (d.sd_stage != d.src_stage ? 3 : 2); k++)
 			{
-				uint8_t *dst = B->upload_h + (size_t)off[k] * MULLS_POINT_BYTES;
-				const uint8_t *src = (const uint8_t *)cl[k]->pts;
-				if (!cl[k]->n)
+				if (!cnt[k]) // empty, or left out by the lean staging
 					continue;
-				if (mulls_is_map_memory(ctx, src, (size_t)cl[k]->n * MULLS_POINT_BYTES))
+				const uint8_t *src = (const uint8_t *)cl[k]->pts;
+				if (fmt[k] == MULLS_STAGE_AOS48)
 				{
 					// a class cloud of a device-resident local map (mulls_map_cloud): staged by a device-to-device copy below
 					if (cl[k]->stride != MULLS_POINT_BYTES)
@@ -656,40 +676,48 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 						ctx->err = "device-resident cloud with stride != 48";
 						return MULLS_E_INVALID;
 					}
-					dev_copies.push_back({(size_t)off[k] * MULLS_POINT_BYTES, src, (size_t)cl[k]->n * MULLS_POINT_BYTES});
+					dev_copies.push_back({(size_t)off[k] * 16, src, (size_t)cnt[k] * MULLS_POINT_BYTES});
 					continue;
 				}
-				host_copies.push_back({dst, src, cl[k]->n, cl[k]->stride});
+				host_copies.push_back({B->upload_h + (size_t)off[k] * 16, src, cnt[k], cl[k]->stride, fmt[k]});
 			}
 		}
 	}
 	first_copy_of_pair[n] = host_copies.size();
-	// blocks of pairs: the host threads pack block k into pinned memory while the copy engine moves block k - 1
 	hipStream_t st = ctx->stream;
 	hipError_t e = hipSuccess;
 	const int block = 64;
+	double pack_s = 0.0;
 	for (int p0 = 0; p0 < n && e == hipSuccess; p0 += block)
 	{
 		const int p1 = std::min(n, p0 + block);
 		const long c0 = (long)first_copy_of_pair[p0], c1 = (long)first_copy_of_pair[p1];
-		const int threads = (int)std::max<long>(1, std::min<long>(16, (c1 - c0) / 8));
+		const int threads = (int)std::max<long>(1, std::min<long>(32, (c1 - c0) / 6));
 		(void)threads;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 4) if (threads > 1)
+		const auto t_pack0 = std::chrono::steady_clock::now();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 2) if (threads > 1)
 		for (long i = c0; i < c1; i++)
 		{
 			const HostCopy &hc = host_copies[i];
-			if (hc.stride == MULLS_POINT_BYTES)
-				std::memcpy(hc.dst, hc.src, (size_t)hc.n * MULLS_POINT_BYTES);
-			else
-				for (uint32_t k = 0; k < hc.n; k++)
-					std::memcpy(hc.dst + (size_t)k * MULLS_POINT_BYTES, hc.src + (size_t)k * hc.stride, MULLS_POINT_BYTES);
+			float *pos = reinterpret_cast<float *>(hc.dst), *nrm = pos + (size_t)hc.n * 4;
+			const int nw = hc.fmt == MULLS_STAGE_PACK32 ? 4 : 3;
+			for (uint32_t k = 0; k < hc.n; k++)
+			{
+				float r[10]; // x y z _ nx ny nz _ intensity curvature
+				std::memcpy(r, hc.src + (size_t)k * hc.stride, sizeof(r));
+				float *pp = pos + (size_t)k * 4, *nn = nrm + (size_t)k * nw;
+				pp[0] = r[0], pp[1] = r[1], pp[2] = r[2], pp[3] = r[8];
+				nn[0] = r[4], nn[1] = r[5], nn[2] = r[6];
+				if (nw == 4)
+					nn[3] = r[9];
+			}
 		}
-		// staged records of pairs [p0, p1) are one contiguous range (offsets grow with the pair index)
+		pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
+		// the staged clouds of pairs [p0, p1) are one contiguous range (offsets grow with the pair index)
 		const size_t r0 = B->descs_h[(size_t)p0 * MULLS_NC].src_stage;
 		const size_t r1 = p1 < n ? B->descs_h[(size_t)p1 * MULLS_NC].src_stage : stage_rec;
 		if (r1 > r0)
-			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + r0 * MULLS_POINT_BYTES, B->upload_h + r0 * MULLS_POINT_BYTES,
-							   (r1 - r0) * MULLS_POINT_BYTES, hipMemcpyHostToDevice, st);
+			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + r0 * 16, B->upload_h + r0 * 16, (r1 - r0) * 16, hipMemcpyHostToDevice, st);
 	}
 	for (const DevCopy &dc : dev_copies)
 		if (e == hipSuccess)
@@ -711,6 +739,9 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n)
 		ctx->err = std::string("staging upload: ") + hipGetErrorString(e);
 		return MULLS_E_HIP;
 	}
+	B->fill_ms = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fill0).count() * 1e3;
+	B->fill_pack_ms = pack_s * 1e3;
+	B->fill_bytes = (uint64_t)stage_rec * 16;
 	return MULLS_OK;
 }
 
@@ -1786,10 +1817,12 @@ extern "C"
 			return MULLS_E_INVALID;
 		if (!ctx->scratch)
 			ctx->scratch = new mulls_batch();
-		rc = batch_fill(ctx, ctx->scratch, pairs, n);
+		rc = batch_fill(ctx, ctx->scratch, pairs, n, params);
 		if (rc != MULLS_OK)
 			return rc;
-		return mulls_batch_run(ctx, ctx->scratch, params, results);
+		rc = mulls_batch_run(ctx, ctx->scratch, params, results);
+		ctx->prof.ms_stage = ctx->scratch->fill_ms, ctx->prof.ms_stage_pack = ctx->scratch->fill_pack_ms, ctx->prof.stage_bytes = ctx->scratch->fill_bytes;
+		return rc;
 	}
 	catch (...)
 	{

@@ -22,14 +22,17 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 	float x = 0, y = 0, z = 0;
 	if (in)
 	{
-		const float4 *rec = stage + (size_t)((regen ? d.sd_stage : d.src_stage) + s) * 3;
-		float4 a = rec[0], b = rec[1], c = rec[2]; // (x y z _) (nx ny nz _) (intensity curvature _ _)
+		float4 a, b; // a = x y z intensity, b = nx ny nz curvature
+		if (regen)
+			load_staged(stage, d.sd_stage, (d.stage_fmt >> 4) & 3u, d.sd_n0, s, a, b);
+		else
+			load_staged(stage, d.src_stage, d.stage_fmt & 3u, d.src_n0, s, a, b);
 		if (regen)
 		{
 			// CFilter::apply_motion_compensation(in, out, inverse(initial_guess)) (cfilter.hpp:493-516): the point is moved
 			// by the fraction `curvature` (its time stamp in [0,1]) of the inverse guess — slerp from the identity
 			// quaternion, linear translation — in double, stored as float; normals are copied unrotated.
-			const float sc = c.y;
+			const float sc = b.w;
 			if (!(sc < 0.0f || (double)sc > 1.0 - 0.0f))
 			{
 				const double t = (double)sc, one = 1.0 - 2.220446049250313e-16;
@@ -72,8 +75,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 			ony = (float)(G[4] * nx + G[5] * ny + G[6] * nz);
 			onz = (float)(G[8] * nx + G[9] * ny + G[10] * nz);
 		}
-		tmp_pos[d.src_off + s] = make_float4(x, y, z, c.x);
-		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, c.y);
+		tmp_pos[d.src_off + s] = make_float4(x, y, z, a.w);
+		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, b.w);
 	}
 	if (job.cls == 0 || job.cls == 1 || job.cls == 2)
 	{
@@ -230,10 +233,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 		{
 			if (side)
 			{
-				const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
-				float4 a = rec[0], b = rec[1], c = rec[2];
-				p = make_float4(a.x, a.y, a.z, c.x);
-				q = make_float4(b.x, b.y, b.z, c.y);
+				load_staged(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, d.tgt_n0, i, p, q);
 			}
 			else
 			{
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 		const uint32_t i = sg.start + k + threadIdx.x;
 		if (i < d.tgt_n0)
 		{
-			const float4 p = stage[(size_t)(d.tgt_stage + i) * 3];
+			const float4 p = load_staged_pos(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, i);
 			if (!rp.crop || crop_keep(p, lo, hi))
 			{
 				mine++;
@@ -435,10 +435,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__r
 		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
 		if (i < d.tgt_n0)
 		{
-			const float4 *rec = stage + (size_t)(d.tgt_stage + i) * 3;
-			const float4 a = rec[0], b = rec[1], c = rec[2];
-			p = make_float4(a.x, a.y, a.z, c.x);
-			q = make_float4(b.x, b.y, b.z, c.y);
+			load_staged(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, d.tgt_n0, i, p, q);
 			keep = !rp.crop || crop_keep(p, lo, hi);
 		}
 		const unsigned long long bal = __ballot(keep);
