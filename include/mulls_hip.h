@@ -489,6 +489,22 @@ enum mulls_extract_cloud
 int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *params, void *const out[MULLS_EX_COUNT],
 						   const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT]);
 
+/* ---- device-resident feature block: the cloudblock_t of one scan kept in HBM ----
+ * The per-frame loop of test/mulls_slam.cpp (:359-442, :642-693) hands one cloudblock_t from extract_semantic_pts to mm_lls_icp to update_local_map.
+ * mulls_extract_features_resident is mulls_extract_features with the feature clouds left on the device: mulls_block_cloud() yields device clouds
+ * (48-byte records) that mulls_pair.src[] / tgt[] and mulls_map_update's frame_down[] accept the way they accept mulls_map_cloud() — raw scan in, pose
+ * out, nothing but the scan, a few selection indices and the 4x4 crossing PCIe (the *_down clouds the fixed-number samplers thin on the host — a few
+ * thousand points — make one round trip when fixed_num_downsampling is on).  A block holds the clouds of enum mulls_extract_cloud except MULLS_EX_RAW and
+ * MULLS_EX_DOWN; they are valid until the block is extracted into again or destroyed (mulls_destroy destroys the blocks still alive). */
+typedef struct mulls_block mulls_block;
+int mulls_block_create(mulls_ctx *ctx, mulls_block **out);
+void mulls_block_destroy(mulls_ctx *ctx, mulls_block *block);
+int mulls_extract_features_resident(mulls_ctx *ctx, const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *params, mulls_block *block,
+									uint32_t n_out[MULLS_EX_COUNT]);
+int mulls_block_cloud(mulls_ctx *ctx, const mulls_block *block, int which, mulls_cloud *out);
+/* copy cloud `which` back to the host (48-byte records); *n receives its size, at most cap records are written */
+int mulls_block_download(mulls_ctx *ctx, const mulls_block *block, int which, void *pts, uint32_t cap, uint32_t *n);
+
 /* CFilter::voxel_downsample (cfilter.hpp:83-160): one point per occupied voxel of edge voxel_size, voxels in increasing index
  * ((vx * ny + vy) * nz + vz from the cloud's minimum corner), the point of a voxel being the one std::sort leaves first among that voxel's
  * (voxel, index) pairs, exactly as upstream (bounding box and voxel indices on the device, that one sort on the host).  voxel_size < 0.001

@@ -200,9 +200,10 @@ extern "C"
 	}
 
 	// pts_on_device: `pts` is device memory of this context's device holding packed 48-byte records (mulls_extract_features)
+	// dev_out: leave the clouds on the device (ClassifyDev, ctx.h) instead of copying them to out[] (which may then hold nulls)
 	__attribute__((visibility("hidden"))) int mulls_classify_impl(mulls_ctx *ctx, const void *pts, bool pts_on_device, uint32_t n_in, uint32_t stride, const mulls_classify_params *P,
 							void *const out[MULLS_CL_COUNT], const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after,
-							uint32_t *n_cloud_in_after)
+							uint32_t *n_cloud_in_after, ClassifyDev *dev_out)
 	{
 		if (!ctx || !P || !out || !cap || !n_out || (n_in && !pts) || stride < MULLS_POINT_BYTES || (pts_on_device && stride != MULLS_POINT_BYTES))
 			return MULLS_E_INVALID;
@@ -469,8 +470,10 @@ extern "C"
 		for (int k = 0; k < MULLS_CL_COUNT; k++)
 		{
 			const bool thinned_later = P->fixed_num_downsampling && k >= MULLS_CL_PILLAR_DOWN && k <= MULLS_CL_ROOF_DOWN;
-			const uint32_t want = thinned_later ? cntk[k] : std::min(cntk[k], cap[k]);
+			const uint32_t want = thinned_later ? cntk[k] : (dev_out ? 0u : std::min(cntk[k], cap[k]));
 			n_out[k] = cntk[k];
+			if (dev_out)
+				dev_out->dev[k] = dev[k], dev_out->n[k] = cntk[k], dev_out->on_host[k] = false;
 			if (!want)
 				continue;
 			if (thinned_later)
@@ -483,6 +486,8 @@ extern "C"
 		}
 		if (cloud_in_after)
 			HIPCHK(ctx, hipMemcpyAsync(cloud_in_after, A.recs, (size_t)n * REC, hipMemcpyDeviceToHost, st));
+		if (dev_out)
+			dev_out->cloud_in_after = A.recs, dev_out->n_after = n;
 		HIPCHK(ctx, hipStreamSynchronize(st));
 		if (P->fixed_num_downsampling) // :2247-2257
 		{
@@ -494,6 +499,12 @@ extern "C"
 			for (int k = MULLS_CL_PILLAR_DOWN; k <= MULLS_CL_ROOF_DOWN; k++)
 			{
 				n_out[k] = (uint32_t)(host[k].size() / REC);
+				if (dev_out)
+				{
+					dev_out->n[k] = n_out[k], dev_out->on_host[k] = true;
+					dev_out->host[k].swap(host[k]);
+					continue;
+				}
 				const size_t m = std::min<size_t>(n_out[k], cap[k]);
 				if (m)
 					std::memcpy(out[k], host[k].data(), m * REC);
@@ -506,7 +517,7 @@ extern "C"
 							   const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after, uint32_t *n_cloud_in_after)
 	try
 	{
-		return mulls_classify_impl(ctx, pts, false, n_in, stride, P, out, cap, n_out, cloud_in_after, n_cloud_in_after);
+		return mulls_classify_impl(ctx, pts, false, n_in, stride, P, out, cap, n_out, cloud_in_after, n_cloud_in_after, nullptr);
 	}
 	catch (...)
 	{

@@ -14,6 +14,7 @@
 
 struct mulls_batch;
 struct mulls_map;
+struct mulls_block;
 
 struct mulls_ctx
 {
@@ -28,6 +29,7 @@ struct mulls_ctx
 	hipEvent_t ev[20] = {}; // two sets of ten: one per sub-batch in flight
 	mulls_batch *scratch = nullptr; // cached batch reused by mulls_icp / mulls_icp_batch (no allocator traffic per call)
 	std::vector<mulls_map *> maps; // live local maps: their buffers are the device clouds mulls_pair may point to
+	std::vector<mulls_block *> blocks; // live feature blocks (mulls_extract_features_resident): device clouds too
 	void *gf_buf = nullptr; // mulls_ground_filter's device arena (grow-only)
 	void *gf_rnd = nullptr; // ... and PCL's RANSAC sample sequence (normal method 3), made on first use
 	void *cl_buf = nullptr; // mulls_classify_nground's device arena (grow-only)
@@ -171,5 +173,26 @@ int grow_pinned(mulls_ctx *ctx, T **p, size_t *cap, size_t need, unsigned flags)
 
 } // namespace
 
-// is [p, p + bytes) inside a live local map's device buffers? (mulls_cloud.pts of a map-resident target, map.cpp)
+// is [p, p + bytes) inside a live local map's or feature block's device buffers? (mulls_cloud.pts of a device-resident cloud; map.cpp)
 bool mulls_is_map_memory(const mulls_ctx *ctx, const void *p, size_t bytes);
+
+// device-resident feature clouds of one scan (mulls_extract_features_resident, ground.cpp): 48-byte records, one buffer
+struct mulls_block
+{
+	unsigned char *buf = nullptr;
+	size_t cap = 0;					 // bytes
+	size_t off[MULLS_EX_COUNT] = {}; // where cloud k starts
+	uint32_t n[MULLS_EX_COUNT] = {}; // its size (RAW and DOWN are not kept: 0)
+};
+
+// classify_nground_pts' clouds where the kernels left them (mulls_classify_impl with a ClassifyDev instead of host buffers): valid until the
+// context's next classification; the *_down clouds the fixed-number samplers thin on the host come back as host records
+struct ClassifyDev
+{
+	const void *dev[MULLS_CL_COUNT] = {};
+	uint32_t n[MULLS_CL_COUNT] = {};
+	std::vector<unsigned char> host[MULLS_CL_COUNT]; // non-empty: this cloud's records are here instead
+	bool on_host[MULLS_CL_COUNT] = {};
+	const void *cloud_in_after = nullptr; // cloud_in as upstream leaves it (device)
+	uint32_t n_after = 0;
+};

@@ -1047,6 +1047,8 @@ extern "C"
 			mulls_batch_destroy(ctx, ctx->scratch);
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
 			mulls_map_destroy(ctx, ctx->maps.back());
+		while (!ctx->blocks.empty()) // ... and so do feature blocks
+			mulls_block_destroy(ctx, ctx->blocks.back());
 		for (auto &e : ctx->ev)
 			if (e)
 				(void)hipEventDestroy(e);

@@ -21,7 +21,7 @@
 
 extern "C" __attribute__((visibility("hidden"))) int mulls_classify_impl(mulls_ctx *ctx, const void *pts, bool pts_on_device, uint32_t n_in, uint32_t stride, const mulls_classify_params *P,
 								   void *const out[MULLS_CL_COUNT], const uint32_t cap[MULLS_CL_COUNT], uint32_t n_out[MULLS_CL_COUNT], void *cloud_in_after,
-								   uint32_t *n_cloud_in_after);
+								   uint32_t *n_cloud_in_after, ClassifyDev *dev_out);
 
 extern "C"
 {
@@ -258,21 +258,15 @@ extern "C"
 		*n_down = (uint32_t)first.size();
 		return MULLS_OK;
 	}
-	// cloud_ground (n_ground records at g) -> cloud_ground_down (cfilter.hpp:1955-1968), taken on the host from the downloaded cloud
-	static uint32_t gf_ground_down(const mulls_ground_params *P, const unsigned char *g, uint32_t n_ground, void *ground_down, uint32_t cap_ground_down)
+	// which points of cloud_ground make cloud_ground_down (cfilter.hpp:1955-1968): every ground_random_down_down_rate-th, or the seeded fixed-number selection
+	static void gf_ground_down_indices(const mulls_ground_params *P, uint32_t n_ground, std::vector<uint32_t> &idx)
 	{
-		uint32_t nd = 0;
-		unsigned char *gd = static_cast<unsigned char *>(ground_down);
-		auto take = [&](uint32_t i) {
-			if (nd < cap_ground_down)
-				std::memcpy(gd + (size_t)nd * MULLS_POINT_BYTES, g + (size_t)i * MULLS_POINT_BYTES, MULLS_POINT_BYTES);
-			nd++;
-		};
+		idx.clear();
 		if (!P->fixed_num_downsampling)
 		{
 			for (uint32_t i = 0; i < n_ground; i++)
 				if ((int)i % P->ground_random_down_down_rate == 0)
-					take(i);
+					idx.push_back(i);
 		}
 		else
 		{
@@ -280,9 +274,18 @@ extern "C"
 			thin_mask(mask.data(), n_ground, P->down_ground_fixed_num, P->rng_seed, 12);
 			for (uint32_t i = 0; i < n_ground; i++)
 				if (mask[i])
-					take(i);
+					idx.push_back(i);
 		}
-		return nd;
+	}
+	// ... taken on the host from the downloaded cloud (n_ground records at g)
+	static uint32_t gf_ground_down(const mulls_ground_params *P, const unsigned char *g, uint32_t n_ground, void *ground_down, uint32_t cap_ground_down)
+	{
+		std::vector<uint32_t> idx;
+		gf_ground_down_indices(P, n_ground, idx);
+		unsigned char *gd = static_cast<unsigned char *>(ground_down);
+		for (size_t k = 0; k < idx.size() && k < cap_ground_down; k++)
+			std::memcpy(gd + k * MULLS_POINT_BYTES, g + (size_t)idx[k] * MULLS_POINT_BYTES, MULLS_POINT_BYTES);
+		return (uint32_t)idx.size();
 	}
 
 	int mulls_ground_filter(mulls_ctx *ctx, const void *pts, uint32_t n, uint32_t stride, const mulls_ground_params *P, void *ground, uint32_t cap_ground,
@@ -402,12 +405,15 @@ extern "C"
 		return mulls::abi_caught(ctx); // nothing is thrown across the ABI
 	}
 
-	int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n_in, uint32_t stride, const mulls_extract_params *X, void *const out[MULLS_EX_COUNT],
-							   const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT])
-	try
+	// blk: keep the feature clouds on the device (mulls_extract_features_resident) instead of copying them to out[]
+	static int extract_impl(mulls_ctx *ctx, const void *scan, uint32_t n_in, uint32_t stride, const mulls_extract_params *X, void *const out[MULLS_EX_COUNT],
+							const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT], mulls_block *blk)
 	{
 		if (!ctx || !X || !out || !cap || !n_out || (n_in && !scan) || stride < MULLS_POINT_BYTES)
 			return MULLS_E_INVALID;
+		if (blk)
+			for (int k = 0; k < MULLS_EX_COUNT; k++)
+				blk->n[k] = 0;
 		for (int k = 0; k < MULLS_EX_COUNT; k++)
 		{
 			n_out[k] = 0;
@@ -487,12 +493,63 @@ extern "C"
 		const int rc = gf_run(ctx, a, reinterpret_cast<const float4 *>(cur), n, P, go);
 		if (rc != MULLS_OK)
 			return rc;
+		if (blk)
+		{
+			// ---- device-resident block: nothing but selection indices, the clouds the host-side samplers thin and the sizes cross PCIe -------------
+			ClassifyDev cd;
+			void *no_out[MULLS_CL_COUNT] = {};
+			uint32_t no_cap[MULLS_CL_COUNT] = {};
+			const int rc2 = mulls_classify_impl(ctx, base + a.o_unground, true, go.n_unground, MULLS_POINT_BYTES, &X->classify, no_out, no_cap, n_out + MULLS_EX_PILLAR, nullptr,
+												&n_out[MULLS_EX_UNGROUND], &cd);
+			if (rc2 != MULLS_OK)
+				return rc2;
+			std::vector<uint32_t> gd_idx;
+			gf_ground_down_indices(P, go.n_ground, gd_idx);
+			n_out[MULLS_EX_GROUND] = go.n_ground;
+			n_out[MULLS_EX_GROUND_DOWN] = (uint32_t)gd_idx.size();
+			uint32_t cnt[MULLS_EX_COUNT] = {};
+			cnt[MULLS_EX_GROUND] = go.n_ground, cnt[MULLS_EX_GROUND_DOWN] = (uint32_t)gd_idx.size(), cnt[MULLS_EX_UNGROUND] = cd.n_after;
+			for (int k = 0; k < MULLS_CL_COUNT; k++)
+				cnt[MULLS_EX_PILLAR + k] = cd.n[k];
+			size_t need = 0, off[MULLS_EX_COUNT];
+			for (int k = 0; k < MULLS_EX_COUNT; k++)
+			{
+				off[k] = need;
+				need += ((size_t)cnt[k] * MULLS_POINT_BYTES + 255) & ~(size_t)255;
+			}
+			need += (size_t)gd_idx.size() * 4 + 256; // the selection indices ride at the end
+			if (blk->cap < need)
+			{
+				if (blk->buf)
+					(void)hipFree(blk->buf);
+				blk->buf = nullptr, blk->cap = 0;
+				HIPCHK(ctx, hipMalloc((void **)&blk->buf, need + need / 4));
+				blk->cap = need + need / 4;
+			}
+			auto put = [&](int k, const void *src, hipMemcpyKind kind) -> hipError_t {
+				return cnt[k] ? hipMemcpyAsync(blk->buf + off[k], src, (size_t)cnt[k] * MULLS_POINT_BYTES, kind, st) : hipSuccess;
+			};
+			HIPCHK(ctx, put(MULLS_EX_GROUND, base + a.o_ground, hipMemcpyDeviceToDevice));
+			if (!gd_idx.empty())
+			{
+				uint32_t *d_idx = reinterpret_cast<uint32_t *>(blk->buf + need - (gd_idx.size() * 4 + 128));
+				HIPCHK(ctx, hipMemcpyAsync(d_idx, gd_idx.data(), gd_idx.size() * 4, hipMemcpyHostToDevice, st));
+				launch_cl_gather(st, reinterpret_cast<const float4 *>(base + a.o_ground), d_idx, reinterpret_cast<float4 *>(blk->buf + off[MULLS_EX_GROUND_DOWN]), (uint32_t)gd_idx.size());
+			}
+			HIPCHK(ctx, put(MULLS_EX_UNGROUND, cd.cloud_in_after, hipMemcpyDeviceToDevice));
+			for (int k = 0; k < MULLS_CL_COUNT; k++)
+				HIPCHK(ctx, cd.on_host[k] ? put(MULLS_EX_PILLAR + k, cd.host[k].data(), hipMemcpyHostToDevice) : put(MULLS_EX_PILLAR + k, cd.dev[k], hipMemcpyDeviceToDevice));
+			HIPCHK(ctx, hipStreamSynchronize(st)); // gd_idx, cd.host are host vectors; the arenas the copies read are reused by the next call
+			for (int k = 0; k < MULLS_EX_COUNT; k++)
+				blk->off[k] = off[k], blk->n[k] = cnt[k];
+			return MULLS_OK;
+		}
 		std::vector<unsigned char> g((size_t)go.n_ground * MULLS_POINT_BYTES);
 		if (go.n_ground)
 			HIPCHK(ctx, hipMemcpyAsync(g.data(), base + a.o_ground, g.size(), hipMemcpyDeviceToHost, st));
 		// classify_nground_pts on the non-ground cloud where the filter left it
 		const int rc2 = mulls_classify_impl(ctx, base + a.o_unground, true, go.n_unground, MULLS_POINT_BYTES, &X->classify, out + MULLS_EX_PILLAR, cap + MULLS_EX_PILLAR,
-											n_out + MULLS_EX_PILLAR, cap[MULLS_EX_UNGROUND] >= go.n_unground ? out[MULLS_EX_UNGROUND] : nullptr, &n_out[MULLS_EX_UNGROUND]);
+											n_out + MULLS_EX_PILLAR, cap[MULLS_EX_UNGROUND] >= go.n_unground ? out[MULLS_EX_UNGROUND] : nullptr, &n_out[MULLS_EX_UNGROUND], nullptr);
 		if (rc2 != MULLS_OK)
 			return rc2;
 		HIPCHK(ctx, hipStreamSynchronize(st));
@@ -501,6 +558,82 @@ extern "C"
 			std::memcpy(out[MULLS_EX_GROUND], g.data(), (size_t)kg * MULLS_POINT_BYTES);
 		n_out[MULLS_EX_GROUND] = go.n_ground;
 		n_out[MULLS_EX_GROUND_DOWN] = gf_ground_down(P, g.data(), go.n_ground, out[MULLS_EX_GROUND_DOWN], cap[MULLS_EX_GROUND_DOWN]);
+		return MULLS_OK;
+	}
+
+	int mulls_extract_features(mulls_ctx *ctx, const void *scan, uint32_t n_in, uint32_t stride, const mulls_extract_params *X, void *const out[MULLS_EX_COUNT],
+							   const uint32_t cap[MULLS_EX_COUNT], uint32_t n_out[MULLS_EX_COUNT])
+	try
+	{
+		return extract_impl(ctx, scan, n_in, stride, X, out, cap, n_out, nullptr);
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(ctx); // nothing is thrown across the ABI
+	}
+
+	// ---- device-resident feature blocks ------------------------------------------------------------------------------------------------
+	int mulls_block_create(mulls_ctx *ctx, mulls_block **out)
+	try
+	{
+		if (!ctx || !out)
+			return MULLS_E_INVALID;
+		*out = new mulls_block();
+		ctx->blocks.push_back(*out);
+		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(ctx);
+	}
+	void mulls_block_destroy(mulls_ctx *ctx, mulls_block *b)
+	{
+		if (!b)
+			return;
+		if (ctx)
+		{
+			(void)hipSetDevice(ctx->device);
+			ctx->blocks.erase(std::remove(ctx->blocks.begin(), ctx->blocks.end(), b), ctx->blocks.end());
+		}
+		if (b->buf)
+			(void)hipFree(b->buf);
+		delete b;
+	}
+	int mulls_extract_features_resident(mulls_ctx *ctx, const void *scan, uint32_t n, uint32_t stride, const mulls_extract_params *params, mulls_block *block,
+										uint32_t n_out[MULLS_EX_COUNT])
+	try
+	{
+		if (!block)
+			return MULLS_E_INVALID;
+		void *no_out[MULLS_EX_COUNT] = {};
+		uint32_t no_cap[MULLS_EX_COUNT] = {};
+		return extract_impl(ctx, scan, n, stride, params, no_out, no_cap, n_out, block);
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(ctx);
+	}
+	int mulls_block_cloud(mulls_ctx *ctx, const mulls_block *b, int which, mulls_cloud *out)
+	{
+		if (!ctx || !b || !out || which < 0 || which >= MULLS_EX_COUNT || which == MULLS_EX_RAW || which == MULLS_EX_DOWN)
+			return MULLS_E_INVALID;
+		out->pts = b->n[which] ? b->buf + b->off[which] : nullptr;
+		out->n = b->n[which];
+		out->stride = MULLS_POINT_BYTES;
+		return MULLS_OK;
+	}
+	int mulls_block_download(mulls_ctx *ctx, const mulls_block *b, int which, void *pts, uint32_t cap, uint32_t *n)
+	try
+	{
+		if (!ctx || !b || !n || which < 0 || which >= MULLS_EX_COUNT || (cap && !pts))
+			return MULLS_E_INVALID;
+		*n = b->n[which];
+		const uint32_t k = std::min(cap, b->n[which]);
+		if (k)
+		{
+			HIPCHK(ctx, hipSetDevice(ctx->device));
+			HIPCHK(ctx, hipMemcpy(pts, b->buf + b->off[which], (size_t)k * MULLS_POINT_BYTES, hipMemcpyDeviceToHost));
+		}
 		return MULLS_OK;
 	}
 	catch (...)

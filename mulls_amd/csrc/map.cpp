@@ -46,6 +46,9 @@ bool mulls_is_map_memory(const mulls_ctx *ctx, const void *p, size_t bytes)
 			if (lo && q >= lo && q + bytes <= lo + m->cap[c] * 3 * sizeof(float4))
 				return true;
 		}
+	for (const mulls_block *b : ctx->blocks)
+		if (b->buf && q >= (const char *)b->buf && q + bytes <= (const char *)b->buf + b->cap)
+			return true;
 	return false;
 }
 

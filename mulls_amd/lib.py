@@ -80,6 +80,12 @@ def load():
     lib.mulls_extract_default_params.argtypes = [C.POINTER(abi.ExtractParams)]
     lib.mulls_extract_default_params.restype = None
     lib.mulls_extract_features.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ExtractParams), C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mulls_block_create.argtypes = [vp, C.POINTER(vp)]
+    lib.mulls_block_destroy.argtypes = [vp, vp]
+    lib.mulls_block_destroy.restype = None
+    lib.mulls_extract_features_resident.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ExtractParams), vp, C.POINTER(C.c_uint32)]
+    lib.mulls_block_cloud.argtypes = [vp, vp, C.c_int, C.POINTER(abi.Cloud)]
+    lib.mulls_block_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_voxel_downsample.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_float, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -192,14 +198,24 @@ class Context:
         self._check(self.lib.mulls_icp(self.h, C.byref(p), C.byref(params), res), "mulls_icp")
         return res
 
-    def icp_batch(self, pairs, params, trace_cap=0):
-        arr = abi.make_pair_array(pairs)
-        res = abi.make_result_array(len(pairs), trace_cap)
-        self._check(self.lib.mulls_icp_batch(self.h, arr, len(pairs), C.byref(params), res), "mulls_icp_batch")
+    def icp_batch(self, pairs, params, trace_cap=0, marshalled=None):
+        """mulls_icp_batch.  marshalled: (the mulls_pair array of `pairs`, a result array) made earlier — callers timing the library leave the
+        Python-side marshalling out that way; last_call_s = seconds spent inside the C call."""
+        arr, res = marshalled if marshalled is not None else (abi.make_pair_array(pairs), abi.make_result_array(len(pairs), trace_cap))
+        import time
+
+        t0 = time.perf_counter()
+        rc = self.lib.mulls_icp_batch(self.h, arr, len(pairs), C.byref(params), res)
+        self.last_call_s = time.perf_counter() - t0
+        self._check(rc, "mulls_icp_batch")
         return res
 
     def batch(self, pairs):
         return Batch(self, pairs)
+
+    def block(self):
+        """an empty device-resident feature block (Block.extract fills it)"""
+        return Block(self)
 
     def local_map(self, clouds=None, pose=None):
         """Device-resident local map (mulls_map_*), optionally initialised from six host class clouds and a pose_lo."""
@@ -348,6 +364,55 @@ class Batch:
             pass
 
 
+class Block:
+    """mulls_block: the feature clouds of one scan, device-resident (mulls_extract_features_resident)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.n = [0] * abi.EX_COUNT
+        ctx._check(ctx.lib.mulls_block_create(ctx.h, C.byref(self.h)), "mulls_block_create")
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.mulls_block_destroy(self.ctx.h, self.h)
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def extract(self, scan, params):
+        raw_in = abi.records(scan)
+        nout = (C.c_uint32 * abi.EX_COUNT)()
+        self.ctx._check(self.ctx.lib.mulls_extract_features_resident(self.ctx.h, raw_in.ctypes.data_as(C.c_void_p), len(raw_in), abi.POINT_BYTES, C.byref(params), self.h, nout),
+                        "mulls_extract_features_resident")
+        self.n = list(nout)
+        return self
+
+    def cloud(self, which):
+        """device-resident mulls_cloud of cloud `which` (enum mulls_extract_cloud: abi.EX_*)"""
+        c = abi.Cloud()
+        self.ctx._check(self.ctx.lib.mulls_block_cloud(self.ctx.h, self.h, which, C.byref(c)), "mulls_block_cloud")
+        return c
+
+    def download(self, which):
+        n = C.c_uint32(0)
+        self.ctx._check(self.ctx.lib.mulls_block_download(self.ctx.h, self.h, which, None, 0, C.byref(n)), "mulls_block_download")
+        out = np.zeros((n.value, abi.POINT_BYTES), np.uint8)
+        if n.value:
+            self.ctx._check(self.ctx.lib.mulls_block_download(self.ctx.h, self.h, which, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "mulls_block_download")
+        return out
+
+    def class_clouds(self, down):
+        """the six class clouds in the ABI's order (ground, pillar, facade, beam, roof, vertex) as device clouds: the *_down ones (+ pc_vertex) or the full ones"""
+        P = abi.EX_PILLAR
+        which = [abi.EX_GROUND_DOWN, P + 4, P + 6, P + 5, P + 7, abi.EX_VERTEX] if down else [abi.EX_GROUND, P, P + 2, P + 1, P + 3, abi.EX_VERTEX]
+        return [self.cloud(k) for k in which]
+
+
 class LocalMap:
     """mulls_map: the six undown class clouds of the reference's local_map cloudblock, kept in HBM between frames."""
 
@@ -371,10 +436,11 @@ class LocalMap:
 
     @staticmethod
     def _clouds(clouds):
-        keep = [abi.as_points(c) for c in clouds]
+        """six clouds, each a point array or an abi.Cloud (a device cloud of a Block / LocalMap)"""
+        keep = [c if isinstance(c, abi.Cloud) else abi.as_points(c) for c in clouds]
         arr = (abi.Cloud * abi.NCLASS)()
         for c in range(abi.NCLASS):
-            arr[c] = abi.as_cloud(keep[c])
+            arr[c] = keep[c] if isinstance(keep[c], abi.Cloud) else abi.as_cloud(keep[c])
         return arr, keep
 
     def set(self, clouds, pose):
@@ -416,11 +482,11 @@ class LocalMap:
 
     def icp(self, src, params, init_guess=None, tgt_bound=None, trace_cap=0):
         """mm_lls_icp with this map as block1 (target clouds stay on the device) and `src` as block2's six source clouds."""
-        keep = [abi.as_points(s) for s in src]
+        keep = [s if isinstance(s, abi.Cloud) else abi.as_points(s) for s in src]
         pair = abi.Pair()
         for c in range(abi.NCLASS):
             pair.tgt[c] = self.cloud(c)
-            pair.src[c] = abi.as_cloud(keep[c])
+            pair.src[c] = keep[c] if isinstance(keep[c], abi.Cloud) else abi.as_cloud(keep[c])
             pair.src_down[c] = abi.as_cloud(None)
         for k in range(6):
             pair.tgt_bound[k] = float(tgt_bound[k])

@@ -501,8 +501,48 @@ def test_odometry_front_end_from_raw_scans():
     spec = importlib.util.spec_from_file_location("gpu_odometry_tool", os.path.join(os.path.dirname(GOLD), "..", "tools", "gpu_odometry.py"))
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
-    et, er = tool.main(["6", "--check", "2"])
+    et, er = tool.main(["6", "--check", "2"])  # the frame's feature clouds stay in a device-resident block
     assert et < 0.05 and er < 0.005
+    tool.frames_pose[:] = [np.eye(4)]
+    eth, erh = tool.main(["6", "--check", "2", "--host"])  # ... or travel through the host: the same poses
+    assert (eth, erh) == (et, er)
+
+
+@pytest.mark.gpu
+def test_resident_feature_block_equals_host_clouds(ctx_auto):
+    """mulls_extract_features_resident: every cloud of the block, downloaded, equals what mulls_extract_features hands to the host — with and
+    without the fixed-number samplers (whose *_down clouds make the one round trip), ground normal methods 0 and 3 — and registering the block's
+    device clouds (source and target) gives the bits of registering the host copies."""
+    scan_a, scan_b = raw_scan(21), raw_scan(22)
+    for X in (abi.extract_params(ground=abi.ground_params(estimate_ground_normal_method=3, distance_weight_downsampling_method=2), classify=abi.classify_params(neighbor_k=30)),
+              abi.extract_params(ground=abi.ground_params(fixed_num_downsampling=1, down_ground_fixed_num=800, rng_seed=3),
+                                 classify=abi.classify_params(neighbor_k=25, fixed_num_downsampling=1, pillar_down_fixed_num=300, facade_down_fixed_num=900, rng_seed=3),
+                                 apply_dist_filter=1, min_dist_used=1.5, max_dist_used=100.0)):
+        blocks, hosts = [], []
+        for scan in (scan_a, scan_b):
+            ex = ctx_auto.extract_features(scan, X)
+            b = ctx_auto.block().extract(scan, X)
+            for k in range(abi.EX_COUNT):
+                if k in (abi.EX_RAW, abi.EX_DOWN):
+                    continue
+                assert b.n[k] == len(ex[k]) and np.array_equal(b.download(k), ex[k]), k
+            blocks.append(b)
+            hosts.append(ex)
+        P = abi.kitti_params(dis_thre_unit=2.4, used_feature_type="111110")
+        fa = [hosts[0][k] for k in (abi.EX_GROUND, abi.EX_PILLAR, abi.EX_PILLAR + 2, abi.EX_PILLAR + 1, abi.EX_PILLAR + 3, abi.EX_VERTEX)]
+        db = [hosts[1][k] for k in (abi.EX_GROUND_DOWN, abi.EX_PILLAR + 4, abi.EX_PILLAR + 6, abi.EX_PILLAR + 5, abi.EX_PILLAR + 7, abi.EX_VERTEX)]
+        host_pair = abi.PairData([abi.points_of(t) for t in fa], [abi.points_of(s) for s in db])
+        r_host = ctx_auto.icp(host_pair, P)[0]
+        pair = host_pair.as_pair()
+        for c, (t, s_) in enumerate(zip(blocks[0].class_clouds(down=False), blocks[1].class_clouds(down=True))):
+            pair.tgt[c], pair.src[c] = t, s_
+        import ctypes as C
+
+        res = abi.make_result_array(1)
+        ctx_auto._check(ctx_auto.lib.mulls_icp(ctx_auto.h, C.byref(pair), C.byref(P), res), "mulls_icp")
+        assert res[0].code == r_host.code == 1 and list(res[0].T[:]) == list(r_host.T[:]) and list(res[0].ncorr) == list(r_host.ncorr)
+        for b in blocks:
+            b.close()
 
 
 @pytest.mark.gpu

@@ -1,7 +1,9 @@
 """LiDAR odometry front end on the device, frame by frame as test/mulls_slam.cpp runs it: raw scan -> extract_semantic_pts
 (mulls_extract_features) -> scan-to-map mm_lls_icp against the device-resident local map -> update_local_map (map-based dynamic removal, PCA
 refresh of the linear features every 5th frame).  Synthetic drive through one scene; prints the time per frame by stage and the drift against
-the ground truth.  usage: gpu_odometry.py [frames] [--check N: run the first N frames through the oracle too and compare]"""
+the ground truth.  usage: gpu_odometry.py [frames] [--check N: run the first N frames through the oracle too and compare] [--host: the frame's
+feature clouds come back to the host and are uploaded again by the registration and the map update (the round-2 form); default: they stay in a
+device-resident feature block (mulls_extract_features_resident), only the scan, selection indices and the pose cross PCIe]"""
 import sys, time, warnings
 sys.path.insert(0, "."); warnings.filterwarnings("ignore")
 import numpy as np
@@ -34,6 +36,7 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     n_frames = int(argv[0]) if argv and not argv[0].startswith("-") else 12
     n_check = int(argv[argv.index("--check") + 1]) if "--check" in argv else 0
+    resident = "--host" not in argv
     del frames_pose[1:]
     frames = raw_drive(11, n_frames)
     X = abi.extract_params(ground=abi.ground_params(fixed_num_downsampling=1, down_ground_fixed_num=800, rng_seed=1),
@@ -51,11 +54,16 @@ def main(argv=None):
     bound = list(abi.PairData(down, down).tgt_bound)
     pose, prev_rel = np.eye(4), np.eye(4)
     worst = (0.0, 0.0)
+    blk = ctx.block() if resident else None
     for k in range(1, n_frames):
         scan, gt = frames[k]
         t0 = time.time()
-        ex = ctx.extract_features(scan, X)
-        full, down = block_of(ex)
+        if resident:
+            blk.extract(scan, X)
+            down = blk.class_clouds(down=True)  # device clouds: the registration's source and the map update's frame
+        else:
+            ex = ctx.extract_features(scan, X)
+            full, down = block_of(ex)
         t1 = time.time()
         rg = dev.icp(down, P, init_guess=prev_rel, tgt_bound=bound)[0]  # constant-velocity guess
         t2 = time.time()
@@ -71,7 +79,11 @@ def main(argv=None):
         worst = (max(worst[0], et), max(worst[1], er))
         if k <= n_check:
             exo = pyoracle.extract_features(scan, X)
-            assert all(np.array_equal(a, b) for a, b in zip(ex, exo)), "features differ from the oracle's at frame %d" % k
+            if resident:
+                ex = [None if n in (abi.EX_RAW, abi.EX_DOWN) else blk.download(n) for n in range(abi.EX_COUNT)]
+                assert all(a is None or np.array_equal(a, b) for a, b in zip(ex, exo)), "features differ from the oracle's at frame %d" % k
+            else:
+                assert all(np.array_equal(a, b) for a, b in zip(ex, exo)), "features differ from the oracle's at frame %d" % k
             fo, do = block_of(exo)
             ro = pyoracle.icp(abi.PairData(host_map, do, init_guess=prev_rel, tgt_bound=bound), P)[0]
             dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
@@ -87,7 +99,7 @@ def main(argv=None):
         bound = list(rep.local_bound)
         assert rg.code == 1, (k, rg.code)
     m = max(n_frames - 2, 1)
-    print("%d frames of %d returns: features %.2f ms, scan-to-map registration %.2f ms, map update %.2f ms per frame -> %.1f frames/s; drift after %.0f m: %.3f m, %.4f rad"
+    print(("feature block resident in HBM: " if resident else "feature clouds through the host: ") + "%d frames of %d returns: features %.2f ms, scan-to-map registration %.2f ms, map update %.2f ms per frame -> %.1f frames/s; drift after %.0f m: %.3f m, %.4f rad"
           % (n_frames, len(frames[0][0]), t_feat / m * 1e3, t_reg / m * 1e3, t_map / m * 1e3, m / max(t_feat + t_reg + t_map, 1e-9),
              np.linalg.norm(frames[-1][1][:3, 3]), worst[0], worst[1]))
     if n_check:
