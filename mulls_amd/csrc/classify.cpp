@@ -401,18 +401,24 @@ extern "C"
 						HIPCHK(ctx, hipMemcpyAsync(keys.data() + (size_t)c * n, L.keys + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyDeviceToHost, st));
 				HIPCHK(ctx, hipStreamSynchronize(st));
 				std::vector<uint32_t> perm((size_t)n * 4);
-				std::vector<KeyIdx> ki;
+				// the four classes' visiting orders, one host thread each (the sorts are the frame path's longest host step)
+#pragma omp parallel for num_threads(4) schedule(dynamic, 1)
 				for (int c = 0; c < 4; c++)
 				{
 					if (!(fixed_num[c] > 0 && ncls[c] >= 10))
 						continue;
-					ki.resize(ncls[c]);
+					std::vector<KeyIdx> ki(ncls[c]);
 					for (uint32_t i = 0; i < ncls[c]; i++)
 						ki[i] = KeyIdx{keys[(size_t)c * n + i], i};
 					// the comparator of cfilter.hpp:1255; the permutation std::sort leaves depends on keys and count only
 					std::sort(ki.begin(), ki.end(), [](const KeyIdx &a, const KeyIdx &b) { return a.key > b.key; });
 					for (uint32_t i = 0; i < ncls[c]; i++)
 						perm[(size_t)c * n + i] = ki[i].idx;
+				}
+				for (int c = 0; c < 4; c++)
+				{
+					if (!(fixed_num[c] > 0 && ncls[c] >= 10))
+						continue;
 					HIPCHK(ctx, hipMemcpyAsync(L.perm + (size_t)c * n, perm.data() + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyHostToDevice, st));
 					launch_cl_gather(st, cls[c], L.perm + (size_t)c * n, L.cls_sorted[c], ncls[c]);
 					cls[c] = L.cls_sorted[c]; // std::sort works on cloud_in itself: the class cloud stays in this order

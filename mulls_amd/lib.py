@@ -103,6 +103,7 @@ EXPORTS = [
     "mulls_map_cloud", "mulls_map_pose", "mulls_map_download", "mulls_map_frame_download", "mulls_io_read_kitti_bin", "mulls_io_read_pcd",
     "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
     "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features", "mulls_voxel_downsample",
+    "mulls_set_option", "mulls_get_option", "mulls_block_create", "mulls_block_destroy", "mulls_extract_features_resident", "mulls_block_cloud", "mulls_block_download",
 ]
 
 
