@@ -226,7 +226,10 @@ enum mulls_option
 											 classes left out report 0; every output of the reference's interface is unchanged.  The C++ bridge switches it on. */
 	MULLS_OPT_DEBUG_STOP = 14,			  /* [0] kernel bring-up switches (tools/gpu_time_nn.py) */
 	MULLS_OPT_DEBUG_TICK = 15,			  /* [0] tests: start a fresh batch's duplicate-table epoch counter here */
-	MULLS_OPT_COUNT = 16
+	MULLS_OPT_SPLIT_MIN_PAIRS = 16,		  /* [96]    lock-step loop stepped on the device: batches of MIN .. MAX pairs iterate as two sub-batches on two streams, */
+	MULLS_OPT_SPLIT_MAX_PAIRS = 17,		  /* [2^30]  so that one half's kernels fill the gaps of the other's (MAX < MIN: never; not while profiling: +3 % at */
+										  /*         128 - 4096 pairs, nothing below 96, profiles/r03_modes.txt) */
+	MULLS_OPT_COUNT = 18
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

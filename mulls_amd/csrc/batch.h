@@ -77,7 +77,7 @@ struct mulls_batch
 	size_t cap_icp[5] = {};
 	mulls::StepState *steps = nullptr; // lock-step loop with the device step: per-pair loop state
 	size_t cap_steps = 0;
-	uint32_t epoch2 = 0; // ... and the last epoch issued on its 8-byte word (words 32-33 of epoch_h)
+	uint32_t epoch2 = 0, epoch3 = 0; // ... and the last epochs issued on its 8-byte words (words 32-33 / 48-49 of epoch_h: one per sub-batch)
 	int nsub = 1;		 // sub-batches the job tables are laid out for (build_jobs)
 	double fill_ms = 0.0, fill_pack_ms = 0.0; // the last batch_fill: wall time, host packing time ...
 	uint64_t fill_bytes = 0;				   // ... and bytes staged

@@ -362,10 +362,11 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 }
 
 __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
-											 const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute)
+											 const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute,
+											 uint32_t pair_base)
 {
 	__shared__ StepLds L;
-	(void)step_pair(blockIdx.x, descs, states, rp, K, out, steps, results, brute, L);
+	(void)step_pair(pair_base + blockIdx.x, descs, states, rp, K, out, steps, results, brute, L);
 }
 
 // Small batches (launch_finish_step decides): k_finish, k_step and k_step_publish as ONE launch — a workgroup sums its pair's partials, its
@@ -375,10 +376,10 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 __global__ __launch_bounds__(MULLS_BLOCK) void k_finish_step(CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
 															  const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
 															  mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, uint32_t *__restrict__ ticket,
-															  volatile unsigned long long *host_word, uint32_t epoch)
+															  volatile unsigned long long *host_word, uint32_t epoch, uint32_t pair_base)
 {
 	__shared__ StepLds L;
-	const uint32_t pair = blockIdx.x;
+	const uint32_t pair = pair_base + blockIdx.x;
 	if (states[pair].active || states[pair].want_residual) // uniform per workgroup
 		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
 	__threadfence_block();
@@ -528,7 +529,7 @@ void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, c
 		hipLaunchKernelGGL(k_step_init, dim3((npairs + 63u) / 64u), dim3(64), 0, st, npairs, setup, K, steps, states);
 }
 
-void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
+void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
 						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
 						uint32_t *ticket)
 {
@@ -536,13 +537,14 @@ void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairS
 		return;
 	if (ticket) // small batch: one launch
 	{
-		hipLaunchKernelGGL(k_finish_step, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, K, partial, out, bbox, steps, results, brute, ticket, host_word, epoch);
+		hipLaunchKernelGGL(k_finish_step, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, K, partial, out, bbox, steps, results, brute, ticket, host_word, epoch,
+						   pair_base);
 		return;
 	}
-	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, 0u, static_cast<uint4 *>(nullptr),
+	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, pair_base, static_cast<uint4 *>(nullptr),
 					   static_cast<uint32_t *>(nullptr), static_cast<volatile uint32_t *>(nullptr), 0u);
-	hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute);
-	hipLaunchKernelGGL(k_step_publish, dim3(1), dim3(1024), 0, st, states, npairs, host_word, epoch);
+	hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute, pair_base);
+	hipLaunchKernelGGL(k_step_publish, dim3(1), dim3(1024), 0, st, states + pair_base, npairs, host_word, epoch);
 }
 
 void launch_push_states(hipStream_t st, const PairState *host_states, PairState *dev_states, uint32_t npairs)

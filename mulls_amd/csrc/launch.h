@@ -47,7 +47,7 @@ struct StepState;
 } // namespace mulls
 // lock-step loop with the O(1) half of the iteration on the device: initial per-pair state and first PairState; k_finish followed by the step (k_step)
 void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, const mulls::IcpConst &K, mulls::StepState *steps, PairState *states);
-void launch_finish_step(hipStream_t st, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
+void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
 						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
 						uint32_t *ticket = nullptr); // ticket: two zeroed device words -> finish, step and publication in one launch (small batches)
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);

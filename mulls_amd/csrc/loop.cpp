@@ -90,7 +90,10 @@ int run_setup(Run &R)
 	uint32_t lds_cap = 0;
 	int tier = 0;
 	bool resident = false;
-	rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident, dstep ? 1 : 0);
+	// device-stepped loop: one sub-batch, or two on two streams for the batch sizes whose kernels leave most of the chip idle (not while profiling:
+	// the event sets are laid out for one)
+	const int dstep_nsub = (ctx->profiling == 0 && n >= (int)ctx->opt[MULLS_OPT_SPLIT_MIN_PAIRS] && n <= (int)ctx->opt[MULLS_OPT_SPLIT_MAX_PAIRS]) ? 2 : 1;
+	rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident, dstep ? dstep_nsub : 0);
 	if (rc != MULLS_OK)
 		return rc;
 	const bool use_grid = tier != 0;
@@ -254,119 +257,196 @@ int run_device_step(Run &R)
 {
 RUN_ALIASES
 	int rc;
-
-	// ---- lock-step loop with the O(1) half of the iteration on the device (k_reduce.hip: k_finish_step) ----------------------------
-	// One launch set per iteration for the whole batch: search (+ filter), accumulation, finish + step.  The host keeps two sets queued
-	// and reads one 8-byte word per set — (epoch << 32 | pairs still iterating) — to know when to stop queueing; a set queued behind the
-	// last useful one finds no active pair and falls through.
+	// One launch set per iteration: search (+ filter), accumulation, finish + step + publication.  The host keeps two sets queued and reads one
+	// 8-byte word per set — (epoch << 32 | pairs still iterating) — to know when to stop queueing; a set queued behind the last useful one finds no
+	// active pair and falls through.  Mid-size batches (R.nsub == 2) run as two sub-batches on two streams, each with its own sets, word and
+	// ticket: their kernels are a few hundred workgroups each and bound by latency, so the chip runs one sub-batch's kernel beside the other's.
 	if (grow(ctx, &B->steps, &B->cap_steps, (size_t)n) != MULLS_OK || grow(ctx, &B->icp_outs, &B->cap_icp[3], (size_t)n) != MULLS_OK)
 		return MULLS_E_HIP;
-	volatile unsigned long long *word = reinterpret_cast<volatile unsigned long long *>(B->epoch_h + 32);
-	unsigned long long *word_dev = reinterpret_cast<unsigned long long *>(B->epoch_dev + 32);
 	HIPCHK(ctx, hipMemsetAsync(B->icp_outs, 0, sizeof(IcpOut) * (size_t)n, st));
 	launch_step_init(st, (uint32_t)n, B->setup, K, B->steps, B->states);
-	EvTimer ev2[2] = {EvTimer{ctx}, EvTimer{ctx}};
-	ev2[1].base = 10;
-	ev2[0].used = evt.used; // the setup events were recorded on the first set
+	// Small batches are bound by the NUMBER of launches (a kernel of a few hundred workgroups takes ~5 us whatever it does; one pair is bound by
+	// the host's ~4 us per launch): the three accumulation launches become one, finish + step + publication one (k_finish_step)
+	const bool few_launches = n <= (int)ctx->opt[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS];
+	struct Sub
+	{
+		int lo = 0, hi = 0;
+		uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
+		const uint32_t *ajob_split = nullptr;
+		hipStream_t st = nullptr;
+		volatile unsigned long long *word = nullptr;
+		unsigned long long *word_dev = nullptr;
+		uint32_t *epoch_ctr = nullptr, *ticket = nullptr, *wl = nullptr, *wl_ctr = nullptr;
+		uint32_t epoch0 = 0, nn_launches = 0, left = 0;
+		int s = 0;
+		bool done = false;
+		EvTimer ev2[2] = {EvTimer{nullptr}, EvTimer{nullptr}};
+	};
+	const int nsub = B->nsub;
+	Sub subs[2];
+	for (int k = 0; k < nsub; k++)
+	{
+		Sub &S = subs[k];
+		S.lo = (int)((long)n * k / nsub);
+		S.hi = (int)((long)n * (k + 1) / nsub);
+		auto first_of = [](const std::vector<Job> &v, uint32_t pair) {
+			return (uint32_t)(std::lower_bound(v.begin(), v.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; }) - v.begin());
+		};
+		S.job_lo = first_of(B->jobs_h, (uint32_t)S.lo);
+		S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
+		S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
+		S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
+		S.ajob_split = B->ajob_split[k];
+		S.st = k == 0 ? ctx->stream : ctx->stream2;
+		S.word = reinterpret_cast<volatile unsigned long long *>(B->epoch_h + 32 + 16 * k);
+		S.word_dev = reinterpret_cast<unsigned long long *>(B->epoch_dev + 32 + 16 * k);
+		S.epoch_ctr = k == 0 ? &B->epoch2 : &B->epoch3;
+		S.epoch0 = *S.epoch_ctr;
+		S.ticket = B->ticket + 2 + 4 * k;
+		S.wl = B->wl + S.cjob_lo;
+		S.wl_ctr = B->wl_ctr + 8 * k;
+		S.left = (uint32_t)(S.hi - S.lo);
+		for (int e = 0; e < 2; e++)
+		{
+			S.ev2[e].ctx = ctx;
+			S.ev2[e].base = 10 * e;
+		}
+	}
+	subs[0].ev2[0].used = evt.used; // the setup events were recorded on the first set (profiling: one sub-batch)
 	for (int k = 0; k < 5; k++)
-		ev2[0].slot[k] = evt.slot[k];
+		subs[0].ev2[0].slot[k] = evt.slot[k];
 	evt.used = 0;
-	struct DrainOnError // an error from here on leaves kernels in flight that still write the pinned word
+	if (nsub == 2)
+	{
+		HIPCHK(ctx, hipEventRecord(ctx->ev_setup, ctx->stream));
+		HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_setup, 0));
+	}
+	struct DrainOnError // an error from here on leaves kernels in flight that still write the pinned words
 	{
 		mulls_ctx *ctx;
 		bool armed = true;
 		~DrainOnError()
 		{
 			if (armed)
+			{
 				(void)hipStreamSynchronize(ctx->stream);
+				(void)hipStreamSynchronize(ctx->stream2);
+			}
 		}
 	} drain{ctx};
-	const uint32_t epoch0 = B->epoch2;
-	uint32_t left = (uint32_t)n, nn_launches = 0;
-	// Small batches are bound by the NUMBER of launches (a kernel of a few hundred workgroups takes ~5 us whatever it does; one pair is bound by
-	// the host's ~4 us per launch): the three accumulation launches become one, finish + step + publication one (k_finish_step)
-	const bool few_launches = n <= (int)ctx->opt[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS];
-	// wait until launch set `set` has published; left = pairs still iterating after the newest published set
-	auto wait_set = [&](int set) -> int {
-		const uint32_t want = epoch0 + (uint32_t)set + 1u;
+	// wait until launch set `set` of a sub-batch has published; S.left = its pairs still iterating after the newest published set
+	auto wait_set = [&](Sub &S, int set) -> int {
+		const uint32_t want = S.epoch0 + (uint32_t)set + 1u;
 		const auto t0 = std::chrono::steady_clock::now();
 		bool synced = false;
 		for (uint64_t spins = 0;; spins++)
 		{
-			const unsigned long long w = *word;
+			const unsigned long long w = *S.word;
 			if ((int32_t)((uint32_t)(w >> 32) - want) >= 0)
 			{
 				std::atomic_thread_fence(std::memory_order_acquire);
-				left = (uint32_t)w;
+				S.left = (uint32_t)w;
 				return MULLS_OK;
 			}
 			if (synced)
 				break;
 			if ((spins & 0xfff) == 0xfff && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
 			{
-				HIPCHK(ctx, hipStreamSynchronize(st)); // a stalled device, or an asynchronous error: surfaces here
+				HIPCHK(ctx, hipStreamSynchronize(S.st)); // a stalled device, or an asynchronous error: surfaces here
 				synced = true;
 			}
 		}
 		ctx->err = "device did not publish the iteration epoch";
 		return MULLS_E_HIP;
 	};
-	const auto t_loop0 = std::chrono::steady_clock::now();
-	for (int s = 0; s <= P->max_iter_num; s++) // max_iter_num iterations and the residual pass of the last pairs to finish
-	{
+	// queue launch set S.s of a sub-batch (after its set S.s - 2 has published); marks the sub-batch done when nothing is left to queue
+	auto advance = [&](Sub &S) -> int {
+		const int s = S.s;
+		if (s > P->max_iter_num) // max_iter_num iterations and the residual pass of the last pairs to finish have been queued
+		{
+			S.done = true;
+			return MULLS_OK;
+		}
 		if (s >= 2)
 		{
 			const auto t_wait0 = std::chrono::steady_clock::now();
-			if ((rc = wait_set(s - 2)) != MULLS_OK)
-				return rc;
+			int rcw;
+			if ((rcw = wait_set(S, s - 2)) != MULLS_OK)
+				return rcw;
 			ctx->prof.ms_host_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait0).count() * 1e3;
-			ev2[s & 1].collect();
-			if (left == 0)
-				break;
+			S.ev2[s & 1].collect();
+			if (S.left == 0)
+			{
+				S.done = true;
+				return MULLS_OK;
+			}
 		}
-		EvTimer &ev = ev2[s & 1];
+		hipStream_t sst = S.st;
+		EvTimer &ev = S.ev2[s & 1];
+		ev.stream = sst;
+		const Job *jobs = B->jobs + S.job_lo;
 		const bool search = s < P->max_iter_num; // the last set can only hold residual passes
 		if (search)
 		{
 			ev.begin(&ctx->prof.ms_nn);
 			if (tier == 2)
 			{
-				if (launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
-								  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr,
-								  nn_launches++) != 0)
+				if (launch_nn_lds(sst, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx,
+								  B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, S.wl, S.wl_ctr, S.nn_launches++) != 0)
 				{
 					ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 					return MULLS_E_HIP;
 				}
 			}
 			else if (tier == 1)
-				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
-							   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
+				launch_nn_grid(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx, B->nn_d2,
+							   B->winner, B->tpos, B->nn_hint, B->match, B->mq);
 			else
-				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				launch_nn(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (rp.normal_shooting)
-				launch_nn_shoot(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+				launch_nn_shoot(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			ev.end();
 			ev.begin(&ctx->prof.ms_filter);
 			if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
-				launch_filter(st, B->njobs, B->jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
+				launch_filter(sst, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
 			ev.end();
-			ctx->prof.launches_nn++;
+			if (&S == &subs[0])
+				ctx->prof.launches_nn++;
 		}
 		// a set without a search holds only posterior-residual passes (every pair ran its last iteration in the set before): that is the
 		// residual kernel time; a set of a converging batch mixes both kinds of pairs and is charged to the accumulation
 		ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-		for (int k = 0; k < B->nsub; k++)
-			launch_accum(st, B->ajobs, B->ajob_split[k], B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
-		launch_finish_step(st, (uint32_t)n, B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, word_dev, ++B->epoch2,
-						   use_grid ? 0 : 1, few_launches ? B->ticket + 2 : nullptr);
+		launch_accum(sst, B->ajobs, S.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
+		launch_finish_step(sst, (uint32_t)S.lo, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, S.word_dev,
+						   ++*S.epoch_ctr, use_grid ? 0 : 1, few_launches ? S.ticket : nullptr);
 		ev.end();
+		S.s++;
+		return MULLS_OK;
+	};
+	const auto t_loop0 = std::chrono::steady_clock::now();
+	for (;;)
+	{
+		bool any = false;
+		for (int k = 0; k < nsub; k++)
+			if (!subs[k].done)
+			{
+				if ((rc = advance(subs[k])) != MULLS_OK)
+					return rc;
+				any = true;
+			}
+		if (!any)
+			break;
 	}
 	ctx->prof.ms_host_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() * 1e3 - ctx->prof.ms_host_wait;
-	HIPCHK(ctx, hipStreamSynchronize(st));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	if (nsub == 2)
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
 	drain.armed = false;
-	ev2[0].collect();
-	ev2[1].collect();
+	for (int k = 0; k < nsub; k++)
+	{
+		subs[k].ev2[0].collect();
+		subs[k].ev2[1].collect();
+	}
 	return results_from_device(R, 0, false);
 }
 

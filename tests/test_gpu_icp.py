@@ -166,17 +166,21 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
     empty = abi.PairData(tgt, [None] * 6)
     plist = ([p for p, _ in pairs_small] + [far, empty]) * 7
     b = ctx.batch(plist)
-    forms = {"few": 384, "separate": 0}
+    # ... and batches of SPLIT_MIN .. SPLIT_MAX pairs iterate as two sub-batches on two streams (own launch sets, epoch word, ticket, work list)
+    forms = {"few": (384, 1 << 30), "separate": (0, 1 << 30), "few split": (384, 2), "separate split": (0, 2)}
+    split_min = ctx.get_option(abi.OPT_SPLIT_MIN_PAIRS)
     for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0),
               abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
         got = {}
-        for name in ("few", "separate", "few", "separate"):
-            ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, forms[name])
+        for name in list(forms) * 2:
+            ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, forms[name][0])
+            ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, forms[name][1])
             r = b.run(P)
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
             assert got.setdefault(name, rows) == rows
-        assert got["few"] == got["separate"]
+        assert all(got[name] == got["few"] for name in forms)
     ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
+    ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, split_min)
     b.close()
 
 
