@@ -229,7 +229,9 @@ enum mulls_option
 	MULLS_OPT_SPLIT_MIN_PAIRS = 16,		  /* [96]    lock-step loop stepped on the device: batches of MIN .. MAX pairs iterate as two sub-batches on two streams, */
 	MULLS_OPT_SPLIT_MAX_PAIRS = 17,		  /* [2^30]  so that one half's kernels fill the gaps of the other's (MAX < MIN: never; not while profiling: +3 % at */
 										  /*         128 - 4096 pairs, nothing below 96, profiles/r03_modes.txt) */
-	MULLS_OPT_COUNT = 18
+	MULLS_OPT_FUSED_TGT_SETUP = 18,		  /* [1] LDS tier: the target class clouds are cropped and their grids built in one pass without a cropped working */
+										  /*     copy (k_tgt_grid); 0 = k_crop + k_grid_build_sort.  Same results */
+	MULLS_OPT_COUNT = 19
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

@@ -86,6 +86,8 @@ struct mulls_batch
 	size_t cap_wl = 0;
 	GridDesc *grids = nullptr;
 	float4 *tsorted = nullptr;
+	unsigned long long *dbg = nullptr; // diagnostics (MULLS_OPT_DEBUG_STOP = 20): RunParams::dbg_ticks
+	uint16_t *tmap = nullptr; // LDS tier without a cropped copy of the target clouds (k_tgt_grid): rank in the cropped cloud -> staged index
 	uint32_t *cell_cnt = nullptr, *cell_start = nullptr; // global tier: per-occupied-cell counters / start positions; LDS tier: dense cell table
 	unsigned long long *bm = nullptr;					  // global tier: occupancy words of every grid
 	uint32_t *pf = nullptr;								  // global tier: occupied cells before each word
@@ -105,7 +107,7 @@ struct mulls_batch
 	std::string dev_key;			 // jobs_key of the tables currently resident on the device
 	size_t cap_jobs[6] = {}, cap_cells[2] = {};
 	// capacities (elements) of the grow-only arrays
-	size_t cap_stage = 0, cap_src[11] = {}, cap_tgt[4] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
+	size_t cap_stage = 0, cap_src[11] = {}, cap_tgt[5] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
 
 namespace mulls_drv

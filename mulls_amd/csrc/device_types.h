@@ -169,4 +169,9 @@ struct RunParams
 	// the bound it leaves behind survives the next (smaller) step.  cert = 0 switches the whole mechanism off (diagnostics).
 	uint32_t cert;
 	float cert_slack_min, cert_slack_max, cert_slack_rate;
+	// LDS tier without a working copy of the target clouds (k_tgt_grid): record m of a cropped target class cloud is record tgt_map[tgt_off + m] of
+	// the staged cloud at tgt_stage (tgt_record(), device_util.h).  Null: the cropped copies tpos / tnrm exist (k_crop).
+	const float4 *tgt_stage;
+	const uint16_t *tgt_map;
+	unsigned long long *dbg_ticks; // diagnostics (MULLS_OPT_DEBUG_STOP = 20): k_cert's one-pass walk adds its phase times here (10-ns ticks; [6] = workgroups)
 };

@@ -82,6 +82,23 @@ __device__ __forceinline__ float4 load_staged_pos(const float4 *__restrict__ sta
 	return fmt == MULLS_STAGE_AOS48 ? stage[(size_t)off + (size_t)i * 3] : stage[(size_t)off + i]; // (.w: data[3] or the intensity — callers read x y z)
 }
 
+// Record m of a cropped target class cloud (position + intensity, direction + curvature): out of the cropped working copy, or — LDS tier with
+// rp.tgt_map (k_tgt_grid wrote no copy) — out of the staged cloud through the crop's map.  The same values either way.
+__device__ __forceinline__ void tgt_record(const float4 *__restrict__ tgt_stage, const uint16_t *__restrict__ tgt_map, const CloudDesc &d, uint32_t m,
+											const float4 *__restrict__ tpos, const float4 *__restrict__ tnrm, float4 &q, float4 &n)
+{
+	if (tgt_map)
+		load_staged(tgt_stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, d.tgt_n0, tgt_map[d.tgt_off + m], q, n);
+	else
+		q = tpos[d.tgt_off + m], n = tnrm[d.tgt_off + m];
+}
+// ... its x y z alone (w unspecified)
+__device__ __forceinline__ float4 tgt_point(const float4 *__restrict__ tgt_stage, const uint16_t *__restrict__ tgt_map, const CloudDesc &d, uint32_t m,
+											 const float4 *__restrict__ tpos)
+{
+	return tgt_map ? load_staged_pos(tgt_stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, tgt_map[d.tgt_off + m]) : tpos[d.tgt_off + m];
+}
+
 __device__ __forceinline__ bool class_called(const RunParams &rp, const CloudDesc &d, int cls)
 {
 	// `if (used[c] && src.size() > 0) determine_corres(...)` (cregistration.hpp:1272-1292) combined with the

@@ -1,6 +1,7 @@
 // k_grid.hip — target grids: occupancy-bitmap build of the global-memory tier, in-LDS sort build of the LDS tier
 // (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
 #include "device_util.h"
+#include "crop_grid.h"
 
 // only the words a cloud's grid really uses are cleared (the arena reserves the worst case per cloud)
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const GridDesc *__restrict__ grids, RunParams rp, unsigned long long *__restrict__ bm)
@@ -223,8 +224,273 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LDS tier, the setup of one target class cloud in one pass (rp.tgt_map): intersection crop + grid build WITHOUT a working copy of the cloud.
+// k_crop + k_grid_build_sort read the staged cloud (32 B per point), write the cropped copy (32 B), read its positions twice more (count,
+// scatter) and write the cell-sorted positions (16 B): 112 B per target point, ~30 000 target points per pair.  Here one 1024-lane workgroup
+// reads the staged POSITIONS once (16 B; all of a lane's <= MULLS_TG_TRIPS loads in flight together) and keeps them in registers through the
+// crop, the cell count and the scatter; it writes the map rank in the cropped cloud -> staged index (2 B: the consumers gather the few target
+// records they need — a correspondence's position and direction when it changes — from the staged cloud through it, tgt_record()) and the
+// cell-sorted positions (16 B): 34 B per point.  Same cropped order (stable), grid descriptor, cell table and tsorted records (w = rank in the
+// cropped cloud) as the two kernels give.  LDS: the cell counters (two 16-bit counters per word) or the sort keys — 64 KiB, two workgroups per CU.
+#define MULLS_TG_LANES 512u
+#define MULLS_TG_WAVES (MULLS_TG_LANES / 64u)
+#define MULLS_TG_TRIPS ((MULLS_LDS_MAXPTS + MULLS_TG_LANES - 1u) / MULLS_TG_LANES)
+__global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__restrict__ descs, const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
+															   const float4 *__restrict__ stage, RunParams rp, GridDesc *__restrict__ grids, uint16_t *__restrict__ tmap,
+															   uint32_t *__restrict__ cell_start, float4 *__restrict__ tsorted)
+{
+	__shared__ uint32_t K[16384];						  // counting path: cell counters, two per word; sort path: (cell id, rank) keys
+	__shared__ uint32_t wcnt[MULLS_TG_TRIPS * MULLS_TG_WAVES + 32u]; // survivors per (trip, wave), then their exclusive prefix: the stable order of the points
+	__shared__ float box_red[MULLS_TG_LANES / 64][6];
+	__shared__ uint32_t wave_tot[MULLS_TG_LANES / 64];
+	__shared__ GridDesc g_sh;
+	const uint32_t pair = blockIdx.x / MULLS_NC, cls = blockIdx.x % MULLS_NC;
+	CloudDesc &d = descs[blockIdx.x];
+	const uint32_t n0 = d.tgt_n0, fmt = (d.stage_fmt >> 2) & 3u;
+	const bool used = rp.used[cls] != 0;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// diagnostics (MULLS_DEBUG_STOP = 11 .. 15): leave after a phase, the cloud reported empty (timing of the phases with rocprofv3)
+#define TG_STOP(k)                                                     \
+	if (rp.debug_stop == (k))                                          \
+	{                                                                  \
+		if (threadIdx.x == 0)                                          \
+		{                                                              \
+			const float inf3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, ninf3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()}; \
+			grids[blockIdx.x] = make_grid(inf3, ninf3, 0u, rp, pair, cls); \
+			d.tgt_n = 0u;                                              \
+		}                                                              \
+		return;                                                        \
+	}
+	double lo[3], hi[3];
+	if (rp.crop)
+		crop_box(pair, bbox, setup, lo, hi);
+	float px[MULLS_TG_TRIPS], py[MULLS_TG_TRIPS], pz[MULLS_TG_TRIPS];
+	{
+		// x y z of load_staged_pos's records, 12-byte loads (ten float4 results in flight would not fit the register budget of a 1024-lane workgroup),
+		// all of them unconditional at clamped indices: no control flow between them, every load in flight before the first is consumed.  An empty
+		// cloud reads the pair's setup record instead (any mapped address: nothing of it is kept)
+		const float4 *base = n0 ? stage + (size_t)d.tgt_stage : reinterpret_cast<const float4 *>(setup + pair);
+		const uint32_t last = n0 ? n0 - 1u : 0u, stride = fmt == MULLS_STAGE_AOS48 ? 3u : 1u;
+#pragma unroll
+		for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+		{
+			const float *q = reinterpret_cast<const float *>(base + (size_t)min(t * MULLS_TG_LANES + threadIdx.x, last) * stride);
+			px[t] = q[0], py[t] = q[1], pz[t] = q[2];
+		}
+	}
+	__builtin_amdgcn_sched_barrier(0); // every load is issued before the first one is consumed
+	uint32_t keepmask = 0;
+#pragma unroll
+	for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+	{
+		const uint32_t i = t * MULLS_TG_LANES + threadIdx.x;
+		__builtin_amdgcn_sched_barrier(0); // one trip at a time: interleaving the ten trips' arithmetic spills
+		const bool keep = i < n0 && (!rp.crop || crop_keep(make_float4(px[t], py[t], pz[t], 0.0f), lo, hi));
+		const unsigned long long bal = __ballot(keep);
+		keepmask |= keep ? (1u << t) : 0u;
+		if (lane == 0)
+			wcnt[t * MULLS_TG_WAVES + (uint32_t)wave] = (uint32_t)__popcll(bal);
+	}
+	if (threadIdx.x < 32u)
+		wcnt[MULLS_TG_TRIPS * MULLS_TG_WAVES + threadIdx.x] = 0u;
+	__syncthreads();
+	TG_STOP(11u)
+	if (wave == 0)
+	{
+		// exclusive scan of the (trip, wave) counts, three per lane
+		const uint32_t c0 = wcnt[3 * lane], c1 = wcnt[3 * lane + 1], c2 = wcnt[3 * lane + 2];
+		const uint32_t sum = c0 + c1 + c2;
+		uint32_t incl = sum;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if (lane >= off)
+				incl += o;
+		}
+		const uint32_t before = incl - sum;
+		wcnt[3 * lane] = before;
+		wcnt[3 * lane + 1] = before + c0;
+		wcnt[3 * lane + 2] = before + c0 + c1;
+	}
+	static_assert(MULLS_TG_TRIPS * MULLS_TG_WAVES + 1u <= 3u * 64u, "one wave scans the (trip, wave) counts, three per lane");
+	__syncthreads();
+	const uint32_t n = wcnt[MULLS_TG_TRIPS * MULLS_TG_WAVES]; // the prefix of the first padding entry = the number of survivors
+	// rank of this lane's trip-t point in the cropped cloud (every lane of the wave calls it: ballot)
+	auto rank_of = [&](uint32_t t, bool keep) { return wcnt[t * MULLS_TG_WAVES + (uint32_t)wave] + (uint32_t)__popcll(__ballot(keep) & ((1ull << lane) - 1ull)); };
+	float bmin[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, bmax[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+	for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+	{
+		__builtin_amdgcn_sched_barrier(0);
+		const bool keep = (keepmask >> t) & 1u;
+		const uint32_t rank = rank_of(t, keep);
+		if (keep)
+		{
+			if (used)
+				tmap[d.tgt_off + rank] = (uint16_t)(t * MULLS_TG_LANES + threadIdx.x);
+			if (fabsf(px[t]) <= 1.0e18f && fabsf(py[t]) <= 1.0e18f && fabsf(pz[t]) <= 1.0e18f) // the grid covers the finite points; others clamp into its border cells
+			{
+				bmin[0] = fminf(bmin[0], px[t]), bmin[1] = fminf(bmin[1], py[t]), bmin[2] = fminf(bmin[2], pz[t]);
+				bmax[0] = fmaxf(bmax[0], px[t]), bmax[1] = fmaxf(bmax[1], py[t]), bmax[2] = fmaxf(bmax[2], pz[t]);
+			}
+		}
+	}
+	for (int k = 0; k < 3; k++)
+		for (int off = 32; off > 0; off >>= 1)
+		{
+			bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
+			bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
+		}
+	if (lane == 0)
+		for (int k = 0; k < 3; k++)
+		{
+			box_red[wave][k] = bmin[k];
+			box_red[wave][3 + k] = bmax[k];
+		}
+	__syncthreads();
+	TG_STOP(12u)
+	if (threadIdx.x == 0)
+	{
+		float lo3[3], hi3[3];
+		for (int k = 0; k < 3; k++)
+		{
+			lo3[k] = box_red[0][k], hi3[k] = box_red[0][3 + k];
+			for (int w = 1; w < MULLS_TG_LANES / 64; w++)
+				lo3[k] = fminf(lo3[k], box_red[w][k]), hi3[k] = fmaxf(hi3[k], box_red[w][3 + k]);
+		}
+		const GridDesc gd = make_grid(lo3, hi3, n, rp, pair, cls);
+		grids[blockIdx.x] = gd;
+		g_sh = gd;
+		d.tgt_n = n;
+	}
+	__syncthreads();
+	const GridDesc g = g_sh;
+	__syncthreads();
+	TG_STOP(13u)
+	if (!used || g.ncell == 0)
+		return;
+	uint16_t *cs16 = reinterpret_cast<uint16_t *>(cell_start) + g.cell_off;
+	if (g.ncell < 16384u)
+	{
+		// counting sort with LDS atomics on 16-bit counters packed in pairs (a count never exceeds n <= MULLS_LDS_MAXPTS: no carry into the neighbour)
+		uint16_t *cnt16 = reinterpret_cast<uint16_t *>(K);
+		for (uint32_t w = threadIdx.x; w <= (g.ncell >> 1); w += MULLS_TG_LANES)
+			K[w] = 0u;
+		__syncthreads();
+#pragma unroll
+		for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			if ((keepmask >> t) & 1u)
+			{
+				const uint32_t c = grid_cell_id(g, px[t], py[t], pz[t]);
+				atomicAdd(&K[c >> 1], (c & 1u) ? 0x10000u : 1u);
+			}
+		}
+		__syncthreads();
+		TG_STOP(14u)
+		const uint32_t per = (g.ncell + 1u + MULLS_TG_LANES - 1u) / MULLS_TG_LANES;
+		const uint32_t c0 = threadIdx.x * per, c1 = min(g.ncell + 1u, c0 + per);
+		uint32_t sum = 0;
+		for (uint32_t c = c0; c < c1; c++)
+			sum += cnt16[c];
+		uint32_t incl = sum;
+		for (int off = 1; off < 64; off <<= 1)
+		{
+			const uint32_t o = __shfl_up(incl, off);
+			if (lane >= off)
+				incl += o;
+		}
+		if (lane == 63)
+			wave_tot[wave] = incl;
+		__syncthreads();
+		uint32_t before = incl - sum;
+		for (int w = 0; w < wave; w++)
+			before += wave_tot[w];
+		for (uint32_t c = c0; c < c1; c++)
+		{
+			const uint32_t v = cnt16[c];
+			cnt16[c] = (uint16_t)before; // becomes the insertion cursor of the cell
+			before += v;
+		}
+		__syncthreads();
+		// the cursors are the cell table (16-bit entries): copied out as whole words, coalesced (the table slot is 32-byte aligned and padded)
+		for (uint32_t w = threadIdx.x; w <= (g.ncell >> 1); w += MULLS_TG_LANES)
+			reinterpret_cast<uint32_t *>(cs16)[w] = K[w];
+		__syncthreads();
+		TG_STOP(15u)
+#pragma unroll
+		for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+		{
+			__builtin_amdgcn_sched_barrier(0);
+			const bool keep = (keepmask >> t) & 1u;
+			const uint32_t rank = rank_of(t, keep);
+			if (keep)
+			{
+				const uint32_t c = grid_cell_id(g, px[t], py[t], pz[t]);
+				const uint32_t old = atomicAdd(&K[c >> 1], (c & 1u) ? 0x10000u : 1u);
+				const uint32_t pos = (c & 1u) ? (old >> 16) : (old & 0xffffu);
+				tsorted[d.tgt_off + pos] = make_float4(px[t], py[t], pz[t], __int_as_float((int)rank));
+			}
+		}
+		return;
+	}
+	// many cells (small clouds only: the cell budget shrinks as the staged cloud grows): sort (cell id, rank) keys with a bitonic network in LDS
+	uint32_t npow = 64;
+	while (npow < n)
+		npow <<= 1;
+	for (uint32_t i = n + threadIdx.x; i < npow; i += MULLS_TG_LANES)
+		K[i] = 0xffffffffu;
+#pragma unroll
+	for (uint32_t t = 0; t < MULLS_TG_TRIPS; t++)
+	{
+		const bool keep = (keepmask >> t) & 1u;
+		const uint32_t rank = rank_of(t, keep);
+		if (keep)
+			K[rank] = (grid_cell_id(g, px[t], py[t], pz[t]) << 14) | rank;
+	}
+	__threadfence_block(); // the map entries are read back below
+	__syncthreads();
+	for (uint32_t kk = 2; kk <= npow; kk <<= 1)
+		for (uint32_t j = kk >> 1; j > 0; j >>= 1)
+		{
+			for (uint32_t i = threadIdx.x; i < (npow >> 1); i += MULLS_TG_LANES)
+			{
+				const uint32_t a = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), b = a | j;
+				const uint32_t x = K[a], y = K[b];
+				if ((x > y) == ((a & kk) == 0u))
+				{
+					K[a] = y;
+					K[b] = x;
+				}
+			}
+			__syncthreads();
+		}
+	for (uint32_t pos = threadIdx.x; pos < n; pos += MULLS_TG_LANES)
+	{
+		const uint32_t idx = K[pos] & 16383u;
+		const float4 q = load_staged_pos(stage, d.tgt_stage, fmt, tmap[d.tgt_off + idx]);
+		tsorted[d.tgt_off + pos] = make_float4(q.x, q.y, q.z, __int_as_float((int)idx));
+	}
+	for (uint32_t c = threadIdx.x; c <= g.ncell; c += MULLS_TG_LANES)
+	{
+		uint32_t lo_ = 0, hi_ = n;
+		while (lo_ < hi_)
+		{
+			const uint32_t mid = (lo_ + hi_) >> 1;
+			if ((K[mid] >> 14) < c)
+				lo_ = mid + 1u;
+			else
+				hi_ = mid;
+		}
+		cs16[c] = (uint16_t)lo_;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
+#include <algorithm>
 
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
 					   const RunParams &rp, const float4 *tpos, unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cell_start,
@@ -244,4 +510,12 @@ void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const J
 	hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
 	hipLaunchKernelGGL(k_bm_starts, dim3(npairs * MULLS_NC), dim3(1024), 0, st, descs, grids, rp, cnt, cell_start);
 	hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cell_start, tsorted);
+}
+
+int launch_tgt_grid(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage, const RunParams &rp,
+					GridDesc *grids, uint16_t *tmap, uint32_t *cell_start, float4 *tsorted)
+{
+	if (npairs)
+		hipLaunchKernelGGL(k_tgt_grid, dim3(npairs * MULLS_NC), dim3(MULLS_TG_LANES), 0, st, descs, setup, bbox, stage, rp, grids, tmap, cell_start, tsorted);
+	return 0;
 }

@@ -112,7 +112,7 @@ __device__ __forceinline__ int fused_class(const RunParams &rp, const PairState 
 		const uint32_t hj = hv & 0xffffu;
 		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (hj < tgt_n)
-			tj = (int32_t)hj == pm ? Q0[k] : tpos[d.tgt_off + hj];
+			tj = (int32_t)hj == pm ? Q0[k] : tgt_point(rp.tgt_stage, rp.tgt_map, d, hj, tpos);
 		// rigid step (cregistration.hpp:1690-1695): double math, float store, in place
 		const double *T = ps.T;
 		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
@@ -258,8 +258,7 @@ __device__ __forceinline__ int fused_class(const RunParams &rp, const PairState 
 					else
 					{
 						match[gi] = m;
-						n2 = tnrm[d.tgt_off + m];
-						Q0[k] = tpos[d.tgt_off + m];
+						tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, Q0[k], n2);
 						Q1[k] = n2;
 						mq[2u * gi] = Q0[k];
 						mq[2u * gi + 1u] = n2;
@@ -470,7 +469,7 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 				const uint32_t hj = hv & 0xffffu;
 				float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 				if (hj < tgt_n)
-					tj = (int32_t)hj == pm ? q0 : tpos[A.tgt_off + hj];
+					tj = (int32_t)hj == pm ? q0 : tgt_point(rp.tgt_stage, rp.tgt_map, pd[A.cls], hj, tpos);
 				// rigid step (cregistration.hpp:1690-1695): double math, float store, in place
 				const double *T = ps.T;
 				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
@@ -622,8 +621,9 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 						else
 						{
 							match[gi] = m;
-							n2 = tnrm[A.tgt_off + m];
-							mq[2u * gi] = tpos[A.tgt_off + m];
+							float4 q2;
+							tgt_record(rp.tgt_stage, rp.tgt_map, pd[A.cls], (uint32_t)m, tpos, tnrm, q2, n2);
+							mq[2u * gi] = q2;
 							mq[2u * gi + 1u] = n2;
 						}
 						fresh = true;

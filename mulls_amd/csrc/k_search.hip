@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 	const float thr = ps.thr[job.cls];
 	// vertex correspondences skip the direction check (cregistration.hpp:1292)
 	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u, rp.rej_strict != 0, thr * thr, rp.cos_bearing,
-						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32};
+						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32, rp.tgt_stage, rp.tgt_map};
 	uint32_t n_alive = 0, n_valid = 0;
 #pragma unroll
 	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
@@ -397,7 +397,13 @@ __global__ __launch_bounds__(BLK) void k_cert(const Job *__restrict__ cjobs, Clo
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	if (!cert_class<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
+	// a whole class cloud that fits the lanes' registers goes through in one pass (cert_class_flat); chunk-level jobs, larger clouds and classes that
+	// sit the iteration out take the general walk
+	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
+	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
+	const bool done = flat ? cert_class_flat<BLK, FLAT_TRIPS>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
+						   : cert_class<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+	if (!done)
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }

@@ -14,6 +14,9 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 				 const Job *big_clouds, uint32_t *seg_cnt, uint32_t *big_box);
 void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
 				 float4 *tpos, float4 *tnrm);
+// LDS tier with rp.tgt_map: crop + grid build of every target class cloud (<= MULLS_LDS_MAXPTS points) in one pass, no working copy (k_grid.hip)
+int launch_tgt_grid(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage, const RunParams &rp,
+					GridDesc *grids, uint16_t *tmap, uint32_t *cell_start, float4 *tsorted);
 void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
 					   const RunParams &rp, const float4 *tpos, unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cell_start,
 					   float4 *tsorted, bool lds_tier);

@@ -13,6 +13,8 @@ struct FilterCtx
 	float max_sqr;	 // CorrespondenceRejectorDistance::setMaximumDistance (float)
 	double cos_thre; // cos(angle_thre_degree / 180.0 * M_PI), evaluated on the host (:1818)
 	unsigned long long key_hi;
+	const float4 *tgt_stage; // RunParams::tgt_stage / tgt_map (tgt_record)
+	const uint16_t *tgt_map;
 };
 __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc &d, uint32_t s, const float4 *__restrict__ snrm,
 											  const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag, const int32_t *__restrict__ nn_idx,
@@ -52,8 +54,9 @@ __device__ __forceinline__ void filter_point(const FilterCtx &F, const CloudDesc
 				else
 				{
 					match[g] = m;
-					n2 = tnrm[d.tgt_off + m];
-					mq[2u * g] = tpos[d.tgt_off + m];
+					float4 q2;
+					tgt_record(F.tgt_stage, F.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n2);
+					mq[2u * g] = q2;
 					mq[2u * g + 1u] = n2;
 				}
 				fresh = true;
@@ -426,7 +429,7 @@ __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState 
 		total_matched += red[w];
 	const float thr = ps.thr[job.cls];
 	// vertex correspondences skip the direction check (cregistration.hpp:1292)
-	const FilterCtx F = {C.gate, total_matched > 0u, job.cls != 5, true, rp.rej_strict != 0, thr * thr, rp.cos_bearing, C.key_hi};
+	const FilterCtx F = {C.gate, total_matched > 0u, job.cls != 5, true, rp.rej_strict != 0, thr * thr, rp.cos_bearing, C.key_hi, rp.tgt_stage, rp.tgt_map};
 	uint32_t n_alive = 0, n_valid = 0;
 	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
 		filter_point(F, d, s, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq, n_alive, n_valid);
@@ -492,14 +495,15 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 	for (uint32_t s = job.start + threadIdx.x; s < q_end; s += BLK)
 	{
 		const uint32_t gi = d.src_off + s;
-		if (!(flag[gi] & MULLS_F_ALIVE))
-			continue;
-		// every record of the point is requested at once (position, direction, hint, standing match and its target position): one memory
-		// round trip instead of a chain of three
+		// every record of the point is requested at once, before the flag is looked at (position, direction, hint, standing match and its target
+		// position): one memory round trip instead of a chain of four
+		const uint32_t fl = flag[gi];
 		const float4 p = spos[gi], n = snrm[gi];
 		const int2 h = hint2[gi];
 		const int32_t pm0 = match[gi];
 		const float4 q0 = mq[2u * gi];
+		if (!(fl & MULLS_F_ALIVE))
+			continue;
 		uint32_t hv = 0xffffu;
 		float lb = 0.0f;
 		int32_t pm = -1;
@@ -517,7 +521,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 		const uint32_t hj = hv & 0xffffu;
 		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (hj < tgt_n)
-			tj = (int32_t)hj == pm ? q0 : tpos[d.tgt_off + hj];
+			tj = (int32_t)hj == pm ? q0 : tgt_point(rp.tgt_stage, rp.tgt_map, d, hj, tpos);
 		// fused rigid step (cregistration.hpp:1690-1695): double math, float store, in place
 		const double *T = ps.T;
 		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
@@ -603,6 +607,307 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 			matched_cnt++;
 	}
 	class_tail<BLK>(rp, ps, C, d, job, q_end, matched_cnt, U, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+	return true;
+}
+
+// cert_class for a WHOLE class cloud of at most TRIPS * BLK source slots held by one workgroup (class-level job, rp.lds_dedup): one pass.
+// cert_class + class_tail walk the cloud three times (certificates; duplicate rule; rejection chain) and hand everything from one walk to the
+// next through memory — nn_idx, nn_d2, the flags, the standing match, the transformed direction — which the second and third walk read back
+// from beyond the L2 (a launch has 20 MB of class clouds in flight per XCD): 126 B fetched per source slot where 77 are owed (rocprofv3
+// FETCH_SIZE, profiles/r02_zzz_pmc_traffic.txt).  Here a lane keeps its TRIPS points' state in registers across the workgroup barriers, requests
+// every record of every point (the target direction of the standing match included) before anything is consumed, and stores only what a later
+// kernel reads: positions, directions, hints, flags, pcl::Correspondence::distance, the (match, record) of a changed correspondence.  nn_idx /
+// nn_d2 are written for the points a search has to see — its own leftovers, or every live point when the cloud goes to k_nn_lds (return false).
+// The same arithmetic, decisions and outputs as cert_class + class_tail; `called` class clouds only (class_called: the caller checks).
+template <int BLK, int TRIPS>
+__device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
+												 float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
+												 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+												 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
+												 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+{
+	__shared__ float4 uq[MULLS_CERT_SMALL]; // the few queries this workgroup searches itself
+	__shared__ uint32_t us[MULLS_CERT_SMALL];
+	__shared__ uint32_t ucount, red[3 * (BLK / 64)];
+	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
+	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
+	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, true);
+	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
+	const uint32_t q_end = src_n;		// class-level job: job.start == 0, job.count >= src_n
+	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
+#define FLAT_TICK(k)                                                  \
+	if (rp.dbg_ticks && threadIdx.x == 0)                             \
+	{                                                                 \
+		const unsigned long long now_ = wall_clock64();               \
+		atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);                   \
+		t_prev = now_;                                                \
+	}
+
+	// phase 0: every record of every point of the lane, requested together (clamped slots beyond the cloud re-read its last point: no branch between the loads)
+	uint32_t FL[TRIPS];
+	int32_t M[TRIPS], PM[TRIPS];
+	float D0[TRIPS], NX[TRIPS], NY[TRIPS], NZ[TRIPS], TX[TRIPS], TY[TRIPS], TZ[TRIPS];
+	float3 P3[TRIPS], N3[TRIPS], Q3[TRIPS]; // x y z of the records: the fourth words (intensity, curvature) stay where they are
+	int2 H[TRIPS];
+	const uint32_t last = d.src_off + (q_end ? q_end - 1u : 0u);
+#pragma unroll
+	for (int k = 0; k < TRIPS; k++)
+	{
+		const uint32_t gi = min(d.src_off + threadIdx.x + (uint32_t)k * BLK, last);
+		FL[k] = flag[gi];
+		P3[k] = *reinterpret_cast<const float3 *>(spos + gi), N3[k] = *reinterpret_cast<const float3 *>(snrm + gi);
+		H[k] = hint2[gi];
+		PM[k] = match[gi];
+		Q3[k] = *reinterpret_cast<const float3 *>(mq + 2u * gi);
+	}
+	if (C.dedup)
+		for (uint32_t t = threadIdx.x; t < tgt_n; t += BLK)
+			W[t] = 0xffffffffu;
+	if (threadIdx.x == 0)
+		ucount = 0u;
+	__syncthreads(); // the duplicate table is armed
+	FLAT_TICK(0)
+	if (rp.dbg_ticks)
+	{
+		// diagnostics: wait for the loads here, so that the memory round trip is charged to its own slot
+		float acc = 0.0f;
+#pragma unroll
+		for (int k = 0; k < TRIPS; k++)
+			acc += P3[k].x + N3[k].x + Q3[k].x + (float)H[k].x + (float)PM[k] + (float)FL[k];
+		if (acc == 1.2345e-30f)
+			W[0] = 0u;
+		FLAT_TICK(1)
+	}
+
+	// phase 1: rigid step + certificate (cert_class's arithmetic)
+	uint32_t matched_cnt = 0;
+#pragma unroll
+	for (int k = 0; k < TRIPS; k++)
+	{
+		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
+		M[k] = -1, D0[k] = 0.0f, NX[k] = NY[k] = NZ[k] = 0.0f, TX[k] = TY[k] = TZ[k] = 0.0f;
+		if (s >= q_end || !(FL[k] & MULLS_F_ALIVE))
+		{
+			FL[k] = 0u;
+			continue;
+		}
+		const float3 p = P3[k], n = N3[k];
+		const float4 q0 = make_float4(Q3[k].x, Q3[k].y, Q3[k].z, 0.0f);
+		{
+			// the standing correspondence's target direction: wanted by the rejection chain only, requested now that the point's records have landed
+			const float3 t1 = *reinterpret_cast<const float3 *>(mq + 2u * gi + 1u);
+			TX[k] = t1.x, TY[k] = t1.y, TZ[k] = t1.z;
+		}
+		uint32_t hv = 0xffffu;
+		float lb = 0.0f;
+		int32_t pm = -1;
+		if (have_prev)
+		{
+			lb = __int_as_float(H[k].y);
+			hv = (uint32_t)H[k].x;
+			pm = PM[k];
+		}
+		const uint32_t hj = hv & 0xffffu;
+		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (hj < tgt_n)
+			tj = (int32_t)hj == pm ? q0 : tgt_point(rp.tgt_stage, rp.tgt_map, d, hj, tpos);
+		// fused rigid step (cregistration.hpp:1690-1695): double math, float store, in place
+		const double *T = ps.T;
+		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+		float4 out;
+		out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+		out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+		out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+		NX[k] = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+		NY[k] = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+		NZ[k] = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+		*reinterpret_cast<float3 *>(spos + gi) = make_float3(out.x, out.y, out.z);
+		*reinterpret_cast<float3 *>(snrm + gi) = make_float3(NX[k], NY[k], NZ[k]);
+		const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
+		const float moved = sqrtf((mx * mx + my * my) + mz * mz);
+		const float lb_next = lb - moved * 1.00001f;
+		out.w = __builtin_inff(); // sweep radius of a search: +inf = no hint
+		bool certified = false;
+		if (hj < tgt_n)
+		{
+			const float dx = out.x - tj.x, dy = out.y - tj.y, dz = out.z - tj.z;
+			const float d0 = (dx * dx + dy * dy) + dz * dz; // the very expression a search evaluates for this candidate
+			if (d0 >= 0.0f)
+			{
+				const float dh = sqrtf(d0);
+				certified = rp.cert != 0u && (dh * 1.00001f + moved * 1.00001f < lb * 0.99999f); // NaN anywhere fails the test
+				out.w = dh + fminf(fmaxf(rp.cert_slack_rate * moved, rp.cert_slack_min), rp.cert_slack_max);
+				if (certified)
+				{
+					const bool matched = !((double)d0 > C.max_dist_sqr);
+					M[k] = matched ? (int32_t)hj : -1;
+					D0[k] = d0;
+					hint2[gi] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
+					if (matched)
+					{
+						matched_cnt++;
+						if (C.dedup) // (rp.lds_dedup: the duplicate rule in force means the table is this workgroup's)
+							atomicMin(&W[hj], s);
+					}
+				}
+			}
+		}
+		if (!certified)
+		{
+			M[k] = MULLS_NEEDS_SEARCH;
+			D0[k] = out.w;
+			nn_idx[gi] = MULLS_NEEDS_SEARCH;
+			nn_d2[gi] = out.w;
+			const uint32_t u = atomicAdd(&ucount, 1u);
+			if (u < MULLS_CERT_SMALL)
+			{
+				uq[u] = out;
+				us[u] = s;
+			}
+		}
+	}
+	__syncthreads();
+	FLAT_TICK(2)
+	const uint32_t U = ucount;
+	if (U > MULLS_CERT_SMALL)
+	{
+		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
+#pragma unroll
+		for (int k = 0; k < TRIPS; k++)
+			if ((FL[k] & MULLS_F_ALIVE) && M[k] != MULLS_NEEDS_SEARCH)
+			{
+				const uint32_t gi = d.src_off + threadIdx.x + (uint32_t)k * BLK;
+				nn_idx[gi] = M[k];
+				nn_d2[gi] = D0[k];
+			}
+		return false;
+	}
+	// the few leftovers against the grid where the setup left it (L2-resident): same sweeps, same keys
+	{
+		const GlobGrid L = {tsorted + d.tgt_off, reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off};
+		const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+		for (uint32_t i = grp; i < U; i += BLK / MULLS_LDS_GROUP)
+		{
+			nnkey bk;
+			float sec, Rfin;
+			uint32_t trips;
+			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
+			if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+				matched_cnt++;
+		}
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = matched_cnt;
+	__threadfence_block(); // the searched points' nn_idx / nn_d2, read back below by the lanes that own them
+	__syncthreads();
+	uint32_t total_matched = 0;
+	for (int w = 0; w < BLK / 64; w++)
+		total_matched += red[w];
+	FLAT_TICK(3)
+
+	// phases 2 + 3: duplicate rule, rejection chain (filter_point's decisions, on the registers)
+	const float thr = ps.thr[job.cls], max_sqr = thr * thr; // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	const bool any_match = total_matched > 0u, normal_check = job.cls != 5, strict = rp.rej_strict != 0; // vertex correspondences skip the direction check (:1292)
+	uint32_t n_alive = 0, n_valid = 0;
+#pragma unroll
+	for (int k = 0; k < TRIPS; k++)
+	{
+		if (!(FL[k] & MULLS_F_ALIVE))
+			continue;
+		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
+		int32_t m = M[k];
+		float dist = D0[k];
+		if (m == MULLS_NEEDS_SEARCH)
+		{
+			m = nn_idx[gi];
+			dist = nn_d2[gi];
+		}
+		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched
+		if (C.dedup && m >= 0 && W[m] != s)
+			m = -1;
+		bool alive = true, valid, fresh = false;
+		float n2x = 0.0f, n2y = 0.0f, n2z = 0.0f;
+		if (any_match)
+		{
+			valid = m >= 0;
+			if (C.gate && m < 0) // (rp.lds_dedup: the duplicate rule was resolved above)
+			{
+				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+				valid = false;
+			}
+			if (valid)
+			{
+				valid = strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
+				if (valid)
+				{
+					wd[gi] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+					if (PM[k] == m)
+						n2x = TX[k], n2y = TY[k], n2z = TZ[k];
+					else
+					{
+						match[gi] = m;
+						float4 q2, n2;
+						tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n2);
+						mq[2u * gi] = q2;
+						mq[2u * gi + 1u] = n2;
+						n2x = n2.x, n2y = n2.y, n2z = n2.z;
+					}
+					fresh = true;
+				}
+			}
+		}
+		else if (C.gate)
+		{
+			alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+			valid = false;
+		}
+		else
+			valid = (FL[k] & MULLS_F_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
+		if (valid && normal_check)
+		{
+			if (!fresh)
+				n2x = TX[k], n2y = TY[k], n2z = TZ[k]; // the standing correspondence's target direction
+			const double dot = (double)NX[k] * (double)n2x + (double)NY[k] * (double)n2y + (double)NZ[k] * (double)n2z;
+			const float c = (float)fabs(dot);
+			if ((double)c < rp.cos_bearing)
+				valid = false;
+		}
+		const uint32_t nf = (alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u);
+		if (nf != FL[k])
+			flag[gi] = (uint8_t)nf;
+		n_alive += alive ? 1u : 0u;
+		n_valid += valid ? 1u : 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		n_alive += __shfl_down(n_alive, off);
+		n_valid += __shfl_down(n_valid, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		red[BLK / 64 + (threadIdx.x >> 6)] = n_alive;
+		red[2 * (BLK / 64) + (threadIdx.x >> 6)] = n_valid;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t ta = 0, tv = 0;
+		for (int w = 0; w < BLK / 64; w++)
+		{
+			ta += red[BLK / 64 + w];
+			tv += red[2 * (BLK / 64) + w];
+		}
+		d.n_matched = total_matched; // k_finish reset it to 0 after the previous iteration
+		d.alive_next = ta;
+		d.valid_next = tv;
+		d.n_search = U;
+	}
+	FLAT_TICK(4)
+	if (rp.dbg_ticks && threadIdx.x == 0)
+		atomicAdd(&rp.dbg_ticks[6], 1ull);
+#undef FLAT_TICK
 	return true;
 }
 

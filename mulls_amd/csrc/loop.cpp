@@ -99,6 +99,25 @@ int run_setup(Run &R)
 	const bool use_grid = tier != 0;
 	R.lds_cap = lds_cap, R.tier = tier, R.use_grid = use_grid, R.dstep = dstep, R.resident = resident;
 
+	// LDS tier: the target clouds are cropped and their grids built in one pass that writes no cropped copy (k_tgt_grid) — unless something needs the
+	// copy (the keep-less thinning, the normal-shooting search) or a cloud of a class the run does not read is larger than the kernel's lanes cover
+	bool fused_tgt = tier == 2 && ctx->opt[MULLS_OPT_FUSED_TGT_SETUP] != 0.0 && !P->keep_less_source_points && !rp.normal_shooting && B->big_clouds_h.empty();
+	for (size_t k = 0; k < B->descs_h.size() && fused_tgt; k++)
+		fused_tgt = B->descs_h[k].tgt_n0 <= MULLS_LDS_MAXPTS;
+	if (fused_tgt)
+	{
+		rp.tgt_stage = B->stage;
+		rp.tgt_map = B->tmap;
+	}
+
+	if (rp.debug_stop == 20u)
+	{
+		if (!B->dbg && dmalloc(ctx, &B->dbg, 16) != MULLS_OK)
+			return MULLS_E_HIP;
+		HIPCHK(ctx, hipMemsetAsync(B->dbg, 0, 16 * sizeof(unsigned long long), st));
+		rp.dbg_ticks = B->dbg;
+	}
+
 	// setup: clone + initial guess + intersection filter (cregistration.hpp:1180-1188), then the target grids
 	evt.begin(&ctx->prof.ms_setup);
 	launch_clone_src(st, (uint32_t)B->setup_jobs_h.size(), B->setup_jobs, B->descs, B->setup, B->stage, B->tmp_pos, B->tmp_nrm, B->bbox, rp);
@@ -146,7 +165,9 @@ int run_setup(Run &R)
 			return MULLS_E_HIP;
 		}
 	}
-	if (use_grid)
+	if (fused_tgt)
+		(void)launch_tgt_grid(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, rp, B->grids, B->tmap, B->cell_start, B->tsorted);
+	else if (use_grid)
 		launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
 						  B->tsorted, tier == 2);
 	evt.end();
@@ -217,6 +238,14 @@ RUN_ALIASES
 			max_it = std::max(max_it, o.iters);
 		}
 		ctx->prof.iterations = max_it;
+		if (rp.dbg_ticks) // diagnostics: k_cert's phase clocks, summed over its workgroups, in the resident loop's slots ([5] = workgroups)
+		{
+			unsigned long long t[16];
+			HIPCHK(ctx, hipMemcpy(t, rp.dbg_ticks, sizeof(t), hipMemcpyDeviceToHost));
+			for (int k = 0; k < 5; k++)
+				ctx->prof.icp_fused_ms[k] += (double)t[k] * 1e-5;
+			ctx->prof.icp_fused_ms[5] += (double)t[6];
+		}
 		return MULLS_OK;
 }
 

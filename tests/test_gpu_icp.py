@@ -184,6 +184,53 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
     b.close()
 
 
+def test_fused_target_setup_is_bit_identical(ctx, pairs_small):
+    """LDS tier: k_tgt_grid (crop + grid build of a target class cloud in one pass, no cropped copy: the records a correspondence needs are gathered
+    from the staged cloud through the crop's map) against k_crop + k_grid_build_sort: same bits, with and without the intersection filter, healthy
+    and failing pairs, lock-step and resident loop (the ctx fixture's tiers), single calls and batches."""
+    rng = np.random.default_rng(17)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    empty_t = abi.PairData([None] * 6, transformed_copy(tgt, synth.se3(0.1, 0, 0)))
+    plist = ([p for p, _ in pairs_small] + [far, empty_t]) * 3
+    b = ctx.batch(plist)
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", apply_intersection_filter=0),
+              abi.kitti_params(dis_thre_unit=2.4, apply_motion_undistortion=1)):
+        got = {}
+        for fused in (1, 0, 1):
+            ctx.set_option(abi.OPT_FUSED_TGT_SETUP, fused)
+            r = list(b.run(P)) + [ctx.icp(plist[0], P)[0]]
+            rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), tuple(x.ntgt0), x.cropped, tuple(x.crop_box), np.array(x.T[:]).tobytes(),
+                     np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
+            assert got.setdefault(fused, rows) == rows
+        assert got[0] == got[1]
+    ctx.set_option(abi.OPT_FUSED_TGT_SETUP, 1)
+    b.close()
+
+
+def test_one_pass_class_walk_is_bit_identical(ctx, pairs_small):
+    """k_cert takes a whole class cloud that fits its lanes' registers through certificates, duplicate rule and rejection chain in one pass
+    (cert_class_flat); MULLS_OPT_DEBUG_STOP = 9 sends every class cloud through the general three-walk form instead.  Same bits: healthy and
+    failing pairs, every class, gate on and off (clouds above and below 500 live points), the iteration where nothing matches."""
+    rng = np.random.default_rng(23)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    near_far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(3.0, 0.5, 0, 0, 0, 0.05)))
+    plist = ([p for p, _ in pairs_small] + [far, near_far]) * 5
+    b = ctx.batch(plist)
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0, rejector_strict=0),
+              abi.kitti_params(dis_thre_unit=0.4, max_iter_num=6)):
+        got = {}
+        for stop in (0, 9, 0):
+            ctx.set_option(abi.OPT_DEBUG_STOP, stop)
+            r = list(b.run(P)) + [ctx.icp(plist[1], P)[0]]
+            rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
+            assert got.setdefault(stop, rows) == rows
+        assert got[0] == got[9]
+    ctx.set_option(abi.OPT_DEBUG_STOP, 0)
+    b.close()
+
+
 def test_resident_batch_is_repeatable(ctx, pairs_small):
     """mulls_batch_run re-clones the staged clouds every run: identical results run after run, run-to-run deterministic."""
     P = abi.kitti_params(dis_thre_unit=2.4)
