@@ -125,7 +125,7 @@ void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 	uint32_t max_src_cap = 0;
 	for (const Job &j : B->cjobs_h)
 		max_src_cap = std::max(max_src_cap, j.count);
-	if (B->cjobs_h.size() < 512 && max_src_cap > 4096u)
+	if ((B->cjobs_h.size() < 512 && max_src_cap > 4096u) || max_src_cap > 65534u) // (k_cert's duplicate table holds 16-bit source indices)
 	{
 		// few AND large class clouds (a pair of dense scans): split them into 512-query jobs (each stages its target cloud itself) so that more than a
 		// handful of workgroups walk them.  Down-sampled class clouds stay whole whatever the batch size: a class-level job resolves the duplicate

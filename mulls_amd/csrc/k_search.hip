@@ -378,7 +378,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 // BLK lanes per class cloud: 512 when there are enough class clouds to give every CU several workgroups, 1024 for small batches (a class cloud of
 // 1200 points is then two trips instead of three, and the launch is as long as its longest workgroup)
 template <int BLK>
-__global__ __launch_bounds__(BLK) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
+__global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
 															const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BLK) void k_cert(const Job *__restrict__ cjobs, Clo
 															uint32_t *__restrict__ wl, uint32_t *__restrict__ wl_ctr, uint32_t parity)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-	uint32_t *W = reinterpret_cast<uint32_t *>(lds_raw); // [cap] lowest source index matched to each target (lds_dedup)
+	uint32_t *W = reinterpret_cast<uint32_t *>(lds_raw); // [cap / 2] lowest source index matched to each target, 16-bit entries (lds_dedup; dedup_min<true>)
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 		wl_ctr[2u * (parity ^ 1u)] = wl_ctr[2u * (parity ^ 1u) + 1u] = 0u; // the next iteration's queue (this one's predecessor has been drained)
 	const Job job = cjobs[blockIdx.x];
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(BLK) void k_cert(const Job *__restrict__ cjobs, Clo
 	// sit the iteration out take the general walk
 	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
 	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
-	const bool done = flat ? cert_class_flat<BLK, FLAT_TRIPS>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
-						   : cert_class<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+	const bool done = flat ? cert_class_flat<BLK, FLAT_TRIPS, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
+						   : cert_class<BLK, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
 	if (!done)
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
@@ -605,10 +605,10 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 		return 0;
 	const bool dedup = rp.lds_dedup != 0u;
 	if (njobs <= 2u * n_cu)
-		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? (size_t)cap * 4u : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
+		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
 						   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	else
-		hipLaunchKernelGGL(k_cert<MULLS_CERT_BLOCK>, dim3(njobs), dim3(MULLS_CERT_BLOCK), dedup ? (size_t)cap * 4u : 0u, st, jobs, descs, states, rp, spos, snrm, grids,
+		hipLaunchKernelGGL(k_cert<MULLS_CERT_BLOCK>, dim3(njobs), dim3(MULLS_CERT_BLOCK), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids,
 						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	// one workgroup per CU is all the LDS allows: they take the queued class clouds by ticket
 	hipLaunchKernelGGL(k_nn_lds, dim3(njobs < n_cu ? njobs : n_cu), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm,

@@ -364,7 +364,44 @@ __device__ __forceinline__ ClassCtx class_ctx(const RunParams &rp, const PairSta
 	return C;
 }
 
+// The duplicate table of a class cloud in LDS: per target, the lowest source index matched to it this iteration (0xffff.. = none).  32-bit entries,
+// or — W16, k_cert: source clouds of at most 65534 points, half the LDS, one more workgroup per CU — 16-bit entries packed in pairs and lowered by a
+// compare-and-swap on the word that holds them (a target is rarely claimed twice: one read and one swap).
+template <bool W16>
+__device__ __forceinline__ void dedup_init(uint32_t *W, uint32_t tgt_n, uint32_t blk)
+{
+	const uint32_t words = W16 ? (tgt_n + 1u) >> 1 : tgt_n;
+	for (uint32_t t = threadIdx.x; t < words; t += blk)
+		W[t] = 0xffffffffu;
+}
+template <bool W16>
+__device__ __forceinline__ void dedup_min(uint32_t *W, uint32_t t, uint32_t s)
+{
+	if (!W16)
+	{
+		atomicMin(&W[t], s);
+		return;
+	}
+	uint32_t *w = W + (t >> 1);
+	const uint32_t sh = (t & 1u) << 4;
+	uint32_t old = *w;
+	while (((old >> sh) & 0xffffu) > s)
+	{
+		const uint32_t prev = atomicCAS(w, old, (old & ~(0xffffu << sh)) | (s << sh));
+		if (prev == old)
+			break;
+		old = prev;
+	}
+}
+// whether source s holds target t
+template <bool W16>
+__device__ __forceinline__ bool dedup_holds(const uint32_t *W, uint32_t t, uint32_t s)
+{
+	return W16 ? ((W[t >> 1] >> ((t & 1u) << 4)) & 0xffffu) == s : W[t] == s;
+}
+
 // lane `sub == 0` of a sub-group commits the result of a searched query; returns whether it is a match
+template <bool W16 = false>
 __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc &d, uint32_t s, nnkey bk, float sec, float Rfin, uint32_t trips,
 											   int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, int2 *__restrict__ hint2, uint32_t *W,
 											   unsigned long long *__restrict__ winner)
@@ -379,7 +416,7 @@ __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc
 	if (matched)
 	{
 		if (C.dedup)
-			atomicMin(&W[bi], s); // this workgroup sees every query of the class cloud: the duplicate table stays on chip
+			dedup_min<W16>(W, (uint32_t)bi, s); // this workgroup sees every query of the class cloud: the duplicate table stays on chip
 		else if (C.gate)
 			atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)s);
 	}
@@ -390,7 +427,7 @@ __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc
 // leftovers itself, else k_nn_lds): duplicate rule, then the rejection chain (k_filter's work) on the results while they are
 // still in cache, and the class's counters.  `red`: 3 * (BLK / 64) words of LDS.  Chunk-level jobs (no rp.lds_dedup) only
 // add their matches to the class counter; k_filter does the rest.
-template <int BLK>
+template <int BLK, bool W16 = false>
 __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState &ps, const ClassCtx &C, CloudDesc &d, const Job &job, uint32_t q_end,
 											uint32_t matched_cnt, uint32_t searched, const uint32_t *W, uint32_t *red, const float4 *__restrict__ snrm,
 											const float4 *__restrict__ tnrm, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
@@ -407,7 +444,7 @@ __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState 
 			if (flag[d.src_off + s] & MULLS_F_ALIVE)
 			{
 				const int m = nn_idx[d.src_off + s];
-				if (m >= 0 && W[m] != s)
+				if (m >= 0 && !dedup_holds<W16>(W, (uint32_t)m, s))
 					nn_idx[d.src_off + s] = -1;
 			}
 	}
@@ -466,7 +503,7 @@ __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState 
 // memory, the duplicate rule and the rejection chain.  Returns true when the class cloud is done for this iteration, false when
 // the caller has to stage the target cloud (lds_search_class).  W: LDS, tgt_n words (only touched with rp.lds_dedup).  Every lane
 // of the workgroup must call it (barriers inside).
-template <int BLK>
+template <int BLK, bool W16 = false>
 __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 											float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 											const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
@@ -485,8 +522,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 	const bool use_hint = called && have_prev;
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	if (C.dedup)
-		for (uint32_t t = threadIdx.x; t < tgt_n; t += BLK)
-			W[t] = 0xffffffffu;
+		dedup_init<W16>(W, tgt_n, BLK);
 	if (threadIdx.x == 0)
 		ucount = 0u;
 	__syncthreads();
@@ -568,7 +604,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 					{
 						matched_cnt++;
 						if (C.dedup)
-							atomicMin(&W[hj], s);
+							dedup_min<W16>(W, hj, s);
 						else if (C.gate)
 							atomicMin(&winner[d.tgt_off + hj], C.key_hi | (unsigned long long)s);
 					}
@@ -603,10 +639,10 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 		float sec, Rfin;
 		uint32_t trips;
 		search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
-		if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+		if (sub == 0 && commit_search<W16>(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
 			matched_cnt++;
 	}
-	class_tail<BLK>(rp, ps, C, d, job, q_end, matched_cnt, U, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+	class_tail<BLK, W16>(rp, ps, C, d, job, q_end, matched_cnt, U, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
 	return true;
 }
 
@@ -614,12 +650,19 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 // cert_class + class_tail walk the cloud three times (certificates; duplicate rule; rejection chain) and hand everything from one walk to the
 // next through memory — nn_idx, nn_d2, the flags, the standing match, the transformed direction — which the second and third walk read back
 // from beyond the L2 (a launch has 20 MB of class clouds in flight per XCD): 126 B fetched per source slot where 77 are owed (rocprofv3
-// FETCH_SIZE, profiles/r02_zzz_pmc_traffic.txt).  Here a lane keeps its TRIPS points' state in registers across the workgroup barriers, requests
-// every record of every point (the target direction of the standing match included) before anything is consumed, and stores only what a later
-// kernel reads: positions, directions, hints, flags, pcl::Correspondence::distance, the (match, record) of a changed correspondence.  nn_idx /
-// nn_d2 are written for the points a search has to see — its own leftovers, or every live point when the cloud goes to k_nn_lds (return false).
+// FETCH_SIZE, profiles/r02_zzz_pmc_traffic.txt).  Here a lane keeps three words per point across the workgroup barriers — state bits, the
+// correspondence, its squared distance — and stores only what a later kernel reads: positions, directions, hints, flags,
+// pcl::Correspondence::distance, the (match, record) of a changed correspondence.  The direction check against the STANDING correspondence's
+// target direction is evaluated right after the rigid step, while both directions are in registers (one bit kept); a changed correspondence
+// fetches its new record and the point's direction again.  nn_idx / nn_d2 are written for the points a search has to see — the leftovers, or
+// every live point when the cloud goes to k_nn_lds (return false).  The loads of two trips are in flight at a time.  The kernel is bound by the
+// latency of its memory round trips at the occupancy its registers and LDS allow (profiles/r03_k_cert_occupancy.txt): both are kept small.
 // The same arithmetic, decisions and outputs as cert_class + class_tail; `called` class clouds only (class_called: the caller checks).
-template <int BLK, int TRIPS>
+#define MULLS_FS_ALIVE 1u	 // = MULLS_F_ALIVE
+#define MULLS_FS_VALID 2u	 // = MULLS_F_VALID (member of Corr_f before this iteration)
+#define MULLS_FS_DIR_OK 4u	 // the direction check passes against the standing correspondence's target direction
+#define MULLS_FS_STANDING 8u // the certified correspondence is the standing one (its record is in place)
+template <int BLK, int TRIPS, bool W16>
 __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 												 float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 												 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
@@ -633,6 +676,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
 	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, true);
 	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
+	const bool normal_check = job.cls != 5; // vertex correspondences skip the direction check (:1292)
 	const uint32_t q_end = src_n;		// class-level job: job.start == 0, job.count >= src_n
 	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
 #define FLAT_TICK(k)                                                  \
@@ -643,74 +687,50 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 		t_prev = now_;                                                \
 	}
 
-	// phase 0: every record of every point of the lane, requested together (clamped slots beyond the cloud re-read its last point: no branch between the loads)
-	uint32_t FL[TRIPS];
-	int32_t M[TRIPS], PM[TRIPS];
-	float D0[TRIPS], NX[TRIPS], NY[TRIPS], NZ[TRIPS], TX[TRIPS], TY[TRIPS], TZ[TRIPS];
-	float3 P3[TRIPS], N3[TRIPS], Q3[TRIPS]; // x y z of the records: the fourth words (intensity, curvature) stay where they are
-	int2 H[TRIPS];
+	// the records of one trip's point, requested together (slots beyond the cloud re-read its last point: no branch between the loads)
+	struct Rec
+	{
+		uint32_t fl;
+		int32_t pm;
+		float3 p, n, q, t; // x y z of position, direction, standing target position and direction: the fourth words (intensity, curvature) stay where they are
+		int2 h;
+	};
 	const uint32_t last = d.src_off + (q_end ? q_end - 1u : 0u);
-#pragma unroll
-	for (int k = 0; k < TRIPS; k++)
-	{
+	auto load = [&](int k) {
+		Rec r;
 		const uint32_t gi = min(d.src_off + threadIdx.x + (uint32_t)k * BLK, last);
-		FL[k] = flag[gi];
-		P3[k] = *reinterpret_cast<const float3 *>(spos + gi), N3[k] = *reinterpret_cast<const float3 *>(snrm + gi);
-		H[k] = hint2[gi];
-		PM[k] = match[gi];
-		Q3[k] = *reinterpret_cast<const float3 *>(mq + 2u * gi);
-	}
-	if (C.dedup)
-		for (uint32_t t = threadIdx.x; t < tgt_n; t += BLK)
-			W[t] = 0xffffffffu;
-	if (threadIdx.x == 0)
-		ucount = 0u;
-	__syncthreads(); // the duplicate table is armed
-	FLAT_TICK(0)
-	if (rp.dbg_ticks)
-	{
-		// diagnostics: wait for the loads here, so that the memory round trip is charged to its own slot
-		float acc = 0.0f;
-#pragma unroll
-		for (int k = 0; k < TRIPS; k++)
-			acc += P3[k].x + N3[k].x + Q3[k].x + (float)H[k].x + (float)PM[k] + (float)FL[k];
-		if (acc == 1.2345e-30f)
-			W[0] = 0u;
-		FLAT_TICK(1)
-	}
-
-	// phase 1: rigid step + certificate (cert_class's arithmetic)
+		r.fl = flag[gi];
+		r.p = *reinterpret_cast<const float3 *>(spos + gi), r.n = *reinterpret_cast<const float3 *>(snrm + gi);
+		r.h = hint2[gi];
+		r.pm = match[gi];
+		r.q = *reinterpret_cast<const float3 *>(mq + 2u * gi), r.t = *reinterpret_cast<const float3 *>(mq + 2u * gi + 1u);
+		return r;
+	};
+	uint32_t ST[TRIPS];
+	int32_t M[TRIPS];
+	float D0[TRIPS];
 	uint32_t matched_cnt = 0;
-#pragma unroll
-	for (int k = 0; k < TRIPS; k++)
-	{
+	// rigid step + certificate of one trip's point (cert_class's arithmetic)
+	auto cert = [&](int k, const Rec &r) {
 		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
-		M[k] = -1, D0[k] = 0.0f, NX[k] = NY[k] = NZ[k] = 0.0f, TX[k] = TY[k] = TZ[k] = 0.0f;
-		if (s >= q_end || !(FL[k] & MULLS_F_ALIVE))
-		{
-			FL[k] = 0u;
-			continue;
-		}
-		const float3 p = P3[k], n = N3[k];
-		const float4 q0 = make_float4(Q3[k].x, Q3[k].y, Q3[k].z, 0.0f);
-		{
-			// the standing correspondence's target direction: wanted by the rejection chain only, requested now that the point's records have landed
-			const float3 t1 = *reinterpret_cast<const float3 *>(mq + 2u * gi + 1u);
-			TX[k] = t1.x, TY[k] = t1.y, TZ[k] = t1.z;
-		}
+		ST[k] = 0u, M[k] = -1, D0[k] = 0.0f;
+		if (s >= q_end || !(r.fl & MULLS_F_ALIVE))
+			return;
+		ST[k] = r.fl & (MULLS_FS_ALIVE | MULLS_FS_VALID);
+		const float3 p = r.p, n = r.n;
 		uint32_t hv = 0xffffu;
 		float lb = 0.0f;
 		int32_t pm = -1;
 		if (have_prev)
 		{
-			lb = __int_as_float(H[k].y);
-			hv = (uint32_t)H[k].x;
-			pm = PM[k];
+			lb = __int_as_float(r.h.y);
+			hv = (uint32_t)r.h.x;
+			pm = r.pm;
 		}
 		const uint32_t hj = hv & 0xffffu;
 		float4 tj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (hj < tgt_n)
-			tj = (int32_t)hj == pm ? q0 : tgt_point(rp.tgt_stage, rp.tgt_map, d, hj, tpos);
+			tj = (int32_t)hj == pm ? make_float4(r.q.x, r.q.y, r.q.z, 0.0f) : tgt_point(rp.tgt_stage, rp.tgt_map, d, hj, tpos);
 		// fused rigid step (cregistration.hpp:1690-1695): double math, float store, in place
 		const double *T = ps.T;
 		const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
@@ -718,11 +738,18 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 		out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
 		out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
 		out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-		NX[k] = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
-		NY[k] = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
-		NZ[k] = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+		const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+		const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+		const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
 		*reinterpret_cast<float3 *>(spos + gi) = make_float3(out.x, out.y, out.z);
-		*reinterpret_cast<float3 *>(snrm + gi) = make_float3(NX[k], NY[k], NZ[k]);
+		*reinterpret_cast<float3 *>(snrm + gi) = make_float3(onx, ony, onz);
+		{
+			// the direction check of the rejection chain (:1818-1826) against the standing correspondence's target direction
+			const double dot = (double)onx * (double)r.t.x + (double)ony * (double)r.t.y + (double)onz * (double)r.t.z;
+			const float c = (float)fabs(dot);
+			if (!((double)c < rp.cos_bearing))
+				ST[k] |= MULLS_FS_DIR_OK;
+		}
 		const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
 		const float moved = sqrtf((mx * mx + my * my) + mz * mz);
 		const float lb_next = lb - moved * 1.00001f;
@@ -746,8 +773,10 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 					if (matched)
 					{
 						matched_cnt++;
+						if ((int32_t)hj == r.pm)
+							ST[k] |= MULLS_FS_STANDING;
 						if (C.dedup) // (rp.lds_dedup: the duplicate rule in force means the table is this workgroup's)
-							atomicMin(&W[hj], s);
+							dedup_min<W16>(W, hj, s);
 					}
 				}
 			}
@@ -765,7 +794,22 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 				us[u] = s;
 			}
 		}
-	}
+	};
+
+	static_assert(TRIPS == 2 || TRIPS == 3, "two trips' loads in flight");
+	Rec r0 = load(0), r1 = load(1);
+	if (C.dedup)
+		dedup_init<W16>(W, tgt_n, BLK);
+	if (threadIdx.x == 0)
+		ucount = 0u;
+	__syncthreads(); // the duplicate table is armed
+	FLAT_TICK(0)
+	cert(0, r0);
+	if (TRIPS == 3)
+		r0 = load(2);
+	cert(1, r1);
+	if (TRIPS == 3)
+		cert(2, r0);
 	__syncthreads();
 	FLAT_TICK(2)
 	const uint32_t U = ucount;
@@ -774,7 +818,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
 #pragma unroll
 		for (int k = 0; k < TRIPS; k++)
-			if ((FL[k] & MULLS_F_ALIVE) && M[k] != MULLS_NEEDS_SEARCH)
+			if ((ST[k] & MULLS_FS_ALIVE) && M[k] != MULLS_NEEDS_SEARCH)
 			{
 				const uint32_t gi = d.src_off + threadIdx.x + (uint32_t)k * BLK;
 				nn_idx[gi] = M[k];
@@ -783,6 +827,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 		return false;
 	}
 	// the few leftovers against the grid where the setup left it (L2-resident): same sweeps, same keys
+	if (U)
 	{
 		const GlobGrid L = {tsorted + d.tgt_off, reinterpret_cast<const uint16_t *>(cell_start) + g.cell_off};
 		const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
@@ -792,7 +837,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 			float sec, Rfin;
 			uint32_t trips;
 			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
-			if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+			if (sub == 0 && commit_search<W16>(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
 				matched_cnt++;
 		}
 	}
@@ -807,28 +852,30 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 		total_matched += red[w];
 	FLAT_TICK(3)
 
-	// phases 2 + 3: duplicate rule, rejection chain (filter_point's decisions, on the registers)
+	// duplicate rule + rejection chain (filter_point's decisions) on the registers
 	const float thr = ps.thr[job.cls], max_sqr = thr * thr; // CorrespondenceRejectorDistance::setMaximumDistance (float)
-	const bool any_match = total_matched > 0u, normal_check = job.cls != 5, strict = rp.rej_strict != 0; // vertex correspondences skip the direction check (:1292)
+	const bool any_match = total_matched > 0u, strict = rp.rej_strict != 0;
 	uint32_t n_alive = 0, n_valid = 0;
 #pragma unroll
 	for (int k = 0; k < TRIPS; k++)
 	{
-		if (!(FL[k] & MULLS_F_ALIVE))
+		const uint32_t st = ST[k];
+		if (!(st & MULLS_FS_ALIVE))
 			continue;
 		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
 		int32_t m = M[k];
 		float dist = D0[k];
+		bool standing = (st & MULLS_FS_STANDING) != 0;
 		if (m == MULLS_NEEDS_SEARCH)
 		{
 			m = nn_idx[gi];
 			dist = nn_d2[gi];
+			standing = m >= 0 && match[gi] == m;
 		}
 		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched
-		if (C.dedup && m >= 0 && W[m] != s)
+		if (C.dedup && m >= 0 && !dedup_holds<W16>(W, (uint32_t)m, s))
 			m = -1;
-		bool alive = true, valid, fresh = false;
-		float n2x = 0.0f, n2y = 0.0f, n2z = 0.0f;
+		bool alive = true, valid, dir_ok = (st & MULLS_FS_DIR_OK) != 0;
 		if (any_match)
 		{
 			valid = m >= 0;
@@ -843,18 +890,23 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 				if (valid)
 				{
 					wd[gi] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
-					if (PM[k] == m)
-						n2x = TX[k], n2y = TY[k], n2z = TZ[k];
-					else
+					if (!standing)
 					{
+						// a new correspondence: its target record travels with the source point from here on (filter_point), and the direction check
+						// runs against the new target direction
 						match[gi] = m;
 						float4 q2, n2;
 						tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n2);
 						mq[2u * gi] = q2;
 						mq[2u * gi + 1u] = n2;
-						n2x = n2.x, n2y = n2.y, n2z = n2.z;
+						if (normal_check)
+						{
+							const float3 n1 = *reinterpret_cast<const float3 *>(snrm + gi); // this lane's own store of phase 1
+							const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+							const float c = (float)fabs(dot);
+							dir_ok = !((double)c < rp.cos_bearing);
+						}
 					}
-					fresh = true;
 				}
 			}
 		}
@@ -864,18 +916,11 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 			valid = false;
 		}
 		else
-			valid = (FL[k] & MULLS_F_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
-		if (valid && normal_check)
-		{
-			if (!fresh)
-				n2x = TX[k], n2y = TY[k], n2z = TZ[k]; // the standing correspondence's target direction
-			const double dot = (double)NX[k] * (double)n2x + (double)NY[k] * (double)n2y + (double)NZ[k] * (double)n2z;
-			const float c = (float)fabs(dot);
-			if ((double)c < rp.cos_bearing)
-				valid = false;
-		}
+			valid = (st & MULLS_FS_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
+		if (valid && normal_check && !dir_ok)
+			valid = false;
 		const uint32_t nf = (alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u);
-		if (nf != FL[k])
+		if (nf != (st & (MULLS_FS_ALIVE | MULLS_FS_VALID)))
 			flag[gi] = (uint8_t)nf;
 		n_alive += alive ? 1u : 0u;
 		n_valid += valid ? 1u : 0u;
