@@ -208,7 +208,7 @@ int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
 enum mulls_option
 {
 	MULLS_OPT_HOST_STEP = 0,			  /* [0] 1: the lock-step loop is stepped by the host (what per-iteration traces switch on anyway) */
-	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [160] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs: where one */
+	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [240] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs: where one */
 	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [320] workgroup per CU is the chip's size (profiles/r03_modes.txt); MAX < MIN: never.  nn_mode 4 asks for it at any size */
 	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 4 launches per iteration instead of 7 (one accumulation launch;
 											 finish + step + publication as one kernel) — small batches are bound by the launch count */

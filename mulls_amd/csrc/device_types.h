@@ -28,7 +28,7 @@
 #define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)
 #define MULLS_SEG 4096u		  // ... in segments of this many points
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
-#define MULLS_GRID_H0 1.0f	   // preferred cell edge in metres; grows until the cloud's box fits MULLS_MAXCELLS
+#define MULLS_GRID_H0 1.3f	   // preferred cell edge in metres (measured optimum on the bench workload, profiles/r03_sweeps.txt); grows until the cloud's box fits the cell budget
 
 // bits of the per-source-point flag byte
 #define MULLS_F_ALIVE 1u // still part of the source cloud (reference: survived every compaction, cregistration.hpp:1755-1792)

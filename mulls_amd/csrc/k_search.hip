@@ -375,6 +375,21 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 }
 
 
+// One class-cloud job of the light pass: the one-pass walk for a whole class cloud that fits the lanes' registers (cert_class_flat), the general walk for
+// chunk-level jobs, larger clouds and classes that sit the iteration out.  Returns (to every lane) false when the class cloud needs the heavy pass.
+template <int BLK>
+__device__ __forceinline__ bool cert_job(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W, float4 *__restrict__ spos,
+										  float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
+										  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm,
+										  int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint,
+										  float4 *__restrict__ mq)
+{
+	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
+	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
+	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
+				: cert_class<BLK, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+}
+
 // BLK lanes per class cloud: 512 when there are enough class clouds to give every CU several workgroups, 1024 for small batches (a class cloud of
 // 1200 points is then two trips instead of three, and the launch is as long as its longest workgroup)
 template <int BLK>
@@ -397,15 +412,34 @@ __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__r
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	// a whole class cloud that fits the lanes' registers goes through in one pass (cert_class_flat); chunk-level jobs, larger clouds and classes that
-	// sit the iteration out take the general walk
-	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
-	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
-	const bool done = flat ? cert_class_flat<BLK, FLAT_TRIPS, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
-						   : cert_class<BLK, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
-	if (!done)
+	if (!cert_job<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
+}
+
+// Light and heavy pass in one launch, for batches of at most two class clouds per CU (a single registration: three): the workgroup that finds its class cloud
+// in need of the heavy pass runs it right away (1024 lanes, the whole LDS) instead of queueing it for k_nn_lds — one launch less per iteration where
+// the iteration is bound by the number of launches.  Same functions, same results.
+__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs, const PairState *__restrict__ states,
+															  RunParams rp, float4 *__restrict__ spos, float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
+															  const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
+															  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner,
+															  const float4 *__restrict__ tnrm, int32_t *__restrict__ match, float *__restrict__ wd,
+															  const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	const Job job = cjobs[blockIdx.x];
+	const PairState &ps = states[job.pair];
+	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
+		return;
+	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+	if (cert_job<MULLS_LDS_BLOCK>(rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd,
+								   tpos, nn_hint, mq))
+		return;
+	__syncthreads(); // the light pass's LDS is free
+	lds_search_class(rp, ps, job, d, g, lds_layout(lds_raw, cap, rp.grid_maxcells), lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match,
+					 wd, tpos, nn_hint, mq);
 }
 
 __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
@@ -604,6 +638,26 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	if (!njobs)
 		return 0;
 	const bool dedup = rp.lds_dedup != 0u;
+	static size_t fused_dyn_max = 0; // dynamic LDS k_cert_nn can have next to its static block
+	if (!fused_dyn_max)
+	{
+		hipFuncAttributes fa;
+		fused_dyn_max = 1;
+		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert_nn)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u)
+		{
+			const size_t room = 160u * 1024u - fa.sharedSizeBytes;
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_cert_nn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) == hipSuccess)
+				fused_dyn_max = room;
+		}
+	}
+	// (up to two class clouds per CU: 117 k vs 103 k registrations/s at 192 pairs, 131 k vs 119 k at 256; no gain beyond, profiles/r03_modes_fused.txt)
+	if (njobs <= 2u * n_cu && rp.debug_stop != 10u && nn_lds_bytes(cap, maxcells, dedup) <= fused_dyn_max)
+	{
+		// light and heavy pass in one launch
+		hipLaunchKernelGGL(k_cert_nn, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm, grids, cell_start,
+						   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap);
+		return 0;
+	}
 	if (njobs <= 2u * n_cu)
 		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
 						   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);

@@ -221,12 +221,12 @@ def test_one_pass_class_walk_is_bit_identical(ctx, pairs_small):
     for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0, rejector_strict=0),
               abi.kitti_params(dis_thre_unit=0.4, max_iter_num=6)):
         got = {}
-        for stop in (0, 9, 0):
+        for stop in (0, 9, 10, 0):  # 10: light and heavy pass as two launches (k_cert + k_nn_lds) where a small batch runs them as one (k_cert_nn)
             ctx.set_option(abi.OPT_DEBUG_STOP, stop)
             r = list(b.run(P)) + [ctx.icp(plist[1], P)[0]]
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
             assert got.setdefault(stop, rows) == rows
-        assert got[0] == got[9]
+        assert got[0] == got[9] == got[10]
     ctx.set_option(abi.OPT_DEBUG_STOP, 0)
     b.close()
 
