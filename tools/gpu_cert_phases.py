@@ -17,7 +17,7 @@ ctx.set_profiling(1)
 t = time.time(); b.run(P, results=res); dt = time.time() - t
 pf = ctx.profile()
 wgs = max(pf.icp_fused_ms[5], 1.0)
-names = ["table init + load issue", "loads arrive", "rigid step + certificates + stores", "leftover search + match count", "duplicate rule + rejection chain + counters"]
+names = ["set-up: descriptors, first loads issued, duplicate table armed", "(unused)", "rigid step + certificates + stores (three trips)", "leftover search + match count", "duplicate rule + rejection chain + counters"]
 print("%d pairs: %.2f ms wall, search kernels %.2f ms; %d one-pass workgroups" % (nb, dt * 1e3, pf.ms_nn, wgs))
 tot = sum(pf.icp_fused_ms[k] for k in range(5))
 for k in range(5):
