@@ -210,8 +210,9 @@ enum mulls_option
 	MULLS_OPT_HOST_STEP = 0,			  /* [0] 1: the lock-step loop is stepped by the host (what per-iteration traces switch on anyway) */
 	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [240] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs: where one */
 	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [320] workgroup per CU is the chip's size (profiles/r03_modes.txt); MAX < MIN: never.  nn_mode 4 asks for it at any size */
-	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 4 launches per iteration instead of 7 (one accumulation launch;
-											 finish + step + publication as one kernel) — small batches are bound by the launch count */
+	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 3 - 4 launches per iteration instead of 7 (one accumulation launch;
+											 finish + step + publication as one kernel; light and heavy pass of the search as one launch while there are at most
+											 two class clouds per CU) — small batches are bound by the launch count */
 	MULLS_OPT_SUBBATCHES = 4,			  /* [0 = by batch size] host-stepped loop: sub-batches in flight (1 or 2) */
 	MULLS_OPT_TWO_STREAMS = 5,			  /* [0] host-stepped loop: the second sub-batch on a second stream */
 	MULLS_OPT_CERTIFICATES = 6,			  /* [1] LDS tier: certified correspondences (0: every point is searched every iteration; MULLS_NO_CERT=1) */
@@ -219,7 +220,7 @@ enum mulls_option
 	MULLS_OPT_CERT_SLACK_MAX = 8,		  /* [0.10 m]   clamp(rate * distance moved, min, max)                          */
 	MULLS_OPT_CERT_SLACK_RATE = 9,		  /* [1.0] */
 	MULLS_OPT_LDS_DEDUP = 10,			  /* [1] LDS tier: duplicate rule and rejection chain inside the search kernels (0: k_filter; MULLS_NO_LDS_DEDUP=1) */
-	MULLS_OPT_GRID_H0 = 11,				  /* [0 = 1.0 m] LDS tier: preferred cell edge */
+	MULLS_OPT_GRID_H0 = 11,				  /* [0 = 1.3 m] LDS tier: preferred cell edge */
 	MULLS_OPT_BM_H0 = 12,				  /* [0 = from the point spacing] global-memory tier: one fixed cell edge for every cloud */
 	MULLS_OPT_LEAN_STAGING = 13,		  /* [0] mulls_icp / mulls_icp_batch stage only what the registration reads: the classes of used_feature_type (plus the
 											 source ground / pillar / facade clouds the intersection box is taken from).  mulls_result.nsrc0 / ntgt0 of the
