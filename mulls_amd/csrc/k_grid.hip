@@ -226,12 +226,13 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 // ---------------------------------------------------------------------------------------------------------------
 // LDS tier, the setup of one target class cloud in one pass (rp.tgt_map): intersection crop + grid build WITHOUT a working copy of the cloud.
 // k_crop + k_grid_build_sort read the staged cloud (32 B per point), write the cropped copy (32 B), read its positions twice more (count,
-// scatter) and write the cell-sorted positions (16 B): 112 B per target point, ~30 000 target points per pair.  Here one 1024-lane workgroup
-// reads the staged POSITIONS once (16 B; all of a lane's <= MULLS_TG_TRIPS loads in flight together) and keeps them in registers through the
+// scatter) and write the cell-sorted positions (16 B): 112 B per target point, ~30 000 target points per pair.  Here one 512-lane workgroup
+// reads the staged POSITIONS once (12 of 16 B; all of a lane's MULLS_TG_TRIPS loads in flight together) and keeps them in registers through the
 // crop, the cell count and the scatter; it writes the map rank in the cropped cloud -> staged index (2 B: the consumers gather the few target
 // records they need — a correspondence's position and direction when it changes — from the staged cloud through it, tgt_record()) and the
 // cell-sorted positions (16 B): 34 B per point.  Same cropped order (stable), grid descriptor, cell table and tsorted records (w = rank in the
-// cropped cloud) as the two kernels give.  LDS: the cell counters (two 16-bit counters per word) or the sort keys — 64 KiB, two workgroups per CU.
+// cropped cloud) as the two kernels give.  LDS: the cell counters (two 16-bit counters per word) or the sort keys — 64 KiB; registers capped at 128: two workgroups per CU
+// (1.21 ms per 4096 pairs as one 1024-lane workgroup per CU, 0.88 ms like this; the phases by MULLS_DEBUG_STOP 11 - 15: DESIGN.md section 12.3).
 #define MULLS_TG_LANES 512u
 #define MULLS_TG_WAVES (MULLS_TG_LANES / 64u)
 #define MULLS_TG_TRIPS ((MULLS_LDS_MAXPTS + MULLS_TG_LANES - 1u) / MULLS_TG_LANES)
