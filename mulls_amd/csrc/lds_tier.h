@@ -495,6 +495,132 @@ __device__ __forceinline__ void class_tail(const RunParams &rp, const PairState 
 		d.n_search = searched;
 	}
 }
+// class_tail for a WHOLE class cloud of at most TRIPS * BLK source slots (class-level job, rp.lds_dedup) by the workgroup that searched it: every
+// record the duplicate rule and the rejection chain read — flag, correspondence, distance, standing match, the point's direction, the standing
+// target direction — is requested at once, before the barrier that completes the duplicate table, instead of one after the other behind the
+// tests that need them (k_nn_lds runs one workgroup per CU: each dependent round trip is exposed; the tail took as long as the search,
+// profiles/r03_cert_phases_4096.txt).  Same decisions and outputs as class_tail (losers of the duplicate rule keep their nn_idx in memory: nothing
+// reads it after this).
+template <int BLK, int TRIPS, bool W16>
+__device__ __forceinline__ void class_tail_flat(const RunParams &rp, const PairState &ps, const ClassCtx &C, CloudDesc &d, const Job &job, uint32_t q_end,
+												 uint32_t matched_cnt, uint32_t searched, const uint32_t *W, uint32_t *red, const float4 *__restrict__ snrm,
+												 const float4 *__restrict__ tnrm, uint8_t *flag, const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
+												 int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, float4 *__restrict__ mq)
+{
+	__threadfence_block(); // the searched points' nn_idx / nn_d2 (commit_search, other lanes)
+	__syncthreads();	   // ... and the duplicate table is complete
+	uint32_t FL[TRIPS];
+	int32_t M[TRIPS], PM[TRIPS];
+	float D[TRIPS];
+	float3 N1[TRIPS], T2[TRIPS];
+	const uint32_t last = d.src_off + (q_end ? q_end - 1u : 0u);
+#pragma unroll
+	for (int k = 0; k < TRIPS; k++)
+	{
+		const uint32_t gi = min(d.src_off + threadIdx.x + (uint32_t)k * BLK, last);
+		FL[k] = flag[gi];
+		M[k] = nn_idx[gi];
+		D[k] = nn_d2[gi];
+		PM[k] = match[gi];
+		N1[k] = *reinterpret_cast<const float3 *>(snrm + gi);
+		T2[k] = *reinterpret_cast<const float3 *>(mq + 2u * gi + 1u);
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		matched_cnt += __shfl_down(matched_cnt, off);
+	if ((threadIdx.x & 63) == 0)
+		red[threadIdx.x >> 6] = matched_cnt;
+	__syncthreads();
+	uint32_t total_matched = 0;
+	for (int w = 0; w < BLK / 64; w++)
+		total_matched += red[w];
+	const float thr = ps.thr[job.cls], max_sqr = thr * thr; // CorrespondenceRejectorDistance::setMaximumDistance (float)
+	const bool any_match = total_matched > 0u, normal_check = job.cls != 5, strict = rp.rej_strict != 0; // vertex correspondences skip the direction check (:1292)
+	uint32_t n_alive = 0, n_valid = 0;
+#pragma unroll
+	for (int k = 0; k < TRIPS; k++)
+	{
+		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
+		if (s >= q_end || !(FL[k] & MULLS_F_ALIVE))
+			continue;
+		int32_t m = M[k];
+		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched
+		if (C.dedup && m >= 0 && !dedup_holds<W16>(W, (uint32_t)m, s))
+			m = -1;
+		bool alive = true, valid;
+		float3 n2 = T2[k]; // the standing correspondence's target direction
+		if (any_match)
+		{
+			valid = m >= 0;
+			if (C.gate && m < 0) // (rp.lds_dedup: the duplicate rule was resolved above)
+			{
+				alive = false; // unmatched or duplicate-losing source points vanish for good (:1762-1789)
+				valid = false;
+			}
+			if (valid)
+			{
+				const float dist = D[k];
+				valid = strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
+				if (valid)
+				{
+					wd[gi] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
+					if (PM[k] != m)
+					{
+						match[gi] = m;
+						float4 q2, n4;
+						tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n4);
+						mq[2u * gi] = q2;
+						mq[2u * gi + 1u] = n4;
+						n2 = make_float3(n4.x, n4.y, n4.z);
+					}
+				}
+			}
+		}
+		else if (C.gate)
+		{
+			alive = false; // the whole cloud was swapped for an empty one; reference behaviour undefined, see oracle
+			valid = false;
+		}
+		else
+			valid = (FL[k] & MULLS_F_VALID) != 0; // the previous Corr_f is still in place (SURVEY B-4) and goes through the direction check again
+		if (valid && normal_check)
+		{
+			const double dot = (double)N1[k].x * (double)n2.x + (double)N1[k].y * (double)n2.y + (double)N1[k].z * (double)n2.z;
+			const float c = (float)fabs(dot);
+			if ((double)c < rp.cos_bearing)
+				valid = false;
+		}
+		const uint32_t nf = (alive ? MULLS_F_ALIVE : 0u) | (valid ? MULLS_F_VALID : 0u);
+		if (nf != FL[k])
+			flag[gi] = (uint8_t)nf;
+		n_alive += alive ? 1u : 0u;
+		n_valid += valid ? 1u : 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+	{
+		n_alive += __shfl_down(n_alive, off);
+		n_valid += __shfl_down(n_valid, off);
+	}
+	if ((threadIdx.x & 63) == 0)
+	{
+		red[BLK / 64 + (threadIdx.x >> 6)] = n_alive;
+		red[2 * (BLK / 64) + (threadIdx.x >> 6)] = n_valid;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t ta = 0, tv = 0;
+		for (int w = 0; w < BLK / 64; w++)
+		{
+			ta += red[BLK / 64 + w];
+			tv += red[2 * (BLK / 64) + w];
+		}
+		d.n_matched = total_matched; // k_finish reset it to 0 after the previous iteration
+		d.alive_next = ta;
+		d.valid_next = tv;
+		d.n_search = searched;
+	}
+}
+
 // nn_idx value of a live point that cert_class could not certify and left to lds_search_class (its sweep radius waits in nn_d2)
 #define MULLS_NEEDS_SEARCH (-2)
 
@@ -991,6 +1117,15 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 												  unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
 												  float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
 {
+	// diagnostics (MULLS_OPT_DEBUG_STOP = 20): phase clocks of the heavy pass, summed over its class clouds (rp.dbg_ticks[8..12])
+	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
+#define HEAVY_TICK(k)                                                 \
+	if (rp.dbg_ticks && threadIdx.x == 0)                             \
+	{                                                                 \
+		const unsigned long long now_ = wall_clock64();               \
+		atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);                   \
+		t_prev = now_;                                                \
+	}
 	float4 *qpos = Y.qpos;
 	uint32_t *HIST = Y.HIST;
 	uint16_t *ORDER = Y.ORDER;
@@ -1072,7 +1207,7 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 		for (uint32_t t = threadIdx.x; t < tgt_n; t += MULLS_LDS_BLOCK)
 			W[t] = 0xffffffffu;
 	const LdsGrid L = {P, IDX, CS};
-	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u), grp = threadIdx.x / MULLS_LDS_GROUP;
+	const uint32_t sub = threadIdx.x & (MULLS_LDS_GROUP - 1u);
 	uint32_t matched_cnt = 0, searched = 0;
 
 	if (threadIdx.x < 32u)
@@ -1080,6 +1215,7 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 	for (uint32_t chunk = job.start; chunk < q_end; chunk += q_step)
 	{
 		__syncthreads(); // the previous chunk's queries have been consumed (and, first trip, the staging stores are visible below)
+		HEAVY_TICK(chunk == job.start ? 8 : 10)
 		uint32_t bucket = 0, rank = 0xffffffffu; // cost class of this lane's query (0 = most expensive) and its rank inside the class
 		// phase 1: one source point per lane — uncertified points become the chunk's queries, certified matches enter the duplicate table
 		if (threadIdx.x < MULLS_LDS_QCHUNK && (pf_f & MULLS_F_ALIVE))
@@ -1115,7 +1251,10 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 			HIST[32u + threadIdx.x] = incl - v;
 			HIST[threadIdx.x] = 0u; // ready for the next chunk
 			if (threadIdx.x == 31u)
+			{
 				HIST[64] = incl;
+				HIST[66] = 0u; // the chunk's query counter (phase 2)
+			}
 		}
 		__syncthreads();
 		if (rank != 0xffffffffu)
@@ -1123,20 +1262,41 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 		__syncthreads();
 		const uint32_t n_live = HIST[64];
 		searched += n_live;
+		HEAVY_TICK(9)
 
-		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each
-		for (uint32_t i = grp; i < n_live; i += MULLS_LDS_BLOCK / MULLS_LDS_GROUP)
+		// phase 2: sub-groups of MULLS_LDS_GROUP lanes, one query at a time each.  A wave takes the next eight queries of the cost order from a
+		// counter when its eight sub-groups are done (longest first, whoever is free: the waves finish together instead of by their luck with a
+		// fixed share)
+		for (;;)
 		{
-			const uint32_t k = ORDER[i];
-			nnkey bk;
-			float sec, Rfin;
-			uint32_t trips;
-			search_query(g, L, qpos[k], C.r, C.m, sub, bk, sec, Rfin, trips);
-			if (sub == 0 && commit_search(C, d, chunk + k, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
-				matched_cnt++;
+			uint32_t base = 0;
+			if ((threadIdx.x & 63u) == 0u)
+				base = atomicAdd(&HIST[66], 64u / MULLS_LDS_GROUP);
+			base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+			if (base >= n_live)
+				break;
+			const uint32_t i = base + (threadIdx.x & 63u) / MULLS_LDS_GROUP;
+			if (i < n_live)
+			{
+				const uint32_t k = ORDER[i];
+				nnkey bk;
+				float sec, Rfin;
+				uint32_t trips;
+				search_query(g, L, qpos[k], C.r, C.m, sub, bk, sec, Rfin, trips);
+				if (sub == 0 && commit_search(C, d, chunk + k, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+					matched_cnt++;
+			}
 		}
 	}
+	HEAVY_TICK(10)
 	uint32_t *red = reinterpret_cast<uint32_t *>(lds_raw); // the query block is free once the tail's first barrier has passed
-	class_tail<MULLS_LDS_BLOCK>(rp, ps, C, d, job, q_end, matched_cnt, searched, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+	if (rp.lds_dedup && rp.debug_stop != 9u && job.start == 0u && q_end <= 2u * MULLS_LDS_BLOCK)
+		class_tail_flat<MULLS_LDS_BLOCK, 2, false>(rp, ps, C, d, job, q_end, matched_cnt, searched, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, tpos, mq);
+	else
+		class_tail<MULLS_LDS_BLOCK>(rp, ps, C, d, job, q_end, matched_cnt, searched, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
+	HEAVY_TICK(11)
+	if (rp.dbg_ticks && threadIdx.x == 0)
+		atomicAdd(&rp.dbg_ticks[12], 1ull);
+#undef HEAVY_TICK
 }
 } // namespace

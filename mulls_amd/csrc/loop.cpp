@@ -245,6 +245,9 @@ RUN_ALIASES
 			for (int k = 0; k < 5; k++)
 				ctx->prof.icp_fused_ms[k] += (double)t[k] * 1e-5;
 			ctx->prof.icp_fused_ms[5] += (double)t[6];
+			for (int k = 0; k < 4; k++) // ... and the heavy pass's (k_nn_lds), in the phase slots ([4] = class clouds)
+				ctx->prof.icp_phase_ms[k] += (double)t[8 + k] * 1e-5;
+			ctx->prof.icp_phase_ms[4] += (double)t[12];
 		}
 		return MULLS_OK;
 }

@@ -23,3 +23,10 @@ tot = sum(pf.icp_fused_ms[k] for k in range(5))
 for k in range(5):
     print("  %-46s %7.2f us per workgroup  (%.1f %%)" % (names[k], pf.icp_fused_ms[k] / wgs * 1e3, 100 * pf.icp_fused_ms[k] / tot))
 print("  total %.2f us per workgroup" % (tot / wgs * 1e3))
+jobs = max(pf.icp_phase_ms[4], 1.0)
+hn = ["prefetch + staging of the target cloud + table init", "chunk set-up: queries, cost sort", "search rounds", "duplicate rule + rejection chain + counters"]
+ht = sum(pf.icp_phase_ms[k] for k in range(4))
+print("heavy pass (k_nn_lds): %d class clouds over the run's iterations" % jobs)
+for k in range(4):
+    print("  %-52s %7.2f us per class cloud  (%.1f %%)" % (hn[k], pf.icp_phase_ms[k] / jobs * 1e3, 100 * pf.icp_phase_ms[k] / max(ht, 1e-9)))
+print("  total %.2f us per class cloud" % (ht / jobs * 1e3))

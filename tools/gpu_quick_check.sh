@@ -1,0 +1,4 @@
+O=gpurun_out/r03_z; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_icp.py tests/test_demo_pair.py tests/test_gpu_fuzz.py -m gpu -x -q > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+timeout 120 python tools/gpu_cert_phases.py 4096 | tail -6
+timeout 300 python tools/gpu_modes.py 1 128 1024 4096
