@@ -1223,7 +1223,14 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 			if (pf_i == MULLS_NEEDS_SEARCH)
 			{
 				qpos[threadIdx.x] = make_float4(pf_p.x, pf_p.y, pf_p.z, pf_w);
-				bucket = pf_w < __builtin_inff() ? 31u - ((pf_hv >> 16) & 31u) : 0u; // unhinted queries (the hint word is stale or absent) are the expensive ones
+				// cost class: the candidate trips the query took last time; an unhinted query (first iteration, stale hint) whose own cell is empty will
+				// sweep the whole 2.5 * thr ball — those go first and together, the ones with neighbours in their cell after them
+				bucket = 31u - ((pf_hv >> 16) & 31u);
+				if (!(pf_w < __builtin_inff()))
+				{
+					const uint32_t c = grid_cell_id(g, pf_p.x, pf_p.y, pf_p.z);
+					bucket = CS[c + 1u] > CS[c] ? 8u : 0u;
+				}
 				rank = atomicAdd(&HIST[bucket], 1u);
 			}
 			else if (pf_i >= 0)
