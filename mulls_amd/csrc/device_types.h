@@ -22,7 +22,8 @@
 #define MULLS_LDS_QCHUNK 1024u // LDS tier: queries searched between two workgroup barriers (one per lane in the rigid-step phase)
 #define MULLS_LDS_AUX (320u + 2u * MULLS_LDS_QCHUNK) // LDS tier: cost histogram and query order of a chunk
 #define MULLS_CERT_BLOCK 512	   // k_cert: lanes per class cloud (one source point per lane and trip); several workgroups per CU
-#define MULLS_CERT_SMALL 64u   // k_cert searches up to this many uncertified points of a class cloud itself, against the grid in global memory
+#define MULLS_CERT_SMALL 64u   // the device-resident loop searches up to this many uncertified points of a class cloud against the grid in global memory
+#define MULLS_CERT_SMALL_LOCKSTEP 512u // ... k_cert up to this many (four workgroups per CU hide the walks' latency: 64 -> 512 took 1.5 ms off a 4096-pair step, profiles/r03_sweeps.txt)
 #define MULLS_ICP_STATIC_LDS 9216 // LDS the device-resident loop keeps next to the dynamic block (pair state, class rows, ...; checked at its first launch)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
 #define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)

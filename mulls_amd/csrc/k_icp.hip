@@ -711,6 +711,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 	__shared__ int s_go;
 	__shared__ unsigned long long s_src_pts, s_tgt_pts, s_corr_pts, s_t[6], s_mark;
 	__shared__ uint32_t s_q[4], s_dup[MULLS_NC]; // s_dup: fused_all kept a duplicate table for the class
+	__shared__ CertLds<MULLS_CERT_SMALL> s_cert;  // cert_class's leftover queries and reduction scratch
 	// fused_all's scratch, in the LDS the staged target cloud uses otherwise: leftover queue, class table, then the duplicate tables
 	float4 *fa_uq = reinterpret_cast<float4 *>(Y.P);
 	uint32_t *fa_us = reinterpret_cast<uint32_t *>(fa_uq + MULLS_FA_QCAP);
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 					}
 					// a class that sits this iteration out: its points still move (cert_class)
 					__syncthreads();
-					(void)cert_class<MULLS_ICP_BLOCK>(rp, ps, job, pd[cls], s_grid[cls], Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+					(void)cert_class<MULLS_ICP_BLOCK>(s_cert, rp, ps, job, pd[cls], s_grid[cls], Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
 													  nn_hint, mq);
 				}
 			}
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(MULLS_ICP_BLOCK) void k_icp(const Job *__restrict__
 							pend |= 1u << cls;
 						continue;
 					}
-					if (!cert_class<MULLS_ICP_BLOCK>(rp, ps, job, d, g, Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+					if (!cert_class<MULLS_ICP_BLOCK>(s_cert, rp, ps, job, d, g, Y.W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
 													 nn_hint, mq))
 					{
 						__syncthreads();

@@ -377,8 +377,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 
 // One class-cloud job of the light pass: the one-pass walk for a whole class cloud that fits the lanes' registers (cert_class_flat), the general walk for
 // chunk-level jobs, larger clouds and classes that sit the iteration out.  Returns (to every lane) false when the class cloud needs the heavy pass.
-template <int BLK>
-__device__ __forceinline__ bool cert_job(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W, float4 *__restrict__ spos,
+template <int BLK, int SMALL>
+__device__ __forceinline__ bool cert_job(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W, float4 *__restrict__ spos,
 										  float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
 										  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm,
 										  int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint,
@@ -386,8 +386,8 @@ __device__ __forceinline__ bool cert_job(const RunParams &rp, const PairState &p
 {
 	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
 	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
-	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
-				: cert_class<BLK, true>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true, SMALL>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
+				: cert_class<BLK, true, SMALL>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
 }
 
 // BLK lanes per class cloud: 512 when there are enough class clouds to give every CU several workgroups, 1024 for small batches (a class cloud of
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__r
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	if (!cert_job<BLK>(rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
+	__shared__ CertLds<MULLS_CERT_SMALL_LOCKSTEP> s_cert;
+	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restri
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	if (cert_job<MULLS_LDS_BLOCK>(rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd,
+	__shared__ CertLds<MULLS_CERT_SMALL> s_cert; // (the heavy pass follows in this very workgroup: a small leftover budget, and the LDS for the staged cloud)
+	if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd,
 								   tpos, nn_hint, mq))
 		return;
 	__syncthreads(); // the light pass's LDS is free

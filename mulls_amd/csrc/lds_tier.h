@@ -621,6 +621,15 @@ __device__ __forceinline__ void class_tail_flat(const RunParams &rp, const PairS
 	}
 }
 
+// LDS of the light pass next to the duplicate table: the leftover queries a workgroup searches itself, reduction scratch
+template <int SMALL>
+struct CertLds
+{
+	float4 uq[SMALL];
+	uint32_t us[SMALL];
+	uint32_t ucount, red[3 * 16];
+};
+
 // nn_idx value of a live point that cert_class could not certify and left to lds_search_class (its sweep radius waits in nn_d2)
 #define MULLS_NEEDS_SEARCH (-2)
 
@@ -629,16 +638,16 @@ __device__ __forceinline__ void class_tail_flat(const RunParams &rp, const PairS
 // memory, the duplicate rule and the rejection chain.  Returns true when the class cloud is done for this iteration, false when
 // the caller has to stage the target cloud (lds_search_class).  W: LDS, tgt_n words (only touched with rp.lds_dedup).  Every lane
 // of the workgroup must call it (barriers inside).
-template <int BLK, bool W16 = false>
-__device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
+template <int BLK, bool W16 = false, int SMALL = MULLS_CERT_SMALL>
+__device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 											float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 											const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 											unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
 											float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
 {
-	__shared__ float4 uq[MULLS_CERT_SMALL];				  // the few queries this workgroup searches itself
-	__shared__ uint32_t us[MULLS_CERT_SMALL];
-	__shared__ uint32_t ucount, red[3 * (BLK / 64)];
+	float4 *uq = CL.uq; // the few queries this workgroup searches itself
+	uint32_t *us = CL.us, *red = CL.red;
+	uint32_t &ucount = CL.ucount;
 	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint); // per source point: (hint word, bound on every OTHER target's distance)
 
 	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
@@ -742,7 +751,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 			nn_idx[gi] = MULLS_NEEDS_SEARCH;
 			nn_d2[gi] = out.w;
 			const uint32_t k = atomicAdd(&ucount, 1u);
-			if (k < MULLS_CERT_SMALL)
+			if (k < (uint32_t)SMALL)
 			{
 				uq[k] = out;
 				us[k] = s;
@@ -753,7 +762,7 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 		return true;
 	__syncthreads();
 	const uint32_t U = ucount;
-	if (U > MULLS_CERT_SMALL)
+	if (U > (uint32_t)SMALL)
 		return false; // too many for the global-memory walk: the caller has the target cloud staged (lds_search_class), which counts the
 					  // matches certified here again from nn_idx; chunk-level jobs add theirs to the class counter there too
 	// the few leftovers against the grid where k_grid_build_sort left it (L2-resident): same sweeps, same keys
@@ -788,16 +797,16 @@ __device__ __forceinline__ bool cert_class(const RunParams &rp, const PairState 
 #define MULLS_FS_VALID 2u	 // = MULLS_F_VALID (member of Corr_f before this iteration)
 #define MULLS_FS_DIR_OK 4u	 // the direction check passes against the standing correspondence's target direction
 #define MULLS_FS_STANDING 8u // the certified correspondence is the standing one (its record is in place)
-template <int BLK, int TRIPS, bool W16>
-__device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
+template <int BLK, int TRIPS, bool W16, int SMALL>
+__device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 												 float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 												 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 												 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
 												 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
 {
-	__shared__ float4 uq[MULLS_CERT_SMALL]; // the few queries this workgroup searches itself
-	__shared__ uint32_t us[MULLS_CERT_SMALL];
-	__shared__ uint32_t ucount, red[3 * (BLK / 64)];
+	float4 *uq = CL.uq; // the few queries this workgroup searches itself
+	uint32_t *us = CL.us, *red = CL.red;
+	uint32_t &ucount = CL.ucount;
 	int2 *__restrict__ hint2 = reinterpret_cast<int2 *>(nn_hint);
 	const uint32_t src_n = d.src_n, tgt_n = d.tgt_n;
 	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, true);
@@ -914,7 +923,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 			nn_idx[gi] = MULLS_NEEDS_SEARCH;
 			nn_d2[gi] = out.w;
 			const uint32_t u = atomicAdd(&ucount, 1u);
-			if (u < MULLS_CERT_SMALL)
+			if (u < (uint32_t)SMALL)
 			{
 				uq[u] = out;
 				us[u] = s;
@@ -939,7 +948,7 @@ __device__ __forceinline__ bool cert_class_flat(const RunParams &rp, const PairS
 	__syncthreads();
 	FLAT_TICK(2)
 	const uint32_t U = ucount;
-	if (U > MULLS_CERT_SMALL)
+	if (U > (uint32_t)SMALL)
 	{
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
 #pragma unroll
