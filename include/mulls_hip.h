@@ -232,7 +232,9 @@ enum mulls_option
 										  /*         128 - 4096 pairs, nothing below 96, profiles/r03_modes.txt) */
 	MULLS_OPT_FUSED_TGT_SETUP = 18,		  /* [1] LDS tier: the target class clouds are cropped and their grids built in one pass without a cropped working */
 										  /*     copy (k_tgt_grid); 0 = k_crop + k_grid_build_sort.  Same results */
-	MULLS_OPT_COUNT = 19
+	MULLS_OPT_STAGGER = 19,				  /* [4352] bytes by which the k-th per-point array of a batch starts into its 2 MiB-aligned allocation (k x this): the same index of a dozen
+										     arrays is then not the same offset into a dozen pages (+1.3 % at 4096 pairs, profiles/r03_sweeps.txt) */
+	MULLS_OPT_COUNT = 20
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

@@ -67,7 +67,7 @@ void options_init(mulls_ctx *ctx)
 	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 240, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 320, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 384;
 	o[MULLS_OPT_SUBBATCHES] = 0, o[MULLS_OPT_TWO_STREAMS] = 0, o[MULLS_OPT_CERTIFICATES] = 1;
 	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
-	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0;
+	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0;
 	static const struct
 	{
 		const char *name;
@@ -75,7 +75,7 @@ void options_init(mulls_ctx *ctx)
 	} env[] = {{"MULLS_HOST_STEP", MULLS_OPT_HOST_STEP}, {"MULLS_RESIDENT_MIN_PAIRS", MULLS_OPT_RESIDENT_MIN_PAIRS}, {"MULLS_RESIDENT_MAX_PAIRS", MULLS_OPT_RESIDENT_MAX_PAIRS},
 			   {"MULLS_FEW_LAUNCHES_MAX_PAIRS", MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS}, {"MULLS_SUBBATCHES", MULLS_OPT_SUBBATCHES}, {"MULLS_TWO_STREAMS", MULLS_OPT_TWO_STREAMS},
 			   {"MULLS_CERTIFICATES", MULLS_OPT_CERTIFICATES}, {"MULLS_LDS_DEDUP", MULLS_OPT_LDS_DEDUP}, {"MULLS_GRID_H0", MULLS_OPT_GRID_H0}, {"MULLS_BM_H0", MULLS_OPT_BM_H0},
-			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}};
+			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}};
 	for (const auto &e : env)
 		if (const char *v = std::getenv(e.name))
 			o[e.opt] = std::strtod(v, nullptr);
@@ -425,22 +425,23 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	int rc = MULLS_OK;
 	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
 	bool winner_grew = false;
+	const size_t SG = (size_t)ctx->opt[MULLS_OPT_STAGGER]; // bytes between the starts of the per-point arrays inside their 2 MiB pages
 	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec));
-	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so));
-	A(grow(ctx, &B->tmp_nrm, &B->cap_src[1], so));
-	A(grow(ctx, &B->spos, &B->cap_src[2], so));
-	A(grow(ctx, &B->snrm, &B->cap_src[3], so));
-	A(grow(ctx, &B->flag, &B->cap_src[4], so));
-	A(grow(ctx, &B->match, &B->cap_src[5], so));
-	A(grow(ctx, &B->nn_idx, &B->cap_src[6], so));
-	A(grow(ctx, &B->wd, &B->cap_src[7], so));
-	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so));
-	A(grow(ctx, &B->nn_hint, &B->cap_src[9], 2 * so)); // LDS tier: (hint word, bound) records
-	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so));
+	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so, nullptr, 12 * SG));
+	A(grow(ctx, &B->tmp_nrm, &B->cap_src[1], so, nullptr, 13 * SG));
+	A(grow(ctx, &B->spos, &B->cap_src[2], so, nullptr, 1 * SG));
+	A(grow(ctx, &B->snrm, &B->cap_src[3], so, nullptr, 2 * SG));
+	A(grow(ctx, &B->flag, &B->cap_src[4], so, nullptr, 3 * SG));
+	A(grow(ctx, &B->match, &B->cap_src[5], so, nullptr, 4 * SG));
+	A(grow(ctx, &B->nn_idx, &B->cap_src[6], so, nullptr, 5 * SG));
+	A(grow(ctx, &B->wd, &B->cap_src[7], so, nullptr, 6 * SG));
+	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so, nullptr, 7 * SG));
+	A(grow(ctx, &B->nn_hint, &B->cap_src[9], 2 * so, nullptr, 8 * SG)); // LDS tier: (hint word, bound) records
+	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so, nullptr, 9 * SG));
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
-	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to));
-	A(grow(ctx, &B->tmap, &B->cap_tgt[4], to));
+	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to, nullptr, 10 * SG));
+	A(grow(ctx, &B->tmap, &B->cap_tgt[4], to, nullptr, 11 * SG));
 	A(grow(ctx, &B->winner, &B->cap_tgt[3], to, &winner_grew));
 	A(grow(ctx, &B->descs, &B->cap_pairs[0], (size_t)n * MULLS_NC));
 	A(grow(ctx, &B->setup, &B->cap_pairs[1], (size_t)n));

@@ -82,6 +82,10 @@ struct StreamDrain
 };
 } // namespace mulls
 
+// registry of device arrays that start inside their allocation (driver.cpp)
+void *staggered_base(void *p, bool forget);
+void staggered_note(void *p, void *base);
+
 namespace
 {
 
@@ -140,18 +144,28 @@ uint32_t thin_mask(uint8_t *mask, uint32_t n, int keep_number, uint64_t seed, in
 
 // grow-only device / pinned arrays: a batch object can be refilled with new pairs without touching the allocator when
 // the previous capacity suffices (mulls_icp / mulls_icp_batch reuse one cached batch per context)
+// Device arrays may start `stagger` bytes into their allocation (the per-point arrays of a batch: every large hipMalloc is 2 MiB-aligned, so the same index
+// of eight arrays is the same offset into eight 2 MiB pages); staggered_free() finds the allocation again.
+inline void staggered_free(void *p)
+{
+	if (p)
+		(void)hipFree(staggered_base(p, true));
+}
 template <typename T>
-int grow(mulls_ctx *ctx, T **p, size_t *cap, size_t need, bool *grew = nullptr)
+int grow(mulls_ctx *ctx, T **p, size_t *cap, size_t need, bool *grew = nullptr, size_t stagger = 0)
 {
 	if (grew)
 		*grew = false;
 	if (*p && *cap >= need)
 		return MULLS_OK;
-	if (*p)
-		(void)hipFree(*p);
+	staggered_free(*p);
 	*p = nullptr;
 	const size_t want = std::max<size_t>(need + need / 4, 64);
-	HIPCHK(ctx, hipMalloc((void **)p, want * sizeof(T)));
+	void *base = nullptr;
+	HIPCHK(ctx, hipMalloc(&base, want * sizeof(T) + stagger));
+	*p = reinterpret_cast<T *>(static_cast<unsigned char *>(base) + stagger);
+	if (stagger)
+		staggered_note(*p, base);
 	*cap = want;
 	if (grew)
 		*grew = true;

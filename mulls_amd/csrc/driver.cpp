@@ -12,6 +12,30 @@
 //   stage.cpp    mulls_stage_*
 #include "batch.h"
 
+#include <mutex>
+#include <unordered_map>
+namespace
+{
+std::mutex g_stagger_mu;
+std::unordered_map<void *, void *> g_stagger;
+} // namespace
+void staggered_note(void *p, void *base)
+{
+	std::lock_guard<std::mutex> lk(g_stagger_mu);
+	g_stagger[p] = base;
+}
+void *staggered_base(void *p, bool forget)
+{
+	std::lock_guard<std::mutex> lk(g_stagger_mu);
+	auto it = g_stagger.find(p);
+	if (it == g_stagger.end())
+		return p;
+	void *b = it->second;
+	if (forget)
+		g_stagger.erase(it);
+	return b;
+}
+
 using namespace mulls_drv;
 
 extern "C"
@@ -169,7 +193,7 @@ extern "C"
 					   B->rjobs, B->ajobs, B->pair_rjob, B->order, B->icp_queue, B->icp_outs, B->trace_dev, B->steps};
 		for (void *p : dev)
 			if (p)
-				(void)hipFree(p);
+				staggered_free(p);
 		if (B->states_h)
 			(void)hipHostFree(B->states_h);
 		if (B->outs_h)
