@@ -368,12 +368,15 @@ def main(argv=None, engine_factory=None):
 
     # Process start-up, before the W warm-up steps: the first ~5 runs of a batch in a fresh process hold two or three 40-ms stalls on the host side
     # of the launch path (the HIP runtime growing its kernel-argument and signal pools: kernel times are unchanged, the GPU sits idle; tools/gpu_levels.py,
-    # profiles/r03_process_startup.txt) — they would land in the timed steps whenever W is small.  PRIME untimed runs with the timed region's event
-    # bracketing take them; reported as `untimed_priming_steps`.
-    PRIME = 0 if args.tiny else 8
+    # profiles/r03_process_startup.txt) — they would land in the timed steps whenever W is small.  Untimed runs with the timed region's event
+    # bracketing take them — at least 8 and at least 0.6 s of them (a 1024-pair step is 5 ms: eight of those end before the stalls do); reported as
+    # `untimed_priming_steps`.
+    PRIME = 0
     engine.set_profiling(2)
-    for _ in range(PRIME):
+    t_prime = time.perf_counter()
+    while not args.tiny and (PRIME < 8 or time.perf_counter() - t_prime < 0.6):  # the stalls come with the process's first ~0.3 s of launches, whatever a step takes
         step()
+        PRIME += 1
     engine.set_profiling(0)
     for _ in range(args.warmup):
         step()
