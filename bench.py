@@ -587,8 +587,10 @@ def main(argv=None, engine_factory=None):
                                     "" if abs(pmc_scale - 1.0) < 0.01 else ", measured on launches of %d pairs and scaled by %.2f to this run's %.0f pairs per launch" % (
                                         pmc["config"]["pairs_per_launch"], pmc_scale, pairs_per_launch)),
                 "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "the search is an irregular exact query, bound by VALU issue (instruction count) and dependent memory access, not by HBM "
-                        "bandwidth (DESIGN.md section 4); the HBM fraction is reported as the contract asks",
+                "note": "the search is an irregular exact query: its light pass (k_cert) is bound by the latency of its memory round trips at the occupancy its "
+                        "registers and LDS allow in the early iterations and sits at the HBM roof (4.5-5.2 TB/s of counted traffic) once every point certifies; "
+                        "the heavy pass (k_nn_lds, first iterations) by LDS-latency and VALU issue with one workgroup per CU (DESIGN.md sections 4 and 12.3); "
+                        "the HBM fraction on the algorithmic bytes is reported as the contract asks",
                 "valu_view": valu_view,
                 "kernel_ms_per_step": {k: acc[k] / args.steps for k in ("ms_setup", "ms_nn", "ms_filter", "ms_accum", "ms_residual")},
             },
