@@ -387,14 +387,14 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish_step(CloudDesc *__restri
 	const bool left = step_pair(pair, descs, states, rp, K, out, steps, results, brute, L);
 	if (threadIdx.x == 0)
 	{
-		if (left)
-			atomicAdd(&ticket[1], 1u);
-		__threadfence();
-		const uint32_t t = atomicAdd(&ticket[0], 1u);
-		if (t == gridDim.x - 1u)
+		// arrivals (low half) and pairs still iterating (high half) in ONE 64-bit atomic: no fence between two counters, none per workgroup — what the other
+		// workgroups wrote is read by the next launch (a kernel boundary) or by the host after the stream has drained, never through this word
+		unsigned long long *t64 = reinterpret_cast<unsigned long long *>(ticket);
+		const unsigned long long old = atomicAdd(t64, ((unsigned long long)(left ? 1u : 0u) << 32) | 1ull);
+		if ((uint32_t)old == gridDim.x - 1u)
 		{
-			const uint32_t n_left = atomicExch(&ticket[1], 0u);
-			ticket[0] = 0u; // re-armed for the next launch (stream order: nobody else touches it before)
+			const uint32_t n_left = (uint32_t)(old >> 32) + (left ? 1u : 0u);
+			*t64 = 0ull; // re-armed for the next launch (stream order: nobody else touches it before)
 			__threadfence_system();
 			*host_word = (unsigned long long)epoch << 32 | n_left;
 		}
