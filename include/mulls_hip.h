@@ -234,7 +234,9 @@ enum mulls_option
 										  /*     copy (k_tgt_grid); 0 = k_crop + k_grid_build_sort.  Same results */
 	MULLS_OPT_STAGGER = 19,				  /* [4352] bytes by which the k-th per-point array of a batch starts into its 2 MiB-aligned allocation (k x this): the same index of a dozen
 										     arrays is then not the same offset into a dozen pages (+1.3 % at 4096 pairs, profiles/r03_sweeps.txt) */
-	MULLS_OPT_COUNT = 20
+	MULLS_OPT_STEP_LAUNCH_MAX_PAIRS = 20, /* [640] lock-step loop: batches up to this size run finish + step + publication as one launch (k_finish_step) even when they are
+											 above FEW_LAUNCHES_MAX_PAIRS (which implies it): +2 % at 512 pairs, -2 % at 1024, -7 % at 4096 (one atomic per pair on one word) */
+	MULLS_OPT_COUNT = 21
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

@@ -450,7 +450,7 @@ RUN_ALIASES
 		ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 		launch_accum(sst, B->ajobs, S.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
 		launch_finish_step(sst, (uint32_t)S.lo, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, S.word_dev,
-						   ++*S.epoch_ctr, use_grid ? 0 : 1, few_launches ? S.ticket : nullptr);
+						   ++*S.epoch_ctr, use_grid ? 0 : 1, (few_launches || n <= (int)ctx->opt[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS]) ? S.ticket : nullptr);
 		ev.end();
 		S.s++;
 		return MULLS_OK;
