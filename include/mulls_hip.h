@@ -199,8 +199,8 @@ int mulls_get_profile(const mulls_ctx *ctx, mulls_profile *out);
  * launches (MULLS_E_INVALID when a searched target class cloud exceeds 9728 points), 4 = device-resident loop (k_icp: one launch iterates every pair
  * of the batch to the end; the lock-step LDS tier where the loop does not apply: normal shooting, source class clouds above 16384 points).
  * Auto: searched target class clouds of <= 9728 points -> the grid staged in LDS, stepped by lock-step launch sets (the O(1) half of the iteration
- * on the device too) or, inside the window MULLS_OPT_RESIDENT_MIN_PAIRS .. _MAX_PAIRS, by the device-resident loop; larger targets -> the grid in
- * global memory.  All tiers are exact and return bit-identical results (tests/test_gpu_stages.py, test_gpu_icp.py). */
+ * on the device too; the device-resident loop only inside the window MULLS_OPT_RESIDENT_MIN_PAIRS .. _MAX_PAIRS, empty by default); larger targets ->
+ * the grid in global memory.  All tiers are exact and return bit-identical results (tests/test_gpu_stages.py, test_gpu_icp.py). */
 int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
 /* Execution options of a context (none of them changes a result: every path returns the same bits).  mulls_create presets each from the environment
  * variable named after it (MULLS_OPT_HOST_STEP <- MULLS_HOST_STEP=1, ...: diagnostics and the A/B scripts under tools/); nothing reads the
@@ -208,8 +208,9 @@ int mulls_set_nn_mode(mulls_ctx *ctx, int mode);
 enum mulls_option
 {
 	MULLS_OPT_HOST_STEP = 0,			  /* [0] 1: the lock-step loop is stepped by the host (what per-iteration traces switch on anyway) */
-	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [240] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs: where one */
-	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [320] workgroup per CU is the chip's size (profiles/r03_modes.txt); MAX < MIN: never.  nn_mode 4 asks for it at any size */
+	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [1] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs; MAX < MIN (the  */
+	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [0] default): never — since round 3 the lock-step path is at least as fast at every size (profiles/r03_modes.txt: 256 pairs
+											 139 k both, 320 pairs 152 k against 100 k).  nn_mode 4 asks for the loop at any size */
 	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 3 - 4 launches per iteration instead of 7 (one accumulation launch;
 											 finish + step + publication as one kernel; light and heavy pass of the search as one launch while there are at most
 											 two class clouds per CU) — small batches are bound by the launch count */
