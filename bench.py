@@ -74,7 +74,16 @@ def parse_args(argv=None):
                          "the reference's own extract_semantic_pts lines), test/mulls_reg.cpp:194-195's mm_lls_icp arguments; delta_T against the reference lines' results")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="wall budget of the value_sustained leg (0: skip)")
     ap.add_argument("--no-converging", action="store_true", help="skip the value_converging leg")
-    return ap.parse_args(argv)
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[k]: 1 (default, the headline line) KITTI-like scan-to-scan; 0 the reference's demo pair (= --data demo); 3 the 1024-pair list "
+                         "(= --total-pairs 1024); 2 scan-to-local-map against a ~1 M-point map; 4 128-beam ~240 k-point scans, six classes, 40 iterations")
+    ap.add_argument("--large-pairs", type=int, default=0, help="configs 2 / 4: pairs per GPU and step (default 32 / 16)")
+    a = ap.parse_args(argv)
+    if a.config == 0:
+        a.data = "demo"
+    if a.config == 3 and not a.total_pairs:
+        a.total_pairs = 1024
+    return a
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -243,19 +252,44 @@ def cpu_baseline(scenes, P, budget_s=10.0):
     }
 
 
-def cpu_baseline_manycore(scenes, tiny, procs=8, budget_s=6.0):
-    """'8 processes in parallel for a fair many-core number' — 8 oracle processes, 3 OpenMP sections each."""
+def cpu_baseline_manycore(scenes, tiny, procs=None, budget_s=6.0):
+    """'N processes in parallel for a fair many-core number' — the whole host: one oracle process per three cores (the reference's loop is three
+    OpenMP sections wide), side by side."""
     import multiprocessing as mp
 
     global _MC_SCENES
     _MC_SCENES = scenes
+    host = os.cpu_count() or 1
+    procs = max(1, host // 3) if procs is None else procs
     os.environ.setdefault("OMP_NUM_THREADS", "3")
     with mp.get_context("fork").Pool(procs) as pool:
         out = pool.map(_oracle_many, [(7 * i, budget_s, tiny) for i in range(procs)])
     total = sum(n for n, _ in out)
     wall = max(t for _, t in out)
-    return {"value": total / wall, "unit": "registrations/s", "cores": 3 * procs, "kind": "port",
-            "sample": "%d oracle processes x 3 OpenMP sections side by side, %d registrations in %.1f s" % (procs, total, wall)}
+    return {"value": total / wall, "unit": "registrations/s", "cores": 3 * procs, "host_cores": host, "kind": "port",
+            "sample": "the whole host: %d oracle processes x 3 OpenMP sections side by side (%d of %d cores), %d registrations in %.1f s" % (procs, 3 * procs, host, total, wall)}
+
+
+def cpu_baseline_reference_lines(scenes, P, budget_s=6.0):
+    """The reference's OWN function bodies (oracle/_ref/libmulls_ref.so: cregistration.hpp's lines cut out at build time, compiled against the stand-in
+    for PCL / Eigen in oracle/ref_shim) on the same workload, beside the port.  None where the library was not built."""
+    try:
+        from oracle import pyref
+
+        if not pyref.available():
+            return None
+        pyref.icp(scenes[0][0], P)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            pyref.icp(scenes[n % len(scenes)][0], P)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el > budget_s and n >= 8) or n >= 4096:
+                break
+        return {"value": n / el, "unit": "registrations/s", "cores": 3, "kind": "reference lines + stand-in PCL",
+                "sample": "%d registrations back-to-back in %.1f s through the reference's own mm_lls_icp lines (its kd-tree and Eigen calls answered by oracle/ref_shim)" % (n, el)}
+    except Exception as e:  # the checker's optional strengthening: never a reason to lose the bench line
+        return {"error": repr(e)}
 
 
 def oracle_check_prepare(pairs, P, n_check):
@@ -312,6 +346,8 @@ def main(argv=None, engine_factory=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.config in (2, 4):
+        return large_main(args, rank, local_rank, world, engine_factory)
 
     # --- workload (CPU, before the device is touched: the scene pool and the oracle legs fork) --------------------------------
     P = bench_params(args.tiny)
@@ -326,12 +362,13 @@ def main(argv=None, engine_factory=None):
     else:
         scenes = build_scenes(min(n_scenes, max(n_total, 1)), args.tiny, workers)
     pairs = [global_pair(scenes, g) for g in range(lo, hi)]
-    checks, cpu, cpu_mc, checks_conv = None, None, None, None
+    checks, cpu, cpu_mc, cpu_ref, checks_conv = None, None, None, None, None
     if rank == 0 and not args.no_cpu_baseline:
         if world == 1:  # first: its children fork, and libgomp does not survive a fork once this process has run a parallel region
             if not demo:
-                cpu_mc = cpu_baseline_manycore(scenes, args.tiny, budget_s=1.0 if args.tiny else 6.0)
+                cpu_mc = cpu_baseline_manycore(scenes, args.tiny, procs=2 if args.tiny else None, budget_s=1.0 if args.tiny else 6.0)
             cpu = cpu_baseline(scenes, P, budget_s=2.0 if args.tiny else 10.0)
+            cpu_ref = cpu_baseline_reference_lines(scenes, P, budget_s=1.0 if args.tiny else 6.0)
         checks = oracle_check_prepare(pairs, P, 16) if pairs else []
         checks_conv = oracle_check_prepare(pairs, converging_params(args.tiny), 8) if pairs and not args.no_converging else None
 
@@ -355,10 +392,17 @@ def main(argv=None, engine_factory=None):
     engine.stage(pairs)
     results = abi.make_result_array(max(len(pairs), 1))
 
-    def step():
+    # the ranks' row counts follow from the partition: no size exchange, no host sync before the gather (shard.gather_post)
+    counts = [rank_span(args, world, r)[1] - rank_span(args, world, r)[0] for r in range(world)]
+
+    def step_post(gather=True):
+        """one step; its result gather is only POSTED — completed by shard.gather_wait() while the next step's kernels run"""
         if pairs:
             engine.run(P, results)
-        return shard.gather_results(shard.pack_results(results, len(pairs)), device=device)
+        return shard.gather_post(shard.pack_results(results, len(pairs)), device=device, counts=counts) if gather else None
+
+    def step():
+        return shard.gather_wait(step_post())
 
     def barrier():
         if world > 1:
@@ -391,19 +435,31 @@ def main(argv=None, engine_factory=None):
     step()  # one more untimed step with the timed region's event bracketing on (the first event records of a process are slow)
     barrier()
     t0 = time.perf_counter()
-    gathered = None
+    gathered, pending = None, None
     step_s = []
     for _ in range(args.steps):
         ts = time.perf_counter()
-        gathered = step()
+        h = step_post()  # the gather of step k travels while step k + 1 iterates; every one of the K gathers completes inside the timed region
+        gathered = shard.gather_wait(pending) if pending is not None else gathered
+        pending = h
         step_s.append(time.perf_counter() - ts)
         pf = engine.profile()
         for k in prof_keys:
             acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
         if os.environ.get("MULLS_BENCH_TRACE"):
             print("step %.2f ms: host launch %.2f wait %.2f search %.2f" % (step_s[-1] * 1e3, pf.ms_host_launch, pf.ms_host_wait, pf.ms_nn), file=sys.stderr)
+    gathered = shard.gather_wait(pending)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the same K steps without the result gather (N > 1: what the exchange step costs)
+    elapsed_nogather = None
+    if world > 1:
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            step_post(gather=False)
+        barrier()
+        elapsed_nogather = time.perf_counter() - t5
     engine.set_profiling(1)
     barrier()
     t1 = time.perf_counter()
@@ -424,6 +480,8 @@ def main(argv=None, engine_factory=None):
         return float(t.item())
 
     elapsed, elapsed_all = max_over_ranks(elapsed), max_over_ranks(elapsed_all)
+    if elapsed_nogather is not None:
+        elapsed_nogather = max_over_ranks(elapsed_nogather)
 
     # --- the realistic case next to the metric's case: same pairs, the call site's convergence thresholds ---------------------------
     conv = None
@@ -478,10 +536,11 @@ def main(argv=None, engine_factory=None):
         sub = pairs[: min(1024, len(pairs))]
         lean = hasattr(engine, "ctx")
         if lean:  # what the C++ bridge switches on: only the clouds the registration reads are staged (28 live bytes of each 48-byte record)
+            lean_before = engine.ctx.get_option(abi.OPT_LEAN_STAGING)
             engine.ctx.set_option(abi.OPT_LEAN_STAGING, 1)
         engine.run_from_host(sub, P)
-        calls = []  # the median of five calls: every call allocates and frees its batch, one slow allocation would be the whole figure otherwise
-        for _ in range(5):
+        calls = []  # the median of seven calls (the context's cached batch is reused: no allocation per call); the slowest is reported beside it
+        for _ in range(7):
             t2 = time.perf_counter()
             out2 = engine.run_from_host(sub, P)
             wall = time.perf_counter() - t2
@@ -490,12 +549,13 @@ def main(argv=None, engine_factory=None):
         calls.sort(key=lambda c: c[0])
         e2e_dt, pf2 = calls[len(calls) // 2]
         if lean:
-            engine.ctx.set_option(abi.OPT_LEAN_STAGING, 0)
+            engine.ctx.set_option(abi.OPT_LEAN_STAGING, lean_before)
         same = all(list(r2[i].T[:]) == list(results[i].T[:]) and r2[i].code == results[i].code and list(r2[i].info[:]) == list(results[i].info[:]) for i in range(len(sub)))
         caller_mb = sum(len(c) for p in sub for c in p.tgt + p.src) * abi.POINT_BYTES / 1e6
         e2e = {"value": len(sub) / e2e_dt, "unit": "registrations/s", "pairs": len(sub), "ms": e2e_dt * 1e3,
                "staged_MB": getattr(pf2, "stage_bytes", 0) / 1e6, "caller_clouds_MB": caller_mb, "ms_staging": getattr(pf2, "ms_stage", 0.0),
-               "ms_host_gather": getattr(pf2, "ms_stage_pack", 0.0), "equals_resident_results": bool(same), "calls_ms": [round(c[0] * 1e3, 2) for c in calls],
+               "ms_host_gather": getattr(pf2, "ms_stage_pack", 0.0), "equals_resident_results": bool(same), "calls_ms": [round(c[0] * 1e3, 2) for c in calls], "ms_max": calls[-1][0] * 1e3,
+               "value_slowest_call": len(sub) / calls[-1][0],
                "note": "mulls_icp_batch: class clouds in host memory (48-byte PCL records) -> results; host gather of the live fields of the classes the "
                        "registration reads into pinned memory, upload (PCIe), clone, crop, index build, iterations, residual"}
 
@@ -552,6 +612,7 @@ def main(argv=None, engine_factory=None):
             "data": "real" if demo else "synthetic",
             "profiling_events_on": "around the dominant kernel (correspondence search) in the timed steps",
             "value_all_kernel_events_on": n_reg / elapsed_all,
+            "value_without_gather": n_reg / elapsed_nogather if elapsed_nogather else None,
             "config": {
                 "workload": ("configs[0]: the reference's demo data — 000000 <-> 000001, 000000 <-> 000015 (identity guess), 000000 <-> 000015 (odometry's guess), real 64-beam scans of "
                              "%d / %d points, class clouds by the reference's own extract_semantic_pts lines (ground normal method 3, script/run_mulls_reg.sh's flags), "
@@ -621,6 +682,9 @@ def main(argv=None, engine_factory=None):
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cpu["value"]
         if cpu_mc:
             out["cpu_baseline_manycore"] = cpu_mc
+            out["cpu_baseline_manycore"]["gpu_over_whole_host"] = out["value"] / cpu_mc["value"]
+        if cpu_ref:
+            out["cpu_baseline_reference_lines"] = cpu_ref
         print(json.dumps(out))
     engine.close()
     if world > 1:

@@ -237,7 +237,13 @@ enum mulls_option
 										     arrays is then not the same offset into a dozen pages (+1.3 % at 4096 pairs, profiles/r03_sweeps.txt) */
 	MULLS_OPT_STEP_LAUNCH_MAX_PAIRS = 20, /* [640] lock-step loop: batches up to this size run finish + step + publication as one launch (k_finish_step) even when they are
 											 above FEW_LAUNCHES_MAX_PAIRS (which implies it): +2 % at 512 pairs, -2 % at 1024, -7 % at 4096 (one atomic per pair on one word) */
-	MULLS_OPT_COUNT = 21
+	MULLS_OPT_MIXED_TIERS = 21,			  /* [1] auto mode picks the search tier per (pair, class) cloud: the LDS tier for the down-sampled clouds, the global-memory
+											 tier (certified correspondences on an occupancy-bitmap grid) for larger ones, both in one launch set; 0 = one tier per
+											 batch, decided by its largest searched target cloud (rounds 1 - 3) */
+	MULLS_OPT_BIG_EARLY_SETS = 22,		  /* [2] mixed batches: the first iterations run every global-memory-tier cloud as chunk-level jobs shared by several workgroups
+											 (+ k_filter) — while most points still need a search that beats one workgroup per class cloud; from this iteration on the
+											 down-sampled source clouds are class-level jobs (certificates, leftovers, rejection chain in one workgroup, no k_filter) */
+	MULLS_OPT_COUNT = 23
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

@@ -67,7 +67,7 @@ void options_init(mulls_ctx *ctx)
 	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 1, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 384;
 	o[MULLS_OPT_SUBBATCHES] = 0, o[MULLS_OPT_TWO_STREAMS] = 0, o[MULLS_OPT_CERTIFICATES] = 1;
 	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
-	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0;
+	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0, o[MULLS_OPT_MIXED_TIERS] = 1, o[MULLS_OPT_BIG_EARLY_SETS] = 2;
 	static const struct
 	{
 		const char *name;
@@ -75,7 +75,7 @@ void options_init(mulls_ctx *ctx)
 	} env[] = {{"MULLS_HOST_STEP", MULLS_OPT_HOST_STEP}, {"MULLS_RESIDENT_MIN_PAIRS", MULLS_OPT_RESIDENT_MIN_PAIRS}, {"MULLS_RESIDENT_MAX_PAIRS", MULLS_OPT_RESIDENT_MAX_PAIRS},
 			   {"MULLS_FEW_LAUNCHES_MAX_PAIRS", MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS}, {"MULLS_SUBBATCHES", MULLS_OPT_SUBBATCHES}, {"MULLS_TWO_STREAMS", MULLS_OPT_TWO_STREAMS},
 			   {"MULLS_CERTIFICATES", MULLS_OPT_CERTIFICATES}, {"MULLS_LDS_DEDUP", MULLS_OPT_LDS_DEDUP}, {"MULLS_GRID_H0", MULLS_OPT_GRID_H0}, {"MULLS_BM_H0", MULLS_OPT_BM_H0},
-			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}};
+			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}};
 	for (const auto &e : env)
 		if (const char *v = std::getenv(e.name))
 			o[e.opt] = std::strtod(v, nullptr);
@@ -83,8 +83,6 @@ void options_init(mulls_ctx *ctx)
 		o[MULLS_OPT_CERTIFICATES] = 0;
 	if (std::getenv("MULLS_NO_LDS_DEDUP"))
 		o[MULLS_OPT_LDS_DEDUP] = 0;
-	if (std::getenv("MULLS_NO_RESIDENT"))
-		o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0;
 	if (const char *e = std::getenv("MULLS_CERT_SLACK")) // "min,max,rate"
 	{
 		float a = 0, b = 0, c = 0;
@@ -93,12 +91,74 @@ void options_init(mulls_ctx *ctx)
 	}
 }
 
-void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
+// The largest target class cloud whose duplicate table (4 B per target) still fits next to the staged cloud in the heavy pass's LDS with a 4096-cell
+// table (prepare_run: dedup_fits): the LDS tier's one-pass walk needs it, so auto mode keeps larger clouds off that tier
+uint32_t lds_dedup_max_pts()
+{
+	const long room = 160L * 1024L - 64L - (long)MULLS_ICP_STATIC_LDS - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - 2L * (4096L + 8L);
+	return (uint32_t)((room / 18L) & ~7L);
+}
+
+// Search tier and grid slot of every class cloud pair of the batch.  mode 0 / 1 / 2: one tier for the whole batch (nn_mode 1 - 4, the variants, the stage
+// calls); mode 3 (auto mode of mulls_batch_run): per class cloud — the LDS tier for the down-sampled clouds it was built for (target within
+// lds_dedup_max_pts(), source within MULLS_SMALL_SRC_MAX), the global-memory tier for everything larger, so that one large cloud no longer decides for a batch.
+// Classes the run does not search only need their crop (the reference reports their sizes): k_tgt_grid's when the target fits its lanes, k_crop's otherwise.
+void assign_tiers(mulls_batch *B, const uint8_t used[MULLS_NC], int mode)
+{
+	B->lclouds_h.clear();
+	B->tier_mode = mode;
+	uint32_t n_used = 0;
+	for (int c = 0; c < MULLS_NC; c++)
+		n_used += used[c] ? 1u : 0u;
+	const uint32_t s_max = lds_dedup_max_pts();
+	for (int p = 0; p < B->n; p++)
+	{
+		// a pair whose large clouds hold most of its source points (a dense scan pair: two 100 k-point classes next to a few thousand pillar / beam / vertex
+		// points) keeps its small clouds on the global-memory tier too: they ride along in that tier's launch instead of paying for the LDS tier's
+		uint64_t src_small = 0, src_big = 0;
+		for (int c = 0; c < MULLS_NC && mode == 3; c++)
+		{
+			const CloudDesc &d = B->descs_h[(size_t)p * MULLS_NC + c];
+			if (used[c])
+				((d.tgt_n0 <= s_max && d.src_cap <= MULLS_SMALL_SRC_MAX) ? src_small : src_big) += d.src_cap;
+		}
+		const bool all_big = src_big >= 4u * src_small && src_big > 0;
+		uint32_t rank = 0;
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			CloudDesc &d = B->descs_h[(size_t)p * MULLS_NC + c];
+			uint32_t t = (uint32_t)mode;
+			if (mode == 3)
+			{
+				if (used[c])
+					t = (d.tgt_n0 <= s_max && d.src_cap <= MULLS_SMALL_SRC_MAX && !all_big) ? MULLS_TIER_LDS : MULLS_TIER_BM;
+				else
+					t = d.tgt_n0 <= MULLS_LDS_MAXPTS ? MULLS_TIER_LDS : MULLS_TIER_BM;
+			}
+			d.tier = t;
+			d.grid_slot = (uint32_t)p * n_used + rank;
+			if (t == MULLS_TIER_BM)
+			{
+				d.grid_slot = used[c] ? (uint32_t)B->lclouds_h.size() : 0u;
+				if (used[c])
+					B->lclouds_h.push_back((uint32_t)p * MULLS_NC + (uint32_t)c);
+			}
+			rank += used[c] ? 1u : 0u;
+		}
+	}
+}
+
+void build_jobs(mulls_batch *B, const mulls_params *P, int nsub, int mode)
 {
 	std::string key(P->used_feature_type, 6);
 	key += (char)('0' + nsub);
+	key += (char)('a' + mode);
 	if (key == B->jobs_key)
 		return;
+	uint8_t used[MULLS_NC];
+	for (int c = 0; c < MULLS_NC; c++)
+		used[c] = P->used_feature_type[c] == '1';
+	assign_tiers(B, used, mode);
 	B->nsub = nsub;
 	B->jobs_h.clear();
 	for (int p = 0; p < B->n; p++)
@@ -114,22 +174,25 @@ void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 				}
 			d.job_end = (uint32_t)B->jobs_h.size();
 		}
+	// LDS tier: one class-level job per (pair, used class) cloud on it
 	B->cjobs_h.clear();
 	for (int p = 0; p < B->n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
-			if (P->used_feature_type[c] == '1' && B->descs_h[p * MULLS_NC + c].src_cap > 0)
+		{
+			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			if (used[c] && d.src_cap > 0 && d.tier == MULLS_TIER_LDS)
 			{
-				Job j = {(uint32_t)p, (uint32_t)c, 0u, B->descs_h[p * MULLS_NC + c].src_cap};
+				Job j = {(uint32_t)p, (uint32_t)c, 0u, d.src_cap};
 				B->cjobs_h.push_back(j);
 			}
+		}
 	uint32_t max_src_cap = 0;
 	for (const Job &j : B->cjobs_h)
 		max_src_cap = std::max(max_src_cap, j.count);
-	if ((B->cjobs_h.size() < 512 && max_src_cap > 4096u) || max_src_cap > 65534u) // (k_cert's duplicate table holds 16-bit source indices)
+	if (mode == 2 && ((B->cjobs_h.size() < 512 && max_src_cap > 4096u) || max_src_cap > 65534u)) // (k_cert's duplicate table holds 16-bit source indices)
 	{
-		// few AND large class clouds (a pair of dense scans): split them into 512-query jobs (each stages its target cloud itself) so that more than a
-		// handful of workgroups walk them.  Down-sampled class clouds stay whole whatever the batch size: a class-level job resolves the duplicate
-		// rule and the rejection chain itself (no k_filter launch), and a small batch is bound by the number of launches, not by their width
+		// whole batch on the LDS tier (nn_mode 3 / 4), few AND large class clouds (a pair of dense scans): split them into 512-query jobs (each stages its
+		// target cloud itself) so that more than a handful of workgroups walk them.  (Auto mode sends such clouds to the global-memory tier.)
 		B->cjobs_h.clear();
 		for (int p = 0; p < B->n; p++)
 			for (int c = 0; c < MULLS_NC; c++)
@@ -140,6 +203,38 @@ void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 						B->cjobs_h.push_back(j);
 					}
 	}
+	// global-memory tier: a whole source class cloud per job where one workgroup can hold it (mixed batches: a down-sampled scan against a large map —
+	// no k_filter launch for those), 512-point chunks otherwise
+	B->bjobs_h.clear();
+	B->fjobs_h.clear();
+	B->ejobs_h.clear();
+	bool any_class_job = false;
+	for (int p = 0; p < B->n; p++)
+		for (int c = 0; c < MULLS_NC; c++)
+		{
+			const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+			if (!used[c] || d.src_cap == 0 || d.tier != MULLS_TIER_BM)
+				continue;
+			const bool whole = mode == 3 && d.src_cap <= MULLS_BIG_CLASS_MAX;
+			if (whole)
+			{
+				Job j = {(uint32_t)p, (uint32_t)c, 0u, d.src_cap | MULLS_JOB_CLASS};
+				B->bjobs_h.push_back(j);
+				any_class_job = true;
+			}
+			for (uint32_t s = 0; s < d.src_cap; s += MULLS_SRC_PER_BLOCK)
+			{
+				Job j = {(uint32_t)p, (uint32_t)c, s, MULLS_SRC_PER_BLOCK};
+				B->ejobs_h.push_back(j);
+				if (!whole)
+				{
+					B->bjobs_h.push_back(j);
+					B->fjobs_h.push_back(j);
+				}
+			}
+		}
+	if (!any_class_job)
+		B->ejobs_h.clear(); // (the same list as bjobs_h)
 	// device order of the class-level jobs: longest first inside each sub-batch's slice, so that the last round of workgroups
 	// of a launch is made of the cheap class clouds (cost ~ queries x log(targets); ties keep the pair order)
 	B->cjobs_dev_h = B->cjobs_h;
@@ -182,7 +277,7 @@ void build_jobs(mulls_batch *B, const mulls_params *P, int nsub)
 	B->tjobs_h.clear();
 	for (int p = 0; p < B->n; p++)
 		for (int c = 0; c < MULLS_NC; c++)
-			if (P->used_feature_type[c] == '1')
+			if (P->used_feature_type[c] == '1' && B->descs_h[p * MULLS_NC + c].tier == MULLS_TIER_BM)
 				for (uint32_t s = 0; s < B->descs_h[p * MULLS_NC + c].tgt_n0; s += MULLS_BLOCK)
 				{
 					Job j = {(uint32_t)p, (uint32_t)c, s, 0};
@@ -295,8 +390,9 @@ uint32_t lds_cells_for(uint32_t cap)
 	return (uint32_t)std::max<long>(cells, 4096);
 }
 
-// search tier of a run: 0 = LDS-tiled brute force, 1 = uniform grid in global memory, 2 = uniform grid staged in LDS
-int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[MULLS_NC], uint32_t *lds_cap)
+// search tier of a run: 0 = LDS-tiled brute force, 1 = bitmap grid in global memory, 2 = dense grid staged in LDS, 3 = per class cloud (assign_tiers).
+// *lds_cap: the largest target class cloud the LDS tier's kernels will stage
+int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[MULLS_NC], uint32_t *lds_cap, const mulls_params *P_mixed)
 {
 	uint32_t max_t = 0;
 	for (int p = 0; p < B->n; p++)
@@ -315,10 +411,37 @@ int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[M
 	case 4:
 		return fits ? 2 : -1;
 	default:
-		// the LDS tier whenever the clouds fit, whatever the batch size: with class-level jobs and four launches per iteration one KITTI pair takes
-		// 0.84 ms there against 0.94 ms on the global-memory tier (profiles/r03_modes.txt)
-		return fits ? 2 : 1;
+		break;
 	}
+	// auto.  A caller that can run mixed batches gets the tier per class cloud as soon as one cloud is beyond the LDS tier's one-pass walk — unless the
+	// run needs the cropped target copies everywhere (keep-less thinning, the normal-shooting search) or the LDS tier's fused paths are switched off
+	const bool mixed_ok = P_mixed && !P_mixed->keep_less_source_points && !P_mixed->normal_shooting_on && ctx->opt[MULLS_OPT_MIXED_TIERS] != 0.0 &&
+						  ctx->opt[MULLS_OPT_FUSED_TGT_SETUP] != 0.0 && ctx->opt[MULLS_OPT_LDS_DEDUP] != 0.0;
+	if (mixed_ok)
+	{
+		const uint32_t s_max = lds_dedup_max_pts();
+		uint32_t max_small = 0;
+		bool any_big = false;
+		for (int p = 0; p < B->n; p++)
+			for (int c = 0; c < MULLS_NC; c++)
+			{
+				const CloudDesc &d = B->descs_h[p * MULLS_NC + c];
+				if (!used[c] || d.src_cap == 0)
+					continue;
+				if (d.tgt_n0 <= s_max && d.src_cap <= MULLS_SMALL_SRC_MAX)
+					max_small = std::max(max_small, d.tgt_n0);
+				else
+					any_big = true;
+			}
+		if (any_big)
+		{
+			*lds_cap = std::max(8u, (max_small + 7u) & ~7u);
+			return 3;
+		}
+	}
+	// the LDS tier whenever the clouds fit, whatever the batch size: with class-level jobs and four launches per iteration one KITTI pair takes
+	// 0.84 ms there against 0.94 ms on the global-memory tier (profiles/r03_modes.txt)
+	return fits ? 2 : 1;
 }
 
 // float4 units a staged cloud of n points takes (device_types.h: MULLS_STAGE_*)
@@ -343,6 +466,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	B->setup_jobs_h.clear();
 	B->big_segs_h.clear();
 	B->big_clouds_h.clear();
+	B->n_big_tgt = 0;
 	B->jobs_key.clear(); // the job table depends on the layout
 	B->dev_key.clear();
 	size_t stage_rec = 0, so = 0, to = 0; // stage_rec: float4 units
@@ -393,6 +517,15 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 				for (uint32_t k = 0; k < t.n; k += MULLS_SEG)
 					B->big_segs_h.push_back({(uint32_t)p, (uint32_t)c, k, slot});
 				B->big_clouds_h.push_back({(uint32_t)p, (uint32_t)c, first, (uint32_t)B->big_segs_h.size() - first});
+				B->n_big_tgt++;
+			}
+			if (d.src_cap > MULLS_BIG_CLOUD)
+			{
+				const uint32_t slot = (uint32_t)B->big_clouds_h.size(), first = (uint32_t)B->big_segs_h.size();
+				d.src_big_slot = slot + 1u;
+				for (uint32_t k = 0; k < d.src_cap; k += MULLS_SEG)
+					B->big_segs_h.push_back({(uint32_t)p, (uint32_t)c | MULLS_BIG_SRC_SIDE, k, slot});
+				B->big_clouds_h.push_back({(uint32_t)p, (uint32_t)c | MULLS_BIG_SRC_SIDE, first, (uint32_t)B->big_segs_h.size() - first});
 			}
 			for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
 			{
@@ -597,48 +730,53 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 // used classes, so they are uploaded once (pinned copies would not help: they are simply not re-sent) and every run
 // restores the mutable descriptors / box keys with device-to-device copies — no pageable H2D traffic per run.
 // nsub: sub-batches the lock-step job tables are laid out for (0 = subbatch_count)
-int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out, int nsub)
+int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out, int nsub, bool allow_mixed)
 {
 	hipStream_t st = ctx->stream;
 	const int n = B->n;
-	const std::string old_key = B->jobs_key;
-	build_jobs(B, P_jobs, nsub > 0 ? nsub : subbatch_count(ctx, n));
 	uint32_t lds_cap = 0;
-	const int tier = choose_tier(ctx, B, rp.used, &lds_cap);
+	const int tier = choose_tier(ctx, B, rp.used, &lds_cap, allow_mixed ? P_jobs : nullptr);
 	if (tier < 0)
 	{
 		ctx->err = "nn mode 3 (grid staged in LDS) needs every searched target class cloud to hold <= 9728 points";
 		return MULLS_E_INVALID;
 	}
+	build_jobs(B, P_jobs, nsub > 0 ? nsub : subbatch_count(ctx, n), tier);
 	*lds_cap_out = lds_cap;
 	*tier_out = tier;
 	int n_used = 0;
 	for (int c = 0; c < MULLS_NC; c++)
 		n_used += rp.used[c];
 	rp.bm_h0 = 0.0f;
+	rp.bm_maxwords = rp.bm_stride = 0u;
 	rp.grid_h0 = ctx->opt[MULLS_OPT_GRID_H0] > 0.0 ? std::max(0.05f, (float)ctx->opt[MULLS_OPT_GRID_H0]) : MULLS_GRID_H0;
 	rp.lds_dedup = 0;
+	rp.grid_maxcells = MULLS_MAXCELLS;
+	rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
 	bool resident = false;
-	if (tier == 2)
+	if (tier == 2 || tier == 3)
 	{
 		rp.grid_maxcells = lds_cells_for(lds_cap);
 		// class-level jobs (one workgroup sees every query of a class cloud): keep the duplicate table in LDS if 4 B per target
 		// still leave a useful cell budget next to the staged cloud (MULLS_ICP_STATIC_LDS bytes stay free for the static LDS of k_icp)
-		const bool class_level = !B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK;
+		const bool class_level = tier == 3 || (!B->cjobs_h.empty() && B->cjobs_h[0].count != MULLS_SRC_PER_BLOCK);
 		const long left = 160L * 1024L - 64L - (long)MULLS_ICP_STATIC_LDS - (long)MULLS_LDS_QCHUNK * 16L - (long)MULLS_LDS_AUX - (long)lds_cap * 18L;
 		const bool dedup_fits = !rp.normal_shooting && left / 2 - 8 >= 4096 && ctx->opt[MULLS_OPT_LDS_DEDUP] != 0.0; // k_nn_shoot uses the global table
-		// Device-resident loop (k_icp: one workgroup carries a pair through all its iterations): the default whenever the LDS tier
-		// applies with its on-chip duplicate table, the loop is the plain mm_lls_icp one (resident_out) and no source class cloud is
-		// so large that one workgroup per pair would be the wrong shape (those pairs are spread over many workgroups by the
-		// lock-step path).  In auto mode it runs batches of MULLS_RESIDENT_MIN_PAIRS .. MAX_PAIRS pairs, where it is the faster of the two
-		// (measured, tools/gpu_modes.py, profiles/r02_zzz_modes.txt: 73 k vs 67 k registrations/s at 128 pairs; the lock-step path, whose
-		// light kernels run several workgroups per CU and whose per-iteration step runs on the device too, wins from 512 pairs on — 151 k vs
-		// 142 k, 174 k vs 146 k at 1024 — and the two tie below ~40).  nn_mode 3 keeps the lock-step LDS tier; nn_mode 4 asks for the
-		// resident loop (and gets the lock-step LDS tier where the loop does not apply).
+		if (tier == 3 && !dedup_fits)
+		{
+			ctx->err = "internal: a mixed batch whose LDS-tier clouds do not fit the on-chip duplicate table";
+			return MULLS_E_INVALID;
+		}
+		// Device-resident loop (k_icp: one workgroup carries a pair through all its iterations): only on request (nn_mode 4) since round 3 — the lock-step
+		// path, whose light kernels run several workgroups per CU and whose per-iteration step runs on the device too, is at least as fast at every
+		// batch size (profiles/r03_modes.txt); MULLS_OPT_RESIDENT_MIN_PAIRS .. _MAX_PAIRS can still open a window for it in auto mode.  It needs the
+		// on-chip duplicate table, the plain mm_lls_icp loop (resident_out) and no source class cloud so large that one workgroup per pair would be the
+		// wrong shape; nn_mode 4 gets the lock-step LDS tier where the loop does not apply.
 		uint32_t max_src = 0;
 		for (const Job &j : B->rjobs_h)
 			max_src = std::max(max_src, j.count);
-		resident = resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 && (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && n >= (int)ctx->opt[MULLS_OPT_RESIDENT_MIN_PAIRS] && n <= (int)ctx->opt[MULLS_OPT_RESIDENT_MAX_PAIRS]));
+		resident = tier == 2 && resident_out && dedup_fits && max_src <= 16384u && P_jobs->max_iter_num > 0 &&
+				   (ctx->nn_mode == 4 || (ctx->nn_mode == 0 && n >= (int)ctx->opt[MULLS_OPT_RESIDENT_MIN_PAIRS] && n <= (int)ctx->opt[MULLS_OPT_RESIDENT_MAX_PAIRS]));
 		if ((class_level || resident) && dedup_fits)
 		{
 			rp.lds_dedup = 1;
@@ -646,9 +784,10 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		}
 		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
 	}
-	else if (tier == 1)
+	const size_t nl = B->lclouds_h.size();
+	if (nl)
 	{
-		// occupancy-bitmap grids: grid_maxcells / cell_stride count 64-cell words per cloud
+		// occupancy-bitmap grids: bm_maxwords / bm_stride count 64-cell words per cloud
 		rp.bm_h0 = MULLS_BM_H0;
 		rp.bm_auto = 1;
 		if (ctx->opt[MULLS_OPT_BM_H0] > 0.0) // diagnostics: one fixed cell edge for every cloud
@@ -656,16 +795,9 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 			rp.bm_h0 = std::max(0.05f, (float)ctx->opt[MULLS_OPT_BM_H0]);
 			rp.bm_auto = 0;
 		}
-		const size_t clouds = std::max<size_t>((size_t)n * std::max(n_used, 1), 1);
-		size_t words = std::min<size_t>(MULLS_BM_MAXWORDS, MULLS_BM_TOTALWORDS / clouds);
+		size_t words = std::min<size_t>(MULLS_BM_MAXWORDS, MULLS_BM_TOTALWORDS / nl);
 		words = std::max<size_t>(words & ~(size_t)15, 4096);
-		rp.grid_maxcells = (uint32_t)words;
-		rp.cell_stride = (uint32_t)words;
-	}
-	else
-	{
-		rp.grid_maxcells = MULLS_MAXCELLS;
-		rp.cell_stride = ((rp.grid_maxcells + 1u + 15u) & ~15u);
+		rp.bm_maxwords = rp.bm_stride = (uint32_t)words;
 	}
 
 	if (resident_out)
@@ -680,6 +812,14 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	A(grow(ctx, &B->tjobs, &B->cap_jobs[2], B->tjobs_h.size(), &g2));
 	grew |= g2;
 	A(grow(ctx, &B->cjobs, &B->cap_jobs[3], B->cjobs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->bjobs, &B->cap_bjobs[0], B->bjobs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->fjobs, &B->cap_bjobs[1], B->fjobs_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->lclouds, &B->cap_bjobs[2], B->lclouds_h.size(), &g2));
+	grew |= g2;
+	A(grow(ctx, &B->ejobs, &B->cap_bjobs[3], B->ejobs_h.size(), &g2));
 	grew |= g2;
 	A(grow(ctx, &B->wl, &B->cap_wl, B->cjobs_h.size()));
 	A(grow(ctx, &B->ajobs, &B->cap_ajobs, B->ajobs_h.size(), &g2));
@@ -706,14 +846,14 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	grew |= g2;
 	A(grow(ctx, &B->bbox_init, &B->cap_jobs[5], (size_t)n * 6, &g2));
 	grew |= g2;
-	if (tier == 2)
+	if (tier == 2 || tier == 3)
 		A(grow(ctx, &B->cell_start, &B->cap_cells[1], (size_t)n * n_used * rp.cell_stride));
-	else if (tier == 1)
+	if (nl)
 	{
-		const size_t words = (size_t)n * n_used * rp.cell_stride, cells = B->n_tgt + (size_t)n * MULLS_NC + 1;
+		const size_t words = nl * (size_t)rp.bm_stride, cells = B->n_tgt + (size_t)n * MULLS_NC + 1;
 		A(grow(ctx, &B->bm, &B->cap_bm, words));
 		A(grow(ctx, &B->pf, &B->cap_pf, words));
-		A(grow(ctx, &B->cell_start, &B->cap_cells[1], cells));
+		A(grow(ctx, &B->bm_cs, &B->cap_bm_cs, cells));
 		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
 		if (rc == MULLS_OK)
 		{
@@ -728,6 +868,14 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size(), hipMemcpyHostToDevice, st));
+		if (!B->bjobs_h.empty())
+			HIPCHK(ctx, hipMemcpyAsync(B->bjobs, B->bjobs_h.data(), sizeof(Job) * B->bjobs_h.size(), hipMemcpyHostToDevice, st));
+		if (!B->fjobs_h.empty())
+			HIPCHK(ctx, hipMemcpyAsync(B->fjobs, B->fjobs_h.data(), sizeof(Job) * B->fjobs_h.size(), hipMemcpyHostToDevice, st));
+		if (!B->ejobs_h.empty())
+			HIPCHK(ctx, hipMemcpyAsync(B->ejobs, B->ejobs_h.data(), sizeof(Job) * B->ejobs_h.size(), hipMemcpyHostToDevice, st));
+		if (!B->lclouds_h.empty())
+			HIPCHK(ctx, hipMemcpyAsync(B->lclouds, B->lclouds_h.data(), sizeof(uint32_t) * B->lclouds_h.size(), hipMemcpyHostToDevice, st));
 		HIPCHK(ctx, hipMemcpyAsync(B->ajobs, B->ajobs_h.data(), sizeof(uint32_t) * B->ajobs_h.size(), hipMemcpyHostToDevice, st));
 		if (resident)
 		{
@@ -742,7 +890,6 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	}
 	HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_init, sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyDeviceToDevice, st));
 	HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_init, sizeof(uint32_t) * 6 * n, hipMemcpyDeviceToDevice, st));
-	(void)old_key;
 	return MULLS_OK;
 }
 

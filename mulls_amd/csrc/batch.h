@@ -27,11 +27,18 @@ struct mulls_batch
 	std::vector<CloudDesc> descs_h;
 	std::vector<PairSetup> setup_h;
 	std::vector<Job> setup_jobs_h;
-	std::vector<Job> big_segs_h, big_clouds_h; // target class clouds cropped segment-wise (k_crop_big_*): segments, clouds
+	std::vector<Job> big_segs_h, big_clouds_h; // class clouds cropped segment-wise (k_crop_big_*): segments, clouds (Job::cls carries MULLS_BIG_SRC_SIDE for a source cloud)
+	uint32_t n_big_tgt = 0;					   // ... how many of those clouds are targets
 	std::vector<Job> jobs_h;
 	std::vector<Job> cjobs_h; // one entry per (pair, used class) with source points: the LDS tier's unit of work
 	std::vector<Job> cjobs_dev_h; // the same entries as uploaded: inside each sub-batch's slice the most expensive class clouds come first
-	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the used classes, for the grid build
+	std::vector<Job> bjobs_h; // global-memory tier (k_cert_big): class-level jobs (MULLS_JOB_CLASS) and 512-point chunk-level jobs of the MULLS_TIER_BM clouds, pair order
+	std::vector<Job> fjobs_h; // ... the chunk-level ones among them: k_filter finishes those clouds
+	std::vector<Job> ejobs_h; // ... and every MULLS_TIER_BM cloud as chunk-level jobs, for the first iterations of a mixed batch (empty when bjobs_h holds no class-level job):
+							  // while most points still need a search, many (splittable) workgroups per cloud + k_filter beat one workgroup per cloud
+	std::vector<uint32_t> lclouds_h; // the used class clouds on a bitmap grid (pair * MULLS_NC + class), in grid_slot order
+	int tier_mode = -1;		  // what the descriptors' tier fields were assigned for: 0 / 1 / 2 one tier for the whole batch, 3 per class cloud (assign_tiers)
+	std::vector<Job> tjobs_h; // target-side chunks (256 points) of the bitmap-grid clouds, for the grid build
 	std::vector<uint32_t> ajobs_h; // jobs that start a trip of 1024 source slots: k_accum's workgroups (indices into jobs_h) — per sub-batch slice,
 								   // and inside a slice grouped by trip length (ajob_split)
 	uint32_t ajob_split[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; // [sub-batch][0..3]: the slice's trips of > 512, 257..512, <= 256 slots
@@ -68,6 +75,11 @@ struct mulls_batch
 	double *partial = nullptr;
 	Job *tjobs = nullptr;
 	Job *cjobs = nullptr;
+	Job *bjobs = nullptr, *fjobs = nullptr, *ejobs = nullptr;
+	uint32_t *lclouds = nullptr;
+	size_t cap_bjobs[4] = {};
+	uint32_t *bm_cs = nullptr; // bitmap grids: first sorted position of every occupied cell (indexed like cell_cnt)
+	size_t cap_bm_cs = 0;
 	Job *rjobs = nullptr;
 	uint32_t *ajobs = nullptr;
 	size_t cap_ajobs = 0;
@@ -88,7 +100,7 @@ struct mulls_batch
 	float4 *tsorted = nullptr;
 	unsigned long long *dbg = nullptr; // diagnostics (MULLS_OPT_DEBUG_STOP = 20): RunParams::dbg_ticks
 	uint16_t *tmap = nullptr; // LDS tier without a cropped copy of the target clouds (k_tgt_grid): rank in the cropped cloud -> staged index
-	uint32_t *cell_cnt = nullptr, *cell_start = nullptr; // global tier: per-occupied-cell counters / start positions; LDS tier: dense cell table
+	uint32_t *cell_cnt = nullptr, *cell_start = nullptr; // bitmap grids: per-occupied-cell counters (start positions: bm_cs); LDS tier: dense cell tables
 	unsigned long long *bm = nullptr;					  // global tier: occupancy words of every grid
 	uint32_t *pf = nullptr;								  // global tier: occupied cells before each word
 	size_t cap_bm = 0, cap_pf = 0;
@@ -139,17 +151,21 @@ int check_params(mulls_ctx *ctx, const mulls_params *P);
 void init_cert(const mulls_ctx *ctx, RunParams &rp);
 int subbatch_count(const mulls_ctx *ctx, int n);
 void options_init(mulls_ctx *ctx);
-void build_jobs(mulls_batch *B, const mulls_params *P, int nsub);
+uint32_t lds_dedup_max_pts();
+void assign_tiers(mulls_batch *B, const uint8_t used[MULLS_NC], int mode);
+void build_jobs(mulls_batch *B, const mulls_params *P, int nsub, int mode);
 // `last`: while profiling, the event recorded behind the k_finish that publishes `want` — waiting on it (instead of the whole stream) leaves the
 // other sub-batch's kernels running
 int wait_epoch_word(mulls_ctx *ctx, volatile uint32_t *word, uint32_t want, hipEvent_t last = nullptr, hipStream_t stream = nullptr);
 inline int wait_epoch(mulls_ctx *ctx, mulls_batch *B) { return wait_epoch_word(ctx, B->epoch_h, B->epoch); }
 void unpack_out(const mulls_batch *B, const uint8_t used[MULLS_NC], int p, PairOut &o, bool comb = false);
 uint32_t lds_cells_for(uint32_t cap);
-int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[MULLS_NC], uint32_t *lds_cap);
+// P_mixed: the caller can run a batch whose class clouds are on different tiers (mulls_batch_run): auto mode may answer 3
+int choose_tier(const mulls_ctx *ctx, const mulls_batch *B, const uint8_t used[MULLS_NC], uint32_t *lds_cap, const mulls_params *P_mixed = nullptr);
 int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, const mulls_params *P = nullptr);
 // nsub: sub-batches the lock-step job tables are laid out for (0 = subbatch_count)
-int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr, int nsub = 0);
+int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr, int nsub = 0,
+				bool allow_mixed = false);
 mulls::IcpConst icp_const(const mulls_params *P);
 int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, uint32_t *base);
 

@@ -35,9 +35,8 @@ __device__ __forceinline__ uint32_t grid_dim(float extent, float inv_h)
 	const float c = floorf(extent * inv_h);
 	return c >= 0.0f ? (uint32_t)fminf(c, 4.0e9f) + 1u : 1u; // also false for NaN
 }
-// grid descriptor of a cropped target cloud with bounding box [lo3, hi3] and `running` points
-__device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi3[3], uint32_t running, const RunParams &rp, uint32_t pair,
-											   uint32_t cls)
+// grid descriptor of a cropped target cloud with bounding box [lo3, hi3] and `running` points, of the kind its tier asks for (CloudDesc::tier)
+__device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi3[3], uint32_t running, const RunParams &rp, const CloudDesc &d, uint32_t cls)
 {
 	GridDesc g;
 	g.ox = lo3[0], g.oy = lo3[1], g.oz = lo3[2];
@@ -47,7 +46,10 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 	g.wpr = 1;
 	g.nocc = 0;
 	uint32_t nwords = 1;
-	if (running > 0 && rp.bm_h0 > 0.0f)
+	const bool bitmap = d.tier == MULLS_TIER_BM;
+	if (!rp.used[cls])
+		running = 0; // a class the run does not search gets no grid (its cloud is cropped for the sizes the reference reports)
+	if (running > 0 && bitmap)
 	{
 		// global-memory tier: occupancy bitmap over fine cells; rows are padded to whole 64-cell words
 		g.h = rp.bm_h0;
@@ -60,7 +62,7 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
 			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
 			g.wpr = (g.nx + 63u) >> 6;
-			if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.grid_maxcells)
+			if ((unsigned long long)g.ny * g.nz * g.wpr <= (unsigned long long)rp.bm_maxwords || g.ny * g.nz * g.wpr <= 1u)
 				break;
 			g.h *= 1.25f;
 		}
@@ -74,23 +76,15 @@ __device__ __forceinline__ GridDesc make_grid(const float lo3[3], const float hi
 			g.nx = grid_dim(hi3[0] - g.ox, g.inv_h);
 			g.ny = grid_dim(hi3[1] - g.oy, g.inv_h);
 			g.nz = grid_dim(hi3[2] - g.oz, g.inv_h);
-			if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells)
+			if ((unsigned long long)g.nx * g.ny * g.nz <= (unsigned long long)rp.grid_maxcells || g.nx * g.ny * g.nz <= 1u)
 				break;
 			g.h *= 1.25f;
 		}
 	else
 		g.inv_h = 1.0f;
-	// cell tables are laid out over the USED classes only: slot = pair * n_used + rank of this class among them
-	uint32_t n_used = 0, rank = 0;
-	for (uint32_t c = 0; c < MULLS_NC; c++)
-	{
-		if (c < cls && rp.used[c])
-			rank++;
-		n_used += rp.used[c] ? 1u : 0u;
-	}
-	g.ncell = (running > 0 && rp.used[cls]) ? (rp.bm_h0 > 0.0f ? nwords : g.nx * g.ny * g.nz) : 0u;
-	g.cell_off = (pair * n_used + rank) * (rp.cell_stride);
+	// cell tables exist for the USED classes only; the host handed out their slots (assign_tiers)
+	g.ncell = running > 0 ? (bitmap ? nwords : g.nx * g.ny * g.nz) : 0u;
+	g.cell_off = d.grid_slot * (bitmap ? rp.bm_stride : rp.cell_stride);
 	return g;
 }
 } // namespace
-

@@ -26,9 +26,19 @@
 #define MULLS_CERT_SMALL_LOCKSTEP 512u // ... k_cert up to this many (four workgroups per CU hide the walks' latency: 64 -> 512 took 1.5 ms off a 4096-pair step, profiles/r03_sweeps.txt)
 #define MULLS_ICP_STATIC_LDS 9216 // LDS the device-resident loop keeps next to the dynamic block (pair state, class rows, ...; checked at its first launch)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
-#define MULLS_BIG_CLOUD 65536u // target class clouds above this size are cropped segment-wise (k_crop_big_*)
+#define MULLS_BIG_CLOUD 16384u // class clouds above this size (target or source) are cropped segment-wise (k_crop_big_*): one workgroup walking a 100 k-point
+							   // cloud alone took 290 us (profiles/r04_large_base.txt)
+#define MULLS_BIG_SRC_SIDE 0x100u // Job::cls flag in the segment tables: the segment belongs to the pair's SOURCE cloud of that class
 #define MULLS_SEG 4096u		  // ... in segments of this many points
 #define MULLS_GRID_GROUP 16u   // lanes that cooperate on one query in the grid search tier
+#define MULLS_BIG_BLOCK 512	   // k_cert_big: lanes per job of the global-memory tier (big_tier.h)
+#define MULLS_BIG_CLASS_MAX (3u * MULLS_BIG_BLOCK) // ... and the largest source class cloud one workgroup takes whole (class-level job: three points per lane)
+#define MULLS_JOB_CLASS 0x80000000u // Job::count flag of the global-memory tier: the job is a whole source class cloud (the workgroup runs the rejection chain itself)
+#define MULLS_SMALL_SRC_MAX 4096u  // auto mode: source class clouds above this size go to the global-memory tier's chunk-level jobs whatever their target's size
+// search tier of one (pair, class) cloud pair: CloudDesc::tier
+#define MULLS_TIER_BRUTE 0u // LDS-tiled brute force (k_nn)
+#define MULLS_TIER_BM 1u	// occupancy-bitmap grid in global memory (k_cert_big)
+#define MULLS_TIER_LDS 2u	// dense grid, target cloud staged in LDS (k_cert / k_nn_lds)
 #define MULLS_GRID_H0 1.3f	   // preferred cell edge in metres (measured optimum on the bench workload, profiles/r03_sweeps.txt); grows until the cloud's box fits the cell budget
 
 // bits of the per-source-point flag byte
@@ -58,8 +68,12 @@ struct CloudDesc
 	uint32_t sd_n0;
 	uint32_t src_cap; // slots reserved for this source cloud in the working arenas = max(src_n0, sd_n0)
 	uint32_t big_slot; // target clouds beyond MULLS_BIG_CLOUD points are cropped by many workgroups: 1-based slot, 0 = small
+	uint32_t src_big_slot; // ... and source clouds (0 = small)
 	uint32_t n_search; // LDS tier: queries of this class cloud that went through the grid search in the last iteration (the others were certified)
 	uint32_t stage_fmt; // staged layout of the source (bits 0-1), target (2-3) and src_down (4-5) clouds: MULLS_STAGE_*
+	uint32_t tier;		// search tier of this cloud pair (MULLS_TIER_*), assigned per run by the host (assign_tiers): decides which setup kernels build its target
+						// grid and which search kernel's job table holds it
+	uint32_t grid_slot; // its slot in that tier's cell tables (LDS tier: x RunParams::cell_stride entries; bitmap tier: x RunParams::bm_stride words)
 };
 // staged layouts of one cloud of n points (load_staged, device_util.h)
 #define MULLS_STAGE_AOS48 0u  // n x 3 float4: the caller's 48-byte PointXYZINormal records (device-resident map clouds, copied device to device)
@@ -153,7 +167,7 @@ struct RunParams
 	float z_xy_ratio;
 	float win_pt, win_pl, win_li;
 	uint8_t force_class_w; // stage-level API: take class_w_value instead of the balance rule
-	uint8_t bm_auto; // global-memory tier: cell edge = clamp(sqrt(dx * dy / n), bm_h0, 2.8 * bm_h0) per cloud instead of bm_h0
+	uint8_t bm_auto; // bitmap grids: cell edge = clamp(sqrt(dx * dy / n), bm_h0, 2.8 * bm_h0) per cloud instead of bm_h0
 	float class_w_value;
 	double cos_bearing; // cos(normal_bearing / 180.0 * M_PI) in double, computed on the host
 	int32_t resid_from_iter; // residual weighting applies when iter_num > this (2 for mm_lls_icp, cregistration.hpp:1905-1907; -1 for the 3-DoF variant)
@@ -161,7 +175,9 @@ struct RunParams
 	uint32_t cell_stride;	// entries reserved per cloud in the cell tables (multiple of 4: uint4-aligned), >= grid_maxcells + 1
 	uint32_t grid_maxcells; // cell budget of the target grids built by k_crop (MULLS_MAXCELLS, or what fits in LDS for the LDS tier)
 	float grid_h0;		// LDS tier: preferred cell edge (MULLS_GRID_H0; grows until the cloud's box fits grid_maxcells)
-	float bm_h0;		// > 0: global-memory tier — k_crop sizes occupancy-bitmap grids from this cell edge (grid_maxcells = word budget)
+	float bm_h0;		// bitmap grids (MULLS_TIER_BM clouds): smallest cell edge ...
+	uint32_t bm_maxwords; // ... most 64-cell occupancy words of one grid ...
+	uint32_t bm_stride;	  // ... and the words reserved per grid slot in the bitmap / rank arrays
 	uint32_t pull_comb;	// mm_lls_icp loop: k_finish combines the class rows (normal matrix + rhs, or VTPV + count) and k_pull_outs sends that one row
 	uint32_t lds_dedup;	// LDS tier with class-level jobs: the duplicate rule is resolved inside k_nn_lds (winner table in LDS), losers get nn_idx = -1
 	uint32_t tick_base; // duplicate-table epoch of iteration 0 of this run (see k_nn)

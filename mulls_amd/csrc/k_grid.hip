@@ -4,11 +4,10 @@
 #include "crop_grid.h"
 
 // only the words a cloud's grid really uses are cleared (the arena reserves the worst case per cloud)
-__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const GridDesc *__restrict__ grids, RunParams rp, unsigned long long *__restrict__ bm)
+// (lclouds: the used class clouds on a bitmap grid, pair * MULLS_NC + class each)
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const uint32_t *__restrict__ lclouds, const GridDesc *__restrict__ grids, unsigned long long *__restrict__ bm)
 {
-	if (!rp.used[blockIdx.x % MULLS_NC])
-		return;
-	const GridDesc g = grids[blockIdx.x];
+	const GridDesc g = grids[lclouds[blockIdx.x]];
 	for (uint32_t w = blockIdx.y * MULLS_BLOCK + threadIdx.x; w < g.ncell; w += gridDim.y * MULLS_BLOCK)
 		bm[g.cell_off + w] = 0ull;
 }
@@ -31,19 +30,17 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__
 		atomicOr(word, b);
 }
 
-__global__ __launch_bounds__(1024) void k_bm_scan(GridDesc *__restrict__ grids, RunParams rp, const unsigned long long *__restrict__ bm,
+__global__ __launch_bounds__(1024) void k_bm_scan(const uint32_t *__restrict__ lclouds, GridDesc *__restrict__ grids, const unsigned long long *__restrict__ bm,
 												  uint32_t *__restrict__ pf)
 {
-	const uint32_t cls = blockIdx.x % MULLS_NC;
-	if (!rp.used[cls])
-		return;
-	const GridDesc g = grids[blockIdx.x];
+	const uint32_t ci = lclouds[blockIdx.x];
+	const GridDesc g = grids[ci];
 	const unsigned long long *b = bm + g.cell_off;
 	uint32_t *p = pf + g.cell_off;
 	const uint32_t nocc = block_scan_1024(
 		g.ncell, [&](uint32_t w) { return (uint32_t)__popcll(b[w]); }, [&](uint32_t w, uint32_t ex) { p[w] = ex; });
 	if (threadIdx.x == 0)
-		grids[blockIdx.x].nocc = nocc;
+		grids[ci].nocc = nocc;
 }
 
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
@@ -63,14 +60,12 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict_
 }
 
 // counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors
-__global__ __launch_bounds__(1024) void k_bm_starts(const CloudDesc *__restrict__ descs, const GridDesc *__restrict__ grids, RunParams rp,
+__global__ __launch_bounds__(1024) void k_bm_starts(const uint32_t *__restrict__ lclouds, const CloudDesc *__restrict__ descs, const GridDesc *__restrict__ grids,
 													uint32_t *__restrict__ cnt, uint32_t *__restrict__ cs)
 {
-	const uint32_t cls = blockIdx.x % MULLS_NC;
-	if (!rp.used[cls])
-		return;
-	const GridDesc g = grids[blockIdx.x];
-	const uint32_t off = descs[blockIdx.x].tgt_off + blockIdx.x;
+	const uint32_t ci = lclouds[blockIdx.x];
+	const GridDesc g = grids[ci];
+	const uint32_t off = descs[ci].tgt_off + ci;
 	uint32_t *c = cnt + off, *s = cs + off;
 	const uint32_t total = block_scan_1024(
 		g.nocc, [&](uint32_t r) { return c[r]; },
@@ -119,7 +114,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_grid_build_sort(const Cloud
 	const CloudDesc &d = descs[blockIdx.x];
 	const GridDesc g = grids[blockIdx.x];
 	const uint32_t n = d.tgt_n;
-	if (g.ncell == 0)
+	if (g.ncell == 0 || d.tier != MULLS_TIER_LDS)
 		return;
 	if (g.ncell < 16384u)
 	{
@@ -247,6 +242,8 @@ __global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__res
 	__shared__ GridDesc g_sh;
 	const uint32_t pair = blockIdx.x / MULLS_NC, cls = blockIdx.x % MULLS_NC;
 	CloudDesc &d = descs[blockIdx.x];
+	if (d.tier != MULLS_TIER_LDS)
+		return; // a cloud of another tier (mixed batch): k_crop writes its cropped copy, the bitmap kernels build its grid
 	const uint32_t n0 = d.tgt_n0, fmt = (d.stage_fmt >> 2) & 3u;
 	const bool used = rp.used[cls] != 0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__res
 		if (threadIdx.x == 0)                                          \
 		{                                                              \
 			const float inf3[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, ninf3[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()}; \
-			grids[blockIdx.x] = make_grid(inf3, ninf3, 0u, rp, pair, cls); \
+			grids[blockIdx.x] = make_grid(inf3, ninf3, 0u, rp, d, cls); \
 			d.tgt_n = 0u;                                              \
 		}                                                              \
 		return;                                                        \
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__res
 			for (int w = 1; w < MULLS_TG_LANES / 64; w++)
 				lo3[k] = fminf(lo3[k], box_red[w][k]), hi3[k] = fmaxf(hi3[k], box_red[w][3 + k]);
 		}
-		const GridDesc gd = make_grid(lo3, hi3, n, rp, pair, cls);
+		const GridDesc gd = make_grid(lo3, hi3, n, rp, d, cls);
 		grids[blockIdx.x] = gd;
 		g_sh = gd;
 		d.tgt_n = n;
@@ -493,24 +490,30 @@ __global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__res
 #include "launch.h"
 #include <algorithm>
 
-void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
-					   const RunParams &rp, const float4 *tpos, unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cell_start,
-					   float4 *tsorted, bool lds_tier)
+// LDS tier without the fused setup: one workgroup per cropped target class cloud (k_crop wrote the copies)
+void launch_grid_build_sort(hipStream_t st, uint32_t npairs, const CloudDesc *descs, GridDesc *grids, const RunParams &rp, const float4 *tpos, uint32_t *cell_start,
+							float4 *tsorted)
 {
-	if (!ntjobs || !npairs)
-		return;
-	if (lds_tier)
-	{
+	if (npairs)
 		hipLaunchKernelGGL(k_grid_build_sort, dim3(npairs * MULLS_NC), dim3(MULLS_LDS_BLOCK), 0, st, descs, grids, rp, tpos, cell_start, tsorted);
+}
+
+// global-memory tier: occupancy bitmap + ranks + counting sort by rank (cs holds the start positions) of the `nl` class clouds lclouds[]; tjobs = their
+// 256-point chunks
+void launch_bm_build(hipStream_t st, uint32_t nl, const uint32_t *lclouds, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids, const float4 *tpos,
+					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted)
+{
+	if (!nl)
 		return;
-	}
-	// global-memory tier: occupancy bitmap + ranks + counting sort by rank (cell_start holds the start positions)
-	hipLaunchKernelGGL(k_bm_clear, dim3(npairs * MULLS_NC, npairs >= 64 ? 4 : 64), dim3(MULLS_BLOCK), 0, st, grids, rp, bm);
-	hipLaunchKernelGGL(k_bm_mark, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm);
-	hipLaunchKernelGGL(k_bm_scan, dim3(npairs * MULLS_NC), dim3(1024), 0, st, grids, rp, bm, pf);
-	hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
-	hipLaunchKernelGGL(k_bm_starts, dim3(npairs * MULLS_NC), dim3(1024), 0, st, descs, grids, rp, cnt, cell_start);
-	hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cell_start, tsorted);
+	hipLaunchKernelGGL(k_bm_clear, dim3(nl, nl >= 64 ? 4 : 64), dim3(MULLS_BLOCK), 0, st, lclouds, grids, bm);
+	if (ntjobs)
+		hipLaunchKernelGGL(k_bm_mark, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm);
+	hipLaunchKernelGGL(k_bm_scan, dim3(nl), dim3(1024), 0, st, lclouds, grids, bm, pf);
+	if (ntjobs)
+		hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
+	hipLaunchKernelGGL(k_bm_starts, dim3(nl), dim3(1024), 0, st, lclouds, descs, grids, cnt, cs);
+	if (ntjobs)
+		hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cs, tsorted);
 }
 
 int launch_tgt_grid(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage, const RunParams &rp,

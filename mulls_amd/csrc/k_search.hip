@@ -2,6 +2,7 @@
 // (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
 #include "device_util.h"
 #include "lds_tier.h"
+#include "big_tier.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Correspondence search.  A workgroup is 2 wave64 (MULLS_NN_BLOCK = 128 lanes); each lane owns MULLS_NN_PTS = 4
@@ -155,193 +156,58 @@ __global__ __launch_bounds__(MULLS_NN_BLOCK) void k_nn(const Job *__restrict__ j
 		atomicAdd(&d.n_matched, matched_cnt);
 }
 
-// Correspondence search, global-memory grid tier (target class clouds too large for LDS).  Phase 1: the workgroup applies
-// this iteration's rigid step to its slice of a 512-point job (coalesced 16-B traffic, double math once per point) and
-// parks the transformed positions in LDS, together with the distance to the target the point found in the previous iteration
-// (an exact upper bound, as in k_nn_lds).  Phase 2: a 16-lane sub-group owns one query at a time: the cube of that bound —
-// or, without one, the own cell and then the cube of min(cell edge, distance found) —, then — while nothing lies inside the probed radius — one last cube of the distance
-// found, or cubes of twice the radius up to the rejection radius; rows are swept 16 at a time with coalesced candidate
-// loads, 4 xor-shuffles reduce (distance, index).  `split` workgroups share one job (batches with few jobs would leave
-// most CUs idle otherwise).  Outputs are identical to k_nn.
-__global__ __launch_bounds__(MULLS_BLOCK) void k_nn_grid(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
-														  const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
-														  float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
-														  const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
-														  const uint32_t *__restrict__ cs, const float4 *__restrict__ tsorted,
-														  const uint8_t *__restrict__ flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
-														  unsigned long long *__restrict__ winner, uint32_t split, const float4 *__restrict__ tpos,
-														  int32_t *__restrict__ nn_hint, const int32_t *__restrict__ match, const float4 *__restrict__ mq)
+// Correspondence search, global-memory tier (big_tier.h): rigid step + certificates + search against the occupancy-bitmap grid for the class clouds that do
+// not fit the LDS tier.  A job is a whole source class cloud of at most 1536 points (MULLS_JOB_CLASS: the workgroup also resolves the duplicate rule and
+// runs the rejection chain — no k_filter) or 512 consecutive points of a larger one, which `split` workgroups share when the launch would not fill the chip
+// otherwise (k_filter finishes those clouds).  Outputs are identical to k_nn.
+__global__ __launch_bounds__(MULLS_BIG_BLOCK, 4) void k_cert_big(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
+																 float4 *__restrict__ spos, float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
+																 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf, const uint32_t *__restrict__ cs,
+																 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+																 unsigned long long *__restrict__ winner, uint32_t split, const float4 *__restrict__ tpos,
+																 const float4 *__restrict__ tnrm, int32_t *__restrict__ nn_hint, int32_t *__restrict__ match, float *__restrict__ wd,
+																 float4 *__restrict__ mq)
 {
-	__shared__ float4 qpos[MULLS_SRC_PER_BLOCK]; // transformed query positions; w = upper bound on the squared NN distance (+inf: none), -1 = dead / out of range
+	__shared__ BigLds<MULLS_BIG_BLOCK * 3> s_big;
 	const uint32_t wg = xcd_job(blockIdx.x, gridDim.x);
 	const Job job = jobs[wg / split];
-	const uint32_t per = MULLS_SRC_PER_BLOCK / split, q0 = (wg % split) * per; // this workgroup's queries of the job: [q0, q0 + per)
+	const uint32_t part = wg % split;
 	const PairState &ps = states[job.pair];
 	if (!ps.active || (rp.normal_shooting && (job.cls == 0 || job.cls == 2 || job.cls == 4)))
-		return;
+		return; // planar classes are served by k_nn_shoot while normal shooting is on
 	const uint32_t ci = job.pair * MULLS_NC + job.cls;
 	CloudDesc &d = descs[ci];
-	const uint32_t src_n = d.src_n, alive_cur = d.alive_cur;
-	const bool called = class_called(rp, d, job.cls);
-	// temporal coherence, as in k_nn_lds: the target a point found in the previous iteration bounds this iteration's search
-	// exactly (any target is an upper bound).  Here every probe is a chain of dependent global loads (occupancy word -> rank /
-	// start -> candidates), so starting with the cube of that radius instead of the own-cell probe saves a whole chain.
-	const bool use_hint = called && ps.iter > 0;
-	const uint32_t tgt_n = d.tgt_n;
+	const bool class_level = (job.count & MULLS_JOB_CLASS) != 0u;
+	const uint32_t cnt = (job.count & ~MULLS_JOB_CLASS) ? (job.count & ~MULLS_JOB_CLASS) : (uint32_t)MULLS_SRC_PER_BLOCK;
+	uint32_t q0, q1;
+	if (class_level)
 	{
-		const double *T = ps.T;
-		for (uint32_t k = threadIdx.x; k < per; k += MULLS_BLOCK)
-		{
-			const uint32_t s = job.start + q0 + k;
-			float4 out = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-			if (s < src_n && (flag[d.src_off + s] & MULLS_F_ALIVE))
-			{
-				// pcl::transformPointCloudWithNormals<PointT,double> (cregistration.hpp:1690-1695)
-				const float4 p = spos[d.src_off + s], n = snrm[d.src_off + s];
-				const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
-				out.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
-				out.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
-				out.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
-				out.w = __builtin_inff();
-				if (use_hint)
-				{
-					const uint32_t h = (uint32_t)nn_hint[d.src_off + s];
-					if (h < tgt_n)
-					{
-						// a point whose hint is its standing correspondence carries that target's position in its own record
-						const float4 t = (int32_t)h == match[d.src_off + s] ? mq[2u * (d.src_off + s)] : tpos[d.tgt_off + h];
-						const float dx = out.x - t.x, dy = out.y - t.y, dz = out.z - t.z;
-						const float d0 = (dx * dx + dy * dy) + dz * dz;
-						if (d0 >= 0.0f)
-							out.w = d0;
-					}
-				}
-				const float onx = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
-				const float ony = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
-				const float onz = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
-				spos[d.src_off + s] = make_float4(out.x, out.y, out.z, p.w);
-				snrm[d.src_off + s] = make_float4(onx, ony, onz, n.w);
-			}
-			qpos[k] = out;
-		}
+		if (part)
+			return; // a class-level job is one workgroup's
+		q0 = 0u, q1 = min(d.src_n, cnt);
 	}
-	if (!called)
-		return; // correspondences of the previous iteration stay in force
-	__syncthreads();
-
+	else
+	{
+		const uint32_t per = cnt / split;
+		q0 = job.start + part * per, q1 = min(d.src_n, q0 + per);
+		if (q0 >= q1)
+			return;
+	}
 	const GridDesc g = grids[ci];
 	const BmGrid B = {bm + g.cell_off, pf + g.cell_off, cs + d.tgt_off + ci};
-	const float4 *__restrict__ ts = tsorted + d.tgt_off;
-	const float r = 2.5f * ps.thr[job.cls]; // filter_dis_times * dis_thre (float), cregistration.hpp:1745
-	const double maxd = (double)r;
-	const double max_dist_sqr = maxd * maxd;
-	const bool gate = alive_cur >= 500u;
-	const unsigned long long key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
-	const float m = fminf(r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
-	const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
-	uint32_t matched_cnt = 0;
-	for (uint32_t k = grp; k < per; k += MULLS_BLOCK / MULLS_GRID_GROUP)
-	{
-		const uint32_t s = job.start + q0 + k;
-		if (s >= src_n)
-			break;
-		const float4 q = qpos[k];
-		if (q.w < 0.0f)
-			continue;
-		float best = __builtin_inff();
-		int bi = -1;
-		if (q.w < __builtin_inff())
-		{
-			// bounded by last iteration's correspondence: one sweep of the cube of that radius (it contains that target)
-			grid_scan_box(g, B, ts, q.x, q.y, q.z, fminf(m, sqrtf(q.w)), sub, best, bi);
-			group_min(best, bi);
-		}
-		else
-		{
-		// probe 0: the query's own cell
-		const int ocx = grid_cell(q.x, g.ox, g.inv_h, g.nx), ocy = grid_cell(q.y, g.oy, g.inv_h, g.ny), ocz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
-		{
-			uint32_t lo, hi;
-			bm_row_range(B, ((uint32_t)ocz * g.ny + (uint32_t)ocy) * g.wpr, (uint32_t)ocx, (uint32_t)ocx, lo, hi);
-			for (uint32_t t = lo + sub; t < hi; t += 4 * MULLS_GRID_GROUP)
-			{
-				float4 c[4];
-				bool v[4];
-#pragma unroll
-				for (int w = 0; w < 4; w++)
-				{
-					v[w] = t + w * MULLS_GRID_GROUP < hi;
-					if (v[w])
-						c[w] = ts[t + w * MULLS_GRID_GROUP];
-				}
-#pragma unroll
-				for (int w = 0; w < 4; w++)
-					if (v[w])
-					{
-						const float dx = q.x - c[w].x, dy = q.y - c[w].y, dz = q.z - c[w].z;
-						const float dist = (dx * dx + dy * dy) + dz * dz;
-						const int idx = __float_as_int(c[w].w);
-						if (dist < best || (dist == best && idx < bi))
-						{
-							best = dist;
-							bi = idx;
-						}
-					}
-			}
-		}
-		group_min(best, bi);
-		// probe 1: the cells within min(first-probe radius, current best distance); skipped when that box is the own cell
-		{
-			const float R1 = bi >= 0 ? fminf(m, sqrtf(best)) : m;
-			const float Rm = R1 * 1.0001f + 1e-4f;
-			const bool own_only = grid_cell(q.x - Rm, g.ox, g.inv_h, g.nx) == ocx && grid_cell(q.x + Rm, g.ox, g.inv_h, g.nx) == ocx &&
-								  grid_cell(q.y - Rm, g.oy, g.inv_h, g.ny) == ocy && grid_cell(q.y + Rm, g.oy, g.inv_h, g.ny) == ocy &&
-								  grid_cell(q.z - Rm, g.oz, g.inv_h, g.nz) == ocz && grid_cell(q.z + Rm, g.oz, g.inv_h, g.nz) == ocz;
-			if (!own_only)
-			{
-				grid_scan_box(g, B, ts, q.x, q.y, q.z, R1, sub, best, bi);
-				group_min(best, bi);
-			}
-		}
-		}
-		// nothing inside the probed radius yet: one last probe at the distance found, else double the radius (up to r)
-		float Rc = m;
-		while (!(bi >= 0 && best <= Rc * Rc) && Rc < r)
-		{
-			const bool last = bi >= 0;
-			Rc = last ? fminf(r, sqrtf(best)) : fminf(r, 2.0f * Rc);
-			grid_scan_box(g, B, ts, q.x, q.y, q.z, Rc, sub, best, bi);
-			group_min(best, bi);
-			if (last)
-				break;
-		}
-		if (sub == 0)
-		{
-			const bool matched = bi >= 0 && !((double)best > max_dist_sqr);
-			nn_idx[d.src_off + s] = matched ? bi : -1;
-			nn_d2[d.src_off + s] = best;
-			nn_hint[d.src_off + s] = bi;
-			if (matched)
-			{
-				matched_cnt++;
-				if (gate)
-					atomicMin(&winner[d.tgt_off + bi], key_hi | (unsigned long long)s);
-			}
-		}
-	}
-	for (int off = 32; off > 0; off >>= 1)
-		matched_cnt += __shfl_down(matched_cnt, off);
-	if ((threadIdx.x & 63) == 0 && matched_cnt)
-		atomicAdd(&d.n_matched, matched_cnt);
+	cert_big<MULLS_BIG_BLOCK, 3>(s_big, rp, ps, job.cls, q0, q1, class_level, d, g, B, tsorted + d.tgt_off, spos, snrm, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+								 reinterpret_cast<int2 *>(nn_hint), mq);
 }
 
+// rejection chain of the class clouds whose correspondences are spread over several workgroups (chunk-level jobs).  big: jobs of the global-memory tier
+// (duplicate rule through the batch's winner table, cropped target copies) whatever the LDS tier of the same batch does
 __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ jobs, CloudDesc *__restrict__ descs,
 														 const PairState *__restrict__ states, RunParams rp,
 														 const float4 *__restrict__ snrm, const float4 *__restrict__ tnrm, uint8_t *__restrict__ flag,
 														 const int32_t *__restrict__ nn_idx, const float *__restrict__ nn_d2,
 														 int32_t *__restrict__ match, float *__restrict__ wd,
 														 const unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos,
-														 float4 *__restrict__ mq)
+														 float4 *__restrict__ mq, uint32_t big)
 {
 	__shared__ uint32_t red4[4];
 	const Job job = jobs[xcd_job(blockIdx.x, gridDim.x)];
@@ -353,8 +219,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 		return;
 	const float thr = ps.thr[job.cls];
 	// vertex correspondences skip the direction check (cregistration.hpp:1292)
-	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u, rp.rej_strict != 0, thr * thr, rp.cos_bearing,
-						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32, rp.tgt_stage, rp.tgt_map};
+	const FilterCtx F = {d.alive_cur >= 500u, d.n_matched > 0u, job.cls != 5, rp.lds_dedup != 0u && !big, rp.rej_strict != 0, thr * thr, rp.cos_bearing,
+						 (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32, big ? nullptr : rp.tgt_stage, big ? nullptr : rp.tgt_map};
 	uint32_t n_alive = 0, n_valid = 0;
 #pragma unroll
 	for (int u = 0; u < MULLS_SRC_PER_THREAD; u++)
@@ -672,19 +538,18 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	return 0;
 }
 
-void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
-					float4 *spos, float4 *snrm, const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs,
-					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tpos,
-					int32_t *nn_hint, const int32_t *match, const float4 *mq)
+void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, bool splittable, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
+					 const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
+					 float *nn_d2, unsigned long long *winner, const float4 *tpos, const float4 *tnrm, int32_t *nn_hint, int32_t *match, float *wd, float4 *mq)
 {
 	if (!njobs)
 		return;
-	// few jobs (one scan against a big map): several workgroups share a 512-query job so that the chip is not left idle
+	// few chunk-level jobs (one dense scan pair): several workgroups share a 512-query job so that the chip is not left idle
 	uint32_t split = 1;
-	while (split < 16 && njobs * split < 1024u)
+	while (splittable && split < 16 && njobs * split < 1024u)
 		split <<= 1;
-	hipLaunchKernelGGL(k_nn_grid, dim3(njobs * split), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, bm, pf, cs, tsorted,
-					   flag, nn_idx, nn_d2, winner, split, tpos, nn_hint, match, mq);
+	hipLaunchKernelGGL(k_cert_big, dim3(njobs * split), dim3(MULLS_BIG_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, bm, pf, cs, tsorted, flag, nn_idx, nn_d2, winner,
+					   split, tpos, tnrm, nn_hint, match, wd, mq);
 }
 
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
@@ -704,9 +569,9 @@ void launch_nn_shoot(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc 
 
 void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,
-				   const unsigned long long *winner, const float4 *tpos, float4 *mq)
+				   const unsigned long long *winner, const float4 *tpos, float4 *mq, bool big)
 {
 	if (njobs)
 		hipLaunchKernelGGL(k_filter, dim3(njobs), dim3(MULLS_BLOCK), 0, st, jobs, descs, states, rp, snrm, tnrm, flag, nn_idx, nn_d2, match, wd,
-						   winner, tpos, mq);
+						   winner, tpos, mq, big ? 1u : 0u);
 }

@@ -94,11 +94,15 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 				k[j] = min(k[j], (uint32_t)__shfl_down(k[j], off));
 				k[3 + j] = max(k[3 + j], (uint32_t)__shfl_down(k[3 + j], off));
 			}
+		// a wave only sends what moves the box: the keys are monotone under the atomics, so a value that does not beat what a (possibly stale) read returns
+		// cannot beat the entry either — a dense scan's thousands of waves on six words were 250 us of its setup (profiles/r04_large_base.txt)
 		if ((threadIdx.x & 63) == 0)
 			for (int j = 0; j < 3; j++)
 			{
-				atomicMin(&bbox[job.pair * 6 + j], k[j]);
-				atomicMax(&bbox[job.pair * 6 + 3 + j], k[3 + j]);
+				if (k[j] < __builtin_nontemporal_load(&bbox[job.pair * 6 + j]))
+					atomicMin(&bbox[job.pair * 6 + j], k[j]);
+				if (k[3 + j] > __builtin_nontemporal_load(&bbox[job.pair * 6 + 3 + j]))
+					atomicMax(&bbox[job.pair * 6 + 3 + j], k[3 + j]);
 			}
 	}
 }
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 	CloudDesc &d = descs[pair * MULLS_NC + cls];
 	const uint32_t n0 = side ? d.tgt_n0 : ((rp.undistort && cls != 5) ? d.sd_n0 : d.src_n0);
 	const uint32_t off = side ? d.tgt_off : d.src_off;
-	if (side && rp.tgt_map)
-		return; // k_tgt_grid crops the target clouds (no working copy: rank -> staged index map) and builds their grids in one pass
+	if (side && rp.tgt_map && d.tier == MULLS_TIER_LDS)
+		return; // k_tgt_grid crops the LDS tier's target clouds (no working copy: rank -> staged index map) and builds their grids in one pass
 	if (side && d.big_slot)
 	{
 		// cropped by k_crop_big_* (many workgroups); this one only arms the cloud's bounding-box keys
@@ -130,6 +134,8 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			big_box[(d.big_slot - 1u) * 6u + threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
 		return;
 	}
+	if (!side && d.src_big_slot)
+		return; // likewise
 	double lo[3], hi[3];
 	if (crop)
 		crop_box(pair, bbox, setup, lo, hi);
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 				lo3[k] = fminf(fminf(box_red[0][k], box_red[1][k]), fminf(box_red[2][k], box_red[3][k]));
 				hi3[k] = fmaxf(fmaxf(box_red[0][3 + k], box_red[1][3 + k]), fmaxf(box_red[2][3 + k], box_red[3][3 + k]));
 			}
-			grids[pair * MULLS_NC + cls] = make_grid(lo3, hi3, running, rp, pair, cls);
+			grids[pair * MULLS_NC + cls] = make_grid(lo3, hi3, running, rp, d, cls);
 		}
 	}
 	if (threadIdx.x == 0)
@@ -242,12 +248,15 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 // count -> per-cloud scan of the segment counts (+ bounding box -> grid descriptor) -> scatter; same stable order.
 __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
 																 const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
-																 const float4 *__restrict__ stage, RunParams rp, uint32_t *__restrict__ seg_cnt,
-																 uint32_t *__restrict__ big_box)
+																 const float4 *__restrict__ stage, const float4 *__restrict__ tmp_pos, RunParams rp,
+																 uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ big_box)
 {
 	__shared__ uint32_t red4[4];
 	const Job sg = segs[blockIdx.x]; // count = big slot
-	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	const uint32_t cls = sg.cls & 0xffu;
+	const bool src_side = (sg.cls & MULLS_BIG_SRC_SIDE) != 0u;
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + cls];
+	const uint32_t n0 = src_side ? ((rp.undistort && cls != 5u) ? d.sd_n0 : d.src_n0) : d.tgt_n0;
 	double lo[3], hi[3];
 	if (rp.crop)
 		crop_box(sg.pair, bbox, setup, lo, hi);
@@ -256,9 +265,9 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 	for (uint32_t k = 0; k < MULLS_SEG; k += MULLS_BLOCK)
 	{
 		const uint32_t i = sg.start + k + threadIdx.x;
-		if (i < d.tgt_n0)
+		if (i < n0)
 		{
-			const float4 p = load_staged_pos(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, i);
+			const float4 p = src_side ? tmp_pos[d.src_off + i] : load_staged_pos(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, i);
 			if (!rp.crop || crop_keep(p, lo, hi))
 			{
 				mine++;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 			bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
 			bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
 		}
-		if ((threadIdx.x & 63) == 0 && bmin[k] <= bmax[k])
+		if ((threadIdx.x & 63) == 0 && bmin[k] <= bmax[k] && !src_side) // (the box sizes a target's grid)
 		{
 			atomicMin(&big_box[sg.count * 6u + k], f2ord(bmin[k]));
 			atomicMax(&big_box[sg.count * 6u + 3 + k], f2ord(bmax[k]));
@@ -310,7 +319,17 @@ __global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ cl
 			seg_cnt[bc.start + s] = running + incl - v;
 		running += __shfl(incl, 63);
 	}
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0 && (bc.cls & MULLS_BIG_SRC_SIDE))
+	{
+		CloudDesc &d = descs[bc.pair * MULLS_NC + (bc.cls & 0xffu)];
+		d.src_n = running;
+		d.alive_cur = running;
+		d.alive_next = 0;
+		d.n_matched = 0;
+		d.valid_next = 0;
+		d.n_valid = 0;
+	}
+	else if (threadIdx.x == 0)
 	{
 		descs[bc.pair * MULLS_NC + bc.cls].tgt_n = running;
 		if (grids)
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ cl
 				lo3[k] = running ? ord2f(big_box[blockIdx.x * 6u + k]) : __builtin_inff();
 				hi3[k] = running ? ord2f(big_box[blockIdx.x * 6u + 3 + k]) : -__builtin_inff();
 			}
-			grids[bc.pair * MULLS_NC + bc.cls] = make_grid(lo3, hi3, running, rp, bc.pair, bc.cls);
+			grids[bc.pair * MULLS_NC + bc.cls] = make_grid(lo3, hi3, running, rp, descs[bc.pair * MULLS_NC + bc.cls], bc.cls);
 		}
 	}
 }
@@ -330,11 +349,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__r
 																   const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
 																   const float4 *__restrict__ stage, RunParams rp,
 																   const uint32_t *__restrict__ seg_base, float4 *__restrict__ tpos,
-																   float4 *__restrict__ tnrm)
+																   float4 *__restrict__ tnrm, const float4 *__restrict__ tmp_pos, const float4 *__restrict__ tmp_nrm,
+																   float4 *__restrict__ spos, float4 *__restrict__ snrm, uint8_t *__restrict__ flag,
+																   int32_t *__restrict__ match, float *__restrict__ wd)
 {
 	__shared__ uint32_t wave_cnt[4];
 	const Job sg = segs[blockIdx.x];
-	const CloudDesc &d = descs[sg.pair * MULLS_NC + sg.cls];
+	const uint32_t cls = sg.cls & 0xffu;
+	const bool src_side = (sg.cls & MULLS_BIG_SRC_SIDE) != 0u;
+	const CloudDesc &d = descs[sg.pair * MULLS_NC + cls];
+	const uint32_t n0 = src_side ? ((rp.undistort && cls != 5u) ? d.sd_n0 : d.src_n0) : d.tgt_n0;
 	double lo[3], hi[3];
 	if (rp.crop)
 		crop_box(sg.pair, bbox, setup, lo, hi);
@@ -345,9 +369,12 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__r
 		const uint32_t i = sg.start + k + threadIdx.x;
 		bool keep = false;
 		float4 p = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
-		if (i < d.tgt_n0)
+		if (i < n0)
 		{
-			load_staged(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, d.tgt_n0, i, p, q);
+			if (src_side)
+				p = tmp_pos[d.src_off + i], q = tmp_nrm[d.src_off + i];
+			else
+				load_staged(stage, d.tgt_stage, (d.stage_fmt >> 2) & 3u, d.tgt_n0, i, p, q);
 			keep = !rp.crop || crop_keep(p, lo, hi);
 		}
 		const unsigned long long bal = __ballot(keep);
@@ -363,7 +390,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__r
 				wbase += wave_cnt[w];
 			total += wave_cnt[w];
 		}
-		if (keep)
+		if (keep && src_side)
+		{
+			const uint32_t dst = d.src_off + running + wbase + before;
+			spos[dst] = p;
+			snrm[dst] = q;
+			flag[dst] = MULLS_F_ALIVE;
+			match[dst] = -1;
+			wd[dst] = 0.0f;
+		}
+		else if (keep)
 		{
 			tpos[d.tgt_off + running + wbase + before] = p;
 			tnrm[d.tgt_off + running + wbase + before] = q;
@@ -456,10 +492,10 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 					   tnrm, flag, match, wd, rp, grids, big_box);
 	if (nbig_clouds)
 	{
-		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, big_box);
+		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, tmp_pos, rp, seg_cnt, big_box);
 		hipLaunchKernelGGL(k_crop_big_scan, dim3(nbig_clouds), dim3(64), 0, st, big_clouds, descs, rp, seg_cnt, big_box, grids);
 		hipLaunchKernelGGL(k_crop_big_scatter, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, tpos,
-						   tnrm);
+						   tnrm, tmp_pos, tmp_nrm, spos, snrm, flag, match, wd);
 	}
 }
 

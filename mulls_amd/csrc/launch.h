@@ -17,25 +17,28 @@ void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_
 // LDS tier with rp.tgt_map: crop + grid build of every target class cloud (<= MULLS_LDS_MAXPTS points) in one pass, no working copy (k_grid.hip)
 int launch_tgt_grid(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage, const RunParams &rp,
 					GridDesc *grids, uint16_t *tmap, uint32_t *cell_start, float4 *tsorted);
-void launch_grid_build(hipStream_t st, uint32_t npairs, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids,
-					   const RunParams &rp, const float4 *tpos, unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cell_start,
-					   float4 *tsorted, bool lds_tier);
+// LDS tier without the fused setup (k_crop wrote the cropped copies)
+void launch_grid_build_sort(hipStream_t st, uint32_t npairs, const CloudDesc *descs, GridDesc *grids, const RunParams &rp, const float4 *tpos, uint32_t *cell_start,
+							float4 *tsorted);
+// bitmap grids of the `nl` class clouds lclouds[] (pair * MULLS_NC + class each); tjobs: their 256-point chunks
+void launch_bm_build(hipStream_t st, uint32_t nl, const uint32_t *lclouds, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids, const float4 *tpos,
+					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted);
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup);
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
 				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells,
 				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity);
-void launch_nn_grid(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
-					float4 *spos, float4 *snrm, const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs,
-					const float4 *tsorted, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tpos,
-					int32_t *nn_hint, const int32_t *match, const float4 *mq);
+// global-memory tier (big_tier.h): class-level (MULLS_JOB_CLASS) and chunk-level jobs; splittable: chunk-level jobs may be shared by several workgroups
+void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, bool splittable, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
+					 const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
+					 float *nn_d2, unsigned long long *winner, const float4 *tpos, const float4 *tnrm, int32_t *nn_hint, int32_t *match, float *wd, float4 *mq);
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 			   float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner);
 void launch_nn_shoot(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 					 float4 *spos, float4 *snrm, const float4 *tpos, const uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner);
 void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp,
 				   const float4 *snrm, const float4 *tnrm, uint8_t *flag, const int32_t *nn_idx, const float *nn_d2, int32_t *match, float *wd,
-				   const unsigned long long *winner, const float4 *tpos, float4 *mq);
+				   const unsigned long long *winner, const float4 *tpos, float4 *mq, bool big = false);
 // leaders: job indices of the trip starts, grouped by trip length (split[0..3]: see k_reduce.hip)
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
 				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single = false);

@@ -93,7 +93,7 @@ int run_setup(Run &R)
 	// device-stepped loop: one sub-batch, or two on two streams for the batch sizes whose kernels leave most of the chip idle (not while profiling:
 	// the event sets are laid out for one)
 	const int dstep_nsub = (ctx->profiling == 0 && n >= (int)ctx->opt[MULLS_OPT_SPLIT_MIN_PAIRS] && n <= (int)ctx->opt[MULLS_OPT_SPLIT_MAX_PAIRS]) ? 2 : 1;
-	rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident, dstep ? dstep_nsub : 0);
+	rc = prepare_run(ctx, B, P, rp, &lds_cap, &tier, &resident, dstep ? dstep_nsub : 0, true);
 	if (rc != MULLS_OK)
 		return rc;
 	const bool use_grid = tier != 0;
@@ -101,9 +101,11 @@ int run_setup(Run &R)
 
 	// LDS tier: the target clouds are cropped and their grids built in one pass that writes no cropped copy (k_tgt_grid) — unless something needs the
 	// copy (the keep-less thinning, the normal-shooting search) or a cloud of a class the run does not read is larger than the kernel's lanes cover
-	bool fused_tgt = tier == 2 && ctx->opt[MULLS_OPT_FUSED_TGT_SETUP] != 0.0 && !P->keep_less_source_points && !rp.normal_shooting && B->big_clouds_h.empty();
+	// (a mixed batch — tier 3 — exists only with the fused setup: its LDS-tier clouds are the ones that fit, choose_tier)
+	bool fused_tgt = tier == 2 && ctx->opt[MULLS_OPT_FUSED_TGT_SETUP] != 0.0 && !P->keep_less_source_points && !rp.normal_shooting && B->n_big_tgt == 0;
 	for (size_t k = 0; k < B->descs_h.size() && fused_tgt; k++)
 		fused_tgt = B->descs_h[k].tgt_n0 <= MULLS_LDS_MAXPTS;
+	fused_tgt = fused_tgt || tier == 3;
 	if (fused_tgt)
 	{
 		rp.tgt_stage = B->stage;
@@ -167,12 +169,83 @@ int run_setup(Run &R)
 	}
 	if (fused_tgt)
 		(void)launch_tgt_grid(st, (uint32_t)n, B->descs, B->setup, B->bbox, B->stage, rp, B->grids, B->tmap, B->cell_start, B->tsorted);
-	else if (use_grid)
-		launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
-						  B->tsorted, tier == 2);
+	else if (tier == 2)
+		launch_grid_build_sort(st, (uint32_t)n, B->descs, B->grids, rp, B->tpos, B->cell_start, B->tsorted);
+	launch_bm_build(st, (uint32_t)B->lclouds_h.size(), B->lclouds, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, B->tpos, B->bm, B->pf, B->cell_cnt, B->bm_cs,
+					B->tsorted);
 	evt.end();
 
 	R.K = icp_const(P);
+	return MULLS_OK;
+}
+
+// a sub-batch's slices of the batch's job tables
+struct Slice
+{
+	uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0, bjob_lo = 0, bjob_n = 0, fjob_lo = 0, fjob_n = 0, ejob_lo = 0, ejob_n = 0;
+	const uint32_t *ajob_split = nullptr;
+};
+Slice slice_of(const mulls_batch *B, int lo, int hi, int k)
+{
+	auto first_of = [](const std::vector<Job> &v, uint32_t pair) {
+		return (uint32_t)(std::lower_bound(v.begin(), v.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; }) - v.begin());
+	};
+	Slice L;
+	L.job_lo = first_of(B->jobs_h, (uint32_t)lo);
+	L.job_n = first_of(B->jobs_h, (uint32_t)hi) - L.job_lo;
+	L.cjob_lo = first_of(B->cjobs_h, (uint32_t)lo);
+	L.cjob_n = first_of(B->cjobs_h, (uint32_t)hi) - L.cjob_lo;
+	L.bjob_lo = first_of(B->bjobs_h, (uint32_t)lo);
+	L.bjob_n = first_of(B->bjobs_h, (uint32_t)hi) - L.bjob_lo;
+	L.fjob_lo = first_of(B->fjobs_h, (uint32_t)lo);
+	L.fjob_n = first_of(B->fjobs_h, (uint32_t)hi) - L.fjob_lo;
+	L.ejob_lo = first_of(B->ejobs_h, (uint32_t)lo);
+	L.ejob_n = first_of(B->ejobs_h, (uint32_t)hi) - L.ejob_lo;
+	L.ajob_split = B->ajob_split[k];
+	return L;
+}
+
+// One iteration's correspondence search + rejection chain of a sub-batch: the class clouds of each tier by that tier's kernels (a mixed batch launches both
+// families; a batch on one tier only its own), then k_filter for the clouds whose correspondences are spread over several workgroups
+int launch_search(Run &R, hipStream_t sst, const Slice &L, uint32_t *wl, uint32_t *wl_ctr, uint32_t parity, EvTimer &ev, int iter)
+{
+RUN_ALIASES
+	const Job *jobs = B->jobs + L.job_lo;
+	ev.begin(&ctx->prof.ms_nn);
+	if (tier == 0)
+		launch_nn(sst, L.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+	if (L.cjob_n &&
+		launch_nn_lds(sst, L.cjob_n, B->cjobs + L.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner,
+					  B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, wl, wl_ctr, parity) != 0)
+	{
+		ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
+		return MULLS_E_HIP;
+	}
+	// mixed batch, first iterations: chunk-level jobs for every cloud of the global-memory tier (MULLS_OPT_BIG_EARLY_SETS)
+	const bool early = L.ejob_n && iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS];
+	if (early)
+		launch_cert_big(sst, L.ejob_n, B->ejobs + L.ejob_lo, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
+						B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
+	else if (L.bjob_n)
+		launch_cert_big(sst, L.bjob_n, B->bjobs + L.bjob_lo, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
+						B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
+	if (rp.normal_shooting)
+		launch_nn_shoot(sst, L.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
+	ev.end();
+	ev.begin(&ctx->prof.ms_filter);
+	if (tier == 0 || (tier == 2 && !rp.lds_dedup)) // (else the LDS tier's kernels ran the rejection chain themselves)
+		launch_filter(sst, L.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
+	else if (early)
+		launch_filter(sst, L.ejob_n, B->ejobs + L.ejob_lo, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq, true);
+	else if (L.fjob_n)
+		launch_filter(sst, L.fjob_n, B->fjobs + L.fjob_lo, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq, true);
+	ev.end();
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+	{
+		ctx->err = std::string("correspondence search launch: ") + hipGetErrorString(e);
+		return MULLS_E_HIP;
+	}
 	return MULLS_OK;
 }
 
@@ -303,8 +376,7 @@ RUN_ALIASES
 	struct Sub
 	{
 		int lo = 0, hi = 0;
-		uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
-		const uint32_t *ajob_split = nullptr;
+		Slice L;
 		hipStream_t st = nullptr;
 		volatile unsigned long long *word = nullptr;
 		unsigned long long *word_dev = nullptr;
@@ -321,21 +393,14 @@ RUN_ALIASES
 		Sub &S = subs[k];
 		S.lo = (int)((long)n * k / nsub);
 		S.hi = (int)((long)n * (k + 1) / nsub);
-		auto first_of = [](const std::vector<Job> &v, uint32_t pair) {
-			return (uint32_t)(std::lower_bound(v.begin(), v.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; }) - v.begin());
-		};
-		S.job_lo = first_of(B->jobs_h, (uint32_t)S.lo);
-		S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
-		S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
-		S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
-		S.ajob_split = B->ajob_split[k];
+		S.L = slice_of(B, S.lo, S.hi, k);
 		S.st = k == 0 ? ctx->stream : ctx->stream2;
 		S.word = reinterpret_cast<volatile unsigned long long *>(B->epoch_h + 32 + 16 * k);
 		S.word_dev = reinterpret_cast<unsigned long long *>(B->epoch_dev + 32 + 16 * k);
 		S.epoch_ctr = k == 0 ? &B->epoch2 : &B->epoch3;
 		S.epoch0 = *S.epoch_ctr;
 		S.ticket = B->ticket + 2 + 4 * k;
-		S.wl = B->wl + S.cjob_lo;
+		S.wl = B->wl + S.L.cjob_lo;
 		S.wl_ctr = B->wl_ctr + 8 * k;
 		S.left = (uint32_t)(S.hi - S.lo);
 		for (int e = 0; e < 2; e++)
@@ -416,42 +481,34 @@ RUN_ALIASES
 		hipStream_t sst = S.st;
 		EvTimer &ev = S.ev2[s & 1];
 		ev.stream = sst;
-		const Job *jobs = B->jobs + S.job_lo;
 		const bool search = s < P->max_iter_num; // the last set can only hold residual passes
 		if (search)
 		{
-			ev.begin(&ctx->prof.ms_nn);
-			if (tier == 2)
+			int rcs;
+			if ((rcs = launch_search(R, sst, S.L, S.wl, S.wl_ctr, S.nn_launches++, ev, s)) != MULLS_OK)
 			{
-				if (launch_nn_lds(sst, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx,
-								  B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, S.wl, S.wl_ctr, S.nn_launches++) != 0)
-				{
-					ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
-					return MULLS_E_HIP;
-				}
+				(void)hipMemsetAsync(S.ticket, 0, 2 * sizeof(uint32_t), sst); // (a failed launch set must not leave the next run an armed ticket)
+				return rcs;
 			}
-			else if (tier == 1)
-				launch_nn_grid(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx, B->nn_d2,
-							   B->winner, B->tpos, B->nn_hint, B->match, B->mq);
-			else
-				launch_nn(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			if (rp.normal_shooting)
-				launch_nn_shoot(sst, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			ev.end();
-			ev.begin(&ctx->prof.ms_filter);
-			if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
-				launch_filter(sst, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-			ev.end();
 			if (&S == &subs[0])
 				ctx->prof.launches_nn++;
 		}
 		// a set without a search holds only posterior-residual passes (every pair ran its last iteration in the set before): that is the
 		// residual kernel time; a set of a converging batch mixes both kinds of pairs and is charged to the accumulation
 		ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-		launch_accum(sst, B->ajobs, S.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
+		launch_accum(sst, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
 		launch_finish_step(sst, (uint32_t)S.lo, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, S.word_dev,
 						   ++*S.epoch_ctr, use_grid ? 0 : 1, (few_launches || n <= (int)ctx->opt[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS]) ? S.ticket : nullptr);
 		ev.end();
+		{
+			const hipError_t e = hipGetLastError(); // a rejected launch (dynamic LDS size, ...) would otherwise only show as an epoch that never arrives
+			if (e != hipSuccess)
+			{
+				ctx->err = std::string("iteration launch set: ") + hipGetErrorString(e);
+				(void)hipMemsetAsync(S.ticket, 0, 2 * sizeof(uint32_t), sst);
+				return MULLS_E_HIP;
+			}
+		}
 		S.s++;
 		return MULLS_OK;
 	};
@@ -528,8 +585,7 @@ RUN_ALIASES
 	struct Sub
 	{
 		int lo = 0, hi = 0;
-		uint32_t job_lo = 0, job_n = 0, cjob_lo = 0, cjob_n = 0;
-		const uint32_t *ajob_split = nullptr;
+		Slice L;
 		int iter = 0;
 		bool inflight = false;
 		uint32_t nn_launches = 0; // parity of the LDS tier's queue counters
@@ -547,14 +603,7 @@ RUN_ALIASES
 		Sub &S = subs[k];
 		S.lo = (int)((long)n * k / nsub);
 		S.hi = (int)((long)n * (k + 1) / nsub);
-		auto first_of = [](const std::vector<Job> &v, uint32_t pair) {
-			return (uint32_t)(std::lower_bound(v.begin(), v.end(), pair, [](const Job &j, uint32_t q) { return j.pair < q; }) - v.begin());
-		};
-		S.job_lo = first_of(B->jobs_h, (uint32_t)S.lo);
-		S.job_n = first_of(B->jobs_h, (uint32_t)S.hi) - S.job_lo;
-		S.cjob_lo = first_of(B->cjobs_h, (uint32_t)S.lo);
-		S.cjob_n = first_of(B->cjobs_h, (uint32_t)S.hi) - S.cjob_lo;
-		S.ajob_split = B->ajob_split[k];
+		S.L = slice_of(B, S.lo, S.hi, k);
 		S.epoch_ctr = k == 0 ? &B->epoch : &B->epoch1;
 		S.word = B->epoch_h + 16 * k;
 		S.word_dev = B->epoch_dev + 16 * k;
@@ -610,39 +659,18 @@ RUN_ALIASES
 			s.pad_[0] = s.pad_[1] = s.pad_[2] = 0;
 		}
 		EvTimer &ev = S.evt;
-		const Job *jobs = B->jobs + S.job_lo;
 		launch_push_states(st, B->states_pin + S.lo, B->states + S.lo, (uint32_t)(S.hi - S.lo));
 		if (any_active)
 		{
-			ev.begin(&ctx->prof.ms_nn);
-			if (tier == 2)
-			{
-				if (launch_nn_lds(st, S.cjob_n, B->cjobs + S.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted,
-								  B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells,
-								  B->wl + S.cjob_lo, B->wl_ctr + 8 * (int)(&S - subs), S.nn_launches++) != 0)
-				{
-					ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
-					return MULLS_E_HIP;
-				}
-			}
-			else if (tier == 1)
-				launch_nn_grid(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag, B->nn_idx,
-							   B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
-			else
-				launch_nn(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			if (rp.normal_shooting)
-				launch_nn_shoot(st, S.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-			ev.end();
-			ev.begin(&ctx->prof.ms_filter);
-			if (!rp.lds_dedup) // else k_nn_lds ran the rejection chain itself
-				launch_filter(st, S.job_n, jobs, B->descs, B->states, rp, B->snrm, B->tnrm, B->flag, B->nn_idx, B->nn_d2, B->match, B->wd, B->winner, B->tpos, B->mq);
-			ev.end();
+			int rcs;
+			if ((rcs = launch_search(R, st, S.L, B->wl + S.L.cjob_lo, B->wl_ctr + 8 * (int)(&S - subs), S.nn_launches++, ev, S.iter)) != MULLS_OK)
+				return rcs;
 			ctx->prof.launches_nn++;
 			if (&S == &subs[0])
 				ctx->prof.iterations++;
 		}
 		ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-		launch_accum(st, B->ajobs, S.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+		launch_accum(st, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
 		launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 					  (uint32_t)S.lo);
 		ev.end();

@@ -83,9 +83,10 @@ extern "C"
 		launch_crop(st, 1, B->descs, B->setup, B->bbox, B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match,
 					B->wd, *rp, B->grids, (uint32_t)B->big_segs_h.size(), B->big_segs, (uint32_t)B->big_clouds_h.size(), B->big_clouds, B->seg_cnt,
 					B->big_box);
-		if (tier != 0)
-			launch_grid_build(st, 1, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, *rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
-							  B->tsorted, tier == 2);
+		if (tier == 2)
+			launch_grid_build_sort(st, 1, B->descs, B->grids, *rp, B->tpos, B->cell_start, B->tsorted);
+		launch_bm_build(st, (uint32_t)B->lclouds_h.size(), B->lclouds, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, B->tpos, B->bm, B->pf, B->cell_cnt, B->bm_cs,
+						B->tsorted);
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)
@@ -125,8 +126,8 @@ extern "C"
 				launch_nn_lds(st, (uint32_t)B->cjobs_h.size(), B->cjobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag,
 							  B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, B->wl, B->wl_ctr, 0u);
 			else if (tier == 1)
-				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
-							   B->nn_idx, B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
+				launch_cert_big(st, (uint32_t)B->bjobs_h.size(), B->bjobs, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag,
+								B->nn_idx, B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 			else if (tier < 0)
 				rc = MULLS_E_INVALID;
 			else

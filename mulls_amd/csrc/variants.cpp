@@ -80,9 +80,10 @@ extern "C"
 				return MULLS_E_HIP;
 			}
 		}
-		if (tier != 0)
-			launch_grid_build(st, (uint32_t)n, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, rp, B->tpos, B->bm, B->pf, B->cell_cnt, B->cell_start,
-							  B->tsorted, tier == 2);
+		if (tier == 2)
+			launch_grid_build_sort(st, (uint32_t)n, B->descs, B->grids, rp, B->tpos, B->cell_start, B->tsorted);
+		launch_bm_build(st, (uint32_t)B->lclouds_h.size(), B->lclouds, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, B->tpos, B->bm, B->pf, B->cell_cnt, B->bm_cs,
+						B->tsorted);
 
 		struct H3
 		{
@@ -132,8 +133,8 @@ extern "C"
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
-				launch_nn_grid(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->cell_start, B->tsorted, B->flag,
-							   B->nn_idx, B->nn_d2, B->winner, B->tpos, B->nn_hint, B->match, B->mq);
+				launch_cert_big(st, (uint32_t)B->bjobs_h.size(), B->bjobs, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag,
+								B->nn_idx, B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
 			if (!rp.lds_dedup)

@@ -37,27 +37,44 @@ def pack_results(results, n):
     return out
 
 
-def gather_results(table, device=None, dst=0):
+def gather_results(table, device=None, dst=0, counts=None):
     """Gather every rank's (n_r, RECORD) table on rank `dst`.  Returns the concatenated table there, None elsewhere.
-    Without an initialised process group (single-GPU run) the table is returned unchanged."""
+    Without an initialised process group (single-GPU run) the table is returned unchanged.
+    counts: the ranks' row counts when the caller knows them (block_partition makes them static): no size exchange, no host sync before the gather."""
+    h = gather_post(table, device, dst, counts)
+    return gather_wait(h)
+
+
+def gather_post(table, device=None, dst=0, counts=None):
+    """Post the gather of one step's result table without waiting for it (the next step's kernels run meanwhile); gather_wait() completes it."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return table
+        return ("local", table)
     world, rank = dist.get_world_size(), dist.get_rank()
     t = torch.from_numpy(np.ascontiguousarray(table))
     if device is not None:
-        t = t.to(device)
-    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
-    counts = [int(c.item()) for c in counts]
-    pad = max(counts)
+        t = t.to(device, non_blocking=True)
+    if counts is None:
+        cl = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+        dist.all_gather(cl, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
+        counts = [int(c.item()) for c in cl]
+    pad = max(max(counts), 1)
     buf = torch.zeros((pad, RECORD), dtype=torch.float64, device=t.device)
     buf[: t.shape[0]] = t
-    if rank == dst:
-        parts = [torch.zeros_like(buf) for _ in range(world)]
-        dist.gather(buf, parts, dst=dst)
-        return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)])
-    dist.gather(buf, None, dst=dst)
-    return None
+    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    work = dist.gather(buf, parts, dst=dst, async_op=True)
+    return ("dist", work, parts, list(counts), buf)
+
+
+def gather_wait(handle):
+    if handle is None:
+        return None
+    if handle[0] == "local":
+        return handle[1]
+    _, work, parts, counts, _buf = handle
+    work.wait()
+    if parts is None:
+        return None
+    return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)])
