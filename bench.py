@@ -335,6 +335,187 @@ def respawn(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] and configs[4]: the large-cloud configurations as resident batches (one process per GPU, weak scaling: every rank its own batch)
+LARGE = {
+    2: dict(pairs=32, name="configs[2]", metric="scan-to-local-map registrations/sec (~1 M-point map, 20 ICP iters); dT vs ref",
+            kernel="correspondence search of one ICP iteration, global-memory tier: k_cert_big (rigid step, certificates, exact fixed-radius 1-NN of the uncertified queries on an "
+                   "occupancy-bitmap grid) + k_filter (duplicate rule, rejection chain)"),
+    4: dict(pairs=16, name="configs[4]", metric="scan-pair registrations/sec (128-beam ~240k pts, six classes, 40 ICP iters); dT vs ref",
+            kernel="correspondence search of one ICP iteration, global-memory tier: k_cert_big (rigid step, certificates, exact fixed-radius 1-NN of the uncertified queries on an "
+                   "occupancy-bitmap grid) + k_filter (duplicate rule, rejection chain)"),
+}
+
+
+def large_workload(cfg, n_pairs, rank):
+    from mulls_amd import workloads as W
+
+    if cfg == 2:
+        return W.submap_batch(n_pairs, seed=7 + 100 * rank), W.submap_params(), W.submap_params(converge=True)
+    return W.dense_batch(n_pairs, seed=301 + 100 * rank), W.dense_params(), W.dense_params(converge=True)
+
+
+def large_main(args, rank, local_rank, world, engine_factory=None):
+    """python bench.py --config 2|4: the same JSON shape as the headline line — value, roofline of the dominant kernel (SURVEY 8d's algorithmic bytes of the
+    search against its live hipEvent duration), cpu_baseline (the oracle on a bounded sample), delta_T_vs_ref."""
+    from mulls_amd import workloads as W
+
+    cfg = args.config
+    L = LARGE[cfg]
+    n_pairs = args.large_pairs or (4 if args.tiny else L["pairs"])
+    if args.tiny:  # plumbing sizes: never a bench line
+        pair, T_gt = synth.make_pair(SEED0 + rank, n_beams=16, n_az=400, src_counts={c: None for c in range(abi.NCLASS)} if cfg == 4 else synth.R_SOURCE,
+                                     tgt_counts={c: None for c in range(abi.NCLASS)}, vertex_count=50)
+        pairs = W._guesses(pair, T_gt, n_pairs, 5)
+        P = abi.default_params(used_feature_type="111111" if cfg == 4 else "111110", max_iter_num=4, converge_translation=0.0, converge_rotation_d=0.0)
+        Pc = None
+    else:
+        pairs, P, Pc = large_workload(cfg, n_pairs, rank)
+    used = bytes(P.used_feature_type).decode()[:6]
+    n_total = n_pairs * world
+    cpu, checks = None, None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+
+        if world == 1:
+            pyoracle.icp(pairs[0], P)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                pyoracle.icp(pairs[n % len(pairs)], P, nn_mode=0, use_omp=1)
+                n += 1
+                el = time.perf_counter() - t0
+                if (el > (1.0 if args.tiny else 10.0) and n >= 3) or n >= 512:
+                    break
+            cpu = {"value": n / el, "unit": "registrations/s", "cores": 3, "kind": "port",
+                   "sample": "%d registrations of the same workload back-to-back in %.1f s; oracle/mulls_oracle.cpp, kd-tree NN, the reference's 3 OpenMP sections "
+                             "(effective width 3 of %d host cores)" % (n, el, os.cpu_count())}
+        checks = oracle_check_prepare(pairs, P, 2 if cfg == 4 else 4)
+
+    import torch
+    import torch.distributed as dist
+
+    use_cuda = torch.cuda.is_available()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # RCCL
+        else:
+            dist.init_process_group(backend="gloo")
+    elif use_cuda:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local_rank if world > 1 else 0) if use_cuda else None
+    engine = (engine_factory or HipEngine)(local_rank if world > 1 else 0, args.nn_mode)
+    engine.stage(pairs)
+    results = abi.make_result_array(n_pairs)
+    counts = [n_pairs] * world
+
+    def step(gather=True):
+        engine.run(P, results)
+        return shard.gather_results(shard.pack_results(results, n_pairs), device=device, counts=counts) if gather else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if use_cuda:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device if use_cuda else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    PRIME = 0
+    engine.set_profiling(2)
+    t_prime = time.perf_counter()
+    while not args.tiny and (PRIME < 4 or time.perf_counter() - t_prime < 0.6):  # process start-up stalls (see main)
+        step()
+        PRIME += 1
+    for _ in range(args.warmup):
+        step()
+    prof_keys = ("ms_nn", "launches_nn", "nn_src_pts", "nn_tgt_unique", "ms_setup", "ms_filter", "ms_accum", "ms_residual")
+    acc = {k: 0.0 for k in prof_keys}
+    barrier()
+    t0 = time.perf_counter()
+    gathered = None
+    for _ in range(args.steps):
+        gathered = step()
+        pf = engine.profile()
+        for k in ("ms_nn", "launches_nn", "nn_src_pts", "nn_tgt_unique"):
+            acc[k] += getattr(pf, k)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    engine.set_profiling(1)
+    for _ in range(args.steps):
+        step()
+        pf = engine.profile()
+        for k in ("ms_setup", "ms_filter", "ms_accum", "ms_residual"):
+            acc[k] += getattr(pf, k)
+    engine.set_profiling(0)
+    conv = None
+    if Pc is not None and not args.no_converging:
+        res_c = abi.make_result_array(n_pairs)
+        engine.run(Pc, res_c)
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            engine.run(Pc, res_c)
+        barrier()
+        el_c = max_over_ranks(time.perf_counter() - t3)
+        it_c = [res_c[i].iters for i in range(n_pairs)]
+        conv = {"value": n_total * args.steps / el_c, "unit": "registrations/s", "ms_per_step": el_c / args.steps * 1e3, "mean_iterations": float(np.mean(it_c)),
+                "all_converged_code_1": bool(all(res_c[i].code == 1 for i in range(n_pairs))),
+                "params": "the same pairs with the call site's convergence thresholds (converge_tran 0.0005 m, converge_rot_d 0.001 deg) instead of the forced iteration count"}
+    if rank == 0:
+        n_reg = n_total * args.steps
+        launches = max(acc["launches_nn"], 1)
+        avg_ms = acc["ms_nn"] / launches
+        alg_bytes = (72.0 * acc["nn_src_pts"] + 16.0 * acc["nn_tgt_unique"]) / launches  # SURVEY 8d: 64 + 8 B per live source point, 16 B per target point of a searched cloud
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        b_reg = W.algorithmic_bytes([results[i] for i in range(n_pairs)], used) / n_pairs  # the whole path's B_reg per registration (SURVEY 8d)
+        value = n_reg / elapsed
+        p0 = pairs[0]
+        out = {
+            "metric": L["metric"], "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_priming_steps": PRIME,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("%s: " % L["name"]) + (
+                    "scan-to-local-map, source %s points (ground / pillar / facade / beam / roof, fixed-number down-sampled) against ONE ~%.2f M-point map (%s per class: one "
+                    "128 x 7500-ray revolution, nothing down-sampled), used_feature_type %s, 20 ICP iterations, weights 1111; every pair of the batch registers its own scan "
+                    "guess against the map (a localisation server's load); clouds resident in HBM" % (
+                        [len(c) for c in p0.src[:5]], sum(len(c) for c in p0.tgt) / 1e6, [len(c) for c in p0.tgt[:5]], used) if cfg == 2 else
+                    "synthetic 128-beam scan pairs, ~%dk returns each, regime D (every return in a class cloud: source %s, target %s), all six classes, 40 ICP iterations, "
+                    "weights 1111; clouds resident in HBM" % (sum(len(c) for c in p0.src[:5]) // 1000, [len(c) for c in p0.src], [len(c) for c in p0.tgt])),
+                "pairs_per_gpu_per_step": n_pairs, "pairs_per_step": n_total, "registrations_timed": n_reg,
+                "parallelism": "%d lock-step batch(es), one process per GPU, no data-path collective; result gather (%s) on rank 0" % (world, "RCCL" if use_cuda else "gloo"),
+                "engine": engine.name, "all_code_1": bool((gathered[:, 52] == 1).all()), "mean_iterations": float(np.mean(gathered[:, 53])),
+            },
+            "roofline": {
+                "kernel": L["kernel"], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
+                "whole_path": {"B_reg_bytes_per_registration": b_reg, "achieved_GBs": b_reg * value / 1e9, "frac": b_reg * value / 1e9 / HBM_PEAK_GBS,
+                               "note": "SURVEY 8d's B_reg (setup + every iteration's search and accumulation + residual pass) x registrations/s against the HBM peak"},
+                "kernel_ms_per_step": {k: acc[k] / args.steps for k in ("ms_setup", "ms_nn", "ms_filter", "ms_accum", "ms_residual")},
+                "note": "live hipEvent duration of the search launches of the timed steps (the library's stream); traffic: no PMC pass of this configuration is committed",
+            },
+        }
+        if checks is not None:
+            out["delta_T_vs_ref"] = oracle_check_compare(checks, results)
+        if conv:
+            out["value_converging"] = conv
+        if cpu:
+            out["cpu_baseline"] = cpu
+            out["cpu_baseline"]["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    engine.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None, engine_factory=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)

@@ -527,9 +527,11 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 					B->big_segs_h.push_back({(uint32_t)p, (uint32_t)c | MULLS_BIG_SRC_SIDE, k, slot});
 				B->big_clouds_h.push_back({(uint32_t)p, (uint32_t)c | MULLS_BIG_SRC_SIDE, first, (uint32_t)B->big_segs_h.size() - first});
 			}
-			for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK)
+			// clone jobs: 256 source points each; eight times that for a dense scan's clouds (k_clone_src: fewer atomics on the pair's box)
+			const uint32_t chunks = d.src_cap > 8192u ? 8u : 1u;
+			for (uint32_t k = 0; k < d.src_cap; k += MULLS_BLOCK * chunks)
 			{
-				Job j = {(uint32_t)p, (uint32_t)c, k, 0};
+				Job j = {(uint32_t)p, (uint32_t)c, k, chunks};
 				B->setup_jobs_h.push_back(j);
 			}
 		}

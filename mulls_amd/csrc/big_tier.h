@@ -44,7 +44,7 @@ __device__ __forceinline__ void take_one(const float4 c, float px, float py, flo
 	bk = k < bk ? k : bk;
 }
 // grid_scan_box (device_util.h) with the (best key, second-smallest distance) state of the certificates: every target in the cells that meet the
-// cube [p - R, p + R] is evaluated; 16 rows per two memory latencies, eight candidate loads in flight per lane
+// cube [p - R, p + R] is evaluated; 16 rows per two memory latencies, four candidate loads in flight per lane
 __device__ __forceinline__ void bm_scan_box2(const GridDesc &g, const BmGrid &B, const float4 *__restrict__ ts, float px, float py, float pz, float R,
 											  uint32_t sub, nnkey &bk, float &sec)
 {
@@ -67,22 +67,22 @@ __device__ __forceinline__ void bm_scan_box2(const GridDesc &g, const BmGrid &B,
 		if (!nonempty)
 			continue;
 #pragma unroll
-		for (int half = 0; half < 2; half++)
-		{
-			if (!((nonempty >> (8 * half)) & 0xffu))
+		for (int quarter = 0; quarter < 4; quarter++) // four rows at a time: eight candidate records in flight per lane cost 13 more registers than the kernel has at
+		{											  // four waves per SIMD (-Rpass-analysis: 128 + 15 spilled against 115)
+			if (!((nonempty >> (4 * quarter)) & 0xfu))
 				continue;
-			float4 q[8];
-			bool ok[8];
+			float4 q[4];
+			bool ok[4];
 #pragma unroll
-			for (int jj = 0; jj < 8; jj++)
+			for (int jj = 0; jj < 4; jj++)
 			{
-				const uint32_t t = __shfl(lo, 8 * half + jj, MULLS_GRID_GROUP) + sub;
-				ok[jj] = t < __shfl(hi, 8 * half + jj, MULLS_GRID_GROUP);
+				const uint32_t t = __shfl(lo, 4 * quarter + jj, MULLS_GRID_GROUP) + sub;
+				ok[jj] = t < __shfl(hi, 4 * quarter + jj, MULLS_GRID_GROUP);
 				if (ok[jj])
 					q[jj] = ts[t];
 			}
 #pragma unroll
-			for (int jj = 0; jj < 8; jj++)
+			for (int jj = 0; jj < 4; jj++)
 				if (ok[jj])
 					take_one(q[jj], px, py, pz, bk, sec);
 		}
@@ -404,8 +404,19 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 				nn_idx[gi] = M[k];
 				nn_d2[gi] = D0[k];
 			}
-		if ((threadIdx.x & 63) == 0 && matched_cnt)
-			atomicAdd(&d.n_matched, matched_cnt);
+		// the class's |Corr| > 0 flag (k_filter's any_match: the count itself is never read) — one plain store per workgroup: an atomicAdd per wave was
+		// 1700 atomics on one word for a 108 k-point class cloud, 20 us of the launch's 35 (profiles/r04_large_steps.txt)
+		if ((threadIdx.x & 63) == 0)
+			CL.red[threadIdx.x >> 6] = matched_cnt;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			uint32_t any = 0;
+			for (int w = 0; w < BLK / 64; w++)
+				any |= CL.red[w];
+			if (any)
+				d.n_matched = 1u;
+		}
 		return;
 	}
 	if ((threadIdx.x & 63) == 0)

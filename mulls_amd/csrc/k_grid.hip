@@ -12,6 +12,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const uint32_t *__rest
 		bm[g.cell_off + w] = 0ull;
 }
 
+// Wave aggregation of the bitmap kernels' atomics.  A dense map puts hundreds of consecutive scan points into one cell (and thousands into one 64-cell
+// word): one atomic per point on the same address took 316 + 133 + 170 us for a 1 M-point map (profiles/r04_large_steps.txt).  The lanes of a wave that
+// share the address are served by one leader, MULLS_BM_ROUNDS distinct addresses per wave; what is left (sparse clouds: every lane its own cell) goes one by one.
+#define MULLS_BM_ROUNDS 4
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
 														  const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 														  unsigned long long *__restrict__ bm)
@@ -19,15 +23,35 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__
 	const Job job = tjobs[blockIdx.x];
 	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t t = job.start + threadIdx.x;
-	if (t >= d.tgt_n)
-		return;
-	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	const float4 p = tpos[d.tgt_off + t];
-	const uint32_t bit = bm_bit(g, p.x, p.y, p.z);
-	unsigned long long *word = &bm[g.cell_off + (bit >> 6)];
-	const unsigned long long b = 1ull << (bit & 63u);
-	if (!(__builtin_nontemporal_load(word) & b)) // dense maps put tens of points in a cell: most find their bit set already
-		atomicOr(word, b);
+	const int lane = threadIdx.x & 63;
+	bool pending = t < d.tgt_n;
+	uint32_t widx = 0xffffffffu;
+	unsigned long long b = 0ull;
+	if (pending)
+	{
+		const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+		const float4 p = tpos[d.tgt_off + t];
+		const uint32_t bit = bm_bit(g, p.x, p.y, p.z);
+		widx = g.cell_off + (bit >> 6);
+		b = 1ull << (bit & 63u);
+	}
+	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
+	{
+		const unsigned long long act = __ballot(pending);
+		if (!act)
+			break;
+		const int leader = __ffsll((long long)act) - 1;
+		const uint32_t lw = (uint32_t)__shfl((int)widx, leader);
+		const bool mine = pending && widx == lw;
+		unsigned long long v = mine ? b : 0ull;
+		for (int off = 32; off > 0; off >>= 1)
+			v |= __shfl_xor(v, off);
+		if (lane == leader && (__builtin_nontemporal_load(&bm[lw]) & v) != v) // most words of a dense map are complete after their first few waves
+			atomicOr(&bm[lw], v);
+		pending = pending && !mine;
+	}
+	if (pending && !(__builtin_nontemporal_load(&bm[widx]) & b))
+		atomicOr(&bm[widx], b);
 }
 
 __global__ __launch_bounds__(1024) void k_bm_scan(const uint32_t *__restrict__ lclouds, GridDesc *__restrict__ grids, const unsigned long long *__restrict__ bm,
@@ -52,11 +76,30 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict_
 	const uint32_t ci = job.pair * MULLS_NC + job.cls;
 	const CloudDesc &d = descs[ci];
 	const uint32_t t = job.start + threadIdx.x;
-	if (t >= d.tgt_n)
-		return;
-	const GridDesc g = grids[ci];
-	const float4 p = tpos[d.tgt_off + t];
-	atomicAdd(&cnt[d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z))], 1u);
+	const int lane = threadIdx.x & 63;
+	bool pending = t < d.tgt_n;
+	uint32_t r = 0xffffffffu; // counter of this point's cell
+	if (pending)
+	{
+		const GridDesc g = grids[ci];
+		const float4 p = tpos[d.tgt_off + t];
+		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
+	}
+	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
+	{
+		const unsigned long long act = __ballot(pending);
+		if (!act)
+			break;
+		const int leader = __ffsll((long long)act) - 1;
+		const uint32_t lr = (uint32_t)__shfl((int)r, leader);
+		const bool mine = pending && r == lr;
+		const unsigned long long m = __ballot(mine);
+		if (lane == leader)
+			atomicAdd(&cnt[lr], (uint32_t)__popcll(m));
+		pending = pending && !mine;
+	}
+	if (pending)
+		atomicAdd(&cnt[r], 1u);
 }
 
 // counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors
@@ -77,7 +120,8 @@ __global__ __launch_bounds__(1024) void k_bm_starts(const uint32_t *__restrict__
 		s[g.nocc] = total;
 }
 
-// counting-sort scatter: target positions ordered by cell, original index carried in .w
+// counting-sort scatter: target positions ordered by cell, original index carried in .w (the order inside a cell is whatever the atomics give: every
+// consumer breaks distance ties by original index)
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
 															 const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 															 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
@@ -87,13 +131,38 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restric
 	const uint32_t ci = job.pair * MULLS_NC + job.cls;
 	const CloudDesc &d = descs[ci];
 	const uint32_t t = job.start + threadIdx.x;
-	if (t >= d.tgt_n)
-		return;
-	const GridDesc g = grids[ci];
-	const float4 p = tpos[d.tgt_off + t];
-	const uint32_t r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
-	const uint32_t slot = cs[r] + atomicAdd(&cnt[r], 1u);
-	tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
+	const int lane = threadIdx.x & 63;
+	const bool in = t < d.tgt_n;
+	bool pending = in;
+	uint32_t r = 0xffffffffu, slot = 0;
+	float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (in)
+	{
+		const GridDesc g = grids[ci];
+		p = tpos[d.tgt_off + t];
+		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
+	}
+	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
+	{
+		const unsigned long long act = __ballot(pending);
+		if (!act)
+			break;
+		const int leader = __ffsll((long long)act) - 1;
+		const uint32_t lr = (uint32_t)__shfl((int)r, leader);
+		const bool mine = pending && r == lr;
+		const unsigned long long m = __ballot(mine);
+		uint32_t base = 0;
+		if (lane == leader)
+			base = cs[lr] + atomicAdd(&cnt[lr], (uint32_t)__popcll(m));
+		base = (uint32_t)__shfl((int)base, leader);
+		if (mine)
+			slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		pending = pending && !mine;
+	}
+	if (pending)
+		slot = cs[r] + atomicAdd(&cnt[r], 1u);
+	if (in)
+		tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

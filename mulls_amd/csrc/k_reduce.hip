@@ -52,20 +52,20 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
 		if (rp.used[c]) // unused classes contribute nothing: their slots are not even sent over PCIe
 		{
-			// the trip partials in trip order (the library's one summation order).  A dense class cloud has a hundred of them: eight loads in flight, then
+			// the trip partials in trip order (the library's one summation order).  A dense class cloud has a hundred of them: sixteen loads in flight, then
 			// the chain of adds — one lane's dependent round trips were 41 us of a 236 k-point pair's 170 us iteration (profiles/r04_large_base.txt)
 			constexpr uint32_t STEP = MULLS_ACC_LANES / MULLS_SRC_PER_BLOCK; // the jobs that start a trip (k_accum)
 			double sum = 0.0;
 			uint32_t j = pd[c].job_begin;
 			const uint32_t je = pd[c].job_end;
-			for (; j + 8u * STEP <= je; j += 8u * STEP)
+			for (; j + 16u * STEP <= je; j += 16u * STEP)
 			{
-				double v[8];
+				double v[16];
 #pragma unroll
-				for (uint32_t k = 0; k < 8u; k++)
+				for (uint32_t k = 0; k < 16u; k++)
 					v[k] = partial[(size_t)(j + k * STEP) * MULLS_NTERM + t];
 #pragma unroll
-				for (uint32_t k = 0; k < 8u; k++)
+				for (uint32_t k = 0; k < 16u; k++)
 					sum += v[k];
 			}
 			for (; j < je; j += STEP)

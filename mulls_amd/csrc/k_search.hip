@@ -538,15 +538,17 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	return 0;
 }
 
-void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, bool splittable, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
+void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
 					 const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
 					 float *nn_d2, unsigned long long *winner, const float4 *tpos, const float4 *tnrm, int32_t *nn_hint, int32_t *match, float *wd, float4 *mq)
 {
 	if (!njobs)
 		return;
-	// few chunk-level jobs (one dense scan pair): several workgroups share a 512-query job so that the chip is not left idle
+	// few chunk-level jobs: several workgroups share a 512-query job so that the chip is not left idle — up to max_wgs workgroups.  Splitting pays while the
+	// jobs still search (first iterations: the caller allows four rounds of resident workgroups); once every point certifies a split launch is only more
+	// workgroups for the same walk (a 236 k-point pair: 1860 workgroups took 30 us where 465 take 12), so later launches stop at one round
 	uint32_t split = 1;
-	while (splittable && split < 16 && njobs * split < 1024u)
+	while (split < 16 && njobs * split * 2u <= max_wgs)
 		split <<= 1;
 	hipLaunchKernelGGL(k_cert_big, dim3(njobs * split), dim3(MULLS_BIG_BLOCK), 0, st, jobs, descs, states, rp, spos, snrm, grids, bm, pf, cs, tsorted, flag, nn_idx, nn_d2, winner,
 					   split, tpos, tnrm, nn_hint, match, wd, mq);

@@ -11,18 +11,24 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 															float4 *__restrict__ tmp_pos, float4 *__restrict__ tmp_nrm,
 															uint32_t *__restrict__ bbox /* [pair][6] ordered keys */, RunParams rp)
 {
+	__shared__ uint32_t box_red[MULLS_BLOCK / 64][6];
 	const Job job = jobs[blockIdx.x];
 	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
-	const uint32_t s = job.start + threadIdx.x;
 	// motion undistortion regenerates the five non-vertex clouds from block2->pc_*_down (cregistration.hpp:1251-1253)
 	const bool regen = rp.undistort && job.cls != 5;
 	const uint32_t n_in = regen ? d.sd_n0 : d.src_n0;
-	const bool in = s < n_in;
 	const PairSetup &su = setup[job.pair];
 	const double *G = su.guess;
-	float x = 0, y = 0, z = 0;
-	if (in)
+	uint32_t k[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+	// job.count consecutive 256-point chunks (0 = one): a dense scan's clouds take eight per workgroup, so that the box below costs a few hundred atomics on
+	// the pair's six words instead of tens of thousands (250 us of a 236 k-point pair's setup, profiles/r04_large_base.txt)
+	const uint32_t reps = job.count ? job.count : 1u;
+	for (uint32_t rep_chunk = 0; rep_chunk < reps; rep_chunk++)
 	{
+		const uint32_t s = job.start + rep_chunk * MULLS_BLOCK + threadIdx.x;
+		if (s >= n_in)
+			continue;
+		float x = 0, y = 0, z = 0;
 		float4 a, b; // a = x y z intensity, b = nx ny nz curvature
 		if (regen)
 			load_staged(stage, d.sd_stage, (d.stage_fmt >> 4) & 3u, d.sd_n0, s, a, b);
@@ -63,10 +69,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 				a.z = (float)(rz + t * su.inv_t[2]);
 			}
 		}
-		const int reps = (rp.undistort && job.cls == 5) ? 2 : 1; // the vertex cloud is not regenerated: it receives the guess twice
-		float onx = b.x, ony = b.y, onz = b.z;					  // (cregistration.hpp:1183 and :1257)
+		const int reps_g = (rp.undistort && job.cls == 5) ? 2 : 1; // the vertex cloud is not regenerated: it receives the guess twice
+		float onx = b.x, ony = b.y, onz = b.z;						 // (cregistration.hpp:1183 and :1257)
 		x = a.x, y = a.y, z = a.z;
-		for (int rep = 0; rep < reps; rep++)
+		for (int rep = 0; rep < reps_g; rep++)
 		{
 			const double px = x, py = y, pz = z, nx = onx, ny = ony, nz = onz;
 			x = (float)(G[0] * px + G[1] * py + G[2] * pz + G[3]);
@@ -78,32 +84,32 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 		}
 		tmp_pos[d.src_off + s] = make_float4(x, y, z, a.w);
 		tmp_nrm[d.src_off + s] = make_float4(onx, ony, onz, b.w);
+		k[0] = min(k[0], f2ord(x)), k[1] = min(k[1], f2ord(y)), k[2] = min(k[2], f2ord(z));
+		k[3] = max(k[3], f2ord(x)), k[4] = max(k[4], f2ord(y)), k[5] = max(k[5], f2ord(z));
 	}
 	if (job.cls == 0 || job.cls == 1 || job.cls == 2)
 	{
-		uint32_t k[6];
-		k[0] = in ? f2ord(x) : 0xffffffffu;
-		k[1] = in ? f2ord(y) : 0xffffffffu;
-		k[2] = in ? f2ord(z) : 0xffffffffu;
-		k[3] = in ? f2ord(x) : 0u;
-		k[4] = in ? f2ord(y) : 0u;
-		k[5] = in ? f2ord(z) : 0u;
+		// the bounding box of the transformed ground / pillar / facade source clouds (cregistration.hpp:2912-2915): wave, workgroup, then six atomics
 		for (int off = 32; off > 0; off >>= 1)
 			for (int j = 0; j < 3; j++)
 			{
 				k[j] = min(k[j], (uint32_t)__shfl_down(k[j], off));
 				k[3 + j] = max(k[3 + j], (uint32_t)__shfl_down(k[3 + j], off));
 			}
-		// a wave only sends what moves the box: the keys are monotone under the atomics, so a value that does not beat what a (possibly stale) read returns
-		// cannot beat the entry either — a dense scan's thousands of waves on six words were 250 us of its setup (profiles/r04_large_base.txt)
 		if ((threadIdx.x & 63) == 0)
-			for (int j = 0; j < 3; j++)
-			{
-				if (k[j] < __builtin_nontemporal_load(&bbox[job.pair * 6 + j]))
-					atomicMin(&bbox[job.pair * 6 + j], k[j]);
-				if (k[3 + j] > __builtin_nontemporal_load(&bbox[job.pair * 6 + 3 + j]))
-					atomicMax(&bbox[job.pair * 6 + 3 + j], k[3 + j]);
-			}
+			for (int j = 0; j < 6; j++)
+				box_red[threadIdx.x >> 6][j] = k[j];
+		__syncthreads();
+		if (threadIdx.x < 6)
+		{
+			uint32_t v = box_red[0][threadIdx.x];
+			for (int w = 1; w < MULLS_BLOCK / 64; w++)
+				v = threadIdx.x < 3 ? min(v, box_red[w][threadIdx.x]) : max(v, box_red[w][threadIdx.x]);
+			if (threadIdx.x < 3 && v != 0xffffffffu)
+				atomicMin(&bbox[job.pair * 6 + threadIdx.x], v);
+			else if (threadIdx.x >= 3 && v != 0u)
+				atomicMax(&bbox[job.pair * 6 + threadIdx.x], v);
+		}
 	}
 }
 

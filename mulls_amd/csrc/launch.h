@@ -28,8 +28,9 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
 				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells,
 				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity);
-// global-memory tier (big_tier.h): class-level (MULLS_JOB_CLASS) and chunk-level jobs; splittable: chunk-level jobs may be shared by several workgroups
-void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, bool splittable, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
+// global-memory tier (big_tier.h): class-level (MULLS_JOB_CLASS) and chunk-level jobs; max_wgs: chunk-level jobs are shared by 2 / 4 / 8 / 16 workgroups while
+// the launch stays within this many
+void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,
 					 const GridDesc *grids, const unsigned long long *bm, const uint32_t *pf, const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
 					 float *nn_d2, unsigned long long *winner, const float4 *tpos, const float4 *tnrm, int32_t *nn_hint, int32_t *match, float *wd, float4 *mq);
 void launch_nn(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,

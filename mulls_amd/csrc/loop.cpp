@@ -222,12 +222,15 @@ RUN_ALIASES
 		return MULLS_E_HIP;
 	}
 	// mixed batch, first iterations: chunk-level jobs for every cloud of the global-memory tier (MULLS_OPT_BIG_EARLY_SETS)
-	const bool early = L.ejob_n && iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS];
+	// ... and every iteration of a small one: a handful of class-level workgroups cannot search a dense map's leftovers fast enough (a 1 M-point map leaves most
+	// points uncertified for ten iterations: its second-nearest targets are millimetres behind the nearest), while k_filter costs such a batch 6 us
+	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
+	const uint32_t max_wgs = iter < 3 ? 2048u : 512u; // (resident workgroups of k_cert_big: two per CU)
 	if (early)
-		launch_cert_big(sst, L.ejob_n, B->ejobs + L.ejob_lo, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
+		launch_cert_big(sst, L.ejob_n, B->ejobs + L.ejob_lo, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
 						B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 	else if (L.bjob_n)
-		launch_cert_big(sst, L.bjob_n, B->bjobs + L.bjob_lo, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
+		launch_cert_big(sst, L.bjob_n, B->bjobs + L.bjob_lo, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
 						B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 	if (rp.normal_shooting)
 		launch_nn_shoot(sst, L.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);

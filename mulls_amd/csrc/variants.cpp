@@ -133,7 +133,7 @@ extern "C"
 					return MULLS_E_HIP;
 			}
 			else if (tier == 1)
-				launch_cert_big(st, (uint32_t)B->bjobs_h.size(), B->bjobs, true, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag,
+				launch_cert_big(st, (uint32_t)B->bjobs_h.size(), B->bjobs, 2048u, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag,
 								B->nn_idx, B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 			else
 				launch_nn(st, B->njobs, B->jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);

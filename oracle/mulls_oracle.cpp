@@ -1338,15 +1338,15 @@ void quat_rotate(const Quat &q, const double v[3], double out[3])
 	out[1] = v[1] + q.w * uvy + (uz * uvx - ux * uvz);
 	out[2] = v[2] + q.w * uvz + (ux * uvy - uy * uvx);
 }
-// CFilter::apply_motion_compensation(in, out, Tran) (cfilter.hpp:493-516); serial restatement
-void apply_motion_compensation(const Cloud &in, Cloud &out, const M4 &Tran)
+// CFilter::apply_motion_compensation(in, out, Tran, s_ambigous_thre) (cfilter.hpp:493-516; the in-place overload :470-491 is the same loop); serial restatement
+void apply_motion_compensation(const Cloud &in, Cloud &out, const M4 &Tran, float s_ambigous_thre = 0.0f)
 {
 	out = in;
 	Quat q21 = quat_from_matrix(Tran);
 	for (size_t i = 0; i < in.size(); i++)
 	{
 		float s = in[i].curvature;
-		if (s < 0.0f || s > 1.0 - 0.0f)
+		if (s < s_ambigous_thre || s > 1.0 - s_ambigous_thre) // curvature as the timestamp (float against float; float against the double 1.0 - thre)
 			continue;
 		Quat dq = slerp_from_identity((double)s, q21);
 		double v[3] = {in[i].x, in[i].y, in[i].z}, r[3];
@@ -2011,6 +2011,20 @@ extern "C"
 		transform_cloud(c, m);
 		for (uint32_t i = 0; i < n; i++)
 			std::memcpy((uint8_t *)pts + (size_t)i * stride, &c[i], sizeof(Pt));
+		return 0;
+	}
+
+	// same contract as mulls_motion_compensate (include/mulls_hip.h): CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre), cfilter.hpp:470-491
+	int mulls_oracle_motion_compensate(void *pts, uint32_t n, uint32_t stride, const double Tran[16], float s_ambigous_thre)
+	{
+		Cloud c, o;
+		mulls_cloud mc = {pts, n, stride};
+		load_cloud(mc, c);
+		M4 m;
+		std::memcpy(m.a, Tran, sizeof(m.a));
+		apply_motion_compensation(c, o, m, s_ambigous_thre);
+		for (uint32_t i = 0; i < n; i++)
+			std::memcpy((uint8_t *)pts + (size_t)i * stride, &o[i], sizeof(Pt));
 		return 0;
 	}
 

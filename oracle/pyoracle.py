@@ -50,6 +50,17 @@ def transform(pts, T):
     return pts
 
 
+def motion_compensate(pts, Tran, s_ambiguous_thre=0.0, fn=None):
+    """CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre) (cfilter.hpp:470-491) on a copy of pts."""
+    pts = np.ascontiguousarray(pts).copy()
+    Tc = (C.c_double * 16)(*np.asarray(Tran, dtype=np.float64).T.reshape(-1))
+    f = fn if fn is not None else lib().mulls_oracle_motion_compensate
+    rc = f(C.c_void_p(pts.ctypes.data), C.c_uint32(len(pts)), C.c_uint32(abi.POINT_BYTES), Tc, C.c_float(s_ambiguous_thre))
+    if rc != 0:
+        raise RuntimeError("motion_compensate returned %d" % rc)
+    return pts
+
+
 def correspond(src, tgt, dis_thre, normal_check=True, angle_deg=45.0, nn_mode=0):
     n = len(src)
     match = np.zeros(n, np.int32)

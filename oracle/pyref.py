@@ -55,6 +55,13 @@ def icp_4dof_global(pair, heading_step_d, station, max_iter_num=20, dis_thre_uni
     return res, bool(ok.value)
 
 
+def motion_compensate(pts, Tran, s_ambiguous_thre=0.0):
+    """CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre), the reference's own lines (cfilter.hpp:470-491)."""
+    from oracle import pyoracle
+
+    return pyoracle.motion_compensate(pts, Tran, s_ambiguous_thre, fn=lib().mulls_ref_motion_compensate)
+
+
 def map_update(map_clouds, map_pose, frame_down, frame_pose, params):
     """MapManager::update_local_map, the reference's own lines (src/map_manager.cpp:18-256)."""
     from oracle import pyoracle

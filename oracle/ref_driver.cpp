@@ -112,6 +112,21 @@ extern "C" int mulls_ref_ground_filter(const void *pts, uint32_t n, uint32_t str
 	return 0;
 }
 
+// CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre), the reference's own lines (cfilter.hpp:470-491), in place on 48-byte records
+extern "C" int mulls_ref_motion_compensate(void *pts, uint32_t n, uint32_t stride, const double Tran[16], float s_ambigous_thre)
+{
+	pcTPtr pc(new pcT);
+	mulls_cloud c = {pts, n, stride};
+	fill_cloud(c, pc);
+	Eigen::Matrix4d T;
+	std::memcpy(T.data(), Tran, sizeof(double) * 16);
+	lo::CFilter<Point_T> cf;
+	cf.apply_motion_compensation(pc, T, s_ambigous_thre);
+	for (uint32_t i = 0; i < n; i++)
+		std::memcpy((unsigned char *)pts + (size_t)i * stride, &pc->points[i], sizeof(Point_T));
+	return 0;
+}
+
 extern "C" int mulls_ref_icp_3dof_ground(const mulls_pair *pair, const mulls_params *P, mulls_result *R)
 {
 	lo::constraint_t con;

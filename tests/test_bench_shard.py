@@ -75,3 +75,25 @@ def test_global_pair_list_is_rank_independent():
     assert spans[0] == (0, 128) and spans[7] == (896, 1024)
     args = bench.parse_args(["--pairs", "4096", "--gpus", "2"])
     assert bench.rank_span(args, 2, 1) == (4096, 8192)
+
+
+def test_config_flag_selects_every_baseline_configuration():
+    """bench.py --config k: 0 / 3 are aliases of --data demo / --total-pairs 1024, 2 / 4 the large-cloud lines with the headline line's JSON shape
+    (tiny plumbing sizes here, the CPU oracle as the engine; two gloo ranks for configs[2])."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.parse_args([]).config == 1 and bench.parse_args([]).total_pairs == 0  # the driver's default line is configs[1]
+    assert bench.parse_args(["--config", "0"]).data == "demo"
+    assert bench.parse_args(["--config", "3"]).total_pairs == 1024 and bench.parse_args(["--config", "3", "--total-pairs", "64"]).total_pairs == 64
+    common = ["--tiny", "--steps", "1", "--warmup", "0"]
+    p4 = _run([sys.executable, SHIM, "--config", "4"] + common)
+    assert p4.returncode == 0, p4.stderr[-2000:]
+    j4 = _json_line(p4.stdout)
+    assert j4["config"]["workload"].startswith("configs[4]") and j4["unit"] == "registrations/s" and j4["scaling"] == "weak" and j4["dtype"] == "f32"
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j4["roofline"]) and j4["roofline"]["whole_path"]["B_reg_bytes_per_registration"] > 0
+    assert j4["cpu_baseline"]["kind"] == "port" and j4["delta_T_vs_ref"]["integer_outputs_equal"]
+    p2 = _run([sys.executable, SHIM, "--config", "2", "--gpus", "2", "--no-cpu-baseline"] + common)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    j2 = _json_line(p2.stdout)
+    assert j2["n_gpus"] == 2 and j2["config"]["workload"].startswith("configs[2]") and j2["config"]["pairs_per_step"] == 2 * j2["config"]["pairs_per_gpu_per_step"]
