@@ -579,6 +579,36 @@ inline bool classify_nground_pts(typename pcl::PointCloud<PointT>::Ptr &cloud_in
 	return 1;
 }
 
+// CFilter<PointT>::apply_motion_compensation (include/common/cfilter.hpp:470-491), verbatim signature: the frame's points moved by their time-stamp
+// fraction of Tran, in place (mulls_motion_compensate: one upload, one kernel, one download).  test/mulls_slam.cpp:705 binds it with one early return.
+template <typename PointT>
+inline void apply_motion_compensation(typename pcl::PointCloud<PointT>::Ptr pc_in_out, Eigen::Matrix4d &Tran, float s_ambigous_thre = 0.000)
+{
+	static_assert(sizeof(PointT) == MULLS_POINT_BYTES, "in-place compensation expects 48-byte pcl::PointXYZINormal records");
+	if (pc_in_out->points.empty())
+		return;
+	mulls_ctx *ctx = thread_context();
+	const int rc = mulls_motion_compensate(ctx, pc_in_out->points.data(), static_cast<uint32_t>(pc_in_out->points.size()), MULLS_POINT_BYTES, Tran.data(), s_ambigous_thre);
+	if (rc != MULLS_OK)
+		throw std::runtime_error(std::string("mulls_motion_compensate failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
+}
+// CFilter<PointT>::batch_apply_motion_compensation, the in-place overload (cfilter.hpp:519-531), verbatim signature (the argument NAMES are upstream's:
+// test/mulls_slam.cpp:706-710 passes facade third and beam fourth, which makes no difference — every cloud gets the same treatment)
+template <typename PointT>
+inline void batch_apply_motion_compensation(typename pcl::PointCloud<PointT>::Ptr pc_ground, typename pcl::PointCloud<PointT>::Ptr pc_pillar,
+											typename pcl::PointCloud<PointT>::Ptr pc_beam, typename pcl::PointCloud<PointT>::Ptr pc_facade,
+											typename pcl::PointCloud<PointT>::Ptr pc_roof, typename pcl::PointCloud<PointT>::Ptr pc_vertex, Eigen::Matrix4d &Tran,
+											bool undistort_keypoints_or_not = false)
+{
+	apply_motion_compensation<PointT>(pc_ground, Tran);
+	apply_motion_compensation<PointT>(pc_pillar, Tran);
+	apply_motion_compensation<PointT>(pc_beam, Tran);
+	apply_motion_compensation<PointT>(pc_facade, Tran);
+	apply_motion_compensation<PointT>(pc_roof, Tran);
+	if (undistort_keypoints_or_not)
+		apply_motion_compensation<PointT>(pc_vertex, Tran);
+}
+
 // CFilter<PointT>::voxel_downsample (include/common/cfilter.hpp:83-160), verbatim signature
 template <typename PointT>
 inline bool voxel_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_in, typename pcl::PointCloud<PointT>::Ptr &cloud_out, float voxel_size)

@@ -522,6 +522,16 @@ int mulls_block_cloud(mulls_ctx *ctx, const mulls_block *block, int which, mulls
 /* copy cloud `which` back to the host (48-byte records); *n receives its size, at most cap records are written */
 int mulls_block_download(mulls_ctx *ctx, const mulls_block *block, int which, void *pts, uint32_t cap, uint32_t *n);
 
+/* ---- motion compensation of a frame after its registration (test/mulls_slam.cpp:703-712, on in the 32- and 128-beam configurations) ----
+ * mulls_motion_compensate = CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre) (cfilter.hpp:470-491), in place on `n` 48-byte records: every
+ * point whose time stamp t (the curvature field, pts time-stamp ratio in the frame) lies in [thre, 1 - thre] is moved by the fraction t of Tran — slerp of the
+ * rotation from the identity, t times the translation, double arithmetic, float store; directions are left as they are.  Tran: 4 x 4, column-major.
+ * pts: host memory (one upload, one download) or a device-resident cloud (mulls_block_cloud, mulls_map_cloud: in place, nothing crosses PCIe).
+ * mulls_block_motion_compensate = the two batch_apply_motion_compensation calls of mulls_slam.cpp:706-710 on a device-resident feature block: its ground /
+ * pillar / facade / beam / roof clouds and their *_down clouds (the vertex cloud only with undistort_keypoints, which no caller of the reference sets). */
+int mulls_motion_compensate(mulls_ctx *ctx, void *pts, uint32_t n, uint32_t stride, const double Tran[16], float s_ambiguous_thre);
+int mulls_block_motion_compensate(mulls_ctx *ctx, mulls_block *block, const double Tran[16], int undistort_keypoints);
+
 /* CFilter::voxel_downsample (cfilter.hpp:83-160): one point per occupied voxel of edge voxel_size, voxels in increasing index
  * ((vx * ny + vy) * nz + vz from the cloud's minimum corner), the point of a voxel being the one std::sort leaves first among that voxel's
  * (voxel, index) pairs, exactly as upstream (bounding box and voxel indices on the device, that one sort on the host).  voxel_size < 0.001

@@ -60,6 +60,36 @@ int subbatch_count(const mulls_ctx *ctx, int n)
 	return n < 2 ? 1 : nsub;
 }
 
+// Is `*value` acceptable for `option`?  Options are cast to counts and sizes where they are used (no option changes a result, but a negative or infinite
+// value would be an undefined cast, a huge one an absurd allocation): finite, inside the option's range; the array stagger is rounded down to a multiple of
+// 256 bytes (the per-point arrays hold float4 records).
+bool option_value_ok(int option, double *value)
+{
+	const double v = *value;
+	if (!(v == v) || v > 1.0e15 || v < -1.0e15)
+		return false;
+	switch (option)
+	{
+	case MULLS_OPT_STAGGER:
+		if (v < 0.0 || v > 65536.0)
+			return false;
+		*value = (double)((uint64_t)v & ~(uint64_t)255);
+		return true;
+	case MULLS_OPT_GRID_H0:
+	case MULLS_OPT_BM_H0:
+		return v >= 0.0 && v <= 1.0e4;
+	case MULLS_OPT_CERT_SLACK_MIN:
+	case MULLS_OPT_CERT_SLACK_MAX:
+		return v >= 0.0 && v <= 1.0e3;
+	case MULLS_OPT_CERT_SLACK_RATE:
+		return v >= 0.0 && v <= 1.0e3;
+	case MULLS_OPT_DEBUG_TICK:
+		return v >= 0.0 && v <= 4294967295.0;
+	default:
+		return v >= 0.0 && v <= 2147483647.0; // switches, pair counts, iteration counts
+	}
+}
+
 // defaults of enum mulls_option, then the presets from the environment (read here and nowhere else)
 void options_init(mulls_ctx *ctx)
 {
@@ -78,7 +108,11 @@ void options_init(mulls_ctx *ctx)
 			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}};
 	for (const auto &e : env)
 		if (const char *v = std::getenv(e.name))
-			o[e.opt] = std::strtod(v, nullptr);
+		{
+			double x = std::strtod(v, nullptr);
+			if (option_value_ok(e.opt, &x)) // (an unusable preset is ignored: the default stays)
+				o[e.opt] = x;
+		}
 	if (std::getenv("MULLS_NO_CERT"))
 		o[MULLS_OPT_CERTIFICATES] = 0;
 	if (std::getenv("MULLS_NO_LDS_DEDUP"))

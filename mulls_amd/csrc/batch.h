@@ -151,6 +151,7 @@ int check_params(mulls_ctx *ctx, const mulls_params *P);
 void init_cert(const mulls_ctx *ctx, RunParams &rp);
 int subbatch_count(const mulls_ctx *ctx, int n);
 void options_init(mulls_ctx *ctx);
+bool option_value_ok(int option, double *value);
 uint32_t lds_dedup_max_pts();
 void assign_tiers(mulls_batch *B, const uint8_t used[MULLS_NC], int mode);
 void build_jobs(mulls_batch *B, const mulls_params *P, int nsub, int mode);

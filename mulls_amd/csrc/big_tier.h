@@ -117,8 +117,10 @@ __device__ __forceinline__ void bm_scan_box2(const GridDesc &g, const BmGrid &B,
 //   hinted    the cube of q.w (>= the distance to the hinted target: it contains that target, so the sweep is complete);
 //   unhinted  the own cell, the cube of min(first-probe radius, best so far), then — while nothing lies inside the probed radius — one last cube
 //             of the distance found, or cubes of twice the radius up to the rejection radius r (k_nn_grid's policy, rounds 1-3).
+//             probe_own = false skips the own-cell probe: on a grid with one or two points per occupied cell it rarely bounds the search inside the cell and
+//             costs three dependent round trips of the query's six (a 236 k-point pair's first iteration: 2.2 ms of a 15 ms step, profiles/r04_large_steps.txt)
 __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid &B, const float4 *__restrict__ ts, const float4 q, float r, float m, uint32_t sub,
-												 nnkey &bk, float &sec, float &Rfin)
+												 bool probe_own, nnkey &bk, float &sec, float &Rfin)
 {
 	bk = NNKEY_NONE;
 	sec = __builtin_inff();
@@ -142,6 +144,11 @@ __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid 
 	if (q.w < __builtin_inff())
 	{
 		Rc = fminf(r, q.w);
+		sweep(Rc);
+	}
+	else if (!probe_own)
+	{
+		Rc = m;
 		sweep(Rc);
 	}
 	else
@@ -368,11 +375,12 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	if (U)
 	{
 		const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
+		const bool probe_own = tgt_n >= 4u * g.nocc; // dense cells (a map of many scans): the own cell first; a scan's own density: straight to the cube
 		for (uint32_t i = grp; i < U; i += BLK / MULLS_GRID_GROUP)
 		{
 			nnkey bk;
 			float sec, Rfin;
-			search_query_bm(g, B, ts, CL.uq[i], C.r, C.m, sub, bk, sec, Rfin);
+			search_query_bm(g, B, ts, CL.uq[i], C.r, C.m, sub, probe_own, bk, sec, Rfin);
 			if (sub == 0)
 			{
 				const uint32_t s = q0 + CL.us[i], gi = d.src_off + s;

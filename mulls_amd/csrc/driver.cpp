@@ -155,8 +155,13 @@ extern "C"
 
 	int mulls_set_option(mulls_ctx *ctx, int option, double value)
 	{
-		if (!ctx || option < 0 || option >= MULLS_OPT_COUNT || !(value == value))
+		if (!ctx || option < 0 || option >= MULLS_OPT_COUNT)
 			return MULLS_E_INVALID;
+		if (!option_value_ok(option, &value))
+		{
+			ctx->err = "mulls_set_option: value out of the option's range";
+			return MULLS_E_INVALID;
+		}
 		ctx->opt[option] = value;
 		return MULLS_OK;
 	}

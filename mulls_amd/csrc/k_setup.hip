@@ -477,8 +477,69 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_thin(CloudDesc *__restrict__ de
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre) (cfilter.hpp:470-491) on a cloud of 48-byte records in device memory: the point
+// with time stamp t = curvature in [thre, 1 - thre] moves by the fraction t of Tran — slerp from the identity quaternion (Eigen's
+// QuaternionBase::slerp), linear translation — in double, stored as float; directions, intensities and time stamps stay.  What mulls_slam applies to a
+// frame's clouds after its registration (test/mulls_slam.cpp:703-712); k_clone_src does the same inside a registration (cregistration.hpp:1251-1253).
+struct MotionComp
+{
+	double q[4]; // Eigen::Quaterniond(Tran.block<3,3>(0,0)): w x y z
+	double t[3]; // Tran.block<3,1>(0,3)
+	float thre;
+};
+__global__ __launch_bounds__(MULLS_BLOCK) void k_motion_comp(float4 *__restrict__ recs, uint32_t n, MotionComp M)
+{
+	const uint32_t i = blockIdx.x * MULLS_BLOCK + threadIdx.x;
+	if (i >= n)
+		return;
+	float4 a = recs[(size_t)i * 3];
+	const float sc = recs[(size_t)i * 3 + 2].y; // curvature
+	if (sc < M.thre || (double)sc > 1.0 - M.thre)
+		return;
+	const double t = (double)sc, one = 1.0 - 2.220446049250313e-16;
+	const double dq = M.q[0], absD = fabs(dq);
+	double s0, s1;
+	if (absD >= one)
+	{
+		s0 = 1.0 - t;
+		s1 = t;
+	}
+	else
+	{
+		const double theta = acos(absD), sinTheta = sin(theta);
+		s0 = sin((1.0 - t) * theta) / sinTheta;
+		s1 = sin((t * theta)) / sinTheta;
+	}
+	if (dq < 0)
+		s1 = -s1;
+	const double qw = s0 + s1 * M.q[0], qx = s1 * M.q[1], qy = s1 * M.q[2], qz = s1 * M.q[3];
+	const double vx = a.x, vy = a.y, vz = a.z;
+	const double uvx = 2.0 * (qy * vz - qz * vy), uvy = 2.0 * (qz * vx - qx * vz), uvz = 2.0 * (qx * vy - qy * vx);
+	const double rx = vx + qw * uvx + (qy * uvz - qz * uvy);
+	const double ry = vy + qw * uvy + (qz * uvx - qx * uvz);
+	const double rz = vz + qw * uvz + (qx * uvy - qy * uvx);
+	a.x = (float)(rx + t * M.t[0]);
+	a.y = (float)(ry + t * M.t[1]);
+	a.z = (float)(rz + t * M.t[2]);
+	recs[(size_t)i * 3] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
+
+void launch_motion_comp(hipStream_t st, float4 *recs, uint32_t n, const double q[4], const double t[3], float thre)
+{
+	if (!n)
+		return;
+	MotionComp M;
+	for (int k = 0; k < 4; k++)
+		M.q[k] = q[k];
+	for (int k = 0; k < 3; k++)
+		M.t[k] = t[k];
+	M.thre = thre;
+	hipLaunchKernelGGL(k_motion_comp, dim3((n + MULLS_BLOCK - 1) / MULLS_BLOCK), dim3(MULLS_BLOCK), 0, st, recs, n, M);
+}
 
 void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
 					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp)

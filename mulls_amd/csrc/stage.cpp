@@ -43,6 +43,81 @@ extern "C"
 		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
 	}
 
+	// ---- motion compensation of a frame's clouds after its registration (test/mulls_slam.cpp:703-712) ----------------------------------------------------
+	int mulls_motion_compensate(mulls_ctx *ctx, void *pts, uint32_t n, uint32_t stride, const double Tran[16], float s_ambiguous_thre)
+	try
+	{
+		if (!ctx || (n && !pts) || stride != MULLS_POINT_BYTES || !Tran)
+			return MULLS_E_INVALID;
+		if (!n)
+			return MULLS_OK;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		Mat4 T;
+		std::memcpy(T.v, Tran, sizeof(T.v));
+		double q[4];
+		mulls::rotation_quaternion(T, q); // Eigen::Quaterniond(Tran.block<3, 3>(0, 0)), cfilter.hpp:476
+		const double t[3] = {T.at(0, 3), T.at(1, 3), T.at(2, 3)};
+		if (mulls_is_map_memory(ctx, pts, (size_t)n * MULLS_POINT_BYTES))
+		{
+			// a device-resident cloud (mulls_block_cloud / mulls_map_cloud): in place, nothing crosses PCIe
+			launch_motion_comp(ctx->stream, static_cast<float4 *>(pts), n, q, t, s_ambiguous_thre);
+			HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+			return MULLS_OK;
+		}
+		float4 *d = nullptr;
+		if (dmalloc(ctx, &d, (size_t)n * 3) != MULLS_OK)
+			return MULLS_E_HIP;
+		hipError_t e = hipMemcpyAsync(d, pts, (size_t)n * MULLS_POINT_BYTES, hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess)
+		{
+			launch_motion_comp(ctx->stream, d, n, q, t, s_ambiguous_thre);
+			e = hipMemcpyAsync(pts, d, (size_t)n * MULLS_POINT_BYTES, hipMemcpyDeviceToHost, ctx->stream);
+		}
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(ctx->stream);
+		(void)hipFree(d);
+		if (e != hipSuccess)
+		{
+			ctx->err = hipGetErrorString(e);
+			return MULLS_E_HIP;
+		}
+		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
+
+	int mulls_block_motion_compensate(mulls_ctx *ctx, mulls_block *block, const double Tran[16], int undistort_keypoints)
+	try
+	{
+		if (!ctx || !block || !Tran)
+			return MULLS_E_INVALID;
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		Mat4 T;
+		std::memcpy(T.v, Tran, sizeof(T.v));
+		double q[4];
+		mulls::rotation_quaternion(T, q);
+		const double t[3] = {T.at(0, 3), T.at(1, 3), T.at(2, 3)};
+		// batch_apply_motion_compensation (cfilter.hpp:519-531) on the five class clouds, then on their *_down clouds, as test/mulls_slam.cpp:706-710 calls it;
+		// pc_vertex rides in both calls and moves only with undistort_keypoints (twice then, as upstream would)
+		static const int clouds[] = {MULLS_EX_GROUND, MULLS_EX_PILLAR + MULLS_CL_PILLAR, MULLS_EX_PILLAR + MULLS_CL_FACADE, MULLS_EX_PILLAR + MULLS_CL_BEAM,
+									 MULLS_EX_PILLAR + MULLS_CL_ROOF, MULLS_EX_GROUND_DOWN, MULLS_EX_PILLAR + MULLS_CL_PILLAR_DOWN, MULLS_EX_PILLAR + MULLS_CL_FACADE_DOWN,
+									 MULLS_EX_PILLAR + MULLS_CL_BEAM_DOWN, MULLS_EX_PILLAR + MULLS_CL_ROOF_DOWN};
+		for (int which : clouds)
+			if (block->n[which])
+				launch_motion_comp(ctx->stream, reinterpret_cast<float4 *>(block->buf + block->off[which]), block->n[which], q, t, 0.0f);
+		for (int rep = 0; rep < (undistort_keypoints ? 2 : 0); rep++)
+			if (block->n[MULLS_EX_VERTEX])
+				launch_motion_comp(ctx->stream, reinterpret_cast<float4 *>(block->buf + block->off[MULLS_EX_VERTEX]), block->n[MULLS_EX_VERTEX], q, t, 0.0f);
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		return MULLS_OK;
+	}
+	catch (...)
+	{
+		return mulls::abi_caught(const_cast<mulls_ctx *>(ctx)); // nothing is thrown across the ABI
+	}
+
 	namespace
 	{
 	// one-pair, one-class batch with identity guess and no intersection filter; leaves the batch set up (clone + crop run)

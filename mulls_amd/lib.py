@@ -86,6 +86,8 @@ def load():
     lib.mulls_extract_features_resident.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(abi.ExtractParams), vp, C.POINTER(C.c_uint32)]
     lib.mulls_block_cloud.argtypes = [vp, vp, C.c_int, C.POINTER(abi.Cloud)]
     lib.mulls_block_download.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.mulls_motion_compensate.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_float]
+    lib.mulls_block_motion_compensate.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_int]
     lib.mulls_voxel_downsample.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_float, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_kitti_bin.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.mulls_io_read_pcd.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -104,6 +106,7 @@ EXPORTS = [
     "mulls_io_write_pcd", "mulls_io_write_pose", "mulls_ground_default_params", "mulls_ground_filter",
     "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features", "mulls_voxel_downsample",
     "mulls_set_option", "mulls_get_option", "mulls_block_create", "mulls_block_destroy", "mulls_extract_features_resident", "mulls_block_cloud", "mulls_block_download",
+    "mulls_motion_compensate", "mulls_block_motion_compensate",
 ]
 
 
@@ -308,6 +311,13 @@ class Context:
         return out[: n_out.value].copy()
 
     # --- stage-level entry points --------------------------------------------------------------------------------
+    def motion_compensate(self, pts, Tran, s_ambiguous_thre=0.0):
+        """CFilter::apply_motion_compensation on a copy of a host cloud (structured array of 48-byte records)."""
+        raw = abi.records(pts).copy()  # every byte of the records kept (a copy of a record array would drop the bytes between its fields)
+        Tc = abi.colmajor16(Tran)
+        self._check(self.lib.mulls_motion_compensate(self.h, C.c_void_p(raw.ctypes.data), len(raw), abi.POINT_BYTES, Tc, C.c_float(s_ambiguous_thre)), "mulls_motion_compensate")
+        return abi.points_of(raw)
+
     def transform(self, pts, T):
         pts = np.ascontiguousarray(pts).copy()
         Tc = (C.c_double * 16)(*np.asarray(T, dtype=np.float64).T.reshape(-1))
@@ -406,6 +416,10 @@ class Block:
         if n.value:
             self.ctx._check(self.ctx.lib.mulls_block_download(self.ctx.h, self.h, which, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "mulls_block_download")
         return out
+
+    def motion_compensate(self, Tran, undistort_keypoints=False):
+        """the two batch_apply_motion_compensation calls of test/mulls_slam.cpp:706-710 on the block's clouds, in place on the device"""
+        self.ctx._check(self.ctx.lib.mulls_block_motion_compensate(self.ctx.h, self.h, abi.colmajor16(Tran), 1 if undistort_keypoints else 0), "mulls_block_motion_compensate")
 
     def class_clouds(self, down):
         """the six class clouds in the ABI's order (ground, pillar, facade, beam, roof, vertex) as device clouds: the *_down ones (+ pc_vertex) or the full ones"""

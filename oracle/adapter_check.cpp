@@ -211,6 +211,44 @@ int main(int argc, char **argv)
 		}
 		return 0;
 	}
+	if (std::string(argv[2]) == "motion")
+	{
+		// test/mulls_slam.cpp:703-712: the frame's clouds (block2 here: the *_down clouds and the key points) moved by their time-stamp fraction of the
+		// registration result — the reference's CFilter members vs the bridge functions of the same names, same arguments
+		for (int w = 0; w < 2; w++)
+		{
+			lo::cloudblock_t &b = *cons[w]->block2;
+			Eigen::Matrix4d T = initial_guess_tran;
+			if (w == 0)
+			{
+				lo::CFilter<Point_T> cf;
+				cf.apply_motion_compensation(b.pc_ground_down, T, 0.1f);
+				cf.batch_apply_motion_compensation(b.pc_ground_down, b.pc_pillar_down, b.pc_facade_down, b.pc_beam_down, b.pc_roof_down, b.pc_vertex, T);
+			}
+			else
+			{
+				lo::hip::apply_motion_compensation<Point_T>(b.pc_ground_down, T, 0.1f);
+				lo::hip::batch_apply_motion_compensation<Point_T>(b.pc_ground_down, b.pc_pillar_down, b.pc_facade_down, b.pc_beam_down, b.pc_roof_down, b.pc_vertex, T);
+			}
+			pcTPtr all[6] = {b.pc_ground_down, b.pc_pillar_down, b.pc_facade_down, b.pc_beam_down, b.pc_roof_down, b.pc_vertex};
+			printf("{\"who\": \"%s\", \"sizes\": [", w == 0 ? "reference" : "hip");
+			for (int k = 0; k < 6; k++)
+				printf("%s%zu", k ? ", " : "", all[k]->points.size());
+			printf("], \"xyz\": [");
+			bool first = true;
+			for (int k = 0; k < 6; k++)
+				for (size_t i = 0; i < all[k]->points.size(); i++)
+				{
+					const Point_T &p = all[k]->points[i];
+					unsigned int u[3];
+					std::memcpy(u, &p.x, 12);
+					printf("%s%u, %u, %u", first ? "" : ", ", u[0], u[1], u[2]);
+					first = false;
+				}
+			printf("]}\n");
+		}
+		return 0;
+	}
 	if (std::string(argv[2]) == "map")
 	{
 		// scan-to-map step of test/mulls_slam.cpp: mm_lls_icp against the local map (block1), then update_local_map with the

@@ -1990,6 +1990,10 @@ extern "C"
 			if (reset)
 				g_census[k] = 0;
 		}
+		// [7]: plane_ransac's stopping test (pcl_restated.h): evaluations (bits 0-31), those within 1e-9 of the boundary (32-47), disagreements of the two forms (48-63)
+		out[7] = (restated::ransac_census(2) & 0xffffffffull) | ((restated::ransac_census(0) & 0xffffull) << 32) | ((restated::ransac_census(1) & 0xffffull) << 48);
+		if (reset)
+			restated::ransac_census(0) = restated::ransac_census(1) = restated::ransac_census(2) = 0;
 	}
 
 	// nn_mode: 0 = kd-tree (the PCL/FLANN cost model), 1 = brute force (cross-check).  use_omp: 1 = the reference's
@@ -2023,8 +2027,8 @@ extern "C"
 		M4 m;
 		std::memcpy(m.a, Tran, sizeof(m.a));
 		apply_motion_compensation(c, o, m, s_ambigous_thre);
-		for (uint32_t i = 0; i < n; i++)
-			std::memcpy((uint8_t *)pts + (size_t)i * stride, &o[i], sizeof(Pt));
+		for (uint32_t i = 0; i < n; i++) // the reference assigns x, y, z of the point it was given: every other byte of the record stays (data[3], the padding)
+			std::memcpy((uint8_t *)pts + (size_t)i * stride, &o[i].x, 3 * sizeof(float));
 		return 0;
 	}
 

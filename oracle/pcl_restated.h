@@ -361,6 +361,14 @@ inline void smallest_eigenvector(const float cov6[6], float n[3])
 // dot of a plane (4 coefficients) with (x, y, z, w) as Eigen's 4-float packet reduction adds it up
 inline float plane_dot(const float c[4], float x, float y, float z, float w) { return (c[0] * x + c[2] * z) + (c[1] * y + c[3] * w); }
 
+// counters of plane_ransac's stopping test (oracle census, tests/test_pcl_operators.py): [0] evaluations with `iterations` within 1e-9 of k, [1] evaluations where
+// PCL's `iterations_ < k` and the libm-free product form disagree, [2] evaluations in all
+inline unsigned long long &ransac_census(int which)
+{
+	static unsigned long long c[3] = {0, 0, 0};
+	return c[which];
+}
+
 // pcl::SACSegmentation<PointT>::segment as CProceesing::plane_seg_ransac sets it up.  Out: the inliers (ascending indices) and the four
 // plane coefficients; false when no model could be found (upstream then leaves both outputs empty).
 inline bool plane_ransac(const std::vector<P4> &pts, double threshold, int max_iterations, std::vector<int> &inliers, float coeff[4])
@@ -378,14 +386,25 @@ inline bool plane_ransac(const std::vector<P4> &pts, double threshold, int max_i
 	bool have = false;
 	double p_no_outliers = 0.0;
 	const double one_over_indices = 1.0 / static_cast<double>(n), log_arg = 1.0 - 0.99; // probability_ = 0.99
+	double k = 1.0; // ransac.hpp: "double k = 1.0" — the loop is `while (iterations_ < k && ...)`
 	for (;;)
 	{
-		if (have) // while (iterations_ < k), k = log(1 - probability) / log(p_no_outliers)
+		if (have)
 		{
+			// PCL's own test, `iterations_ < k` with k = log(1 - probability_) / log(p_no_outliers) (std::log / std::pow as ransac.hpp calls them), decides.
+			// The device evaluates the same test without libm, as p_no_outliers^iterations > 1 - probability_ (k_gf_ransac: a product of doubles is the same bits
+			// on every platform); the two can only disagree when `iterations` sits within rounding of k — counted, and asserted to be 0 on the demo data
+			// (tests/test_pcl_operators.py)
 			double pw = 1.0;
 			for (int i = 0; i < iterations; i++)
 				pw *= p_no_outliers;
-			if (!(pw > log_arg))
+			const bool go_product = pw > log_arg, go = (double)iterations < k;
+			ransac_census(2)++;
+			if (std::fabs((double)iterations - k) <= 1e-9 * std::max(k, 1.0))
+				ransac_census(0)++;
+			if (go != go_product)
+				ransac_census(1)++;
+			if (!go)
 				break;
 		}
 		else if (iterations > 0)
@@ -431,9 +450,16 @@ inline bool plane_ransac(const std::vector<P4> &pts, double threshold, int max_i
 				best[k] = c[k];
 			have = true;
 			const double w = static_cast<double>(n_best) * one_over_indices;
-			p_no_outliers = 1.0 - w * w * w; // pow(w, 3.0)
+			p_no_outliers = 1.0 - w * w * w; // the device's form of pow(w, 3.0): feeds the product test above only
 			p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
 			p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+			{
+				// ransac.hpp: p_no_outliers = 1 - pow(w, selection.size()), clamped to [eps, 1 - eps]; k = log_probability / log(p_no_outliers)
+				double pno = 1.0 - std::pow(w, 3.0);
+				pno = std::max(std::numeric_limits<double>::epsilon(), pno);
+				pno = std::min(1.0 - std::numeric_limits<double>::epsilon(), pno);
+				k = std::log(1.0 - 0.99) / std::log(pno);
+			}
 		}
 		++iterations;
 		if (iterations > max_iterations)

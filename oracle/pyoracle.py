@@ -52,13 +52,13 @@ def transform(pts, T):
 
 def motion_compensate(pts, Tran, s_ambiguous_thre=0.0, fn=None):
     """CFilter::apply_motion_compensation(pc_in_out, Tran, s_ambigous_thre) (cfilter.hpp:470-491) on a copy of pts."""
-    pts = np.ascontiguousarray(pts).copy()
+    raw = abi.records(pts).copy()  # raw bytes: a copy of a RECORD array would drop the bytes between its fields (data[3], the padding), which the reference keeps
     Tc = (C.c_double * 16)(*np.asarray(Tran, dtype=np.float64).T.reshape(-1))
     f = fn if fn is not None else lib().mulls_oracle_motion_compensate
-    rc = f(C.c_void_p(pts.ctypes.data), C.c_uint32(len(pts)), C.c_uint32(abi.POINT_BYTES), Tc, C.c_float(s_ambiguous_thre))
+    rc = f(C.c_void_p(raw.ctypes.data), C.c_uint32(len(raw)), C.c_uint32(abi.POINT_BYTES), Tc, C.c_float(s_ambiguous_thre))
     if rc != 0:
         raise RuntimeError("motion_compensate returned %d" % rc)
-    return pts
+    return abi.points_of(raw)
 
 
 def correspond(src, tgt, dis_thre, normal_check=True, angle_deg=45.0, nn_mode=0):
@@ -171,7 +171,9 @@ def census(reset=False):
     out = (C.c_ulonglong * 8)()
     lib().mulls_oracle_census(out, int(reset))
     names = ("radius_tests", "radius_equal", "rejector_tests", "rejector_equal", "rejector_nan", "brute_queries", "brute_ties")
-    return {n: int(out[i]) for i, n in enumerate(names)}
+    d = {n: int(out[i]) for i, n in enumerate(names)}
+    d["ransac_tests"], d["ransac_near_boundary"], d["ransac_forms_disagree"] = int(out[7]) & 0xffffffff, (int(out[7]) >> 32) & 0xffff, int(out[7]) >> 48
+    return d
 
 
 def _ground_filter(fn, pts, params):

@@ -115,3 +115,28 @@ def test_adapter_feature_extraction_matches_reference_members():
     assert refv["sizes"][0] == refb["sizes"][0] and 1000 < refv["sizes"][1] < refv["sizes"][0]  # pc_raw as before, pc_down one point per voxel
     assert refv["rates"] == hipv["rates"] and refv["rates"][0] == 10 and 1 <= refv["rates"][1] < 20  # 20 - 200 / (facade_down + pillar_down)
     assert refb["rates"] == hipb["rates"] == [10, 3]
+
+
+def test_adapter_motion_compensation_matches_reference_members(pairs_small):
+    """test/mulls_slam.cpp:703-712 through the bridge: lo::hip::apply_motion_compensation / batch_apply_motion_compensation against the reference's CFilter
+    members on the same cloudblock_t (time stamps in the curvature field), float bit patterns compared (one ulp on at most 1e-4 of the coordinates: the
+    device's acos / sin against glibc's)."""
+    pair, T_gt = pairs_small[0]
+    rng = np.random.default_rng(5)
+    src = []
+    for c in pair.src:
+        c = c.copy()
+        c["curvature"] = rng.uniform(-0.05, 1.05, len(c)).astype(np.float32)
+        src.append(c)
+    stamped = abi.PairData(pair.tgt, src, init_guess=synth.se3(1.1, 0.04, -0.02, 0.003, -0.002, 0.03), tgt_bound=pair.tgt_bound)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "pair.bin")
+        dump(stamped, path)
+        out = subprocess.check_output([BIN, path, "motion"], timeout=120).decode().strip().split("\n")
+    ref, hip = json.loads(out[0]), json.loads(out[1])
+    assert ref["who"] == "reference" and hip["who"] == "hip" and ref["sizes"] == hip["sizes"] and sum(ref["sizes"]) > 1000
+    a, b = np.array(ref["xyz"], np.int64), np.array(hip["xyz"], np.int64)
+    d = np.abs(a - b)
+    assert d.max() <= 1 and (d != 0).sum() <= max(1, len(a) // 10000)
+    moved = np.array(ref["xyz"], np.uint32).view(np.float32).reshape(-1, 3)[: ref["sizes"][0]]
+    assert np.abs(moved - np.stack([src[0]["x"], src[0]["y"], src[0]["z"]], 1)).max() > 0.5  # the ground cloud really moved

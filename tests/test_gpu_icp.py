@@ -414,3 +414,21 @@ def test_normal_shooting_survives_nan_queries(ctx, pairs_small):
         compare(ro, rg)
     rb = ctx.icp_batch([p for p, _ in pairs_small] * 40, P)
     assert [r.code for r in rb[:3]] == [ctx.icp(p, P)[0].code for p, _ in pairs_small]
+
+
+def test_option_values_are_validated(ctx):
+    """mulls_set_option refuses what a cast to a count or a size could not take (non-finite, negative, absurd) and keeps the old value; the array stagger is
+    rounded down to a multiple of 256 bytes (the per-point arrays hold 16-byte records)."""
+    from mulls_amd import lib
+
+    before = ctx.get_option(abi.OPT_STAGGER)
+    for bad in (float("nan"), float("inf"), -1.0, 1e18):
+        for opt in (abi.OPT_STAGGER, abi.OPT_SPLIT_MIN_PAIRS, abi.OPT_CERT_SLACK_MIN, abi.OPT_GRID_H0):
+            with pytest.raises(lib.MullsError):
+                ctx.set_option(opt, bad)
+    assert ctx.get_option(abi.OPT_STAGGER) == before
+    ctx.set_option(abi.OPT_STAGGER, 4400)
+    assert ctx.get_option(abi.OPT_STAGGER) == 4352
+    ctx.set_option(abi.OPT_STAGGER, before)
+    with pytest.raises(lib.MullsError):
+        ctx.set_option(abi.OPT_COUNT, 1)

@@ -102,3 +102,35 @@ def test_strict_rejector_on_the_device(ctx):
     assert rg.code == ro.code == 1 and rg.iters == ro.iters and list(rg.ncorr) == list(ro.ncorr)
     dt, dr = synth.pose_error(np.array(rg.T[:]).reshape(4, 4).T, np.array(ro.T[:]).reshape(4, 4).T)
     assert dt <= 1e-7 and dr <= 1e-7
+
+
+def test_ransac_stopping_rule_is_pcl_s_and_never_near_its_boundary():
+    """pcl::RandomSampleConsensus::computeModel stops on `iterations_ < k`, k = log(1 - probability_) / log(1 - pow(w, 3)) (ransac.hpp).  The oracle evaluates
+    exactly that (std::pow, std::log); the device evaluates the libm-free equivalent p_no_outliers^iterations > 1 - probability_.  The two can only part when
+    `iterations` is within rounding of k: counted on the demo scan's and synthetic scans' ground cells (normal method 3, every shipped configuration) — no
+    evaluation within 1e-9 of the boundary, no disagreement of the two forms."""
+    import os
+
+    from mulls_amd import synth
+
+    scans = []
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_pair.npz")
+    if os.path.exists(gold):
+        g = np.load(gold)
+        for k in ("scan_0", "scan_15"):
+            s = g[k]
+            scans.append(abi.make_points(s[:, :3], np.zeros_like(s[:, :3]), s[:, 3], np.zeros(len(s), np.float32)))
+    for seed in (3, 4):
+        scene = synth.Scene(seed)
+        sc = synth.raycast(scene, synth.se3(0, 0, scene.sensor_height), 64, 1200, seed=seed)
+        scans.append(abi.make_points(sc["xyz"], np.zeros_like(sc["xyz"]), sc["intensity"], sc["t"]))
+    G = abi.ground_params(estimate_ground_normal_method=3)
+    pyoracle.census(reset=True)
+    cells = 0
+    for pts in scans:
+        ground = pyoracle.ground_filter(pts, G)[0]
+        cells += len(ground) > 0
+    c = pyoracle.census(reset=True)
+    print("plane RANSAC stopping test over %d scans: %s" % (len(scans), {k: v for k, v in c.items() if k.startswith("ransac")}))
+    assert cells == len(scans) and c["ransac_tests"] > 1000
+    assert c["ransac_near_boundary"] == 0 and c["ransac_forms_disagree"] == 0

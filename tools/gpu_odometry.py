@@ -3,7 +3,9 @@
 refresh of the linear features every 5th frame).  Synthetic drive through one scene; prints the time per frame by stage and the drift against
 the ground truth.  usage: gpu_odometry.py [frames] [--check N: run the first N frames through the oracle too and compare] [--host: the frame's
 feature clouds come back to the host and are uploaded again by the registration and the map update (the round-2 form); default: they stay in a
-device-resident feature block (mulls_extract_features_resident), only the scan, selection indices and the pose cross PCIe]"""
+device-resident feature block (mulls_extract_features_resident), only the scan, selection indices and the pose cross PCIe]
+[--motion-compensation 1: test/mulls_slam.cpp:703-712 — the frame's clouds are moved by their time-stamp fraction of the estimated motion before they enter the
+map (mulls_block_motion_compensate on the resident block; on in the reference's 32- and 128-beam configurations)]"""
 import sys, time, warnings
 sys.path.insert(0, "."); warnings.filterwarnings("ignore")
 import numpy as np
@@ -37,6 +39,7 @@ def main(argv=None):
     n_frames = int(argv[0]) if argv and not argv[0].startswith("-") else 12
     n_check = int(argv[argv.index("--check") + 1]) if "--check" in argv else 0
     resident = "--host" not in argv
+    mocomp = "--motion-compensation" in argv and argv[argv.index("--motion-compensation") + 1] not in ("0", "false")
     del frames_pose[1:]
     frames = raw_drive(11, n_frames)
     X = abi.extract_params(ground=abi.ground_params(fixed_num_downsampling=1, down_ground_fixed_num=800, rng_seed=1),
@@ -65,10 +68,18 @@ def main(argv=None):
             ex = ctx.extract_features(scan, X)
             full, down = block_of(ex)
         t1 = time.time()
+        if resident and k <= n_check:  # (the check's copy of the block, before the motion compensation moves its clouds)
+            ex = [None if n in (abi.EX_RAW, abi.EX_DOWN) else blk.download(n) for n in range(abi.EX_COUNT)]
         rg = dev.icp(down, P, init_guess=prev_rel, tgt_bound=bound)[0]  # constant-velocity guess
         t2 = time.time()
         rel = rg.T_matrix()
         pose = pose @ rel
+        if mocomp:
+            adjacent = np.linalg.inv(rel)  # adjacent_pose_out: frame k -> frame k + 1 (test/mulls_slam.cpp:699)
+            if resident:
+                blk.motion_compensate(adjacent)
+            else:
+                down = [ctx.motion_compensate(c, adjacent) if i < 5 else c for i, c in enumerate(down)]
         MP = abi.map_params(max_num_pts=20000, map_based_dynamic_removal_on=1, tree_mode=2 if rg.cropped else 1, tree_used="111000", tree_box=list(rg.crop_box),
                             recalculate_feature_on=1 if k % 5 == 0 else 0, rng_seed=k)
         rep = dev.update(down, pose, MP)
@@ -80,7 +91,6 @@ def main(argv=None):
         if k <= n_check:
             exo = pyoracle.extract_features(scan, X)
             if resident:
-                ex = [None if n in (abi.EX_RAW, abi.EX_DOWN) else blk.download(n) for n in range(abi.EX_COUNT)]
                 assert all(a is None or np.array_equal(a, b) for a, b in zip(ex, exo)), "features differ from the oracle's at frame %d" % k
             else:
                 assert all(np.array_equal(a, b) for a, b in zip(ex, exo)), "features differ from the oracle's at frame %d" % k
@@ -88,6 +98,8 @@ def main(argv=None):
             ro = pyoracle.icp(abi.PairData(host_map, do, init_guess=prev_rel, tgt_bound=bound), P)[0]
             dt, dr = synth.pose_error(rg.T_matrix(), ro.T_matrix())
             assert rg.code == ro.code and dt <= 1e-6 and dr <= 1e-6, (k, rg.code, ro.code, dt, dr)
+            if mocomp:
+                do = [pyoracle.motion_compensate(c, np.linalg.inv(rel)) if i < 5 else c for i, c in enumerate(do)]
             host_map, _, _ = pyoracle.map_update(host_map, frames_pose[-1], do, pose, MP)
             for c in range(6):
                 a, b = abi.records(dev.download(c)), abi.records(host_map[c])
@@ -99,7 +111,7 @@ def main(argv=None):
         bound = list(rep.local_bound)
         assert rg.code == 1, (k, rg.code)
     m = max(n_frames - 2, 1)
-    print(("feature block resident in HBM: " if resident else "feature clouds through the host: ") + "%d frames of %d returns: features %.2f ms, scan-to-map registration %.2f ms, map update %.2f ms per frame -> %.1f frames/s; drift after %.0f m: %.3f m, %.4f rad"
+    print(("motion compensation on; " if mocomp else "") + ("feature block resident in HBM: " if resident else "feature clouds through the host: ") + "%d frames of %d returns: features %.2f ms, scan-to-map registration %.2f ms, map update %.2f ms per frame -> %.1f frames/s; drift after %.0f m: %.3f m, %.4f rad"
           % (n_frames, len(frames[0][0]), t_feat / m * 1e3, t_reg / m * 1e3, t_map / m * 1e3, m / max(t_feat + t_reg + t_map, 1e-9),
              np.linalg.norm(frames[-1][1][:3, 3]), worst[0], worst[1]))
     if n_check:
