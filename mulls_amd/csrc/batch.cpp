@@ -709,12 +709,11 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	{
 		const int p1 = std::min(n, p0 + block);
 		const long c0 = (long)first_copy_of_pair[p0], c1 = (long)first_copy_of_pair[p1];
-		const int threads = (int)std::max<long>(1, std::min<long>(32, (c1 - c0) / 6));
-		(void)threads;
 		const auto t_pack0 = std::chrono::steady_clock::now();
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 2) if (threads > 1)
-		for (long i = c0; i < c1; i++)
-		{
+		// (the context's sleeping thread pool, not an OpenMP team: see HostPool, ctx.h)
+		if (!ctx->pool && c1 - c0 >= 12)
+			ctx->pool = new HostPool((int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2u)));
+		const std::function<void(long)> pack_one = [&](long i) {
 			const HostCopy &hc = host_copies[i];
 			float *pos = reinterpret_cast<float *>(hc.dst), *nrm = pos + (size_t)hc.n * 4;
 			const int nw = hc.fmt == MULLS_STAGE_PACK32 ? 4 : 3;
@@ -728,7 +727,12 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 				if (nw == 4)
 					nn[3] = r[9];
 			}
-		}
+		};
+		if (ctx->pool)
+			ctx->pool->parallel_for(c0, c1, 2, pack_one);
+		else
+			for (long i = c0; i < c1; i++)
+				pack_one(i);
 		pack_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_pack0).count();
 		// the staged clouds of pairs [p0, p1) are one contiguous range (offsets grow with the pair index)
 		const size_t r0 = B->descs_h[(size_t)p0 * MULLS_NC].src_stage;

@@ -3,7 +3,12 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <exception>
 #include <new>
@@ -15,6 +20,31 @@
 struct mulls_batch;
 struct mulls_map;
 struct mulls_block;
+
+// A few host threads that SLEEP between their jobs (condition variable), for the staging gather of mulls_icp_batch.  An OpenMP team keeps spinning after its
+// parallel region; 32 spinning threads inside a container with a CPU quota get the whole process throttled for the rest of the scheduler period: every fourth
+// call of a 1024-pair mulls_icp_batch took 63 ms instead of 12 (profiles/r04_e2e_calls.txt; OMP_WAIT_POLICY=passive showed the same cure).
+class HostPool
+{
+  public:
+	explicit HostPool(int n_threads);
+	~HostPool();
+	// fn(i) for every i in [begin, end), `grain` indices at a time, on the pool's threads and the caller's; returns when all are done
+	void parallel_for(long begin, long end, long grain, const std::function<void(long)> &fn);
+	int size() const { return (int)th_.size() + 1; }
+
+  private:
+	void worker();
+	std::vector<std::thread> th_;
+	std::mutex mu_;
+	std::condition_variable cv_, done_;
+	const std::function<void(long)> *fn_ = nullptr;
+	std::atomic<long> next_{0};
+	long end_ = 0, grain_ = 1;
+	unsigned long gen_ = 0;
+	int busy_ = 0;
+	bool stop_ = false;
+};
 
 struct mulls_ctx
 {
@@ -36,6 +66,7 @@ struct mulls_ctx
 	size_t cl_cap = 0;
 	size_t gf_cap = 0;
 	double opt[MULLS_OPT_COUNT] = {}; // enum mulls_option (mulls_set_option; preset from the environment by mulls_create)
+	HostPool *pool = nullptr; // host threads of the staging gather (made on first use)
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 

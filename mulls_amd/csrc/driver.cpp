@@ -36,6 +36,72 @@ void *staggered_base(void *p, bool forget)
 	return b;
 }
 
+HostPool::HostPool(int n_threads)
+{
+	for (int k = 1; k < n_threads; k++)
+		th_.emplace_back([this] { worker(); });
+}
+HostPool::~HostPool()
+{
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		stop_ = true;
+	}
+	cv_.notify_all();
+	for (std::thread &t : th_)
+		t.join();
+}
+void HostPool::worker()
+{
+	unsigned long seen = 0;
+	for (;;)
+	{
+		const std::function<void(long)> *fn;
+		long end, grain;
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+			if (stop_)
+				return;
+			seen = gen_;
+			fn = fn_, end = end_, grain = grain_;
+		}
+		for (long i = next_.fetch_add(grain); i < end; i = next_.fetch_add(grain))
+			for (long k = i; k < std::min(end, i + grain); k++)
+				(*fn)(k);
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			if (--busy_ == 0)
+				done_.notify_one();
+		}
+	}
+}
+void HostPool::parallel_for(long begin, long end, long grain, const std::function<void(long)> &fn)
+{
+	if (end <= begin)
+		return;
+	grain = std::max<long>(grain, 1);
+	if (th_.empty() || end - begin <= grain)
+	{
+		for (long k = begin; k < end; k++)
+			fn(k);
+		return;
+	}
+	{
+		std::lock_guard<std::mutex> lk(mu_);
+		fn_ = &fn, end_ = end, grain_ = grain;
+		next_.store(begin);
+		busy_ = (int)th_.size();
+		gen_++;
+	}
+	cv_.notify_all();
+	for (long i = next_.fetch_add(grain); i < end; i = next_.fetch_add(grain))
+		for (long k = i; k < std::min(end, i + grain); k++)
+			fn(k);
+	std::unique_lock<std::mutex> lk(mu_);
+	done_.wait(lk, [&] { return busy_ == 0; });
+}
+
 using namespace mulls_drv;
 
 extern "C"
@@ -107,6 +173,7 @@ extern "C"
 			(void)hipFree(ctx->cl_buf);
 		if (ctx->scratch)
 			mulls_batch_destroy(ctx, ctx->scratch);
+		delete ctx->pool;
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
 			mulls_map_destroy(ctx, ctx->maps.back());
 		while (!ctx->blocks.empty()) // ... and so do feature blocks
