@@ -243,16 +243,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 
 // One class-cloud job of the light pass: the one-pass walk for a whole class cloud that fits the lanes' registers (cert_class_flat), the general walk for
 // chunk-level jobs, larger clouds and classes that sit the iteration out.  Returns (to every lane) false when the class cloud needs the heavy pass.
-template <int BLK, int SMALL>
+template <int BLK, int SMALL, bool PARK = false>
 __device__ __forceinline__ bool cert_job(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W, float4 *__restrict__ spos,
 										  float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
 										  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm,
 										  int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint,
-										  float4 *__restrict__ mq)
+										  float4 *__restrict__ mq, uint32_t *park = nullptr)
 {
 	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
 	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
-	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true, SMALL>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq)
+	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true, SMALL, PARK>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, park)
 				: cert_class<BLK, true, SMALL>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
 }
 
@@ -279,7 +279,9 @@ __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__r
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	__shared__ CertLds<MULLS_CERT_SMALL_LOCKSTEP> s_cert;
-	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq))
+	constexpr bool PARK = BLK == 512; // (the 1024-lane form serves small batches: two workgroups per CU, 128 registers)
+	__shared__ uint32_t s_park[PARK ? 2 * 3 * 512 : 1];
+	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP, PARK>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, s_park))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }

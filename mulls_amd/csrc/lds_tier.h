@@ -797,12 +797,12 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 #define MULLS_FS_VALID 2u	 // = MULLS_F_VALID (member of Corr_f before this iteration)
 #define MULLS_FS_DIR_OK 4u	 // the direction check passes against the standing correspondence's target direction
 #define MULLS_FS_STANDING 8u // the certified correspondence is the standing one (its record is in place)
-template <int BLK, int TRIPS, bool W16, int SMALL>
+template <int BLK, int TRIPS, bool W16, int SMALL, bool PARK = false>
 __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 												 float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 												 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 												 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
-												 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+												 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t *park = nullptr)
 {
 	float4 *uq = CL.uq; // the few queries this workgroup searches itself
 	uint32_t *us = CL.us, *red = CL.red;
@@ -841,17 +841,37 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		r.q = *reinterpret_cast<const float3 *>(mq + 2u * gi), r.t = *reinterpret_cast<const float3 *>(mq + 2u * gi + 1u);
 		return r;
 	};
-	uint32_t ST[TRIPS];
-	int32_t M[TRIPS];
-	float D0[TRIPS];
+	// per point and trip across the workgroup barriers: state bits, the correspondence, its squared distance.  PARK: the last two wait in LDS (`park`,
+	// 2 * TRIPS * BLK words; the state bits ride in the correspondence's word) instead of registers — k_cert<512> holds 64 registers per lane (four workgroups per CU) and spilled twelve of them to scratch
+	// PARK: word 0 = state bits << 24 | (correspondence + 2), word 1 = the distance's bits
+	uint32_t STr[PARK ? 1 : TRIPS];
+	int32_t Mr[PARK ? 1 : TRIPS];
+	float D0r[PARK ? 1 : TRIPS];
+	auto setSM = [&](int k, uint32_t st, int32_t m) {
+		if (PARK)
+			park[(uint32_t)k * BLK + threadIdx.x] = (st << 24) | (uint32_t)(m + 2);
+		else
+			STr[PARK ? 0 : k] = st, Mr[PARK ? 0 : k] = m;
+	};
+	auto getST = [&](int k) -> uint32_t { return PARK ? park[(uint32_t)k * BLK + threadIdx.x] >> 24 : STr[PARK ? 0 : k]; };
+	auto getM = [&](int k) -> int32_t { return PARK ? (int32_t)(park[(uint32_t)k * BLK + threadIdx.x] & 0xffffffu) - 2 : Mr[PARK ? 0 : k]; };
+	auto setD0 = [&](int k, float v) {
+		if (PARK)
+			park[(uint32_t)(TRIPS + k) * BLK + threadIdx.x] = __float_as_uint(v);
+		else
+			D0r[PARK ? 0 : k] = v;
+	};
+	auto getD0 = [&](int k) -> float { return PARK ? __uint_as_float(park[(uint32_t)(TRIPS + k) * BLK + threadIdx.x]) : D0r[PARK ? 0 : k]; };
 	uint32_t matched_cnt = 0;
 	// rigid step + certificate of one trip's point (cert_class's arithmetic)
 	auto cert = [&](int k, const Rec &r) {
 		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
-		ST[k] = 0u, M[k] = -1, D0[k] = 0.0f;
+		uint32_t st_k = 0u;
+		int32_t m_k = -1;
+		setSM(k, 0u, -1), setD0(k, 0.0f);
 		if (s >= q_end || !(r.fl & MULLS_F_ALIVE))
 			return;
-		ST[k] = r.fl & (MULLS_FS_ALIVE | MULLS_FS_VALID);
+		st_k = r.fl & (MULLS_FS_ALIVE | MULLS_FS_VALID);
 		const float3 p = r.p, n = r.n;
 		uint32_t hv = 0xffffu;
 		float lb = 0.0f;
@@ -883,7 +903,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			const double dot = (double)onx * (double)r.t.x + (double)ony * (double)r.t.y + (double)onz * (double)r.t.z;
 			const float c = (float)fabs(dot);
 			if (!((double)c < rp.cos_bearing))
-				ST[k] |= MULLS_FS_DIR_OK;
+				st_k |= MULLS_FS_DIR_OK;
 		}
 		const float mx = out.x - p.x, my = out.y - p.y, mz = out.z - p.z;
 		const float moved = sqrtf((mx * mx + my * my) + mz * mz);
@@ -902,14 +922,14 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 				if (certified)
 				{
 					const bool matched = !((double)d0 > C.max_dist_sqr);
-					M[k] = matched ? (int32_t)hj : -1;
-					D0[k] = d0;
+					m_k = matched ? (int32_t)hj : -1;
+					setD0(k, d0);
 					hint2[gi] = make_int2((int32_t)hj, __float_as_int(lb_next)); // cost class 0
 					if (matched)
 					{
 						matched_cnt++;
 						if ((int32_t)hj == r.pm)
-							ST[k] |= MULLS_FS_STANDING;
+							st_k |= MULLS_FS_STANDING;
 						if (C.dedup) // (rp.lds_dedup: the duplicate rule in force means the table is this workgroup's)
 							dedup_min<W16>(W, hj, s);
 					}
@@ -918,8 +938,8 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		}
 		if (!certified)
 		{
-			M[k] = MULLS_NEEDS_SEARCH;
-			D0[k] = out.w;
+			m_k = MULLS_NEEDS_SEARCH;
+			setD0(k, out.w);
 			nn_idx[gi] = MULLS_NEEDS_SEARCH;
 			nn_d2[gi] = out.w;
 			const uint32_t u = atomicAdd(&ucount, 1u);
@@ -929,6 +949,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 				us[u] = s;
 			}
 		}
+		setSM(k, st_k, m_k);
 	};
 
 	static_assert(TRIPS == 2 || TRIPS == 3, "two trips' loads in flight");
@@ -953,11 +974,11 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
 #pragma unroll
 		for (int k = 0; k < TRIPS; k++)
-			if ((ST[k] & MULLS_FS_ALIVE) && M[k] != MULLS_NEEDS_SEARCH)
+			if ((getST(k) & MULLS_FS_ALIVE) && getM(k) != MULLS_NEEDS_SEARCH)
 			{
 				const uint32_t gi = d.src_off + threadIdx.x + (uint32_t)k * BLK;
-				nn_idx[gi] = M[k];
-				nn_d2[gi] = D0[k];
+				nn_idx[gi] = getM(k);
+				nn_d2[gi] = getD0(k);
 			}
 		return false;
 	}
@@ -994,12 +1015,12 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 #pragma unroll
 	for (int k = 0; k < TRIPS; k++)
 	{
-		const uint32_t st = ST[k];
+		const uint32_t st = getST(k);
 		if (!(st & MULLS_FS_ALIVE))
 			continue;
 		const uint32_t s = threadIdx.x + (uint32_t)k * BLK, gi = d.src_off + s;
-		int32_t m = M[k];
-		float dist = D0[k];
+		int32_t m = getM(k);
+		float dist = getD0(k);
 		bool standing = (st & MULLS_FS_STANDING) != 0;
 		if (m == MULLS_NEEDS_SEARCH)
 		{
