@@ -477,6 +477,14 @@ def large_main(args, rank, local_rank, world, engine_factory=None):
         b_reg = W.algorithmic_bytes([results[i] for i in range(n_pairs)], used) / n_pairs  # the whole path's B_reg per registration
         value = n_reg / elapsed
         p0 = pairs[0]
+        pmc = None
+        try:  # the committed PMC passes, only if they describe this very configuration
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_cfg%d.json" % cfg)) as f:
+                pmc = json.load(f)
+            if pmc["config"]["pairs_per_gpu_per_step"] != n_pairs or args.tiny or args.nn_mode != 0:
+                pmc = None
+        except Exception:
+            pmc = None
         out = {
             "metric": L["metric"], "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_priming_steps": PRIME,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -493,12 +501,14 @@ def large_main(args, rank, local_rank, world, engine_factory=None):
                 "engine": engine.name, "all_code_1": bool((gathered[:, 52] == 1).all()), "mean_iterations": float(np.mean(gathered[:, 53])),
             },
             "roofline": {
-                "kernel": L["kernel"], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": L["kernel"], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic_note": "bytes per launch set (search + rejection chain) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (%s; 2 x FETCH + "
+                                "WRITE per the gfx950 guide); null when no pass of this very configuration is committed" % (pmc.get("source") if pmc else "profiles/pmc_traffic_cfg%d.json" % cfg),
                 "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
                 "whole_path": {"B_reg_bytes_per_registration": b_reg, "achieved_GBs": b_reg * value / 1e9, "frac": b_reg * value / 1e9 / HBM_PEAK_GBS,
                                "note": "SURVEY 8d's B_reg (setup + every iteration's search and accumulation + residual pass) x registrations/s against the HBM peak"},
                 "kernel_ms_per_step": {k: acc[k] / args.steps for k in ("ms_setup", "ms_nn", "ms_filter", "ms_accum", "ms_residual")},
-                "note": "live hipEvent duration of the search launches of the timed steps (the library's stream); traffic: no PMC pass of this configuration is committed",
+                "note": "live hipEvent duration of the search launches of the timed steps (the library's stream)",
             },
         }
         if checks is not None:

@@ -45,12 +45,13 @@ def gather_results(table, device=None, dst=0, counts=None):
     return gather_wait(h)
 
 
-def gather_post(table, device=None, dst=0, counts=None):
-    """Post the gather of one step's result table without waiting for it (the next step's kernels run meanwhile); gather_wait() completes it."""
+def gather_post(table, device=None, dst=0, counts=None, force_collective=False):
+    """Post the gather of one step's result table without waiting for it (the next step's kernels run meanwhile); gather_wait() completes it.
+    force_collective: issue the collective even in a process group of one rank (tests: the RCCL call path on a single-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return ("local", table)
     world, rank = dist.get_world_size(), dist.get_rank()
     t = torch.from_numpy(np.ascontiguousarray(table))
