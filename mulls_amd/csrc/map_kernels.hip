@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void k_map_bbox(MapBoxArgs a)
 }
 
 // Exact nearest tree point (FLANN L2_Simple<float> distance) of every frame point, brute force: blockIdx.y splits the tree
-// into chunks of 16384 points staged through LDS, atomicMin on the float bits combines the chunks (distances are >= 0).
-#define MAP_NN_CHUNK 16384u
+// into chunks of MAP_NN_CHUNK points staged through LDS, atomicMin on the float bits combines the chunks (distances are >= 0).
+#define MAP_NN_CHUNK 2048u // (a down-sampled frame against a 20 000-point map: 16384 made 8 workgroups of it, 284 us; 2048: ~40 workgroups)
 #define MAP_NN_TILE 1024u
 __global__ __launch_bounds__(256) void k_map_nn(const float4 *__restrict__ frame, uint32_t n_frame, const float4 *__restrict__ tree, uint32_t n_tree,
 												 int use_box, double b0, double b1, double b2, double b3, double b4, double b5,
