@@ -84,9 +84,12 @@ def test_random_options_large_batch_equals_single(ctx_auto, pairs_small, block):
             assert r1.sigma == rb[i].sigma or (np.isnan(r1.sigma) and np.isnan(rb[i].sigma))
 
 
-def degenerate_pair(rng, kind):
-    """Small pathological inputs (finite values): the reference has no special cases for them, neither may the device."""
+def degenerate_pair(rng, kind, nt=None, ns=None):
+    """Small pathological inputs (finite values): the reference has no special cases for them, neither may the device.
+    nt / ns: six target / source sizes (tools/gpu_fuzz_mixed.py: class clouds of every search tier in one pair); default one small size for all."""
     n_t, n_s = int(rng.integers(3, 900)), int(rng.integers(3, 700))
+    nt = [n_t] * 6 if nt is None else [int(v) for v in nt]
+    ns = [n_s] * 6 if ns is None else [int(v) for v in ns]
 
     def cloud(n, spread, offset=0.0):
         xyz = rng.normal(0, spread, (n, 3)) + offset
@@ -96,29 +99,90 @@ def degenerate_pair(rng, kind):
 
     if kind == "duplicates":  # many identical points: distance ties everywhere, the lowest target index must win
         base = cloud(7, 3.0)
-        tgt = [base[rng.integers(0, 7, n_t)] for _ in range(6)]
-        src = [base[rng.integers(0, 7, n_s)] for _ in range(6)]
+        tgt = [base[rng.integers(0, 7, nt[c])] for c in range(6)]
+        src = [base[rng.integers(0, 7, ns[c])] for c in range(6)]
     elif kind == "one_cell":  # everything inside a few centimetres
-        tgt = [cloud(n_t, 0.01) for _ in range(6)]
-        src = [cloud(n_s, 0.01) for _ in range(6)]
+        tgt = [cloud(nt[c], 0.01) for c in range(6)]
+        src = [cloud(ns[c], 0.01) for c in range(6)]
     elif kind == "far_origin":  # coordinates around 1e5 m: float cell arithmetic at its coarsest
-        tgt = [cloud(n_t, 5.0, 1e5) for _ in range(6)]
-        src = [cloud(n_s, 5.0, 1e5) for _ in range(6)]
+        tgt = [cloud(nt[c], 5.0, 1e5) for c in range(6)]
+        src = [cloud(ns[c], 5.0, 1e5) for c in range(6)]
     elif kind == "collinear":
         def line(n):
             t = rng.uniform(-20, 20, n)
             return abi.make_points(np.column_stack([t, 0.5 * t, 0 * t]), np.tile([0, 0, 1.0], (n, 1)), rng.uniform(0, 255, n))
-        tgt = [line(n_t) for _ in range(6)]
-        src = [line(n_s) for _ in range(6)]
+        tgt = [line(nt[c]) for c in range(6)]
+        src = [line(ns[c]) for c in range(6)]
     elif kind == "sparse_far":  # nothing within any search radius
-        tgt = [cloud(n_t, 2.0) for _ in range(6)]
-        src = [cloud(n_s, 2.0, 500.0) for _ in range(6)]
+        tgt = [cloud(nt[c], 2.0) for c in range(6)]
+        src = [cloud(ns[c], 2.0, 500.0) for c in range(6)]
     else:  # "ragged": empty and tiny clouds mixed with normal ones
         sizes_t = rng.choice([0, 1, 2, 3, 50, 600], 6)
         sizes_s = rng.choice([0, 1, 2, 3, 40, 550], 6)
         tgt = [cloud(int(k), 4.0) if k else None for k in sizes_t]
         src = [cloud(int(k), 4.0) if k else None for k in sizes_s]
     return abi.PairData(tgt, src)
+
+
+def noisy_copy(rng, nt, ns):
+    """Source class clouds = samples of the target's, moved by a small rigid motion plus noise: registrations that run their iterations (hints,
+    certificates, duplicate losers, the rejection chain) on class clouds of the given sizes."""
+    T = synth.se3(*rng.normal(0, 0.1, 3), *np.deg2rad(rng.normal(0, 0.3, 3)))
+    Ti = np.linalg.inv(T)
+    tgt, src = [], []
+    for c in range(6):
+        xyz = rng.uniform(-25, 25, (nt[c], 3)) * np.array([1.0, 1.0, 0.15])
+        nrm = rng.normal(0, 1, (nt[c], 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        tgt.append(abi.make_points(xyz, nrm, rng.uniform(0, 255, nt[c])))
+        k = rng.integers(0, nt[c], ns[c])
+        sx = (xyz[k] + rng.normal(0, 0.03, (ns[c], 3))) @ Ti[:3, :3].T + Ti[:3, 3]
+        src.append(abi.make_points(sx, nrm[k] @ Ti[:3, :3].T, rng.uniform(0, 255, ns[c])))
+    return abi.PairData(tgt, src)
+
+
+MIXED_KINDS = ("copy", "duplicates", "copy", "one_cell", "far_origin", "copy", "collinear", "sparse_far")
+MIXED_T_SIZES = [(3, 64), (200, 900), (3000, 7088), (7089, 9000), (16000, 30000)]  # brute force, LDS tier (small / at its limit), global-memory tier
+MIXED_S_SIZES = [(3, 64), (200, 700), (1400, 1600), (3900, 4300), (9000, 14000)]  # around 1536 (class-level job limit) and 4096 (LDS tier's source limit), chunked
+
+
+def mixed_tier_pair(rng, kind):
+    """A pair whose six class clouds draw their sizes from the ranges of all three search tiers (and sources from both sides of the class-level job
+    limit), on the degenerate shapes above or as a noisy copy: one batch of them holds class-level and chunk-level jobs of both grid tiers."""
+    nt = [int(rng.integers(*MIXED_T_SIZES[rng.integers(0, len(MIXED_T_SIZES))])) for _ in range(6)]
+    ns = [int(rng.integers(*MIXED_S_SIZES[rng.integers(0, len(MIXED_S_SIZES))])) for _ in range(6)]
+    return noisy_copy(rng, nt, ns) if kind == "copy" else degenerate_pair(rng, kind, nt, ns)
+
+
+def mixed_tier_block(rng, per):
+    """One option point and `per` mixed-tier pairs (tools/gpu_fuzz_mixed.py runs many blocks)."""
+    P = random_params(rng)
+    P.apply_motion_undistortion = 0
+    P.normal_shooting_on = 0
+    P.max_iter_num = int(rng.integers(2, 9))
+    P.max_bearable_rotation_d = 45.0
+    k0 = int(rng.integers(0, len(MIXED_KINDS)))
+    return P, [mixed_tier_pair(rng, MIXED_KINDS[(k0 + i) % len(MIXED_KINDS)]) for i in range(per)]
+
+
+@pytest.mark.parametrize("block", [0, 1, 2, 3])
+def test_mixed_tier_degenerate_batches_match_oracle(ctx_auto, block):
+    """Auto mode (a tier per class cloud) and the global-memory tier forced on every cloud, on batches whose class clouds span every search tier,
+    pathological shapes included: each pair equals the oracle's.  (The LDS tier and the resident loop refuse clouds of that size when forced.)"""
+    from mulls_amd import lib
+
+    rng = np.random.default_rng(block * 15485863 + 11)
+    P, pairs = mixed_tier_block(rng, 10)
+    ro = [pyoracle.icp(pair, P)[0] for pair in pairs]
+    for r, g in zip(ro, ctx_auto.icp_batch(pairs, P)):
+        compare(r, g, check_trace=False, x_tol=1e-6)
+    forced = lib.Context(0)
+    try:
+        forced.set_nn_mode(2)
+        for r, g in zip(ro, forced.icp_batch(pairs, P)):
+            compare(r, g, check_trace=False, x_tol=1e-6)
+    finally:
+        forced.close()
 
 
 @pytest.mark.parametrize("kind", ["duplicates", "one_cell", "far_origin", "collinear", "sparse_far", "ragged"])
