@@ -374,6 +374,8 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	// the leftovers against the bitmap grid: 16-lane sub-groups, one query at a time each
 	if (U)
 	{
+		const bool dbg = rp.dbg_ticks && rp.debug_stop == 21u; // diagnostics: leftover queries and the workgroup time they take
+		const unsigned long long t_dbg = dbg ? wall_clock64() : 0ull;
 		const uint32_t sub = threadIdx.x & (MULLS_GRID_GROUP - 1u), grp = threadIdx.x / MULLS_GRID_GROUP;
 		const bool probe_own = tgt_n >= 4u * g.nocc; // dense cells (a map of many scans): the own cell first; a scan's own density: straight to the cube
 		for (uint32_t i = grp; i < U; i += BLK / MULLS_GRID_GROUP)
@@ -396,6 +398,15 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 					if (C.gate)
 						atomicMin(&winner[d.tgt_off + (uint32_t)bi], C.key_hi | (unsigned long long)s);
 				}
+			}
+		}
+		if (dbg)
+		{
+			__syncthreads();
+			if (threadIdx.x == 0)
+			{
+				atomicAdd(&rp.dbg_ticks[13], (unsigned long long)U);
+				atomicAdd(&rp.dbg_ticks[7], wall_clock64() - t_dbg);
 			}
 		}
 	}

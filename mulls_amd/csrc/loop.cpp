@@ -112,7 +112,7 @@ int run_setup(Run &R)
 		rp.tgt_map = B->tmap;
 	}
 
-	if (rp.debug_stop == 20u)
+	if (rp.debug_stop == 20u || rp.debug_stop == 21u)
 	{
 		if (!B->dbg && dmalloc(ctx, &B->dbg, 16) != MULLS_OK)
 			return MULLS_E_HIP;
@@ -318,6 +318,11 @@ RUN_ALIASES
 		{
 			unsigned long long t[16];
 			HIPCHK(ctx, hipMemcpy(t, rp.dbg_ticks, sizeof(t), hipMemcpyDeviceToHost));
+			if (rp.debug_stop == 21u) // the global-memory tier's leftover search: queries, workgroup time (summed over the workgroups)
+			{
+				ctx->prof.icp_fused_ms[0] += (double)t[13], ctx->prof.icp_fused_ms[1] += (double)t[7] * 1e-5;
+				return MULLS_OK;
+			}
 			for (int k = 0; k < 5; k++)
 				ctx->prof.icp_fused_ms[k] += (double)t[k] * 1e-5;
 			ctx->prof.icp_fused_ms[5] += (double)t[6];
