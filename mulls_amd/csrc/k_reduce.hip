@@ -42,11 +42,24 @@ __global__ __launch_bounds__(LANES, MIN_WG) void k_accum(const uint32_t *__restr
 //
 namespace
 {
+// what finish_pair leaves on chip for a step that follows in the same workgroup (k_finish_step): the class rows, the combined row, the record's counter block
+struct FinishLds
+{
+	double sums[MULLS_NC][MULLS_NTERM_PAD], comb[MULLS_NTERM_PAD];
+	uint32_t cnt[32]; // n_valid, n_alive, src_n, tgt_n, bbox (6 each)
+};
+// M (k_finish_step): the rows are combined from LDS and the step reads them there — the record in memory is written all the same (pulled by the host-stepped
+// loop, read by nothing else in that launch), but no result of this workgroup makes the round trip through memory
 __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, const RunParams &rp, const double *__restrict__ partial,
-											 PairOut &o, const uint32_t *__restrict__ pair_bbox)
+											 PairOut &o, const uint32_t *__restrict__ pair_bbox, FinishLds *M = nullptr)
 {
 	if (threadIdx.x >= 192 && threadIdx.x < 198)
-		o.bbox[threadIdx.x - 192] = pair_bbox[threadIdx.x - 192];
+	{
+		const uint32_t v = pair_bbox[threadIdx.x - 192];
+		o.bbox[threadIdx.x - 192] = v;
+		if (M)
+			M->cnt[24 + threadIdx.x - 192] = v;
+	}
 	if (threadIdx.x < MULLS_NC * MULLS_NTERM)
 	{
 		const int c = threadIdx.x / MULLS_NTERM, t = threadIdx.x % MULLS_NTERM;
@@ -71,11 +84,21 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 			for (; j < je; j += STEP)
 				sum += partial[(size_t)j * MULLS_NTERM + t];
 			o.sums[c][t] = sum;
+			if (M)
+				M->sums[c][t] = sum;
 		}
 	}
 	__syncthreads();
 	if (rp.pull_comb && threadIdx.x >= 64 && threadIdx.x < 64 + MULLS_NTERM)
-		combine_rows(rp, ps.want_residual != 0, o.sums, o.comb, (int)threadIdx.x - 64); // only this row crosses PCIe (224 B instead of 224 B per used class)
+	{
+		if (M)
+		{
+			combine_rows(rp, ps.want_residual != 0, M->sums, M->comb, (int)threadIdx.x - 64);
+			o.comb[threadIdx.x - 64] = M->comb[threadIdx.x - 64];
+		}
+		else
+			combine_rows(rp, ps.want_residual != 0, o.sums, o.comb, (int)threadIdx.x - 64); // only this row crosses PCIe (224 B instead of 224 B per used class)
+	}
 	if (threadIdx.x < MULLS_NC)
 	{
 		const int c = threadIdx.x;
@@ -95,6 +118,8 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 		o.n_alive[c] = d.alive_cur;
 		o.src_n[c] = d.src_n;
 		o.tgt_n[c] = d.tgt_n;
+		if (M)
+			M->cnt[c] = d.n_valid, M->cnt[6 + c] = d.alive_cur, M->cnt[12 + c] = d.src_n, M->cnt[18 + c] = d.tgt_n;
 	}
 }
 } // namespace
@@ -224,13 +249,16 @@ struct StepLds
 {
 	mulls::StepState S;
 	SolveWs ws;
-	double comb[MULLS_NTERM_PAD];
-	uint32_t cnt[32]; // the record's counter block: n_valid, n_alive, src_n, tgt_n, bbox (6 each)
+	FinishLds F; // the combined row and the record's counter block (k_step: read from the record; k_finish_step: left here by finish_pair)
 	uint32_t jobs[MULLS_NC], n0[MULLS_NC];
 	int go, iter, active, resid, done, left;
 };
+constexpr uint32_t STEP_WORDS = (uint32_t)(sizeof(mulls::StepState) / 8), STEP_WORDS_PER_LANE = (STEP_WORDS + 63u) / 64u;
+// PRE (k_finish_step): finish_pair of this workgroup has filled L.F, and the pair's StepState words were requested at the start of the kernel (sw: lanes 0..63)
+template <bool PRE = false>
 __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__restrict__ descs, PairState *__restrict__ states, const RunParams &rp, const mulls::IcpConst &K,
-										   const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, StepLds &L)
+										   const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, StepLds &L,
+										   const unsigned long long *sw = nullptr)
 {
 	const int l = (int)threadIdx.x;
 	mulls::StepState &S = L.S;
@@ -249,13 +277,24 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 		{
 			const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&steps[pair]);
 			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&S);
-			for (uint32_t w = (uint32_t)l; w < sizeof(mulls::StepState) / 8; w += 64u)
-				dst[w] = src[w];
+			if (PRE)
+			{
+#pragma unroll
+				for (uint32_t k = 0; k < STEP_WORDS_PER_LANE; k++)
+					if ((uint32_t)l + 64u * k < STEP_WORDS)
+						dst[(uint32_t)l + 64u * k] = sw[k];
+			}
+			else
+				for (uint32_t w = (uint32_t)l; w < STEP_WORDS; w += 64u)
+					dst[w] = src[w];
 		}
-		if (l < MULLS_NTERM_PAD)
-			L.comb[l] = o.comb[l];
-		if (l < 30)
-			L.cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
+		if (!PRE)
+		{
+			if (l < MULLS_NTERM_PAD)
+				L.F.comb[l] = o.comb[l];
+			if (l < 30)
+				L.F.cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
+		}
 		if (l < MULLS_NC)
 		{
 			const CloudDesc &d = descs[pair * MULLS_NC + l];
@@ -263,13 +302,13 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 			L.n0[l] = d.src_n0;
 		}
 		__syncthreads();
-		const uint32_t *n_valid = L.cnt, *n_alive = L.cnt + 6, *src_n = L.cnt + 12, *tgt_n = L.cnt + 18, *obox = L.cnt + 24;
+		const uint32_t *n_valid = L.F.cnt, *n_alive = L.F.cnt + 6, *src_n = L.F.cnt + 12, *tgt_n = L.F.cnt + 18, *obox = L.F.cnt + 24;
 		mulls::PairIter &h = S.h;
 		if (l == 0)
 		{
 			L.go = 0;
 			if (L.resid)
-				mulls::step_residual(h, K, L.comb[0], L.comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
+				mulls::step_residual(h, K, L.F.comb[0], L.F.comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
 			else
 			{
 				const int i = L.iter;
@@ -311,7 +350,7 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 		}
 		__syncthreads();
 		if (L.go && l < 64)
-			solve_wave(h, K, L.comb, L.iter, L.ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
+			solve_wave(h, K, L.F.comb, L.iter, L.ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
 		__syncthreads();
 		if (l == 0)
 		{
@@ -395,11 +434,20 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish_step(CloudDesc *__restri
 {
 	__shared__ StepLds L;
 	const uint32_t pair = pair_base + blockIdx.x;
-	if (states[pair].active || states[pair].want_residual) // uniform per workgroup
-		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6);
-	__threadfence_block();
-	__syncthreads(); // the record is read back by the step below
-	const bool left = step_pair(pair, descs, states, rp, K, out, steps, results, brute, L);
+	const bool live = states[pair].active || states[pair].want_residual; // uniform per workgroup
+	// the pair's StepState is requested before the partial sums: the step below finds it in registers instead of starting another round trip
+	unsigned long long sw[STEP_WORDS_PER_LANE];
+	if (live && threadIdx.x < 64u)
+	{
+		const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&steps[pair]);
+#pragma unroll
+		for (uint32_t k = 0; k < STEP_WORDS_PER_LANE; k++)
+			sw[k] = src[min(threadIdx.x + 64u * k, STEP_WORDS - 1u)];
+	}
+	if (live)
+		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6, &L.F);
+	__syncthreads(); // L.F is complete
+	const bool left = step_pair<true>(pair, descs, states, rp, K, out, steps, results, brute, L, sw);
 	if (threadIdx.x == 0)
 	{
 		// arrivals (low half) and pairs still iterating (high half) in ONE 64-bit atomic: no fence between two counters, none per workgroup — what the other
