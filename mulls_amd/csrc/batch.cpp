@@ -90,6 +90,57 @@ bool option_value_ok(int option, double *value)
 	}
 }
 
+} // namespace mulls_drv
+int SegCopier::flush(hipStream_t st)
+{
+	using namespace mulls;
+	size_t total = 0;
+	for (const Pending &h : host)
+		total += (h.bytes + 255u) & ~(size_t)255;
+	bool direct = false; // ranges k_copy_segs does not take (misaligned, not whole words, 4 GiB): plain copy commands
+	for (const Pending &h : host)
+		direct = direct || (h.bytes & 3u) || ((uintptr_t)h.dst & 15u) || h.bytes > 0xfffffff0ull;
+	for (const CopySeg &g : segs)
+		direct = direct || (g.bytes & 3u) || (g.dst & 15ull) || (g.src & 15ull);
+	if (direct)
+	{
+		for (const CopySeg &g : segs)
+			HIPCHK(ctx, hipMemcpyAsync((void *)(uintptr_t)g.dst, (const void *)(uintptr_t)g.src, g.bytes, hipMemcpyDeviceToDevice, st));
+		for (const Pending &h : host)
+			HIPCHK(ctx, hipMemcpyAsync(h.dst, h.src, h.bytes, hipMemcpyHostToDevice, st));
+		segs.clear(), host.clear();
+		return MULLS_OK;
+	}
+	if (total > ctx->mail_cap)
+	{
+		HIPCHK(ctx, hipStreamSynchronize(st)); // (nothing may still be reading the old mailbox)
+		if (ctx->mail_h)
+			(void)hipHostFree(ctx->mail_h);
+		ctx->mail_h = nullptr, ctx->mail_cap = 0;
+		const size_t want = std::max<size_t>(total + total / 2, (size_t)1 << 20);
+		HIPCHK(ctx, hipHostMalloc((void **)&ctx->mail_h, want, hipHostMallocMapped));
+		ctx->mail_cap = want;
+	}
+	unsigned char *mail_d = nullptr;
+	if (total)
+		HIPCHK(ctx, hipHostGetDevicePointer((void **)&mail_d, ctx->mail_h, 0));
+	size_t off = 0;
+	for (const Pending &h : host)
+	{
+		std::memcpy(ctx->mail_h + off, h.src, h.bytes);
+		segs.push_back({(unsigned long long)(uintptr_t)h.dst, (unsigned long long)(uintptr_t)(mail_d + off), (uint32_t)h.bytes, 0u});
+		off += (h.bytes + 255u) & ~(size_t)255;
+	}
+	if (!segs.empty())
+	{
+		launch_copy_segs(st, segs.data(), (uint32_t)segs.size());
+		HIPCHK(ctx, hipGetLastError());
+	}
+	segs.clear(), host.clear();
+	return MULLS_OK;
+}
+namespace mulls_drv
+{
 // defaults of enum mulls_option, then the presets from the environment (read here and nowhere else)
 void options_init(mulls_ctx *ctx)
 {
@@ -740,17 +791,19 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 		if (r1 > r0)
 			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + r0 * 16, B->upload_h + r0 * 16, (r1 - r0) * 16, hipMemcpyHostToDevice, st);
 	}
-	for (const DevCopy &dc : dev_copies)
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(reinterpret_cast<uint8_t *>(B->stage) + dc.dst, dc.src, dc.bytes, hipMemcpyDeviceToDevice, st);
 	if (e == hipSuccess)
-		e = hipMemcpyAsync(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
-	if (e == hipSuccess && !B->big_segs_h.empty())
-		e = hipMemcpyAsync(B->big_segs, B->big_segs_h.data(), B->big_segs_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
-	if (e == hipSuccess && !B->big_clouds_h.empty())
-		e = hipMemcpyAsync(B->big_clouds, B->big_clouds_h.data(), B->big_clouds_h.size() * sizeof(Job), hipMemcpyHostToDevice, st);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(B->setup, B->setup_h.data(), sizeof(PairSetup) * n, hipMemcpyHostToDevice, st);
+	{
+		// the device-resident clouds and the fill's tables: one launch (SegCopier)
+		SegCopier up(ctx);
+		for (const DevCopy &dc : dev_copies)
+			up.add_dev(reinterpret_cast<uint8_t *>(B->stage) + dc.dst, dc.src, dc.bytes);
+		up.add_host(B->setup_jobs, B->setup_jobs_h.data(), B->setup_jobs_h.size() * sizeof(Job));
+		up.add_host(B->big_segs, B->big_segs_h.data(), B->big_segs_h.size() * sizeof(Job));
+		up.add_host(B->big_clouds, B->big_clouds_h.data(), B->big_clouds_h.size() * sizeof(Job));
+		up.add_host(B->setup, B->setup_h.data(), sizeof(PairSetup) * n);
+		if (up.flush(st) != MULLS_OK)
+			return MULLS_E_HIP;
+	}
 	if (e == hipSuccess && winner_grew) // later epochs always sort below older entries (k_nn), so only fresh memory needs the fill
 		e = hipMemsetAsync(B->winner, 0xff, B->cap_tgt[3] * sizeof(unsigned long long), st);
 	if (e == hipSuccess)
@@ -905,31 +958,35 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 	const std::string want_key = B->jobs_key + (resident ? "R" : "");
 	if (grew || B->dev_key != want_key || B->dev_key.empty())
 	{
-		HIPCHK(ctx, hipMemcpyAsync(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs, hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size(), hipMemcpyHostToDevice, st));
-		if (!B->bjobs_h.empty())
-			HIPCHK(ctx, hipMemcpyAsync(B->bjobs, B->bjobs_h.data(), sizeof(Job) * B->bjobs_h.size(), hipMemcpyHostToDevice, st));
-		if (!B->fjobs_h.empty())
-			HIPCHK(ctx, hipMemcpyAsync(B->fjobs, B->fjobs_h.data(), sizeof(Job) * B->fjobs_h.size(), hipMemcpyHostToDevice, st));
-		if (!B->ejobs_h.empty())
-			HIPCHK(ctx, hipMemcpyAsync(B->ejobs, B->ejobs_h.data(), sizeof(Job) * B->ejobs_h.size(), hipMemcpyHostToDevice, st));
-		if (!B->lclouds_h.empty())
-			HIPCHK(ctx, hipMemcpyAsync(B->lclouds, B->lclouds_h.data(), sizeof(uint32_t) * B->lclouds_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->ajobs, B->ajobs_h.data(), sizeof(uint32_t) * B->ajobs_h.size(), hipMemcpyHostToDevice, st));
+		SegCopier up(ctx); // one launch for the dozen tables
+		up.add_host(B->jobs, B->jobs_h.data(), sizeof(Job) * B->njobs);
+		up.add_host(B->tjobs, B->tjobs_h.data(), sizeof(Job) * B->tjobs_h.size());
+		up.add_host(B->cjobs, B->cjobs_dev_h.data(), sizeof(Job) * B->cjobs_dev_h.size());
+		up.add_host(B->bjobs, B->bjobs_h.data(), sizeof(Job) * B->bjobs_h.size());
+		up.add_host(B->fjobs, B->fjobs_h.data(), sizeof(Job) * B->fjobs_h.size());
+		up.add_host(B->ejobs, B->ejobs_h.data(), sizeof(Job) * B->ejobs_h.size());
+		up.add_host(B->lclouds, B->lclouds_h.data(), sizeof(uint32_t) * B->lclouds_h.size());
+		up.add_host(B->ajobs, B->ajobs_h.data(), sizeof(uint32_t) * B->ajobs_h.size());
 		if (resident)
 		{
-			HIPCHK(ctx, hipMemcpyAsync(B->rjobs, B->rjobs_h.data(), sizeof(Job) * B->rjobs_h.size(), hipMemcpyHostToDevice, st));
-			HIPCHK(ctx, hipMemcpyAsync(B->pair_rjob, B->pair_rjob_h.data(), sizeof(uint32_t) * B->pair_rjob_h.size(), hipMemcpyHostToDevice, st));
-			HIPCHK(ctx, hipMemcpyAsync(B->order, B->order_h.data(), sizeof(uint32_t) * B->order_h.size(), hipMemcpyHostToDevice, st));
+			up.add_host(B->rjobs, B->rjobs_h.data(), sizeof(Job) * B->rjobs_h.size());
+			up.add_host(B->pair_rjob, B->pair_rjob_h.data(), sizeof(uint32_t) * B->pair_rjob_h.size());
+			up.add_host(B->order, B->order_h.data(), sizeof(uint32_t) * B->order_h.size());
 		}
-		HIPCHK(ctx, hipMemcpyAsync(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyHostToDevice, st));
-		HIPCHK(ctx, hipMemcpyAsync(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n, hipMemcpyHostToDevice, st));
+		up.add_host(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size());
+		up.add_host(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n);
+		if (up.flush(st) != MULLS_OK)
+			return MULLS_E_HIP;
 		HIPCHK(ctx, hipStreamSynchronize(st)); // the host vectors may be rebuilt by a later call
 		B->dev_key = want_key;
 	}
-	HIPCHK(ctx, hipMemcpyAsync(B->descs, B->descs_init, sizeof(CloudDesc) * B->descs_h.size(), hipMemcpyDeviceToDevice, st));
-	HIPCHK(ctx, hipMemcpyAsync(B->bbox, B->bbox_init, sizeof(uint32_t) * 6 * n, hipMemcpyDeviceToDevice, st));
+	{
+		SegCopier reset(ctx); // this run's working copies of the descriptors and of the crop boxes
+		reset.add_dev(B->descs, B->descs_init, sizeof(CloudDesc) * B->descs_h.size());
+		reset.add_dev(B->bbox, B->bbox_init, sizeof(uint32_t) * 6 * n);
+		if (reset.flush(st) != MULLS_OK)
+			return MULLS_E_HIP;
+	}
 	return MULLS_OK;
 }
 

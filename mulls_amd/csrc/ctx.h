@@ -67,6 +67,8 @@ struct mulls_ctx
 	size_t gf_cap = 0;
 	double opt[MULLS_OPT_COUNT] = {}; // enum mulls_option (mulls_set_option; preset from the environment by mulls_create)
 	HostPool *pool = nullptr; // host threads of the staging gather (made on first use)
+	unsigned char *mail_h = nullptr; // host-mapped mailbox of the small-table uploads (SegCopier, batch.h): written by the host, read by k_copy_segs
+	size_t mail_cap = 0;
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 

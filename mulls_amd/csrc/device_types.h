@@ -154,6 +154,19 @@ struct Job
 	uint32_t count; // LDS-tier jobs only: number of consecutive source points this workgroup searches (0 = MULLS_SRC_PER_BLOCK)
 };
 
+// One launch moves up to MULLS_COPY_SEGS byte ranges (k_copy_segs): the small tables a fill / a run uploads (their host copies wait in a host-mapped mailbox) and the
+// device-resident clouds a pair points to — instead of one copy command each.  Addresses 16-byte aligned, sizes multiples of 4.
+#define MULLS_COPY_SEGS 24
+struct CopySeg
+{
+	unsigned long long dst, src;
+	uint32_t bytes, pad_;
+};
+struct CopyArgs
+{
+	CopySeg seg[MULLS_COPY_SEGS];
+};
+
 // Run-wide constants (kernel argument, by value).
 struct RunParams
 {

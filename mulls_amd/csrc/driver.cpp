@@ -174,6 +174,8 @@ extern "C"
 		if (ctx->scratch)
 			mulls_batch_destroy(ctx, ctx->scratch);
 		delete ctx->pool;
+		if (ctx->mail_h)
+			(void)hipHostFree(ctx->mail_h);
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
 			mulls_map_destroy(ctx, ctx->maps.back());
 		while (!ctx->blocks.empty()) // ... and so do feature blocks

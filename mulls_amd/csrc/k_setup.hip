@@ -525,6 +525,34 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_motion_comp(float4 *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// blockIdx.y: the segment; blockIdx.x: its 16-KiB chunk (256 lanes x 4 x 16 B).  A source in the host-mapped mailbox is read over PCIe by the loads themselves.
+__global__ __launch_bounds__(256) void k_copy_segs(CopyArgs a)
+{
+	const CopySeg s = a.seg[blockIdx.y];
+	const uint32_t w16 = s.bytes >> 4, first = blockIdx.x * 1024u;
+	if (first >= w16 + 1u)
+		return;
+	const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(s.src);
+	uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(s.dst);
+	uint4 v[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t w = first + threadIdx.x + 256u * (uint32_t)k;
+		if (w < w16)
+			v[k] = src[w];
+	}
+#pragma unroll
+	for (int k = 0; k < 4; k++)
+	{
+		const uint32_t w = first + threadIdx.x + 256u * (uint32_t)k;
+		if (w < w16)
+			dst[w] = v[k];
+	}
+	if (blockIdx.x == 0 && threadIdx.x < ((s.bytes & 15u) >> 2)) // the tail: up to three 4-byte words
+		reinterpret_cast<uint32_t *>(s.dst)[(size_t)w16 * 4u + threadIdx.x] = reinterpret_cast<const uint32_t *>(s.src)[(size_t)w16 * 4u + threadIdx.x];
+}
+
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
 
@@ -571,4 +599,20 @@ void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_
 {
 	if (npairs)
 		hipLaunchKernelGGL(k_thin, dim3(npairs * MULLS_NC * 2), dim3(MULLS_BLOCK), 0, st, descs, src_keep, tgt_keep, spos, snrm, tpos, tnrm);
+}
+
+void launch_copy_segs(hipStream_t st, const CopySeg *segs, uint32_t n)
+{
+	for (uint32_t i0 = 0; i0 < n; i0 += MULLS_COPY_SEGS)
+	{
+		CopyArgs a;
+		const uint32_t m = n - i0 < (uint32_t)MULLS_COPY_SEGS ? n - i0 : (uint32_t)MULLS_COPY_SEGS;
+		uint32_t most = 0;
+		for (uint32_t k = 0; k < (uint32_t)MULLS_COPY_SEGS; k++)
+		{
+			a.seg[k] = k < m ? segs[i0 + k] : CopySeg{0ull, 0ull, 0u, 0u};
+			most = a.seg[k].bytes > most ? a.seg[k].bytes : most;
+		}
+		hipLaunchKernelGGL(k_copy_segs, dim3(((most >> 4) + 1024u) / 1024u, m), dim3(256), 0, st, a);
+	}
 }

@@ -12,6 +12,8 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 				 const float4 *tmp_pos, const float4 *tmp_nrm, float4 *spos, float4 *snrm, float4 *tpos, float4 *tnrm, uint8_t *flag,
 				 int32_t *match, float *wd, const RunParams &rp, GridDesc *grids, uint32_t nbig_segs, const Job *big_segs, uint32_t nbig_clouds,
 				 const Job *big_clouds, uint32_t *seg_cnt, uint32_t *big_box);
+// n byte ranges in one launch per MULLS_COPY_SEGS of them (device_types.h: CopySeg)
+void launch_copy_segs(hipStream_t st, const CopySeg *segs, uint32_t n);
 // CFilter::apply_motion_compensation on `n` 48-byte records in device memory (q: w x y z of Tran's rotation, t: its translation)
 void launch_motion_comp(hipStream_t st, float4 *recs, uint32_t n, const double q[4], const double t[3], float thre);
 void launch_thin(hipStream_t st, uint32_t npairs, CloudDesc *descs, const uint8_t *src_keep, const uint8_t *tgt_keep, float4 *spos, float4 *snrm,
