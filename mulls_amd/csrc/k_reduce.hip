@@ -517,6 +517,33 @@ __global__ void k_transform_aos(float4 *__restrict__ recs, uint32_t n, const dou
 	recs[(size_t)i * 3 + 1] = b;
 }
 
+// ... on up to six clouds in one launch (blockIdx.y), the transform travelling with the launch: the local map's update moves the frame's clouds and then the
+// whole map (map.cpp) — eleven launches and two uploads otherwise
+struct TransformArgs
+{
+	float4 *recs[6];
+	uint32_t n[6];
+	double T[12];
+};
+__global__ void k_transform_clouds(TransformArgs A)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= A.n[blockIdx.y])
+		return;
+	float4 *__restrict__ recs = A.recs[blockIdx.y];
+	const double *T = A.T;
+	float4 a = recs[(size_t)i * 3], b = recs[(size_t)i * 3 + 1];
+	double x = a.x, y = a.y, z = a.z, nx = b.x, ny = b.y, nz = b.z;
+	a.x = (float)(T[0] * x + T[1] * y + T[2] * z + T[3]);
+	a.y = (float)(T[4] * x + T[5] * y + T[6] * z + T[7]);
+	a.z = (float)(T[8] * x + T[9] * y + T[10] * z + T[11]);
+	b.x = (float)(T[0] * nx + T[1] * ny + T[2] * nz);
+	b.y = (float)(T[4] * nx + T[5] * ny + T[6] * nz);
+	b.z = (float)(T[8] * nx + T[9] * ny + T[10] * nz);
+	recs[(size_t)i * 3] = a;
+	recs[(size_t)i * 3 + 1] = b;
+}
+
 // force a given correspondence list into the flag/match/wd arrays (mulls_stage_accumulate)
 __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, const int32_t *__restrict__ ct, const float *__restrict__ cd,
 						   uint32_t n, uint8_t *__restrict__ flag, int32_t *__restrict__ match, float *__restrict__ wd, uint32_t tgt_off,
@@ -616,6 +643,22 @@ void launch_push_states(hipStream_t st, const PairState *host_states, PairState 
 	if (nwords)
 		hipLaunchKernelGGL(k_push_states, dim3((nwords + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4 *>(host_states),
 						   reinterpret_cast<uint4 *>(dev_states), nwords);
+}
+
+void launch_transform_clouds(hipStream_t st, float4 *const recs[], const uint32_t n[], int count, const double T12[12])
+{
+	TransformArgs a;
+	uint32_t most = 0;
+	for (int c = 0; c < 6; c++)
+	{
+		a.recs[c] = c < count ? recs[c] : nullptr;
+		a.n[c] = c < count ? n[c] : 0u;
+		most = a.n[c] > most ? a.n[c] : most;
+	}
+	for (int k = 0; k < 12; k++)
+		a.T[k] = T12[k];
+	if (most)
+		hipLaunchKernelGGL(k_transform_clouds, dim3((most + 255) / 256, 6), dim3(256), 0, st, a);
 }
 
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12)

@@ -62,6 +62,8 @@ void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, Clo
 						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
 						uint32_t *ticket = nullptr); // ticket: two zeroed device words -> finish, step and publication in one launch (small batches)
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
+// the same on `count` (<= 6) clouds in one launch, T12 (host) by value
+void launch_transform_clouds(hipStream_t st, float4 *const recs[], const uint32_t n[], int count, const double T12[12]);
 void launch_set_corr(hipStream_t st, uint32_t src_off, const int32_t *cs, const int32_t *ct, const float *cd, uint32_t n, uint8_t *flag,
 					 int32_t *match, float *wd, uint32_t tgt_off, const float4 *tpos, const float4 *tnrm, float4 *mq);
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "batch.h"
 #include "ctx.h"
 #include "device_types.h"
 #include "hostmath.h"
@@ -32,6 +33,8 @@ struct mulls_map
 	uint32_t *best = nullptr;
 	uint8_t *keep = nullptr;
 	size_t cap_best = 0, cap_keep = 0;
+	uint8_t *dmask = nullptr; // the thinning masks of a frame's update
+	size_t cap_dmask = 0;
 	uint32_t *seg = nullptr; // per-segment counters of the stable compactions
 	size_t cap_seg = 0;
 };
@@ -83,26 +86,46 @@ int reserve(mulls_ctx *ctx, float4 **p, size_t *cap, size_t need, size_t keep_n)
 	return MULLS_OK;
 }
 
-int upload_cloud(mulls_ctx *ctx, const mulls_cloud &c, float4 **dst, size_t *cap, std::vector<unsigned char> &pack)
+// the six clouds of a frame / a map at once: device-resident sources (a feature block's, another map's) move in one launch and nobody waits; host sources are
+// copied one by one and waited for once
+int upload_clouds(mulls_ctx *ctx, const mulls_cloud clouds[MULLS_NC], float4 **dst, size_t *cap)
 {
-	if (c.n && (!c.pts || c.stride < REC))
+	std::vector<unsigned char> pack[MULLS_NC];
+	SegCopier dev(ctx);
+	bool any_host = false;
+	for (int c = 0; c < MULLS_NC; c++)
 	{
-		ctx->err = "cloud with points but null pointer or stride < 48";
-		return MULLS_E_INVALID;
+		const mulls_cloud &cl = clouds[c];
+		if (cl.n && (!cl.pts || cl.stride < REC))
+		{
+			ctx->err = "cloud with points but null pointer or stride < 48";
+			return MULLS_E_INVALID;
+		}
+		const int rc = reserve(ctx, &dst[c], &cap[c], cl.n, 0);
+		if (rc != MULLS_OK)
+			return rc;
+		if (!cl.n)
+			continue;
+		if (cl.stride == REC && mulls_is_map_memory(ctx, cl.pts, (size_t)cl.n * REC))
+		{
+			dev.add_dev(dst[c], cl.pts, (size_t)cl.n * REC);
+			continue;
+		}
+		const void *src = cl.pts;
+		if (cl.stride != REC)
+		{
+			pack[c].resize((size_t)cl.n * REC);
+			for (uint32_t i = 0; i < cl.n; i++)
+				std::memcpy(pack[c].data() + (size_t)i * REC, (const unsigned char *)cl.pts + (size_t)i * cl.stride, REC);
+			src = pack[c].data();
+		}
+		HIPCHK(ctx, hipMemcpyAsync(dst[c], src, (size_t)cl.n * REC, hipMemcpyDefault, ctx->stream));
+		any_host = true;
 	}
-	int rc = reserve(ctx, dst, cap, c.n, 0);
-	if (rc != MULLS_OK || !c.n)
-		return rc;
-	const void *src = c.pts;
-	if (c.stride != REC)
-	{
-		pack.resize((size_t)c.n * REC);
-		for (uint32_t i = 0; i < c.n; i++)
-			std::memcpy(pack.data() + (size_t)i * REC, (const unsigned char *)c.pts + (size_t)i * c.stride, REC);
-		src = pack.data();
-	}
-	HIPCHK(ctx, hipMemcpyAsync(*dst, src, (size_t)c.n * REC, hipMemcpyDefault, ctx->stream));
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // `pack` / the caller's buffer may go away
+	if (dev.flush(ctx->stream) != MULLS_OK)
+		return MULLS_E_HIP;
+	if (any_host)
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // `pack` / the caller's buffers may go away
 	return MULLS_OK;
 }
 
@@ -190,7 +213,7 @@ extern "C"
 				if (q)
 					(void)hipFree(q);
 		}
-		void *p[] = {m->counts, m->keys, m->T12, m->best, m->keep, m->seg};
+		void *p[] = {m->counts, m->keys, m->T12, m->best, m->keep, m->seg, m->dmask};
 		for (void *q : p)
 			if (q)
 				(void)hipFree(q);
@@ -203,12 +226,11 @@ extern "C"
 		if (!ctx || !m || !clouds || !pose_lo)
 			return MULLS_E_INVALID;
 		HIPCHK(ctx, hipSetDevice(ctx->device));
-		std::vector<unsigned char> pack;
+		const int rc_up = upload_clouds(ctx, clouds, m->rec, m->cap);
+		if (rc_up != MULLS_OK)
+			return rc_up;
 		for (int c = 0; c < MULLS_NC; c++)
 		{
-			const int rc = upload_cloud(ctx, clouds[c], &m->rec[c], &m->cap[c], pack);
-			if (rc != MULLS_OK)
-				return rc;
 			m->n[c] = clouds[c].n;
 			m->frame_n[c] = 0;
 		}
@@ -237,14 +259,11 @@ extern "C"
 		std::memset(rep, 0, sizeof(*rep));
 
 		// 1. the frame's clouds on the device
-		std::vector<unsigned char> pack;
+		const int rc_up = upload_clouds(ctx, frame_down, m->frame, m->cap_frame);
+		if (rc_up != MULLS_OK)
+			return rc_up;
 		for (int c = 0; c < MULLS_NC; c++)
-		{
-			const int rc = upload_cloud(ctx, frame_down[c], &m->frame[c], &m->cap_frame[c], pack);
-			if (rc != MULLS_OK)
-				return rc;
 			m->frame_n[c] = frame_down[c].n;
-		}
 		// 2. tran_target_map = last_target.pose_lo^-1 * local_map.pose_lo (:28); the five *_down clouds go to the map frame (:32)
 		Mat4 map_T, frame_T;
 		std::memcpy(map_T.v, m->pose, sizeof(map_T.v));
@@ -253,10 +272,7 @@ extern "C"
 		const Mat4 inv = mulls::invert4(tran_target_map);
 		double t12[12];
 		rows12_of(inv, t12);
-		HIPCHK(ctx, hipMemcpyAsync(m->T12, t12, sizeof(t12), hipMemcpyHostToDevice, st));
-		for (int c = 0; c < 5; c++)
-			launch_transform_aos(st, m->frame[c], m->frame_n[c], m->T12);
-		HIPCHK(ctx, hipStreamSynchronize(st)); // t12 is reused below
+		launch_transform_clouds(st, m->frame, m->frame_n, 5, t12); // (the transform travels with the launch)
 
 		// 3. map-based dynamic-object removal on the frame's pillar, beam and facade clouds (:37-47, :149-268)
 		float dmax = P->dynamic_dist_thre_max;
@@ -268,67 +284,90 @@ extern "C"
 		if (P->map_based_dynamic_removal_on && fpn0 > P->max_num_pts / 5 && P->tree_mode != 0)
 		{
 			rep->dynamic_removal_ran = 1;
+			// the three classes side by side (nearest tree point, verdict), then ONE compaction and one read of the counts
 			static const int order[3] = {MULLS_PILLAR, MULLS_BEAM, MULLS_FACADE};
+			uint32_t first[3] = {0, 0, 0}, total = 0;
+			bool run[3];
 			for (int k = 0; k < 3; k++)
 			{
 				const int c = order[k];
-				const uint32_t nf = m->frame_n[c];
-				if (P->used_feature_type[c] != '1' || P->tree_used[c] != '1' || nf <= 10 || m->n[c] == 0)
-					continue;
-				if (m->cap_best < nf)
+				run[k] = !(P->used_feature_type[c] != '1' || P->tree_used[c] != '1' || m->frame_n[c] <= 10 || m->n[c] == 0);
+				first[k] = total;
+				if (run[k])
+					total += (m->frame_n[c] + 3u) & ~3u;
+			}
+			if (total)
+			{
+				if (m->cap_best < total)
 				{
+					HIPCHK(ctx, hipStreamSynchronize(st));
 					if (m->best)
 						(void)hipFree(m->best);
 					if (m->keep)
 						(void)hipFree(m->keep);
 					m->best = nullptr, m->keep = nullptr;
-					if (dmalloc(ctx, &m->best, (size_t)nf * 2) != MULLS_OK || dmalloc(ctx, &m->keep, (size_t)nf * 2) != MULLS_OK)
+					if (dmalloc(ctx, &m->best, (size_t)total * 2) != MULLS_OK || dmalloc(ctx, &m->keep, (size_t)total * 2) != MULLS_OK)
 						return MULLS_E_HIP;
-					m->cap_best = (size_t)nf * 2;
+					m->cap_best = (size_t)total * 2;
 				}
-				HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)m->best, 0x7f800000, nf, st));
-				launch_map_nn(st, m->frame[c], nf, m->rec[c], m->n[c], P->tree_mode == 2, P->tree_box, m->best);
-				launch_map_keep(st, m->frame[c], nf, m->best, P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, dmax, P->near_dist_thre,
-								m->keep);
-				int rc = reserve(ctx, &m->frame_alt[c], &m->cap_frame_alt[c], nf, 0);
-				if (rc != MULLS_OK)
-					return rc;
+				HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)m->best, 0x7f800000, total, st));
 				MapCompactArgs a;
 				std::memset(&a, 0, sizeof(a));
-				a.cloud[0].in = m->frame[c];
-				a.cloud[0].out = m->frame_alt[c];
-				a.cloud[0].mask = m->keep;
-				a.cloud[0].n = nf;
+				for (int k = 0; k < 3; k++)
+				{
+					if (!run[k])
+						continue;
+					const int c = order[k];
+					const uint32_t nf = m->frame_n[c];
+					launch_map_nn(st, m->frame[c], nf, m->rec[c], m->n[c], P->tree_mode == 2, P->tree_box, m->best + first[k]);
+					launch_map_keep(st, m->frame[c], nf, m->best + first[k], P->dynamic_removal_center_radius, P->dynamic_dist_thre_min, dmax, P->near_dist_thre,
+									m->keep + first[k]);
+					const int rc = reserve(ctx, &m->frame_alt[c], &m->cap_frame_alt[c], nf, 0);
+					if (rc != MULLS_OK)
+						return rc;
+					a.cloud[k].in = m->frame[c];
+					a.cloud[k].out = m->frame_alt[c];
+					a.cloud[k].mask = m->keep + first[k];
+					a.cloud[k].n = nf;
+				}
 				a.out_n = m->counts;
 				a.mode = 0;
-				if (compact(ctx, m, a) != MULLS_OK) // slots 1..5 are empty clouds
+				if (compact(ctx, m, a) != MULLS_OK) // the other slots are empty clouds
 					return MULLS_E_HIP;
 				uint32_t cnt[6];
 				HIPCHK(ctx, hipMemcpyAsync(cnt, m->counts, sizeof(cnt), hipMemcpyDeviceToHost, st));
 				HIPCHK(ctx, hipStreamSynchronize(st));
-				std::swap(m->frame[c], m->frame_alt[c]);
-				std::swap(m->cap_frame[c], m->cap_frame_alt[c]);
-				m->frame_n[c] = cnt[0];
+				for (int k = 0; k < 3; k++)
+					if (run[k])
+					{
+						const int c = order[k];
+						std::swap(m->frame[c], m->frame_alt[c]);
+						std::swap(m->cap_frame[c], m->cap_frame_alt[c]);
+						m->frame_n[c] = cnt[k];
+					}
 			}
 		}
 		for (int c = 0; c < MULLS_NC; c++)
 			rep->frame_n[c] = m->frame_n[c];
 
 		// 4. append_feature(last_target, true, used) (:54): the vertex cloud always
-		for (int c = 0; c < MULLS_NC; c++)
-			if ((c == MULLS_VERTEX || P->used_feature_type[c] == '1') && m->frame_n[c])
-			{
-				const int rc = reserve(ctx, &m->rec[c], &m->cap[c], (size_t)m->n[c] + m->frame_n[c], m->n[c]);
-				if (rc != MULLS_OK)
-					return rc;
-				HIPCHK(ctx, hipMemcpyAsync(m->rec[c] + (size_t)m->n[c] * 3, m->frame[c], (size_t)m->frame_n[c] * REC, hipMemcpyDeviceToDevice, st));
-				m->n[c] += m->frame_n[c];
-			}
+		{
+			SegCopier app(ctx);
+			for (int c = 0; c < MULLS_NC; c++)
+				if ((c == MULLS_VERTEX || P->used_feature_type[c] == '1') && m->frame_n[c])
+				{
+					const int rc = reserve(ctx, &m->rec[c], &m->cap[c], (size_t)m->n[c] + m->frame_n[c], m->n[c]);
+					if (rc != MULLS_OK)
+						return rc;
+					app.add_dev(m->rec[c] + (size_t)m->n[c] * 3, m->frame[c], (size_t)m->frame_n[c] * REC);
+					m->n[c] += m->frame_n[c];
+				}
+			if (app.flush(st) != MULLS_OK)
+				return MULLS_E_HIP;
+		}
 		// 5. the map moves to the frame's coordinates (:57-59)
 		rows12_of(tran_target_map, t12);
-		HIPCHK(ctx, hipMemcpyAsync(m->T12, t12, sizeof(t12), hipMemcpyHostToDevice, st));
-		for (int c = 0; c < MULLS_NC; c++)
-			launch_transform_aos(st, m->rec[c], m->n[c], m->T12);
+		launch_transform_clouds(st, m->rec, m->n, MULLS_NC, t12);
 		std::memcpy(m->pose, frame_pose_lo, sizeof(m->pose));
 		// 6. dist_filter(cloud, local_map_radius) on all six (:62-67)
 		MapCompactArgs a;
@@ -373,9 +412,17 @@ extern "C"
 		if (any_thin)
 		{
 			std::vector<uint8_t> mask(mask_total);
-			uint8_t *dmask = nullptr;
-			if (dmalloc(ctx, &dmask, mask_total) != MULLS_OK)
-				return MULLS_E_HIP;
+			if (m->cap_dmask < mask_total) // (grow-only: no allocator call per frame)
+			{
+				HIPCHK(ctx, hipStreamSynchronize(st));
+				if (m->dmask)
+					(void)hipFree(m->dmask);
+				m->dmask = nullptr, m->cap_dmask = 0;
+				if (dmalloc(ctx, &m->dmask, mask_total * 2) != MULLS_OK)
+					return MULLS_E_HIP;
+				m->cap_dmask = mask_total * 2;
+			}
+			uint8_t *dmask = m->dmask;
 			std::memset(&a, 0, sizeof(a));
 			size_t off = 0;
 			uint32_t newn[MULLS_NC];
@@ -401,7 +448,6 @@ extern "C"
 				else
 					e = hipStreamSynchronize(st);
 			}
-			(void)hipFree(dmask);
 			if (e != hipSuccess)
 			{
 				ctx->err = std::string("map thinning: ") + hipGetErrorString(e);
