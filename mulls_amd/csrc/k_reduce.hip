@@ -249,18 +249,20 @@ struct StepLds
 {
 	mulls::StepState S;
 	SolveWs ws;
-	FinishLds F; // the combined row and the record's counter block (k_step: read from the record; k_finish_step: left here by finish_pair)
+	double comb[MULLS_NTERM_PAD];
+	uint32_t cnt[32]; // the record's counter block: n_valid, n_alive, src_n, tgt_n, bbox (6 each)
 	uint32_t jobs[MULLS_NC], n0[MULLS_NC];
 	int go, iter, active, resid, done, left;
 };
 constexpr uint32_t STEP_WORDS = (uint32_t)(sizeof(mulls::StepState) / 8), STEP_WORDS_PER_LANE = (STEP_WORDS + 63u) / 64u;
-// PRE (k_finish_step): finish_pair of this workgroup has filled L.F, and the pair's StepState words were requested at the start of the kernel (sw: lanes 0..63)
-template <bool PRE = false>
+// PRE (k_finish_step): the workgroup has filled L.comb / L.cnt from its own finish_pair, and the pair's StepState words were requested at the start of the kernel
+// (sw: lanes 0..63; nullptr: k_step)
 __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__restrict__ descs, PairState *__restrict__ states, const RunParams &rp, const mulls::IcpConst &K,
 										   const PairOut *__restrict__ out, mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, StepLds &L,
 										   const unsigned long long *sw = nullptr)
 {
 	const int l = (int)threadIdx.x;
+	const bool PRE = sw != nullptr; // (one function, inlined into both kernels: two instantiations would each call solve_wave out of line — 168 registers instead of 104)
 	mulls::StepState &S = L.S;
 	if (l == 0)
 	{
@@ -291,9 +293,9 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 		if (!PRE)
 		{
 			if (l < MULLS_NTERM_PAD)
-				L.F.comb[l] = o.comb[l];
+				L.comb[l] = o.comb[l];
 			if (l < 30)
-				L.F.cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
+				L.cnt[l] = (&o.n_valid[0])[l]; // n_valid, n_alive, src_n, tgt_n, bbox are consecutive
 		}
 		if (l < MULLS_NC)
 		{
@@ -302,13 +304,13 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 			L.n0[l] = d.src_n0;
 		}
 		__syncthreads();
-		const uint32_t *n_valid = L.F.cnt, *n_alive = L.F.cnt + 6, *src_n = L.F.cnt + 12, *tgt_n = L.F.cnt + 18, *obox = L.F.cnt + 24;
+		const uint32_t *n_valid = L.cnt, *n_alive = L.cnt + 6, *src_n = L.cnt + 12, *tgt_n = L.cnt + 18, *obox = L.cnt + 24;
 		mulls::PairIter &h = S.h;
 		if (l == 0)
 		{
 			L.go = 0;
 			if (L.resid)
-				mulls::step_residual(h, K, L.F.comb[0], L.F.comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
+				mulls::step_residual(h, K, L.comb[0], L.comb[1]); // get_multi_metrics_lls_residual + information matrix (:2518-2544, :1386)
 			else
 			{
 				const int i = L.iter;
@@ -350,7 +352,7 @@ __device__ __forceinline__ bool step_pair(uint32_t pair, const CloudDesc *__rest
 		}
 		__syncthreads();
 		if (L.go && l < 64)
-			solve_wave(h, K, L.F.comb, L.iter, L.ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
+			solve_wave(h, K, L.comb, L.iter, L.ws); // solve :1924-1964, step test :1348-1354, convergence :1357, guess update :1400
 		__syncthreads();
 		if (l == 0)
 		{
@@ -444,10 +446,15 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_finish_step(CloudDesc *__restri
 		for (uint32_t k = 0; k < STEP_WORDS_PER_LANE; k++)
 			sw[k] = src[min(threadIdx.x + 64u * k, STEP_WORDS - 1u)];
 	}
+	__shared__ FinishLds F;
 	if (live)
-		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6, &L.F);
-	__syncthreads(); // L.F is complete
-	const bool left = step_pair<true>(pair, descs, states, rp, K, out, steps, results, brute, L, sw);
+		finish_pair(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6, &F);
+	__syncthreads(); // F is complete
+	if (threadIdx.x < MULLS_NTERM_PAD)
+		L.comb[threadIdx.x] = F.comb[threadIdx.x];
+	else if (threadIdx.x >= 64u && threadIdx.x < 94u)
+		L.cnt[threadIdx.x - 64u] = F.cnt[threadIdx.x - 64u];
+	const bool left = step_pair(pair, descs, states, rp, K, out, steps, results, brute, L, sw);
 	if (threadIdx.x == 0)
 	{
 		// arrivals (low half) and pairs still iterating (high half) in ONE 64-bit atomic: no fence between two counters, none per workgroup — what the other
