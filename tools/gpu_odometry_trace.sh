@@ -4,7 +4,7 @@ set -u
 TAG=${1:-odo_trace}; N=${2:-260}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python tools/gpu_odometry.py 8 > $OUT/run.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- python tools/gpu_odometry.py 8 > $OUT/run.log 2>&1
 python - "$OUT/trace" $N > $OUT/timeline.txt <<'PY'
 import csv, glob, sys
 rows=[]
