@@ -2284,6 +2284,10 @@ void get_pc_pca_feature(Cloud &cloud, std::vector<PcaFeature> &features, bool wi
 // CFilter::classify_nground_pts (cfilter.hpp:2058-2290) and what it calls: encode_stable_points (:1071-1181), non_max_suppress
 // (:1243-1311), xy_normal_balanced_downsample (:551-602), random_downsample_pcl (:606-628).
 std::atomic<unsigned long long> g_nms_ties{0}; // pairs of neighbours in non_max_suppress's visiting order with equal normal[3]
+// classify_nground_pts' decisions against Eigen's accuracy: [0] points with a decision (enough neighbours), [1] / [2] those of them where an eigenvalue ratio or an eigenvector
+// component the chain compares lies within 1e-5 / 1e-4 of the threshold it is compared with (upstream's SelfAdjointEigenSolver<Matrix3f> is good to ~1e-6 of the largest
+// eigenvalue; pcl_restated.h decomposes in double) — how many labels COULD differ from a run with real PCL
+std::atomic<unsigned long long> g_cls_census[3];
 
 // non_max_suppress(cloud_in, cloud_out, nms_radius).  The visiting order is std::sort's by normal[3] descending: among equal keys — a few
 // hundred per scan, points of one small cluster share their neighbourhood — it is whatever this toolchain's introsort leaves, upstream as
@@ -2422,6 +2426,20 @@ int classify_nground_impl(Cloud &cloud_in, const mulls_classify_params &P, Cloud
 		const PcaFeature &f = cloud_features[i];
 		if (f.pt_num > neigh_k_min)
 		{
+			{
+				const double pz = std::abs((double)f.principal[2]), nz = std::abs((double)f.normal[2]);
+				const double gaps[] = {std::abs(f.linear_2 - edge_thre),	 std::abs(f.linear_2 - edge_thre_down),	   std::abs(f.planar_2 - planar_thre),
+									   std::abs(f.planar_2 - planar_thre_down), std::abs(pz - linear_vertical_sin_high_thre), std::abs(pz - linear_vertical_sin_low_thre),
+									   std::abs(nz - planar_vertical_sin_high_thre), std::abs(nz - planar_vertical_sin_low_thre)};
+				double g = 1e300;
+				for (double v : gaps)
+					g = std::min(g, v);
+				g_cls_census[0]++;
+				if (g < 1e-5)
+					g_cls_census[1]++;
+				if (g < 1e-4)
+					g_cls_census[2]++;
+			}
 			if (f.linear_2 > edge_thre)
 			{
 				if (std::abs(f.principal[2]) > linear_vertical_sin_high_thre)
@@ -2718,6 +2736,28 @@ extern "C"
 			std::memcpy(in_after, in.data(), in.size() * sizeof(Pt));
 		return MULLS_OK;
 	}
+	// classify_nground_pts' threshold margins (g_cls_census): out[0..2]; reset != 0 clears them afterwards
+	void mulls_oracle_classify_census(unsigned long long out[3], int reset)
+	{
+		for (int k = 0; k < 3; k++)
+		{
+			out[k] = g_cls_census[k];
+			if (reset)
+				g_cls_census[k] = 0;
+		}
+	}
+
+	// restated::search_census (pcl_restated.h): out[0..3]; reset != 0 clears it afterwards
+	void mulls_oracle_search_census(unsigned long long out[4], int reset)
+	{
+		for (int k = 0; k < 4; k++)
+		{
+			out[k] = restated::search_census(k);
+			if (reset)
+				restated::search_census(k) = 0;
+		}
+	}
+
 	unsigned long long mulls_oracle_nms_ties(int reset)
 	{
 		const unsigned long long v = g_nms_ties;

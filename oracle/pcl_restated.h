@@ -32,6 +32,7 @@
 //       into 0.577); one-pass float moments in that order; the normal = the smallest eigenvector as above, turned towards the origin.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdint>
 #include <random>
@@ -53,6 +54,16 @@ inline float l2_simple(const P &a, const Q &b)
 	diff = a.z - b.z;
 	result += diff * diff;
 	return result;
+}
+
+// Census of the places where the restated searches had to CHOOSE what FLANN leaves to its implementation (tests/test_pcl_operators.py reads it on the demo scans):
+//   [0] searches   [1] searches whose max_nn cut falls inside a group of equal distances (which of them stay is FLANN's business)
+//   [2] candidates exactly ON the radius (d == r^2: in or out depends on `<` against `<=`)   [3] searches that return two neighbours at the same distance
+//       (their order decides the order of the float sums of the PCA that follows)
+inline std::atomic<unsigned long long> &search_census(int which)
+{
+	static std::atomic<unsigned long long> c[4];
+	return c[which];
 }
 
 // exact radius / radius-k search over a fixed point set; a uniform grid only limits which points are looked at
@@ -123,6 +134,8 @@ class RadiusIndex
 			for (size_t t = 0; t < n_; t++)
 			{
 				const float d = l2_simple(q, pts[t]);
+				if (d == r2)
+					search_census(2)++;
 				if (d < r2)
 					all.push_back(std::make_pair(d, (int)t));
 			}
@@ -146,14 +159,27 @@ class RadiusIndex
 						{
 							const int t = order_[s];
 							const float d = l2_simple(q, pts[t]);
+							if (d == r2)
+								search_census(2)++;
 							if (d < r2)
 								all.push_back(std::make_pair(d, t));
 						}
 					}
 		}
 		std::sort(all.begin(), all.end()); // (distance, index)
+		search_census(0)++;
 		if (max_nn > 0 && all.size() > (size_t)max_nn)
+		{
+			if (all[max_nn - 1].first == all[max_nn].first)
+				search_census(1)++;
 			all.resize(max_nn);
+		}
+		for (size_t k = 1; k < all.size(); k++)
+			if (all[k].first == all[k - 1].first)
+			{
+				search_census(3)++;
+				break;
+			}
 		idx.resize(all.size());
 		d2.resize(all.size());
 		for (size_t k = 0; k < all.size(); k++)

@@ -218,6 +218,22 @@ def classify_nground(pts, params):
     return _classify(lib().mulls_oracle_classify_nground, pts, params)
 
 
+def search_census(reset=False):
+    """Where the restated PCL / FLANN searches had to choose (oracle/pcl_restated.h: search_census): dict of searches, max_nn cuts inside a group of equal
+    distances, candidates exactly on the radius, searches returning two neighbours at the same distance."""
+    out = (C.c_ulonglong * 4)()
+    lib().mulls_oracle_search_census(out, int(reset))
+    return dict(searches=int(out[0]), cut_in_tie=int(out[1]), on_radius=int(out[2]), equal_neighbours=int(out[3]))
+
+
+def classify_census(reset=False):
+    """classify_nground's decisions against the accuracy of upstream's float eigen-solver: points with a decision, and those among them where a compared
+    quantity lies within 1e-5 / 1e-4 of its threshold."""
+    out = (C.c_ulonglong * 3)()
+    lib().mulls_oracle_classify_census(out, int(reset))
+    return dict(decisions=int(out[0]), within_1e5=int(out[1]), within_1e4=int(out[2]))
+
+
 def nms_ties(reset=False):
     """How many neighbours in non_max_suppress's visiting order had equal normal[3] so far (the order upstream leaves to std::sort)."""
     f = lib().mulls_oracle_nms_ties

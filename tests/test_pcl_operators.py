@@ -134,3 +134,43 @@ def test_ransac_stopping_rule_is_pcl_s_and_never_near_its_boundary():
     print("plane RANSAC stopping test over %d scans: %s" % (len(scans), {k: v for k, v in c.items() if k.startswith("ransac")}))
     assert cells == len(scans) and c["ransac_tests"] > 1000
     assert c["ransac_near_boundary"] == 0 and c["ransac_forms_disagree"] == 0
+
+
+def test_census_of_what_flann_and_eigen_leave_open():
+    """pcl::KdTreeFLANN / pcl::PCA are restated (oracle/pcl_restated.h, "parity unpinned"): where could a run with the real libraries differ?  Counted on the
+    non-ground clouds of the demo scans and of two synthetic scans through classify_nground's whole chain (neighbourhood PCA, labels, non_max_suppress):
+      * a max_nn cut that falls inside a group of equal distances (FLANN decides which of them stay),
+      * a candidate exactly on the search radius (`<` against `<=`),
+      * neighbours at equal distances (their order is the order of the PCA's float sums),
+      * a label decision whose eigenvalue ratio / eigenvector component lies within 1e-5 of its threshold (Eigen's float solver is good to ~1e-6).
+    The counts bound the exposure: they are reported, and the first two — which would change a neighbourhood — have to stay rare."""
+    import os
+
+    from mulls_amd import synth
+
+    scans = []
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_pair.npz")
+    if os.path.exists(gold):
+        g = np.load(gold)
+        for k in ("scan_0", "scan_15"):
+            s = g[k]
+            scans.append(abi.make_points(s[:, :3], np.zeros_like(s[:, :3]), s[:, 3], np.zeros(len(s), np.float32)))
+    for seed in (3, 4):
+        scene = synth.Scene(seed)
+        sc = synth.raycast(scene, synth.se3(0, 0, scene.sensor_height), 64, 1200, seed=seed)
+        scans.append(abi.make_points(sc["xyz"], np.zeros_like(sc["xyz"]), sc["intensity"], sc["t"]))
+    G, P = abi.ground_params(), abi.classify_params()
+    pyoracle.search_census(reset=True), pyoracle.classify_census(reset=True)
+    n_pts = 0
+    for pts in scans:
+        unground = pyoracle.ground_filter(pts, G)[2]
+        out, _ = pyoracle.classify_nground(unground, P)
+        n_pts += len(unground)
+        assert sum(len(c) for c in out) > 0
+    s, c = pyoracle.search_census(reset=True), pyoracle.classify_census(reset=True)
+    print("restated searches on %d scans (%d non-ground points): %s; label decisions: %s" % (len(scans), n_pts, s, c))
+    assert s["searches"] > 10000 and c["decisions"] > 1000
+    # a neighbourhood that could differ with the real FLANN: fewer than one search in a thousand
+    assert s["cut_in_tie"] + s["on_radius"] <= s["searches"] // 1000
+    # labels within reach of the eigen-solver's accuracy: fewer than one decision in a thousand
+    assert c["within_1e5"] <= max(1, c["decisions"] // 1000)
