@@ -312,6 +312,68 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restri
 					 wd, tpos, nn_hint, mq);
 }
 
+// A small MIXED batch (a scan against a local map whose ground class outgrew the LDS tier): the class clouds of both tiers in ONE launch.  Workgroups
+// [0, n_lds) are k_cert_nn's (1024 lanes, the staged search at hand), the rest k_cert_big's (their upper eight waves leave at once; BigLds lives in the dynamic
+// LDS block) — the two kernels ran one after the other although neither reads what the other writes: 14 + 8 us per iteration of a single registration.
+// Same functions, same results; k_filter follows for the chunk-level jobs as before.
+__global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_mixed(uint32_t n_lds, const Job *__restrict__ cjobs, const Job *__restrict__ bjobs, uint32_t split,
+																 CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
+																 float4 *__restrict__ snrm, const GridDesc *__restrict__ grids, const uint32_t *__restrict__ cell_start,
+																 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf, const uint32_t *__restrict__ cs,
+																 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
+																 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
+																 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+	if (blockIdx.x < n_lds)
+	{
+		const Job job = cjobs[blockIdx.x];
+		const PairState &ps = states[job.pair];
+		if (!ps.active)
+			return;
+		CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+		const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
+		__shared__ CertLds<MULLS_CERT_SMALL> s_cert;
+		if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
+														   match, wd, tpos, nn_hint, mq))
+			return;
+		__syncthreads(); // the light pass's LDS is free
+		lds_search_class(rp, ps, job, d, g, lds_layout(lds_raw, cap, rp.grid_maxcells), lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
+						 nn_hint, mq);
+		return;
+	}
+	if (threadIdx.x >= MULLS_BIG_BLOCK)
+		return; // (a terminated wave does not hold the others' barriers up)
+	const uint32_t wg = blockIdx.x - n_lds;
+	const Job job = bjobs[wg / split];
+	const uint32_t part = wg % split;
+	const PairState &ps = states[job.pair];
+	if (!ps.active)
+		return;
+	const uint32_t ci = job.pair * MULLS_NC + job.cls;
+	CloudDesc &d = descs[ci];
+	const bool class_level = (job.count & MULLS_JOB_CLASS) != 0u;
+	const uint32_t cnt = (job.count & ~MULLS_JOB_CLASS) ? (job.count & ~MULLS_JOB_CLASS) : (uint32_t)MULLS_SRC_PER_BLOCK;
+	uint32_t q0, q1;
+	if (class_level)
+	{
+		if (part)
+			return;
+		q0 = 0u, q1 = min(d.src_n, cnt);
+	}
+	else
+	{
+		const uint32_t per = cnt / split;
+		q0 = job.start + part * per, q1 = min(d.src_n, q0 + per);
+		if (q0 >= q1)
+			return;
+	}
+	const GridDesc g = grids[ci];
+	const BmGrid B = {bm + g.cell_off, pf + g.cell_off, cs + d.tgt_off + ci};
+	cert_big<MULLS_BIG_BLOCK, 3>(*reinterpret_cast<BigLds<MULLS_BIG_BLOCK * 3> *>(lds_raw), rp, ps, job.cls, q0, q1, class_level, d, g, B, tsorted + d.tgt_off, spos, snrm, flag, nn_idx,
+								 nn_d2, winner, tnrm, match, wd, tpos, reinterpret_cast<int2 *>(nn_hint), mq);
+}
+
 __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															 const PairState *__restrict__ states, RunParams rp, const float4 *__restrict__ spos,
 															 const float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
@@ -538,6 +600,45 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	hipLaunchKernelGGL(k_nn_lds, dim3(njobs < n_cu ? njobs : n_cu), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm,
 					   grids, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, wl, wl_ctr, parity & 1u);
 	return 0;
+}
+
+// both tiers' class clouds of a small mixed batch in one launch (k_cert_mixed): 1 = launched, 0 = not applicable (the caller launches the tiers one after the other)
+int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states,
+					  const RunParams &rp, float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const unsigned long long *bm, const uint32_t *pf,
+					  const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match,
+					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells)
+{
+	static size_t dyn_max = 0;
+	static uint32_t n_cu = 256;
+	if (!dyn_max)
+	{
+		hipFuncAttributes fa;
+		dyn_max = 1;
+		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert_mixed)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u)
+		{
+			const size_t room = 160u * 1024u - fa.sharedSizeBytes;
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_cert_mixed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) == hipSuccess)
+				dyn_max = room;
+		}
+		int dev = 0, cus = 0;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+			n_cu = (uint32_t)cus;
+	}
+	if (!n_lds || !n_big || rp.normal_shooting || rp.debug_stop == 10u || rp.debug_stop == 22u)
+		return 0;
+	uint32_t split = 1;
+	while (split < 16 && n_big * split * 2u <= max_wgs)
+		split <<= 1;
+	// one workgroup per CU (each holds the whole LDS): only while every workgroup of both tiers is resident at once
+	while (split > 1 && n_lds + n_big * split > n_cu)
+		split >>= 1;
+	const bool dedup = rp.lds_dedup != 0u;
+	const size_t dyn = nn_lds_bytes(cap, maxcells, dedup) > sizeof(BigLds<MULLS_BIG_BLOCK * 3>) ? nn_lds_bytes(cap, maxcells, dedup) : sizeof(BigLds<MULLS_BIG_BLOCK * 3>);
+	if (n_lds + n_big * split > n_cu || dyn > dyn_max)
+		return 0;
+	hipLaunchKernelGGL(k_cert_mixed, dim3(n_lds + n_big * split), dim3(MULLS_LDS_BLOCK), dyn, st, n_lds, cjobs, bjobs, split, descs, states, rp, spos, snrm, grids, cell_start, bm, pf, cs,
+					   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap);
+	return 1;
 }
 
 void launch_cert_big(hipStream_t st, uint32_t njobs, const Job *jobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos, float4 *snrm,

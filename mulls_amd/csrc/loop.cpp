@@ -214,19 +214,28 @@ RUN_ALIASES
 	ev.begin(&ctx->prof.ms_nn);
 	if (tier == 0)
 		launch_nn(sst, L.job_n, jobs, B->descs, B->states, rp, B->spos, B->snrm, B->tpos, B->flag, B->nn_idx, B->nn_d2, B->winner);
-	if (L.cjob_n &&
+	// mixed batch, first iterations: chunk-level jobs for every cloud of the global-memory tier (MULLS_OPT_BIG_EARLY_SETS)
+	// ... and every iteration of a small one: a handful of class-level workgroups cannot search a dense map's leftovers fast enough (a 1 M-point map leaves most
+	// points uncertified for ten iterations: its second-nearest targets are millimetres behind the nearest), while k_filter costs such a batch 6 us
+	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
+	const uint32_t max_wgs = iter < 3 ? 2048u : 512u; // (resident workgroups of k_cert_big: two per CU)
+	// a small mixed batch: both tiers' class clouds in one launch
+	const uint32_t big_n = early ? L.ejob_n : L.bjob_n;
+	const Job *big_jobs = early ? B->ejobs + L.ejob_lo : B->bjobs + L.bjob_lo;
+	const bool together = tier == 3 && L.cjob_n && big_n &&
+						  launch_cert_mixed(sst, L.cjob_n, B->cjobs + L.cjob_lo, big_n, big_jobs, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->bm,
+											B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap,
+											rp.grid_maxcells) != 0;
+	if (!together && L.cjob_n &&
 		launch_nn_lds(sst, L.cjob_n, B->cjobs + L.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner,
 					  B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, wl, wl_ctr, parity) != 0)
 	{
 		ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 		return MULLS_E_HIP;
 	}
-	// mixed batch, first iterations: chunk-level jobs for every cloud of the global-memory tier (MULLS_OPT_BIG_EARLY_SETS)
-	// ... and every iteration of a small one: a handful of class-level workgroups cannot search a dense map's leftovers fast enough (a 1 M-point map leaves most
-	// points uncertified for ten iterations: its second-nearest targets are millimetres behind the nearest), while k_filter costs such a batch 6 us
-	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
-	const uint32_t max_wgs = iter < 3 ? 2048u : 512u; // (resident workgroups of k_cert_big: two per CU)
-	if (early)
+	if (together)
+		;
+	else if (early)
 		launch_cert_big(sst, L.ejob_n, B->ejobs + L.ejob_lo, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->bm, B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx,
 						B->nn_d2, B->winner, B->tpos, B->tnrm, B->nn_hint, B->match, B->wd, B->mq);
 	else if (L.bjob_n)

@@ -99,3 +99,24 @@ def test_mixed_batch_with_traces_and_device_step(ctx_auto, zoo):
         assert ro.trace_len == host[i].trace_len
         for k in range(ro.trace_len):
             assert list(ro.trace[k].ncorr) == list(host[i].trace[k].ncorr) and list(ro.trace[k].nsrc) == list(host[i].trace[k].nsrc), (i, k)
+
+
+def test_small_mixed_batch_one_launch_for_both_tiers(zoo):
+    """A small mixed batch runs the class clouds of both tiers in ONE launch (k_cert_mixed); MULLS_OPT_DEBUG_STOP = 22 launches the tiers one after the other
+    as large batches do.  Same bits either way, equal to the oracle."""
+    from mulls_amd import lib
+
+    P = abi.kitti_params()
+    c = lib.Context(0)
+    try:
+        for n in (1, 3):
+            pairs = [z[0] for z in zoo[1 : 1 + n]] if n > 1 else [zoo[1][0]]
+            together = c.icp_batch(pairs, P)
+            c.set_option(abi.OPT_DEBUG_STOP, 22)
+            apart = c.icp_batch(pairs, P)
+            c.set_option(abi.OPT_DEBUG_STOP, 0)
+            for i, p in enumerate(pairs):
+                assert same_bits(together[i], apart[i]), (n, i)
+                oracle_equal(pyoracle.icp(p, P)[0], together[i])
+    finally:
+        c.close()
