@@ -243,7 +243,13 @@ enum mulls_option
 	MULLS_OPT_BIG_EARLY_SETS = 22,		  /* [2] mixed batches: the first iterations run every global-memory-tier cloud as chunk-level jobs shared by several workgroups
 											 (+ k_filter) — while most points still need a search that beats one workgroup per class cloud; from this iteration on the
 											 down-sampled source clouds are class-level jobs (certificates, leftovers, rejection chain in one workgroup, no k_filter) */
-	MULLS_OPT_COUNT = 23
+	MULLS_OPT_KCERT = 23,				  /* [1] k-candidate certificates: a point whose hinted target fails the certificate evaluates the few nearest targets its last search
+											 saw before it is searched again (0: round 4's certificates only) */
+	MULLS_OPT_KCERT_MIN = 24,			  /* [64] LDS tier: leftover lists shorter than this skip the look (it costs one chain of round trips whatever the length) */
+	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [0 = never] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
+											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits).  Measured no faster than one
+											 workgroup per trip at 4096 pairs (profiles/r05_experiments.txt), so off by default; set before the batch is filled */
+	MULLS_OPT_COUNT = 26
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

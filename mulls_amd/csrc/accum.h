@@ -94,10 +94,12 @@ __device__ __forceinline__ constexpr int li_term(int slot) { return slot == 0 ? 
 		else if ((k) >= T0 && (k) < T0 + NT)                   \
 			t[(k)-T0] = (TS)(v);                               \
 	} while (0)
-template <typename TS, int T0, int NT, int MODE = 0>
+// METRIC >= 0: the caller knows the metric at compile time (k_accum_wave: the other metrics' arithmetic is not even compiled — their temporaries would set the
+// kernel's register count)
+template <typename TS, int T0, int NT, int MODE = 0, int METRIC = -1>
 __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS t[NT])
 {
-	const int metric = A.metric, iter_num = A.iter_num;
+	const int metric = METRIC >= 0 ? METRIC : A.metric, iter_num = A.iter_num;
 	const bool residual_pass = A.residual_pass, dist_w = A.dist_w, resid_w = A.resid_w, inten_w = A.inten_w, faithful = A.faithful;
 	const float class_w = A.class_w, window = A.window;
 	const float px = P.x, py = P.y, pz = P.z;
@@ -314,6 +316,7 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 //   (in double), a butterfly adds the 64 partial sums ((xor 1, xor 2, mirror 8, mirror 16) inside the 16-lane rows, then
 //   (row0 + row1) + (row2 + row3)); the trip sums are added to 0.0 in trip order.
 #define MULLS_ACC_LANES 1024
+#define MULLS_WI_MAGIC 0x57493031u // marks a written entry of the intensity-weight memo (RunParams::wi_memo)
 #define MULLS_RED_BYTES ((size_t)27 * MULLS_ACC_LANES * sizeof(float)) // the LDS term buffer: 27 float terms, or 13 double terms, of 1024 slots
 #define MULLS_RED_BYTES_HALF ((size_t)14 * MULLS_ACC_LANES * sizeof(float)) // ... in the two-halves mode: 14 float terms (or 7 double terms)
 
@@ -325,6 +328,15 @@ __device__ __forceinline__ double dpp_add_f64(double v)
 	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
 	const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xf, 0xf, false);
 	const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xf, 0xf, false);
+	return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// ... through a DPP control that reaches only the rows of ROWS (row_bcast:15 / :31): the other rows add +0.0
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_add_f64_rows(double v)
+{
+	const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROWS, 0xf, false);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROWS, 0xf, false);
 	return v + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane)

@@ -49,6 +49,8 @@ void init_cert(const mulls_ctx *ctx, RunParams &rp)
 	rp.cert_slack_min = (float)ctx->opt[MULLS_OPT_CERT_SLACK_MIN];
 	rp.cert_slack_max = (float)ctx->opt[MULLS_OPT_CERT_SLACK_MAX];
 	rp.cert_slack_rate = (float)ctx->opt[MULLS_OPT_CERT_SLACK_RATE];
+	rp.kcert = rp.cert && ctx->opt[MULLS_OPT_KCERT] != 0.0 ? 1u : 0u;
+	rp.kcert_min = (uint32_t)ctx->opt[MULLS_OPT_KCERT_MIN];
 }
 
 // sub-batches in flight of a host-stepped lock-step batch of n pairs
@@ -148,7 +150,7 @@ void options_init(mulls_ctx *ctx)
 	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 1, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 384;
 	o[MULLS_OPT_SUBBATCHES] = 0, o[MULLS_OPT_TWO_STREAMS] = 0, o[MULLS_OPT_CERTIFICATES] = 1;
 	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
-	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0, o[MULLS_OPT_MIXED_TIERS] = 1, o[MULLS_OPT_BIG_EARLY_SETS] = 2;
+	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0, o[MULLS_OPT_MIXED_TIERS] = 1, o[MULLS_OPT_BIG_EARLY_SETS] = 2, o[MULLS_OPT_KCERT] = 1, o[MULLS_OPT_KCERT_MIN] = 64, o[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS] = 0;
 	static const struct
 	{
 		const char *name;
@@ -156,7 +158,7 @@ void options_init(mulls_ctx *ctx)
 	} env[] = {{"MULLS_HOST_STEP", MULLS_OPT_HOST_STEP}, {"MULLS_RESIDENT_MIN_PAIRS", MULLS_OPT_RESIDENT_MIN_PAIRS}, {"MULLS_RESIDENT_MAX_PAIRS", MULLS_OPT_RESIDENT_MAX_PAIRS},
 			   {"MULLS_FEW_LAUNCHES_MAX_PAIRS", MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS}, {"MULLS_SUBBATCHES", MULLS_OPT_SUBBATCHES}, {"MULLS_TWO_STREAMS", MULLS_OPT_TWO_STREAMS},
 			   {"MULLS_CERTIFICATES", MULLS_OPT_CERTIFICATES}, {"MULLS_LDS_DEDUP", MULLS_OPT_LDS_DEDUP}, {"MULLS_GRID_H0", MULLS_OPT_GRID_H0}, {"MULLS_BM_H0", MULLS_OPT_BM_H0},
-			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}};
+			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}, {"MULLS_KCERT", MULLS_OPT_KCERT}, {"MULLS_KCERT_MIN", MULLS_OPT_KCERT_MIN}, {"MULLS_ACCUM_WAVE_MIN_TRIPS", MULLS_OPT_ACCUM_WAVE_MIN_TRIPS}};
 	for (const auto &e : env)
 		if (const char *v = std::getenv(e.name))
 		{
@@ -644,7 +646,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 
 	int rc = MULLS_OK;
 	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
-	bool winner_grew = false;
+	bool winner_grew = false, cand_grew = false, memo_grew = false;
 	const size_t SG = (size_t)ctx->opt[MULLS_OPT_STAGGER]; // bytes between the starts of the per-point arrays inside their 2 MiB pages
 	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec));
 	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so, nullptr, 12 * SG));
@@ -658,6 +660,9 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	A(grow(ctx, &B->nn_d2, &B->cap_src[8], so, nullptr, 7 * SG));
 	A(grow(ctx, &B->nn_hint, &B->cap_src[9], 2 * so, nullptr, 8 * SG)); // LDS tier: (hint word, bound) records
 	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so, nullptr, 9 * SG));
+	A(grow(ctx, &B->nn_cand, &B->cap_src[11], so, &cand_grew, 14 * SG)); // k-candidate certificates: 16-byte candidate records
+	if (ctx->opt[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS] > 0.0)
+		A(grow(ctx, &B->wi_memo, &B->cap_src[12], so, &memo_grew, 15 * SG)); // k_accum_wave: memo of the intensity weight (the kernel runs without it: wi_memo null = no memo)
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
 	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to, nullptr, 10 * SG));
@@ -804,6 +809,10 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 		if (up.flush(st) != MULLS_OK)
 			return MULLS_E_HIP;
 	}
+	if (e == hipSuccess && memo_grew) // (an entry counts only with its magic word: fresh memory is cleared of chance hits)
+		e = hipMemsetAsync(B->wi_memo, 0, B->cap_src[12] * sizeof(uint4), st);
+	if (e == hipSuccess && cand_grew) // epoch 0 never passes the epoch test of a run (take_epochs starts at 1)
+		e = hipMemsetAsync(B->nn_cand, 0, B->cap_src[11] * sizeof(uint4), st);
 	if (e == hipSuccess && winner_grew) // later epochs always sort below older entries (k_nn), so only fresh memory needs the fill
 		e = hipMemsetAsync(B->winner, 0xff, B->cap_tgt[3] * sizeof(unsigned long long), st);
 	if (e == hipSuccess)
@@ -1010,14 +1019,19 @@ mulls::IcpConst icp_const(const mulls_params *P)
 // Reserve `n` consecutive epochs of the batch's duplicate table.  The winner key is (descending epoch << 32 | source index)
 // under atomicMin, so newer epochs must sort below older ones: before the 32-bit counter would wrap, the table is refilled
 // with 0xff and the count restarts (stream order puts the fill before this run's kernels).
-int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, uint32_t *base)
+int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, RunParams &rp)
 {
+	uint32_t *base = &rp.tick_base;
+	rp.cand = B->nn_cand;
+	rp.wi_memo = B->wi_memo;
 	if (ctx->opt[MULLS_OPT_DEBUG_TICK] > 0.0 && B->tick == 1) // tests only: put a fresh batch's counter next to the wrap
 		B->tick = (uint32_t)ctx->opt[MULLS_OPT_DEBUG_TICK];
 	if (B->tick > 0xfffffff0u - n)
 	{
 		if (B->winner)
 			HIPCHK(ctx, hipMemsetAsync(B->winner, 0xff, B->cap_tgt[3] * sizeof(unsigned long long), ctx->stream));
+		if (B->nn_cand) // the candidate records carry epochs of the same counter
+			HIPCHK(ctx, hipMemsetAsync(B->nn_cand, 0, B->cap_src[11] * sizeof(uint4), ctx->stream));
 		B->tick = 1;
 	}
 	*base = B->tick;

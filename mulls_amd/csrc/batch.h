@@ -83,6 +83,8 @@ struct mulls_batch
 	float4 *spos = nullptr, *snrm = nullptr, *tpos = nullptr, *tnrm = nullptr;
 	uint8_t *flag = nullptr;
 	int32_t *match = nullptr, *nn_idx = nullptr, *nn_hint = nullptr;
+	uint4 *wi_memo = nullptr; // per source slot: memo of the intensity weight (RunParams::wi_memo)
+	uint4 *nn_cand = nullptr; // per source point: candidate record of the k-candidate certificates (RunParams::cand)
 	float4 *mq = nullptr; // per source point: position and direction of its matched target (2 records), written with match[]
 	float *wd = nullptr, *nn_d2 = nullptr;
 	unsigned long long *winner = nullptr;
@@ -147,7 +149,7 @@ struct mulls_batch
 	std::string dev_key;			 // jobs_key of the tables currently resident on the device
 	size_t cap_jobs[6] = {}, cap_cells[2] = {};
 	// capacities (elements) of the grow-only arrays
-	size_t cap_stage = 0, cap_src[11] = {}, cap_tgt[5] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
+	size_t cap_stage = 0, cap_src[13] = {}, cap_tgt[5] = {}, cap_pairs[5] = {}, cap_setup_jobs = 0, cap_pin[4] = {};
 };
 
 namespace mulls_drv
@@ -196,7 +198,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunParams &rp, uint32_t *lds_cap_out, int *tier_out, bool *resident_out = nullptr, int nsub = 0,
 				bool allow_mixed = false);
 mulls::IcpConst icp_const(const mulls_params *P);
-int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, uint32_t *base);
+int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, RunParams &rp);
 
 struct EvTimer
 {

@@ -119,25 +119,29 @@ __device__ __forceinline__ void bm_scan_box2(const GridDesc &g, const BmGrid &B,
 //             of the distance found, or cubes of twice the radius up to the rejection radius r (k_nn_grid's policy, rounds 1-3).
 //             probe_own = false skips the own-cell probe: on a grid with one or two points per occupied cell it rarely bounds the search inside the cell and
 //             costs three dependent round trips of the query's six (a 236 k-point pair's first iteration: 2.2 ms of a 15 ms step, profiles/r04_large_steps.txt)
+// co: the other lanes' nearest targets of the sweep that produced (bk, sec), for the k-candidate certificates (lane_bests, lds_tier.h).
 __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid &B, const float4 *__restrict__ ts, const float4 q, float r, float m, uint32_t sub,
-												 bool probe_own, nnkey &bk, float &sec, float &Rfin)
+												 bool probe_own, nnkey &bk, float &sec, float &Rfin, CandOut &co)
 {
 	bk = NNKEY_NONE;
 	sec = __builtin_inff();
 	Rfin = 0.0f;
+	nnkey lane_k = NNKEY_NONE; // this lane's own share of the standing sweep
+	float lane_s = __builtin_inff();
 	// one sweep of the cube of radius R: its cells are a superset of every earlier sweep's cells unless the radius was clipped to r (see search_query)
 	auto sweep = [&](float R) {
 		nnkey lk = NNKEY_NONE;
 		float ls = __builtin_inff();
 		bm_scan_box2(g, B, ts, q.x, q.y, q.z, R, sub, lk, ls);
+		const nnkey own_k = lk;
+		const float own_s = ls;
 		grp16_min2(lk, ls);
-		if (bk < lk)
-			sec = 0.0f;
-		else
-		{
-			bk = lk;
-			sec = ls;
-		}
+		// (selects: two branches ending in stores to different variables are merged into one store through a selected address, which puts both on the stack)
+		const bool adopt = !(bk < lk);
+		bk = adopt ? lk : bk;
+		sec = adopt ? ls : 0.0f;
+		lane_k = adopt ? own_k : lane_k;
+		lane_s = adopt ? own_s : lane_s;
 		Rfin = R;
 	};
 	float Rc;
@@ -175,6 +179,7 @@ __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid 
 						take_one(c[w], q.x, q.y, q.z, bk, sec);
 			}
 		}
+		lane_k = bk, lane_s = sec;
 		grp16_min2(bk, sec);
 		// probe 1: the cells within min(first-probe radius, current best distance); when that cube is the own cell the probe above was complete
 		const float R1 = key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m;
@@ -197,14 +202,19 @@ __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid 
 		if (last)
 			break;
 	}
+	co = lane_bests<(int)MULLS_GRID_GROUP, false>(lane_k, lane_s);
+	if (sec == 0.0f)
+		co.b2 = 0.0f; // the standing result lies outside the last (clipped) sweep: nothing is claimed about the other targets
 }
 
+#define MULLS_US16_KCERT 0x8000u // BigLds::us: a hinted point — it gets the k-candidate certificate's look (slots stay below 1536)
 // LDS of k_cert_big: the leftover queries of the workgroup's points (every point can be one), reduction scratch
 template <int SLOTS>
 struct BigLds
 {
 	float4 uq[SLOTS];
-	uint16_t us[SLOTS]; // the query's slot among the workgroup's points
+	float um[SLOTS];	// how far this iteration's step moved the listed point (the k-candidate certificate's look needs it)
+	uint16_t us[SLOTS]; // the query's slot among the workgroup's points (| MULLS_US16_KCERT: a hinted point, gets the look)
 	uint32_t ucount, red[3 * 16];
 };
 
@@ -231,6 +241,7 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	const ClassCtx C = class_ctx(rp, ps, g, (int)cls, d.alive_cur, called);
 	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
 	const bool normal_check = cls != 5u; // vertex correspondences skip the direction check (cregistration.hpp:1292)
+	const bool kc = rp.kcert != 0u && have_prev && called && C.cand != nullptr; // (uniform)
 	const uint32_t nq = q1 > q0 ? q1 - q0 : 0u;
 	const uint32_t ntrips = (nq + BLK - 1u) / BLK; // uniform
 	const unsigned long long *wtab = winner + d.tgt_off;
@@ -345,8 +356,10 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 			M[k] = MULLS_NEEDS_SEARCH;
 			D0[k] = out.w;
 			const uint32_t u = atomicAdd(&CL.ucount, 1u);
+			const bool second = kc && hj < tgt_n; // a hinted point: the k-candidate certificate gets a look before the search (below)
 			CL.uq[u] = out;
-			CL.us[u] = (uint16_t)(threadIdx.x + (uint32_t)k * BLK);
+			CL.um[u] = moved;
+			CL.us[u] = (uint16_t)((threadIdx.x + (uint32_t)k * BLK) | (second ? MULLS_US16_KCERT : 0u));
 		}
 	};
 
@@ -370,7 +383,92 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	if (!called)
 		return; // correspondences of the previous iteration stay in force
 	__syncthreads();
-	const uint32_t U = CL.ucount;
+	uint32_t U = CL.ucount;
+	// Second chance of the leftovers (the k-candidate certificates, kcert_list of the LDS tier for this tier's list): one lane per listed point gathers the
+	// candidates its last search left behind and either certifies it — results where the search below would put them — or restores the sweep radius.  The
+	// list is compacted in place, BLK entries per round (a round writes below what the later rounds still have to read).
+	if (kc && U)
+	{
+		const uint32_t U0 = U;
+		uint32_t kept_total = 0u, n_tried = 0u, n_pass = 0u;
+		for (uint32_t base = 0; base < U0; base += BLK)
+		{
+			const uint32_t i = base + threadIdx.x;
+			float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			uint32_t es = 0u;
+			bool keep = false;
+			if (i < U0)
+			{
+				e = CL.uq[i];
+				es = CL.us[i];
+				keep = true;
+				if (es & MULLS_US16_KCERT)
+				{
+					es &= ~MULLS_US16_KCERT;
+					n_tried++;
+					const uint32_t s = q0 + es, gi = d.src_off + s;
+					const uint4 cr = C.cand[gi];
+					const int2 h = hint2[gi];
+					nnkey bk;
+					float lb_next;
+					uint4 cr_next;
+					const float moved = CL.um[i];
+					const float4 *__restrict__ tp0 = tpos + d.tgt_off; // (read once: through `d` inside the accessor it is re-loaded before every gather)
+					auto pre = [&](uint32_t t) -> uint32_t { return t; };
+					auto pos = [&](uint32_t t) -> float4 { return tp0[t]; };
+					if (kcert_point<false>(rp, cr, h, (uint32_t)ps.iter, e.x, e.y, e.z, moved, tgt_n, pre, pos, bk, lb_next, cr_next))
+					{
+						const float best = key_dist(bk);
+						const uint32_t bi = (uint32_t)bk;
+						const bool matched = !((double)best > C.max_dist_sqr);
+						nn_idx[gi] = matched ? (int32_t)bi : -1;
+						nn_d2[gi] = best;
+						hint2[gi] = make_int2((int32_t)bi, __float_as_int(lb_next));
+						C.cand[gi] = cr_next;
+						if (matched)
+						{
+							matched_cnt++;
+							if (C.gate)
+								atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)s);
+						}
+						keep = false;
+						n_pass++;
+					}
+				}
+			}
+			const unsigned long long bal = __ballot(keep);
+			const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+			if (lane == 0u)
+				CL.red[wave] = (uint32_t)__popcll(bal);
+			__syncthreads(); // every entry of this round has been read
+			uint32_t pre = 0u, total = 0u;
+			for (uint32_t w = 0; w < (uint32_t)(BLK / 64); w++)
+			{
+				const uint32_t c = CL.red[w];
+				pre += w < wave ? c : 0u;
+				total += c;
+			}
+			if (keep)
+			{
+				const uint32_t k = kept_total + pre + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+				CL.uq[k] = e;
+				CL.us[k] = (uint16_t)es;
+			}
+			kept_total += total;
+			__syncthreads();
+		}
+		U = kept_total;
+		if (rp.dbg_ticks && rp.debug_stop == 21u) // diagnostics: points that got the second chance, points it certified
+		{
+			for (int off = 32; off > 0; off >>= 1)
+				n_tried += __shfl_down(n_tried, off), n_pass += __shfl_down(n_pass, off);
+			if ((threadIdx.x & 63u) == 0u && n_tried)
+			{
+				atomicAdd(&rp.dbg_ticks[14], (unsigned long long)n_tried);
+				atomicAdd(&rp.dbg_ticks[15], (unsigned long long)n_pass);
+			}
+		}
+	}
 	// the leftovers against the bitmap grid: 16-lane sub-groups, one query at a time each
 	if (U)
 	{
@@ -382,16 +480,20 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 		{
 			nnkey bk;
 			float sec, Rfin;
-			search_query_bm(g, B, ts, CL.uq[i], C.r, C.m, sub, probe_own, bk, sec, Rfin);
+			CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+			search_query_bm(g, B, ts, CL.uq[i], C.r, C.m, sub, probe_own, bk, sec, Rfin, co);
 			if (sub == 0)
 			{
-				const uint32_t s = q0 + CL.us[i], gi = d.src_off + s;
+				const uint32_t s = q0 + (CL.us[i] & ~MULLS_US16_KCERT), gi = d.src_off + s;
 				const float best = key_dist(bk);
 				const int bi = (int)(uint32_t)bk; // -1: nothing found
 				const bool matched = bi >= 0 && !((double)best > C.max_dist_sqr);
 				nn_idx[gi] = matched ? bi : -1;
 				nn_d2[gi] = best;
-				hint2[gi] = make_int2(bi, __float_as_int(fminf(sqrtf(sec), Rfin))); // every target but the one found is at least that far away
+				const float lb_new = fminf(sqrtf(sec), Rfin);
+				hint2[gi] = make_int2(bi, __float_as_int(lb_new)); // every target but the one found is at least that far away
+				if (C.cand) // the other lanes' nearest targets, and how much farther everything outside {result, candidates} lies (co.b2 >= sec)
+					C.cand[gi] = make_uint4(co.cx, co.cy, __float_as_uint(fminf(sqrtf(co.b2), Rfin) - lb_new), C.epoch);
 				if (matched)
 				{
 					matched_cnt++;

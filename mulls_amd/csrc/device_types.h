@@ -199,9 +199,19 @@ struct RunParams
 	// the bound it leaves behind survives the next (smaller) step.  cert = 0 switches the whole mechanism off (diagnostics).
 	uint32_t cert;
 	float cert_slack_min, cert_slack_max, cert_slack_rate;
+	// k-candidate certificates (round 5).  A search leaves behind, next to the hint, the nearest targets its OTHER lanes saw (CandRec) and a bound on every
+	// target outside that set; a point whose hinted target fails the certificate evaluates the handful of candidates exactly — same distance expression,
+	// lowest index on ties — and is certified when the nearest of them beats that bound by the margin the plain certificate asks for.  kcert = 0: off.
+	uint32_t kcert;
+	uint32_t kcert_min; // LDS tier: a leftover list gets the look only from this length on (a look is one chain of four round trips for the whole list,
+						// a search round of 64 queries about as much: below a few rounds' worth the look costs what it saves)
+	uint4 *cand; // per source point: x, y = candidates besides the hinted target (LDS tier: 4 x uint16, 0xffff = none; global-memory tier: 2 x uint32,
+				 // 0xffffffff = none), z = float bits of (bound on the targets outside the set) - (bound on the targets other than the hint), w = epoch
+				 // (tick_base + iteration of the search that wrote the record: a record of an earlier run, or none, never passes the epoch test)
 	// LDS tier without a working copy of the target clouds (k_tgt_grid): record m of a cropped target class cloud is record tgt_map[tgt_off + m] of
 	// the staged cloud at tgt_stage (tgt_record(), device_util.h).  Null: the cropped copies tpos / tnrm exist (k_crop).
 	const float4 *tgt_stage;
 	const uint16_t *tgt_map;
+	uint4 *wi_memo; // per source slot: (source intensity, target intensity, intensity weight, MULLS_WI_MAGIC) — k_accum_wave's memo of point_wi; null: none
 	unsigned long long *dbg_ticks; // diagnostics (MULLS_OPT_DEBUG_STOP = 20): k_cert's one-pass walk adds its phase times here (10-ns ticks; [6] = workgroups)
 };

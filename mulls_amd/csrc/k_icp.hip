@@ -199,8 +199,9 @@ __device__ __forceinline__ int fused_class(const RunParams &rp, const PairState 
 			nnkey bk;
 			float sec, Rfin;
 			uint32_t trips;
-			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
-			if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+			CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+			if (sub == 0 && commit_search(C, d, us[i], bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
 				matched_cnt++;
 		}
 	}
@@ -568,8 +569,9 @@ __device__ __forceinline__ uint32_t fused_all(const RunParams &rp, const PairSta
 			nnkey bk;
 			float sec, Rfin;
 			uint32_t trips;
-			search_query(g, L, uq[i], A.C.r, A.C.m, sub, bk, sec, Rfin, trips);
-			if (sub == 0 && commit_search(A.C, pd[A.cls], s, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, Wall + A.w_off, winner))
+			CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+			search_query(g, L, uq[i], A.C.r, A.C.m, sub, bk, sec, Rfin, trips, co);
+			if (sub == 0 && commit_search(A.C, pd[A.cls], s, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, Wall + A.w_off, winner))
 				atomicAdd(&FC[kc].matched, 1u);
 		}
 	}

@@ -36,6 +36,235 @@ __global__ __launch_bounds__(LANES, MIN_WG) void k_accum(const uint32_t *__restr
 		partial[(size_t)job_idx * MULLS_NTERM + threadIdx.x] = part[threadIdx.x];
 }
 
+// The same sums by ONE WAVE per trip (round 5) — for launches with enough trips to fill the chip with waves.  The library's summation order reads "lane j of a
+// wave adds the values j, j + 64, ..., j + 960 in that order, then a butterfly adds the 64 partial sums" (accum.h).  k_accum realises it by 1024 lanes evaluating one slot
+// each, a term buffer in LDS and waves that walk it term by term: 53 B of a slot's records in, 108 B of terms through LDS and back, four barriers per trip and two
+// workgroups per CU (56 KiB each) — the launch ran at 3 TB/s of its own bytes.  Here lane j of a wave evaluates the slots j, j + 64, ... one after the other and keeps the 27
+// running sums in registers: the additions are the very same ones in the very same order (a running sum starts as -0.0, the one value x + (-0.0) == x holds for bit for bit),
+// no LDS, no barrier, sixteen independent waves per CU with the next slot's records in flight while a slot's terms are evaluated.  Trips of point-to-line classes outside
+// the faithful combined-system mode (27 terms of doubles: 108 registers of sums and terms) stay with k_accum; launch_accum decides per launch.
+namespace
+{
+template <typename TS, int W0, int WIN, int MODE, int METRIC, int A0>
+__device__ __forceinline__ void add_window(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc)
+{
+	TS t[WIN];
+#pragma unroll
+	for (int k = 0; k < WIN; k++)
+		t[k] = (TS)0;
+	point_terms<TS, W0, WIN, MODE, METRIC>(A, x, P, Q, N, wi, w, t);
+#pragma unroll
+	for (int k = 0; k < WIN; k++)
+		acc[W0 - A0 + k] += (double)t[k];
+}
+// the terms [W0, W0 + REM) in windows of at most MULLS_ACCW_WIN
+#ifndef MULLS_ACCW_WIN
+#define MULLS_ACCW_WIN 9 // float terms per window
+#endif
+#ifndef MULLS_ACCW_WIN_D
+#define MULLS_ACCW_WIN_D 12 // double terms per window
+#endif
+template <typename TS, int W0, int REM, int MODE, int METRIC, int A0>
+__device__ __forceinline__ void add_windows(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc)
+{
+	constexpr int WMAX = sizeof(TS) == 8 ? MULLS_ACCW_WIN_D : MULLS_ACCW_WIN;
+	constexpr int WIN = REM < WMAX ? REM : WMAX;
+	add_window<TS, W0, WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc);
+	if constexpr (REM > WIN)
+		add_windows<TS, W0 + WIN, REM - WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc);
+}
+// T0, NTW: the terms [T0, T0 + NTW) of the NT the form has are this wave's (two waves share a float trip: 14 + 13 running sums instead of 27 leave registers for the
+// next slot's records in flight and a fifth wave per SIMD)
+template <typename TS, int NT, int MODE, int METRIC, int T0, int NTW>
+__device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t trip0, const float4 *__restrict__ spos, const float4 *__restrict__ mq,
+										   const uint8_t *__restrict__ flag, float *__restrict__ wd, double *__restrict__ out, bool owner, uint4 *__restrict__ rp_wi)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t src_n = d.src_n, src_off = d.src_off;
+	const uint32_t n_here = min(src_n - trip0, (uint32_t)MULLS_ACC_LANES), iters = (n_here + 63u) >> 6; // (uniform)
+	const uint32_t last = src_off + src_n - 1u;
+	struct Rec
+	{
+		uint32_t f;
+		float4 P, Q;
+		float3 N;
+		float w;
+		uint4 c; // the slot's memo of the intensity weight: (source intensity, target intensity, weight, MULLS_WI_MAGIC)
+	};
+	uint4 *__restrict__ wic = (A.inten_w && !A.residual_pass && owner) ? rp_wi : nullptr; // (uniform)
+	auto load = [&](uint32_t i) {
+		Rec r;
+		const uint32_t g = min(src_off + trip0 + lane + 64u * i, last); // (slots beyond the cloud re-read its last point: no branch between the loads)
+		r.f = flag[g];
+		r.P = spos[g], r.Q = mq[2u * g], r.N = *reinterpret_cast<const float3 *>(mq + 2u * g + 1u);
+		r.w = wd[g];
+		r.c = make_uint4(0u, 0u, 0u, 0u);
+		if (wic)
+		{
+			r.c = wic[g];
+		}
+		return r;
+	};
+	double acc[NTW];
+#pragma unroll
+	for (int k = 0; k < NTW; k++)
+		acc[k] = -0.0;
+	// (the records are used under the validity test only, and the compiler would sink their loads behind it — flag first, then the rest: two round trips in
+	// sequence per slot; values named by a volatile asm have been loaded by then)
+#define MULLS_PIN_REC(r) asm volatile("" : "+v"((r).f), "+v"((r).P.x), "+v"((r).Q.x), "+v"((r).N.x), "+v"((r).w), "+v"((r).c.x))
+#if MULLS_ACCW_PREFETCH
+	Rec cur = load(0);
+#endif
+	for (uint32_t i = 0; i < iters; i++)
+	{
+#if MULLS_ACCW_PREFETCH
+		MULLS_PIN_REC(cur);
+		Rec nxt = cur;
+		if (i + 1u < iters)
+			nxt = load(i + 1u); // the next slot's records are in flight while this slot's terms are evaluated
+#else
+		Rec cur = load(i);
+		MULLS_PIN_REC(cur);
+#endif
+		const uint32_t s = trip0 + lane + 64u * i;
+		const bool valid = s < src_n && (cur.f & (MULLS_F_ALIVE | MULLS_F_VALID)) == (MULLS_F_ALIVE | MULLS_F_VALID);
+		// A dead or unmatched slot's terms are +0.0: adding them changes a running sum only from -0.0 to +0.0, which k_finish's `0.0 + partial` does anyway (the 512- and
+		// 256-lane forms of k_accum leave the slots beyond their lanes out the same way) — so such a slot is skipped altogether.
+		// The terms in windows of seven: a window's terms are added to their running sums before the next window's are evaluated (the windows share the weights and the
+		// row vector through common-subexpression elimination).
+		if (valid)
+		{
+			float w = cur.w;
+			const float4 N4 = make_float4(cur.N.x, cur.N.y, cur.N.z, 0.0f);
+			// The intensity weight exp(-|i1 - i2| / 255) — a double-precision exp, a division: a seventh of the slot's instructions — depends on the two intensities
+			// alone, and a correspondence stands for many iterations: the slot keeps (i1, i2, weight) and the weight is taken from there while both intensities are
+			// the bits it was computed from (a memo of a pure function: whatever the entry's history, a hit is the value point_wi returns).
+			float wi = 1.0f;
+			if (A.inten_w && !A.residual_pass)
+			{
+				const uint32_t pw = __float_as_uint(cur.P.w), qw = __float_as_uint(cur.Q.w);
+				if (cur.c.x == pw && cur.c.y == qw && cur.c.w == MULLS_WI_MAGIC)
+					wi = __uint_as_float(cur.c.z);
+				else
+				{
+					wi = point_wi(cur.P, cur.Q);
+					if (wic)
+						wic[src_off + s] = make_uint4(pw, qw, __float_as_uint(wi), MULLS_WI_MAGIC);
+				}
+			}
+			add_windows<TS, T0, NTW, MODE, METRIC, T0>(A, x, cur.P, cur.Q, N4, wi, w, acc);
+			if (owner && __float_as_uint(w) != __float_as_uint(cur.w))
+				wd[src_off + s] = w; // pcl::Correspondence::weight (the wave that holds the form's first terms writes it: the weight does not depend on the terms)
+		}
+#if MULLS_ACCW_PREFETCH
+		cur = nxt;
+#endif
+	}
+	// the butterfly of reduce_terms, term by term: the four row sums as there, then (row0 + row1) and (row2 + row3) by row_bcast:15 into rows 1 and 3, and their sum by
+	// row_bcast:31 into row 3 — (r2 + r3) + (r0 + r1), the same bits as (r0 + r1) + (r2 + r3) — so that lane 63 holds the trip's sum and stores it (readlanes and
+	// a select per term were 900 instructions a trip, an eighth of the kernel)
+	if (NTW == NT && lane < MULLS_NTERM) // the whole form in one wave: it also writes the entries the form does not have (0.0; no entry is written twice)
+	{
+		const bool has = MODE == 1 ? li_slot((int)lane) >= 0 : (int)lane < NT;
+		if (!has)
+			out[lane] = 0.0;
+	}
+#pragma unroll
+	for (int k = 0; k < NTW; k++)
+	{
+		double sum = acc[k];
+		sum = dpp_add_f64<0xB1>(sum);	// quad_perm [1,0,3,2]
+		sum = dpp_add_f64<0x4E>(sum);	// quad_perm [2,3,0,1]
+		sum = dpp_add_f64<0x141>(sum); // row_half_mirror
+		sum = dpp_add_f64<0x140>(sum); // row_mirror: every lane of a row holds the row's sum
+		sum = dpp_add_f64_rows<0x142, 0xa>(sum); // row_bcast:15 -> rows 1, 3
+		sum = dpp_add_f64_rows<0x143, 0xc>(sum); // row_bcast:31 -> rows 2, 3
+		acc[k] = sum;
+	}
+	if (lane == 63u)
+	{
+#pragma unroll
+		for (int k = 0; k < NTW; k++)
+			out[MODE == 1 ? li_term(T0 + k) : T0 + k] = acc[k];
+	}
+}
+} // namespace
+
+#ifndef MULLS_ACCW_SPLIT
+#define MULLS_ACCW_SPLIT 1 // waves that share a float trip (1: one wave holds all 27 running sums; 2: 14 + 13)
+#endif
+#ifndef MULLS_ACCW_PREFETCH
+#define MULLS_ACCW_PREFETCH 0
+#endif
+#ifndef MULLS_ACCW_OCC
+#define MULLS_ACCW_OCC 4
+#endif
+#define MULLS_ACCW_WAVES 4 // waves per workgroup of k_accum_wave
+__global__ __launch_bounds__(64 * MULLS_ACCW_WAVES, MULLS_ACCW_OCC) void k_accum_wave(const uint32_t *__restrict__ leaders, uint32_t n_trips, const Job *__restrict__ jobs,
+																					   const CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
+																					   const float4 *__restrict__ spos, const float4 *__restrict__ mq, const uint8_t *__restrict__ flag,
+																					   float *__restrict__ wd, double *__restrict__ partial)
+{
+	const uint32_t wave = threadIdx.x >> 6, part = wave % MULLS_ACCW_SPLIT;
+	const uint32_t trip = xcd_job(blockIdx.x, gridDim.x) * (MULLS_ACCW_WAVES / MULLS_ACCW_SPLIT) + wave / MULLS_ACCW_SPLIT;
+	if (trip >= n_trips)
+		return;
+	const uint32_t job_idx = leaders[trip];
+	const Job job = jobs[job_idx];
+	const PairState &ps = states[job.pair];
+	if (!ps.active && !ps.want_residual)
+		return;
+	const CloudDesc *pd = descs + job.pair * MULLS_NC;
+	const bool residual_pass = ps.want_residual != 0;
+	int cnt[MULLS_NC];
+	for (int c = 0; c < MULLS_NC; c++)
+		cnt[c] = (int)(class_called(rp, pd[c], c) ? pd[c].valid_next : pd[c].n_valid);
+	const AccumCtx A = accum_ctx(rp, job.cls, ps.iter, residual_pass, class_weight(rp, job.cls, residual_pass, cnt));
+	const CloudDesc &d = pd[job.cls];
+	double *out = partial + (size_t)job_idx * MULLS_NTERM;
+	if (d.src_n <= job.start) // (a trip starts inside its cloud; an emptied descriptor must not turn into a wild index)
+	{
+		if (part == 0u && (threadIdx.x & 63u) < MULLS_NTERM)
+			out[threadIdx.x & 63u] = 0.0;
+		return;
+	}
+	// (the metric is a template argument: one kernel holds every form, and its registers are those of the largest form that is compiled, not of all of point_terms)
+	if (residual_pass || A.metric == 1)
+	{
+		if (part) // two sums, or the twelve of the faithful point-to-line system: one wave
+			return;
+		if (!residual_pass)
+			wave_trip<double, 12, 1, 1, 0, 12>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo); // (li_diag: launch_accum keeps other point-to-line sums away)
+		else if (A.metric == 0)
+			wave_trip<double, 2, 0, 0, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		else if (A.metric == 1)
+			wave_trip<double, 2, 0, 1, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		else
+			wave_trip<double, 2, 0, 2, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+	}
+#if MULLS_ACCW_SPLIT == 2
+	else if (A.metric == 0)
+	{
+		if (part == 0u)
+			wave_trip<float, 27, 0, 0, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		else
+			wave_trip<float, 27, 0, 0, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false, rp.wi_memo);
+	}
+	else
+	{
+		if (part == 0u)
+			wave_trip<float, 27, 0, 2, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		else
+			wave_trip<float, 27, 0, 2, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false, rp.wi_memo);
+	}
+#else
+	else if (A.metric == 0)
+		wave_trip<float, 27, 0, 0, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+	else
+		wave_trip<float, 27, 0, 2, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // One workgroup per pair: sum the per-job partials of every class in job order, then roll the per-class counters
 // over to the next iteration.
@@ -572,13 +801,22 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 #include "launch.h"
 
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single)
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single, uint32_t wave_min_trips)
 {
 	static bool attr_set = false;
 	if (!attr_set)
 	{
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
 		attr_set = true;
+	}
+	// One wave per trip once the launch has trips enough to fill the chip with waves (k_accum_wave; below that a trip's sixteen slots per lane in sequence are the launch's
+	// latency).  Its point-to-line form is the faithful combined system's (diagonal + right-hand side); other point-to-line sums stay with k_accum.
+	const uint32_t n_trips = split[3] - split[0];
+	if (wave_min_trips && n_trips >= wave_min_trips && rp.faithful && rp.pull_comb)
+	{
+		hipLaunchKernelGGL(k_accum_wave, dim3((n_trips + MULLS_ACCW_WAVES / MULLS_ACCW_SPLIT - 1u) / (MULLS_ACCW_WAVES / MULLS_ACCW_SPLIT)), dim3(64 * MULLS_ACCW_WAVES), 0, st, leaders + split[0], n_trips, jobs, descs, states, rp, spos,
+						   mq, flag, wd, partial);
+		return;
 	}
 	if (single)
 	{

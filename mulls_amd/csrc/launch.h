@@ -51,7 +51,7 @@ void launch_filter(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *d
 				   const unsigned long long *winner, const float4 *tpos, float4 *mq, bool big = false);
 // leaders: job indices of the trip starts, grouped by trip length (split[0..3]: see k_reduce.hip)
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
-				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single = false);
+				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single = false, uint32_t wave_min_trips = 0);
 void launch_finish(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairState *states, const RunParams &rp, const double *partial,
 				   PairOut *out, PairOut *out_host, const uint32_t *bbox, uint32_t *ticket, volatile uint32_t *host_epoch, uint32_t epoch,
 				   uint32_t pair_base);

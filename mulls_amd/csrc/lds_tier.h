@@ -219,6 +219,99 @@ __device__ __forceinline__ void take_pair(float da, uint32_t ia, float db, uint3
 	bk = kb < bk ? kb : bk;
 }
 
+// ---- k-candidate certificates (round 5): what a search leaves behind besides its result -------------------------------------------------------
+// The lanes of a sub-group evaluate disjoint shares of the candidates of a sweep.  Lane l ends with its own nearest key lk_l and the
+// second-smallest distance ls_l among ITS candidates, so every target the sweep evaluated is either some lane's best or at least
+// min_l ls_l away.  The bests of the other lanes are therefore a ready-made candidate set — no work per candidate, a few DPP moves per query:
+// the NO nearest of them (by key) go into the record, and b2 = min(min_l ls_l, the nearest lane best that did not fit) bounds every evaluated
+// target outside {the result, the record}.  (On 8 lanes that set is about as good as the true 3 nearest: profiles/r05_kcert_study.txt.)
+struct CandOut
+{
+	uint32_t cx, cy; // candidates besides the result: LDS tier 4 x uint16 (0xffff = none), global-memory tier 2 x uint32 (0xffffffff = none)
+	float b2;		 // squared distance every evaluated target outside {result, candidates} keeps at least (0: nothing claimed)
+};
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// the value of lane (i ^ J) of an 8-lane sub-group / of lane (i + J) mod 16 of a 16-lane sub-group (quad permutes, row_half_mirror, row_ror)
+template <int G, int J>
+__device__ __forceinline__ uint32_t sub_peer(uint32_t v)
+{
+	static_assert(G == 8 || G == 16, "sub-groups of 8 or 16 lanes");
+	if constexpr (G == 16)
+		return dpp_mov<0x120 + J>(v);
+	else if constexpr (J == 1)
+		return dpp_mov<0xB1>(v);
+	else if constexpr (J == 2)
+		return dpp_mov<0x4E>(v);
+	else if constexpr (J == 3)
+		return dpp_mov<0x1B>(v);
+	else if constexpr (J == 7)
+		return dpp_mov<0x141>(v);
+	else
+		return dpp_mov<0x141>(sub_peer<8, 7 - J>(v)); // i ^ J = (i ^ 7) ^ (7 - J) for J = 4, 5, 6
+}
+template <int G, int J>
+struct RankLoop
+{
+	static __device__ __forceinline__ void run(uint32_t kh, uint32_t kl, nnkey lk, uint32_t &rank)
+	{
+		const nnkey o = ((nnkey)sub_peer<G, J>(kh) << 32) | sub_peer<G, J>(kl);
+		rank += o < lk ? 1u : 0u;
+		RankLoop<G, J + 1>::run(kh, kl, lk, rank);
+	}
+};
+template <int G>
+struct RankLoop<G, G>
+{
+	static __device__ __forceinline__ void run(uint32_t, uint32_t, nnkey, uint32_t &) {}
+};
+template <int CTRL>
+__device__ __forceinline__ void dpp_and_step(uint32_t &v)
+{
+	v &= dpp_mov<CTRL>(v);
+}
+// lk / ls: this lane's own best key and second-smallest distance of the sweep whose merged result stands.  Every lane of the sub-group calls it;
+// the result is valid in every lane.  Keys of different lanes differ unless both are NNKEY_NONE (a target is evaluated by one lane).
+template <int G, bool W16>
+__device__ __forceinline__ CandOut lane_bests(nnkey lk, float ls)
+{
+	constexpr uint32_t NO = W16 ? 4u : 2u;
+	uint32_t rank = 0;
+	RankLoop<G, 1>::run((uint32_t)(lk >> 32), (uint32_t)lk, lk, rank); // lanes of the sub-group with a smaller key
+	float c = fminf(ls, rank > NO ? key_dist(lk) : __builtin_inff());
+	dpp_fmin_step<0xB1>(c);
+	dpp_fmin_step<0x4E>(c);
+	dpp_fmin_step<0x141>(c);
+	if constexpr (G == 16)
+		dpp_fmin_step<0x140>(c);
+	// (selects, not conditional stores: the compiler turns `if (..) vx = w; else vy = w;` into a dynamically indexed stack array)
+	const bool fits = key_found(lk) && rank >= 1u && rank <= NO;
+	const uint32_t idx = (uint32_t)lk;
+	uint32_t vx, vy;
+	if (W16)
+	{
+		const uint32_t sh = ((rank - 1u) & 1u) << 4, w = ~(0xffffu << sh) | ((idx & 0xffffu) << sh);
+		vx = fits && rank <= 2u ? w : 0xffffffffu;
+		vy = fits && rank > 2u ? w : 0xffffffffu;
+	}
+	else
+	{
+		vx = fits && rank == 1u ? idx : 0xffffffffu;
+		vy = fits && rank == 2u ? idx : 0xffffffffu;
+	}
+	dpp_and_step<0xB1>(vx), dpp_and_step<0xB1>(vy);
+	dpp_and_step<0x4E>(vx), dpp_and_step<0x4E>(vy);
+	dpp_and_step<0x141>(vx), dpp_and_step<0x141>(vy);
+	if constexpr (G == 16)
+		dpp_and_step<0x140>(vx), dpp_and_step<0x140>(vy);
+	CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+	co.cx = vx, co.cy = vy, co.b2 = c;
+	return co;
+}
+
 // Evaluate every target in the cells intersecting the cube [p - R, p + R] (same exactness argument as grid_scan_box).  The
 // rows (x-runs of cells, contiguous in the sorted cloud) are taken two at a time: every lane of the sub-group reads their
 // bounds (same addresses: LDS broadcast), the candidate ranges are laid end to end and the sub-group strides over the
@@ -285,14 +378,17 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 // a sub-group.  Out: bk = (squared distance, original index) of the nearest target or NNKEY_NONE; sec = second-smallest squared
 // distance the last sweep saw (0 = unknown), Rfin = that sweep's radius: every target other than bk's is at least
 // min(sqrt(sec), Rfin) away; trips = candidate trips taken (cost class of the next iteration).
+// co: the other lanes' nearest targets of the sweep that produced (bk, sec), for the k-candidate certificates (lane_bests; b2 = 0 with sec = 0).
 template <class G>
 __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, const float4 q, float r, float m, uint32_t sub, nnkey &bk, float &sec,
-											  float &Rfin, uint32_t &trips)
+											  float &Rfin, uint32_t &trips, CandOut &co)
 {
 	bk = NNKEY_NONE;
 	sec = __builtin_inff();
 	Rfin = 0.0f;
 	trips = 0u;
+	nnkey lane_k = NNKEY_NONE; // this lane's own share of the standing sweep
+	float lane_s = __builtin_inff();
 	// One sweep of the cube of radius R.  Its cells are a superset of every earlier sweep's cells, so its own (best, second)
 	// pair replaces the standing one; only when the radius was clipped to the rejection radius can the standing best lie
 	// outside — it stays the answer then, and nothing is claimed about the other targets.
@@ -301,14 +397,15 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 		float ls = __builtin_inff();
 		if (lds_scan_box(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
 		{
+			const nnkey own_k = lk;
+			const float own_s = ls;
 			row16_min2(lk, ls);
-			if (bk < lk)
-				sec = 0.0f;
-			else
-			{
-				bk = lk;
-				sec = ls;
-			}
+			// (selects: two branches ending in stores to different variables are merged into one store through a selected address, which puts both on the stack)
+			const bool adopt = !(bk < lk);
+			bk = adopt ? lk : bk;
+			sec = adopt ? ls : 0.0f;
+			lane_k = adopt ? own_k : lane_k;
+			lane_s = adopt ? own_s : lane_s;
 		}
 		Rfin = R;
 	};
@@ -335,12 +432,16 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 			const float db = (dx * dx + dy * dy) + dz * dz;
 			take_pair(da, ia, db, ib, ok2, bk, sec);
 		}
+		lane_k = bk, lane_s = sec;
 		row16_min2(bk, sec);
 		// probe 1: every cell within min(first-probe radius, current best distance) of the query
 		sweep(key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m, true);
 	}
 	if (!(key_found(bk) && key_dist(bk) <= m * m))
 		sweep(key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r, false); // nothing within the first-probe radius: widen to the best distance, or to the rejection radius
+	co = lane_bests<(int)MULLS_LDS_GROUP, true>(lane_k, lane_s);
+	if (sec == 0.0f)
+		co.b2 = 0.0f; // the standing result lies outside the last (clipped) sweep: nothing is claimed about the other targets
 }
 
 // what the search of one class cloud needs to know about its iteration
@@ -350,6 +451,8 @@ struct ClassCtx
 	double max_dist_sqr; // (double)r squared: CorrespondenceEstimation's max_distance test
 	bool gate, dedup;	 // >= 500 live source points: duplicate rule in force; ... and resolved in this workgroup's LDS table
 	unsigned long long key_hi;
+	uint4 *cand;	// candidate records of the k-candidate certificates (RunParams::cand; null: none are kept)
+	uint32_t epoch; // ... and the epoch a record written in this iteration carries
 };
 __device__ __forceinline__ ClassCtx class_ctx(const RunParams &rp, const PairState &ps, const GridDesc &g, int cls, uint32_t alive_cur, bool called)
 {
@@ -361,6 +464,8 @@ __device__ __forceinline__ ClassCtx class_ctx(const RunParams &rp, const PairSta
 	C.gate = alive_cur >= 500u;
 	C.dedup = rp.lds_dedup != 0u && called && C.gate;
 	C.key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
+	C.cand = rp.cand;
+	C.epoch = rp.tick_base + (uint32_t)ps.iter;
 	return C;
 }
 
@@ -402,7 +507,7 @@ __device__ __forceinline__ bool dedup_holds(const uint32_t *W, uint32_t t, uint3
 
 // lane `sub == 0` of a sub-group commits the result of a searched query; returns whether it is a match
 template <bool W16 = false>
-__device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc &d, uint32_t s, nnkey bk, float sec, float Rfin, uint32_t trips,
+__device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc &d, uint32_t s, nnkey bk, float sec, float Rfin, uint32_t trips, const CandOut &co,
 											   int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, int2 *__restrict__ hint2, uint32_t *W,
 											   unsigned long long *__restrict__ winner)
 {
@@ -412,7 +517,10 @@ __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc
 	nn_idx[d.src_off + s] = matched ? bi : -1;
 	nn_d2[d.src_off + s] = best;
 	// hint and cost class of the next iteration; every target but the one found is at least min(second, radius swept) away
-	hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(fminf(sqrtf(sec), Rfin)));
+	const float lb_new = fminf(sqrtf(sec), Rfin);
+	hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(lb_new));
+	if (C.cand) // the other lanes' nearest targets, and how much farther than lb_new everything outside {result, candidates} lies (co.b2 >= sec)
+		C.cand[d.src_off + s] = make_uint4(co.cx, co.cy, __float_as_uint(fminf(sqrtf(co.b2), Rfin) - lb_new), C.epoch);
 	if (matched)
 	{
 		if (C.dedup)
@@ -627,11 +735,186 @@ struct CertLds
 {
 	float4 uq[SMALL];
 	uint32_t us[SMALL];
+	static constexpr bool LOOK = SMALL >= 128; // lists of a few dozen entries (the resident loop, the small batches' one-launch search) never get the look: no room kept
+	float um[LOOK ? SMALL : 1];				   // how far this iteration's step moved the listed point (entries flagged MULLS_US_KCERT: the k-candidate certificate's look needs it)
 	uint32_t ucount, red[3 * 16];
 };
 
 // nn_idx value of a live point that cert_class could not certify and left to lds_search_class (its sweep radius waits in nn_d2)
 #define MULLS_NEEDS_SEARCH (-2)
+
+// The k-candidate certificate of one point (px, py, pz: its position after this iteration's rigid step, `moved`: how far the step took it) whose
+// hinted target alone did not certify.  h = its (hint, bound) record, cr = its candidate record, tp(i) = position of target i.  The hinted target and
+// the candidates are evaluated with the search's own distance expression and compared as keys (lowest index on ties): the nearest of them IS the
+// nearest target if it beats, by the plain certificate's margins, the bound on everything outside the set — (bound on the non-hinted targets) + cr.z
+// at the previous position, hence `moved` less here.  Exactness: DESIGN.md section 14.1 (the triangle inequality of section 4 on a larger exception set).
+// Returns whether it certifies; then bk = (squared distance, index) of the nearest target, lb_next = the bound on every OTHER target from here (what a
+// search would leave as min(sqrt(sec), Rfin)), cr_next = the record with the old hint in the new one's slot.  pre(i) / pos(token): the two dependent
+// loads of a target's position (the crop map's entry, then the staged record), so that all candidates' loads of a stage are in flight together.
+template <bool W16, class TPre, class TPos>
+__device__ __forceinline__ bool kcert_point(const RunParams &rp, const uint4 cr, const int2 h, uint32_t iter, float px, float py, float pz, float moved, uint32_t tgt_n,
+											 const TPre &pre, const TPos &pos, nnkey &bk, float &lb_next, uint4 &cr_next)
+{
+	constexpr int NO = W16 ? 4 : 2;
+	const uint32_t hj = W16 ? ((uint32_t)h.x & 0xffffu) : (uint32_t)h.x; // (hj < tgt_n: the caller's condition)
+	if (!(rp.kcert != 0u && cr.w - rp.tick_base <= iter)) // not written by a search of THIS run (unsigned: an older or a zeroed record wraps far above iter)
+		return false;
+	const float Bp = __int_as_float(h.y) + __uint_as_float(cr.z); // every target outside the set kept at least this distance before the step
+	if (!(moved * 1.00001f < Bp * 0.99999f))					   // hopeless whatever the candidates' distances are: no gathers
+		return false;
+	// every load of a stage is issued before the first is used, at indices that are valid whatever the record holds (an absent candidate re-reads the hint)
+	uint32_t ci[NO + 1], tok[NO + 1];
+	bool ok[NO + 1];
+	ci[0] = hj, ok[0] = true;
+#pragma unroll
+	for (int j = 0; j < NO; j++)
+	{
+		const uint32_t w = j < NO / 2 ? cr.x : cr.y, c = W16 ? (w >> ((j & 1) << 4)) & 0xffffu : w;
+		ok[j + 1] = c < tgt_n;
+		ci[j + 1] = ok[j + 1] ? c : hj;
+	}
+#pragma unroll
+	for (int j = 0; j <= NO; j++)
+		tok[j] = pre(ci[j]);
+	float4 cp[NO + 1];
+#pragma unroll
+	for (int j = 0; j <= NO; j++)
+		cp[j] = pos(tok[j]);
+	bk = NNKEY_NONE;
+	float sec = __builtin_inff();
+	int slot = -1;
+#pragma unroll
+	for (int j = 0; j <= NO; j++)
+	{
+		const float dx = px - cp[j].x, dy = py - cp[j].y, dz = pz - cp[j].z;
+		const float dj = ok[j] ? (dx * dx + dy * dy) + dz * dz : __builtin_inff(); // L2_Simple<float>, no FMA: the expression of lds_scan_box / take_one
+		sec = __builtin_amdgcn_fmed3f(sec, dj, key_dist(bk));
+		const nnkey kj = ok[j] ? nn_key(dj, ci[j]) : NNKEY_NONE;
+		const bool take = kj < bk;
+		bk = take ? kj : bk;
+		slot = take ? j - 1 : slot;
+	}
+	const float best = key_dist(bk);
+	if (!(best >= 0.0f) || !(sqrtf(best) * 1.00001f + moved * 1.00001f < Bp * 0.99999f)) // NaN anywhere fails the test
+		return false;
+	const float Bn = Bp - moved * 1.00001f;
+	lb_next = fminf(sqrtf(sec), Bn);
+	// the old hint takes the new one's place among the candidates
+	if (W16)
+	{
+		const uint32_t sh = ((uint32_t)slot & 1u) << 4, keepm = ~(0xffffu << sh), put = hj << sh;
+		cr_next.x = slot >= 0 && slot < NO / 2 ? (cr.x & keepm) | put : cr.x;
+		cr_next.y = slot >= NO / 2 ? (cr.y & keepm) | put : cr.y;
+	}
+	else
+	{
+		cr_next.x = slot == 0 ? hj : cr.x;
+		cr_next.y = slot == 1 ? hj : cr.y;
+	}
+	cr_next.z = __float_as_uint(Bn - lb_next);
+	cr_next.w = cr.w;
+	return true;
+}
+
+// Second chance of a light pass's leftover list (the k-candidate certificates): one lane per listed point whose slot word carries MULLS_US_KCERT (a hinted
+// point) loads the point's records, gathers the candidates and, if they certify it, puts the results where a search would put them — nn_idx, nn_d2, the hint
+// and candidate records, the duplicate table.  The list (U <= SMALL entries) is compacted in place; returns the number of points left to search.
+// Every lane of the workgroup calls it; barriers inside.
+#define MULLS_US_KCERT 0x80000000u
+template <int BLK, bool W16, int SMALL>
+__device__ __forceinline__ uint32_t kcert_list(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const ClassCtx &C, const CloudDesc &d, uint32_t U,
+												int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, int2 *__restrict__ hint2, uint32_t *W,
+												unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos, uint32_t &matched_cnt)
+{
+	static_assert(SMALL <= BLK, "one lane per listed point");
+	const uint32_t UL = U; // (<= SMALL: the caller's condition)
+	float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	uint32_t es = 0u;
+	bool keep = false;
+	if (threadIdx.x < UL)
+	{
+		e = CL.uq[threadIdx.x];
+		es = CL.us[threadIdx.x];
+		keep = true;
+		if (es & MULLS_US_KCERT)
+		{
+			es &= ~MULLS_US_KCERT;
+			const uint32_t gi = d.src_off + es;
+			const uint4 cr = C.cand[gi];
+			const int2 h = hint2[gi];
+			nnkey bk;
+			float lb_next;
+			uint4 cr_next;
+			const float moved = CL.um[threadIdx.x];
+			// (the descriptor's fields in registers: read through `d` inside the accessors they are re-loaded, with a wait, before every gather)
+			const uint32_t tgt_off = d.tgt_off, tgt_n = d.tgt_n, st_off = d.tgt_stage, st_mul = ((d.stage_fmt >> 2) & 3u) == MULLS_STAGE_AOS48 ? 3u : 1u;
+			const uint16_t *__restrict__ tmap = rp.tgt_map;
+			const float4 *__restrict__ stage = rp.tgt_stage;
+			bool pass;
+			if (tmap) // (uniform) no cropped copy of the target: the crop map's entry, then the staged record (tgt_point)
+			{
+				auto pre = [&](uint32_t i) -> uint32_t { return (uint32_t)tmap[tgt_off + i]; };
+				auto pos = [&](uint32_t t) -> float4 { return stage[(size_t)st_off + (size_t)t * st_mul]; };
+				pass = kcert_point<true>(rp, cr, h, (uint32_t)ps.iter, e.x, e.y, e.z, moved, tgt_n, pre, pos, bk, lb_next, cr_next);
+			}
+			else
+			{
+				auto pre = [&](uint32_t i) -> uint32_t { return i; };
+				auto pos = [&](uint32_t t) -> float4 { return tpos[tgt_off + t]; };
+				pass = kcert_point<true>(rp, cr, h, (uint32_t)ps.iter, e.x, e.y, e.z, moved, tgt_n, pre, pos, bk, lb_next, cr_next);
+			}
+			if (pass)
+			{
+				const float best = key_dist(bk);
+				const uint32_t bi = (uint32_t)bk;
+				const bool matched = !((double)best > C.max_dist_sqr);
+				nn_idx[gi] = matched ? (int32_t)bi : -1;
+				nn_d2[gi] = best;
+				hint2[gi] = make_int2((int32_t)bi, __float_as_int(lb_next)); // cost class 0
+				C.cand[gi] = cr_next;
+				if (matched)
+				{
+					matched_cnt++;
+					if (C.dedup)
+						dedup_min<W16>(W, bi, es);
+					else if (C.gate)
+						atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)es);
+				}
+				keep = false;
+			}
+		}
+	}
+	const unsigned long long bal = __ballot(keep);
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	if (rp.dbg_ticks) // diagnostics (MULLS_OPT_DEBUG_STOP = 20): points that got the second chance, points it certified
+	{
+		const unsigned long long tried = __ballot(threadIdx.x < UL && (CL.us[min(threadIdx.x, (uint32_t)SMALL - 1u)] & MULLS_US_KCERT) != 0u);
+		const unsigned long long passed = __ballot(threadIdx.x < UL && !keep);
+		if (lane == 0u && tried)
+		{
+			atomicAdd(&rp.dbg_ticks[14], (unsigned long long)__popcll(tried));
+			atomicAdd(&rp.dbg_ticks[15], (unsigned long long)__popcll(passed));
+		}
+	}
+	if (lane == 0u)
+		CL.red[wave] = (uint32_t)__popcll(bal);
+	__syncthreads(); // every listed entry has been read
+	uint32_t base = 0u, total = 0u;
+	for (uint32_t w = 0; w < (uint32_t)(BLK / 64); w++)
+	{
+		const uint32_t c = CL.red[w];
+		base += w < wave ? c : 0u;
+		total += c;
+	}
+	if (keep)
+	{
+		const uint32_t k = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+		CL.uq[k] = e;
+		CL.us[k] = es;
+	}
+	__syncthreads();
+	return total;
+}
 
 // Light pass of one class cloud's iteration, BLK lanes, one source point per lane and trip (see the tier's description above):
 // rigid step, certificates, and — when at most MULLS_CERT_SMALL points are left over — their search against the grid in global
@@ -655,6 +938,7 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, called);
 	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
 	const bool use_hint = called && have_prev;
+	const bool kc = CertLds<SMALL>::LOOK && rp.kcert != 0u && use_hint && C.cand != nullptr; // (uniform)
 	const uint32_t q_end = min(src_n, job.start + (job.count ? job.count : (uint32_t)MULLS_SRC_PER_BLOCK));
 	if (C.dedup)
 		dedup_init<W16>(W, tgt_n, BLK);
@@ -753,15 +1037,20 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 			const uint32_t k = atomicAdd(&ucount, 1u);
 			if (k < (uint32_t)SMALL)
 			{
+				const bool second = kc && hj < tgt_n; // a hinted point: the k-candidate certificate gets a look before the search (kcert_list)
 				uq[k] = out;
-				us[k] = s;
+				us[k] = second ? s | MULLS_US_KCERT : s;
+				if (CertLds<SMALL>::LOOK)
+					CL.um[k] = moved;
 			}
 		}
 	}
 	if (!called)
 		return true;
 	__syncthreads();
-	const uint32_t U = ucount;
+	uint32_t U = ucount;
+	if (kc && U >= rp.kcert_min && U <= (uint32_t)SMALL) // (a list that overflowed goes to the heavy pass, whose searches cost a tenth of a look)
+		U = kcert_list<BLK, W16, SMALL>(CL, rp, ps, C, d, U, nn_idx, nn_d2, hint2, W, winner, tpos, matched_cnt);
 	if (U > (uint32_t)SMALL)
 		return false; // too many for the global-memory walk: the caller has the target cloud staged (lds_search_class), which counts the
 					  // matches certified here again from nn_idx; chunk-level jobs add theirs to the class counter there too
@@ -773,8 +1062,9 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 		nnkey bk;
 		float sec, Rfin;
 		uint32_t trips;
-		search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
-		if (sub == 0 && commit_search<W16>(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+		CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+		search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+		if (sub == 0 && commit_search<W16>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
 			matched_cnt++;
 	}
 	class_tail<BLK, W16>(rp, ps, C, d, job, q_end, matched_cnt, U, W, red, snrm, tnrm, flag, nn_idx, nn_d2, match, wd, winner, tpos, mq);
@@ -812,6 +1102,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 	const ClassCtx C = class_ctx(rp, ps, g, job.cls, d.alive_cur, true);
 	const bool have_prev = ps.iter > 0; // hint records of this run exist from its second iteration on
 	const bool normal_check = job.cls != 5; // vertex correspondences skip the direction check (:1292)
+	const bool kc = CertLds<SMALL>::LOOK && rp.kcert != 0u && have_prev && C.cand != nullptr; // (uniform)
 	const uint32_t q_end = src_n;		// class-level job: job.start == 0, job.count >= src_n
 	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
 #define FLAT_TICK(k)                                                  \
@@ -945,8 +1236,11 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			const uint32_t u = atomicAdd(&ucount, 1u);
 			if (u < (uint32_t)SMALL)
 			{
+				const bool second = kc && hj < tgt_n; // a hinted point: the k-candidate certificate gets a look before the search (kcert_list)
 				uq[u] = out;
-				us[u] = s;
+				us[u] = second ? s | MULLS_US_KCERT : s;
+				if (CertLds<SMALL>::LOOK)
+					CL.um[u] = moved;
 			}
 		}
 		setSM(k, st_k, m_k);
@@ -968,7 +1262,16 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		cert(2, r0);
 	__syncthreads();
 	FLAT_TICK(2)
-	const uint32_t U = ucount;
+	uint32_t U = ucount;
+	const uint32_t U0 = U;
+	if (kc && U >= rp.kcert_min && U <= (uint32_t)SMALL) // (a list that overflowed goes to the heavy pass, whose searches cost a tenth of a look)
+		U = kcert_list<BLK, W16, SMALL>(CL, rp, ps, C, d, U, nn_idx, nn_d2, hint2, W, winner, tpos, matched_cnt);
+	FLAT_TICK(1)
+	if (rp.dbg_ticks && threadIdx.x == 0)
+	{
+		atomicAdd(&rp.dbg_ticks[13], (unsigned long long)U0); // points the plain certificate left over ...
+		atomicAdd(&rp.dbg_ticks[7], (unsigned long long)U);	  // ... and what is searched (here or, beyond SMALL, by the heavy pass)
+	}
 	if (U > (uint32_t)SMALL)
 	{
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
@@ -992,8 +1295,9 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			nnkey bk;
 			float sec, Rfin;
 			uint32_t trips;
-			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips);
-			if (sub == 0 && commit_search<W16>(C, d, us[i], bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+			CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+			if (sub == 0 && commit_search<W16>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
 				matched_cnt++;
 		}
 	}
@@ -1001,7 +1305,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		matched_cnt += __shfl_down(matched_cnt, off);
 	if ((threadIdx.x & 63) == 0)
 		red[threadIdx.x >> 6] = matched_cnt;
-	__threadfence_block(); // the searched points' nn_idx / nn_d2, read back below by the lanes that own them
+	__threadfence_block(); // the searched (or k-candidate certified) points' nn_idx / nn_d2, read back below by the lanes that own them
 	__syncthreads();
 	uint32_t total_matched = 0;
 	for (int w = 0; w < BLK / 64; w++)
@@ -1319,8 +1623,9 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 				nnkey bk;
 				float sec, Rfin;
 				uint32_t trips;
-				search_query(g, L, qpos[k], C.r, C.m, sub, bk, sec, Rfin, trips);
-				if (sub == 0 && commit_search(C, d, chunk + k, bk, sec, Rfin, trips, nn_idx, nn_d2, hint2, W, winner))
+				CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
+				search_query(g, L, qpos[k], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+				if (sub == 0 && commit_search(C, d, chunk + k, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
 					matched_cnt++;
 			}
 		}

@@ -76,7 +76,7 @@ int run_setup(Run &R)
 	rp.cos_bearing = std::cos(P->normal_bearing / 180.0 * M_PI);
 	rp.resid_from_iter = 2;
 	init_cert(ctx, rp);
-	if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
+	if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, rp)) != MULLS_OK)
 		return rc;
 	rp.debug_stop = (uint32_t)ctx->opt[MULLS_OPT_DEBUG_STOP];
 
@@ -335,6 +335,9 @@ RUN_ALIASES
 			for (int k = 0; k < 5; k++)
 				ctx->prof.icp_fused_ms[k] += (double)t[k] * 1e-5;
 			ctx->prof.icp_fused_ms[5] += (double)t[6];
+			// the k-candidate certificates of the one-pass walk, in the (otherwise unused) per-iteration slots: points the plain certificate left over, points
+			// that got the second chance, points it certified, points searched
+			ctx->prof.icp_search_ms[0] += (double)t[13], ctx->prof.icp_search_ms[1] += (double)t[14], ctx->prof.icp_search_ms[2] += (double)t[15], ctx->prof.icp_search_ms[3] += (double)t[7];
 			for (int k = 0; k < 4; k++) // ... and the heavy pass's (k_nn_lds), in the phase slots ([4] = class clouds)
 				ctx->prof.icp_phase_ms[k] += (double)t[8 + k] * 1e-5;
 			ctx->prof.icp_phase_ms[4] += (double)t[12];
@@ -513,7 +516,7 @@ RUN_ALIASES
 		// a set without a search holds only posterior-residual passes (every pair ran its last iteration in the set before): that is the
 		// residual kernel time; a set of a converging batch mixes both kinds of pairs and is charged to the accumulation
 		ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-		launch_accum(sst, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches);
+		launch_accum(sst, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches, (uint32_t)ctx->opt[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS]);
 		launch_finish_step(sst, (uint32_t)S.lo, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, S.word_dev,
 						   ++*S.epoch_ctr, use_grid ? 0 : 1, (few_launches || n <= (int)ctx->opt[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS]) ? S.ticket : nullptr);
 		ev.end();
@@ -687,7 +690,7 @@ RUN_ALIASES
 				ctx->prof.iterations++;
 		}
 		ev.begin(any_active ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
-		launch_accum(st, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial);
+		launch_accum(st, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, false, (uint32_t)ctx->opt[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS]);
 		launch_finish(st, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, B->partial, B->outs, B->outs_pin, B->bbox, S.ticket, S.word_dev, ++*S.epoch_ctr,
 					  (uint32_t)S.lo);
 		ev.end();

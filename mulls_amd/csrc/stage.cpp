@@ -143,7 +143,7 @@ extern "C"
 		rp->faithful = 1;
 		rp->rej_strict = P.rejector_strict != 0;
 		rp->resid_from_iter = 2;
-		if ((rc = take_epochs(ctx, B, 4u, &rp->tick_base)) != MULLS_OK)
+		if ((rc = take_epochs(ctx, B, 4u, *rp)) != MULLS_OK)
 			return rc;
 		uint32_t lds_cap = 0;
 		int tier = 0;

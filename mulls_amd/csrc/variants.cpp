@@ -38,7 +38,7 @@ extern "C"
 		rp.cos_bearing = std::cos(40.0f / 180.0 * M_PI); // determine_corres' default angle_thre_degree (:1704)
 		rp.resid_from_iter = -1;							  // no iteration gate in ground_3dof_lls_tran_estimation (:2294)
 		init_cert(ctx, rp);
-		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, &rp.tick_base)) != MULLS_OK)
+		if ((rc = take_epochs(ctx, B, (uint32_t)std::max(P->max_iter_num, 0) + 2u, rp)) != MULLS_OK)
 			return rc;
 		mulls_params Pj = *P;
 		std::memset(Pj.used_feature_type, 0, sizeof(Pj.used_feature_type));

@@ -165,9 +165,13 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
     far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
     empty = abi.PairData(tgt, [None] * 6)
     plist = ([p for p, _ in pairs_small] + [far, empty]) * 7
+    wave_min = ctx.get_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS)
+    ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, 1)  # (set while the batch is filled: the wave form's memo of the intensity weights is allocated with the batch)
     b = ctx.batch(plist)
     # ... and batches of SPLIT_MIN .. SPLIT_MAX pairs iterate as two sub-batches on two streams (own launch sets, epoch word, ticket, work list)
-    forms = {"few": (384, 1 << 30), "separate": (0, 1 << 30), "few split": (384, 2), "separate split": (0, 2)}
+    # ... and (round 5) the normal equations summed by one wave per trip (k_accum_wave: ACCUM_WAVE_MIN_TRIPS = 1) instead of one workgroup per trip (0)
+    forms = {"few": (384, 1 << 30, 0), "separate": (0, 1 << 30, 0), "few split": (384, 2, 0), "separate split": (0, 2, 0), "few wave": (384, 1 << 30, 1), "separate wave": (0, 1 << 30, 1),
+             "separate split wave": (0, 2, 1)}
     split_min = ctx.get_option(abi.OPT_SPLIT_MIN_PAIRS)
     for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0),
               abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
@@ -175,13 +179,55 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
         for name in list(forms) * 2:
             ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, forms[name][0])
             ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, forms[name][1])
+            ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, forms[name][2])
             r = b.run(P)
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
             assert got.setdefault(name, rows) == rows
         assert all(got[name] == got["few"] for name in forms)
     ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
     ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, split_min)
+    ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, wave_min)
     b.close()
+
+
+def test_k_candidate_certificates_are_bit_identical(ctx, pairs_small):
+    """Round 5: a point whose hinted target fails the certificate evaluates the few nearest targets its last search's other lanes saw (k-candidate
+    certificates, MULLS_OPT_KCERT) before it is searched again.  Certificates never change a result: on, off, and taken from list lengths of 1 and 64
+    on, every output is the same bits — healthy, failing and empty pairs, every class, run after run on the same batch (records of an earlier run carry
+    an older epoch and must not be believed), and with the duplicate-table epoch next to its wrap (the records are cleared with the table)."""
+    rng = np.random.default_rng(23)
+    tgt = planes_scene(rng)
+    far = abi.PairData(tgt, transformed_copy(tgt, synth.se3(200.0, 0, 0)))
+    empty = abi.PairData(tgt, [None] * 6)
+    plist = ([p for p, _ in pairs_small] + [far, empty]) * 5
+    keep = (ctx.get_option(abi.OPT_KCERT), ctx.get_option(abi.OPT_KCERT_MIN), ctx.get_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS))
+    ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 0)  # k_cert + k_nn_lds as separate launches: the 512-entry leftover lists that take the look
+    b = ctx.batch(plist)
+    for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0)):
+        got = None
+        for kc, kmin in ((0, 64), (1, 1), (1, 64), (0, 1), (1, 1), (1, 512)):
+            ctx.set_option(abi.OPT_KCERT, kc)
+            ctx.set_option(abi.OPT_KCERT_MIN, kmin)
+            r = b.run(P)
+            rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
+            if got is None:
+                got = rows
+            assert rows == got, (kc, kmin)
+    b.close()
+    # the epoch counter of a fresh batch next to its wrap: the fourth run crosses it (the candidate records are cleared with the duplicate table)
+    ctx.set_option(abi.OPT_KCERT, 1)
+    ctx.set_option(abi.OPT_KCERT_MIN, 1)
+    ctx.set_option(abi.OPT_DEBUG_TICK, 0xfffffff0 - 3 * 22 - 5)
+    b = ctx.batch(plist)
+    P = abi.default_params(used_feature_type="111111", faithful=0)
+    for _ in range(6):
+        rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in b.run(P)]
+        assert rows == got
+    b.close()
+    ctx.set_option(abi.OPT_DEBUG_TICK, 0)
+    ctx.set_option(abi.OPT_KCERT, keep[0])
+    ctx.set_option(abi.OPT_KCERT_MIN, keep[1])
+    ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, keep[2])
 
 
 def test_fused_target_setup_is_bit_identical(ctx, pairs_small):
