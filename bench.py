@@ -31,6 +31,10 @@ The JSON line also carries
   value_end_to_end — the same registrations from host buffers (mulls_icp_batch: staging upload included).
   value_converging — the same pairs with the call site's convergence thresholds (test/mulls_slam.cpp:642-648: converge_tran 0.0005 m,
                   converge_rot_d 0.001 deg) instead of the metric's forced 20 iterations: registrations/s and the mean iteration count.
+  other_configs  — (default one-GPU line only) compact legs of every other BASELINE configuration on the same box, same process: configs[0] (the reference's demo
+                  scans), configs[2] (scans against a ~1 M-point map), the 128-pair shard configs[3] gives each of 8 GPUs, configs[4] (128-beam dense pairs, six
+                  classes, 40 iterations) and the reference's own scan-to-map regime (64 scans against 20 000-point local maps) — value, ms per step, the search's
+                  roofline fraction, delta T against the checker.  `python bench.py --config k` is the full-length line of each.
   value_sustained — the timed configuration again over a fixed wall budget (>= 2 s of back-to-back steps), so that a sampler outside
                   the process sees the device busy; value stays the K-step figure the contract defines.
 """
@@ -78,6 +82,9 @@ def parse_args(argv=None):
                     help="BASELINE.json configs[k]: 1 (default, the headline line) KITTI-like scan-to-scan; 0 the reference's demo pair (= --data demo); 3 the 1024-pair list "
                          "(= --total-pairs 1024); 2 scan-to-local-map against a ~1 M-point map; 4 128-beam ~240 k-point scans, six classes, 40 iterations")
     ap.add_argument("--large-pairs", type=int, default=0, help="configs 2 / 4: pairs per GPU and step (default 32 / 16)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact legs of the other BASELINE configurations (configs[0], [2], the 128-pair shard of [3], [4] and the 20 000-point scan-to-map batch) "
+                         "that the default one-GPU line carries as `other_configs`")
     a = ap.parse_args(argv)
     if a.config == 0:
         a.data = "demo"
@@ -178,6 +185,86 @@ def rank_span(args, world, rank):
     if args.total_pairs:
         return shard.block_partition(args.total_pairs, world, rank)
     return rank * args.pairs, (rank + 1) * args.pairs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# other_configs: compact legs of the other BASELINE configurations inside the default line (the driver runs only `python bench.py --gpus 1`)
+OTHER_LEGS = {
+    # name: (pairs per step, timed steps, pairs checked against the oracle)
+    "configs[2]": (32, 4, 2),
+    "configs[4]": (16, 3, 1),
+    "scan_to_map_20k": (64, 8, 2),
+    "configs[3]_shard_128": (128, 10, 4),
+    "configs[0]": (512, 4, 3),
+}
+
+
+def _gen_other(name):
+    """(forked worker, before the parent touches OpenMP or the device) the pairs of one leg's workload"""
+    from mulls_amd import workloads as W
+
+    n = OTHER_LEGS[name][0]
+    if name == "configs[2]":
+        return W.submap_batch(n)
+    if name == "configs[4]":
+        return W.dense_batch(n)
+    return W.s2m20k_batch(n)
+
+
+def other_params(name):
+    from mulls_amd import workloads as W
+
+    return {"configs[2]": W.submap_params, "configs[4]": W.dense_params, "scan_to_map_20k": W.s2m_params}[name]()
+
+
+def other_leg(ctx, name, pairs, P, checks, workload, demo_refs=None):
+    """One compact leg on the context of the headline run: its own resident batch, untimed priming, K timed steps with the search launches bracketed by
+    hipEvents (the roofline fraction of SURVEY 8d's algorithmic bytes), the checker's pairs compared."""
+    from mulls_amd import workloads as W
+
+    n, steps, _ = OTHER_LEGS[name]
+    n = len(pairs)
+    b = ctx.batch(pairs)
+    res = abi.make_result_array(n)
+    ctx.set_profiling(2)
+    t_prime, k = time.perf_counter(), 0
+    while k < 3 or time.perf_counter() - t_prime < 0.25:
+        b.run(P, results=res)
+        k += 1
+    acc = {"ms_nn": 0.0, "launches_nn": 0.0, "nn_src_pts": 0.0, "nn_tgt_unique": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run(P, results=res)
+        pf = ctx.profile()
+        for kk in acc:
+            acc[kk] += getattr(pf, kk)
+    el = time.perf_counter() - t0
+    ctx.set_profiling(0)
+    launches = max(acc["launches_nn"], 1)
+    avg_ms = acc["ms_nn"] / launches
+    alg = (72.0 * acc["nn_src_pts"] + 16.0 * acc["nn_tgt_unique"]) / launches
+    achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    used = bytes(P.used_feature_type).decode()[:6]
+    value = n * steps / el
+    b_reg = W.algorithmic_bytes([res[i] for i in range(n)], used) / n
+    out = {"workload": workload, "value": value, "unit": "registrations/s", "pairs_per_step": n, "steps": steps, "untimed_priming_steps": k, "ms_per_step": el / steps * 1e3,
+           "mean_iterations": float(np.mean([res[i].iters for i in range(n)])), "all_code_1": bool(all(res[i].code == 1 for i in range(n))),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms,
+                        "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg, "whole_path_frac": b_reg * value / 1e9 / HBM_PEAK_GBS,
+                        "kernel": "the correspondence search launches of one ICP iteration (the tier each class cloud runs on), live hipEvents in the timed steps"}}
+    if checks:
+        out["delta_T_vs_ref"] = oracle_check_compare(checks, res)
+    if demo_refs:  # the fixture's registrations themselves: against the REFERENCE'S OWN LINES' results
+        dt_max = dr_max = 0.0
+        codes_equal = True
+        for i, (pd, T_ref) in enumerate(demo_refs):
+            dt, dr = synth.pose_error(abi_T(res[i]), T_ref)
+            dt_max, dr_max = max(dt_max, dt), max(dr_max, dr)
+            codes_equal &= res[i].code == int(pd.ref_row[54])
+        out["delta_T_vs_reference_lines"] = {"pairs_checked": len(demo_refs), "max_abs_dt_m": dt_max, "max_drot_rad": dr_max, "codes_equal": bool(codes_equal),
+                                             "within_tolerance": bool(dt_max <= 1e-4 and dr_max <= 1e-4)}
+    b.close()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -547,13 +634,34 @@ def main(argv=None, engine_factory=None):
     n_total = args.total_pairs if args.total_pairs else world * args.pairs
     workers = max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
     demo = args.data == "demo"
+    # the default one-GPU line also carries compact legs of the other BASELINE configurations: their clouds are ray-cast by three forked workers while the
+    # headline's scenes are (before this process runs an OpenMP region or touches the device)
+    others_on = (world == 1 and not args.tiny and not demo and not args.total_pairs and not args.no_other_configs and args.nn_mode == 0 and engine_factory is None
+                 and args.config == 1)
+    other_pool, other_jobs = None, {}
+    if others_on:
+        import multiprocessing as mp
+
+        other_pool = mp.get_context("fork").Pool(3)
+        other_jobs = {name: other_pool.apply_async(_gen_other, (name,)) for name in ("configs[2]", "configs[4]", "scan_to_map_20k")}
     if demo:
         scenes, P = demo_scenes()
         args.no_converging = True  # the call site's own thresholds are this configuration's
     else:
         scenes = build_scenes(min(n_scenes, max(n_total, 1)), args.tiny, workers)
     pairs = [global_pair(scenes, g) for g in range(lo, hi)]
+    other_work = {}
+    if others_on:
+        for name, job in other_jobs.items():
+            other_work[name] = (job.get(), other_params(name))
+        other_pool.close()
+        other_pool.join()
+        other_work["configs[3]_shard_128"] = ([global_pair(scenes, g) for g in range(OTHER_LEGS["configs[3]_shard_128"][0])], P)
+        d_scenes, d_P = demo_scenes()
+        n_demo = OTHER_LEGS["configs[0]"][0]
+        other_work["configs[0]"] = ([global_pair(d_scenes, g) for g in range(n_demo)], d_P)
     checks, cpu, cpu_mc, cpu_ref, checks_conv = None, None, None, None, None
+    other_checks = {}
     if rank == 0 and not args.no_cpu_baseline:
         if world == 1:  # first: its children fork, and libgomp does not survive a fork once this process has run a parallel region
             if not demo:
@@ -562,6 +670,10 @@ def main(argv=None, engine_factory=None):
             cpu_ref = cpu_baseline_reference_lines(scenes, P, budget_s=1.0 if args.tiny else 6.0)
         checks = oracle_check_prepare(pairs, P, 16) if pairs else []
         checks_conv = oracle_check_prepare(pairs, converging_params(args.tiny), 8) if pairs and not args.no_converging else None
+    if others_on:  # the checker's results of a few pairs of every leg (also with --no-cpu-baseline: a leg without its delta T is half a leg)
+        for name, (opairs, oP) in other_work.items():
+            if name != "configs[0]":  # (configs[0] is held to the reference's own lines' results, which travel in the fixture)
+                other_checks[name] = oracle_check_prepare(opairs, oP, OTHER_LEGS[name][2])
 
     import torch
     import torch.distributed as dist
@@ -750,6 +862,29 @@ def main(argv=None, engine_factory=None):
                "note": "mulls_icp_batch: class clouds in host memory (48-byte PCL records) -> results; host gather of the live fields of the classes the "
                        "registration reads into pinned memory, upload (PCIe), clone, crop, index build, iterations, residual"}
 
+    others = None
+    if others_on and rank == 0:
+        t_o = time.perf_counter()
+        descr = {
+            "configs[2]": "BASELINE configs[2]: %d scans (800 / 400 / 1200 / 300 / 200 points) per step against ONE ~1 M-point local map, classes 111110, 20 iterations; resident batch",
+            "configs[4]": "BASELINE configs[4]: %d synthetic 128-beam scan pairs (~236 k returns each, every return in a class cloud) per step, six classes, 40 iterations; resident batch",
+            "scan_to_map_20k": "the reference's own scan-to-map regime (src/map_manager.cpp:73-86): %d scans per step against 20 000-point local maps with an 11.5 k-point ground class, "
+                               "classes 111000, 20 iterations; resident batch",
+            "configs[3]_shard_128": "BASELINE configs[3]'s shard: the %d first pairs of the global list = what each of 8 GPUs registers of the 1024 (same pairs as configs[1]); resident batch",
+            "configs[0]": "BASELINE configs[0]: the reference's demo scans (000000 <-> 000001 / 000015), its own class clouds, test/mulls_reg.cpp:194-195's arguments (<= 10 iterations), "
+                          "%d pairs per step (the three registrations, then the reference result perturbed by (0.3 m, 0.5 deg) as the guess); resident batch",
+        }
+        others = {}
+        for name in ("configs[0]", "configs[2]", "configs[3]_shard_128", "configs[4]", "scan_to_map_20k"):
+            opairs, oP = other_work[name]
+            try:
+                others[name] = other_leg(engine.ctx, name, opairs, oP, other_checks.get(name), descr[name] % len(opairs), demo_refs=d_scenes if name == "configs[0]" else None)
+            except Exception as e:  # a leg must never cost the headline line
+                others[name] = {"error": repr(e)}
+        others["seconds"] = time.perf_counter() - t_o
+        others["note"] = ("compact legs in the headline run's process and context, each a resident batch of its own: value = pairs x steps / wall of the timed steps; "
+                          "roofline.frac = SURVEY 8d's algorithmic bytes of the search launches / their live hipEvent duration / 8 TB/s; full-length lines: python bench.py --config k")
+
     if rank == 0:
         n_reg = n_total * args.steps
         codes, iters = gathered[:, 52], gathered[:, 53]
@@ -868,6 +1003,8 @@ def main(argv=None, engine_factory=None):
             out["value_sustained"] = sustained
         if e2e:
             out["value_end_to_end"] = e2e
+        if others:
+            out["other_configs"] = others
         if cpu:
             out["cpu_baseline"] = cpu
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / cpu["value"]

@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 T=${1:-r04_prof}; O=gpurun_out/$T; mkdir -p $O
 # --- configs[1], the headline line: kernel statistics of the bench command, SQ counters, FETCH / WRITE passes of the batch alone
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-converging --sustain-s 0"
+CMD="python bench.py --no-other-configs --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end --no-converging --sustain-s 0"
 rm -rf /tmp/prof_stats
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $CMD > $O/bench_under_profiler.json 2> $O/bench_under_profiler.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats.csv
