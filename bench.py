@@ -855,10 +855,40 @@ def main(argv=None, engine_factory=None):
             engine.ctx.set_option(abi.OPT_LEAN_STAGING, lean_before)
         same = all(list(r2[i].T[:]) == list(results[i].T[:]) and r2[i].code == results[i].code and list(r2[i].info[:]) == list(results[i].info[:]) for i in range(len(sub)))
         caller_mb = sum(len(c) for p in sub for c in p.tgt + p.src) * abi.POINT_BYTES / 1e6
+        # ... and the same calls through mulls_pipe (include/mulls_hip.h): begun back to back on alternating contexts, so that call k + 1's host gather and
+        # upload run under call k's kernels — what a C++ caller with a stream of requests gets (value_pipelined: calls / wall of the whole sequence)
+        piped = None
+        if lean:
+            try:
+                from mulls_amd import lib as mlib
+
+                piped = {}
+                for depth in (2, 3):
+                    pipe = mlib.Pipe(0, depth)
+                    pipe.set_option(abi.OPT_LEAN_STAGING, 1)
+                    marsh = [(abi.make_pair_array(sub), abi.make_result_array(len(sub))) for _ in range(depth + 1)]
+                    for k in range(depth):  # every lane's first call allocates its staging arenas
+                        pipe.end(pipe.begin(sub, P, marshalled=marsh[k]))
+                    n_calls, pend, last_res = 12, [], None
+                    tq = time.perf_counter()
+                    for k in range(n_calls):
+                        pend.append(pipe.begin(sub, P, marshalled=marsh[k % len(marsh)]))
+                        if len(pend) > depth - 1:
+                            last_res = pipe.end(pend.pop(0))
+                    while pend:
+                        last_res = pipe.end(pend.pop(0))
+                    wall = time.perf_counter() - tq
+                    same_p = all(list(last_res[i].T[:]) == list(results[i].T[:]) and last_res[i].code == results[i].code and list(last_res[i].info[:]) == list(results[i].info[:])
+                                 for i in range(len(sub)))
+                    piped["depth_%d" % depth] = {"value": n_calls * len(sub) / wall, "ms_per_call": wall / n_calls * 1e3, "calls": n_calls, "equals_resident_results": bool(same_p)}
+                    pipe.close()
+            except Exception as e:  # never a reason to lose the bench line
+                piped = {"error": repr(e)}
         e2e = {"value": len(sub) / e2e_dt, "unit": "registrations/s", "pairs": len(sub), "ms": e2e_dt * 1e3,
                "staged_MB": getattr(pf2, "stage_bytes", 0) / 1e6, "caller_clouds_MB": caller_mb, "ms_staging": getattr(pf2, "ms_stage", 0.0),
                "ms_host_gather": getattr(pf2, "ms_stage_pack", 0.0), "equals_resident_results": bool(same), "calls_ms": [round(c[0] * 1e3, 2) for c in calls], "ms_max": calls[-1][0] * 1e3,
                "value_slowest_call": len(sub) / calls[-1][0],
+               "value_pipelined": piped,
                "note": "mulls_icp_batch: class clouds in host memory (48-byte PCL records) -> results; host gather of the live fields of the classes the "
                        "registration reads into pinned memory, upload (PCIe), clone, crop, index build, iterations, residual"}
 

@@ -262,6 +262,31 @@ int mulls_icp(mulls_ctx *ctx, const mulls_pair *pair, const mulls_params *params
 /* n independent pairs advanced in lock-step (one launch set + one host sync per ICP iteration for the batch) */
 int mulls_icp_batch(mulls_ctx *ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
 
+/* ---- independent scan pairs over several contexts of one process ("one host thread + one HIP stream set per GPU") ----
+ * The reference has one kind of caller: a C++ program that holds its clouds in host memory (test/mulls_slam.cpp).  These two forms give such a caller
+ * what bench.py's torch.distributed launcher gives the benchmark, without a second process:
+ *
+ * mulls_icp_batch_sharded: the n pairs block-partitioned over n_ctx contexts — pair p goes to context floor(p * n_ctx / n), as mulls_amd/shard.py does —
+ *   one per GPU of the node (mulls_create(device k)), or several on one GPU; the calling thread drives the first shard, one host thread each of the others;
+ *   results[p] is pair p's, the very bits mulls_icp_batch returns on one context.  No collective: the shards share nothing.  Returns the first failing
+ *   shard's code (its context has the text).  The contexts must be distinct and not in use by another thread. */
+int mulls_icp_batch_sharded(mulls_ctx *const *ctxs, int n_ctx, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
+
+/* mulls_pipe: calls from host buffers in flight on `depth` alternating contexts of one device, so that call k + 1's host gather and PCIe upload run under
+ *   call k's kernels (a serial mulls_icp_batch caller waits for 9 ms of staging in front of 3.7 ms of kernels per 1024 pairs).
+ *   mulls_icp_batch_begin returns a ticket (>= 0) at once — or, when the lane it falls on (ticket mod depth) is still running its previous call, as soon as
+ *   that call has finished; a negative value is an error code.  pairs, the clouds they point to and results belong to the call until mulls_icp_batch_end(ticket)
+ *   has returned its code (MULLS_OK: results[] are written).  A ticket can be waited for until its lane is given another call.
+ *   mulls_pipe_set_option applies a mulls_option to every lane (it waits for running calls); mulls_pipe_ctx hands out a lane's context (profile, error text). */
+typedef struct mulls_pipe mulls_pipe;
+int mulls_pipe_create(int device, int depth, mulls_pipe **out);
+void mulls_pipe_destroy(mulls_pipe *pipe);
+int mulls_pipe_depth(const mulls_pipe *pipe);
+mulls_ctx *mulls_pipe_ctx(mulls_pipe *pipe, int lane);
+int mulls_pipe_set_option(mulls_pipe *pipe, int option, double value);
+int mulls_icp_batch_begin(mulls_pipe *pipe, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
+int mulls_icp_batch_end(mulls_pipe *pipe, int ticket);
+
 /* device-resident form: stage once, run many times (each run re-clones the staged clouds like
  * cloudblock_t::clone_feature does, utility.hpp:524-550) */
 int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_batch **out);

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmulls_hip.so")
-SOURCES = ["k_setup.hip", "k_grid.hip", "k_search.hip", "k_reduce.hip", "k_icp.hip", "k_ground.hip", "k_ground_normals.hip", "k_classify.hip", "map_kernels.hip", "driver.cpp", "batch.cpp", "loop.cpp", "variants.cpp", "stage.cpp", "map.cpp", "ground.cpp", "classify.cpp", "io.cpp"]
+SOURCES = ["k_setup.hip", "k_grid.hip", "k_search.hip", "k_reduce.hip", "k_icp.hip", "k_ground.hip", "k_ground_normals.hip", "k_classify.hip", "map_kernels.hip", "driver.cpp", "batch.cpp", "loop.cpp", "variants.cpp", "stage.cpp", "shard.cpp", "map.cpp", "ground.cpp", "classify.cpp", "io.cpp"]
 DEPS = ["device_types.h", "device_util.h", "lds_tier.h", "big_tier.h", "crop_grid.h", "solve_wave.h", "detmath.h", "accum.h", "icp_step.h", "launch.h", "map_launch.h", "classify_launch.h", "ground_launch.h", "pca_device.h", "ctx.h", "batch.h", "hostmath.h", os.path.join("..", "..", "include", "mulls_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fopenmp", "-Wall", "-Wno-unused-function"]
 

@@ -766,9 +766,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 		const int p1 = std::min(n, p0 + block);
 		const long c0 = (long)first_copy_of_pair[p0], c1 = (long)first_copy_of_pair[p1];
 		const auto t_pack0 = std::chrono::steady_clock::now();
-		// (the context's sleeping thread pool, not an OpenMP team: see HostPool, ctx.h)
-		if (!ctx->pool && c1 - c0 >= 12)
-			ctx->pool = new HostPool((int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2u)));
+		// (the process's sleeping thread pool, not an OpenMP team: see HostPool, ctx.h)
 		const std::function<void(long)> pack_one = [&](long i) {
 			const HostCopy &hc = host_copies[i];
 			float *pos = reinterpret_cast<float *>(hc.dst), *nrm = pos + (size_t)hc.n * 4;
@@ -784,8 +782,8 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 					nn[3] = r[9];
 			}
 		};
-		if (ctx->pool)
-			ctx->pool->parallel_for(c0, c1, 2, pack_one);
+		if (c1 - c0 >= 12)
+			shared_host_pool().parallel_for(c0, c1, 2, pack_one);
 		else
 			for (long i = c0; i < c1; i++)
 				pack_one(i);

@@ -403,8 +403,6 @@ extern "C"
 				std::vector<uint32_t> perm((size_t)n * 4);
 				// the four classes' visiting orders, one host thread each (the sorts are the frame path's longest host step)
 				// (the context's sleeping thread pool, not an OpenMP team whose threads go on spinning into the kernels that follow: HostPool, ctx.h)
-				if (!ctx->pool)
-					ctx->pool = new HostPool((int)std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 2u)));
 				const std::function<void(long)> sort_class = [&](long c) {
 					if (!(fixed_num[c] > 0 && ncls[c] >= 10))
 						return;
@@ -416,7 +414,7 @@ extern "C"
 					for (uint32_t i = 0; i < ncls[c]; i++)
 						perm[(size_t)c * n + i] = ki[i].idx;
 				};
-				ctx->pool->parallel_for(0, 4, 1, sort_class);
+				shared_host_pool().parallel_for(0, 4, 1, sort_class);
 				for (int c = 0; c < 4; c++)
 				{
 					if (!(fixed_num[c] > 0 && ncls[c] >= 10))

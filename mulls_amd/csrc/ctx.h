@@ -35,8 +35,10 @@ class HostPool
 
   private:
 	void worker();
+	void drain(const std::function<void(long)> &fn, long end, long grain);
 	std::vector<std::thread> th_;
-	std::mutex mu_;
+	std::mutex mu_, call_mu_;
+	std::exception_ptr error_;
 	std::condition_variable cv_, done_;
 	const std::function<void(long)> *fn_ = nullptr;
 	std::atomic<long> next_{0};
@@ -45,6 +47,9 @@ class HostPool
 	int busy_ = 0;
 	bool stop_ = false;
 };
+
+int usable_cpus();			   // affinity mask cut by the container's CPU quota
+HostPool &shared_host_pool(); // the process's one pool
 
 struct mulls_ctx
 {
@@ -66,7 +71,6 @@ struct mulls_ctx
 	size_t cl_cap = 0;
 	size_t gf_cap = 0;
 	double opt[MULLS_OPT_COUNT] = {}; // enum mulls_option (mulls_set_option; preset from the environment by mulls_create)
-	HostPool *pool = nullptr; // host threads of the staging gather (made on first use)
 	unsigned char *mail_h = nullptr; // host-mapped mailbox of the small-table uploads (SegCopier, batch.h): written by the host, read by k_copy_segs
 	size_t mail_cap = 0;
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS

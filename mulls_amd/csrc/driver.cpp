@@ -12,6 +12,10 @@
 //   stage.cpp    mulls_stage_*
 #include "batch.h"
 
+#include <sched.h>
+#include <cstdio>
+#include <cstdlib>
+
 #include <mutex>
 #include <unordered_map>
 namespace
@@ -36,6 +40,53 @@ void *staggered_base(void *p, bool forget)
 	return b;
 }
 
+// CPUs this process may actually use: the affinity mask, cut by the container's CPU quota (cgroup v2 cpu.max, cgroup v1 cfs quota / period).  A pool sized from
+// hardware_concurrency() alone — 32 threads on a 256-CPU host whose container holds a 16-CPU quota — gets the whole process throttled for the rest of every
+// scheduler period as soon as two contexts gather at once (profiles/r05_pipe_calls.txt: 83 ms of "staging" per call with three contexts).
+int usable_cpus()
+{
+	int n = (int)std::max(1u, std::thread::hardware_concurrency());
+	cpu_set_t set;
+	CPU_ZERO(&set);
+	if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0)
+		n = std::min(n, CPU_COUNT(&set));
+	auto quota = [&](const char *path_quota, const char *path_period) {
+		FILE *f = std::fopen(path_quota, "r");
+		if (!f)
+			return;
+		char a[64] = {0}, b[64] = {0};
+		const int got = std::fscanf(f, "%63s %63s", a, b);
+		std::fclose(f);
+		double q = -1.0, per = 100000.0;
+		if (got >= 1 && std::strcmp(a, "max") != 0)
+			q = std::atof(a);
+		if (got >= 2)
+			per = std::atof(b);
+		else if (path_period)
+		{
+			if (FILE *g = std::fopen(path_period, "r"))
+			{
+				if (std::fscanf(g, "%63s", b) == 1)
+					per = std::atof(b);
+				std::fclose(g);
+			}
+		}
+		if (q > 0.0 && per > 0.0)
+			n = std::min(n, std::max(1, (int)(q / per)));
+	};
+	quota("/sys/fs/cgroup/cpu.max", nullptr);
+	quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+	return std::max(1, n);
+}
+
+// The process's one pool (every context's staging gather and host sorts go through it, one parallel_for at a time: the CPUs are one resource however many contexts
+// and pipes the process holds): up to 32 threads, and two of the usable CPUs left to the threads that drive the launch loops.
+HostPool &shared_host_pool()
+{
+	static HostPool pool(std::max(1, std::min(32, usable_cpus() - 2)));
+	return pool;
+}
+
 HostPool::HostPool(int n_threads)
 {
 	for (int k = 1; k < n_threads; k++)
@@ -50,6 +101,23 @@ HostPool::~HostPool()
 	cv_.notify_all();
 	for (std::thread &t : th_)
 		t.join();
+}
+// the share of one thread (a worker or the caller); an exception ends the loop for everybody and is kept for the caller to rethrow
+void HostPool::drain(const std::function<void(long)> &fn, long end, long grain)
+{
+	try
+	{
+		for (long i = next_.fetch_add(grain); i < end; i = next_.fetch_add(grain))
+			for (long k = i; k < std::min(end, i + grain); k++)
+				fn(k);
+	}
+	catch (...)
+	{
+		next_.store(end); // nobody takes another index
+		std::lock_guard<std::mutex> lk(mu_);
+		if (!error_)
+			error_ = std::current_exception();
+	}
 }
 void HostPool::worker()
 {
@@ -66,9 +134,7 @@ void HostPool::worker()
 			seen = gen_;
 			fn = fn_, end = end_, grain = grain_;
 		}
-		for (long i = next_.fetch_add(grain); i < end; i = next_.fetch_add(grain))
-			for (long k = i; k < std::min(end, i + grain); k++)
-				(*fn)(k);
+		drain(*fn, end, grain);
 		{
 			std::lock_guard<std::mutex> lk(mu_);
 			if (--busy_ == 0)
@@ -87,19 +153,26 @@ void HostPool::parallel_for(long begin, long end, long grain, const std::functio
 			fn(k);
 		return;
 	}
+	std::lock_guard<std::mutex> one_call(call_mu_); // callers of different contexts take turns
 	{
 		std::lock_guard<std::mutex> lk(mu_);
 		fn_ = &fn, end_ = end, grain_ = grain;
 		next_.store(begin);
 		busy_ = (int)th_.size();
+		error_ = nullptr;
 		gen_++;
 	}
 	cv_.notify_all();
-	for (long i = next_.fetch_add(grain); i < end; i = next_.fetch_add(grain))
-		for (long k = i; k < std::min(end, i + grain); k++)
-			fn(k);
-	std::unique_lock<std::mutex> lk(mu_);
-	done_.wait(lk, [&] { return busy_ == 0; });
+	drain(fn, end, grain);
+	std::exception_ptr err;
+	{
+		std::unique_lock<std::mutex> lk(mu_);
+		done_.wait(lk, [&] { return busy_ == 0; }); // (every worker has left fn before it goes out of scope, also after an exception)
+		err = error_;
+		error_ = nullptr;
+	}
+	if (err)
+		std::rethrow_exception(err); // reaches the ABI's function-try-block like an exception of the calling thread
 }
 
 using namespace mulls_drv;
@@ -173,7 +246,6 @@ extern "C"
 			(void)hipFree(ctx->cl_buf);
 		if (ctx->scratch)
 			mulls_batch_destroy(ctx, ctx->scratch);
-		delete ctx->pool;
 		if (ctx->mail_h)
 			(void)hipHostFree(ctx->mail_h);
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)

@@ -1044,20 +1044,15 @@ int launch_icp(hipStream_t st, uint32_t npairs, uint32_t pair_base, const Job *r
 			   int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, const uint32_t *bbox, uint32_t cap, uint32_t maxcells, IcpOut *outs,
 			   mulls_iter_trace *trace, uint32_t trace_cap)
 {
-	static bool attr_set = false;
-	static uint32_t n_cu = 256;
-	if (!attr_set)
-	{
+	const DevLaunch D = dev_launch<2>([](DevLaunch &) { // per device (launch.h)
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_icp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - MULLS_ICP_STATIC_LDS) != hipSuccess)
-			return -1;
+			return false;
 		hipFuncAttributes fa;
-		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_icp)) != hipSuccess || fa.sharedSizeBytes > (size_t)MULLS_ICP_STATIC_LDS)
-			return -1;
-		int dev = 0, cus = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-			n_cu = (uint32_t)cus;
-		attr_set = true;
-	}
+		return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_icp)) == hipSuccess && fa.sharedSizeBytes <= (size_t)MULLS_ICP_STATIC_LDS;
+	});
+	if (!D.ok)
+		return -1;
+	const uint32_t n_cu = D.n_cu;
 	if (!npairs)
 		return 0;
 	size_t lds = nn_lds_bytes(cap, maxcells, true);

@@ -803,12 +803,9 @@ __global__ void k_set_corr(uint32_t src_off, const int32_t *__restrict__ cs, con
 void launch_accum(hipStream_t st, const uint32_t *leaders, const uint32_t split[4], const Job *jobs, const CloudDesc *descs, const PairState *states, const RunParams &rp,
 				  const float4 *spos, const float4 *mq, const uint8_t *flag, float *wd, double *partial, bool single, uint32_t wave_min_trips)
 {
-	static bool attr_set = false;
-	if (!attr_set)
-	{
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF);
-		attr_set = true;
-	}
+	(void)dev_launch<3>([](DevLaunch &) { // per device (launch.h)
+		return hipFuncSetAttribute(reinterpret_cast<const void *>(k_accum<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MULLS_RED_BYTES_HALF) == hipSuccess;
+	});
 	// One wave per trip once the launch has trips enough to fill the chip with waves (k_accum_wave; below that a trip's sixteen slots per lane in sequence are the launch's
 	// latency).  Its point-to-line form is the faithful combined system's (diagonal + right-hand side); other point-to-line sums stay with k_accum.
 	const uint32_t n_trips = split[3] - split[0];

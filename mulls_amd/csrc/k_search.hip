@@ -556,32 +556,27 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells,
 				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity)
 {
-	static bool attr_set = false;
-	static uint32_t n_cu = 256;
-	if (!attr_set)
-	{
+	// per device (launch.h: DevLaunch): k_nn_lds may take the whole LDS; dyn_max[0] = the dynamic LDS k_cert_nn can have next to its static block
+	const DevLaunch D = dev_launch<0>([](DevLaunch &d) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-			return -1;
-		int dev = 0, cus = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-			n_cu = (uint32_t)cus;
-		attr_set = true;
-	}
-	if (!njobs)
-		return 0;
-	const bool dedup = rp.lds_dedup != 0u;
-	static size_t fused_dyn_max = 0; // dynamic LDS k_cert_nn can have next to its static block
-	if (!fused_dyn_max)
-	{
+			return false;
 		hipFuncAttributes fa;
-		fused_dyn_max = 1;
+		d.dyn_max[0] = 1;
 		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert_nn)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u)
 		{
 			const size_t room = 160u * 1024u - fa.sharedSizeBytes;
 			if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_cert_nn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) == hipSuccess)
-				fused_dyn_max = room;
+				d.dyn_max[0] = room;
 		}
-	}
+		return true;
+	});
+	if (!D.ok)
+		return -1;
+	const uint32_t n_cu = D.n_cu;
+	const size_t fused_dyn_max = D.dyn_max[0];
+	if (!njobs)
+		return 0;
+	const bool dedup = rp.lds_dedup != 0u;
 	// (up to two class clouds per CU: 117 k vs 103 k registrations/s at 192 pairs, 131 k vs 119 k at 256; no gain beyond, profiles/r03_modes_fused.txt)
 	if (njobs <= 2u * n_cu && rp.debug_stop != 10u && nn_lds_bytes(cap, maxcells, dedup) <= fused_dyn_max)
 	{
@@ -608,22 +603,19 @@ int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t
 					  const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match,
 					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells)
 {
-	static size_t dyn_max = 0;
-	static uint32_t n_cu = 256;
-	if (!dyn_max)
-	{
+	const DevLaunch D = dev_launch<1>([](DevLaunch &d) { // per device (launch.h): the dynamic LDS k_cert_mixed can have next to its static block, the CU count
 		hipFuncAttributes fa;
-		dyn_max = 1;
+		d.dyn_max[0] = 1;
 		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert_mixed)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u)
 		{
 			const size_t room = 160u * 1024u - fa.sharedSizeBytes;
 			if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_cert_mixed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)room) == hipSuccess)
-				dyn_max = room;
+				d.dyn_max[0] = room;
 		}
-		int dev = 0, cus = 0;
-		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-			n_cu = (uint32_t)cus;
-	}
+		return true;
+	});
+	const size_t dyn_max = D.dyn_max[0];
+	const uint32_t n_cu = D.n_cu;
 	if (!n_lds || !n_big || rp.normal_shooting || rp.debug_stop == 10u || rp.debug_stop == 22u)
 		return 0;
 	uint32_t split = 1;

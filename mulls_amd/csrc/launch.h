@@ -6,6 +6,37 @@
 #include "device_types.h"
 
 #include <hip/hip_vector_types.h>
+#include <mutex>
+
+// Launch state that belongs to a DEVICE, not to the process: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current at the call, and
+// the CU count is the device's.  mulls_create(device) allows contexts on several GPUs of one process (and every host thread may own one), so each launch wrapper
+// keeps one DevLaunch per device, set up under a lock by the first launch on that device.  TAG: one table per wrapper.
+struct DevLaunch
+{
+	bool ready = false, ok = false;
+	size_t dyn_max[2] = {0, 0}; // dynamic LDS the wrapper's kernels may ask for on this device
+	uint32_t n_cu = 256;
+};
+template <int TAG, class Init>
+inline DevLaunch dev_launch(Init init)
+{
+	static std::mutex mu;
+	static DevLaunch table[64];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+		dev = 0;
+	std::lock_guard<std::mutex> lock(mu);
+	DevLaunch &D = table[dev];
+	if (!D.ready)
+	{
+		int cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+			D.n_cu = (uint32_t)cus;
+		D.ok = init(D);
+		D.ready = true;
+	}
+	return D;
+}
 void launch_clone_src(hipStream_t st, uint32_t njobs, const Job *jobs, const CloudDesc *descs, const PairSetup *setup, const float4 *stage,
 					  float4 *tmp_pos, float4 *tmp_nrm, uint32_t *bbox, const RunParams &rp);
 void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage,

@@ -46,6 +46,16 @@ def load():
     lib.mulls_stream.restype = vp
     lib.mulls_icp.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
     lib.mulls_icp_batch.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_icp_batch_sharded.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_pipe_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    lib.mulls_pipe_destroy.argtypes = [vp]
+    lib.mulls_pipe_destroy.restype = None
+    lib.mulls_pipe_depth.argtypes = [vp]
+    lib.mulls_pipe_ctx.argtypes = [vp, C.c_int]
+    lib.mulls_pipe_ctx.restype = vp
+    lib.mulls_pipe_set_option.argtypes = [vp, C.c_int, C.c_double]
+    lib.mulls_icp_batch_begin.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_icp_batch_end.argtypes = [vp, C.c_int]
     lib.mulls_batch_create.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(vp)]
     lib.mulls_batch_run.argtypes = [vp, vp, C.POINTER(abi.Params), C.POINTER(abi.Result)]
     lib.mulls_batch_destroy.argtypes = [vp, vp]
@@ -107,6 +117,7 @@ EXPORTS = [
     "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features", "mulls_voxel_downsample",
     "mulls_set_option", "mulls_get_option", "mulls_block_create", "mulls_block_destroy", "mulls_extract_features_resident", "mulls_block_cloud", "mulls_block_download",
     "mulls_motion_compensate", "mulls_block_motion_compensate",
+    "mulls_icp_batch_sharded", "mulls_pipe_create", "mulls_pipe_destroy", "mulls_pipe_depth", "mulls_pipe_ctx", "mulls_pipe_set_option", "mulls_icp_batch_begin", "mulls_icp_batch_end",
 ]
 
 
@@ -144,6 +155,68 @@ def write_pose(path, T, append=False):
     rc = load().mulls_io_write_pose(path.encode(), abi.colmajor16(T), int(append))
     if rc != 0:
         raise MullsError("mulls_io_write_pose(%s) failed with %d" % (path, rc))
+
+
+def icp_batch_sharded(contexts, pairs, params, marshalled=None):
+    """mulls_icp_batch_sharded: the pairs block-partitioned over `contexts` (Context objects: one per GPU, or several on one), one host thread each."""
+    lib = load()
+    arr, res = marshalled if marshalled is not None else (abi.make_pair_array(pairs), abi.make_result_array(len(pairs)))
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = lib.mulls_icp_batch_sharded(hs, len(contexts), arr, len(pairs), C.byref(params), res)
+    if rc != 0:
+        raise MullsError("mulls_icp_batch_sharded failed with %d: %s" % (rc, "; ".join((lib.mulls_last_error(c.h) or b"").decode() for c in contexts)))
+    return res
+
+
+class Pipe:
+    """mulls_pipe: mulls_icp_batch calls from host buffers in flight on alternating contexts of one device (begin / end by ticket)."""
+
+    def __init__(self, device=0, depth=2):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.mulls_pipe_create(device, depth, C.byref(self.h))
+        if rc != 0:
+            raise MullsError("mulls_pipe_create(device=%d, depth=%d) failed with %d" % (device, depth, rc))
+        self._keep = {}
+
+    def set_option(self, option, value):
+        rc = self.lib.mulls_pipe_set_option(self.h, option, float(value))
+        if rc != 0:
+            raise MullsError("mulls_pipe_set_option failed with %d" % rc)
+
+    def begin(self, pairs, params, marshalled=None):
+        """-> ticket; the marshalled arrays (and through them the clouds) are kept alive until end(ticket)"""
+        arr, res = marshalled if marshalled is not None else (abi.make_pair_array(pairs), abi.make_result_array(len(pairs)))
+        t = self.lib.mulls_icp_batch_begin(self.h, arr, len(pairs), C.byref(params), res)
+        if t < 0:
+            raise MullsError("mulls_icp_batch_begin failed with %d" % t)
+        self._keep[t] = (arr, res, pairs, params)
+        return t
+
+    def end(self, ticket):
+        rc = self.lib.mulls_icp_batch_end(self.h, ticket)
+        arr, res, _, _ = self._keep.pop(ticket)
+        if rc != 0:
+            lane = ticket % self.lib.mulls_pipe_depth(self.h)
+            raise MullsError("mulls_icp_batch_end(%d) failed with %d: %s" % (ticket, rc, (self.lib.mulls_last_error(self.lib.mulls_pipe_ctx(self.h, lane)) or b"").decode()))
+        return res
+
+    def lane_profile(self, lane):
+        """mulls_profile of one lane's context (its latest call)"""
+        pf = abi.Profile()
+        self.lib.mulls_get_profile(self.lib.mulls_pipe_ctx(self.h, lane), C.byref(pf))
+        return pf
+
+    def close(self):
+        if self.h:
+            self.lib.mulls_pipe_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
