@@ -590,7 +590,7 @@ def large_main(args, rank, local_rank, world, engine_factory=None):
             "roofline": {
                 "kernel": L["kernel"], "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                 "traffic_note": "bytes per launch set (search + rejection chain) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration (%s; 2 x FETCH + "
-                                "WRITE per the gfx950 guide); null when no pass of this very configuration is committed" % (pmc.get("source") if pmc else "profiles/pmc_traffic_cfg%d.json" % cfg),
+                                "WRITE per the gfx950 guide); null when no pass of this very configuration is committed" % (pmc.get("source") if pmc else "none committed for configs[%d] at this batch size" % cfg),
                 "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
                 "whole_path": {"B_reg_bytes_per_registration": b_reg, "achieved_GBs": b_reg * value / 1e9, "frac": b_reg * value / 1e9 / HBM_PEAK_GBS,
                                "note": "SURVEY 8d's B_reg (setup + every iteration's search and accumulation + residual pass) x registrations/s against the HBM peak"},
