@@ -226,7 +226,8 @@ def other_leg(ctx, name, pairs, P, checks, workload, demo_refs=None):
     n = len(pairs)
     b = ctx.batch(pairs)
     res = abi.make_result_array(n)
-    ctx.set_profiling(2)
+    events_live = n >= 512  # (small batches: timed without the event pairs, the search launches bracketed in as many further steps — as in main)
+    ctx.set_profiling(2 if events_live else 0)
     t_prime, k = time.perf_counter(), 0
     while k < 3 or time.perf_counter() - t_prime < 0.25:
         b.run(P, results=res)
@@ -235,10 +236,19 @@ def other_leg(ctx, name, pairs, P, checks, workload, demo_refs=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         b.run(P, results=res)
-        pf = ctx.profile()
-        for kk in acc:
-            acc[kk] += getattr(pf, kk)
+        if events_live:
+            pf = ctx.profile()
+            for kk in acc:
+                acc[kk] += getattr(pf, kk)
     el = time.perf_counter() - t0
+    if not events_live:
+        ctx.set_profiling(2)
+        b.run(P, results=res)
+        for _ in range(steps):
+            b.run(P, results=res)
+            pf = ctx.profile()
+            for kk in acc:
+                acc[kk] += getattr(pf, kk)
     ctx.set_profiling(0)
     launches = max(acc["launches_nn"], 1)
     avg_ms = acc["ms_nn"] / launches
@@ -251,7 +261,8 @@ def other_leg(ctx, name, pairs, P, checks, workload, demo_refs=None):
            "mean_iterations": float(np.mean([res[i].iters for i in range(n)])), "all_code_1": bool(all(res[i].code == 1 for i in range(n))),
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms,
                         "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg, "whole_path_frac": b_reg * value / 1e9 / HBM_PEAK_GBS,
-                        "kernel": "the correspondence search launches of one ICP iteration (the tier each class cloud runs on), live hipEvents in the timed steps"}}
+                        "kernel": "the correspondence search launches of one ICP iteration (the tier each class cloud runs on), hipEvents " +
+                                  ("live in the timed steps" if events_live else "in %d steps right after the timed ones" % steps)}}
     if checks:
         out["delta_T_vs_ref"] = oracle_check_compare(checks, res)
     if demo_refs:  # the fixture's registrations themselves: against the REFERENCE'S OWN LINES' results
@@ -734,7 +745,10 @@ def main(argv=None, engine_factory=None):
     # untimed steps with events around every launch (level 1), which also gives value_all_kernel_events_on.
     prof_keys = ("ms_nn", "launches_nn", "nn_pair_evals", "nn_src_pts", "nn_tgt_unique", "nn_tgt_pts", "ms_setup", "ms_filter", "ms_accum", "ms_residual", "nn_corr_pts", "icp_loop_ms")
     acc = {k: 0.0 for k in prof_keys}
-    engine.set_profiling(2)
+    # A shard of a few hundred pairs (configs[3] over 8 GPUs: 128 pairs, a 1.2 ms step) is timed WITHOUT the event pairs — forty event records and their read-back
+    # are a tenth of such a step — and the search launches are bracketed in K further steps right after the timed ones (roofline.measured_in says which)
+    events_live = len(pairs) >= 512 or args.tiny
+    engine.set_profiling(2 if events_live else 0)
     step()  # one more untimed step with the timed region's event bracketing on (the first event records of a process are slow)
     barrier()
     t0 = time.perf_counter()
@@ -746,14 +760,23 @@ def main(argv=None, engine_factory=None):
         gathered = shard.gather_wait(pending) if pending is not None else gathered
         pending = h
         step_s.append(time.perf_counter() - ts)
-        pf = engine.profile()
-        for k in prof_keys:
-            acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
+        if events_live:
+            pf = engine.profile()
+            for k in prof_keys:
+                acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
         if os.environ.get("MULLS_BENCH_TRACE"):
             print("step %.2f ms: host launch %.2f wait %.2f search %.2f" % (step_s[-1] * 1e3, pf.ms_host_launch, pf.ms_host_wait, pf.ms_nn), file=sys.stderr)
     gathered = shard.gather_wait(pending)
     barrier()
     elapsed = time.perf_counter() - t0
+    if not events_live:
+        engine.set_profiling(2)
+        step()
+        for _ in range(args.steps):
+            step()
+            pf = engine.profile()
+            for k in prof_keys:
+                acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
     # the same K steps without the result gather (N > 1: what the exchange step costs)
     elapsed_nogather = None
     if world > 1:
@@ -966,7 +989,7 @@ def main(argv=None, engine_factory=None):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "real" if demo else "synthetic",
-            "profiling_events_on": "around the dominant kernel (correspondence search) in the timed steps",
+            "profiling_events_on": "around the dominant kernel (correspondence search) in the timed steps" if events_live else "none in the timed steps (see roofline.measured_in)",
             "value_all_kernel_events_on": n_reg / elapsed_all,
             "value_without_gather": n_reg / elapsed_nogather if elapsed_nogather else None,
             "config": {
@@ -1006,6 +1029,8 @@ def main(argv=None, engine_factory=None):
                                     "" if abs(pmc_scale - 1.0) < 0.01 else ", measured on launches of %d pairs and scaled by %.2f to this run's %.0f pairs per launch" % (
                                         pmc["config"]["pairs_per_launch"], pmc_scale, pairs_per_launch)),
                 "avg_launch_ms": avg_ms, "launches": int(acc["launches_nn"]), "algorithmic_bytes_per_launch": alg_bytes,
+                "measured_in": "the timed steps (hipEvents around the search launches of every iteration, live)" if events_live else
+                               "%d steps run right after the timed ones with hipEvents around the search launches (batches below 512 pairs are timed without the event pairs)" % args.steps,
                 "note": "the search is an irregular exact query: its light pass (k_cert) is bound by the latency of its memory round trips at the occupancy its "
                         "registers and LDS allow in the early iterations and sits at the HBM roof (4.5-5.2 TB/s of counted traffic) once every point certifies; "
                         "the heavy pass (k_nn_lds, first iterations) by LDS-latency and VALU issue with one workgroup per CU (DESIGN.md sections 4 and 12.3); "

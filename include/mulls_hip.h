@@ -287,6 +287,10 @@ int mulls_pipe_set_option(mulls_pipe *pipe, int option, double value);
 int mulls_icp_batch_begin(mulls_pipe *pipe, const mulls_pair *pairs, int n, const mulls_params *params, mulls_result *results);
 int mulls_icp_batch_end(mulls_pipe *pipe, int ticket);
 
+/* the n result records as rows of 56 doubles — T (16, column-major), information matrix (36), code, iterations, sigma, confidence — the table bench.py's ranks
+ * gather over RCCL (mulls_amd/shard.py: RECORD); host code, no context */
+void mulls_pack_results(const mulls_result *results, int n, double *table);
+
 /* device-resident form: stage once, run many times (each run re-clones the staged clouds like
  * cloudblock_t::clone_feature does, utility.hpp:524-550) */
 int mulls_batch_create(mulls_ctx *ctx, const mulls_pair *pairs, int n, mulls_batch **out);

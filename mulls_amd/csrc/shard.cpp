@@ -127,6 +127,20 @@ extern "C"
 		return mulls::abi_caught(nullptr); // nothing is thrown across the ABI
 	}
 
+	void mulls_pack_results(const mulls_result *results, int n, double *table)
+	{
+		if (!results || !table)
+			return;
+		for (int i = 0; i < n; i++)
+		{
+			const mulls_result &r = results[i];
+			double *row = table + (size_t)i * 56;
+			std::memcpy(row, r.T, sizeof(double) * 16);
+			std::memcpy(row + 16, r.info, sizeof(double) * 36);
+			row[52] = (double)r.code, row[53] = (double)r.iters, row[54] = (double)r.sigma, row[55] = (double)r.confidence;
+		}
+	}
+
 	int mulls_pipe_create(int device, int depth, mulls_pipe **out)
 	try
 	{

@@ -46,6 +46,8 @@ def load():
     lib.mulls_stream.restype = vp
     lib.mulls_icp.argtypes = [vp, C.POINTER(abi.Pair), C.POINTER(abi.Params), C.POINTER(abi.Result)]
     lib.mulls_icp_batch.argtypes = [vp, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
+    lib.mulls_pack_results.argtypes = [C.POINTER(abi.Result), C.c_int, C.c_void_p]
+    lib.mulls_pack_results.restype = None
     lib.mulls_icp_batch_sharded.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(abi.Pair), C.c_int, C.POINTER(abi.Params), C.POINTER(abi.Result)]
     lib.mulls_pipe_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
     lib.mulls_pipe_destroy.argtypes = [vp]
@@ -117,7 +119,7 @@ EXPORTS = [
     "mulls_classify_default_params", "mulls_classify_nground", "mulls_extract_default_params", "mulls_extract_features", "mulls_voxel_downsample",
     "mulls_set_option", "mulls_get_option", "mulls_block_create", "mulls_block_destroy", "mulls_extract_features_resident", "mulls_block_cloud", "mulls_block_download",
     "mulls_motion_compensate", "mulls_block_motion_compensate",
-    "mulls_icp_batch_sharded", "mulls_pipe_create", "mulls_pipe_destroy", "mulls_pipe_depth", "mulls_pipe_ctx", "mulls_pipe_set_option", "mulls_icp_batch_begin", "mulls_icp_batch_end",
+    "mulls_pack_results", "mulls_icp_batch_sharded", "mulls_pipe_create", "mulls_pipe_destroy", "mulls_pipe_depth", "mulls_pipe_ctx", "mulls_pipe_set_option", "mulls_icp_batch_begin", "mulls_icp_batch_end",
 ]
 
 

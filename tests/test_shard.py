@@ -103,3 +103,25 @@ def test_pack_results_matches_field_access():
         assert list(tab[i, :16]) == list(res[i].T[:]) and list(tab[i, 16:52]) == list(res[i].info[:])
         assert tab[i, 52] == res[i].code and tab[i, 53] == res[i].iters
         assert tab[i, 54] == res[i].sigma and tab[i, 55] == res[i].confidence
+
+
+def test_native_pack_equals_the_numpy_statement():
+    """mulls_pack_results (the library's host helper behind shard.pack_results) writes the very table the column slices of the raw records give."""
+    import os
+
+    import pytest
+    from mulls_amd import abi, lib as mlib, shard
+
+    if not os.path.exists(mlib.LIB_PATH):
+        pytest.skip("libmulls_hip.so is not built")
+    rng = np.random.default_rng(9)
+    for n in (1, 7, 300):
+        res = abi.make_result_array(n)
+        for i in range(n):
+            for k in range(16):
+                res[i].T[k] = rng.normal()
+            for k in range(36):
+                res[i].info[k] = rng.normal()
+            res[i].code, res[i].iters = int(rng.integers(-3, 2)), int(rng.integers(0, 41))
+            res[i].sigma, res[i].confidence = float(rng.normal()), float(rng.uniform())
+        assert np.array_equal(shard.pack_results(res, n, native=True), shard.pack_results(res, n, native=False))
