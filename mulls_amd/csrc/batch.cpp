@@ -633,7 +633,9 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 			B->setup_h[p].inv_t[0] = gi.at(0, 3);
 			B->setup_h[p].inv_t[1] = gi.at(1, 3);
 			B->setup_h[p].inv_t[2] = gi.at(2, 3);
-			B->setup_h[p].inv_t[3] = 0.0;
+			// theta of the slerp from the identity (k_clone_src): one value per pair, by the host's libm — the reference's own acos; its sine and the two sines per
+			// point are detmath.h's on the device (the same bits on every toolchain)
+			B->setup_h[p].inv_t[3] = std::acos(std::min(1.0, std::fabs(B->setup_h[p].inv_q[0])));
 		}
 	}
 	if (stage_rec >= (1ull << 32) || so >= (1ull << 31) || to >= (1ull << 31))

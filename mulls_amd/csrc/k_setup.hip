@@ -2,6 +2,7 @@
 // (gfx950 / CDNA4, wave64; numerics policy and launch geometry: device_util.h)
 #include "device_util.h"
 #include "crop_grid.h"
+#include "detmath.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Setup 1: clone the staged source clouds into SoA and apply the initial guess (double math, float store); reduce
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_clone_src(const Job *__restrict
 				}
 				else
 				{
-					const double theta = acos(absD), sinTheta = sin(theta);
-					s0 = sin((1.0 - t) * theta) / sinTheta;
-					s1 = sin((t * theta)) / sinTheta;
+					const double theta = su.inv_t[3], sinTheta = mulls::det::sin_cr(theta); // (theta: the host's acos of |q.w|, batch_fill)
+					s0 = mulls::det::sin_cr((1.0 - t) * theta) / sinTheta;
+					s1 = mulls::det::sin_cr((t * theta)) / sinTheta;
 				}
 				if (dq < 0)
 					s1 = -s1;
@@ -485,6 +486,7 @@ struct MotionComp
 {
 	double q[4]; // Eigen::Quaterniond(Tran.block<3,3>(0,0)): w x y z
 	double t[3]; // Tran.block<3,1>(0,3)
+	double theta, sin_theta; // acos(|q.w|) — one value per transform, by the HOST's libm, the reference's own (launch_motion_comp) — and its sine (detmath.h)
 	float thre;
 };
 __global__ __launch_bounds__(MULLS_BLOCK) void k_motion_comp(float4 *__restrict__ recs, uint32_t n, MotionComp M)
@@ -506,9 +508,11 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_motion_comp(float4 *__restrict_
 	}
 	else
 	{
-		const double theta = acos(absD), sinTheta = sin(theta);
-		s0 = sin((1.0 - t) * theta) / sinTheta;
-		s1 = sin((t * theta)) / sinTheta;
+		// (the two sines per point by detmath.h's correctly rounded sine: the same bits on every ROCm version and on the host, like the rest of the library's
+		// trigonometry; the device library's acos / sin were the one place where a result depended on the toolchain — advisor, round 4)
+		const double theta = M.theta, sinTheta = M.sin_theta;
+		s0 = mulls::det::sin_cr((1.0 - t) * theta) / sinTheta;
+		s1 = mulls::det::sin_cr((t * theta)) / sinTheta;
 	}
 	if (dq < 0)
 		s1 = -s1;
@@ -566,6 +570,8 @@ void launch_motion_comp(hipStream_t st, float4 *recs, uint32_t n, const double q
 	for (int k = 0; k < 3; k++)
 		M.t[k] = t[k];
 	M.thre = thre;
+	M.theta = std::acos(std::fabs(q[0]) < 1.0 ? std::fabs(q[0]) : 1.0);
+	M.sin_theta = mulls::det::sin_cr(M.theta);
 	hipLaunchKernelGGL(k_motion_comp, dim3((n + MULLS_BLOCK - 1) / MULLS_BLOCK), dim3(MULLS_BLOCK), 0, st, recs, n, M);
 }
 
