@@ -246,9 +246,10 @@ enum mulls_option
 	MULLS_OPT_KCERT = 23,				  /* [1] k-candidate certificates: a point whose hinted target fails the certificate evaluates the few nearest targets its last search
 											 saw before it is searched again (0: round 4's certificates only) */
 	MULLS_OPT_KCERT_MIN = 24,			  /* [64] LDS tier: leftover lists shorter than this skip the look (it costs one chain of round trips whatever the length) */
-	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [0 = never] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
-											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits).  Measured no faster than one
-											 workgroup per trip at 4096 pairs (profiles/r05_experiments.txt), so off by default; set before the batch is filled */
+	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [2048] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
+											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits; -0.26 ms of a 17.8 ms
+											 step at 4096 pairs, profiles/r05_experiments.txt); 0 = always one workgroup per trip (k_accum).  Read when a batch is filled
+											 (the memo of the intensity weights is allocated with it) and at every launch */
 	MULLS_OPT_COUNT = 26
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(64 * MULLS_ACCW_WAVES, MULLS_ACCW_OCC) void k_accum
 																					   float *__restrict__ wd, double *__restrict__ partial)
 {
 	const uint32_t wave = threadIdx.x >> 6, part = wave % MULLS_ACCW_SPLIT;
-	const uint32_t trip = xcd_job(blockIdx.x, gridDim.x) * (MULLS_ACCW_WAVES / MULLS_ACCW_SPLIT) + wave / MULLS_ACCW_SPLIT;
+	// (blockIdx in launch order, NOT xcd_job's contiguous eighths: the leaders come longest trip first, so an eighth of the table per XCD gives XCD 0 the sixteen-slot
+	// trips and XCD 7 the three-slot ones — the launch then lasts as long as XCD 0; round robin deals every length to every XCD)
+	const uint32_t trip = blockIdx.x * (MULLS_ACCW_WAVES / MULLS_ACCW_SPLIT) + wave / MULLS_ACCW_SPLIT;
 	if (trip >= n_trips)
 		return;
 	const uint32_t job_idx = leaders[trip];
