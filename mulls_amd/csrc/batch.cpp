@@ -807,7 +807,10 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 		up.add_host(B->big_clouds, B->big_clouds_h.data(), B->big_clouds_h.size() * sizeof(Job));
 		up.add_host(B->setup, B->setup_h.data(), sizeof(PairSetup) * n);
 		if (up.flush(st) != MULLS_OK)
+		{
+			(void)hipStreamSynchronize(st); // (the uploads queued above still read upload_h / setup_h: nothing may rewrite them before they have run)
 			return MULLS_E_HIP;
+		}
 	}
 	if (e == hipSuccess && memo_grew) // (an entry counts only with its magic word: fresh memory is cleared of chance hits)
 		e = hipMemsetAsync(B->wi_memo, 0, B->cap_src[12] * sizeof(uint4), st);
@@ -985,7 +988,10 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		up.add_host(B->descs_init, B->descs_h.data(), sizeof(CloudDesc) * B->descs_h.size());
 		up.add_host(B->bbox_init, B->bbox_h, sizeof(uint32_t) * 6 * n);
 		if (up.flush(st) != MULLS_OK)
+		{
+			(void)hipStreamSynchronize(st);
 			return MULLS_E_HIP;
+		}
 		HIPCHK(ctx, hipStreamSynchronize(st)); // the host vectors may be rebuilt by a later call
 		B->dev_key = want_key;
 	}

@@ -42,8 +42,13 @@ struct SegCopier
 	}
 	void add_dev(void *dst, const void *src, size_t bytes)
 	{
-		if (bytes)
-			segs.push_back({(unsigned long long)(uintptr_t)dst, (unsigned long long)(uintptr_t)src, (uint32_t)bytes, 0u});
+		// (CopySeg carries a 32-bit size: a range of 4 GiB or more — a device-resident cloud of 89 M records — goes in as several segments, each a multiple of 16 bytes)
+		const size_t piece = (size_t)0xfffffff0u;
+		for (size_t off = 0; off < bytes; off += piece)
+		{
+			const size_t b = std::min(piece, bytes - off);
+			segs.push_back({(unsigned long long)(uintptr_t)dst + off, (unsigned long long)(uintptr_t)src + off, (uint32_t)b, 0u});
+		}
 	}
 	int flush(hipStream_t st); // batch.cpp
 };

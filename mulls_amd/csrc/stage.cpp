@@ -57,9 +57,22 @@ extern "C"
 		double q[4];
 		mulls::rotation_quaternion(T, q); // Eigen::Quaterniond(Tran.block<3, 3>(0, 0)), cfilter.hpp:476
 		const double t[3] = {T.at(0, 3), T.at(1, 3), T.at(2, 3)};
-		if (mulls_is_map_memory(ctx, pts, (size_t)n * MULLS_POINT_BYTES))
+		// where do the records live?  A cloud of the library (mulls_block_cloud / mulls_map_cloud) or any other device allocation of the caller's runs in place; host
+		// memory (pageable or pinned) makes the round trip.  (Round 4 treated every pointer it did not own as host memory: a caller's own hipMalloc buffer got an
+		// invalid copy kind — advisor.)
+		bool on_device = mulls_is_map_memory(ctx, pts, (size_t)n * MULLS_POINT_BYTES);
+		if (!on_device)
 		{
-			// a device-resident cloud (mulls_block_cloud / mulls_map_cloud): in place, nothing crosses PCIe
+			hipPointerAttribute_t at;
+			std::memset(&at, 0, sizeof(at));
+			if (hipPointerGetAttributes(&at, pts) == hipSuccess)
+				on_device = at.type == hipMemoryTypeDevice;
+			else
+				(void)hipGetLastError(); // (an ordinary host pointer: the query reports an error on some runtimes — cleared)
+		}
+		if (on_device)
+		{
+			// in place, nothing crosses PCIe
 			launch_motion_comp(ctx->stream, static_cast<float4 *>(pts), n, q, t, s_ambiguous_thre);
 			HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 			return MULLS_OK;
@@ -93,6 +106,11 @@ extern "C"
 	{
 		if (!ctx || !block || !Tran)
 			return MULLS_E_INVALID;
+		if (std::find(ctx->blocks.begin(), ctx->blocks.end(), block) == ctx->blocks.end())
+		{
+			ctx->err = "mulls_block_motion_compensate: the block does not belong to this context";
+			return MULLS_E_INVALID;
+		}
 		HIPCHK(ctx, hipSetDevice(ctx->device));
 		Mat4 T;
 		std::memcpy(T.v, Tran, sizeof(T.v));

@@ -112,3 +112,34 @@ def test_resident_block_is_compensated_in_place(ctx_auto):
         again = abi.points_of(b.download(abi.EX_GROUND))
         ulp_close(again, pyoracle.motion_compensate(pyoracle.motion_compensate(before[abi.EX_GROUND], T), np.linalg.inv(T)))
         b.close()
+
+
+@pytest.mark.gpu
+def test_callers_own_device_buffer_and_foreign_blocks(ctx_auto):
+    """mulls_motion_compensate on a device allocation the library does not own (the caller's own buffer — here a torch tensor): compensated in place like a cloud
+    of the library, the same bytes as the host path returns.  mulls_block_motion_compensate refuses a block of another context.  (Advisor findings of round 4.)"""
+    import ctypes as C
+
+    import torch
+    from mulls_amd import lib
+
+    T = TRANS[1]
+    pts = scan_points(77, n_beams=32, n_az=700)
+    want = ctx_auto.motion_compensate(pts, T, 0.1)
+    raw = abi.records(pts).copy()
+    dev = torch.from_numpy(raw.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    ctx_auto._check(ctx_auto.lib.mulls_motion_compensate(ctx_auto.h, C.c_void_p(dev.data_ptr()), len(raw), abi.POINT_BYTES, abi.colmajor16(T), C.c_float(0.1)), "mulls_motion_compensate")
+    got = abi.points_of(dev.cpu().numpy().view(raw.dtype).reshape(raw.shape))
+    assert all(np.array_equal(got[f], want[f]) for f in FIELDS)
+    # a block belongs to the context that made it
+    other = lib.Context(0)
+    scene = synth.Scene(62)
+    scan = synth.raycast(scene, synth.se3(0, 0, scene.sensor_height), 16, 400, seed=62)
+    spts = abi.make_points(scan["xyz"], np.zeros_like(scan["xyz"]), scan["intensity"], scan["t"])
+    X = abi.extract_params(ground=abi.ground_params(nonground_random_down_rate=1), classify=abi.classify_params(neighbor_k=20))
+    b = ctx_auto.block().extract(spts, X)
+    rc = other.lib.mulls_block_motion_compensate(other.h, b.h, abi.colmajor16(T), 0)
+    assert rc == abi.MULLS_E_INVALID
+    b.motion_compensate(T)  # its own context: fine
+    b.close()
+    other.close()
