@@ -120,16 +120,24 @@ def test_callers_own_device_buffer_and_foreign_blocks(ctx_auto):
     of the library, the same bytes as the host path returns.  mulls_block_motion_compensate refuses a block of another context.  (Advisor findings of round 4.)"""
     import ctypes as C
 
-    import torch
     from mulls_amd import lib
 
+    hip = C.CDLL("libamdhip64.so")  # the caller's own allocation: straight from the HIP runtime, nothing of the library's
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     T = TRANS[1]
     pts = scan_points(77, n_beams=32, n_az=700)
     want = ctx_auto.motion_compensate(pts, T, 0.1)
     raw = abi.records(pts).copy()
-    dev = torch.from_numpy(raw.view(np.uint8).reshape(-1).copy()).to("cuda:0")
-    ctx_auto._check(ctx_auto.lib.mulls_motion_compensate(ctx_auto.h, C.c_void_p(dev.data_ptr()), len(raw), abi.POINT_BYTES, abi.colmajor16(T), C.c_float(0.1)), "mulls_motion_compensate")
-    got = abi.points_of(dev.cpu().numpy().view(raw.dtype).reshape(raw.shape))
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), raw.nbytes) == 0
+    assert hip.hipMemcpy(dev, C.c_void_p(raw.ctypes.data), raw.nbytes, 1) == 0  # hipMemcpyHostToDevice
+    ctx_auto._check(ctx_auto.lib.mulls_motion_compensate(ctx_auto.h, dev, len(raw), abi.POINT_BYTES, abi.colmajor16(T), C.c_float(0.1)), "mulls_motion_compensate")
+    back = np.empty_like(raw)
+    assert hip.hipMemcpy(C.c_void_p(back.ctypes.data), dev, raw.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    assert hip.hipFree(dev) == 0
+    got = abi.points_of(back)
     assert all(np.array_equal(got[f], want[f]) for f in FIELDS)
     # a block belongs to the context that made it
     other = lib.Context(0)
