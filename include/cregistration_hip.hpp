@@ -634,8 +634,10 @@ inline bool voxel_downsample(const typename pcl::PointCloud<PointT>::Ptr &cloud_
 //     #ifdef MULLS_USE_HIP
 //         return lo::hip::extract_semantic_pts<PointT>(in_block, vf_downsample_resolution, gf_grid_resolution, ...);
 //     #endif
-// Not available and refused: semantic_assisted.  apply_roi_filtering is dead code upstream ("#if 0") and
-// ignored here too.  use_adpative_parameters runs upstream's update (:2416-2444) on the host; where upstream would divide by zero (no facade and
+// semantic_assisted (deprecated upstream, off in every shipped configuration; round 5): the pre-filter filter_with_dynamic_object_mask_pre (cfilter.hpp:2487-2504 —
+// Semantic-KITTI labels in the curvature field: moving objects, labels >= 250, and outliers, label 1, leave pc_raw) runs here on the host, in place on pc_raw as
+// upstream does, INSTEAD of the scanner filter (upstream's `else if`, :2331-2345); the post-filter filter_with_semantic_mask(in_block) is called with its default mask
+// "000000" (:2396), with which it touches nothing.  apply_roi_filtering is dead code upstream ("#if 0") and ignored here too.  use_adpative_parameters runs upstream's update (:2416-2444) on the host; where upstream would divide by zero (no facade and
 // no pillar point left) this throws instead.
 // One side effect is not reproduced: upstream's ground filter writes (0,0,1) normals and data[3] heights into the points of pc_down (= pc_raw)
 // it classifies; here pc_raw / pc_down / pc_sketch keep the scan's records (the clouds handed out carry those values).
@@ -657,7 +659,15 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 {
 	(void)extract_curb_or_not, (void)apply_roi_filtering, (void)roi_min_y, (void)roi_max_y;
 	if (semantic_assisted)
-		throw std::runtime_error("lo::hip::extract_semantic_pts: semantic masks are not part of this build");
+	{
+		// filter_with_dynamic_object_mask_pre(in_block->pc_raw), cfilter.hpp:2487-2504: the float comparisons as written there
+		typename pcl::PointCloud<PointT>::Ptr kept(new pcl::PointCloud<PointT>());
+		for (size_t i = 0; i < in_block->pc_raw->points.size(); i++)
+			if (in_block->pc_raw->points[i].curvature < 250 && in_block->pc_raw->points[i].curvature != 1)
+				kept->points.push_back(in_block->pc_raw->points[i]);
+		kept->points.swap(in_block->pc_raw->points);
+	}
+	const bool scanner_stage = apply_scanner_filter && !semantic_assisted; // upstream: `if (semantic_assisted) ... else if (apply_scanner_filter) scanner_filter(...)`
 	mulls_ctx *ctx = thread_context();
 	mulls_extract_params X;
 	mulls_extract_default_params(&X);
@@ -699,7 +709,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	K.roof_down_fixed_num = roof_down_fixed_num, K.unground_down_fixed_num = unground_down_fixed_num;
 	K.beam_height_max = beam_height_max, K.roof_height_min = roof_height_min, K.feature_pts_ratio_guess = feature_pts_ratio_guess;
 	K.rng_seed = feature_rng_seed()++;
-	X.apply_scanner_filter = apply_scanner_filter;
+	X.apply_scanner_filter = scanner_stage;
 	X.self_ring_radius = 1.75f; // :2340-2343
 	X.ghost_radius = 20.0f;
 	X.z_min = -approx_scanner_height - 4.0;
@@ -714,7 +724,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	uint32_t cap[MULLS_EX_COUNT], n_out[MULLS_EX_COUNT];
 	for (int k = 0; k < MULLS_EX_COUNT; k++)
 	{
-		const bool want = k == MULLS_EX_RAW ? apply_scanner_filter : k == MULLS_EX_DOWN ? voxels : true; // without the scanner filter pc_raw stays what it is, without voxels pc_down is pc_raw
+		const bool want = k == MULLS_EX_RAW ? scanner_stage : k == MULLS_EX_DOWN ? voxels : true; // without the scanner filter pc_raw stays what it is, without voxels pc_down is pc_raw
 		raw[k].resize(want ? (size_t)in.n * MULLS_POINT_BYTES : 0);
 		out[k] = want ? raw[k].data() : nullptr;
 		cap[k] = want ? in.n : 0;
@@ -722,7 +732,7 @@ inline bool extract_semantic_pts(cloudblock_Ptr in_block, float vf_downsample_re
 	const int rc = mulls_extract_features(ctx, in.pts, in.n, in.stride, &X, out, cap, n_out);
 	if (rc != MULLS_OK)
 		throw std::runtime_error(std::string("mulls_extract_features failed (") + std::to_string(rc) + "): " + mulls_last_error(ctx));
-	if (apply_scanner_filter)
+	if (scanner_stage)
 		take_cloud<PointT>(b.pc_raw, raw[MULLS_EX_RAW], n_out[MULLS_EX_RAW], false); // scanner_filter works on pc_raw itself
 	if (voxels)
 		take_cloud<PointT>(b.pc_down, raw[MULLS_EX_DOWN], n_out[MULLS_EX_DOWN], true); // `cloud_out->push_back(...)` (:147)

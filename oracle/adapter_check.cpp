@@ -52,9 +52,8 @@ template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
-	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
-	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
-	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }
+	// (the semantic-mask filters of extract_semantic_pts — filter_with_dynamic_object_mask_pre cfilter.hpp:2487-2504, filter_with_semantic_mask :2508-2609 — are
+	// among the cut lines since round 5)
 #include "cfilter_body.inc"
 };
 template <typename PointT>
@@ -172,26 +171,27 @@ int main(int argc, char **argv)
 		// the same chain through its one entry point, extract_semantic_pts, with the scanner filter on: the reference member vs the bridge, on
 		// cloudblocks; a second time with a voxel grid ahead of the ground filter, a high non-ground down-sampling rate and the adaptive parameter
 		// update (which then lowers that rate: fewer than 200 facade + pillar points come out)
-		for (int w = 0; w < 4; w++)
+		// ... and a third pair of runs with semantic_assisted (round 5): the label pre-filter in place of the scanner filter
+		for (int w = 0; w < 6; w++)
 		{
 			lo::cloudblock_Ptr blk(new lo::cloudblock_t());
 			*blk->pc_raw = *scan;
-			const bool second = w >= 2;
+			const bool second = w >= 2 && w < 4, semantic = w >= 4;
 			int gdr = 10, ndr = second ? 20 : 3;
 			const float vox = second ? 0.08f : 0.0f, thre_down = 0.75f;
 			if (w % 2 == 0)
 			{
 				lo::CFilter<Point_T> cf;
 				cf.extract_semantic_pts(blk, vox, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, thre_down, thre_down, false, 0, 15.0f, 0, 2.0f, second, true, false, 2, 8, 0, 2,
-										8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f, false, false, 0.0f, 0.0f);
+										8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f, semantic, false, 0.0f, 0.0f);
 			}
 			else
 				lo::hip::extract_semantic_pts<Point_T>(blk, vox, 2.0f, 0.25f, 1.2f, 2.0f, gdr, ndr, 1.0f, 50, 0.65f, 0.65f, 0.10f, thre_down, thre_down, false, 0, 15.0f, 0, 2.0f, second, true, false, 2,
 													   8, 0, 2, 8, 1, FLT_MAX, 0.94f, 0.17f, 0.98f, 0.34f, true, false, 500, 200, 800, 200, 200, 20000, FLT_MAX, 0.0f, 2.0f, -7.0f, 0.3f,
-													   false, false, 0.0f, 0.0f);
+													   semantic, false, 0.0f, 0.0f);
 			pcTPtr all[15] = {blk->pc_raw,	  blk->pc_down,	 blk->pc_sketch, blk->pc_ground,	  blk->pc_ground_down, blk->pc_unground,	blk->pc_pillar,	   blk->pc_beam,
 							  blk->pc_facade, blk->pc_roof, blk->pc_pillar_down, blk->pc_beam_down, blk->pc_facade_down, blk->pc_roof_down, blk->pc_vertex};
-			static const char *who[4] = {"reference_block", "hip_block", "reference_block_voxels", "hip_block_voxels"};
+			static const char *who[6] = {"reference_block", "hip_block", "reference_block_voxels", "hip_block_voxels", "reference_block_semantic", "hip_block_semantic"};
 			printf("{\"who\": \"%s\", \"down_feature_point_num\": %d, \"rates\": [%d, %d], \"sizes\": [", who[w], blk->down_feature_point_num, gdr, ndr);
 			for (int k = 0; k < 15; k++)
 				printf("%s%zu", k ? ", " : "", all[k]->points.size());

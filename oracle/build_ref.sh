@@ -57,6 +57,9 @@ extract cfilter.hpp 2038 2056 "bool estimate_ground_normal_by_ransac" cfilter_bo
 extract cfilter.hpp 2058 2290 "bool classify_nground_pts" cfilter_body.inc
 extract cfilter.hpp 2295 2413 "bool extract_semantic_pts" cfilter_body.inc
 extract cfilter.hpp 2416 2482 "void update_parameters_self_adaptive" cfilter_body.inc
+# the semantic-mask filters of extract_semantic_pts (semantic_assisted: Semantic-KITTI labels in the curvature field)
+extract cfilter.hpp 2487 2504 "bool filter_with_dynamic_object_mask_pre" cfilter_body.inc
+extract cfilter.hpp 2508 2609 "void filter_with_semantic_mask" cfilter_body.inc
 # pca.hpp: pca_feature_t and the neighbourhood PCA (get_pc_pca_feature x2, calculate_normal_inconsistency, get_pca_feature, assign_normal)
 extract pca.hpp 23 54 "struct eigenvalue_t" pca_types.inc
 extract pca.hpp 207 454 "// R - K neighborhood (without already built-kd tree)" pca_body.inc

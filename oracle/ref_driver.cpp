@@ -53,9 +53,8 @@ template <typename PointT>
 class CFilter : public CloudUtility<PointT>
 {
   public:
-	// semantic-mask filters of extract_semantic_pts (semantic_assisted, Semantic-KITTI labels in the curvature field): never taken
-	bool filter_with_dynamic_object_mask_pre(const typename pcl::PointCloud<PointT>::Ptr &) { std::abort(); }
-	bool filter_with_semantic_mask(lo::cloudblock_Ptr) { std::abort(); }
+	// (the semantic-mask filters of extract_semantic_pts — filter_with_dynamic_object_mask_pre cfilter.hpp:2487-2504, filter_with_semantic_mask :2508-2609 — are
+	// among the cut lines since round 5)
 #include "cfilter_body.inc" // (with estimate_ground_normal_by_ransac, cfilter.hpp:2038-2056)
 };
 

@@ -92,6 +92,11 @@ def test_adapter_feature_extraction_matches_reference_members():
     from test_classify import with_ego_and_ghost_points
 
     scan = with_ego_and_ghost_points(raw_scan(14, n_beams=48, n_az=1400))
+    # Semantic-KITTI labels in the curvature field (only the semantic_assisted runs read them; every run's clouds carry them along)
+    labels = np.array([0, 1, 10, 40, 44, 48, 50, 51, 71, 80, 99, 249, 250, 252, 255, 259], np.float32)
+    scan = scan.copy()
+    scan["curvature"] = labels[np.random.default_rng(21).integers(0, len(labels), len(scan))]
+    n_semantic_kept = int(((scan["curvature"] < 250) & (scan["curvature"] != 1)).sum())
     empty = np.zeros(0, abi.POINT_DTYPE)
     pair = abi.PairData([scan] + [empty] * 5, [empty] * 6)
     with tempfile.TemporaryDirectory() as d:
@@ -115,6 +120,13 @@ def test_adapter_feature_extraction_matches_reference_members():
     assert refv["sizes"][0] == refb["sizes"][0] and 1000 < refv["sizes"][1] < refv["sizes"][0]  # pc_raw as before, pc_down one point per voxel
     assert refv["rates"] == hipv["rates"] and refv["rates"][0] == 10 and 1 <= refv["rates"][1] < 20  # 20 - 200 / (facade_down + pillar_down)
     assert refb["rates"] == hipb["rates"] == [10, 3]
+    # ... and with semantic_assisted (round 5): the label pre-filter filter_with_dynamic_object_mask_pre in place of the scanner filter (upstream's `else if`),
+    # the reference's own lines against the bridge's host statement of them + the device chain
+    refs, hips = json.loads(out[6]), json.loads(out[7])
+    assert refs["who"] == "reference_block_semantic" and hips["who"] == "hip_block_semantic"
+    assert refs["sizes"] == hips["sizes"] and refs["sums"] == hips["sums"] and refs["down_feature_point_num"] == hips["down_feature_point_num"] > 0
+    assert refs["sizes"][0] == n_semantic_kept < len(scan) and refs["sizes"][1] == refs["sizes"][0]  # moving objects (>= 250) and outliers (1) left pc_raw; pc_down = pc_raw
+    assert sum(refs["sizes"][3:]) > 1000 and refs["sizes"] != refb["sizes"]  # (the underground ghost points stay without the scanner filter: little ground, as in the first run)
 
 
 def test_adapter_motion_compensation_matches_reference_members(pairs_small):
