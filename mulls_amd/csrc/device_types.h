@@ -202,6 +202,7 @@ struct RunParams
 	// k-candidate certificates (round 5).  A search leaves behind, next to the hint, the nearest targets its OTHER lanes saw (CandRec) and a bound on every
 	// target outside that set; a point whose hinted target fails the certificate evaluates the handful of candidates exactly — same distance expression,
 	// lowest index on ties — and is certified when the nearest of them beats that bound by the margin the plain certificate asks for.  kcert = 0: off.
+	// (The LDS tier is built without it by default — lds_tier.h: MULLS_LDS_KCERT.)
 	uint32_t kcert;
 	uint32_t cert_small; // LDS tier: a class cloud with more leftovers than this goes to the staged search (k_nn_lds); at most the leftover list's capacity
 	uint32_t kcert_min; // LDS tier: a leftover list gets the look only from this length on (a look is one chain of four round trips for the whole list,

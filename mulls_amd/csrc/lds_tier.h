@@ -225,6 +225,13 @@ __device__ __forceinline__ void take_pair(float da, uint32_t ia, float db, uint3
 // min_l ls_l away.  The bests of the other lanes are therefore a ready-made candidate set — no work per candidate, a few DPP moves per query:
 // the NO nearest of them (by key) go into the record, and b2 = min(min_l ls_l, the nearest lane best that did not fit) bounds every evaluated
 // target outside {the result, the record}.  (On 8 lanes that set is about as good as the true 3 nearest: profiles/r05_kcert_study.txt.)
+// The k-candidate certificates on the LDS tier are compiled OUT by default.  Measured (profiles/r05_experiments.txt item 6, 4096 pairs, search ms per step):
+// records kept + look 11.92, records kept without the look 12.03, neither 11.46 — keeping the records (lane_bests: ~70 VALU instructions per search and lane,
+// 24 M searches a step, half of them in the VALU-bound staged pass) costs 0.57 ms and the look returns 0.11.  The global-memory tier keeps them (+4 ... 8 % there).
+// -DMULLS_LDS_KCERT=1 builds the LDS tier with them (tools/build_variant.sh; same bits either way: tests/test_gpu_icp.py runs against MULLS_HIP_LIB).
+#ifndef MULLS_LDS_KCERT
+#define MULLS_LDS_KCERT 0
+#endif
 struct CandOut
 {
 	uint32_t cx, cy; // candidates besides the result: LDS tier 4 x uint16 (0xffff = none), global-memory tier 2 x uint32 (0xffffffff = none)
@@ -439,9 +446,14 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 	}
 	if (!(key_found(bk) && key_dist(bk) <= m * m))
 		sweep(key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r, false); // nothing within the first-probe radius: widen to the best distance, or to the rejection radius
+#if MULLS_LDS_KCERT
 	co = lane_bests<(int)MULLS_LDS_GROUP, true>(lane_k, lane_s);
 	if (sec == 0.0f)
 		co.b2 = 0.0f; // the standing result lies outside the last (clipped) sweep: nothing is claimed about the other targets
+#else
+	(void)lane_k, (void)lane_s;
+	co.cx = co.cy = 0xffffffffu, co.b2 = 0.0f;
+#endif
 }
 
 // what the search of one class cloud needs to know about its iteration
@@ -519,8 +531,12 @@ __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc
 	// hint and cost class of the next iteration; every target but the one found is at least min(second, radius swept) away
 	const float lb_new = fminf(sqrtf(sec), Rfin);
 	hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(lb_new));
+#if MULLS_LDS_KCERT
 	if (C.cand) // the other lanes' nearest targets, and how much farther than lb_new everything outside {result, candidates} lies (co.b2 >= sec)
 		C.cand[d.src_off + s] = make_uint4(co.cx, co.cy, __float_as_uint(fminf(sqrtf(co.b2), Rfin) - lb_new), C.epoch);
+#else
+	(void)co;
+#endif
 	if (matched)
 	{
 		if (C.dedup)
@@ -735,7 +751,7 @@ struct CertLds
 {
 	float4 uq[SMALL];
 	uint32_t us[SMALL];
-	static constexpr bool LOOK = SMALL >= 128; // lists of a few dozen entries (the resident loop, the small batches' one-launch search) never get the look: no room kept
+	static constexpr bool LOOK = MULLS_LDS_KCERT != 0 && SMALL >= 128; // lists of a few dozen entries (the resident loop, the small batches' one-launch search) never get the look: no room kept
 	float um[LOOK ? SMALL : 1];				   // how far this iteration's step moved the listed point (entries flagged MULLS_US_KCERT: the k-candidate certificate's look needs it)
 	uint32_t ucount, red[3 * 16];
 };
