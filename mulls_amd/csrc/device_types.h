@@ -25,7 +25,9 @@
 #define MULLS_CERT_SMALL 64u   // the device-resident loop searches up to this many uncertified points of a class cloud against the grid in global memory
 #define MULLS_CERT_SMALL_LOCKSTEP 512u // ... k_cert up to this many (four workgroups per CU hide the walks' latency: 64 -> 512 took 1.5 ms off a 4096-pair step, profiles/r03_sweeps.txt)
 #define MULLS_ICP_STATIC_LDS 9216 // LDS the device-resident loop keeps next to the dynamic block (pair state, class rows, ...; checked at its first launch)
+#ifndef MULLS_LDS_GROUP // (4u / 16u: A/B builds, tools/build_variant.sh)
 #define MULLS_LDS_GROUP 8u	   // lanes that cooperate on one query in the LDS grid tier (DPP reductions stay inside a 16-lane row)
+#endif
 #define MULLS_BIG_CLOUD 16384u // class clouds above this size (target or source) are cropped segment-wise (k_crop_big_*): one workgroup walking a 100 k-point
 							   // cloud alone took 290 us (profiles/r04_large_base.txt)
 #define MULLS_BIG_SRC_SIDE 0x100u // Job::cls flag in the segment tables: the segment belongs to the pair's SOURCE cloud of that class
