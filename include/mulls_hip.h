@@ -251,9 +251,7 @@ enum mulls_option
 											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits; -0.26 ms of a 17.8 ms
 											 step at 4096 pairs, profiles/r05_experiments.txt); 0 = always one workgroup per trip (k_accum).  Read when a batch is filled
 											 (the memo of the intensity weights is allocated with it) and at every launch */
-	MULLS_OPT_CERT_SMALL = 26,			  /* [512] LDS tier: a class cloud whose light pass leaves more points over than this is searched by the staged pass (k_nn_lds); the light pass's list holds
-											 512 (64 in the small batches' one-launch form): larger values change nothing */
-	MULLS_OPT_COUNT = 27
+	MULLS_OPT_COUNT = 26
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

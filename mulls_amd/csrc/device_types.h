@@ -206,7 +206,6 @@ struct RunParams
 	// lowest index on ties — and is certified when the nearest of them beats that bound by the margin the plain certificate asks for.  kcert = 0: off.
 	// (The LDS tier is built without it by default — lds_tier.h: MULLS_LDS_KCERT.)
 	uint32_t kcert;
-	uint32_t cert_small; // LDS tier: a class cloud with more leftovers than this goes to the staged search (k_nn_lds); at most the leftover list's capacity
 	uint32_t kcert_min; // LDS tier: a leftover list gets the look only from this length on (a look is one chain of four round trips for the whole list,
 						// a search round of 64 queries about as much: below a few rounds' worth the look costs what it saves)
 	uint4 *cand; // per source point: x, y = candidates besides the hinted target (LDS tier: 4 x uint16, 0xffff = none; global-memory tier: 2 x uint32,

@@ -1067,7 +1067,7 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 	uint32_t U = ucount;
 	if (kc && U >= rp.kcert_min && U <= (uint32_t)SMALL) // (a list that overflowed goes to the heavy pass, whose searches cost a tenth of a look)
 		U = kcert_list<BLK, W16, SMALL>(CL, rp, ps, C, d, U, nn_idx, nn_d2, hint2, W, winner, tpos, matched_cnt);
-	if (U > (rp.cert_small ? min((uint32_t)SMALL, rp.cert_small) : (uint32_t)SMALL)) // (rp.cert_small: the list length from which the staged search takes the cloud; 0 = the list's capacity)
+	if (U > (uint32_t)SMALL) // (a compile-time bound: the same test against a run-time option cost configs[0] 9 % of its search time, profiles/r05_experiments.txt item 5)
 		return false; // too many for the global-memory walk: the caller has the target cloud staged (lds_search_class), which counts the
 					  // matches certified here again from nn_idx; chunk-level jobs add theirs to the class counter there too
 	// the few leftovers against the grid where k_grid_build_sort left it (L2-resident): same sweeps, same keys
@@ -1288,7 +1288,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		atomicAdd(&rp.dbg_ticks[13], (unsigned long long)U0); // points the plain certificate left over ...
 		atomicAdd(&rp.dbg_ticks[7], (unsigned long long)U);	  // ... and what is searched (here or, beyond SMALL, by the heavy pass)
 	}
-	if (U > (rp.cert_small ? min((uint32_t)SMALL, rp.cert_small) : (uint32_t)SMALL)) // (rp.cert_small: the list length from which the staged search takes the cloud; 0 = the list's capacity)
+	if (U > (uint32_t)SMALL) // (a compile-time bound: the same test against a run-time option cost configs[0] 9 % of its search time, profiles/r05_experiments.txt item 5)
 	{
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
 #pragma unroll

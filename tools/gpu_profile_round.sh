@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# SKIP_PMC=1: without the counter passes (they hang now and then on this pool: 150 s each)
 # The round's judged profiles on the GPU box: tools/gpu_profile_round.sh <tag>   (outputs under gpurun_out/<tag>/; copy what is to be judged into profiles/).
 # Kernel statistics and counters are separate runs (gpurun refuses --pmc next to the hip / hsa trace domains).
 set -u
@@ -10,10 +11,8 @@ rm -rf /tmp/prof_stats
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- $CMD > $O/bench_under_profiler.json 2> $O/bench_under_profiler.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats.csv
 python tools/kernel_stats.py /tmp/prof_stats "rocprofv3 --kernel-trace --stats -- $CMD" > $O/kernel_stats.txt
-rm -rf /tmp/prof_pmc_3
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d /tmp/prof_pmc_3 -- $CMD > /dev/null 2> $O/pmc_3.err
-python tools/pmc_summary.py /tmp/prof_pmc_3 > $O/pmc_sq.txt
-bash tools/gpu_pmc_traffic.sh $T 4096 > /dev/null 2>&1
+# (SQ counters: tools/gpu_pmc_sq.sh, two counters per pass — passes of eight do not return on this pool)
+[ "${SKIP_PMC:-0}" = 1 ] || bash tools/gpu_pmc_traffic.sh $T 4096 > /dev/null 2>&1
 # --- configs[4] and configs[2]: kernel statistics of the bench command, FETCH / WRITE passes of the batch alone
 for c in 4 2; do
 	CMDC="python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-converging"
@@ -21,12 +20,14 @@ for c in 4 2; do
 	timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c$c -- $CMDC > $O/bench_cfg${c}_under_profiler.json 2> $O/bench_cfg${c}_under_profiler.err
 	python tools/kernel_stats.py /tmp/prof_c$c "rocprofv3 --kernel-trace --stats -- $CMDC" > $O/kernel_stats_bench_cfg$c.txt
 done
+if [ "${SKIP_PMC:-0}" != 1 ]; then
 i=0
 for cnt in FETCH_SIZE WRITE_SIZE; do
 	i=$((i + 1)); rm -rf /tmp/pmc_c4_$i
 	timeout 200 rocprofv3 --pmc $cnt --output-format csv -d /tmp/pmc_c4_$i -- python tools/gpu_large_bench.py cfg4 16 1 > $O/pmc_cfg4_run_$i.log 2>&1
 done
 python tools/pmc_summary.py /tmp/pmc_c4_1 /tmp/pmc_c4_2 > $O/pmc_traffic_cfg4.txt
+fi
 # --- the bench lines of every configuration
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 600 python bench.py --config 0 --no-cpu-baseline > $O/bench_cfg0.json 2> $O/bench_cfg0.err
