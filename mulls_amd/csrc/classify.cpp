@@ -163,6 +163,43 @@ struct KeyIdx
 	float key;
 	uint32_t idx;
 };
+// Rounds of a settle-until-nothing-is-undecided loop (the promotion of vertex candidates, the suppression rounds): launch(slot) runs one round that adds the points
+// it leaves undecided to round_cnt[slot].  A round over a settled state changes nothing, so rounds are launched in batches and the counters read once per batch — the
+// first batch as long as the previous call's loop turned out to be (+ 2: consecutive frames need about the same), further ones `step` rounds: one wait per loop instead
+// of one per `step` rounds (28 us each on the frame path).  All 64 counters come down, so the round that settled is known and the hint follows the data both ways.
+template <class Launch>
+int run_rounds(mulls_ctx *ctx, hipStream_t st, uint32_t *round_cnt, uint32_t step, uint32_t *hint, const Launch &launch, const char *what)
+{
+	uint32_t h[64];
+	const uint32_t first = std::min(32u, std::max(step, (*hint + 2u + 3u) & ~3u));
+	for (uint32_t round = 0;;)
+	{
+		const uint32_t lo = round, batch = round == 0 ? first : step;
+		for (uint32_t r = 0; r < batch; r++, round++)
+			launch(round & 63u);
+		HIPCHK(ctx, hipMemcpyAsync(h, round_cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		if (h[(round - 1u) & 63u] == 0)
+		{
+			uint32_t needed = round;
+			for (uint32_t r = lo; r < round; r++)
+				if (h[r & 63u] == 0)
+				{
+					needed = r + 1u;
+					break;
+				}
+			*hint = needed;
+			return MULLS_OK;
+		}
+		if ((round & 63u) == 0)
+			HIPCHK(ctx, hipMemsetAsync(round_cnt, 0, 64 * 4, st));
+		if (round > (1u << 22))
+		{
+			ctx->err = what;
+			return MULLS_E_HIP;
+		}
+	}
+}
 } // namespace
 
 extern "C"
@@ -308,23 +345,10 @@ extern "C"
 		launch_cl_label(st, A, Q);
 		if (Q.vertex_method == 2)
 		{
-			for (uint32_t round = 0;;)
-			{
-				for (int r = 0; r < 4; r++, round++)
-					launch_cl_promote_round(st, A, Q, round & 63u);
-				uint32_t left = 0;
-				HIPCHK(ctx, hipMemcpyAsync(&left, A.round_cnt + ((round - 1u) & 63u), 4, hipMemcpyDeviceToHost, st));
-				HIPCHK(ctx, hipStreamSynchronize(st));
-				if (left == 0)
-					break;
-				if ((round & 63u) == 0)
-					HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
-				if (round > (1u << 22))
-				{
-					ctx->err = "mulls_classify_nground: the promotion loop did not settle";
-					return MULLS_E_HIP;
-				}
-			}
+			const int rcr = run_rounds(ctx, st, A.round_cnt, 4u, &ctx->cl_rounds_hint[0], [&](uint32_t slot) { launch_cl_promote_round(st, A, Q, slot); },
+									   "mulls_classify_nground: the promotion loop did not settle");
+			if (rcr != MULLS_OK)
+				return rcr;
 		}
 		launch_cl_encode_and_masks(st, A, Q);
 		// stable compactions: the class clouds (first-pass members, then promoted ones), the key points, the *_down clouds of sharpen_with_nms = 0
@@ -395,12 +419,15 @@ extern "C"
 			}
 			if (any)
 			{
-				std::vector<float> keys((size_t)n * 4);
+				// keys down, visiting orders up: through the context's pinned scratch (a pageable vector is staged by the runtime, and 2 MB of it are zero-filled per frame)
+				if (grow_pinned(ctx, &ctx->cl_pin, &ctx->cl_pin_cap, (size_t)n * 32, hipHostMallocDefault) != MULLS_OK)
+					return MULLS_E_HIP;
+				float *keys = reinterpret_cast<float *>(ctx->cl_pin);
+				uint32_t *perm = reinterpret_cast<uint32_t *>(ctx->cl_pin + (size_t)n * 16);
 				for (int c = 0; c < 4; c++)
 					if (fixed_num[c] > 0 && ncls[c] >= 10)
-						HIPCHK(ctx, hipMemcpyAsync(keys.data() + (size_t)c * n, L.keys + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyDeviceToHost, st));
+						HIPCHK(ctx, hipMemcpyAsync(keys + (size_t)c * n, L.keys + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyDeviceToHost, st));
 				HIPCHK(ctx, hipStreamSynchronize(st));
-				std::vector<uint32_t> perm((size_t)n * 4);
 				// the four classes' visiting orders, one host thread each (the sorts are the frame path's longest host step)
 				// (the context's sleeping thread pool, not an OpenMP team whose threads go on spinning into the kernels that follow: HostPool, ctx.h)
 				const std::function<void(long)> sort_class = [&](long c) {
@@ -419,7 +446,7 @@ extern "C"
 				{
 					if (!(fixed_num[c] > 0 && ncls[c] >= 10))
 						continue;
-					HIPCHK(ctx, hipMemcpyAsync(L.perm + (size_t)c * n, perm.data() + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyHostToDevice, st));
+					HIPCHK(ctx, hipMemcpyAsync(L.perm + (size_t)c * n, perm + (size_t)c * n, (size_t)ncls[c] * 4, hipMemcpyHostToDevice, st));
 					launch_cl_gather(st, cls[c], L.perm + (size_t)c * n, L.cls_sorted[c], ncls[c]);
 					cls[c] = L.cls_sorted[c]; // std::sort works on cloud_in itself: the class cloud stays in this order
 					na.recs[c] = L.cls_sorted[c];
@@ -431,26 +458,11 @@ extern "C"
 					na.wcur[c] = L.nms_wcur[c];
 				}
 				na.pool = L.nms_pool, na.pool_used = L.nms_pool_used, na.pool_cap = L.nms_pool_cap;
-				HIPCHK(ctx, hipMemsetAsync(L.nms_pool_used, 0, 8, st));
-				launch_cl_nms_lists(st, na);
-				HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
-				for (uint32_t round = 0;;)
-				{
-					for (int r = 0; r < 8; r++, round++)
-						launch_cl_nms_round(st, na, A.round_cnt + (round & 63u));
-					uint32_t left = 0;
-					HIPCHK(ctx, hipMemcpyAsync(&left, A.round_cnt + ((round - 1u) & 63u), 4, hipMemcpyDeviceToHost, st));
-					HIPCHK(ctx, hipStreamSynchronize(st));
-					if (left == 0)
-						break;
-					if ((round & 63u) == 0)
-						HIPCHK(ctx, hipMemsetAsync(A.round_cnt, 0, 64 * 4, st));
-					if (round > (1u << 22))
-					{
-						ctx->err = "mulls_classify_nground: the suppression rounds did not settle";
-						return MULLS_E_HIP;
-					}
-				}
+				launch_cl_nms_lists(st, na, A.round_cnt); // (zeroes the pool cursor and the round counters with its own arrays)
+				const int rcn = run_rounds(ctx, st, A.round_cnt, 8u, &ctx->cl_rounds_hint[1], [&](uint32_t slot) { launch_cl_nms_round(st, na, A.round_cnt + slot); },
+										   "mulls_classify_nground: the suppression rounds did not settle");
+				if (rcn != MULLS_OK)
+					return rcn;
 				std::memset(&ca, 0, sizeof(ca));
 				for (int c = 0; c < 4; c++)
 				{

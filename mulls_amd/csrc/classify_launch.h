@@ -77,7 +77,7 @@ struct ClNmsArgs
 	uint32_t pool_cap;
 	float r2;
 };
-void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a);
+void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt); // round_cnt: 64 counters, zeroed here with the lists' own arrays
 void launch_cl_nms_round(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt); // *round_cnt += points still undecided
 // keys[i] = normal[3] of record i
 void launch_cl_keys(hipStream_t st, const float4 *recs, uint32_t n, float *keys);

@@ -73,6 +73,9 @@ struct mulls_ctx
 	double opt[MULLS_OPT_COUNT] = {}; // enum mulls_option (mulls_set_option; preset from the environment by mulls_create)
 	unsigned char *mail_h = nullptr; // host-mapped mailbox of the small-table uploads (SegCopier, batch.h): written by the host, read by k_copy_segs
 	size_t mail_cap = 0;
+	unsigned char *cl_pin = nullptr, *scan_pin = nullptr; // pinned host scratch of the feature stage: the visiting orders' keys and permutations; the raw scan on its way up
+	size_t cl_pin_cap = 0, scan_pin_cap = 0;
+	uint32_t cl_rounds_hint[2] = {4, 8}; // rounds the promotion loop / the suppression rounds needed in the previous call: this call's first batch
 	int nn_mode = 0;   // 0 auto, 1 LDS-tiled brute force, 2 uniform grid in global memory, 3 uniform grid staged in LDS
 };
 

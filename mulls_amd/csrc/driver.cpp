@@ -248,6 +248,10 @@ extern "C"
 			mulls_batch_destroy(ctx, ctx->scratch);
 		if (ctx->mail_h)
 			(void)hipHostFree(ctx->mail_h);
+		if (ctx->cl_pin)
+			(void)hipHostFree(ctx->cl_pin);
+		if (ctx->scan_pin)
+			(void)hipHostFree(ctx->scan_pin);
 		while (!ctx->maps.empty()) // local maps die with their context (mulls_map_destroy unregisters them)
 			mulls_map_destroy(ctx, ctx->maps.back());
 		while (!ctx->blocks.empty()) // ... and so do feature blocks

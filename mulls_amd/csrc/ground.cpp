@@ -439,7 +439,31 @@ extern "C"
 		// two scan-sized buffers (base, alt): every stage ahead of the ground filter reads one and writes the other
 		unsigned char *cur = (prefilter != voxels) ? base + a.o_alt : base, *other = (prefilter != voxels) ? base : base + a.o_alt;
 		if (stride == MULLS_POINT_BYTES)
-			HIPCHK(ctx, hipMemcpyAsync(cur, scan, rec_in, hipMemcpyHostToDevice, st));
+		{
+			// A pageable scan of a few MB is pinned and unpinned by the runtime around its copy (0.15 ms in front of a 0.1 ms transfer on the frame path): the
+			// process's host pool moves it into the context's pinned scratch instead, and the transfer starts from there.  A caller's pinned buffer goes up as it is.
+			const void *up = scan;
+			hipPointerAttribute_t at;
+			const bool pinned = hipPointerGetAttributes(&at, scan) == hipSuccess && at.type == hipMemoryTypeHost;
+			if (!pinned)
+				(void)hipGetLastError(); // (an unregistered host pointer is "invalid value" to the query: not an error of this call)
+			if (!pinned && rec_in >= ((size_t)1 << 20))
+			{
+				if (grow_pinned(ctx, &ctx->scan_pin, &ctx->scan_pin_cap, rec_in, hipHostMallocDefault) != MULLS_OK)
+					return MULLS_E_HIP;
+				const size_t chunk = (size_t)256 << 10;
+				const long nchunk = (long)((rec_in + chunk - 1) / chunk);
+				unsigned char *dst = ctx->scan_pin;
+				const unsigned char *srcb = static_cast<const unsigned char *>(scan);
+				const std::function<void(long)> move = [&](long k) {
+					const size_t o = (size_t)k * chunk;
+					std::memcpy(dst + o, srcb + o, std::min(chunk, rec_in - o));
+				};
+				shared_host_pool().parallel_for(0, nchunk, 1, move);
+				up = dst;
+			}
+			HIPCHK(ctx, hipMemcpyAsync(cur, up, rec_in, hipMemcpyHostToDevice, st));
+		}
 		else
 			HIPCHK(ctx, hipMemcpy2DAsync(cur, MULLS_POINT_BYTES, scan, stride, MULLS_POINT_BYTES, n_in, hipMemcpyHostToDevice, st));
 		uint32_t n = n_in;

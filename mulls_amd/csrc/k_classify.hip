@@ -649,6 +649,23 @@ __global__ __launch_bounds__(256) void k_cl_nms_lists(ClNmsArgs a)
 // the points whose earlier neighbours did not fit the fixed list (dozens of points within a quarter of the PCA radius) take cnt entries of a
 // shared pool and the tile pairs are walked once more for them; only a cloud that exhausts the pool (pathological: everything within the
 // radius of everything) leaves points to the direct scan of k_cl_nms_round
+// before the lists: every point undecided, no earlier neighbours counted, the pool empty, the round counters zero (one launch instead of a fill command per array)
+__global__ __launch_bounds__(256) void k_cl_nms_init(ClNmsArgs a, uint32_t *round_cnt)
+{
+	const uint32_t c = blockIdx.y, n = a.n[c], p = blockIdx.x * 256u + threadIdx.x;
+	if (c == 0 && blockIdx.x == 0)
+	{
+		if (threadIdx.x < 64u)
+			round_cnt[threadIdx.x] = 0u;
+		if (threadIdx.x == 64u)
+			*a.pool_used = 0ull;
+	}
+	if (p < n)
+	{
+		a.cnt[c][p] = 0u;
+		a.keep[c][p] = 2;
+	}
+}
 __global__ __launch_bounds__(256) void k_cl_nms_reserve(ClNmsArgs a)
 {
 	const uint32_t c = blockIdx.y, n = a.n[c], p = blockIdx.x * 256u + threadIdx.x;
@@ -819,18 +836,12 @@ void launch_cl_encode_and_masks(hipStream_t st, const ClArrays &A, const ClParam
 {
 	hipLaunchKernelGGL(k_cl_encode, dim3((P.n + 255u) / 256u), dim3(256), 0, st, A, P);
 }
-void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a)
+void launch_cl_nms_lists(hipStream_t st, const ClNmsArgs &a, uint32_t *round_cnt)
 {
 	uint32_t nmax = 0;
 	for (int c = 0; c < 4; c++)
-	{
 		nmax = max(nmax, a.n[c]);
-		if (a.n[c])
-		{
-			(void)hipMemsetAsync(a.cnt[c], 0, (size_t)a.n[c] * 4, st);
-			(void)hipMemsetAsync(a.keep[c], 2, a.n[c], st); // every point undecided
-		}
-	}
+	hipLaunchKernelGGL(k_cl_nms_init, dim3(nmax ? (nmax + 255u) / 256u : 1u, 4), dim3(256), 0, st, a, round_cnt);
 	if (nmax)
 	{
 		const uint32_t nb = (nmax + 255u) / 256u;
