@@ -444,10 +444,12 @@ extern "C"
 			// process's host pool moves it into the context's pinned scratch instead, and the transfer starts from there.  A caller's pinned buffer goes up as it is.
 			const void *up = scan;
 			hipPointerAttribute_t at;
-			const bool pinned = hipPointerGetAttributes(&at, scan) == hipSuccess && at.type == hipMemoryTypeHost;
-			if (!pinned)
-				(void)hipGetLastError(); // (an unregistered host pointer is "invalid value" to the query: not an error of this call)
-			if (!pinned && rec_in >= ((size_t)1 << 20))
+			// (an unregistered host pointer is "invalid value" to the query, or of type "unregistered": only that is staged — pinned, managed or device memory goes as it is)
+			const hipError_t qe = hipPointerGetAttributes(&at, scan);
+			const bool pageable = qe != hipSuccess || at.type == hipMemoryTypeUnregistered;
+			if (qe != hipSuccess)
+				(void)hipGetLastError(); // not an error of this call
+			if (pageable && rec_in >= ((size_t)1 << 20))
 			{
 				if (grow_pinned(ctx, &ctx->scan_pin, &ctx->scan_pin_cap, rec_in, hipHostMallocDefault) != MULLS_OK)
 					return MULLS_E_HIP;

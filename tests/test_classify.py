@@ -458,6 +458,42 @@ def test_extract_features_equals_the_stages(ctx_auto):
 
 
 @pytest.mark.gpu
+def test_extract_features_from_a_pinned_scan(ctx_auto):
+    """A pageable scan of a megabyte or more goes up through the context's pinned scratch (the process's host pool moves it there); a scan the caller
+    has pinned itself (hipHostMalloc) goes up as it is.  Same clouds byte for byte, call after call."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    name, scan, X = [c for c in extract_cases() if len(c[1]) * abi.POINT_BYTES >= (1 << 20)][0]
+    raw = abi.records(scan)
+    want = ctx_auto.extract_features(scan, X)  # pageable numpy memory: staged
+    pin = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(pin), raw.nbytes, 0) == 0
+    try:
+        C.memmove(pin, raw.ctypes.data, raw.nbytes)
+        n = len(raw)
+        outs = [np.zeros((n, abi.POINT_BYTES), np.uint8) for _ in range(abi.EX_COUNT)]
+        out_p = (C.c_void_p * abi.EX_COUNT)(*[o.ctypes.data for o in outs])
+        cap = (C.c_uint32 * abi.EX_COUNT)(*([n] * abi.EX_COUNT))
+        nout = (C.c_uint32 * abi.EX_COUNT)()
+        for _ in range(2):
+            ctx_auto._check(ctx_auto.lib.mulls_extract_features(ctx_auto.h, pin, n, abi.POINT_BYTES, C.byref(X), out_p, cap, nout), "mulls_extract_features")
+            for k in range(abi.EX_COUNT):
+                if k == abi.EX_RAW and not (X.apply_scanner_filter or X.apply_dist_filter):
+                    continue  # (lib.extract_features hands the input back for these)
+                if k == abi.EX_DOWN and X.vf_downsample_resolution < 0.001:
+                    continue
+                assert nout[k] == len(want[k]), (name, k)
+                assert np.array_equal(outs[k][: nout[k]], want[k]), (name, k)
+        again = ctx_auto.extract_features(scan, X)
+        assert all(np.array_equal(a, b) for a, b in zip(want, again))
+    finally:
+        assert hip.hipHostFree(pin) == 0
+
+
+@pytest.mark.gpu
 def test_device_voxel_downsample(ctx_auto):
     """mulls_voxel_downsample against the oracle byte for byte: voxel sizes from "nearly every point its own voxel" to a handful of voxels (long
     runs of equal indices in the sort), a cloud with one point, an empty one, a stride with padding, truncation, and the refusals."""
