@@ -469,10 +469,11 @@ struct ClassCtx
 __device__ __forceinline__ ClassCtx class_ctx(const RunParams &rp, const PairState &ps, const GridDesc &g, int cls, uint32_t alive_cur, bool called)
 {
 	ClassCtx C;
-	C.r = 2.5f * ps.thr[cls];
-	const double maxd = (double)C.r;
-	C.max_dist_sqr = maxd * maxd;
-	C.m = fminf(C.r, 0.999f * g.h - 2e-4f); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
+	// (wave-uniform values a VALU computed sit in VGPRs — two for the double — for the whole kernel; k_cert<512> has 64 and spilled this one: read back into SGPRs)
+	C.r = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(2.5f * ps.thr[cls])));
+	const double maxd = (double)C.r, md2 = maxd * maxd;
+	C.max_dist_sqr = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(md2)), __builtin_amdgcn_readfirstlane(__double2loint(md2)));
+	C.m = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(fminf(C.r, 0.999f * g.h - 2e-4f)))); // first-probe radius: its margin-inflated cube spans at most 3 cells per axis
 	C.gate = alive_cur >= 500u;
 	C.dedup = rp.lds_dedup != 0u && called && C.gate;
 	C.key_hi = (unsigned long long)(0xffffffffu - (rp.tick_base + (uint32_t)ps.iter)) << 32;
@@ -1121,11 +1122,13 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 	const bool kc = CertLds<SMALL>::LOOK && rp.kcert != 0u && have_prev && C.cand != nullptr; // (uniform)
 	const uint32_t q_end = src_n;		// class-level job: job.start == 0, job.count >= src_n
 	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
+	// (t_prev is updated by every lane: a value only lane 0 writes is divergent, lives in two VGPRs for the whole kernel and was spilled to scratch in k_cert<512>)
 #define FLAT_TICK(k)                                                  \
-	if (rp.dbg_ticks && threadIdx.x == 0)                             \
+	if (rp.dbg_ticks)                                                 \
 	{                                                                 \
 		const unsigned long long now_ = wall_clock64();               \
-		atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);                   \
+		if (threadIdx.x == 0)                                         \
+			atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);               \
 		t_prev = now_;                                                \
 	}
 
@@ -1470,10 +1473,11 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 	// diagnostics (MULLS_OPT_DEBUG_STOP = 20): phase clocks of the heavy pass, summed over its class clouds (rp.dbg_ticks[8..12])
 	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
 #define HEAVY_TICK(k)                                                 \
-	if (rp.dbg_ticks && threadIdx.x == 0)                             \
+	if (rp.dbg_ticks)                                                 \
 	{                                                                 \
 		const unsigned long long now_ = wall_clock64();               \
-		atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);                   \
+		if (threadIdx.x == 0)                                         \
+			atomicAdd(&rp.dbg_ticks[k], now_ - t_prev);               \
 		t_prev = now_;                                                \
 	}
 	float4 *qpos = Y.qpos;
