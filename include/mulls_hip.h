@@ -251,7 +251,11 @@ enum mulls_option
 											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits; -0.26 ms of a 17.8 ms
 											 step at 4096 pairs, profiles/r05_experiments.txt); 0 = always one workgroup per trip (k_accum).  Read when a batch is filled
 											 (the memo of the intensity weights is allocated with it) and at every launch */
-	MULLS_OPT_COUNT = 26
+	MULLS_OPT_FIRST_DIRECT = 26,		  /* [1] LDS tier, lock-step loop: the setup applies iteration 0's rigid step (the identity) where it writes the cropped source clouds, and
+											 iteration 0 runs no light pass — without hints it could only list every point and hand the class clouds over, or search a small
+											 cloud unhinted against the grid in global memory: every called class cloud goes straight to the staged search.  0 = light pass
+											 first, as in every other iteration.  Same bits */
+	MULLS_OPT_COUNT = 27
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

@@ -171,7 +171,8 @@ template <class Launch>
 int run_rounds(mulls_ctx *ctx, hipStream_t st, uint32_t *round_cnt, uint32_t step, uint32_t *hint, const Launch &launch, const char *what)
 {
 	uint32_t h[64];
-	const uint32_t first = std::min(32u, std::max(step, (*hint + 2u + 3u) & ~3u));
+	// a multiple of `step` (4 or 8; 32 is one of both), so that `round` stays one and the reset below meets every multiple of 64
+	const uint32_t first = std::min(32u, std::max(step, (*hint + 2u + step - 1u) / step * step));
 	for (uint32_t round = 0;;)
 	{
 		const uint32_t lo = round, batch = round == 0 ? first : step;

@@ -77,6 +77,21 @@ __device__ __forceinline__ void load_staged(const float4 *__restrict__ stage, ui
 		nrm = make_float4(b.x, b.y, b.z, c.y);
 	}
 }
+// The rigid step of iteration 0 — TempTran is the identity there (cregistration.hpp:1131, :1260) — as pcl::transformPointCloudWithNormals<PointT,double>
+// evaluates it: the search kernels' own expression (((T0 x + T1 y) + T2 z) + T3, double math, float store) with the identity's entries.  Not a no-op bit for
+// bit (-0.0 becomes +0.0, a non-finite coordinate spreads), but idempotent on finite coordinates (non-finite input is unsupported: DESIGN.md section 2):
+// the setup applies it where it writes the cropped source cloud, so that iteration 0 may go straight to the staged search (k_nn_lds `first`) — and a
+// kernel that applies it again at iteration 0 changes nothing.
+__device__ __forceinline__ void identity_step(float4 &p, float4 &n)
+{
+	const double x = p.x, y = p.y, z = p.z, nx = n.x, ny = n.y, nz = n.z;
+	p.x = (float)(1.0 * x + 0.0 * y + 0.0 * z + 0.0);
+	p.y = (float)(0.0 * x + 1.0 * y + 0.0 * z + 0.0);
+	p.z = (float)(0.0 * x + 0.0 * y + 1.0 * z + 0.0);
+	n.x = (float)(1.0 * nx + 0.0 * ny + 0.0 * nz);
+	n.y = (float)(0.0 * nx + 1.0 * ny + 0.0 * nz);
+	n.z = (float)(0.0 * nx + 0.0 * ny + 1.0 * nz);
+}
 __device__ __forceinline__ float4 load_staged_pos(const float4 *__restrict__ stage, uint32_t off, uint32_t fmt, uint32_t i)
 {
 	return fmt == MULLS_STAGE_AOS48 ? stage[(size_t)off + (size_t)i * 3] : stage[(size_t)off + i]; // (.w: data[3] or the intensity — callers read x y z)

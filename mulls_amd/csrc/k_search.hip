@@ -241,6 +241,18 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_filter(const Job *__restrict__ 
 }
 
 
+// Iteration 0 of a class-level job (`first`: the host's word that this launch set is the run's first and that the setup has applied the iteration's rigid step,
+// identity_step).  No point has a hint, so the light pass would list every live point and hand the class cloud to the staged search after one walk's worth
+// of loads and stores (k_cert 680 - 710 us of a 4096-pair launch, 290 us once everything certifies) — or, up to its own search budget of points, search them
+// all unhinted against the grid in global memory, seven rounds of dependent gathers for a 400-point pillar cloud (470 us of a launch for those alone).  Every
+// called class cloud therefore skips the light pass in iteration 0: lds_search_class(first) reads the flags and positions the setup wrote and searches every
+// live point against the staged cloud.  A class that sits the iteration out has nothing to do (its points do not move; it is never called later: its sizes
+// only shrink).
+__device__ __forceinline__ bool first_goes_direct(const RunParams &rp, const CloudDesc &d, int cls)
+{
+	return class_called(rp, d, cls);
+}
+
 // One class-cloud job of the light pass: the one-pass walk for a whole class cloud that fits the lanes' registers (cert_class_flat), the general walk for
 // chunk-level jobs, larger clouds and classes that sit the iteration out.  Returns (to every lane) false when the class cloud needs the heavy pass.
 template <int BLK, int SMALL, bool PARK = false>
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restri
 															  const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
 															  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner,
 															  const float4 *__restrict__ tnrm, int32_t *__restrict__ match, float *__restrict__ wd,
-															  const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
+															  const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap, uint32_t first)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const Job job = cjobs[blockIdx.x];
@@ -304,12 +316,16 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restri
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	__shared__ CertLds<MULLS_CERT_SMALL> s_cert; // (the heavy pass follows in this very workgroup: a small leftover budget, and the LDS for the staged cloud)
-	if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd,
-								   tpos, nn_hint, mq))
-		return;
-	__syncthreads(); // the light pass's LDS is free
+	const bool direct = first && first_goes_direct(rp, d, job.cls); // (uniform) iteration 0: straight to the staged search
+	if (!direct)
+	{
+		if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match,
+														wd, tpos, nn_hint, mq))
+			return;
+		__syncthreads(); // the light pass's LDS is free
+	}
 	lds_search_class(rp, ps, job, d, g, lds_layout(lds_raw, cap, rp.grid_maxcells), lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match,
-					 wd, tpos, nn_hint, mq);
+					 wd, tpos, nn_hint, mq, direct);
 }
 
 // A small MIXED batch (a scan against a local map whose ground class outgrew the LDS tier): the class clouds of both tiers in ONE launch.  Workgroups
@@ -322,7 +338,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_mixed(uint32_t n_lds, 
 																 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf, const uint32_t *__restrict__ cs,
 																 const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 																 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
-																 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap)
+																 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq, uint32_t cap,
+																 uint32_t first)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	if (blockIdx.x < n_lds)
@@ -334,12 +351,16 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_mixed(uint32_t n_lds, 
 		CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 		const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 		__shared__ CertLds<MULLS_CERT_SMALL> s_cert;
-		if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
-														   match, wd, tpos, nn_hint, mq))
-			return;
-		__syncthreads(); // the light pass's LDS is free
+		const bool direct = first && first_goes_direct(rp, d, job.cls); // (uniform) iteration 0: straight to the staged search
+		if (!direct)
+		{
+			if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
+															match, wd, tpos, nn_hint, mq))
+				return;
+			__syncthreads(); // the light pass's LDS is free
+		}
 		lds_search_class(rp, ps, job, d, g, lds_layout(lds_raw, cap, rp.grid_maxcells), lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos,
-						 nn_hint, mq);
+						 nn_hint, mq, direct);
 		return;
 	}
 	if (threadIdx.x >= MULLS_BIG_BLOCK)
@@ -381,13 +402,14 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 															 uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 															 unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
 															 float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq,
-															 uint32_t cap, const uint32_t *__restrict__ wl, uint32_t *__restrict__ wl_ctr, uint32_t parity)
+															 uint32_t cap, const uint32_t *__restrict__ wl, uint32_t *__restrict__ wl_ctr, uint32_t parity, uint32_t first_njobs)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 	const LdsLayout Y = lds_layout(lds_raw, cap, rp.grid_maxcells);
 
-	// persistent workgroup: class clouds come from the queue k_cert filled (complete before this kernel starts)
-	const uint32_t n_queued = wl_ctr[2u * parity];
+	// persistent workgroup: class clouds come from the queue k_cert filled (complete before this kernel starts) — or, iteration 0 (first_njobs != 0: the
+	// table's length), straight from the job table: no light pass ran (first_goes_direct)
+	const uint32_t n_queued = first_njobs ? first_njobs : wl_ctr[2u * parity];
 	for (;;)
 	{
 		__syncthreads(); // the previous class cloud's LDS contents have been consumed
@@ -397,9 +419,12 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_nn_lds(const Job *__restric
 		const uint32_t ticket = Y.HIST[65];
 		if (ticket >= n_queued)
 			return;
-		const Job job = cjobs[wl[ticket]];
-		lds_search_class(rp, states[job.pair], job, descs[job.pair * MULLS_NC + job.cls], grids[job.pair * MULLS_NC + job.cls], Y, lds_raw, spos, snrm,
-						 cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
+		const Job job = cjobs[first_njobs ? ticket : wl[ticket]];
+		CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
+		if (first_njobs && !(states[job.pair].active && first_goes_direct(rp, d, job.cls)))
+			continue;
+		lds_search_class(rp, states[job.pair], job, d, grids[job.pair * MULLS_NC + job.cls], Y, lds_raw, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
+						 match, wd, tpos, nn_hint, mq, first_njobs != 0u);
 	}
 }
 
@@ -554,8 +579,10 @@ size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,
 				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells,
-				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity)
+				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity, bool first)
 {
+	// first: the run's iteration 0 with the rigid step applied by the setup (identity_step; class-level jobs, rp.lds_dedup, no normal shooting: the caller's
+	// conditions) — every called class cloud goes straight to the staged search (first_goes_direct)
 	// per device (launch.h: DevLaunch): k_nn_lds may take the whole LDS; dyn_max[0] = the dynamic LDS k_cert_nn can have next to its static block
 	const DevLaunch D = dev_launch<0>([](DevLaunch &d) {
 		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_nn_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -582,10 +609,12 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	{
 		// light and heavy pass in one launch
 		hipLaunchKernelGGL(k_cert_nn, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm, grids, cell_start,
-						   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap);
+						   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, first ? 1u : 0u);
 		return 0;
 	}
-	if (njobs <= 2u * n_cu)
+	if (first)
+		; // no light pass in iteration 0 (first_goes_direct; the next iteration's queue counters are as prepare_run cleared them)
+	else if (njobs <= 2u * n_cu)
 		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
 						   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	else
@@ -593,7 +622,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	// one workgroup per CU is all the LDS allows: they take the queued class clouds by ticket
 	hipLaunchKernelGGL(k_nn_lds, dim3(njobs < n_cu ? njobs : n_cu), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm,
-					   grids, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, wl, wl_ctr, parity & 1u);
+					   grids, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, wl, wl_ctr, parity & 1u, first ? njobs : 0u);
 	return 0;
 }
 
@@ -601,7 +630,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states,
 					  const RunParams &rp, float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const unsigned long long *bm, const uint32_t *pf,
 					  const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match,
-					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells)
+					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells, bool first)
 {
 	const DevLaunch D = dev_launch<1>([](DevLaunch &d) { // per device (launch.h): the dynamic LDS k_cert_mixed can have next to its static block, the CU count
 		hipFuncAttributes fa;
@@ -629,7 +658,7 @@ int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t
 	if (n_lds + n_big * split > n_cu || dyn > dyn_max)
 		return 0;
 	hipLaunchKernelGGL(k_cert_mixed, dim3(n_lds + n_big * split), dim3(MULLS_LDS_BLOCK), dyn, st, n_lds, cjobs, bjobs, split, descs, states, rp, spos, snrm, grids, cell_start, bm, pf, cs,
-					   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap);
+					   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, first ? 1u : 0u);
 	return 1;
 }
 

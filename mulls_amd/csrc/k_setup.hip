@@ -197,6 +197,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 			}
 			else
 			{
+				identity_step(p, q); // iteration 0's rigid step (TempTran = I), so that its search may start from these records (device_util.h)
 				spos[dst] = p;
 				snrm[dst] = q;
 				flag[dst] = MULLS_F_ALIVE;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_scatter(const Job *__r
 		if (keep && src_side)
 		{
 			const uint32_t dst = d.src_off + running + wbase + before;
+			identity_step(p, q); // (as k_crop)
 			spos[dst] = p;
 			snrm[dst] = q;
 			flag[dst] = MULLS_F_ALIVE;

@@ -1468,8 +1468,11 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 												  const float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
 												  const float4 *__restrict__ tsorted, uint8_t *flag, int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2,
 												  unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm, int32_t *__restrict__ match,
-												  float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq)
+												  float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint, float4 *__restrict__ mq,
+												  bool first = false)
 {
+	// first (uniform): iteration 0 without a light pass in front — the setup has applied the iteration's rigid step (identity_step), no point has a hint or a
+	// correspondence, so every live point is a query of the whole rejection ball and nothing of nn_idx / nn_d2 / the hint records is read
 	// diagnostics (MULLS_OPT_DEBUG_STOP = 20): phase clocks of the heavy pass, summed over its class clouds (rp.dbg_ticks[8..12])
 	unsigned long long t_prev = rp.dbg_ticks ? wall_clock64() : 0ull;
 #define HEAVY_TICK(k)                                                 \
@@ -1507,10 +1510,15 @@ __device__ __forceinline__ void lds_search_class(const RunParams &rp, const Pair
 		if (chunk < q_end && s < min(q_end, chunk + q_step))
 		{
 			pf_f = flag[gi];
-			pf_i = nn_idx[gi];
 			pf_p = spos[gi];
-			pf_w = nn_d2[gi];
-			pf_hv = (uint32_t)hint2[gi].x;
+			if (first)
+				pf_i = MULLS_NEEDS_SEARCH, pf_w = __builtin_inff(), pf_hv = 0u;
+			else
+			{
+				pf_i = nn_idx[gi];
+				pf_w = nn_d2[gi];
+				pf_hv = (uint32_t)hint2[gi].x;
+			}
 		}
 	};
 	prefetch(job.start);

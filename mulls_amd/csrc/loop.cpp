@@ -222,13 +222,16 @@ RUN_ALIASES
 	// a small mixed batch: both tiers' class clouds in one launch
 	const uint32_t big_n = early ? L.ejob_n : L.bjob_n;
 	const Job *big_jobs = early ? B->ejobs + L.ejob_lo : B->bjobs + L.bjob_lo;
+	// iteration 0 of the LDS tier's class-level jobs: the setup has applied the rigid step (identity_step), no point has a hint — every called class cloud
+	// goes straight to the staged search, no light pass (k_search.hip: first_goes_direct)
+	const bool first = iter == 0 && rp.lds_dedup != 0u && !rp.normal_shooting && ctx->opt[MULLS_OPT_FIRST_DIRECT] != 0.0;
 	const bool together = tier == 3 && L.cjob_n && big_n &&
 						  launch_cert_mixed(sst, L.cjob_n, B->cjobs + L.cjob_lo, big_n, big_jobs, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->bm,
 											B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap,
-											rp.grid_maxcells) != 0;
+											rp.grid_maxcells, first) != 0;
 	if (!together && L.cjob_n &&
 		launch_nn_lds(sst, L.cjob_n, B->cjobs + L.cjob_lo, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner,
-					  B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, wl, wl_ctr, parity) != 0)
+					  B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap, rp.grid_maxcells, wl, wl_ctr, parity, first) != 0)
 	{
 		ctx->err = "could not raise the dynamic LDS limit of k_nn_lds";
 		return MULLS_E_HIP;
