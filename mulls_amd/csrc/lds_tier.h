@@ -325,11 +325,19 @@ __device__ __forceinline__ CandOut lane_bests(nnkey lk, float ls)
 // concatenation, two candidates per lane in flight — the trip count is that of the total, not the sum of the per-row
 // round-ups, and the only per-row work is two table reads and a running sum.  Returns false when the cube lies inside the
 // query's own cell and `own_done` says that cell has been swept already.
+// CHUNK = rows per step.  2 against the cloud staged in LDS (k_nn_lds is bound by its instruction count: every further row costs a select per candidate).  4 against
+// the grid in global memory (the light pass's leftovers, bound by the latency of their chains: a hinted cube spans at most two cells per axis, i.e. at most four
+// rows — with four rows per step a round of sub-groups is one table trip and one or two candidate trips where two rows per step took two of each as soon as
+// ONE of its 64 queries straddled a cell boundary in y and in z).
 #define MULLS_LDS_CHUNK 2
-template <class G>
+#ifndef MULLS_GLOB_CHUNK
+#define MULLS_GLOB_CHUNK 2
+#endif
+template <int CHUNK, class G>
 __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, float px, float py, float pz, float R, uint32_t sub, nnkey &bk,
 											  float &sec, uint32_t &trips, bool own_done = false)
 {
+	static_assert(CHUNK == 1 || CHUNK == 2 || CHUNK == 4, "rows per step");
 	const float Rm = R * 1.0001f + 1e-4f;
 	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
 	const int y0 = grid_cell(py - Rm, g.oy, g.inv_h, g.ny), y1 = grid_cell(py + Rm, g.oy, g.inv_h, g.ny);
@@ -339,21 +347,27 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 	int cy = y0, cz = z0;
 	while (cz <= z1)
 	{
-		uint32_t lo[MULLS_LDS_CHUNK], pre[MULLS_LDS_CHUNK], acc = 0;
+		uint32_t lo[CHUNK], pre[CHUNK], acc = 0;
+		uint32_t a[CHUNK], e[CHUNK];
+		bool valid[CHUNK];
 #pragma unroll
-		for (int jj = 0; jj < MULLS_LDS_CHUNK; jj++)
+		for (int jj = 0; jj < CHUNK; jj++) // every row's bounds requested before the first is used
 		{
-			const bool valid = cz <= z1;
-			const uint32_t row = ((uint32_t)(valid ? cz : z0) * g.ny + (uint32_t)cy) * g.nx;
-			const uint32_t a = L.cs(row + x0), e = L.cs(row + x1);
-			lo[jj] = a - acc; // candidate f of the concatenation lives at lo[jj] + f while f < pre[jj]
-			acc += valid ? e - a : 0u;
-			pre[jj] = acc;
+			valid[jj] = cz <= z1;
+			const uint32_t row = ((uint32_t)(valid[jj] ? cz : z0) * g.ny + (uint32_t)cy) * g.nx;
+			a[jj] = L.cs(row + x0), e[jj] = L.cs(row + x1);
 			if (++cy > y1)
 			{
 				cy = y0;
 				cz++;
 			}
+		}
+#pragma unroll
+		for (int jj = 0; jj < CHUNK; jj++)
+		{
+			lo[jj] = a[jj] - acc; // candidate f of the concatenation lives at lo[jj] + f while f < pre[jj]
+			acc += valid[jj] ? e[jj] - a[jj] : 0u;
+			pre[jj] = acc;
 		}
 		trips += (acc + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
 		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
@@ -361,12 +375,19 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 			const uint32_t f2 = f + MULLS_LDS_GROUP;
 			const bool ok2 = f2 < acc;
 			const uint32_t ff = ok2 ? f2 : f;
-#if MULLS_LDS_CHUNK == 1
-			const uint32_t ta = f + lo[0], tb = ff + lo[0];
-#else
-			const uint32_t ta = f + (f < pre[0] ? lo[0] : lo[1]);
-			const uint32_t tb = ff + (ff < pre[0] ? lo[0] : lo[1]);
-#endif
+			uint32_t ta, tb;
+			if constexpr (CHUNK == 1)
+				ta = f + lo[0], tb = ff + lo[0];
+			else if constexpr (CHUNK == 2)
+			{
+				ta = f + (f < pre[0] ? lo[0] : lo[1]);
+				tb = ff + (ff < pre[0] ? lo[0] : lo[1]);
+			}
+			else
+			{
+				ta = f + (f < pre[1] ? (f < pre[0] ? lo[0] : lo[1]) : (f < pre[2] ? lo[2] : lo[3]));
+				tb = ff + (ff < pre[1] ? (ff < pre[0] ? lo[0] : lo[1]) : (ff < pre[2] ? lo[2] : lo[3]));
+			}
 			float ax, ay, az, bx, by, bz;
 			uint32_t ia, ib;
 			L.cand(ta, ax, ay, az, ia);
@@ -386,7 +407,7 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 // distance the last sweep saw (0 = unknown), Rfin = that sweep's radius: every target other than bk's is at least
 // min(sqrt(sec), Rfin) away; trips = candidate trips taken (cost class of the next iteration).
 // co: the other lanes' nearest targets of the sweep that produced (bk, sec), for the k-candidate certificates (lane_bests; b2 = 0 with sec = 0).
-template <class G>
+template <int CHUNK = MULLS_LDS_CHUNK, class G>
 __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, const float4 q, float r, float m, uint32_t sub, nnkey &bk, float &sec,
 											  float &Rfin, uint32_t &trips, CandOut &co)
 {
@@ -402,7 +423,7 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 	auto sweep = [&](float R, bool own_done) {
 		nnkey lk = NNKEY_NONE;
 		float ls = __builtin_inff();
-		if (lds_scan_box(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
+		if (lds_scan_box<CHUNK>(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
 		{
 			const nnkey own_k = lk;
 			const float own_s = ls;
@@ -545,6 +566,39 @@ __device__ __forceinline__ bool commit_search(const ClassCtx &C, const CloudDesc
 		else if (C.gate)
 			atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)s);
 	}
+	return matched;
+}
+
+// state bits of a point in the one-pass walk (cert_class_flat)
+#define MULLS_FS_ALIVE 1u	 // = MULLS_F_ALIVE
+#define MULLS_FS_VALID 2u	 // = MULLS_F_VALID (member of Corr_f before this iteration)
+#define MULLS_FS_DIR_OK 4u	 // the direction check passes against the standing correspondence's target direction
+#define MULLS_FS_STANDING 8u // the certified correspondence is the standing one (its record is in place)
+#define MULLS_FS_SEARCH 16u	 // PARK: the point waits for a search; the correspondence's word holds its STANDING match meanwhile, the distance's word the sweep radius
+// ... of a query the one-pass walk (cert_class_flat, PARK) searches itself: the result goes into the owner lane's two parked words in LDS — park[s] = state bits << 24 |
+// (correspondence + 2) with the wait mark cleared and "it is the standing match" set from the match the word held, park[D0 + s] = the squared distance — instead of
+// nn_idx / nn_d2 in memory; the hint record and the duplicate table as commit_search.  (rp.lds_dedup: a duplicate rule in force is this workgroup's table.)
+template <bool W16, int D0>
+__device__ __forceinline__ bool commit_search_park(const ClassCtx &C, const CloudDesc &d, uint32_t s, nnkey bk, float sec, float Rfin, uint32_t trips, const CandOut &co,
+													int2 *__restrict__ hint2, uint32_t *W, uint32_t *park)
+{
+	const float best = key_dist(bk);
+	const int bi = (int)(uint32_t)bk; // -1: nothing found
+	const bool matched = bi >= 0 && !((double)best > C.max_dist_sqr);
+	const float lb_new = fminf(sqrtf(sec), Rfin);
+	hint2[d.src_off + s] = make_int2((int32_t)(((uint32_t)bi & 0xffffu) | (min(trips, 31u) << 16)), __float_as_int(lb_new));
+#if MULLS_LDS_KCERT
+	if (C.cand)
+		C.cand[d.src_off + s] = make_uint4(co.cx, co.cy, __float_as_uint(fminf(sqrtf(co.b2), Rfin) - lb_new), C.epoch);
+#else
+	(void)co;
+#endif
+	const uint32_t w0 = park[s], st = (w0 >> 24) & ~MULLS_FS_SEARCH;
+	const int32_t pm = (int32_t)(w0 & 0xffffffu) - 2, m = matched ? bi : -1;
+	park[s] = ((st | ((matched && bi == pm) ? MULLS_FS_STANDING : 0u)) << 24) | (uint32_t)(m + 2);
+	park[(uint32_t)D0 + s] = __float_as_uint(best);
+	if (matched && C.dedup)
+		dedup_min<W16>(W, (uint32_t)bi, s);
 	return matched;
 }
 
@@ -1080,7 +1134,7 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 		float sec, Rfin;
 		uint32_t trips;
 		CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
-		search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+		search_query<MULLS_GLOB_CHUNK>(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
 		if (sub == 0 && commit_search<W16>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
 			matched_cnt++;
 	}
@@ -1100,10 +1154,6 @@ __device__ __forceinline__ bool cert_class(CertLds<SMALL> &CL, const RunParams &
 // every live point when the cloud goes to k_nn_lds (return false).  The loads of two trips are in flight at a time.  The kernel is bound by the
 // latency of its memory round trips at the occupancy its registers and LDS allow (profiles/r03_k_cert_occupancy.txt): both are kept small.
 // The same arithmetic, decisions and outputs as cert_class + class_tail; `called` class clouds only (class_called: the caller checks).
-#define MULLS_FS_ALIVE 1u	 // = MULLS_F_ALIVE
-#define MULLS_FS_VALID 2u	 // = MULLS_F_VALID (member of Corr_f before this iteration)
-#define MULLS_FS_DIR_OK 4u	 // the direction check passes against the standing correspondence's target direction
-#define MULLS_FS_STANDING 8u // the certified correspondence is the standing one (its record is in place)
 template <int BLK, int TRIPS, bool W16, int SMALL, bool PARK = false>
 __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W,
 												 float4 *__restrict__ spos, float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start,
@@ -1172,6 +1222,10 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			D0r[PARK ? 0 : k] = v;
 	};
 	auto getD0 = [&](int k) -> float { return PARK ? __uint_as_float(park[(uint32_t)(TRIPS + k) * BLK + threadIdx.x]) : D0r[PARK ? 0 : k]; };
+	// PARK: a point that waits for a search is marked by a state bit, and the sub-group that searches it here puts the result into the point's two words
+	// (commit_search_park: the owner's tail reads LDS instead of waiting for nn_idx / nn_d2 / match to come back from memory — one round trip less in the chain
+	// search -> tail, which is what a workgroup with leftovers spends its time on); nn_idx / nn_d2 are written only when the class cloud goes to k_nn_lds
+	auto waits = [&](int k) -> bool { return PARK ? (getST(k) & MULLS_FS_SEARCH) != 0u : getM(k) == MULLS_NEEDS_SEARCH; };
 	uint32_t matched_cnt = 0;
 	// rigid step + certificate of one trip's point (cert_class's arithmetic)
 	auto cert = [&](int k, const Rec &r) {
@@ -1248,10 +1302,18 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		}
 		if (!certified)
 		{
-			m_k = MULLS_NEEDS_SEARCH;
 			setD0(k, out.w);
-			nn_idx[gi] = MULLS_NEEDS_SEARCH;
-			nn_d2[gi] = out.w;
+			if (PARK)
+			{
+				st_k |= MULLS_FS_SEARCH;
+				m_k = r.pm; // (>= -1: the setup's -1 or a target index)
+			}
+			else
+			{
+				m_k = MULLS_NEEDS_SEARCH;
+				nn_idx[gi] = MULLS_NEEDS_SEARCH;
+				nn_d2[gi] = out.w;
+			}
 			const uint32_t u = atomicAdd(&ucount, 1u);
 			if (u < (uint32_t)SMALL)
 			{
@@ -1296,11 +1358,11 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		// too many for the global-memory walk: k_nn_lds stages the target cloud (lds_search_class) and reads every live point's result from memory
 #pragma unroll
 		for (int k = 0; k < TRIPS; k++)
-			if ((getST(k) & MULLS_FS_ALIVE) && getM(k) != MULLS_NEEDS_SEARCH)
+			if ((getST(k) & MULLS_FS_ALIVE) && (PARK || !waits(k)))
 			{
 				const uint32_t gi = d.src_off + threadIdx.x + (uint32_t)k * BLK;
-				nn_idx[gi] = getM(k);
-				nn_d2[gi] = getD0(k);
+				nn_idx[gi] = waits(k) ? MULLS_NEEDS_SEARCH : getM(k);
+				nn_d2[gi] = getD0(k); // (a waiting point: its sweep radius)
 			}
 		return false;
 	}
@@ -1315,8 +1377,9 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			float sec, Rfin;
 			uint32_t trips;
 			CandOut co = {0xffffffffu, 0xffffffffu, 0.0f};
-			search_query(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
-			if (sub == 0 && commit_search<W16>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner))
+			search_query<MULLS_GLOB_CHUNK>(g, L, uq[i], C.r, C.m, sub, bk, sec, Rfin, trips, co);
+			if (sub == 0 && (PARK ? commit_search_park<W16, BLK * TRIPS>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, hint2, W, park)
+								  : commit_search<W16>(C, d, us[i] & ~MULLS_US_KCERT, bk, sec, Rfin, trips, co, nn_idx, nn_d2, hint2, W, winner)))
 				matched_cnt++;
 		}
 	}
@@ -1324,7 +1387,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		matched_cnt += __shfl_down(matched_cnt, off);
 	if ((threadIdx.x & 63) == 0)
 		red[threadIdx.x >> 6] = matched_cnt;
-	__threadfence_block(); // the searched (or k-candidate certified) points' nn_idx / nn_d2, read back below by the lanes that own them
+	__threadfence_block(); // the searched (or k-candidate certified) points' results, read back below by the lanes that own them
 	__syncthreads();
 	uint32_t total_matched = 0;
 	for (int w = 0; w < BLK / 64; w++)
@@ -1345,7 +1408,7 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		int32_t m = getM(k);
 		float dist = getD0(k);
 		bool standing = (st & MULLS_FS_STANDING) != 0;
-		if (m == MULLS_NEEDS_SEARCH)
+		if (PARK ? (st & MULLS_FS_SEARCH) != 0u : m == MULLS_NEEDS_SEARCH) // (PARK: only what kcert_list certified is still marked — a searched point's words hold its result)
 		{
 			m = nn_idx[gi];
 			dist = nn_d2[gi];
