@@ -1335,12 +1335,21 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		ucount = 0u;
 	__syncthreads(); // the duplicate table is armed
 	FLAT_TICK(0)
+	// (a cloud of at most two trips — the ground and pillar clouds of a down-sampled scan — does not wait for a third trip's loads; uniform)
+	const bool third = TRIPS == 3 && q_end > 2u * (uint32_t)BLK;
 	cert(0, r0);
-	if (TRIPS == 3)
+	if (third)
+	{
 		r0 = load(2);
-	cert(1, r1);
-	if (TRIPS == 3)
+		cert(1, r1);
 		cert(2, r0);
+	}
+	else
+	{
+		cert(1, r1);
+		if (TRIPS == 3)
+			setSM(2, 0u, -1), setD0(2, 0.0f);
+	}
 	__syncthreads();
 	FLAT_TICK(2)
 	uint32_t U = ucount;
@@ -1428,28 +1437,29 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 			}
 			if (valid)
 			{
-				valid = strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
-				if (valid)
+				if (!standing)
 				{
-					wd[gi] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
-					if (!standing)
+					// a new nearest target: its record travels with the source point from here on (filter_point), and the direction check runs against the new
+					// target direction.  Written whether or not the distance rejector below keeps the correspondence (only valid points' records are ever used, and
+					// a valid point's record is its correspondence's: every change of the nearest target passes here): the next walk then finds the hinted target's
+					// position in the point's own record instead of gathering it through the crop map — two dependent round trips in the middle of its certificates
+					// for every wave that holds one such point
+					match[gi] = m;
+					float4 q2, n2;
+					tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n2);
+					mq[2u * gi] = q2;
+					mq[2u * gi + 1u] = n2;
+					if (normal_check)
 					{
-						// a new correspondence: its target record travels with the source point from here on (filter_point), and the direction check
-						// runs against the new target direction
-						match[gi] = m;
-						float4 q2, n2;
-						tgt_record(rp.tgt_stage, rp.tgt_map, d, (uint32_t)m, tpos, tnrm, q2, n2);
-						mq[2u * gi] = q2;
-						mq[2u * gi + 1u] = n2;
-						if (normal_check)
-						{
-							const float3 n1 = *reinterpret_cast<const float3 *>(snrm + gi); // this lane's own store of phase 1
-							const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
-							const float c = (float)fabs(dot);
-							dir_ok = !((double)c < rp.cos_bearing);
-						}
+						const float3 n1 = *reinterpret_cast<const float3 *>(snrm + gi); // this lane's own store of phase 1
+						const double dot = (double)n1.x * (double)n2.x + (double)n1.y * (double)n2.y + (double)n1.z * (double)n2.z;
+						const float c = (float)fabs(dot);
+						dir_ok = !((double)c < rp.cos_bearing);
 					}
 				}
+				valid = strict ? dist < max_sqr : !(dist > max_sqr); // CorrespondenceRejectorDistance (see mulls_params.rejector_strict)
+				if (valid)
+					wd[gi] = dist; // pcl::Correspondence::distance (shares storage with ::weight)
 			}
 		}
 		else if (C.gate)
