@@ -437,7 +437,7 @@ __global__ __launch_bounds__(MULLS_TG_LANES, 4) void k_tgt_grid(CloudDesc *__res
 	if (!used || g.ncell == 0)
 		return;
 	uint16_t *cs16 = reinterpret_cast<uint16_t *>(cell_start) + g.cell_off;
-	if (g.ncell < 16384u)
+	if (g.ncell < 32768u) // (K holds 32768 16-bit counters; the driver keeps the fused setup's grids below that: run_setup)
 	{
 		// counting sort with LDS atomics on 16-bit counters packed in pairs (a count never exceeds n <= MULLS_LDS_MAXPTS: no carry into the neighbour)
 		uint16_t *cnt16 = reinterpret_cast<uint16_t *>(K);

@@ -255,22 +255,24 @@ __device__ __forceinline__ bool first_goes_direct(const RunParams &rp, const Clo
 
 // One class-cloud job of the light pass: the one-pass walk for a whole class cloud that fits the lanes' registers (cert_class_flat), the general walk for
 // chunk-level jobs, larger clouds and classes that sit the iteration out.  Returns (to every lane) false when the class cloud needs the heavy pass.
-template <int BLK, int SMALL, bool PARK = false>
+template <int BLK, int SMALL, bool PARK = false, int FLAT_TRIPS = (BLK == 512 ? 3 : 2)>
 __device__ __forceinline__ bool cert_job(CertLds<SMALL> &CL, const RunParams &rp, const PairState &ps, const Job &job, CloudDesc &d, const GridDesc &g, uint32_t *W, float4 *__restrict__ spos,
 										  float4 *__restrict__ snrm, const uint32_t *__restrict__ cell_start, const float4 *__restrict__ tsorted, uint8_t *flag,
 										  int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, unsigned long long *__restrict__ winner, const float4 *__restrict__ tnrm,
 										  int32_t *__restrict__ match, float *__restrict__ wd, const float4 *__restrict__ tpos, int32_t *__restrict__ nn_hint,
 										  float4 *__restrict__ mq, uint32_t *park = nullptr)
 {
-	constexpr int FLAT_TRIPS = BLK == 512 ? 3 : 2;
 	const bool flat = rp.lds_dedup != 0u && rp.debug_stop != 9u && job.start == 0u && job.count >= d.src_n && d.src_n <= (uint32_t)(BLK * FLAT_TRIPS) && class_called(rp, d, job.cls);
 	return flat ? cert_class_flat<BLK, FLAT_TRIPS, true, SMALL, PARK>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, park)
 				: cert_class<BLK, true, SMALL>(CL, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq);
 }
 
 // BLK lanes per class cloud: 512 when there are enough class clouds to give every CU several workgroups, 1024 for small batches (a class cloud of
-// 1200 points is then two trips instead of three, and the launch is as long as its longest workgroup)
-template <int BLK>
+// 1200 points is then two trips instead of three, and the launch is as long as its longest workgroup).  TRIPS: the one-pass walk takes class clouds of up to
+// BLK * TRIPS source points (larger ones: the general walk).  Longer one-pass walks for the 1 537 - 3 072-point clouds of real scans — 512 lanes x 6 trips,
+// 1024 lanes x 3 trips, as their own launch or for every job — were built, bit-identical, and slower than the general walk on configs[0]
+// (profiles/r06_experiments.txt item 5): a real scan's time is in the leftover searches of its SHORT class clouds.
+template <int BLK, int TRIPS = (BLK == 512 ? 3 : 2)>
 __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
@@ -291,12 +293,17 @@ __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__r
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 	__shared__ CertLds<MULLS_CERT_SMALL_LOCKSTEP> s_cert;
-	constexpr bool PARK = BLK == 512; // (the 1024-lane form serves small batches: two workgroups per CU, 128 registers)
-	__shared__ uint32_t s_park[PARK ? 2 * 3 * 512 : 1];
-	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP, PARK>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, s_park))
+	constexpr bool PARK = BLK == 512; // (the two-trip 1024-lane form serves small batches: two workgroups per CU, 128 registers)
+	__shared__ uint32_t s_park[PARK ? 2 * TRIPS * BLK : 1];
+	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP, PARK, TRIPS>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, s_park))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }
+
+// The fused kernels' light pass: 1024 lanes, three trips (class clouds of up to 3072 source points: a single registration of real scans), the walk's per-point
+// state parked in the dynamic LDS block behind the 16-bit duplicate table (2 * cap bytes) — fused_lds_bytes() says how much the launch needs for it
+#define MULLS_FUSED_PARK_BYTES (2u * 3u * MULLS_LDS_BLOCK * 4u)
+__device__ __forceinline__ uint32_t *fused_park(unsigned char *lds_raw, uint32_t cap) { return reinterpret_cast<uint32_t *>(lds_raw + (((size_t)cap * 2u + 15u) & ~(size_t)15)); }
 
 // Light and heavy pass in one launch, for batches of at most two class clouds per CU (a single registration: three): the workgroup that finds its class cloud
 // in need of the heavy pass runs it right away (1024 lanes, the whole LDS) instead of queueing it for k_nn_lds — one launch less per iteration where
@@ -319,8 +326,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_nn(const Job *__restri
 	const bool direct = first && first_goes_direct(rp, d, job.cls); // (uniform) iteration 0: straight to the staged search
 	if (!direct)
 	{
-		if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match,
-														wd, tpos, nn_hint, mq))
+		if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL, true, 3>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner,
+																 tnrm, match, wd, tpos, nn_hint, mq, fused_park(lds_raw, cap)))
 			return;
 		__syncthreads(); // the light pass's LDS is free
 	}
@@ -354,8 +361,8 @@ __global__ __launch_bounds__(MULLS_LDS_BLOCK) void k_cert_mixed(uint32_t n_lds, 
 		const bool direct = first && first_goes_direct(rp, d, job.cls); // (uniform) iteration 0: straight to the staged search
 		if (!direct)
 		{
-			if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm,
-															match, wd, tpos, nn_hint, mq))
+			if (cert_job<MULLS_LDS_BLOCK, MULLS_CERT_SMALL, true, 3>(s_cert, rp, ps, job, d, g, reinterpret_cast<uint32_t *>(lds_raw), spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2,
+																	 winner, tnrm, match, wd, tpos, nn_hint, mq, fused_park(lds_raw, cap)))
 				return;
 			__syncthreads(); // the light pass's LDS is free
 		}
@@ -568,6 +575,12 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_nn_shoot(const Job *__restrict_
 // host-callable launch wrappers (the driver is plain C++ and never sees <<< >>>)
 #include "launch.h"
 
+// dynamic LDS of the fused kernels (k_cert_nn, k_cert_mixed): the staged search's block, or what the light pass in front of it parks (fused_park)
+static size_t fused_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
+{
+	const size_t heavy = nn_lds_bytes(cap, maxcells, dedup), light = (((size_t)cap * 2u + 15u) & ~(size_t)15) + MULLS_FUSED_PARK_BYTES;
+	return heavy > light ? heavy : light;
+}
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup)
 {
 	// query block, cost-sort tables, position records + index, cell table, and (lds_dedup) the on-chip duplicate table
@@ -605,10 +618,10 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 		return 0;
 	const bool dedup = rp.lds_dedup != 0u;
 	// (up to two class clouds per CU: 117 k vs 103 k registrations/s at 192 pairs, 131 k vs 119 k at 256; no gain beyond, profiles/r03_modes_fused.txt)
-	if (njobs <= 2u * n_cu && rp.debug_stop != 10u && nn_lds_bytes(cap, maxcells, dedup) <= fused_dyn_max)
+	if (njobs <= 2u * n_cu && rp.debug_stop != 10u && fused_lds_bytes(cap, maxcells, dedup) <= fused_dyn_max)
 	{
 		// light and heavy pass in one launch
-		hipLaunchKernelGGL(k_cert_nn, dim3(njobs), dim3(MULLS_LDS_BLOCK), nn_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm, grids, cell_start,
+		hipLaunchKernelGGL(k_cert_nn, dim3(njobs), dim3(MULLS_LDS_BLOCK), fused_lds_bytes(cap, maxcells, dedup), st, jobs, descs, states, rp, spos, snrm, grids, cell_start,
 						   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, first ? 1u : 0u);
 		return 0;
 	}
@@ -654,7 +667,7 @@ int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t
 	while (split > 1 && n_lds + n_big * split > n_cu)
 		split >>= 1;
 	const bool dedup = rp.lds_dedup != 0u;
-	const size_t dyn = nn_lds_bytes(cap, maxcells, dedup) > sizeof(BigLds<MULLS_BIG_BLOCK * 3>) ? nn_lds_bytes(cap, maxcells, dedup) : sizeof(BigLds<MULLS_BIG_BLOCK * 3>);
+	const size_t dyn = fused_lds_bytes(cap, maxcells, dedup) > sizeof(BigLds<MULLS_BIG_BLOCK * 3>) ? fused_lds_bytes(cap, maxcells, dedup) : sizeof(BigLds<MULLS_BIG_BLOCK * 3>);
 	if (n_lds + n_big * split > n_cu || dyn > dyn_max)
 		return 0;
 	hipLaunchKernelGGL(k_cert_mixed, dim3(n_lds + n_big * split), dim3(MULLS_LDS_BLOCK), dyn, st, n_lds, cjobs, bjobs, split, descs, states, rp, spos, snrm, grids, cell_start, bm, pf, cs,

@@ -171,16 +171,23 @@ __device__ __forceinline__ void dpp_min_step(nnkey &bk)
 	const nnkey o = ((nnkey)oh << 32) | ol;
 	bk = o < bk ? o : bk;
 }
-__device__ __forceinline__ void row16_min(nnkey &bk)
+// GSH: log2 of the lanes that share a query — a template argument (MULLS_LDS_GSH) or, < 0, the run-time value `gsh` (uniform over the workgroup).  The run-time
+// form served one experiment — the light pass choosing 4 or 2 lanes per query when its leftover list is longer than one round of 8-lane sub-groups: slower,
+// profiles/r06_experiments.txt item 6 — and no kernel uses it
+#define MULLS_LDS_GSH (MULLS_LDS_GROUP == 16u ? 4 : (MULLS_LDS_GROUP == 8u ? 3 : 2))
+template <int GSH>
+__device__ __forceinline__ uint32_t sub_lanes(uint32_t gsh) { return GSH >= 0 ? (1u << (GSH >= 0 ? GSH : 0)) : (1u << gsh); }
+template <int GSH = MULLS_LDS_GSH>
+__device__ __forceinline__ void row16_min(nnkey &bk, uint32_t gsh = 0u)
 {
-	dpp_min_step<0xB1>(bk);	 // quad_perm [1,0,3,2]
-	dpp_min_step<0x4E>(bk);	 // quad_perm [2,3,0,1]
-#if MULLS_LDS_GROUP >= 8
-	dpp_min_step<0x141>(bk); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
-#endif
-#if MULLS_LDS_GROUP == 16
-	dpp_min_step<0x140>(bk); // row_mirror: lanes i <-> 15 - i
-#endif
+	const uint32_t GL = sub_lanes<GSH>(gsh);
+	dpp_min_step<0xB1>(bk); // quad_perm [1,0,3,2]
+	if (GL >= 4u)
+		dpp_min_step<0x4E>(bk); // quad_perm [2,3,0,1]
+	if (GL >= 8u)
+		dpp_min_step<0x141>(bk); // row_half_mirror: lanes i <-> 7 - i of each 8-lane half
+	if (GL >= 16u)
+		dpp_min_step<0x140>(bk); // row_mirror: lanes i <-> 15 - i
 }
 // (best key, second-best distance) over the lanes of a sub-group.  Every lane enters with the best key and the second-smallest
 // distance among ITS candidates; a lane whose best lost the sub-group minimum contributes that best's distance instead.
@@ -190,19 +197,20 @@ __device__ __forceinline__ void dpp_fmin_step(float &v)
 	const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 	v = fminf(o, v);
 }
-__device__ __forceinline__ void row16_min2(nnkey &bk, float &sec)
+template <int GSH = MULLS_LDS_GSH>
+__device__ __forceinline__ void row16_min2(nnkey &bk, float &sec, uint32_t gsh = 0u)
 {
+	const uint32_t GL = sub_lanes<GSH>(gsh);
 	nnkey g = bk;
-	row16_min(g);
+	row16_min<GSH>(g, gsh);
 	float c = (bk == g) ? sec : key_dist(bk);
 	dpp_fmin_step<0xB1>(c);
-	dpp_fmin_step<0x4E>(c);
-#if MULLS_LDS_GROUP >= 8
-	dpp_fmin_step<0x141>(c);
-#endif
-#if MULLS_LDS_GROUP == 16
-	dpp_fmin_step<0x140>(c);
-#endif
+	if (GL >= 4u)
+		dpp_fmin_step<0x4E>(c);
+	if (GL >= 8u)
+		dpp_fmin_step<0x141>(c);
+	if (GL >= 16u)
+		dpp_fmin_step<0x140>(c);
 	sec = c;
 	bk = g;
 }
@@ -333,10 +341,11 @@ __device__ __forceinline__ CandOut lane_bests(nnkey lk, float ls)
 #ifndef MULLS_GLOB_CHUNK
 #define MULLS_GLOB_CHUNK 2
 #endif
-template <int CHUNK, class G>
+template <int CHUNK, int GSH, class G>
 __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, float px, float py, float pz, float R, uint32_t sub, nnkey &bk,
-											  float &sec, uint32_t &trips, bool own_done = false)
+											  float &sec, uint32_t &trips, bool own_done = false, uint32_t gsh = 0u)
 {
+	const uint32_t GL = sub_lanes<GSH>(gsh), GS = GSH >= 0 ? (uint32_t)(GSH >= 0 ? GSH : 0) : gsh;
 	static_assert(CHUNK == 1 || CHUNK == 2 || CHUNK == 4, "rows per step");
 	const float Rm = R * 1.0001f + 1e-4f;
 	const uint32_t x0 = (uint32_t)grid_cell(px - Rm, g.ox, g.inv_h, g.nx), x1 = (uint32_t)grid_cell(px + Rm, g.ox, g.inv_h, g.nx) + 1u;
@@ -369,10 +378,10 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 			acc += valid[jj] ? e[jj] - a[jj] : 0u;
 			pre[jj] = acc;
 		}
-		trips += (acc + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
-		for (uint32_t f = sub; f < acc; f += 2 * MULLS_LDS_GROUP)
+		trips += (acc + GL - 1u) >> GS;
+		for (uint32_t f = sub; f < acc; f += 2u * GL)
 		{
-			const uint32_t f2 = f + MULLS_LDS_GROUP;
+			const uint32_t f2 = f + GL;
 			const bool ok2 = f2 < acc;
 			const uint32_t ff = ok2 ? f2 : f;
 			uint32_t ta, tb;
@@ -407,10 +416,11 @@ __device__ __forceinline__ bool lds_scan_box(const GridDesc &g, const G &L, floa
 // distance the last sweep saw (0 = unknown), Rfin = that sweep's radius: every target other than bk's is at least
 // min(sqrt(sec), Rfin) away; trips = candidate trips taken (cost class of the next iteration).
 // co: the other lanes' nearest targets of the sweep that produced (bk, sec), for the k-candidate certificates (lane_bests; b2 = 0 with sec = 0).
-template <int CHUNK = MULLS_LDS_CHUNK, class G>
+template <int CHUNK = MULLS_LDS_CHUNK, int GSH = MULLS_LDS_GSH, class G>
 __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, const float4 q, float r, float m, uint32_t sub, nnkey &bk, float &sec,
-											  float &Rfin, uint32_t &trips, CandOut &co)
+											  float &Rfin, uint32_t &trips, CandOut &co, uint32_t gsh = 0u)
 {
+	const uint32_t GL = sub_lanes<GSH>(gsh), GS = GSH >= 0 ? (uint32_t)(GSH >= 0 ? GSH : 0) : gsh;
 	bk = NNKEY_NONE;
 	sec = __builtin_inff();
 	Rfin = 0.0f;
@@ -423,11 +433,11 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 	auto sweep = [&](float R, bool own_done) {
 		nnkey lk = NNKEY_NONE;
 		float ls = __builtin_inff();
-		if (lds_scan_box<CHUNK>(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done))
+		if (lds_scan_box<CHUNK, GSH>(g, L, q.x, q.y, q.z, R, sub, lk, ls, trips, own_done, gsh))
 		{
 			const nnkey own_k = lk;
 			const float own_s = ls;
-			row16_min2(lk, ls);
+			row16_min2<GSH>(lk, ls, gsh);
 			// (selects: two branches ending in stores to different variables are merged into one store through a selected address, which puts both on the stack)
 			const bool adopt = !(bk < lk);
 			bk = adopt ? lk : bk;
@@ -445,10 +455,10 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 		const int cx = grid_cell(q.x, g.ox, g.inv_h, g.nx), cy = grid_cell(q.y, g.oy, g.inv_h, g.ny), cz = grid_cell(q.z, g.oz, g.inv_h, g.nz);
 		const uint32_t cell = ((uint32_t)cz * g.ny + (uint32_t)cy) * g.nx + (uint32_t)cx;
 		const uint32_t lo = L.cs(cell), hi = L.cs(cell + 1u);
-		trips += (hi - lo + MULLS_LDS_GROUP - 1u) / MULLS_LDS_GROUP;
-		for (uint32_t t = lo + sub; t < hi; t += 2 * MULLS_LDS_GROUP) // two candidates in flight per lane and trip
+		trips += (hi - lo + GL - 1u) >> GS;
+		for (uint32_t t = lo + sub; t < hi; t += 2u * GL) // two candidates in flight per lane and trip
 		{
-			const uint32_t t2 = t + MULLS_LDS_GROUP;
+			const uint32_t t2 = t + GL;
 			const bool ok2 = t2 < hi;
 			float ax, ay, az, bx, by, bz;
 			uint32_t ia, ib;
@@ -461,13 +471,14 @@ __device__ __forceinline__ void search_query(const GridDesc &g, const G &L, cons
 			take_pair(da, ia, db, ib, ok2, bk, sec);
 		}
 		lane_k = bk, lane_s = sec;
-		row16_min2(bk, sec);
+		row16_min2<GSH>(bk, sec, gsh);
 		// probe 1: every cell within min(first-probe radius, current best distance) of the query
 		sweep(key_found(bk) ? fminf(m, sqrtf(key_dist(bk))) : m, true);
 	}
 	if (!(key_found(bk) && key_dist(bk) <= m * m))
 		sweep(key_found(bk) ? fminf(r, sqrtf(key_dist(bk))) : r, false); // nothing within the first-probe radius: widen to the best distance, or to the rejection radius
 #if MULLS_LDS_KCERT
+	static_assert(GSH >= 0, "the k-candidate records are ranked by a compile-time number of lanes");
 	co = lane_bests<(int)MULLS_LDS_GROUP, true>(lane_k, lane_s);
 	if (sec == 0.0f)
 		co.b2 = 0.0f; // the standing result lies outside the last (clipped) sweep: nothing is claimed about the other targets
@@ -1335,20 +1346,22 @@ __device__ __forceinline__ bool cert_class_flat(CertLds<SMALL> &CL, const RunPar
 		ucount = 0u;
 	__syncthreads(); // the duplicate table is armed
 	FLAT_TICK(0)
-	// (a cloud of at most two trips — the ground and pillar clouds of a down-sampled scan — does not wait for a third trip's loads; uniform)
-	const bool third = TRIPS == 3 && q_end > 2u * (uint32_t)BLK;
-	cert(0, r0);
-	if (third)
 	{
-		r0 = load(2);
-		cert(1, r1);
-		cert(2, r0);
-	}
-	else
-	{
-		cert(1, r1);
-		if (TRIPS == 3)
-			setSM(2, 0u, -1), setD0(2, 0.0f);
+		// (a cloud of at most two trips — the ground and pillar clouds of a down-sampled scan — does not wait for a third trip's loads; uniform)
+		const bool third = TRIPS == 3 && q_end > 2u * (uint32_t)BLK;
+		cert(0, r0);
+		if (third)
+		{
+			r0 = load(2);
+			cert(1, r1);
+			cert(2, r0);
+		}
+		else
+		{
+			cert(1, r1);
+			if (TRIPS == 3)
+				setSM(2, 0u, -1), setD0(2, 0.0f);
+		}
 	}
 	__syncthreads();
 	FLAT_TICK(2)

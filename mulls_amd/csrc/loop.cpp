@@ -110,6 +110,9 @@ int run_setup(Run &R)
 	{
 		rp.tgt_stage = B->stage;
 		rp.tgt_map = B->tmap;
+		// k_tgt_grid counting-sorts grids of fewer than 32768 cells in LDS; beyond, it falls back to a bitonic sort of (cell, rank) keys that takes four times
+		// as long (real scans' 2 000 - 5 000-point class clouds leave room for 30 000+ cells: 3.7 ms of setup per 4096 pairs against 0.9, profiles/r06_experiments.txt)
+		rp.grid_maxcells = std::min(rp.grid_maxcells, 32767u);
 	}
 
 	if (rp.debug_stop == 20u || rp.debug_stop == 21u)
