@@ -209,6 +209,7 @@ __device__ __forceinline__ void search_query_bm(const GridDesc &g, const BmGrid 
 
 #define MULLS_US16_KCERT 0x8000u // BigLds::us: a hinted point — it gets the k-candidate certificate's look (slots stay below 1536)
 // LDS of k_cert_big: the leftover queries of the workgroup's points (every point can be one), reduction scratch
+#define MULLS_BIG_HASH 4096u // class-level jobs: slots of the on-chip duplicate table (at most 1536 targets are claimed: load <= 0.375)
 template <int SLOTS>
 struct BigLds
 {
@@ -216,13 +217,40 @@ struct BigLds
 	float um[SLOTS];	// how far this iteration's step moved the listed point (the k-candidate certificate's look needs it)
 	uint16_t us[SLOTS]; // the query's slot among the workgroup's points (| MULLS_US16_KCERT: a hinted point, gets the look)
 	uint32_t ucount, red[3 * 16];
+	// class-level jobs (the workgroup holds every query of its class cloud): what a search found for the point of slot k — correspondence and squared distance, read by
+	// the owner lane's tail from here instead of from nn_idx / nn_d2 in memory — and the duplicate table as an open-addressing hash of the claimed targets (the
+	// batch's winner table took a device-scope fence and a gather past the L2 per point: the chain of a workgroup whose points all certify was mostly that)
+	uint2 res[SLOTS];
+	uint32_t hkey[MULLS_BIG_HASH], hval[MULLS_BIG_HASH];
 };
-
-// device-scope read of a duplicate-table entry this workgroup's atomics may have lowered (a plain load could be served by a line the CU's
-// vector cache fetched for a neighbouring class cloud's workgroup)
-__device__ __forceinline__ unsigned long long winner_now(const unsigned long long *w)
+// lowest source slot that claims target t (duplicate rule: the first source in the serial walk keeps a target, cregistration.hpp:1762-1789)
+template <int SLOTS>
+__device__ __forceinline__ void big_hash_min(BigLds<SLOTS> &CL, uint32_t t, uint32_t s)
 {
-	return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	uint32_t h = (t * 2654435761u) >> 20;
+	for (;;)
+	{
+		const uint32_t k = atomicCAS(&CL.hkey[h], 0xffffffffu, t);
+		if (k == 0xffffffffu || k == t)
+		{
+			atomicMin(&CL.hval[h], s);
+			return;
+		}
+		h = (h + 1u) & (MULLS_BIG_HASH - 1u);
+	}
+}
+// ... of a target this workgroup has claimed (after the barrier that completes the table)
+template <int SLOTS>
+__device__ __forceinline__ uint32_t big_hash_get(const BigLds<SLOTS> &CL, uint32_t t)
+{
+	uint32_t h = (t * 2654435761u) >> 20;
+	for (uint32_t n = 0; n < MULLS_BIG_HASH; n++)
+	{
+		if (CL.hkey[h] == t)
+			return CL.hval[h];
+		h = (h + 1u) & (MULLS_BIG_HASH - 1u);
+	}
+	return 0xffffffffu;
 }
 
 // One job of the big tier: the source points [q0, q1) of class cloud d by one workgroup of BLK lanes, at most TRIPS * BLK of them.
@@ -244,7 +272,14 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	const bool kc = rp.kcert != 0u && have_prev && called && C.cand != nullptr; // (uniform)
 	const uint32_t nq = q1 > q0 ? q1 - q0 : 0u;
 	const uint32_t ntrips = (nq + BLK - 1u) / BLK; // uniform
-	const unsigned long long *wtab = winner + d.tgt_off;
+	static_assert((1u << 12) == MULLS_BIG_HASH && BLK * TRIPS <= 1536, "big_hash_min's 12-bit hash; at most 1536 claims");
+	const bool hashed = class_level && C.gate; // (uniform) the duplicate rule is in force and every query of the cloud is this workgroup's: the table stays on chip
+	auto claim = [&](uint32_t t, uint32_t src) {
+		if (hashed)
+			big_hash_min(CL, t, src);
+		else
+			atomicMin(&winner[d.tgt_off + t], C.key_hi | (unsigned long long)src);
+	};
 
 	struct Rec
 	{
@@ -346,7 +381,7 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 						if ((int32_t)hj == r.pm)
 							ST[k] |= MULLS_FS_STANDING;
 						if (C.gate)
-							atomicMin(&winner[d.tgt_off + hj], C.key_hi | (unsigned long long)s);
+							claim(hj, s);
 					}
 				}
 			}
@@ -354,7 +389,7 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 		if (!certified)
 		{
 			M[k] = MULLS_NEEDS_SEARCH;
-			D0[k] = out.w;
+			D0[k] = __int_as_float(r.pm); // (the sweep radius travels in the list entry; the tail wants the standing match)
 			const uint32_t u = atomicAdd(&CL.ucount, 1u);
 			const bool second = kc && hj < tgt_n; // a hinted point: the k-candidate certificate gets a look before the search (below)
 			CL.uq[u] = out;
@@ -368,6 +403,9 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 		r1 = load(1);
 	if (threadIdx.x == 0)
 		CL.ucount = 0u;
+	if (hashed)
+		for (uint32_t i = threadIdx.x; i < MULLS_BIG_HASH; i += BLK)
+			CL.hkey[i] = 0xffffffffu, CL.hval[i] = 0xffffffffu;
 	__syncthreads();
 	cert(0, r0);
 	if (ntrips > 2u)
@@ -421,15 +459,20 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 						const float best = key_dist(bk);
 						const uint32_t bi = (uint32_t)bk;
 						const bool matched = !((double)best > C.max_dist_sqr);
-						nn_idx[gi] = matched ? (int32_t)bi : -1;
-						nn_d2[gi] = best;
+						if (class_level)
+							CL.res[es] = make_uint2(matched ? bi : 0xffffffffu, __float_as_uint(best));
+						else
+						{
+							nn_idx[gi] = matched ? (int32_t)bi : -1;
+							nn_d2[gi] = best;
+						}
 						hint2[gi] = make_int2((int32_t)bi, __float_as_int(lb_next));
 						C.cand[gi] = cr_next;
 						if (matched)
 						{
 							matched_cnt++;
 							if (C.gate)
-								atomicMin(&winner[d.tgt_off + bi], C.key_hi | (unsigned long long)s);
+								claim(bi, s);
 						}
 						keep = false;
 						n_pass++;
@@ -484,12 +527,17 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 			search_query_bm(g, B, ts, CL.uq[i], C.r, C.m, sub, probe_own, bk, sec, Rfin, co);
 			if (sub == 0)
 			{
-				const uint32_t s = q0 + (CL.us[i] & ~MULLS_US16_KCERT), gi = d.src_off + s;
+				const uint32_t slot = CL.us[i] & ~MULLS_US16_KCERT, s = q0 + slot, gi = d.src_off + s;
 				const float best = key_dist(bk);
 				const int bi = (int)(uint32_t)bk; // -1: nothing found
 				const bool matched = bi >= 0 && !((double)best > C.max_dist_sqr);
-				nn_idx[gi] = matched ? bi : -1;
-				nn_d2[gi] = best;
+				if (class_level)
+					CL.res[slot] = make_uint2(matched ? (uint32_t)bi : 0xffffffffu, __float_as_uint(best));
+				else
+				{
+					nn_idx[gi] = matched ? bi : -1;
+					nn_d2[gi] = best;
+				}
 				const float lb_new = fminf(sqrtf(sec), Rfin);
 				hint2[gi] = make_int2(bi, __float_as_int(lb_new)); // every target but the one found is at least that far away
 				if (C.cand) // the other lanes' nearest targets, and how much farther everything outside {result, candidates} lies (co.b2 >= sec)
@@ -498,7 +546,7 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 				{
 					matched_cnt++;
 					if (C.gate)
-						atomicMin(&winner[d.tgt_off + (uint32_t)bi], C.key_hi | (unsigned long long)s);
+						claim((uint32_t)bi, s);
 				}
 			}
 		}
@@ -542,7 +590,7 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 	}
 	if ((threadIdx.x & 63) == 0)
 		CL.red[threadIdx.x >> 6] = matched_cnt;
-	__threadfence(); // the searched points' nn_idx / nn_d2 (read back below by the lanes that own them) and this workgroup's winner entries
+	__threadfence_block(); // the searched points' results and the duplicate table: LDS (class-level jobs only reach this)
 	__syncthreads();
 	uint32_t total_matched = 0;
 	for (int w = 0; w < BLK / 64; w++)
@@ -564,12 +612,13 @@ __device__ __forceinline__ void cert_big(BigLds<BLK * TRIPS> &CL, const RunParam
 		bool standing = (st & MULLS_FS_STANDING) != 0;
 		if (m == MULLS_NEEDS_SEARCH)
 		{
-			m = nn_idx[gi];
-			dist = nn_d2[gi];
-			standing = m >= 0 && match[gi] == m;
+			const uint2 found = CL.res[threadIdx.x + (uint32_t)k * BLK];
+			m = (int32_t)found.x;
+			standing = m >= 0 && __float_as_int(dist) == m; // (D0 of a waiting point: its standing match)
+			dist = __uint_as_float(found.y);
 		}
 		// first source (lowest index) matched to a target keeps it (cregistration.hpp:1762-1789); the others become unmatched
-		if (C.gate && m >= 0 && winner_now(wtab + (uint32_t)m) != (C.key_hi | (unsigned long long)s))
+		if (hashed && m >= 0 && big_hash_get(CL, (uint32_t)m) != s)
 			m = -1;
 		bool alive = true, valid, dir_ok = (st & MULLS_FS_DIR_OK) != 0;
 		if (any_match)
