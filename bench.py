@@ -191,11 +191,11 @@ def rank_span(args, world, rank):
 # other_configs: compact legs of the other BASELINE configurations inside the default line (the driver runs only `python bench.py --gpus 1`)
 OTHER_LEGS = {
     # name: (pairs per step, timed steps, pairs checked against the oracle)
-    "configs[2]": (32, 4, 2),
-    "configs[4]": (16, 3, 1),
-    "scan_to_map_20k": (64, 8, 2),
-    "configs[3]_shard_128": (128, 10, 4),
-    "configs[0]": (512, 4, 3),
+    "configs[2]": (32, 4, 8),
+    "configs[4]": (16, 3, 4),
+    "scan_to_map_20k": (64, 8, 8),
+    "configs[3]_shard_128": (128, 10, 8),
+    "configs[0]": (512, 4, 8),  # (+ the fixture's three registrations against the reference's own lines' results)
 }
 
 
@@ -682,9 +682,8 @@ def main(argv=None, engine_factory=None):
         checks = oracle_check_prepare(pairs, P, 16) if pairs else []
         checks_conv = oracle_check_prepare(pairs, converging_params(args.tiny), 8) if pairs and not args.no_converging else None
     if others_on:  # the checker's results of a few pairs of every leg (also with --no-cpu-baseline: a leg without its delta T is half a leg)
-        for name, (opairs, oP) in other_work.items():
-            if name != "configs[0]":  # (configs[0] is held to the reference's own lines' results, which travel in the fixture)
-                other_checks[name] = oracle_check_prepare(opairs, oP, OTHER_LEGS[name][2])
+        for name, (opairs, oP) in other_work.items():  # (configs[0] is held to the reference's own lines' results too, which travel in the fixture)
+            other_checks[name] = oracle_check_prepare(opairs, oP, OTHER_LEGS[name][2])
 
     import torch
     import torch.distributed as dist
@@ -765,7 +764,8 @@ def main(argv=None, engine_factory=None):
             for k in prof_keys:
                 acc[k] += pf.icp_phase_ms[5] if k == "icp_loop_ms" else getattr(pf, k)
         if os.environ.get("MULLS_BENCH_TRACE"):
-            print("step %.2f ms: host launch %.2f wait %.2f search %.2f" % (step_s[-1] * 1e3, pf.ms_host_launch, pf.ms_host_wait, pf.ms_nn), file=sys.stderr)
+            tp = engine.profile()  # (batches below 512 pairs run the timed steps without the event pairs: the host-side fields are filled either way)
+            print("step %.2f ms: host launch %.2f wait %.2f search %.2f" % (step_s[-1] * 1e3, tp.ms_host_launch, tp.ms_host_wait, tp.ms_nn), file=sys.stderr)
     gathered = shard.gather_wait(pending)
     barrier()
     elapsed = time.perf_counter() - t0

@@ -74,6 +74,9 @@ inline mulls_cloud borrow(const CloudPtr &cloud)
 // When set (default), block1->tree_{ground,pillar,beam,facade,roof,vertex} are rebuilt on the cropped target clouds
 // like cregistration.hpp:1209-1232 does, because MapManager::map_based_dynamic_close_removal (src/map_manager.cpp:187-243)
 // queries them on the next frame.  The registration itself never uses a CPU kd-tree.  Benchmarks switch it off.
+// The switch only matters while the process keeps NO device-resident local map: as soon as lo::hip::update_local_map() has
+// created a mirror, the trees' one consumer runs on the device against that mirror and no registration builds them — neither
+// the scan-to-map one (its block1 has the mirror) nor the scan-to-scan one against the previous frame's block.
 inline bool &build_cpu_trees()
 {
 	static bool on = true;
@@ -257,7 +260,7 @@ int mm_lls_icp(constraint_t &registration_cons, // cblock_1 (target point cloud)
 		for (int c = 0; c < 6; c++)
 			mirror->tree_used[c] = (used_feature_type[c] == '1' && R.ntgt0[c] > 0) ? '1' : '0';
 	}
-	if (build_cpu_trees() && !mirror)
+	if (build_cpu_trees() && !mirror && map_mirrors().empty())
 	{
 		// kd-tree side effect of cregistration.hpp:1209-1232: trees over the intersection-filtered target clouds
 		typedef typename pcl::PointCloud<PointT> Cloud;

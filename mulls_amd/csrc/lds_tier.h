@@ -841,7 +841,11 @@ __device__ __forceinline__ bool kcert_point(const RunParams &rp, const uint4 cr,
 	const uint32_t hj = W16 ? ((uint32_t)h.x & 0xffffu) : (uint32_t)h.x; // (hj < tgt_n: the caller's condition)
 	if (!(rp.kcert != 0u && cr.w - rp.tick_base <= iter)) // not written by a search of THIS run (unsigned: an older or a zeroed record wraps far above iter)
 		return false;
-	const float Bp = __int_as_float(h.y) + __uint_as_float(cr.z); // every target outside the set kept at least this distance before the step
+	// every target outside the set kept at least this distance before the step.  The bound travels as the sum of two floats (h.y is lowered by every step's move and
+	// may have gone negative while cr.z stayed large): the sum's rounding error is absolute — up to an ulp of the larger term — which the relative 1e-5 margins
+	// below do not cover when the sum is small; four such ulps are taken off (advisor, round 5)
+	const float hy = __int_as_float(h.y), crz = __uint_as_float(cr.z);
+	const float Bp = (hy + crz) - 4.0f * 1.1920929e-7f * fmaxf(fabsf(hy), fabsf(crz));
 	if (!(moved * 1.00001f < Bp * 0.99999f))					   // hopeless whatever the candidates' distances are: no gathers
 		return false;
 	// every load of a stage is issued before the first is used, at indices that are valid whatever the record holds (an absent candidate re-reads the hint)

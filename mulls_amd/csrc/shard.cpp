@@ -110,7 +110,16 @@ extern "C"
 		{
 			int lo, hi;
 			block_of(n, n_ctx, r, &lo, &hi);
-			th.emplace_back([=, &rcs] { rcs[(size_t)r] = run_shard(ctxs[r], pairs, lo, hi, params, results); });
+			try
+			{
+				th.emplace_back([=, &rcs] { rcs[(size_t)r] = run_shard(ctxs[r], pairs, lo, hi, params, results); });
+			}
+			catch (...) // no thread to be had: the shards already running are waited for (a joinable std::thread must not be destroyed), nothing leaves the ABI
+			{
+				for (auto &t : th)
+					t.join();
+				return MULLS_E_NOMEM;
+			}
 		}
 		int lo0, hi0;
 		block_of(n, n_ctx, 0, &lo0, &hi0);
@@ -161,8 +170,16 @@ extern "C"
 			}
 			P->lanes.push_back(std::move(L));
 		}
-		for (auto &l : P->lanes)
-			l->th = std::thread(lane_main, l.get());
+		try
+		{
+			for (auto &l : P->lanes)
+				l->th = std::thread(lane_main, l.get());
+		}
+		catch (...) // no thread to be had: the lanes already started are stopped and joined, every context destroyed
+		{
+			mulls_pipe_destroy(P.release());
+			return MULLS_E_NOMEM;
+		}
 		*out = P.release();
 		return MULLS_OK;
 	}
