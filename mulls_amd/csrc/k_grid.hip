@@ -15,7 +15,35 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const uint32_t *__rest
 // Wave aggregation of the bitmap kernels' atomics.  A dense map puts hundreds of consecutive scan points into one cell (and thousands into one 64-cell
 // word): one atomic per point on the same address took 316 + 133 + 170 us for a 1 M-point map (profiles/r04_large_steps.txt).  The lanes of a wave that
 // share the address are served by one leader, MULLS_BM_ROUNDS distinct addresses per wave; what is left (sparse clouds: every lane its own cell) goes one by one.
+// Round 6: the groups are FOUND first (ballots and lane reads only), then every leader issues its atomic in ONE instruction — the rounds used to be a chain of
+// dependent memory operations each (a pre-check load and the atomic; in the scatter an atomic whose result the round waited for): up to five round trips per
+// 256-point workgroup where one is needed (k_bm_mark 1 285 -> 460 us, k_bm_scatter 874 -> 520 us on configs[2]'s 32 x 961 k points: profiles/r06_experiments.txt).
 #define MULLS_BM_ROUNDS 4
+// the lanes of a wave that hold the same key, MULLS_BM_ROUNDS groups at most: leader = the group's first lane (the lane itself when it stayed alone),
+// rank = its position among the group's lanes, size = the group's lanes.  Every lane of the wave calls it.
+__device__ __forceinline__ void wave_groups(uint32_t key, bool in, int lane, int &leader, uint32_t &rank, uint32_t &size, unsigned long long &members)
+{
+	bool pending = in;
+	leader = lane, rank = 0u, size = in ? 1u : 0u, members = in ? (1ull << lane) : 0ull;
+	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
+	{
+		const unsigned long long act = __ballot(pending);
+		if (!act)
+			break;
+		const int l = __ffsll((long long)act) - 1;
+		const uint32_t lk = (uint32_t)__shfl((int)key, l);
+		const bool mine = pending && key == lk;
+		const unsigned long long m = __ballot(mine);
+		if (mine)
+		{
+			leader = l;
+			rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			size = (uint32_t)__popcll(m);
+			members = m;
+		}
+		pending = pending && !mine;
+	}
+}
 __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
 														  const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 														  unsigned long long *__restrict__ bm)
@@ -24,10 +52,10 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__
 	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const uint32_t t = job.start + threadIdx.x;
 	const int lane = threadIdx.x & 63;
-	bool pending = t < d.tgt_n;
+	const bool in = t < d.tgt_n;
 	uint32_t widx = 0xffffffffu;
 	unsigned long long b = 0ull;
-	if (pending)
+	if (in)
 	{
 		const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
 		const float4 p = tpos[d.tgt_off + t];
@@ -35,23 +63,30 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__
 		widx = g.cell_off + (bit >> 6);
 		b = 1ull << (bit & 63u);
 	}
+	// the groups of lanes that share a word, their bits OR-ed into the group's first lane (wave_groups' rounds with a butterfly over the members each)
+	bool pending = in, lead = in;
+	unsigned long long v = b;
 	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
 	{
 		const unsigned long long act = __ballot(pending);
 		if (!act)
 			break;
-		const int leader = __ffsll((long long)act) - 1;
-		const uint32_t lw = (uint32_t)__shfl((int)widx, leader);
+		const int l = __ffsll((long long)act) - 1;
+		const uint32_t lw = (uint32_t)__shfl((int)widx, l);
 		const bool mine = pending && widx == lw;
-		unsigned long long v = mine ? b : 0ull;
+		unsigned long long g = mine ? b : 0ull;
 		for (int off = 32; off > 0; off >>= 1)
-			v |= __shfl_xor(v, off);
-		if (lane == leader && (__builtin_nontemporal_load(&bm[lw]) & v) != v) // most words of a dense map are complete after their first few waves
-			atomicOr(&bm[lw], v);
+			g |= __shfl_xor(g, off);
+		if (mine)
+		{
+			v = g;
+			lead = lane == l;
+		}
 		pending = pending && !mine;
 	}
-	if (pending && !(__builtin_nontemporal_load(&bm[widx]) & b))
-		atomicOr(&bm[widx], b);
+	const int leader = lead ? lane : -1;
+	if (in && lane == leader)
+		atomicOr(&bm[widx], v); // (no result wanted: nothing waits for it)
 }
 
 __global__ __launch_bounds__(1024) void k_bm_scan(const uint32_t *__restrict__ lclouds, GridDesc *__restrict__ grids, const unsigned long long *__restrict__ bm,
@@ -77,29 +112,20 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict_
 	const CloudDesc &d = descs[ci];
 	const uint32_t t = job.start + threadIdx.x;
 	const int lane = threadIdx.x & 63;
-	bool pending = t < d.tgt_n;
+	const bool in = t < d.tgt_n;
 	uint32_t r = 0xffffffffu; // counter of this point's cell
-	if (pending)
+	if (in)
 	{
 		const GridDesc g = grids[ci];
 		const float4 p = tpos[d.tgt_off + t];
 		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
 	}
-	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
-	{
-		const unsigned long long act = __ballot(pending);
-		if (!act)
-			break;
-		const int leader = __ffsll((long long)act) - 1;
-		const uint32_t lr = (uint32_t)__shfl((int)r, leader);
-		const bool mine = pending && r == lr;
-		const unsigned long long m = __ballot(mine);
-		if (lane == leader)
-			atomicAdd(&cnt[lr], (uint32_t)__popcll(m));
-		pending = pending && !mine;
-	}
-	if (pending)
-		atomicAdd(&cnt[r], 1u);
+	int leader;
+	uint32_t rank, size;
+	unsigned long long members;
+	wave_groups(r, in, lane, leader, rank, size, members);
+	if (in && lane == leader)
+		atomicAdd(&cnt[r], size);
 }
 
 // counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors
@@ -133,8 +159,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restric
 	const uint32_t t = job.start + threadIdx.x;
 	const int lane = threadIdx.x & 63;
 	const bool in = t < d.tgt_n;
-	bool pending = in;
-	uint32_t r = 0xffffffffu, slot = 0;
+	uint32_t r = 0xffffffffu;
 	float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if (in)
 	{
@@ -142,27 +167,16 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restric
 		p = tpos[d.tgt_off + t];
 		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
 	}
-	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
-	{
-		const unsigned long long act = __ballot(pending);
-		if (!act)
-			break;
-		const int leader = __ffsll((long long)act) - 1;
-		const uint32_t lr = (uint32_t)__shfl((int)r, leader);
-		const bool mine = pending && r == lr;
-		const unsigned long long m = __ballot(mine);
-		uint32_t base = 0;
-		if (lane == leader)
-			base = cs[lr] + atomicAdd(&cnt[lr], (uint32_t)__popcll(m));
-		base = (uint32_t)__shfl((int)base, leader);
-		if (mine)
-			slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-		pending = pending && !mine;
-	}
-	if (pending)
-		slot = cs[r] + atomicAdd(&cnt[r], 1u);
+	int leader;
+	uint32_t rank, size;
+	unsigned long long members;
+	wave_groups(r, in, lane, leader, rank, size, members);
+	uint32_t base = 0;
+	if (in && lane == leader)
+		base = cs[r] + atomicAdd(&cnt[r], size); // every leader of the wave in one instruction: one round trip
+	base = (uint32_t)__shfl((int)base, leader);
 	if (in)
-		tsorted[d.tgt_off + slot] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
+		tsorted[d.tgt_off + base + rank] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
