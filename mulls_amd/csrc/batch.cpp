@@ -961,6 +961,7 @@ int prepare_run(mulls_ctx *ctx, mulls_batch *B, const mulls_params *P_jobs, RunP
 		A(grow(ctx, &B->pf, &B->cap_pf, words));
 		A(grow(ctx, &B->bm_cs, &B->cap_bm_cs, cells));
 		A(grow(ctx, &B->cell_cnt, &B->cap_cells[0], cells));
+		A(grow(ctx, &B->bm_rank, &B->cap_bm_rank, 2 * B->n_tgt)); // (counter index, arrival) per target point
 		if (rc == MULLS_OK)
 		{
 			HIPCHK(ctx, hipMemsetAsync(B->cell_cnt, 0, cells * sizeof(uint32_t), st));

@@ -115,6 +115,9 @@ struct mulls_batch
 	size_t cap_bjobs[4] = {};
 	uint32_t *bm_cs = nullptr; // bitmap grids: first sorted position of every occupied cell (indexed like cell_cnt)
 	size_t cap_bm_cs = 0;
+	uint32_t *bm_rank = nullptr; // bitmap grids: every target point's (cell counter index, arrival number in its cell), from k_bm_count to k_bm_scatter — the scatter is
+								 // pure data movement: one pass of atomics per build instead of two
+	size_t cap_bm_rank = 0;
 	Job *rjobs = nullptr;
 	uint32_t *ajobs = nullptr;
 	size_t cap_ajobs = 0;

@@ -44,49 +44,64 @@ __device__ __forceinline__ void wave_groups(uint32_t key, bool in, int lane, int
 		pending = pending && !mine;
 	}
 }
-__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+#define MULLS_BM_CH 4 // consecutive 256-point chunks per workgroup of the per-point kernels (k_bm_count explains)
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_mark(const Job *__restrict__ tjobs, uint32_t ntjobs, const CloudDesc *__restrict__ descs,
 														  const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 														  unsigned long long *__restrict__ bm)
 {
-	const Job job = tjobs[blockIdx.x];
-	const CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
-	const uint32_t t = job.start + threadIdx.x;
 	const int lane = threadIdx.x & 63;
-	const bool in = t < d.tgt_n;
-	uint32_t widx = 0xffffffffu;
-	unsigned long long b = 0ull;
-	if (in)
+	Job job[MULLS_BM_CH];
+	uint32_t ci[MULLS_BM_CH], toff[MULLS_BM_CH], tn[MULLS_BM_CH];
+	bool in[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		job[u] = tjobs[min(blockIdx.x * MULLS_BM_CH + (uint32_t)u, ntjobs - 1u)];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
 	{
-		const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-		const float4 p = tpos[d.tgt_off + t];
-		const uint32_t bit = bm_bit(g, p.x, p.y, p.z);
-		widx = g.cell_off + (bit >> 6);
-		b = 1ull << (bit & 63u);
+		ci[u] = job[u].pair * MULLS_NC + job[u].cls;
+		toff[u] = descs[ci[u]].tgt_off, tn[u] = descs[ci[u]].tgt_n;
 	}
-	// the groups of lanes that share a word, their bits OR-ed into the group's first lane (wave_groups' rounds with a butterfly over the members each)
-	bool pending = in, lead = in;
-	unsigned long long v = b;
-	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
+	GridDesc g[MULLS_BM_CH];
+	float4 p[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
 	{
-		const unsigned long long act = __ballot(pending);
-		if (!act)
-			break;
-		const int l = __ffsll((long long)act) - 1;
-		const uint32_t lw = (uint32_t)__shfl((int)widx, l);
-		const bool mine = pending && widx == lw;
-		unsigned long long g = mine ? b : 0ull;
-		for (int off = 32; off > 0; off >>= 1)
-			g |= __shfl_xor(g, off);
-		if (mine)
+		g[u] = grids[ci[u]];
+		const uint32_t t = job[u].start + threadIdx.x;
+		in[u] = blockIdx.x * MULLS_BM_CH + (uint32_t)u < ntjobs && t < tn[u];
+		p[u] = tpos[toff[u] + (in[u] ? t : 0u)]; // (clamped: no control flow between the loads)
+	}
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+	{
+		const uint32_t bit = in[u] ? bm_bit(g[u], p[u].x, p[u].y, p[u].z) : 0u;
+		const uint32_t widx = in[u] ? g[u].cell_off + (bit >> 6) : 0xffffffffu;
+		const unsigned long long b = 1ull << (bit & 63u);
+		// the groups of lanes that share a word, their bits OR-ed into the group's first lane (wave_groups' rounds with a butterfly over the members each)
+		bool pending = in[u], lead = in[u];
+		unsigned long long v = b;
+		for (int round = 0; round < MULLS_BM_ROUNDS; round++)
 		{
-			v = g;
-			lead = lane == l;
+			const unsigned long long act = __ballot(pending);
+			if (!act)
+				break;
+			const int l = __ffsll((long long)act) - 1;
+			const uint32_t lw = (uint32_t)__shfl((int)widx, l);
+			const bool mine = pending && widx == lw;
+			unsigned long long gb = mine ? b : 0ull;
+			for (int off = 32; off > 0; off >>= 1)
+				gb |= __shfl_xor(gb, off);
+			if (mine)
+			{
+				v = gb;
+				lead = lane == l;
+			}
+			pending = pending && !mine;
 		}
-		pending = pending && !mine;
+		if (in[u] && lead)
+			atomicOr(&bm[widx], v); // (no result wanted: nothing waits for it)
 	}
-	const int leader = lead ? lane : -1;
-	if (in && lane == leader)
-		atomicOr(&bm[widx], v); // (no result wanted: nothing waits for it)
 }
 
 __global__ __launch_bounds__(1024) void k_bm_scan(const uint32_t *__restrict__ lclouds, GridDesc *__restrict__ grids, const unsigned long long *__restrict__ bm,
@@ -102,30 +117,61 @@ __global__ __launch_bounds__(1024) void k_bm_scan(const uint32_t *__restrict__ l
 		grids[ci].nocc = nocc;
 }
 
-__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
+// MULLS_BM_CH consecutive 256-point chunks per workgroup, every stage's loads of all chunks issued before the first is used: a chunk is a chain of five dependent
+// round trips (job -> descriptor -> grid -> point -> bitmap word and rank prefix) around one atomic, and with one chunk per workgroup the launch was as long as
+// that chain times the rounds of workgroups (30 M map points: 120 000 workgroups, 58 rounds).  The chunks may belong to different class clouds.
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict__ tjobs, uint32_t ntjobs, const CloudDesc *__restrict__ descs,
 														   const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
 														   const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
-														   uint32_t *__restrict__ cnt)
+														   uint32_t *__restrict__ cnt, uint32_t *__restrict__ rk)
 {
-	const Job job = tjobs[blockIdx.x];
-	const uint32_t ci = job.pair * MULLS_NC + job.cls;
-	const CloudDesc &d = descs[ci];
-	const uint32_t t = job.start + threadIdx.x;
 	const int lane = threadIdx.x & 63;
-	const bool in = t < d.tgt_n;
-	uint32_t r = 0xffffffffu; // counter of this point's cell
-	if (in)
+	Job job[MULLS_BM_CH];
+	uint32_t ci[MULLS_BM_CH], toff[MULLS_BM_CH], tn[MULLS_BM_CH], t[MULLS_BM_CH];
+	bool in[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		job[u] = tjobs[min(blockIdx.x * MULLS_BM_CH + (uint32_t)u, ntjobs - 1u)];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
 	{
-		const GridDesc g = grids[ci];
-		const float4 p = tpos[d.tgt_off + t];
-		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
+		ci[u] = job[u].pair * MULLS_NC + job[u].cls;
+		toff[u] = descs[ci[u]].tgt_off, tn[u] = descs[ci[u]].tgt_n;
 	}
-	int leader;
-	uint32_t rank, size;
-	unsigned long long members;
-	wave_groups(r, in, lane, leader, rank, size, members);
-	if (in && lane == leader)
-		atomicAdd(&cnt[r], size);
+	GridDesc g[MULLS_BM_CH];
+	float4 p[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+	{
+		g[u] = grids[ci[u]];
+		t[u] = job[u].start + threadIdx.x;
+		in[u] = blockIdx.x * MULLS_BM_CH + (uint32_t)u < ntjobs && t[u] < tn[u];
+		p[u] = tpos[toff[u] + (in[u] ? t[u] : 0u)]; // (clamped: no control flow between the loads)
+	}
+	uint32_t bit[MULLS_BM_CH], pre[MULLS_BM_CH];
+	unsigned long long w[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+	{
+		bit[u] = in[u] ? bm_bit(g[u], p[u].x, p[u].y, p[u].z) : 0u;
+		w[u] = bm[g[u].cell_off + (bit[u] >> 6)];
+		pre[u] = pf[g[u].cell_off + (bit[u] >> 6)];
+	}
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+	{
+		const uint32_t r = in[u] ? toff[u] + ci[u] + pre[u] + (uint32_t)__popcll(w[u] & ((1ull << (bit[u] & 63u)) - 1ull)) : 0xffffffffu; // counter of this point's cell (bm_rank)
+		int leader;
+		uint32_t rank, size;
+		unsigned long long members;
+		wave_groups(r, in[u], lane, leader, rank, size, members);
+		uint32_t first = 0u;
+		if (in[u] && lane == leader)
+			first = atomicAdd(&cnt[r], size); // the group's arrival numbers in its cell
+		first = (uint32_t)__shfl((int)first, leader);
+		if (in[u]) // k_bm_scatter reads both back: its slot is the cell's start + the arrival number — no second pass of atomics, no second ranking
+			reinterpret_cast<uint2 *>(rk)[toff[u] + t[u]] = make_uint2(r, first + rank);
+	}
 }
 
 // counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors
@@ -148,35 +194,40 @@ __global__ __launch_bounds__(1024) void k_bm_starts(const uint32_t *__restrict__
 
 // counting-sort scatter: target positions ordered by cell, original index carried in .w (the order inside a cell is whatever the atomics give: every
 // consumer breaks distance ties by original index)
-__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restrict__ tjobs, const CloudDesc *__restrict__ descs,
-															 const GridDesc *__restrict__ grids, const float4 *__restrict__ tpos,
-															 const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
-															 uint32_t *__restrict__ cnt, const uint32_t *__restrict__ cs, float4 *__restrict__ tsorted)
+__global__ __launch_bounds__(MULLS_BLOCK) void k_bm_scatter(const Job *__restrict__ tjobs, uint32_t ntjobs, const CloudDesc *__restrict__ descs,
+															 const float4 *__restrict__ tpos, const uint32_t *__restrict__ rk, const uint32_t *__restrict__ cs,
+															 float4 *__restrict__ tsorted)
 {
-	const Job job = tjobs[blockIdx.x];
-	const uint32_t ci = job.pair * MULLS_NC + job.cls;
-	const CloudDesc &d = descs[ci];
-	const uint32_t t = job.start + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	const bool in = t < d.tgt_n;
-	uint32_t r = 0xffffffffu;
-	float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	if (in)
+	Job job[MULLS_BM_CH];
+	uint32_t toff[MULLS_BM_CH], tn[MULLS_BM_CH], t[MULLS_BM_CH];
+	bool in[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		job[u] = tjobs[min(blockIdx.x * MULLS_BM_CH + (uint32_t)u, ntjobs - 1u)];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
 	{
-		const GridDesc g = grids[ci];
-		p = tpos[d.tgt_off + t];
-		r = d.tgt_off + ci + bm_rank(bm + g.cell_off, pf + g.cell_off, bm_bit(g, p.x, p.y, p.z));
+		const uint32_t ci = job[u].pair * MULLS_NC + job[u].cls;
+		toff[u] = descs[ci].tgt_off, tn[u] = descs[ci].tgt_n;
 	}
-	int leader;
-	uint32_t rank, size;
-	unsigned long long members;
-	wave_groups(r, in, lane, leader, rank, size, members);
-	uint32_t base = 0;
-	if (in && lane == leader)
-		base = cs[r] + atomicAdd(&cnt[r], size); // every leader of the wave in one instruction: one round trip
-	base = (uint32_t)__shfl((int)base, leader);
-	if (in)
-		tsorted[d.tgt_off + base + rank] = make_float4(p.x, p.y, p.z, __int_as_float((int)t));
+	float4 p[MULLS_BM_CH];
+	uint2 ra[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+	{
+		t[u] = job[u].start + threadIdx.x;
+		in[u] = blockIdx.x * MULLS_BM_CH + (uint32_t)u < ntjobs && t[u] < tn[u];
+		p[u] = tpos[toff[u] + (in[u] ? t[u] : 0u)];
+		ra[u] = reinterpret_cast<const uint2 *>(rk)[toff[u] + (in[u] ? t[u] : 0u)]; // (k_bm_count's counter index and arrival number)
+	}
+	uint32_t start[MULLS_BM_CH];
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		start[u] = in[u] ? cs[ra[u].x] : 0u;
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		if (in[u])
+			tsorted[toff[u] + start[u] + ra[u].y] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float((int)t[u]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -584,19 +635,19 @@ void launch_grid_build_sort(hipStream_t st, uint32_t npairs, const CloudDesc *de
 // global-memory tier: occupancy bitmap + ranks + counting sort by rank (cs holds the start positions) of the `nl` class clouds lclouds[]; tjobs = their
 // 256-point chunks
 void launch_bm_build(hipStream_t st, uint32_t nl, const uint32_t *lclouds, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids, const float4 *tpos,
-					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted)
+					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted, uint32_t *rank)
 {
 	if (!nl)
 		return;
 	hipLaunchKernelGGL(k_bm_clear, dim3(nl, nl >= 64 ? 4 : 64), dim3(MULLS_BLOCK), 0, st, lclouds, grids, bm);
 	if (ntjobs)
-		hipLaunchKernelGGL(k_bm_mark, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm);
+		hipLaunchKernelGGL(k_bm_mark, dim3((ntjobs + MULLS_BM_CH - 1) / MULLS_BM_CH), dim3(MULLS_BLOCK), 0, st, tjobs, ntjobs, descs, grids, tpos, bm);
 	hipLaunchKernelGGL(k_bm_scan, dim3(nl), dim3(1024), 0, st, lclouds, grids, bm, pf);
 	if (ntjobs)
-		hipLaunchKernelGGL(k_bm_count, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt);
+		hipLaunchKernelGGL(k_bm_count, dim3((ntjobs + MULLS_BM_CH - 1) / MULLS_BM_CH), dim3(MULLS_BLOCK), 0, st, tjobs, ntjobs, descs, grids, tpos, bm, pf, cnt, rank);
 	hipLaunchKernelGGL(k_bm_starts, dim3(nl), dim3(1024), 0, st, lclouds, descs, grids, cnt, cs);
 	if (ntjobs)
-		hipLaunchKernelGGL(k_bm_scatter, dim3(ntjobs), dim3(MULLS_BLOCK), 0, st, tjobs, descs, grids, tpos, bm, pf, cnt, cs, tsorted);
+		hipLaunchKernelGGL(k_bm_scatter, dim3((ntjobs + MULLS_BM_CH - 1) / MULLS_BM_CH), dim3(MULLS_BLOCK), 0, st, tjobs, ntjobs, descs, tpos, rank, cs, tsorted);
 }
 
 int launch_tgt_grid(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSetup *setup, const uint32_t *bbox, const float4 *stage, const RunParams &rp,

@@ -57,7 +57,7 @@ void launch_grid_build_sort(hipStream_t st, uint32_t npairs, const CloudDesc *de
 							float4 *tsorted);
 // bitmap grids of the `nl` class clouds lclouds[] (pair * MULLS_NC + class each); tjobs: their 256-point chunks
 void launch_bm_build(hipStream_t st, uint32_t nl, const uint32_t *lclouds, uint32_t ntjobs, const Job *tjobs, const CloudDesc *descs, GridDesc *grids, const float4 *tpos,
-					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted);
+					 unsigned long long *bm, uint32_t *pf, uint32_t *cnt, uint32_t *cs, float4 *tsorted, uint32_t *rank);
 size_t nn_lds_bytes(uint32_t cap, uint32_t maxcells, bool dedup);
 int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *descs, const PairState *states, const RunParams &rp, float4 *spos,
 				  float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx,

@@ -179,7 +179,7 @@ extern "C"
 		if (tier == 2)
 			launch_grid_build_sort(st, 1, B->descs, B->grids, *rp, B->tpos, B->cell_start, B->tsorted);
 		launch_bm_build(st, (uint32_t)B->lclouds_h.size(), B->lclouds, (uint32_t)B->tjobs_h.size(), B->tjobs, B->descs, B->grids, B->tpos, B->bm, B->pf, B->cell_cnt, B->bm_cs,
-						B->tsorted);
+						B->tsorted, B->bm_rank);
 		return MULLS_OK;
 	}
 	void identity_state(PairState *s, int iter)
