@@ -72,6 +72,55 @@ __device__ __forceinline__ AccumCtx accum_ctx(const RunParams &rp, int cls, int 
 	return A;
 }
 
+// The weight of one valid correspondence (normal-equation pass): class weight x distance weight x residual weight x intensity weight, multiplied in the order the
+// metric's summation function does (pt2pl cregistration.hpp:2103-2113, pt2li :2215-2224, pt2pt :2003-2012).  One function for every caller: k_accum_wave evaluates it
+// ONCE per slot and hands it to the term windows (the weights sit under run-time flags, and the compiler does not merge the copies of a conditional computation the
+// windows would otherwise carry: three double divisions, six float divisions and three square roots per slot instead of one, two and one).
+__device__ __forceinline__ float corr_weight(const AccumCtx &A, int metric, const float4 P, const float4 Q, const float4 N, float wi)
+{
+	const float px = P.x, py = P.y, pz = P.z;
+	const float qx = Q.x, qy = Q.y, qz = Q.z;
+	const float dist = sqrtf(qx * qx + qy * qy + qz * qz);
+	if (metric == 0)
+	{
+		float ntx = N.x, nty = N.y, ntz = N.z;
+		float w = A.class_w;
+		float dd = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
+		if (A.dist_w)
+			w = w * w_dist_adaptive(dist, A.iter_num);
+		if (A.resid_w)
+			w = w * w_residual(fabsf(dd), A.window);
+		if (A.inten_w)
+			w = w * wi;
+		return w;
+	}
+	if (metric == 1)
+	{
+		float vx = N.x, vy = N.y, vz = N.z;
+		float dx = px - qx, dy = py - qy, dz = pz - qz;
+		const double b0 = -vy * dz + vz * dy, b1 = -vz * dx + vx * dz, b2 = -vx * dy + vy * dx;
+		float ex = (float)fabs(b0), ey = (float)fabs(b1), ez = (float)fabs(b2);
+		float ed = sqrtf(ex * ex + ey * ey + ez * ez);
+		float wx = A.class_w;
+		if (A.dist_w)
+			wx *= w_dist_adaptive(dist, A.iter_num);
+		if (A.inten_w)
+			wx *= wi;
+		if (A.resid_w)
+			wx = wx * w_residual(ed, A.window);
+		return wx;
+	}
+	float dx = px - qx, dy = py - qy, dz = pz - qz;
+	float wx = A.class_w;
+	if (A.dist_w)
+		wx = wx * w_dist_adaptive(dist, A.iter_num);
+	if (A.resid_w)
+		wx = wx * w_residual(sqrtf(dx * dx + dy * dy + dz * dz), A.window);
+	if (A.inten_w)
+		wx = wx * wi;
+	return wx;
+}
+
 // One valid correspondence: source point P (current, transformed), matched target position Q and direction N (the record
 // filter_point wrote).  x: the solved step (residual pass only).  wdg: pcl::Correspondence's distance / weight union of this point.
 // Writes the terms T0 .. T0 + NT - 1 of the point's contribution into t[] (terms the metric does not have stay as they are: the
@@ -79,6 +128,7 @@ __device__ __forceinline__ AccumCtx accum_ctx(const RunParams &rp, int cls, int 
 // (point_wi; evaluated by the caller, once per point and away from the terms' registers — a double-precision exp).  TS = float where every term is a
 // float expression of the reference (point-to-plane and point-to-point normal equations) — it converts to double exactly when
 // the sum is taken, as the reference's `double += float expression` does — and double elsewhere.
+// wpre: the correspondence's weight if the caller has evaluated it already (corr_weight: the same value), else nullptr.
 // MODE 1 (point-to-line classes with AccumCtx::li_diag): the six diagonal terms (0, 6, 11, 15, 18, 20) and the six right-hand-side
 // terms (21..26) are numbered 0..11, and T0 / NT select among those
 __device__ __forceinline__ constexpr int li_slot(int k) { return k == 0 ? 0 : (k == 6 ? 1 : (k == 11 ? 2 : (k == 15 ? 3 : (k == 18 ? 4 : (k == 20 ? 5 : (k >= 21 ? k - 15 : -1)))))); }
@@ -97,11 +147,11 @@ __device__ __forceinline__ constexpr int li_term(int slot) { return slot == 0 ? 
 // METRIC >= 0: the caller knows the metric at compile time (k_accum_wave: the other metrics' arithmetic is not even compiled — their temporaries would set the
 // kernel's register count)
 template <typename TS, int T0, int NT, int MODE = 0, int METRIC = -1>
-__device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS t[NT])
+__device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &wdg, TS t[NT],
+											 const float *wpre = nullptr)
 {
-	const int metric = METRIC >= 0 ? METRIC : A.metric, iter_num = A.iter_num;
-	const bool residual_pass = A.residual_pass, dist_w = A.dist_w, resid_w = A.resid_w, inten_w = A.inten_w, faithful = A.faithful;
-	const float class_w = A.class_w, window = A.window;
+	const int metric = METRIC >= 0 ? METRIC : A.metric;
+	const bool residual_pass = A.residual_pass, faithful = A.faithful;
 	const float px = P.x, py = P.y, pz = P.z;
 	const float qx = Q.x, qy = Q.y, qz = Q.z;
 
@@ -169,21 +219,14 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 		return;
 	}
 
-	const float dist = sqrtf(qx * qx + qy * qy + qz * qz);
 	if (metric == 0) // pt2pl_lls_summation, cregistration.hpp:2066-2156
 	{
 		float ntx = N.x, nty = N.y, ntz = N.z;
-		float w = class_w;
 		float a = ntz * py - nty * pz;
 		float b = ntx * pz - ntz * px;
 		float c = nty * px - ntx * py;
 		float dd = ntx * qx + nty * qy + ntz * qz - ntx * px - nty * py - ntz * pz;
-		if (dist_w)
-			w = w * w_dist_adaptive(dist, iter_num);
-		if (resid_w)
-			w = w * w_residual(fabsf(dd), window);
-		if (inten_w)
-			w = w * wi;
+		const float w = wpre ? *wpre : corr_weight(A, 0, P, Q, N, wi);
 		wdg = w;
 		ACC(0, w * ntx * ntx);
 		ACC(1, w * ntx * nty);
@@ -215,6 +258,7 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 	}
 	else if (metric == 1) // pt2li_lls_pri_direction_summation, cregistration.hpp:2160-2275
 	{
+		const float wx = wpre ? *wpre : corr_weight(A, 1, P, Q, N, wi); // (in front of the local matrix A)
 		float vx = N.x, vy = N.y, vz = N.z;
 		float dx = px - qx, dy = py - qy, dz = pz - qz;
 		double A[3][6], bv[3];
@@ -239,15 +283,6 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 		bv[0] = -vy * dz + vz * dy;
 		bv[1] = -vz * dx + vx * dz;
 		bv[2] = -vx * dy + vy * dx;
-		float ex = (float)fabs(bv[0]), ey = (float)fabs(bv[1]), ez = (float)fabs(bv[2]);
-		float ed = sqrtf(ex * ex + ey * ey + ez * ez);
-		float wx = class_w;
-		if (dist_w)
-			wx *= w_dist_adaptive(dist, iter_num);
-		if (inten_w)
-			wx *= wi;
-		if (resid_w)
-			wx = wx * w_residual(ed, window);
 		wdg = wx;
 		const double sw = (double)sqrtf(wx);
 		for (int r = 0; r < 3; r++)
@@ -272,15 +307,8 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 	else // pt2pt_lls_summation, cregistration.hpp:1976-2063 (never writes the correspondence weight)
 	{
 		float dx = px - qx, dy = py - qy, dz = pz - qz;
-		float wx = class_w, wy, wz;
-		if (dist_w)
-			wx = wx * w_dist_adaptive(dist, iter_num);
-		if (resid_w)
-			wx = wx * w_residual(sqrtf(dx * dx + dy * dy + dz * dz), window);
-		if (inten_w)
-			wx = wx * wi;
-		wy = wx;
-		wz = wx;
+		const float wx = wpre ? *wpre : corr_weight(A, 2, P, Q, N, wi);
+		const float wy = wx, wz = wx;
 		if (!faithful)
 			wdg = wx; // intended behaviour: weight the vertex residual by its weight, not by d^2
 		ACC(0, wx);
@@ -316,7 +344,6 @@ __device__ __forceinline__ void point_terms(const AccumCtx &A, const double *x, 
 //   (in double), a butterfly adds the 64 partial sums ((xor 1, xor 2, mirror 8, mirror 16) inside the 16-lane rows, then
 //   (row0 + row1) + (row2 + row3)); the trip sums are added to 0.0 in trip order.
 #define MULLS_ACC_LANES 1024
-#define MULLS_WI_MAGIC 0x57493031u // marks a written entry of the intensity-weight memo (RunParams::wi_memo)
 #define MULLS_RED_BYTES ((size_t)27 * MULLS_ACC_LANES * sizeof(float)) // the LDS term buffer: 27 float terms, or 13 double terms, of 1024 slots
 #define MULLS_RED_BYTES_HALF ((size_t)14 * MULLS_ACC_LANES * sizeof(float)) // ... in the two-halves mode: 14 float terms (or 7 double terms)
 

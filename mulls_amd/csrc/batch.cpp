@@ -649,7 +649,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 
 	int rc = MULLS_OK;
 	auto A = [&](int r) { if (rc == MULLS_OK) rc = r; };
-	bool winner_grew = false, cand_grew = false, memo_grew = false;
+	bool winner_grew = false, cand_grew = false;
 	const size_t SG = (size_t)ctx->opt[MULLS_OPT_STAGGER]; // bytes between the starts of the per-point arrays inside their 2 MiB pages
 	A(grow(ctx, &B->stage, &B->cap_stage, stage_rec));
 	A(grow(ctx, &B->tmp_pos, &B->cap_src[0], so, nullptr, 12 * SG));
@@ -664,8 +664,6 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	A(grow(ctx, &B->nn_hint, &B->cap_src[9], 2 * so, nullptr, 8 * SG)); // LDS tier: (hint word, bound) records
 	A(grow(ctx, &B->mq, &B->cap_src[10], 2 * so, nullptr, 9 * SG));
 	A(grow(ctx, &B->nn_cand, &B->cap_src[11], so, &cand_grew, 14 * SG)); // k-candidate certificates: 16-byte candidate records
-	if (ctx->opt[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS] > 0.0)
-		A(grow(ctx, &B->wi_memo, &B->cap_src[12], so, &memo_grew, 15 * SG)); // k_accum_wave: memo of the intensity weight (the kernel runs without it: wi_memo null = no memo)
 	A(grow(ctx, &B->tpos, &B->cap_tgt[0], to));
 	A(grow(ctx, &B->tnrm, &B->cap_tgt[1], to));
 	A(grow(ctx, &B->tsorted, &B->cap_tgt[2], to, nullptr, 10 * SG));
@@ -813,8 +811,6 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 			return MULLS_E_HIP;
 		}
 	}
-	if (e == hipSuccess && memo_grew) // (an entry counts only with its magic word: fresh memory is cleared of chance hits)
-		e = hipMemsetAsync(B->wi_memo, 0, B->cap_src[12] * sizeof(uint4), st);
 	if (e == hipSuccess && cand_grew) // epoch 0 never passes the epoch test of a run (take_epochs starts at 1)
 		e = hipMemsetAsync(B->nn_cand, 0, B->cap_src[11] * sizeof(uint4), st);
 	if (e == hipSuccess && winner_grew) // later epochs always sort below older entries (k_nn), so only fresh memory needs the fill
@@ -1031,7 +1027,6 @@ int take_epochs(mulls_ctx *ctx, mulls_batch *B, uint32_t n, RunParams &rp)
 {
 	uint32_t *base = &rp.tick_base;
 	rp.cand = B->nn_cand;
-	rp.wi_memo = B->wi_memo;
 	if (ctx->opt[MULLS_OPT_DEBUG_TICK] > 0.0 && B->tick == 1) // tests only: put a fresh batch's counter next to the wrap
 		B->tick = (uint32_t)ctx->opt[MULLS_OPT_DEBUG_TICK];
 	if (B->tick > 0xfffffff0u - n)

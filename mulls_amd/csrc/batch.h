@@ -88,7 +88,6 @@ struct mulls_batch
 	float4 *spos = nullptr, *snrm = nullptr, *tpos = nullptr, *tnrm = nullptr;
 	uint8_t *flag = nullptr;
 	int32_t *match = nullptr, *nn_idx = nullptr, *nn_hint = nullptr;
-	uint4 *wi_memo = nullptr; // per source slot: memo of the intensity weight (RunParams::wi_memo)
 	uint4 *nn_cand = nullptr; // per source point: candidate record of the k-candidate certificates (RunParams::cand)
 	float4 *mq = nullptr; // per source point: position and direction of its matched target (2 records), written with match[]
 	float *wd = nullptr, *nn_d2 = nullptr;

@@ -215,6 +215,5 @@ struct RunParams
 	// the staged cloud at tgt_stage (tgt_record(), device_util.h).  Null: the cropped copies tpos / tnrm exist (k_crop).
 	const float4 *tgt_stage;
 	const uint16_t *tgt_map;
-	uint4 *wi_memo; // per source slot: (source intensity, target intensity, intensity weight, MULLS_WI_MAGIC) — k_accum_wave's memo of point_wi; null: none
 	unsigned long long *dbg_ticks; // diagnostics (MULLS_OPT_DEBUG_STOP = 20): k_cert's one-pass walk adds its phase times here (10-ns ticks; [6] = workgroups)
 };

@@ -337,7 +337,7 @@ extern "C"
 			return;
 		if (ctx)
 			(void)hipSetDevice(ctx->device);
-		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->nn_cand, B->wi_memo, B->mq, B->wd,
+		void *dev[] = {B->stage, B->tmp_pos, B->tmp_nrm, B->spos, B->snrm, B->tpos, B->tnrm, B->flag, B->match, B->nn_idx, B->nn_hint, B->nn_cand, B->mq, B->wd,
 					   B->nn_d2, B->winner, B->descs, B->setup, B->states, B->outs, B->ticket, B->bbox, B->setup_jobs, B->big_segs, B->big_clouds, B->seg_cnt, B->big_box, B->jobs, B->partial,
 					   B->tjobs, B->cjobs, B->bjobs, B->fjobs, B->ejobs, B->lclouds, B->bm_cs, B->wl, B->wl_ctr, B->grids, B->tsorted, B->tmap, B->dbg, B->cell_cnt, B->cell_start, B->bm, B->pf, B->descs_init, B->bbox_init,
 					   B->rjobs, B->ajobs, B->pair_rjob, B->order, B->icp_queue, B->icp_outs, B->trace_dev, B->steps, B->bm_rank};

@@ -46,13 +46,13 @@ __global__ __launch_bounds__(LANES, MIN_WG) void k_accum(const uint32_t *__restr
 namespace
 {
 template <typename TS, int W0, int WIN, int MODE, int METRIC, int A0>
-__device__ __forceinline__ void add_window(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc)
+__device__ __forceinline__ void add_window(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc, const float *wpre)
 {
 	TS t[WIN];
 #pragma unroll
 	for (int k = 0; k < WIN; k++)
 		t[k] = (TS)0;
-	point_terms<TS, W0, WIN, MODE, METRIC>(A, x, P, Q, N, wi, w, t);
+	point_terms<TS, W0, WIN, MODE, METRIC>(A, x, P, Q, N, wi, w, t, wpre);
 #pragma unroll
 	for (int k = 0; k < WIN; k++)
 		acc[W0 - A0 + k] += (double)t[k];
@@ -65,19 +65,19 @@ __device__ __forceinline__ void add_window(const AccumCtx &A, const double *x, c
 #define MULLS_ACCW_WIN_D 12 // double terms per window
 #endif
 template <typename TS, int W0, int REM, int MODE, int METRIC, int A0>
-__device__ __forceinline__ void add_windows(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc)
+__device__ __forceinline__ void add_windows(const AccumCtx &A, const double *x, const float4 P, const float4 Q, const float4 N, float wi, float &w, double *acc, const float *wpre)
 {
 	constexpr int WMAX = sizeof(TS) == 8 ? MULLS_ACCW_WIN_D : MULLS_ACCW_WIN;
 	constexpr int WIN = REM < WMAX ? REM : WMAX;
-	add_window<TS, W0, WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc);
+	add_window<TS, W0, WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc, wpre);
 	if constexpr (REM > WIN)
-		add_windows<TS, W0 + WIN, REM - WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc);
+		add_windows<TS, W0 + WIN, REM - WIN, MODE, METRIC, A0>(A, x, P, Q, N, wi, w, acc, wpre);
 }
 // T0, NTW: the terms [T0, T0 + NTW) of the NT the form has are this wave's (two waves share a float trip: 14 + 13 running sums instead of 27 leave registers for the
 // next slot's records in flight and a fifth wave per SIMD)
 template <typename TS, int NT, int MODE, int METRIC, int T0, int NTW>
 __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, const CloudDesc &d, uint32_t trip0, const float4 *__restrict__ spos, const float4 *__restrict__ mq,
-										   const uint8_t *__restrict__ flag, float *__restrict__ wd, double *__restrict__ out, bool owner, uint4 *__restrict__ rp_wi)
+										   const uint8_t *__restrict__ flag, float *__restrict__ wd, double *__restrict__ out, bool owner)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t src_n = d.src_n, src_off = d.src_off;
@@ -89,20 +89,13 @@ __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, co
 		float4 P, Q;
 		float3 N;
 		float w;
-		uint4 c; // the slot's memo of the intensity weight: (source intensity, target intensity, weight, MULLS_WI_MAGIC)
 	};
-	uint4 *__restrict__ wic = (A.inten_w && !A.residual_pass && owner) ? rp_wi : nullptr; // (uniform)
 	auto load = [&](uint32_t i) {
 		Rec r;
 		const uint32_t g = min(src_off + trip0 + lane + 64u * i, last); // (slots beyond the cloud re-read its last point: no branch between the loads)
 		r.f = flag[g];
 		r.P = spos[g], r.Q = mq[2u * g], r.N = *reinterpret_cast<const float3 *>(mq + 2u * g + 1u);
 		r.w = wd[g];
-		r.c = make_uint4(0u, 0u, 0u, 0u);
-		if (wic)
-		{
-			r.c = wic[g];
-		}
 		return r;
 	};
 	double acc[NTW];
@@ -111,7 +104,7 @@ __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, co
 		acc[k] = -0.0;
 	// (the records are used under the validity test only, and the compiler would sink their loads behind it — flag first, then the rest: two round trips in
 	// sequence per slot; values named by a volatile asm have been loaded by then)
-#define MULLS_PIN_REC(r) asm volatile("" : "+v"((r).f), "+v"((r).P.x), "+v"((r).Q.x), "+v"((r).N.x), "+v"((r).w), "+v"((r).c.x))
+#define MULLS_PIN_REC(r) asm volatile("" : "+v"((r).f), "+v"((r).P.x), "+v"((r).Q.x), "+v"((r).N.x), "+v"((r).w))
 #if MULLS_ACCW_PREFETCH
 	Rec cur = load(0);
 #endif
@@ -130,29 +123,19 @@ __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, co
 		const bool valid = s < src_n && (cur.f & (MULLS_F_ALIVE | MULLS_F_VALID)) == (MULLS_F_ALIVE | MULLS_F_VALID);
 		// A dead or unmatched slot's terms are +0.0: adding them changes a running sum only from -0.0 to +0.0, which k_finish's `0.0 + partial` does anyway (the 512- and
 		// 256-lane forms of k_accum leave the slots beyond their lanes out the same way) — so such a slot is skipped altogether.
-		// The terms in windows of seven: a window's terms are added to their running sums before the next window's are evaluated (the windows share the weights and the
-		// row vector through common-subexpression elimination).
+		// The terms in windows: a window's terms are added to their running sums before the next window's are evaluated (the windows share the row vector through
+		// common-subexpression elimination; the weight is handed to them).
 		if (valid)
 		{
 			float w = cur.w;
 			const float4 N4 = make_float4(cur.N.x, cur.N.y, cur.N.z, 0.0f);
-			// The intensity weight exp(-|i1 - i2| / 255) — a double-precision exp, a division: a seventh of the slot's instructions — depends on the two intensities
-			// alone, and a correspondence stands for many iterations: the slot keeps (i1, i2, weight) and the weight is taken from there while both intensities are
-			// the bits it was computed from (a memo of a pure function: whatever the entry's history, a hit is the value point_wi returns).
-			float wi = 1.0f;
-			if (A.inten_w && !A.residual_pass)
-			{
-				const uint32_t pw = __float_as_uint(cur.P.w), qw = __float_as_uint(cur.Q.w);
-				if (cur.c.x == pw && cur.c.y == qw && cur.c.w == MULLS_WI_MAGIC)
-					wi = __uint_as_float(cur.c.z);
-				else
-				{
-					wi = point_wi(cur.P, cur.Q);
-					if (wic)
-						wic[src_off + s] = make_uint4(pw, qw, __float_as_uint(wi), MULLS_WI_MAGIC);
-				}
-			}
-			add_windows<TS, T0, NTW, MODE, METRIC, T0>(A, x, cur.P, cur.Q, N4, wi, w, acc);
+			// The intensity weight exp(-|i1 - i2| / 255) is evaluated every time.  (Round 5 kept a 16-byte memo of it per slot, when the kernel was bound by its
+			// instruction count; with the weights evaluated once per slot — corr_weight — it waits for memory, and the memo's bytes cost more than the exp:
+			// 4.0 -> 3.45 ms of accumulation per 4096-pair step, profiles/r06_experiments.txt item 13.)
+			const float wi = (A.inten_w && !A.residual_pass) ? point_wi(cur.P, cur.Q) : 1.0f;
+			// the correspondence's weight once per slot, in front of the term windows (accum.h: corr_weight — each window would evaluate its own copy)
+			const float wpre = A.residual_pass ? 0.0f : corr_weight(A, METRIC, cur.P, cur.Q, N4, wi);
+			add_windows<TS, T0, NTW, MODE, METRIC, T0>(A, x, cur.P, cur.Q, N4, wi, w, acc, A.residual_pass ? nullptr : &wpre);
 			if (owner && __float_as_uint(w) != __float_as_uint(cur.w))
 				wd[src_off + s] = w; // pcl::Correspondence::weight (the wave that holds the form's first terms writes it: the weight does not depend on the terms)
 		}
@@ -236,34 +219,34 @@ __global__ __launch_bounds__(64 * MULLS_ACCW_WAVES, MULLS_ACCW_OCC) void k_accum
 		if (part) // two sums, or the twelve of the faithful point-to-line system: one wave
 			return;
 		if (!residual_pass)
-			wave_trip<double, 12, 1, 1, 0, 12>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo); // (li_diag: launch_accum keeps other point-to-line sums away)
+			wave_trip<double, 12, 1, 1, 0, 12>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true); // (li_diag: launch_accum keeps other point-to-line sums away)
 		else if (A.metric == 0)
-			wave_trip<double, 2, 0, 0, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+			wave_trip<double, 2, 0, 0, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 		else if (A.metric == 1)
-			wave_trip<double, 2, 0, 1, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+			wave_trip<double, 2, 0, 1, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 		else
-			wave_trip<double, 2, 0, 2, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+			wave_trip<double, 2, 0, 2, 0, 2>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 	}
 #if MULLS_ACCW_SPLIT == 2
 	else if (A.metric == 0)
 	{
 		if (part == 0u)
-			wave_trip<float, 27, 0, 0, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+			wave_trip<float, 27, 0, 0, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 		else
-			wave_trip<float, 27, 0, 0, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false, rp.wi_memo);
+			wave_trip<float, 27, 0, 0, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false);
 	}
 	else
 	{
 		if (part == 0u)
-			wave_trip<float, 27, 0, 2, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+			wave_trip<float, 27, 0, 2, 0, 14>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 		else
-			wave_trip<float, 27, 0, 2, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false, rp.wi_memo);
+			wave_trip<float, 27, 0, 2, 14, 13>(A, ps.x, d, job.start, spos, mq, flag, wd, out, false);
 	}
 #else
 	else if (A.metric == 0)
-		wave_trip<float, 27, 0, 0, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		wave_trip<float, 27, 0, 0, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 	else
-		wave_trip<float, 27, 0, 2, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true, rp.wi_memo);
+		wave_trip<float, 27, 0, 2, 0, 27>(A, ps.x, d, job.start, spos, mq, flag, wd, out, true);
 #endif
 }
 
