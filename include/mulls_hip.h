@@ -250,12 +250,15 @@ enum mulls_option
 	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [2048] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
 											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits; -0.26 ms of a 17.8 ms
 											 step at 4096 pairs, profiles/r05_experiments.txt); 0 = always one workgroup per trip (k_accum).  Read when a batch is filled
-											 (the memo of the intensity weights is allocated with it) and at every launch */
+											 and at every launch */
 	MULLS_OPT_FIRST_DIRECT = 26,		  /* [1] LDS tier, lock-step loop: the setup applies iteration 0's rigid step (the identity) where it writes the cropped source clouds, and
 											 iteration 0 runs no light pass — without hints it could only list every point and hand the class clouds over, or search a small
 											 cloud unhinted against the grid in global memory: every called class cloud goes straight to the staged search.  0 = light pass
 											 first, as in every other iteration.  Same bits */
-	MULLS_OPT_COUNT = 27
+	MULLS_OPT_SUM_STEP = 27,			  /* [1] lock-step loop stepped on the device, batches beyond STEP_LAUNCH_MAX_PAIRS: one wave per pair sums the pair's trip partials AND steps it
+											 (k_sum_step) instead of k_finish followed by k_step — one launch less per iteration; pairs with more than MULLS_SUM_STEP_TRIPS
+											 trips in a class keep the two kernels.  0 = k_finish + k_step.  Same bits */
+	MULLS_OPT_COUNT = 28
 };
 int mulls_set_option(mulls_ctx *ctx, int option, double value);
 int mulls_get_option(const mulls_ctx *ctx, int option, double *value);

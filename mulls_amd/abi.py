@@ -24,7 +24,7 @@ MULLS_E_NOMEM = -105
 # enum mulls_option
 (OPT_HOST_STEP, OPT_RESIDENT_MIN_PAIRS, OPT_RESIDENT_MAX_PAIRS, OPT_FEW_LAUNCHES_MAX_PAIRS, OPT_SUBBATCHES, OPT_TWO_STREAMS, OPT_CERTIFICATES, OPT_CERT_SLACK_MIN,
  OPT_CERT_SLACK_MAX, OPT_CERT_SLACK_RATE, OPT_LDS_DEDUP, OPT_GRID_H0, OPT_BM_H0, OPT_LEAN_STAGING, OPT_DEBUG_STOP, OPT_DEBUG_TICK, OPT_SPLIT_MIN_PAIRS, OPT_SPLIT_MAX_PAIRS,
- OPT_FUSED_TGT_SETUP, OPT_STAGGER, OPT_STEP_LAUNCH_MAX_PAIRS, OPT_MIXED_TIERS, OPT_BIG_EARLY_SETS, OPT_KCERT, OPT_KCERT_MIN, OPT_ACCUM_WAVE_MIN_TRIPS, OPT_FIRST_DIRECT, OPT_COUNT) = range(28)
+ OPT_FUSED_TGT_SETUP, OPT_STAGGER, OPT_STEP_LAUNCH_MAX_PAIRS, OPT_MIXED_TIERS, OPT_BIG_EARLY_SETS, OPT_KCERT, OPT_KCERT_MIN, OPT_ACCUM_WAVE_MIN_TRIPS, OPT_FIRST_DIRECT, OPT_SUM_STEP, OPT_COUNT) = range(29)
 
 # numpy view of pcl::PointXYZINormal (48 B)
 POINT_DTYPE = np.dtype(

@@ -152,6 +152,7 @@ void options_init(mulls_ctx *ctx)
 	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
 	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0, o[MULLS_OPT_MIXED_TIERS] = 1, o[MULLS_OPT_BIG_EARLY_SETS] = 2, o[MULLS_OPT_KCERT] = 1, o[MULLS_OPT_KCERT_MIN] = 64, o[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS] = 2048;
 	o[MULLS_OPT_FIRST_DIRECT] = 1;
+	o[MULLS_OPT_SUM_STEP] = 1;
 	static const struct
 	{
 		const char *name;
@@ -159,7 +160,7 @@ void options_init(mulls_ctx *ctx)
 	} env[] = {{"MULLS_HOST_STEP", MULLS_OPT_HOST_STEP}, {"MULLS_RESIDENT_MIN_PAIRS", MULLS_OPT_RESIDENT_MIN_PAIRS}, {"MULLS_RESIDENT_MAX_PAIRS", MULLS_OPT_RESIDENT_MAX_PAIRS},
 			   {"MULLS_FEW_LAUNCHES_MAX_PAIRS", MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS}, {"MULLS_SUBBATCHES", MULLS_OPT_SUBBATCHES}, {"MULLS_TWO_STREAMS", MULLS_OPT_TWO_STREAMS},
 			   {"MULLS_CERTIFICATES", MULLS_OPT_CERTIFICATES}, {"MULLS_LDS_DEDUP", MULLS_OPT_LDS_DEDUP}, {"MULLS_GRID_H0", MULLS_OPT_GRID_H0}, {"MULLS_BM_H0", MULLS_OPT_BM_H0},
-			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}, {"MULLS_KCERT", MULLS_OPT_KCERT}, {"MULLS_KCERT_MIN", MULLS_OPT_KCERT_MIN}, {"MULLS_ACCUM_WAVE_MIN_TRIPS", MULLS_OPT_ACCUM_WAVE_MIN_TRIPS}, {"MULLS_FIRST_DIRECT", MULLS_OPT_FIRST_DIRECT}};
+			   {"MULLS_LEAN_STAGING", MULLS_OPT_LEAN_STAGING}, {"MULLS_FUSED_TGT_SETUP", MULLS_OPT_FUSED_TGT_SETUP}, {"MULLS_STAGGER", MULLS_OPT_STAGGER}, {"MULLS_STEP_LAUNCH_MAX_PAIRS", MULLS_OPT_STEP_LAUNCH_MAX_PAIRS}, {"MULLS_SPLIT_MIN_PAIRS", MULLS_OPT_SPLIT_MIN_PAIRS}, {"MULLS_SPLIT_MAX_PAIRS", MULLS_OPT_SPLIT_MAX_PAIRS}, {"MULLS_DEBUG_STOP", MULLS_OPT_DEBUG_STOP}, {"MULLS_DEBUG_TICK", MULLS_OPT_DEBUG_TICK}, {"MULLS_MIXED_TIERS", MULLS_OPT_MIXED_TIERS}, {"MULLS_BIG_EARLY_SETS", MULLS_OPT_BIG_EARLY_SETS}, {"MULLS_KCERT", MULLS_OPT_KCERT}, {"MULLS_KCERT_MIN", MULLS_OPT_KCERT_MIN}, {"MULLS_ACCUM_WAVE_MIN_TRIPS", MULLS_OPT_ACCUM_WAVE_MIN_TRIPS}, {"MULLS_FIRST_DIRECT", MULLS_OPT_FIRST_DIRECT}, {"MULLS_SUM_STEP", MULLS_OPT_SUM_STEP}};
 	for (const auto &e : env)
 		if (const char *v = std::getenv(e.name))
 		{

@@ -336,6 +336,83 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 			M->cnt[c] = d.n_valid, M->cnt[6 + c] = d.alive_cur, M->cnt[12 + c] = d.src_n, M->cnt[18 + c] = d.tgt_n;
 	}
 }
+// finish_pair by ONE wave (k_sum_step): lane l takes the sums l, l + 64, l + 128 of the 6 x 27 — every trip partial of the three requested before the first
+// addition (a sum with more than 16 trips falls back to a loop: dense class clouds do not take this path) — the same additions in the same order.
+__device__ __forceinline__ void finish_pair_wave(CloudDesc *pd, const PairState &ps, const RunParams &rp, const double *__restrict__ partial, PairOut &o,
+												  const uint32_t *__restrict__ pair_bbox, FinishLds &M)
+{
+	const uint32_t l = threadIdx.x;
+	constexpr uint32_t STEP = MULLS_ACC_LANES / MULLS_SRC_PER_BLOCK;
+	if (l >= 32u && l < 38u)
+	{
+		const uint32_t v = pair_bbox[l - 32u];
+		o.bbox[l - 32u] = v;
+		M.cnt[24u + l - 32u] = v;
+	}
+	double sum[3] = {0.0, 0.0, 0.0};
+	uint32_t j[3], je[3];
+	bool on[3];
+#pragma unroll
+	for (int u = 0; u < 3; u++)
+	{
+		const uint32_t idx = l + 64u * (uint32_t)u, c = idx / MULLS_NTERM;
+		on[u] = idx < MULLS_NC * MULLS_NTERM && rp.used[c < MULLS_NC ? c : 0u];
+		j[u] = on[u] ? pd[c].job_begin : 0u;
+		je[u] = on[u] ? pd[c].job_end : 0u;
+	}
+	double v[3][4];
+#pragma unroll
+	for (int u = 0; u < 3; u++)
+	{
+		const uint32_t t = (l + 64u * (uint32_t)u) % MULLS_NTERM;
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; k++)
+			v[u][k] = j[u] + k * STEP < je[u] ? partial[(size_t)(j[u] + k * STEP) * MULLS_NTERM + t] : 0.0;
+	}
+#pragma unroll
+	for (int u = 0; u < 3; u++)
+	{
+		const uint32_t idx = l + 64u * (uint32_t)u, c = idx / MULLS_NTERM, t = idx % MULLS_NTERM;
+#pragma unroll
+		for (uint32_t k = 0; k < 4u; k++)
+			if (j[u] + k * STEP < je[u])
+				sum[u] += v[u][k];
+		for (uint32_t jj = j[u] + 4u * STEP; jj < je[u]; jj += STEP)
+			sum[u] += partial[(size_t)jj * MULLS_NTERM + t];
+		if (on[u])
+		{
+			o.sums[c][t] = sum[u];
+			M.sums[c][t] = sum[u];
+		}
+	}
+	__syncthreads();
+	if (rp.pull_comb && l < MULLS_NTERM)
+	{
+		combine_rows(rp, ps.want_residual != 0, M.sums, M.comb, (int)l);
+		o.comb[l] = M.comb[l];
+	}
+	if (l >= 56u && l < 56u + MULLS_NC)
+	{
+		const int c = (int)l - 56;
+		CloudDesc &d = pd[c];
+		if (ps.active)
+		{
+			if (class_called(rp, d, c))
+			{
+				d.n_valid = d.valid_next;
+				d.alive_cur = d.alive_next;
+			}
+			d.alive_next = 0;
+			d.valid_next = 0;
+			d.n_matched = 0;
+		}
+		o.n_valid[c] = d.n_valid;
+		o.n_alive[c] = d.alive_cur;
+		o.src_n[c] = d.src_n;
+		o.tgt_n[c] = d.tgt_n;
+		M.cnt[c] = d.n_valid, M.cnt[6 + c] = d.alive_cur, M.cnt[12 + c] = d.src_n, M.cnt[18 + c] = d.tgt_n;
+	}
+}
 } // namespace
 
 __global__ __launch_bounds__(MULLS_BLOCK) void k_finish(CloudDesc *__restrict__ descs, const PairState *__restrict__ states, RunParams rp,
@@ -639,6 +716,34 @@ __global__ __launch_bounds__(64) void k_step(const CloudDesc *__restrict__ descs
 	(void)step_pair(pair_base + blockIdx.x, descs, states, rp, K, out, steps, results, brute, L);
 }
 
+// Large batches: k_finish and k_step as ONE launch of one wave per pair — the wave sums its pair's trip partials itself (a KITTI-sized pair has four to eight of
+// them per class: three sums per lane, every load in flight at once) and steps the pair.  (k_finish_step — a 256-lane workgroup per pair whose first wave steps —
+// was slower than the two launches at 4096 pairs, profiles/r06_experiments.txt item 7: three of its four waves wait through the step.  Here nothing waits.)
+__global__ __launch_bounds__(64) void k_sum_step(CloudDesc *__restrict__ descs, PairState *__restrict__ states, RunParams rp, mulls::IcpConst K,
+												 const double *__restrict__ partial, PairOut *__restrict__ out, const uint32_t *__restrict__ bbox,
+												 mulls::StepState *__restrict__ steps, IcpOut *__restrict__ results, int brute, uint32_t pair_base)
+{
+	__shared__ StepLds L;
+	__shared__ FinishLds F;
+	const uint32_t pair = pair_base + blockIdx.x;
+	const bool live = states[pair].active || states[pair].want_residual; // uniform
+	unsigned long long sw[STEP_WORDS_PER_LANE];
+	if (live)
+	{
+		const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&steps[pair]);
+#pragma unroll
+		for (uint32_t k = 0; k < STEP_WORDS_PER_LANE; k++)
+			sw[k] = src[min(threadIdx.x + 64u * k, STEP_WORDS - 1u)];
+		finish_pair_wave(descs + pair * MULLS_NC, states[pair], rp, partial, out[pair], bbox + pair * 6, F);
+	}
+	__syncthreads(); // F is complete
+	if (threadIdx.x < MULLS_NTERM_PAD)
+		L.comb[threadIdx.x] = F.comb[threadIdx.x];
+	if (threadIdx.x < 30u)
+		L.cnt[threadIdx.x] = F.cnt[threadIdx.x];
+	(void)step_pair(pair, descs, states, rp, K, out, steps, results, brute, L, sw);
+}
+
 // Small batches (launch_finish_step decides): k_finish, k_step and k_step_publish as ONE launch — a workgroup sums its pair's partials, its
 // first wave steps the pair, and the last workgroup to arrive publishes the word the host reads.  With a few hundred workgroups the arrival
 // ticket (one device-scope fence and two atomics per workgroup) costs less than the two launches it saves; with thousands it does not
@@ -848,7 +953,7 @@ void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, c
 
 void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
 						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
-						uint32_t *ticket)
+						uint32_t *ticket, bool sum_step)
 {
 	if (!npairs)
 		return;
@@ -858,9 +963,14 @@ void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, Clo
 						   pair_base);
 		return;
 	}
-	hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, pair_base, static_cast<uint4 *>(nullptr),
-					   static_cast<uint32_t *>(nullptr), static_cast<volatile uint32_t *>(nullptr), 0u);
-	hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute, pair_base);
+	if (sum_step && rp.pull_comb)
+		hipLaunchKernelGGL(k_sum_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, partial, out, bbox, steps, results, brute, pair_base);
+	else
+	{
+		hipLaunchKernelGGL(k_finish, dim3(npairs), dim3(MULLS_BLOCK), 0, st, descs, states, rp, partial, out, bbox, pair_base, static_cast<uint4 *>(nullptr),
+						   static_cast<uint32_t *>(nullptr), static_cast<volatile uint32_t *>(nullptr), 0u);
+		hipLaunchKernelGGL(k_step, dim3(npairs), dim3(64), 0, st, descs, states, rp, K, out, steps, results, brute, pair_base);
+	}
 	hipLaunchKernelGGL(k_step_publish, dim3(1), dim3(1024), 0, st, states + pair_base, npairs, host_word, epoch);
 }
 

@@ -96,7 +96,8 @@ struct StepState;
 void launch_step_init(hipStream_t st, uint32_t npairs, const PairSetup *setup, const mulls::IcpConst &K, mulls::StepState *steps, PairState *states);
 void launch_finish_step(hipStream_t st, uint32_t pair_base, uint32_t npairs, CloudDesc *descs, PairState *states, const RunParams &rp, const mulls::IcpConst &K, const double *partial,
 						PairOut *out, const uint32_t *bbox, mulls::StepState *steps, IcpOut *results, unsigned long long *host_word, uint32_t epoch, int brute,
-						uint32_t *ticket = nullptr); // ticket: two zeroed device words -> finish, step and publication in one launch (small batches)
+						uint32_t *ticket = nullptr, bool sum_step = false); // ticket: two zeroed device words -> finish, step and publication in one launch (small batches);
+						// sum_step (large batches): one wave per pair sums and steps (k_sum_step) instead of k_finish + k_step
 void launch_transform_aos(hipStream_t st, float4 *recs, uint32_t n, const double *T12);
 // the same on `count` (<= 6) clouds in one launch, T12 (host) by value
 void launch_transform_clouds(hipStream_t st, float4 *const recs[], const uint32_t n[], int count, const double T12[12]);

@@ -399,6 +399,11 @@ RUN_ALIASES
 	// Small batches are bound by the NUMBER of launches (a kernel of a few hundred workgroups takes ~5 us whatever it does; one pair is bound by
 	// the host's ~4 us per launch): the three accumulation launches become one, finish + step + publication one (k_finish_step)
 	const bool few_launches = n <= (int)ctx->opt[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS];
+	// one wave per pair sums and steps (k_sum_step) when no class cloud has more trips than its lanes keep in flight at once (the jobs are 512-slot blocks, a trip is
+	// two of them: KITTI-sized source clouds have one or two trips per class)
+	bool sum_step = ctx->opt[MULLS_OPT_SUM_STEP] != 0.0;
+	for (size_t k = 0; sum_step && k < B->descs_h.size(); k++)
+		sum_step = B->descs_h[k].job_end - B->descs_h[k].job_begin <= 4u * (1024u / MULLS_SRC_PER_BLOCK); // (1024 = MULLS_ACC_LANES, accum.h)
 	struct Sub
 	{
 		int lo = 0, hi = 0;
@@ -524,7 +529,7 @@ RUN_ALIASES
 		ev.begin(search ? &ctx->prof.ms_accum : &ctx->prof.ms_residual);
 		launch_accum(sst, B->ajobs, S.L.ajob_split, B->jobs, B->descs, B->states, rp, B->spos, B->mq, B->flag, B->wd, B->partial, few_launches, (uint32_t)ctx->opt[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS]);
 		launch_finish_step(sst, (uint32_t)S.lo, (uint32_t)(S.hi - S.lo), B->descs, B->states, rp, K, B->partial, B->outs, B->bbox, B->steps, B->icp_outs, S.word_dev,
-						   ++*S.epoch_ctr, use_grid ? 0 : 1, (few_launches || n <= (int)ctx->opt[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS]) ? S.ticket : nullptr);
+						   ++*S.epoch_ctr, use_grid ? 0 : 1, (few_launches || n <= (int)ctx->opt[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS]) ? S.ticket : nullptr, sum_step);
 		ev.end();
 		{
 			const hipError_t e = hipGetLastError(); // a rejected launch (dynamic LDS size, ...) would otherwise only show as an epoch that never arrives
