@@ -247,7 +247,7 @@ enum mulls_option
 											 saw before it is searched again (0: round 4's certificates only).  In force on the global-memory tier (+4 ... 8 % there); the LDS tier's
 											 kernels are built without them by default (keeping the records costs more than the look returns, lds_tier.h: MULLS_LDS_KCERT) */
 	MULLS_OPT_KCERT_MIN = 24,			  /* [64] LDS tier, builds with MULLS_LDS_KCERT=1 only: leftover lists shorter than this skip the look (it costs one chain of round trips whatever the length) */
-	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [2048] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
+	MULLS_OPT_ACCUM_WAVE_MIN_TRIPS = 25,  /* [768; 2048 until round 6, when the kernel lost its memo and two thirds of its divisions: 512 pairs 185 -> 201 k/s, 768 pairs 211 -> 235 k/s] lock-step loop: from this many 1024-slot trips per launch on the normal equations are summed by one wave per trip (k_accum_wave:
 											 the slots of a lane in sequence, the running sums in registers — no term buffer, no barriers; same bits; -0.26 ms of a 17.8 ms
 											 step at 4096 pairs, profiles/r05_experiments.txt); 0 = always one workgroup per trip (k_accum).  Read when a batch is filled
 											 and at every launch */

@@ -166,13 +166,17 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
     empty = abi.PairData(tgt, [None] * 6)
     plist = ([p for p, _ in pairs_small] + [far, empty]) * 7
     wave_min = ctx.get_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS)
-    ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, 1)  # (set while the batch is filled: the wave form's memo of the intensity weights is allocated with the batch)
+    ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, 1)
     b = ctx.batch(plist)
     # ... and batches of SPLIT_MIN .. SPLIT_MAX pairs iterate as two sub-batches on two streams (own launch sets, epoch word, ticket, work list)
     # ... and (round 5) the normal equations summed by one wave per trip (k_accum_wave: ACCUM_WAVE_MIN_TRIPS = 1) instead of one workgroup per trip (0)
-    forms = {"few": (384, 1 << 30, 0), "separate": (0, 1 << 30, 0), "few split": (384, 2, 0), "separate split": (0, 2, 0), "few wave": (384, 1 << 30, 1), "separate wave": (0, 1 << 30, 1),
-             "separate split wave": (0, 2, 1)}
+    # ... and (round 6) one wave per pair that sums the trip partials and steps the pair (k_sum_step: SUM_STEP = 1) instead of k_finish followed by k_step (0)
+    forms = {"few": (384, 1 << 30, 0, 1), "separate": (0, 1 << 30, 0, 1), "few split": (384, 2, 0, 1), "separate split": (0, 2, 0, 1), "few wave": (384, 1 << 30, 1, 1),
+             "separate wave": (0, 1 << 30, 1, 1), "separate split wave": (0, 2, 1, 1),
+             # (STEP_LAUNCH_MAX_PAIRS = 0: finish, step and publication as the separate launches of large batches)
+             "large": (0, 1 << 30, 0, 1, 0), "large two kernels": (0, 1 << 30, 0, 0, 0), "large split wave": (0, 2, 1, 1, 0), "large split wave two kernels": (0, 2, 1, 0, 0)}
     split_min = ctx.get_option(abi.OPT_SPLIT_MIN_PAIRS)
+    step_max = ctx.get_option(abi.OPT_STEP_LAUNCH_MAX_PAIRS)
     for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0),
               abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
         got = {}
@@ -180,6 +184,8 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
             ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, forms[name][0])
             ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, forms[name][1])
             ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, forms[name][2])
+            ctx.set_option(abi.OPT_SUM_STEP, forms[name][3])
+            ctx.set_option(abi.OPT_STEP_LAUNCH_MAX_PAIRS, forms[name][4] if len(forms[name]) > 4 else step_max)
             r = b.run(P)
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
             assert got.setdefault(name, rows) == rows
@@ -187,6 +193,8 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
     ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
     ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, split_min)
     ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, wave_min)
+    ctx.set_option(abi.OPT_SUM_STEP, 1)
+    ctx.set_option(abi.OPT_STEP_LAUNCH_MAX_PAIRS, step_max)
     b.close()
 
 
