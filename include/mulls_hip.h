@@ -240,7 +240,7 @@ enum mulls_option
 	MULLS_OPT_MIXED_TIERS = 21,			  /* [1] auto mode picks the search tier per (pair, class) cloud: the LDS tier for the down-sampled clouds, the global-memory
 											 tier (certified correspondences on an occupancy-bitmap grid) for larger ones, both in one launch set; 0 = one tier per
 											 batch, decided by its largest searched target cloud (rounds 1 - 3) */
-	MULLS_OPT_BIG_EARLY_SETS = 22,		  /* [2] mixed batches: the first iterations run every global-memory-tier cloud as chunk-level jobs shared by several workgroups
+	MULLS_OPT_BIG_EARLY_SETS = 22,		  /* [5; 2 until round 6: 32 scans against a 961 k-point map 5 940 -> 6 420 /s, 64 scans against 20 000-point maps unchanged] mixed batches: the first iterations run every global-memory-tier cloud as chunk-level jobs shared by several workgroups
 											 (+ k_filter) — while most points still need a search that beats one workgroup per class cloud; from this iteration on the
 											 down-sampled source clouds are class-level jobs (certificates, leftovers, rejection chain in one workgroup, no k_filter) */
 	MULLS_OPT_KCERT = 23,				  /* [1] k-candidate certificates: a point whose hinted target fails the certificate evaluates the few nearest targets its last search

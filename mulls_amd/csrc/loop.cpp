@@ -221,7 +221,8 @@ RUN_ALIASES
 	// ... and every iteration of a small one: a handful of class-level workgroups cannot search a dense map's leftovers fast enough (a 1 M-point map leaves most
 	// points uncertified for ten iterations: its second-nearest targets are millimetres behind the nearest), while k_filter costs such a batch 6 us
 	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
-	const uint32_t max_wgs = iter < 3 ? 2048u : 512u; // (resident workgroups of k_cert_big: two per CU)
+	// (resident workgroups of k_cert_big: two per CU; four rounds of them while the chunk-level jobs still search)
+	const uint32_t max_wgs = iter < std::max(3, (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS]) ? 2048u : 512u;
 	// a small mixed batch: both tiers' class clouds in one launch
 	const uint32_t big_n = early ? L.ejob_n : L.bjob_n;
 	const Job *big_jobs = early ? B->ejobs + L.ejob_lo : B->bjobs + L.bjob_lo;
