@@ -90,12 +90,16 @@ __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, co
 		float3 N;
 		float w;
 	};
+	// pcl::Correspondence's distance / weight word: the residual pass reads it (the weight the last iteration left, or d^2 for the point-to-point class: SURVEY A.7); a
+	// normal-equation pass only writes it — point-to-plane and point-to-line always, point-to-point in the non-faithful mode — so it is not fetched there (the search
+	// kernel has just written the squared distance into it: the old "store if the bits differ" test never skipped a store, and cost 4 of the slot's 53 bytes)
+	const bool need_w = A.residual_pass, writes_w = !A.residual_pass && (METRIC != 2 || !A.faithful); // (uniform)
 	auto load = [&](uint32_t i) {
 		Rec r;
 		const uint32_t g = min(src_off + trip0 + lane + 64u * i, last); // (slots beyond the cloud re-read its last point: no branch between the loads)
 		r.f = flag[g];
 		r.P = spos[g], r.Q = mq[2u * g], r.N = *reinterpret_cast<const float3 *>(mq + 2u * g + 1u);
-		r.w = wd[g];
+		r.w = need_w ? wd[g] : 0.0f;
 		return r;
 	};
 	double acc[NTW];
@@ -136,7 +140,7 @@ __device__ __forceinline__ void wave_trip(const AccumCtx &A, const double *x, co
 			// the correspondence's weight once per slot, in front of the term windows (accum.h: corr_weight — each window would evaluate its own copy)
 			const float wpre = A.residual_pass ? 0.0f : corr_weight(A, METRIC, cur.P, cur.Q, N4, wi);
 			add_windows<TS, T0, NTW, MODE, METRIC, T0>(A, x, cur.P, cur.Q, N4, wi, w, acc, A.residual_pass ? nullptr : &wpre);
-			if (owner && __float_as_uint(w) != __float_as_uint(cur.w))
+			if (owner && writes_w)
 				wd[src_off + s] = w; // pcl::Correspondence::weight (the wave that holds the form's first terms writes it: the weight does not depend on the terms)
 		}
 #if MULLS_ACCW_PREFETCH
