@@ -680,7 +680,7 @@ int batch_fill(mulls_ctx *ctx, mulls_batch *B, const mulls_pair *pairs, int n, c
 	A(grow(ctx, &B->big_segs, &B->cap_big[0], B->big_segs_h.size()));
 	A(grow(ctx, &B->big_clouds, &B->cap_big[1], B->big_clouds_h.size()));
 	A(grow(ctx, &B->seg_cnt, &B->cap_big[2], B->big_segs_h.size()));
-	A(grow(ctx, &B->big_box, &B->cap_big[3], B->big_clouds_h.size() * 6));
+	A(grow(ctx, &B->big_box, &B->cap_big[3], (B->big_clouds_h.size() + B->big_segs_h.size()) * 6)); // per cloud (k_crop's reset), then per segment (k_crop_big_count)
 	if (!B->ticket)
 	{
 		A(dmalloc(ctx, &B->ticket, 32));

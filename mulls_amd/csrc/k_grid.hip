@@ -12,38 +12,12 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_clear(const uint32_t *__rest
 		bm[g.cell_off + w] = 0ull;
 }
 
-// Wave aggregation of the bitmap kernels' atomics.  A dense map puts hundreds of consecutive scan points into one cell (and thousands into one 64-cell
-// word): one atomic per point on the same address took 316 + 133 + 170 us for a 1 M-point map (profiles/r04_large_steps.txt).  The lanes of a wave that
-// share the address are served by one leader, MULLS_BM_ROUNDS distinct addresses per wave; what is left (sparse clouds: every lane its own cell) goes one by one.
-// Round 6: the groups are FOUND first (ballots and lane reads only), then every leader issues its atomic in ONE instruction — the rounds used to be a chain of
-// dependent memory operations each (a pre-check load and the atomic; in the scatter an atomic whose result the round waited for): up to five round trips per
-// 256-point workgroup where one is needed (k_bm_mark 1 285 -> 460 us, k_bm_scatter 874 -> 520 us on configs[2]'s 32 x 961 k points: profiles/r06_experiments.txt).
-#define MULLS_BM_ROUNDS 4
-// the lanes of a wave that hold the same key, MULLS_BM_ROUNDS groups at most: leader = the group's first lane (the lane itself when it stayed alone),
-// rank = its position among the group's lanes, size = the group's lanes.  Every lane of the wave calls it.
-__device__ __forceinline__ void wave_groups(uint32_t key, bool in, int lane, int &leader, uint32_t &rank, uint32_t &size, unsigned long long &members)
-{
-	bool pending = in;
-	leader = lane, rank = 0u, size = in ? 1u : 0u, members = in ? (1ull << lane) : 0ull;
-	for (int round = 0; round < MULLS_BM_ROUNDS; round++)
-	{
-		const unsigned long long act = __ballot(pending);
-		if (!act)
-			break;
-		const int l = __ffsll((long long)act) - 1;
-		const uint32_t lk = (uint32_t)__shfl((int)key, l);
-		const bool mine = pending && key == lk;
-		const unsigned long long m = __ballot(mine);
-		if (mine)
-		{
-			leader = l;
-			rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-			size = (uint32_t)__popcll(m);
-			members = m;
-		}
-		pending = pending && !mine;
-	}
-}
+// Aggregation of the bitmap kernels' atomics.  A dense map puts hundreds of consecutive scan points into one cell (and thousands into one 64-cell word), a flat
+// class cloud fifty points of every workgroup into one word — and atomics on one address are served one after the other past the L2: one atomic per point took
+// 316 + 133 + 170 us for a 1 M-point map (profiles/r04_large_steps.txt).  Round 4 let the lanes of a WAVE that share an address be served by one leader (four
+// distinct addresses per wave, the rest one by one); round 6 first issued every leader's atomic in one instruction instead of a chain of dependent memory
+// operations per group, then moved the aggregation into an LDS hash per WORKGROUP (1024 points, 2048 slots): k_bm_mark ORs the bits of a word there, k_bm_count
+// counts a cell's points there and hands out arrival numbers from ONE returning atomic per cell and workgroup (profiles/r06_experiments.txt items 12, 22, 23).
 #define MULLS_BM_CH 4 // consecutive 256-point chunks per workgroup of the per-point kernels (k_bm_count explains)
 #define MULLS_BM_HASH_BITS 11
 #define MULLS_BM_HASH (1u << MULLS_BM_HASH_BITS) // k_bm_mark's LDS table: twice the points of a workgroup
@@ -128,7 +102,6 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict_
 														   const unsigned long long *__restrict__ bm, const uint32_t *__restrict__ pf,
 														   uint32_t *__restrict__ cnt, uint32_t *__restrict__ rk)
 {
-	const int lane = threadIdx.x & 63;
 	Job job[MULLS_BM_CH];
 	uint32_t ci[MULLS_BM_CH], toff[MULLS_BM_CH], tn[MULLS_BM_CH], t[MULLS_BM_CH];
 	bool in[MULLS_BM_CH];
@@ -160,21 +133,42 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_bm_count(const Job *__restrict_
 		w[u] = bm[g[u].cell_off + (bit[u] >> 6)];
 		pre[u] = pf[g[u].cell_off + (bit[u] >> 6)];
 	}
+	// The workgroup's points meet in an LDS hash (cell counter -> points of this workgroup in the cell): a point's arrival number is the number its cell's ONE
+	// global atomic returns plus its rank inside the workgroup.  (One atomic per group of lanes of a wave that shared a cell before: consecutive points of a scan
+	// line share their cell across waves, too — and atomics on one address are served one after the other.)
+	__shared__ uint32_t hkey[MULLS_BM_HASH], hcnt[MULLS_BM_HASH];
+	for (uint32_t k = threadIdx.x; k < MULLS_BM_HASH; k += MULLS_BLOCK)
+		hkey[k] = 0xffffffffu, hcnt[k] = 0u;
+	__syncthreads();
+	uint32_t r[MULLS_BM_CH], slot[MULLS_BM_CH], lrank[MULLS_BM_CH];
 #pragma unroll
 	for (int u = 0; u < MULLS_BM_CH; u++)
 	{
-		const uint32_t r = in[u] ? toff[u] + ci[u] + pre[u] + (uint32_t)__popcll(w[u] & ((1ull << (bit[u] & 63u)) - 1ull)) : 0xffffffffu; // counter of this point's cell (bm_rank)
-		int leader;
-		uint32_t rank, size;
-		unsigned long long members;
-		wave_groups(r, in[u], lane, leader, rank, size, members);
-		uint32_t first = 0u;
-		if (in[u] && lane == leader)
-			first = atomicAdd(&cnt[r], size); // the group's arrival numbers in its cell
-		first = (uint32_t)__shfl((int)first, leader);
-		if (in[u]) // k_bm_scatter reads both back: its slot is the cell's start + the arrival number — no second pass of atomics, no second ranking
-			reinterpret_cast<uint2 *>(rk)[toff[u] + t[u]] = make_uint2(r, first + rank);
+		r[u] = toff[u] + ci[u] + pre[u] + (uint32_t)__popcll(w[u] & ((1ull << (bit[u] & 63u)) - 1ull)); // counter of this point's cell (bm_rank)
+		slot[u] = 0u, lrank[u] = 0u;
+		if (in[u])
+		{
+			uint32_t h = (r[u] * 2654435761u) >> (32 - MULLS_BM_HASH_BITS);
+			for (;;)
+			{
+				const uint32_t old = atomicCAS(&hkey[h], 0xffffffffu, r[u]);
+				if (old == 0xffffffffu || old == r[u])
+					break;
+				h = (h + 1u) & (MULLS_BM_HASH - 1u);
+			}
+			slot[u] = h;
+			lrank[u] = atomicAdd(&hcnt[h], 1u);
+		}
 	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < MULLS_BM_HASH; k += MULLS_BLOCK)
+		if (hkey[k] != 0xffffffffu)
+			hcnt[k] = atomicAdd(&cnt[hkey[k]], hcnt[k]); // the cell's arrival numbers of this workgroup start here
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < MULLS_BM_CH; u++)
+		if (in[u]) // k_bm_scatter reads both back: its slot is the cell's start + the arrival number — no second pass of atomics, no second ranking
+			reinterpret_cast<uint2 *>(rk)[toff[u] + t[u]] = make_uint2(r[u], hcnt[slot[u]] + lrank[u]);
 }
 
 // counts -> start positions; the counters are left at zero so that k_bm_scatter can reuse them as insertion cursors

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop(CloudDesc *__restrict__ de
 __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__restrict__ segs, const CloudDesc *__restrict__ descs,
 																 const PairSetup *__restrict__ setup, const uint32_t *__restrict__ bbox,
 																 const float4 *__restrict__ stage, const float4 *__restrict__ tmp_pos, RunParams rp,
-																 uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ big_box)
+																 uint32_t *__restrict__ seg_cnt, uint32_t *__restrict__ seg_box)
 {
 	__shared__ uint32_t red4[4];
 	const Job sg = segs[blockIdx.x]; // count = big slot
@@ -287,6 +287,9 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 			}
 		}
 	}
+	// the segment's box (ordered keys; 0xffffffff / 0 = nothing) into ITS slot of seg_box — k_crop_big_scan takes the minimum / maximum over a cloud's segments.
+	// (They were atomics on the cloud's six words: a 1 M-point map has 235 segments of four waves each, and atomics on one address are served one after the other.)
+	__shared__ uint32_t box4[4][6];
 	for (int k = 0; k < 3; k++)
 	{
 		for (int off = 32; off > 0; off >>= 1)
@@ -294,27 +297,42 @@ __global__ __launch_bounds__(MULLS_BLOCK) void k_crop_big_count(const Job *__res
 			bmin[k] = fminf(bmin[k], __shfl_down(bmin[k], off));
 			bmax[k] = fmaxf(bmax[k], __shfl_down(bmax[k], off));
 		}
-		if ((threadIdx.x & 63) == 0 && bmin[k] <= bmax[k] && !src_side) // (the box sizes a target's grid)
+		if ((threadIdx.x & 63) == 0)
 		{
-			atomicMin(&big_box[sg.count * 6u + k], f2ord(bmin[k]));
-			atomicMax(&big_box[sg.count * 6u + 3 + k], f2ord(bmax[k]));
+			const bool any = bmin[k] <= bmax[k];
+			box4[threadIdx.x >> 6][k] = any ? f2ord(bmin[k]) : 0xffffffffu;
+			box4[threadIdx.x >> 6][3 + k] = any ? f2ord(bmax[k]) : 0u;
 		}
 	}
-	const uint32_t total = block_sum_u32(mine, red4);
+	const uint32_t total = block_sum_u32(mine, red4); // (barriers inside: box4 is complete behind it)
 	if (threadIdx.x == 0)
 		seg_cnt[blockIdx.x] = total;
+	if (threadIdx.x < 6 && !src_side) // (the box sizes a target's grid)
+	{
+		const uint32_t k = threadIdx.x;
+		const uint32_t a = box4[0][k], b = box4[1][k], c = box4[2][k], e = box4[3][k];
+		seg_box[(size_t)blockIdx.x * 6u + k] = k < 3 ? min(min(a, b), min(c, e)) : max(max(a, b), max(c, e));
+	}
 }
 
 // one wave per big cloud: segment counts -> segment bases, cloud size, grid descriptor
 __global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ clouds, CloudDesc *__restrict__ descs, RunParams rp,
-													   uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ big_box,
+													   uint32_t *__restrict__ seg_cnt, const uint32_t *__restrict__ seg_box,
 													   GridDesc *__restrict__ grids)
 {
 	const Job bc = clouds[blockIdx.x]; // start = first segment, count = number of segments
+	const bool want_box = !(bc.cls & MULLS_BIG_SRC_SIDE) && grids != nullptr;
 	uint32_t running = 0;
+	uint32_t box[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u}; // ordered keys of the cloud's box: this lane's segments
 	for (uint32_t base = 0; base < bc.count; base += 64)
 	{
 		const uint32_t s = base + threadIdx.x;
+		if (want_box && s < bc.count)
+			for (int k = 0; k < 6; k++)
+			{
+				const uint32_t b = seg_box[(size_t)(bc.start + s) * 6u + k];
+				box[k] = k < 3 ? min(box[k], b) : max(box[k], b);
+			}
 		const uint32_t v = s < bc.count ? seg_cnt[bc.start + s] : 0u;
 		uint32_t incl = v;
 		for (int off = 1; off < 64; off <<= 1)
@@ -327,6 +345,13 @@ __global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ cl
 			seg_cnt[bc.start + s] = running + incl - v;
 		running += __shfl(incl, 63);
 	}
+	if (want_box)
+		for (int k = 0; k < 6; k++)
+			for (int off = 32; off > 0; off >>= 1)
+			{
+				const uint32_t o = (uint32_t)__shfl_down((int)box[k], off);
+				box[k] = k < 3 ? min(box[k], o) : max(box[k], o);
+			}
 	if (threadIdx.x == 0 && (bc.cls & MULLS_BIG_SRC_SIDE))
 	{
 		CloudDesc &d = descs[bc.pair * MULLS_NC + (bc.cls & 0xffu)];
@@ -345,8 +370,8 @@ __global__ __launch_bounds__(64) void k_crop_big_scan(const Job *__restrict__ cl
 			float lo3[3], hi3[3];
 			for (int k = 0; k < 3; k++)
 			{
-				lo3[k] = running ? ord2f(big_box[blockIdx.x * 6u + k]) : __builtin_inff();
-				hi3[k] = running ? ord2f(big_box[blockIdx.x * 6u + 3 + k]) : -__builtin_inff();
+				lo3[k] = running ? ord2f(box[k]) : __builtin_inff();
+				hi3[k] = running ? ord2f(box[3 + k]) : -__builtin_inff();
 			}
 			grids[bc.pair * MULLS_NC + bc.cls] = make_grid(lo3, hi3, running, rp, descs[bc.pair * MULLS_NC + bc.cls], bc.cls);
 		}
@@ -595,8 +620,8 @@ void launch_crop(hipStream_t st, uint32_t npairs, CloudDesc *descs, const PairSe
 					   tnrm, flag, match, wd, rp, grids, big_box);
 	if (nbig_clouds)
 	{
-		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, tmp_pos, rp, seg_cnt, big_box);
-		hipLaunchKernelGGL(k_crop_big_scan, dim3(nbig_clouds), dim3(64), 0, st, big_clouds, descs, rp, seg_cnt, big_box, grids);
+		hipLaunchKernelGGL(k_crop_big_count, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, tmp_pos, rp, seg_cnt, big_box + (size_t)nbig_clouds * 6u);
+		hipLaunchKernelGGL(k_crop_big_scan, dim3(nbig_clouds), dim3(64), 0, st, big_clouds, descs, rp, seg_cnt, big_box + (size_t)nbig_clouds * 6u, grids);
 		hipLaunchKernelGGL(k_crop_big_scatter, dim3(nbig_segs), dim3(MULLS_BLOCK), 0, st, big_segs, descs, setup, bbox, stage, rp, seg_cnt, tpos,
 						   tnrm, tmp_pos, tmp_nrm, spos, snrm, flag, match, wd);
 	}
