@@ -640,7 +640,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 }
 
 // both tiers' class clouds of a small mixed batch in one launch (k_cert_mixed): 1 = launched, 0 = not applicable (the caller launches the tiers one after the other)
-int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states,
+int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, uint32_t rounds, CloudDesc *descs, const PairState *states,
 					  const RunParams &rp, float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const unsigned long long *bm, const uint32_t *pf,
 					  const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match,
 					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells, bool first)
@@ -663,12 +663,17 @@ int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t
 	uint32_t split = 1;
 	while (split < 16 && n_big * split * 2u <= max_wgs)
 		split <<= 1;
-	// one workgroup per CU (each holds the whole LDS): only while every workgroup of both tiers is resident at once
-	while (split > 1 && n_lds + n_big * split > n_cu)
+	// one workgroup per CU (each holds the whole LDS): only while every workgroup of both tiers is resident at once — or, while the chunk-level jobs still search
+	// (`rounds` > 1: the run's first iterations), in up to that many rounds: the LDS tier's workgroups come first and stay for the length of their staged search,
+	// the global-memory tier's jobs are shared by more workgroups, which follow each other on the CUs that are left (64 scans against 20 000-point maps: iteration 0
+	// 129 -> 8x us, profiles/r06_experiments.txt item 24)
+	if (n_lds + n_big > n_cu)
+		rounds = 1u; // (only batches that take this launch in every iteration)
+	while (split > 1 && n_lds + n_big * split > n_cu * rounds)
 		split >>= 1;
 	const bool dedup = rp.lds_dedup != 0u;
 	const size_t dyn = fused_lds_bytes(cap, maxcells, dedup) > sizeof(BigLds<MULLS_BIG_BLOCK * 3>) ? fused_lds_bytes(cap, maxcells, dedup) : sizeof(BigLds<MULLS_BIG_BLOCK * 3>);
-	if (n_lds + n_big * split > n_cu || dyn > dyn_max)
+	if (n_lds + n_big * split > n_cu * rounds || n_lds > n_cu || dyn > dyn_max)
 		return 0;
 	hipLaunchKernelGGL(k_cert_mixed, dim3(n_lds + n_big * split), dim3(MULLS_LDS_BLOCK), dyn, st, n_lds, cjobs, bjobs, split, descs, states, rp, spos, snrm, grids, cell_start, bm, pf, cs,
 					   tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, cap, first ? 1u : 0u);

@@ -64,7 +64,7 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 				  float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match, float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells,
 				  uint32_t *wl, uint32_t *wl_ctr, uint32_t parity, bool first = false);
 // a small mixed batch: the class clouds of both tiers in one launch (k_cert_mixed); returns 1 when it launched, 0 when the caller has to launch the tiers separately
-int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, CloudDesc *descs, const PairState *states,
+int launch_cert_mixed(hipStream_t st, uint32_t n_lds, const Job *cjobs, uint32_t n_big, const Job *bjobs, uint32_t max_wgs, uint32_t rounds, CloudDesc *descs, const PairState *states,
 					  const RunParams &rp, float4 *spos, float4 *snrm, const GridDesc *grids, const uint32_t *cell_start, const unsigned long long *bm, const uint32_t *pf,
 					  const uint32_t *cs, const float4 *tsorted, uint8_t *flag, int32_t *nn_idx, float *nn_d2, unsigned long long *winner, const float4 *tnrm, int32_t *match,
 					  float *wd, const float4 *tpos, int32_t *nn_hint, float4 *mq, uint32_t cap, uint32_t maxcells, bool first = false);

@@ -223,14 +223,21 @@ RUN_ALIASES
 	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
 	// (resident workgroups of k_cert_big: two per CU; four rounds of them while the chunk-level jobs still search)
 	const uint32_t max_wgs = iter < std::max(3, (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS]) ? 2048u : 512u;
-	// a small mixed batch: both tiers' class clouds in one launch
+	// a small mixed batch: both tiers' class clouds in one launch (in the first two iterations, whose chunk-level jobs search, in up to three rounds of workgroups)
+#ifndef MULLS_MIXED_WIDE_ITERS
+#define MULLS_MIXED_WIDE_ITERS 2
+#endif
+#ifndef MULLS_MIXED_ROUNDS
+#define MULLS_MIXED_ROUNDS 3u
+#endif
+	const uint32_t mixed_rounds = early && iter < MULLS_MIXED_WIDE_ITERS ? MULLS_MIXED_ROUNDS : 1u;
 	const uint32_t big_n = early ? L.ejob_n : L.bjob_n;
 	const Job *big_jobs = early ? B->ejobs + L.ejob_lo : B->bjobs + L.bjob_lo;
 	// iteration 0 of the LDS tier's class-level jobs: the setup has applied the rigid step (identity_step), no point has a hint — every called class cloud
 	// goes straight to the staged search, no light pass (k_search.hip: first_goes_direct)
 	const bool first = iter == 0 && rp.lds_dedup != 0u && !rp.normal_shooting && ctx->opt[MULLS_OPT_FIRST_DIRECT] != 0.0;
 	const bool together = tier == 3 && L.cjob_n && big_n &&
-						  launch_cert_mixed(sst, L.cjob_n, B->cjobs + L.cjob_lo, big_n, big_jobs, max_wgs, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->bm,
+						  launch_cert_mixed(sst, L.cjob_n, B->cjobs + L.cjob_lo, big_n, big_jobs, max_wgs, mixed_rounds, B->descs, B->states, rp, B->spos, B->snrm, B->grids, B->cell_start, B->bm,
 											B->pf, B->bm_cs, B->tsorted, B->flag, B->nn_idx, B->nn_d2, B->winner, B->tnrm, B->match, B->wd, B->tpos, B->nn_hint, B->mq, lds_cap,
 											rp.grid_maxcells, first) != 0;
 	if (!together && L.cjob_n &&
