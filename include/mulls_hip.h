@@ -211,7 +211,7 @@ enum mulls_option
 	MULLS_OPT_RESIDENT_MIN_PAIRS = 1,	  /* [1] auto mode runs the device-resident loop (one persistent workgroup per pair) for batches of MIN .. MAX pairs; MAX < MIN (the  */
 	MULLS_OPT_RESIDENT_MAX_PAIRS = 2,	  /* [0] default): never — since round 3 the lock-step path is at least as fast at every size (profiles/r03_modes.txt: 256 pairs
 											 139 k both, 320 pairs 152 k against 100 k).  nn_mode 4 asks for the loop at any size */
-	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [384] lock-step loop: batches up to this size run 3 - 4 launches per iteration instead of 7 (one accumulation launch;
+	MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS = 3, /* [640; 384 until round 6: +1 % at 384 - 512 pairs] lock-step loop: batches up to this size run 3 - 4 launches per iteration instead of 7 (one accumulation launch;
 											 finish + step + publication as one kernel; light and heavy pass of the search as one launch while there are at most
 											 two class clouds per CU) — small batches are bound by the launch count */
 	MULLS_OPT_SUBBATCHES = 4,			  /* [0 = by batch size] host-stepped loop: sub-batches in flight (1 or 2) */

@@ -147,7 +147,7 @@ namespace mulls_drv
 void options_init(mulls_ctx *ctx)
 {
 	double *o = ctx->opt;
-	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 1, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 384;
+	o[MULLS_OPT_HOST_STEP] = 0, o[MULLS_OPT_RESIDENT_MIN_PAIRS] = 1, o[MULLS_OPT_RESIDENT_MAX_PAIRS] = 0, o[MULLS_OPT_FEW_LAUNCHES_MAX_PAIRS] = 640;
 	o[MULLS_OPT_SUBBATCHES] = 0, o[MULLS_OPT_TWO_STREAMS] = 0, o[MULLS_OPT_CERTIFICATES] = 1;
 	o[MULLS_OPT_CERT_SLACK_MIN] = 0.02, o[MULLS_OPT_CERT_SLACK_MAX] = 0.10, o[MULLS_OPT_CERT_SLACK_RATE] = 1.0;
 	o[MULLS_OPT_SPLIT_MIN_PAIRS] = 96, o[MULLS_OPT_SPLIT_MAX_PAIRS] = 1 << 30, o[MULLS_OPT_FUSED_TGT_SETUP] = 1, o[MULLS_OPT_STAGGER] = 4352, o[MULLS_OPT_STEP_LAUNCH_MAX_PAIRS] = 640, o[MULLS_OPT_LDS_DEDUP] = 1, o[MULLS_OPT_GRID_H0] = 0, o[MULLS_OPT_BM_H0] = 0, o[MULLS_OPT_LEAN_STAGING] = 0, o[MULLS_OPT_DEBUG_STOP] = 0, o[MULLS_OPT_DEBUG_TICK] = 0, o[MULLS_OPT_MIXED_TIERS] = 1, o[MULLS_OPT_BIG_EARLY_SETS] = 5, o[MULLS_OPT_KCERT] = 1, o[MULLS_OPT_KCERT_MIN] = 64, o[MULLS_OPT_ACCUM_WAVE_MIN_TRIPS] = 768;

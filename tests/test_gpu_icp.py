@@ -177,6 +177,7 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
              "large": (0, 1 << 30, 0, 1, 0), "large two kernels": (0, 1 << 30, 0, 0, 0), "large split wave": (0, 2, 1, 1, 0), "large split wave two kernels": (0, 2, 1, 0, 0)}
     split_min = ctx.get_option(abi.OPT_SPLIT_MIN_PAIRS)
     step_max = ctx.get_option(abi.OPT_STEP_LAUNCH_MAX_PAIRS)
+    few_max = ctx.get_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS)
     for P in (abi.kitti_params(dis_thre_unit=2.4), abi.default_params(), abi.default_params(used_feature_type="111111", faithful=0),
               abi.kitti_params(dis_thre_unit=2.4, max_iter_num=1)):
         got = {}
@@ -190,7 +191,7 @@ def test_lock_step_launch_forms_are_bit_identical(ctx, pairs_small):
             rows = [(x.code, x.iters, tuple(x.ncorr), tuple(x.nsrc0), np.array(x.T[:]).tobytes(), np.array(x.info[:]).tobytes(), np.float32(x.sigma).tobytes()) for x in r]
             assert got.setdefault(name, rows) == rows
         assert all(got[name] == got["few"] for name in forms)
-    ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, 384)
+    ctx.set_option(abi.OPT_FEW_LAUNCHES_MAX_PAIRS, few_max)
     ctx.set_option(abi.OPT_SPLIT_MIN_PAIRS, split_min)
     ctx.set_option(abi.OPT_ACCUM_WAVE_MIN_TRIPS, wave_min)
     ctx.set_option(abi.OPT_SUM_STEP, 1)
