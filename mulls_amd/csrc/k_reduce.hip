@@ -289,6 +289,16 @@ __device__ __forceinline__ void finish_pair(CloudDesc *pd, const PairState &ps, 
 			double sum = 0.0;
 			uint32_t j = pd[c].job_begin;
 			const uint32_t je = pd[c].job_end;
+			for (; j + 32u * STEP <= je; j += 32u * STEP) // (thirty-two in flight: a 108 k-point class cloud's 106 partials are four round trips instead of seven)
+			{
+				double v[32];
+#pragma unroll
+				for (uint32_t k = 0; k < 32u; k++)
+					v[k] = partial[(size_t)(j + k * STEP) * MULLS_NTERM + t];
+#pragma unroll
+				for (uint32_t k = 0; k < 32u; k++)
+					sum += v[k];
+			}
 			for (; j + 16u * STEP <= je; j += 16u * STEP)
 			{
 				double v[16];
