@@ -23,6 +23,7 @@ struct Run
 	RunParams rp;
 	mulls::IcpConst K;
 	uint32_t lds_cap = 0;
+	uint32_t max_big_tgt = 0; // the largest target class cloud on the global-memory tier (launch_search: how long a small batch keeps chunk-level jobs)
 	int tier = 0;
 	bool use_grid = false, dstep = false, resident = false;
 };
@@ -98,6 +99,11 @@ int run_setup(Run &R)
 		return rc;
 	const bool use_grid = tier != 0;
 	R.lds_cap = lds_cap, R.tier = tier, R.use_grid = use_grid, R.dstep = dstep, R.resident = resident;
+	R.max_big_tgt = 0;
+	if (tier == 3)
+		for (const CloudDesc &d : B->descs_h)
+			if (d.tier == MULLS_TIER_BM)
+				R.max_big_tgt = std::max(R.max_big_tgt, d.tgt_n0);
 
 	// LDS tier: the target clouds are cropped and their grids built in one pass that writes no cropped copy (k_tgt_grid) — unless something needs the
 	// copy (the keep-less thinning, the normal-shooting search) or a cloud of a class the run does not read is larger than the kernel's lanes cover
@@ -220,7 +226,9 @@ RUN_ALIASES
 	// mixed batch, first iterations: chunk-level jobs for every cloud of the global-memory tier (MULLS_OPT_BIG_EARLY_SETS)
 	// ... and every iteration of a small one: a handful of class-level workgroups cannot search a dense map's leftovers fast enough (a 1 M-point map leaves most
 	// points uncertified for ten iterations: its second-nearest targets are millimetres behind the nearest), while k_filter costs such a batch 6 us
-	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || L.bjob_n - L.fjob_n < 64u);
+	// (round 6: only against maps of more than 100 000 points per class — a 20 000-point local map's points certify within five iterations like everybody else's,
+	// and from then on the class-level jobs save the k_filter launch: 1 / 4 / 16 scans against such maps 0.97 / 1.14 / 1.21 -> 0.91 / 1.04 / 1.09 ms)
+	const bool early = L.ejob_n && (iter < (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS] || (L.bjob_n - L.fjob_n < 64u && R.max_big_tgt > 100000u));
 	// (resident workgroups of k_cert_big: two per CU; four rounds of them while the chunk-level jobs still search)
 	const uint32_t max_wgs = iter < std::max(3, (int)ctx->opt[MULLS_OPT_BIG_EARLY_SETS]) ? 2048u : 512u;
 	// a small mixed batch: both tiers' class clouds in one launch (in the first two iterations, whose chunk-level jobs search, in up to three rounds of workgroups)
