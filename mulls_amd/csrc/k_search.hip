@@ -272,7 +272,10 @@ __device__ __forceinline__ bool cert_job(CertLds<SMALL> &CL, const RunParams &rp
 // BLK * TRIPS source points (larger ones: the general walk).  Longer one-pass walks for the 1 537 - 3 072-point clouds of real scans — 512 lanes x 6 trips,
 // 1024 lanes x 3 trips, as their own launch or for every job — were built, bit-identical, and slower than the general walk on configs[0]
 // (profiles/r06_experiments.txt item 5): a real scan's time is in the leftover searches of its SHORT class clouds.
-template <int BLK, int TRIPS = (BLK == 512 ? 3 : 2)>
+// SMALL: the leftover list a workgroup searches itself (longer ones go to the staged search).  512 entries — or 768 where four workgroups per CU still fit with them
+// (768 entries + the parked words + the 16-bit duplicate table of the batch's largest target cloud <= 40 KiB, i.e. clouds of up to ~6 000 points: the reference's
+// real scans, whose every iteration carries a few hundred leftover searches per class cloud: configs[0] at 512 pairs +2.4 %, profiles/r06_experiments.txt items 29, 32)
+template <int BLK, int TRIPS = (BLK == 512 ? 3 : 2), int SMALL = MULLS_CERT_SMALL_LOCKSTEP>
 __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__restrict__ cjobs, CloudDesc *__restrict__ descs,
 															const PairState *__restrict__ states, RunParams rp, float4 *__restrict__ spos,
 															float4 *__restrict__ snrm, const GridDesc *__restrict__ grids,
@@ -292,10 +295,10 @@ __global__ __launch_bounds__(BLK, BLK == 512 ? 8 : 4) void k_cert(const Job *__r
 		return;
 	CloudDesc &d = descs[job.pair * MULLS_NC + job.cls];
 	const GridDesc g = grids[job.pair * MULLS_NC + job.cls];
-	__shared__ CertLds<MULLS_CERT_SMALL_LOCKSTEP> s_cert;
+	__shared__ CertLds<SMALL> s_cert;
 	constexpr bool PARK = BLK == 512; // (the two-trip 1024-lane form serves small batches: two workgroups per CU, 128 registers)
 	__shared__ uint32_t s_park[PARK ? 2 * TRIPS * BLK : 1];
-	if (!cert_job<BLK, MULLS_CERT_SMALL_LOCKSTEP, PARK, TRIPS>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, s_park))
+	if (!cert_job<BLK, SMALL, PARK, TRIPS>(s_cert, rp, ps, job, d, g, W, spos, snrm, cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, s_park))
 		if (threadIdx.x == 0)
 			wl[atomicAdd(&wl_ctr[2u * parity], 1u)] = blockIdx.x; // k_nn_lds stages the target cloud and takes the class cloud from here
 }
@@ -602,6 +605,9 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 			return false;
 		hipFuncAttributes fa;
 		d.dyn_max[0] = 1;
+		d.dyn_max[1] = 0; // static LDS of the light pass with the 768-entry leftover list (0: unknown — not used)
+		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert<MULLS_CERT_BLOCK, 3, 768>)) == hipSuccess)
+			d.dyn_max[1] = fa.sharedSizeBytes;
 		if (hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_cert_nn)) == hipSuccess && fa.sharedSizeBytes < 160u * 1024u)
 		{
 			const size_t room = 160u * 1024u - fa.sharedSizeBytes;
@@ -630,6 +636,10 @@ int launch_nn_lds(hipStream_t st, uint32_t njobs, const Job *jobs, CloudDesc *de
 	else if (njobs <= 2u * n_cu)
 		hipLaunchKernelGGL(k_cert<1024>, dim3(njobs), dim3(1024), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids, cell_start, tsorted,
 						   flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
+	else if (dedup && MULLS_CERT_BLOCK == 512 && D.dyn_max[1] && (((size_t)cap * 2u + 3u) & ~(size_t)3) + D.dyn_max[1] <= 40u * 1024u)
+		// (four workgroups per CU with the longer leftover list: dyn_max[1] = the 768-entry kernel's static LDS)
+		hipLaunchKernelGGL((k_cert<MULLS_CERT_BLOCK, 3, 768>), dim3(njobs), dim3(MULLS_CERT_BLOCK), ((size_t)cap * 2u + 3u) & ~(size_t)3, st, jobs, descs, states, rp, spos, snrm, grids,
+						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);
 	else
 		hipLaunchKernelGGL(k_cert<MULLS_CERT_BLOCK>, dim3(njobs), dim3(MULLS_CERT_BLOCK), dedup ? ((size_t)cap * 2u + 3u) & ~(size_t)3 : 0u, st, jobs, descs, states, rp, spos, snrm, grids,
 						   cell_start, tsorted, flag, nn_idx, nn_d2, winner, tnrm, match, wd, tpos, nn_hint, mq, wl, wl_ctr, parity & 1u);

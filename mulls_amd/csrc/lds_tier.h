@@ -912,7 +912,7 @@ __device__ __forceinline__ uint32_t kcert_list(CertLds<SMALL> &CL, const RunPara
 												int32_t *__restrict__ nn_idx, float *__restrict__ nn_d2, int2 *__restrict__ hint2, uint32_t *W,
 												unsigned long long *__restrict__ winner, const float4 *__restrict__ tpos, uint32_t &matched_cnt)
 {
-	static_assert(SMALL <= BLK, "one lane per listed point");
+	static_assert(!CertLds<SMALL>::LOOK || SMALL <= BLK, "one lane per listed point (the look is compiled out of the lists that are longer)");
 	const uint32_t UL = U; // (<= SMALL: the caller's condition)
 	float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	uint32_t es = 0u;
