@@ -223,8 +223,13 @@ extern "C"
 			delete ctx;
 			return MULLS_E_NO_DEVICE;
 		}
+		// the profile's timing events: no system-scope fence when they complete (hipEventDisableSystemFence — "for events that are only being used to measure timing").
+		// With the default flags every recorded event wrote the L2 back and invalidated it: 10 us in front of an iteration's search and 19 us behind it, 0.58 ms of a
+		// 4096-pair step whose search launches bench.py brackets (profiles/r06_experiments.txt item 33).  Nothing the host reads is ordered by these events: results and
+		// the iteration word are read behind hipStreamSynchronize or the kernels' own __threadfence_system.
 		for (auto &e : ctx->ev)
-			(void)hipEventCreate(&e);
+			if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess)
+				(void)hipEventCreate(&e);
 		*out = ctx;
 		return MULLS_OK;
 	}
