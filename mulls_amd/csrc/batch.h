@@ -78,7 +78,8 @@ struct mulls_batch
 	// device-resident loop (k_icp): class-level jobs in pair order, each pair's range in them, the pairs most expensive first
 	std::vector<Job> rjobs_h;
 	std::vector<uint32_t> pair_rjob_h, order_h;
-	std::vector<IcpOut> icp_outs_h;
+	IcpOut *icp_outs_pin = nullptr; // the result records of a device-stepped / device-resident run, downloaded into pinned memory (results_from_device)
+	size_t cap_icp_pin = 0;
 	std::vector<mulls_iter_trace> trace_h;
 	std::string jobs_key;
 	uint32_t njobs = 0;

@@ -359,6 +359,8 @@ extern "C"
 			(void)hipHostFree((void *)B->epoch_h);
 		if (B->upload_h)
 			(void)hipHostFree(B->upload_h);
+		if (B->icp_outs_pin)
+			(void)hipHostFree(B->icp_outs_pin);
 		delete B;
 	}
 

@@ -289,8 +289,10 @@ int results_from_device(Run &R, uint32_t trace_cap, bool from_icp)
 RUN_ALIASES
 	const auto wall0 = R.wall0;
 
-		B->icp_outs_h.resize(n);
-		HIPCHK(ctx, hipMemcpyAsync(B->icp_outs_h.data(), B->icp_outs, sizeof(IcpOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+		// (pinned: a copy into pageable memory goes through the runtime's staging buffers and holds the calling thread)
+		if (grow_pinned(ctx, &B->icp_outs_pin, &B->cap_icp_pin, (size_t)n, hipHostMallocDefault) != MULLS_OK)
+			return MULLS_E_NOMEM;
+		HIPCHK(ctx, hipMemcpyAsync(B->icp_outs_pin, B->icp_outs, sizeof(IcpOut) * (size_t)n, hipMemcpyDeviceToHost, st));
 		if (trace_cap)
 		{
 			B->trace_h.resize((size_t)n * trace_cap);
@@ -302,7 +304,7 @@ RUN_ALIASES
 		int max_it = 0;
 		for (int p = 0; p < n; p++)
 		{
-			const IcpOut &o = B->icp_outs_h[p];
+			const IcpOut &o = B->icp_outs_pin[p];
 			mulls_result &R = results[p];
 			R.code = o.code;
 			R.iters = o.iters;
@@ -574,16 +576,23 @@ RUN_ALIASES
 			break;
 	}
 	ctx->prof.ms_host_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() * 1e3 - ctx->prof.ms_host_wait;
-	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	// the result records' download is stream-ordered behind the last launch set: ONE wait for the run's end instead of a stream synchronisation, then the copy, then
+	// another one (a blocked host thread takes tens of microseconds to come back: 5 % of a single registration)
 	if (nsub == 2)
-		HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+	{
+		HIPCHK(ctx, hipEventRecord(ctx->ev_setup, ctx->stream2));
+		HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_setup, 0));
+	}
+	rc = results_from_device(R, 0, false); // (synchronises ctx->stream, and with it — through the event — the second sub-batch's stream)
+	if (rc != MULLS_OK)
+		return rc;
 	drain.armed = false;
 	for (int k = 0; k < nsub; k++)
 	{
 		subs[k].ev2[0].collect();
 		subs[k].ev2[1].collect();
 	}
-	return results_from_device(R, 0, false);
+	return MULLS_OK;
 }
 
 // ---- lock-step loop stepped by the host: per-iteration traces -----------------------------------------------------------------------------------
